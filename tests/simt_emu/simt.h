@@ -1,0 +1,129 @@
+// tests/simt_emu/simt.h — TEST INFRASTRUCTURE ONLY.
+//
+// Host-side lock-step emulator of ONE gfx950 wavefront (64 lanes + an EXEC mask) exposing the same
+// vocabulary as winnowmap_amd/csrc/simt.h. The test build puts this directory first on the include path
+// so the very same kernel headers (ksw_kernel.h, chain_kernel.h, sketch_kernel.h) compile for the CPU and
+// can be checked bit-for-bit against the oracle WITHOUT a GPU (tests/test_kernels_emu.py). It exists to
+// debug kernel logic cheaply; it is never compiled into, linked with or reachable from the product library.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+
+#define WM_SIMT_EMU 1
+#define WM_DEV inline
+#define WM_EMU_ASSERT(x) do { if (!(x)) { fprintf(stderr, "EMU ASSERT %s:%d: %s\n", __FILE__, __LINE__, #x); abort(); } } while (0)
+
+namespace simt {
+constexpr int WAVE = 64;
+inline uint64_t &exec_mask() { static thread_local uint64_t m = ~0ull; return m; }
+inline bool on(int i) { return exec_mask() >> i & 1; }
+
+template <class T> struct V {
+	T v[WAVE];
+	V() { memset(v, 0xCD, sizeof(v)); }
+	V(T s) { for (int i = 0; i < WAVE; ++i) v[i] = s; }
+	V(const V &o) = default;
+	template <class U> explicit V(const V<U> &o) { for (int i = 0; i < WAVE; ++i) v[i] = (T)o.v[i]; }
+	V &operator=(const V &o) { for (int i = 0; i < WAVE; ++i) if (on(i)) v[i] = o.v[i]; return *this; }
+	V &operator=(T s) { for (int i = 0; i < WAVE; ++i) if (on(i)) v[i] = s; return *this; }
+#define WM_CASSIGN(op) \
+	V &operator op(const V &o) { for (int i = 0; i < WAVE; ++i) if (on(i)) v[i] op o.v[i]; return *this; } \
+	V &operator op(T s) { for (int i = 0; i < WAVE; ++i) if (on(i)) v[i] op s; return *this; }
+	WM_CASSIGN(+=) WM_CASSIGN(-=) WM_CASSIGN(*=) WM_CASSIGN(&=) WM_CASSIGN(|=) WM_CASSIGN(^=) WM_CASSIGN(<<=) WM_CASSIGN(>>=)
+#undef WM_CASSIGN
+};
+using vbool = V<bool>;
+
+#define WM_BINOP(op, R) \
+	template <class T> V<R> operator op(const V<T> &a, const V<T> &b) { V<R> r; for (int i = 0; i < WAVE; ++i) r.v[i] = a.v[i] op b.v[i]; return r; } \
+	template <class T> V<R> operator op(const V<T> &a, T b) { V<R> r; for (int i = 0; i < WAVE; ++i) r.v[i] = a.v[i] op b; return r; } \
+	template <class T> V<R> operator op(T a, const V<T> &b) { V<R> r; for (int i = 0; i < WAVE; ++i) r.v[i] = a op b.v[i]; return r; }
+WM_BINOP(+, T) WM_BINOP(-, T) WM_BINOP(*, T) WM_BINOP(/, T) WM_BINOP(%, T) WM_BINOP(&, T) WM_BINOP(|, T) WM_BINOP(^, T)
+WM_BINOP(==, bool) WM_BINOP(!=, bool) WM_BINOP(<, bool) WM_BINOP(>, bool) WM_BINOP(<=, bool) WM_BINOP(>=, bool)
+#undef WM_BINOP
+// shifts: the count may be a lane vector or a plain int of any integral type
+template <class T> V<T> operator<<(const V<T> &a, int b) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = a.v[i] << b; return r; }
+template <class T> V<T> operator>>(const V<T> &a, int b) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = a.v[i] >> b; return r; }
+template <class T, class U> V<T> operator<<(const V<T> &a, const V<U> &b) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = a.v[i] << b.v[i]; return r; }
+template <class T, class U> V<T> operator>>(const V<T> &a, const V<U> &b) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = a.v[i] >> b.v[i]; return r; }
+template <class T> V<T> operator-(const V<T> &a) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = -a.v[i]; return r; }
+template <class T> V<T> operator~(const V<T> &a) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = ~a.v[i]; return r; }
+inline vbool operator!(const vbool &a) { vbool r; for (int i = 0; i < WAVE; ++i) r.v[i] = !a.v[i]; return r; }
+inline vbool operator&&(const vbool &a, const vbool &b) { vbool r; for (int i = 0; i < WAVE; ++i) r.v[i] = a.v[i] && b.v[i]; return r; }
+inline vbool operator||(const vbool &a, const vbool &b) { vbool r; for (int i = 0; i < WAVE; ++i) r.v[i] = a.v[i] || b.v[i]; return r; }
+inline vbool operator&&(const vbool &a, bool b) { return a && vbool(b); }
+inline vbool operator&&(bool a, const vbool &b) { return vbool(a) && b; }
+inline vbool operator||(const vbool &a, bool b) { return a || vbool(b); }
+inline vbool operator||(bool a, const vbool &b) { return vbool(a) || b; }
+
+template <class T, class U> V<T> cast(const V<U> &a) { return V<T>(a); }
+template <class T, class U> T cast(U a) { return (T)a; }
+
+// ---- divergent control flow -------------------------------------------------------------------------
+struct MaskScope {
+	uint64_t saved, cond;
+	explicit MaskScope(const vbool &c) : saved(exec_mask()), cond(0) { for (int i = 0; i < WAVE; ++i) if (c.v[i]) cond |= 1ull << i; exec_mask() = saved & cond; }
+	explicit MaskScope(bool c) : saved(exec_mask()), cond(c ? ~0ull : 0ull) { exec_mask() = saved & cond; }
+	void flip() { exec_mask() = saved & ~cond; }
+	bool some() const { return exec_mask() != 0; }
+	~MaskScope() { exec_mask() = saved; }
+};
+#define WM_IF(c) { simt::MaskScope _wm_ms(c); if (_wm_ms.some()) {
+#define WM_ELSE } _wm_ms.flip(); if (_wm_ms.some()) {
+#define WM_END } }
+
+inline V<int> lane() { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = i; return r; }
+
+template <class T> V<T> sel(const vbool &c, const V<T> &a, const V<T> &b) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
+template <class T> V<T> sel(const vbool &c, const V<T> &a, T b) { return sel(c, a, V<T>(b)); }
+template <class T> V<T> sel(const vbool &c, T a, const V<T> &b) { return sel(c, V<T>(a), b); }
+template <class T> V<T> sel(const vbool &c, T a, T b) { return sel(c, V<T>(a), V<T>(b)); }
+template <class T> V<T> sel(bool c, const V<T> &a, const V<T> &b) { return c ? a : b; }
+template <class T> V<T> sel(bool c, const V<T> &a, T b) { return c ? a : V<T>(b); }
+template <class T> V<T> sel(bool c, T a, const V<T> &b) { return c ? V<T>(a) : b; }
+inline int sel(bool c, int a, int b) { return c ? a : b; }
+
+inline V<int> vmax(const V<int> &a, const V<int> &b) { return sel(a > b, a, b); }
+inline V<int> vmax(const V<int> &a, int b) { return vmax(a, V<int>(b)); }
+inline V<int> vmin(const V<int> &a, const V<int> &b) { return sel(a < b, a, b); }
+inline V<int> vmin(const V<int> &a, int b) { return vmin(a, V<int>(b)); }
+inline int vmax(int a, int b) { return a > b ? a : b; }
+inline int vmin(int a, int b) { return a < b ? a : b; }
+inline V<int> vmax3(const V<int> &a, const V<int> &b, const V<int> &c) { return vmax(vmax(a, b), c); }
+inline V<int> wadd(const V<int> &a, const V<int> &b) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = (int)((unsigned)a.v[i] + (unsigned)b.v[i]); return r; }
+inline V<int> wadd(const V<int> &a, int b) { return wadd(a, V<int>(b)); }
+inline V<int> wsub(const V<int> &a, const V<int> &b) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = (int)((unsigned)a.v[i] - (unsigned)b.v[i]); return r; }
+inline V<int> wsub(const V<int> &a, int b) { return wsub(a, V<int>(b)); }
+inline V<int> wsub(int a, const V<int> &b) { return wsub(V<int>(a), b); }
+inline int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+inline int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+inline V<int> add3(const V<int> &a, const V<int> &b, int c) { return wadd(wadd(a, b), c); }
+inline V<int> add3(const V<int> &a, const V<int> &b, const V<int> &c) { return wadd(wadd(a, b), c); }
+
+// ---- cross-lane -------------------------------------------------------------------------------------
+// NB (hardware semantics kept): cross-lane reads see the registers of ALL lanes, active or not.
+template <class T> V<T> shr1(const V<T> &x, T fill) { V<T> r; r.v[0] = fill; for (int i = 1; i < WAVE; ++i) r.v[i] = x.v[i - 1]; return r; }
+template <class T> V<T> shr1(const V<T> &x, const V<T> &fill) { V<T> r; r.v[0] = fill.v[0]; for (int i = 1; i < WAVE; ++i) r.v[i] = x.v[i - 1]; return r; }
+template <class T> V<T> shift_down(const V<T> &x, int k, T fill) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = i + k < WAVE ? x.v[i + k] : fill; return r; }
+template <class T> V<T> shift_down(const V<T> &x, int k, const V<T> &fill) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = i + k < WAVE ? x.v[i + k] : fill.v[i]; return r; }
+template <class T> T readlane(const V<T> &x, int l) { WM_EMU_ASSERT(l >= 0 && l < WAVE); return x.v[l]; }
+inline int readlane(int x, int) { return x; }
+template <class T> T uniform(const V<T> &x) { for (int i = 0; i < WAVE; ++i) if (on(i)) return x.v[i]; return x.v[0]; }
+inline int uniform(int x) { return x; }
+inline uint64_t ballot(const vbool &c) { uint64_t m = 0; for (int i = 0; i < WAVE; ++i) if (on(i) && c.v[i]) m |= 1ull << i; return m; }
+inline uint64_t ballot(bool c) { return c ? exec_mask() : 0; }
+inline bool any(const vbool &c) { return ballot(c) != 0; }
+inline bool any(bool c) { return c && exec_mask(); }
+inline V<long long> wave_max_i64(const V<long long> &k) { WM_EMU_ASSERT(exec_mask() == ~0ull); long long m = k.v[0]; for (int i = 1; i < WAVE; ++i) if (k.v[i] > m) m = k.v[i]; return V<long long>(m); }
+inline V<int> wave_sum_i32(const V<int> &k) { WM_EMU_ASSERT(exec_mask() == ~0ull); int s = 0; for (int i = 0; i < WAVE; ++i) s += k.v[i]; return V<int>(s); }
+
+// ---- memory -----------------------------------------------------------------------------------------
+template <class T, class I> V<T> gld(const T *p, const V<I> &idx) { V<T> r(T(0)); for (int i = 0; i < WAVE; ++i) if (on(i)) r.v[i] = p[idx.v[i]]; return r; }
+template <class T> T gld(const T *p, long long idx) { return p[idx]; }
+template <class T, class I> void gst(T *p, const V<I> &idx, const V<T> &v) { for (int i = 0; i < WAVE; ++i) if (on(i)) p[idx.v[i]] = v.v[i]; }
+template <class T, class I> void gst(T *p, const V<I> &idx, T v) { for (int i = 0; i < WAVE; ++i) if (on(i)) p[idx.v[i]] = v; }
+template <class T> void gst(T *p, long long idx, T v) { if (exec_mask()) p[idx] = v; }
+
+} // namespace simt

@@ -1,0 +1,52 @@
+"""Build the in-tree native artefacts: libwmgpu.so (hipcc, gfx950) and the test-side checkers."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libwmgpu.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_gpu(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "wm_gpu.h")]
+    if not force and not _newer(LIB, srcs):
+        return LIB
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
+           "-Wno-unused-value", "-o", LIB, os.path.join(CSRC, "wm_gpu.hip")]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_oracle():
+    """oracle/libwm_oracle.so always; oracle/_ref only where /root/reference exists (the build container)."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], stdout=subprocess.DEVNULL)
+    if os.path.exists("/root/reference/src/map.c"):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref", "-j8"], stdout=subprocess.DEVNULL)
+
+
+def build_emu():
+    emu = os.path.join(ROOT, "tests", "simt_emu")
+    out = os.path.join(emu, "libwm_emu.so")
+    srcs = [os.path.join(emu, f) for f in ("emu_driver.cpp", "simt.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    if _newer(out, srcs):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                               "-I" + emu, "-I" + CSRC, "-o", out, os.path.join(emu, "emu_driver.cpp")])
+    return out
+
+
+if __name__ == "__main__":
+    build_gpu(force="--force" in sys.argv, verbose=True)
+    build_oracle()
+    build_emu()

@@ -1,0 +1,362 @@
+// ksw_kernel.h — wave64 register-resident anti-diagonal DP for ksw_extd2_sse (src/ksw2_extd2_sse.c:26-393).
+//
+// One wavefront owns one alignment. The reference walks anti-diagonals r = i + j and keeps per-target-lane
+// int8 arrays u,v,x,y,x2,y2 (and the score row s) that persist from row to row; only the 16-aligned hull
+// [st,en] of the band is recomputed each row and everything else keeps its last value ("stale lanes", which
+// DO feed back when the band is clipped by w — SURVEY.md §7). This kernel reproduces that machine exactly:
+//
+//   * a sliding window of 64*B consecutive lanes starting at `base` (= the hull start st, a multiple of 16)
+//     lives in VGPRs: thread j holds lanes base+B*j .. base+B*j+B-1. No LDS, no per-row barrier.
+//   * neighbour values (lane t-1 of the previous row) come from the register of the same thread or, for the
+//     first lane of a thread, from one DPP/bpermute shift (simt::shr1).
+//   * when the hull start advances by 16 the whole window is re-based with one cross-lane shift per register.
+//   * int8 WRAPPING arithmetic is exact and free: every value is kept in the TOP BYTE of a 32-bit register
+//     (v << 24), so 32-bit add/sub wrap exactly like _mm_add_epi8/_mm_sub_epi8 and signed compares agree. The
+//     low bits carry a 3-bit tie-break tag so that the five-way "which state wins" selection of the reference
+//     (left- vs right-aligned gaps, src/ksw2_extd2_sse.c:227-234 vs :274-281) is two v_max3_i32.
+//   * traceback: 1 byte per cell, row r at tb + r*n_col, column t - st (the reference's layout, ksw2.h:128);
+//     B=4 → one coalesced 256-byte store per row per wave. Byte = code<<4 | ext_a<<3 | ext_b<<2 | ext_a2<<1 |
+//     ext_b2 with code = winning tag (decoded by ksw_backtrack_thread below).
+//
+// Template: B lanes per thread (4/8/16 → hull up to 64*B-16 lanes), CLIP = the band can be limited by w (then
+// stale score lanes and out-of-band lanes are emulated exactly; otherwise they provably never feed a band cell
+// and are computed loosely), HASN = either sequence contains code 4.
+//
+// Roofline note: ~34 VALU lane-ops per cell, 1 B of HBM written per cell.
+#pragma once
+// NB: the translation unit includes its simt.h first (device: csrc/simt.h; tests: tests/simt_emu/simt.h)
+#ifndef WM_DEV
+#error "include simt.h before ksw_kernel.h"
+#endif
+#include "wm_internal.h"
+
+namespace wmk {
+using namespace simt;
+
+#define KSW_NEG_INF (-0x40000000)
+#define KSW_F_RIGHT 0x02
+#define KSW_F_APPROX_MAX 0x08
+#define KSW_F_EXTZ_ONLY 0x40
+#define KSW_F_REV_CIGAR 0x80
+
+// value (int8 semantics) -> top-byte representation
+WM_DEV int tb8(int v) { return (int)((unsigned)v << 24); }
+
+// read lane t (uniform) of a per-thread register array: thread (t-base)/B, register (t-base)%B
+template <int B> WM_DEV int get_lane(const V<int> (&a)[B], int base, int t)
+{
+	const int o = t - base, jr = o / B, ir = o % B;
+	WM_EMU_ASSERT(o >= 0 && o < 64 * B);
+	int r = 0;
+#pragma unroll
+	for (int i = 0; i < B; ++i)
+		if (ir == i) r = readlane(a[i], jr);
+	return r;
+}
+
+template <int B, bool CLIP, bool HASN>
+WM_DEV void ksw_dp_wave(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const uint8_t *__restrict__ seqs,
+                        uint8_t *__restrict__ tb_arena, wm_ksw_dres_t *__restrict__ res)
+{
+	constexpr int NW = B / 4;       // packed-char words per thread
+	constexpr int D = 16 / B;       // threads per 16-lane block
+	static_assert(B == 4 || B == 8 || B == 16, "B");
+	const int qlen = jb.qlen, tlen = jb.tlen, flag = jb.flag, zdrop = jb.zdrop;
+	const int w = jb.w < 0 ? (tlen > qlen ? tlen : qlen) : jb.w;
+	const bool approx = (flag & KSW_F_APPROX_MAX) != 0, right = (flag & KSW_F_RIGHT) != 0;
+	const uint8_t *query = seqs + jb.q_off, *target = seqs + jb.t_off;
+	uint32_t *tbw = (uint32_t*)(tb_arena + jb.tb_off);
+	const int n_colw = jb.n_col >> 2;
+
+	// gap costs, already ordered so that q+e <= q2+e2 by the host (src/ksw2_extd2_sse.c:70)
+	const int q = sc.q, e = sc.e, q2 = sc.q2, e2 = sc.e2, qe = q + e, qe2 = q2 + e2;
+	const int Q = tb8(q), Q2 = tb8(q2), QE = tb8(qe), QE2 = tb8(qe2);
+	// tie-break tags: left-aligned gaps prefer the EARLIER candidate (s,a,b,a2,b2), right-aligned the later
+	const int tS = right ? 0 : 4, tA = right ? 1 : 3, tB = 2, tA2 = right ? 3 : 1, tB2 = right ? 4 : 0;
+	// "gap continues" test: left a>0, right a>=0 (src/ksw2_extd2_sse.c:255 vs :302)
+	const int hA = right ? tA - 1 : tA, hB = right ? tB - 1 : tB, hA2 = right ? tA2 - 1 : tA2, hB2 = right ? tB2 - 1 : tB2;
+	const int MCH = tb8(sc.match), MCHt = MCH | tS, MISt = tb8(sc.mismatch) | tS;
+	const int NNt = tb8(sc.sc_ambi == 0 ? -e2 : sc.sc_ambi) | tS;
+	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;                    // :94-97
+	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+
+	const V<int> ln = lane();
+	int base = 0;
+	V<int> U[B], Vv[B], X[B], Y[B], X2[B], Y2[B], S[B], H[B];
+	V<int> TP[NW], QP[NW];
+#pragma unroll
+	for (int i = 0; i < B; ++i) {
+		U[i] = tb8(-qe); Vv[i] = tb8(-qe); X[i] = tA; Y[i] = tB; X2[i] = tA2; Y2[i] = tB2;   // :103-108
+		S[i] = tS; H[i] = KSW_NEG_INF;
+	}
+#pragma unroll
+	for (int wd = 0; wd < NW; ++wd) {
+		V<int> pk = 0;
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			V<int> t = ln * B + (wd * 4 + b);
+			V<int> c = 0;
+			WM_IF(t < tlen) c = cast<int>(gld(target, t)); WM_END
+			pk = pk | (c << (8 * b));
+		}
+		TP[wd] = pk; QP[wd] = 0;
+	}
+
+	// ez (src/ksw2.h:153-158)
+	int ez_max = 0, ez_zdropped = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1;
+	int ez_mte = KSW_NEG_INF, ez_mte_q = -1, ez_score = KSW_NEG_INF;
+	int H0 = 0, last_H0_t = 0, Hbelow = KSW_NEG_INF;
+	const int n_rows = qlen + tlen - 1;
+
+	for (int r = 0; r < n_rows; ++r) {
+		int st0 = 0, en0 = tlen - 1;
+		if (st0 < r - qlen + 1) st0 = r - qlen + 1;
+		if (en0 > r) en0 = r;
+		if (st0 < (r - w + 1) >> 1) st0 = (r - w + 1) >> 1;
+		if (en0 > (r + w) >> 1) en0 = (r + w) >> 1;
+		if (st0 > en0) { ez_zdropped = 1; break; }                                // :134-137
+		const int st = st0 / 16 * 16, en = (en0 + 16) / 16 * 16 - 1;
+		const int sched = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;   // :150,154
+
+		// ---- neighbour inputs from the previous row (lane t-1), before any state changes -------------
+		V<int> XL = shr1(X[B - 1], tA);
+		V<int> VL = shr1(Vv[B - 1], st == 0 ? tb8(sched) : tb8(-qe));
+		V<int> X2L = shr1(X2[B - 1], tA2);
+		V<int> HL = shr1(H[B - 1], Hbelow);
+		V<int> QL = shr1(cast<int>(cast<unsigned>(QP[NW - 1]) >> 24), 0);
+
+		// ---- re-base the register window when the hull start moves up by one 16-lane block -----------
+		if (st > base) {
+			WM_EMU_ASSERT(st == base + 16);
+			Hbelow = readlane(H[B - 1], D - 1);
+			const V<int> tnew = ln * B + st;           // first lane of each thread after the shift
+#pragma unroll
+			for (int i = 0; i < B; ++i) {
+				U[i] = shift_down(U[i], D, tb8(-qe)); Vv[i] = shift_down(Vv[i], D, tb8(-qe));
+				X[i] = shift_down(X[i], D, tA); Y[i] = shift_down(Y[i], D, tB);
+				X2[i] = shift_down(X2[i], D, tA2); Y2[i] = shift_down(Y2[i], D, tB2);
+				if (CLIP) S[i] = shift_down(S[i], D, tS);
+				if (!approx) H[i] = shift_down(H[i], D, KSW_NEG_INF);
+			}
+			XL = shift_down(XL, D, tA); VL = shift_down(VL, D, tb8(-qe)); X2L = shift_down(X2L, D, tA2);
+			HL = shift_down(HL, D, KSW_NEG_INF); QL = shift_down(QL, D, 0);
+#pragma unroll
+			for (int wd = 0; wd < NW; ++wd) {
+				// new top lanes: target codes from memory, query codes of row r-1 (index r-1-t, zero outside)
+				V<int> tp = 0, qp = 0;
+				WM_IF(ln >= 64 - D)
+#pragma unroll
+					for (int b = 0; b < 4; ++b) {
+						V<int> t = tnew + (wd * 4 + b);
+						V<int> c = 0, d = 0;
+						WM_IF(t < tlen) c = cast<int>(gld(target, t)); WM_END
+						V<int> qi = (r - 1) - t;
+						WM_IF(qi >= 0 && qi < qlen) d = cast<int>(gld(query, qi)); WM_END
+						tp = tp | (c << (8 * b)); qp = qp | (d << (8 * b));
+					}
+				WM_END
+				TP[wd] = shift_down(TP[wd], D, tp);
+				QP[wd] = shift_down(QP[wd], D, qp);
+			}
+			// the top thread's left-neighbour char after the shift belongs to lane tnew-1 at row r-1
+			{
+				V<int> qi = (r - 1) - (tnew - 1);
+				V<int> d = 0;
+				WM_IF(ln >= 64 - D && qi >= 0 && qi < qlen) d = cast<int>(gld(query, qi)); WM_END
+				QL = sel(ln >= 64 - D, d, QL);
+			}
+			base = st;
+		}
+		const V<int> t0 = ln * B + base;
+
+		// ---- advance the query codes to row r: lane t takes the code of lane t-1 (systolic) ----------
+		{
+			const int qi0 = r - base;
+			const int newc = qi0 >= 0 && qi0 < qlen ? (int)gld(query, qi0) : 0;
+			V<int> carry = sel(ln == 0, newc, QL);
+#pragma unroll
+			for (int wd = 0; wd < NW; ++wd) {
+				V<int> nxt = cast<int>(cast<unsigned>(QP[wd]) >> 24);
+				QP[wd] = (QP[wd] << 8) | carry;
+				carry = nxt;
+			}
+		}
+
+		// ---- first-column / first-row boundary of lane r (src/ksw2_extd2_sse.c:152-155) --------------
+		if (en >= r) {
+			const int o = r - base, jr = o / B, ir = o % B;
+			WM_EMU_ASSERT(o >= 0 && o < 64 * B);
+			WM_IF(ln == jr)
+#pragma unroll
+				for (int i = 0; i < B; ++i)
+					if (ir == i) { Y[i] = tB; Y2[i] = tB2; U[i] = tb8(sched); }
+			WM_END
+		}
+
+		// ---- match/mismatch scores; with CLIP the score row is persistent and only the 16-byte chunks
+		//      starting at st0 are rewritten (:158-173) ------------------------------------------------
+		V<int> Sc[B];
+		{
+			const int cend = st0 + (en0 - st0) / 16 * 16 + 15;
+#pragma unroll
+			for (int i = 0; i < B; ++i) {
+				const int wd = i >> 2, sh = 8 * (i & 3);
+				V<int> tc = (TP[wd] >> sh) & 0xff, qc = (QP[wd] >> sh) & 0xff;
+				V<int> s = sel(tc == qc, MCHt, MISt);
+				if (HASN) s = sel((tc == 4) || (qc == 4), NNt, s);
+				if (CLIP) {
+					V<int> t = t0 + i;
+					S[i] = sel(t >= st0 && t <= cend, s, S[i]);
+					Sc[i] = S[i];
+				} else Sc[i] = s;
+			}
+		}
+
+		// ---- the DP cells of this thread (only threads inside the hull) ------------------------------
+		WM_IF(t0 <= en)
+			V<int> pk[NW];
+#pragma unroll
+			for (int wd = 0; wd < NW; ++wd) pk[wd] = 0;
+#pragma unroll
+			for (int i = B - 1; i >= 0; --i) {          // descending: lane i reads the OLD state of lane i-1
+				V<int> x1 = i ? X[i - 1] : XL, v1 = i ? Vv[i - 1] : VL, x21 = i ? X2[i - 1] : X2L;
+				V<int> ut = U[i];
+				V<int> a = add3(x1, v1, -QE), b = add3(Y[i], ut, -QE);
+				V<int> a2 = add3(x21, v1, -QE2), b2 = add3(Y2[i], ut, -QE2);
+				V<int> zz = vmax3(vmax3(Sc[i], a, b), a2, b2);
+				V<int> z = vmin(zz & (int)0xff000000, MCH);
+				V<int> p = zz & 7;
+				U[i] = wsub(z, v1); Vv[i] = wsub(z, ut);
+				V<int> tmp = wsub(z, Q), tmp2 = wsub(z, Q2);
+				a = wsub(a, tmp); b = wsub(b, tmp); a2 = wsub(a2, tmp2); b2 = wsub(b2, tmp2);
+				p = wadd(wadd(p, p), sel(a > hA, 1, 0));
+				p = wadd(wadd(p, p), sel(b > hB, 1, 0));
+				p = wadd(wadd(p, p), sel(a2 > hA2, 1, 0));
+				p = wadd(wadd(p, p), sel(b2 > hB2, 1, 0));
+				X[i] = vmax(a, tA); Y[i] = vmax(b, tB); X2[i] = vmax(a2, tA2); Y2[i] = vmax(b2, tB2);
+				pk[i >> 2] = pk[i >> 2] | (p << (8 * (i & 3)));
+			}
+			uint32_t *trow = tbw + (size_t)r * n_colw;
+#pragma unroll
+			for (int wd = 0; wd < NW; ++wd)
+				gst(trow, ln * NW + wd, cast<uint32_t>(pk[wd]));
+		WM_END
+
+		if (!approx) {   // ---- exact max with the reference's SIMD tie rule (:315-358) -----------------
+			V<long long> key = (long long)(-0x7fffffffffffffffLL - 1);
+			if (r > 0) {
+				const int en1 = st0 + (en0 - st0) / 4 * 4;
+#pragma unroll
+				for (int i = B - 1; i >= 0; --i) {
+					V<int> t = t0 + i, v8 = Vv[i] >> 24, u8 = U[i] >> 24;
+					V<int> hl = i ? H[i - 1] : HL;
+					V<int> hn = H[i] + v8;
+					hn = sel(t == en0, en0 > 0 ? V<int>(hl + u8) : hn, hn);
+					H[i] = sel(t >= st0 && t <= en0, hn, H[i]);
+					// priority on ties: en0, then residue groups 0..3 of [st0,en1) (earliest first), then the tail
+					V<int> grp = sel(t == en0, 5, sel(t < en1, 4 - ((t - st0) & 3), 0));
+					V<int> pri = (grp << 20) | (0xfffff - t);
+					V<long long> k = cast<long long>(H[i]) * 4294967296LL + cast<long long>(pri);
+					key = sel(t >= st0 && t <= en0 && k > key, k, key);
+				}
+			} else {
+				WM_IF(ln == 0) H[0] = (Vv[0] >> 24) - qe; WM_END
+				V<long long> k = cast<long long>(H[0]) * 4294967296LL + (long long)((5 << 20) | 0xfffff);
+				key = sel(ln == 0, k, key);
+			}
+			key = wave_max_i64(key);
+			const long long kk = uniform(key);
+			const int max_H = (int)(kk >> 32), pri = (int)(kk & 0xffffffffLL);
+			const int max_t = 0xfffff - (pri & 0xfffff);
+			if (en0 == tlen - 1) { const int h = get_lane<B>(H, base, en0); if (h > ez_mte) ez_mte = h, ez_mte_q = r - en; }
+			if (r - st0 == qlen - 1) { const int h = get_lane<B>(H, base, st0); if (h > ez_mqe) ez_mqe = h, ez_mqe_t = st0; }
+			// ksw_apply_zdrop (src/ksw2.h:160-176)
+			if (max_H > ez_max) {
+				ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
+			} else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
+				const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+				if (zdrop >= 0 && ez_max - max_H > zdrop + l * e2) { ez_zdropped = 1; break; }
+			}
+			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = get_lane<B>(H, base, tlen - 1);
+		} else {        // ---- approximate max: follow one diagonal-ish track (:359-375) ---------------
+			if (r > 0) {
+				const bool in0 = last_H0_t >= st0 && last_H0_t <= en0, in1 = last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0;
+				if (in0 && in1) {
+					const int d0 = get_lane<B>(Vv, base, last_H0_t) >> 24, d1 = get_lane<B>(U, base, last_H0_t + 1) >> 24;
+					if (d0 > d1) H0 += d0;
+					else H0 += d1, ++last_H0_t;
+				} else if (in0) {
+					H0 += get_lane<B>(Vv, base, last_H0_t) >> 24;
+				} else {
+					++last_H0_t;
+					H0 += get_lane<B>(U, base, last_H0_t) >> 24;
+				}
+			} else H0 = (readlane(Vv[0], 0) >> 24) - qe, last_H0_t = 0;
+			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = H0;
+		}
+	}
+
+	// ---- results + where the backtrack starts (src/ksw2_extd2_sse.c:381-391) ---------------------------
+	int bt_i = -1, bt_j = -1, reach_end = 0;
+	if (!ez_zdropped && !(flag & KSW_F_EXTZ_ONLY)) bt_i = tlen - 1, bt_j = qlen - 1;
+	else if (!ez_zdropped && (flag & KSW_F_EXTZ_ONLY) && ez_mqe + jb.end_bonus > ez_max) reach_end = 1, bt_i = ez_mqe_t, bt_j = qlen - 1;
+	else if (ez_max_t >= 0 && ez_max_q >= 0) bt_i = ez_max_t, bt_j = ez_max_q;
+	WM_IF(ln == 0)
+		wm_ksw_dres_t o;
+		o.max = ez_max; o.zdropped = ez_zdropped; o.max_q = ez_max_q; o.max_t = ez_max_t;
+		o.mqe = ez_mqe; o.mqe_t = ez_mqe_t; o.mte = ez_mte; o.mte_q = ez_mte_q;
+		o.score = ez_score; o.reach_end = reach_end; o.n_cigar = 0; o.bt_i = bt_i; o.bt_j = bt_j;
+		*res = o;
+	WM_END
+}
+
+// ------------------------------------------------------------------------------------------------------
+// ksw_backtrack (src/ksw2.h:119-151, is_rot = 1, min_intron_len = 0): ONE thread walks the traceback of one
+// alignment and emits run-length CIGAR ops in backtrack order into cig[0..cap); the gather step reverses
+// them unless KSW_EZ_REV_CIGAR. Row r covers lanes [st(r), en(r)] (recomputed here from the band formula).
+// Returns the number of ops (or -needed if cap is too small).
+// ------------------------------------------------------------------------------------------------------
+WM_DEV int ksw_backtrack_thread(const wm_ksw_djob_t jb, const uint8_t *__restrict__ tb_arena, int i0, int j0,
+                                uint32_t *__restrict__ cig, int cap)
+{
+	const uint8_t *p = tb_arena + jb.tb_off;
+	const int qlen = jb.qlen, tlen = jb.tlen, n_col = jb.n_col;
+	const int w = jb.w < 0 ? (tlen > qlen ? tlen : qlen) : jb.w;
+	const bool right = (jb.flag & KSW_F_RIGHT) != 0;
+	int n = 0, i = i0, j = j0, state = 0;
+	uint32_t cur_op = 0xf, cur_len = 0;
+#define WM_PUSH(op_, len_) do { if ((uint32_t)(op_) == cur_op) cur_len += (len_); else { if (cur_len) { if (n < cap) cig[n] = cur_len << 4 | cur_op; ++n; } cur_op = (op_); cur_len = (len_); } } while (0)
+	while (i >= 0 && j >= 0) {
+		const int r = i + j;
+		int st0 = 0, en0 = tlen - 1, force = -1, d, ext;
+		if (st0 < r - qlen + 1) st0 = r - qlen + 1;
+		if (en0 > r) en0 = r;
+		if (st0 < (r - w + 1) >> 1) st0 = (r - w + 1) >> 1;
+		if (en0 > (r + w) >> 1) en0 = (r + w) >> 1;
+		const int off = st0 / 16 * 16, off_end = (en0 + 16) / 16 * 16 - 1;
+		if (i < off) force = 2;
+		if (i > off_end) force = 1;
+		const int raw = force < 0 ? p[(size_t)r * n_col + (i - off)] : -1;
+		// decode our byte into the reference's: low 3 bits = winning state, bits 3..6 = continuation flags
+		if (raw >= 0) {
+			const int code = raw >> 4;
+			d = right ? code : 4 - code;
+			ext = (raw >> 3 & 1) | (raw >> 2 & 1) << 1 | (raw >> 1 & 1) << 2 | (raw & 1) << 3;   // bit (state-1)
+		} else d = 0, ext = 0;
+		if (state == 0) state = d;
+		else if (!(ext >> (state - 1) & 1)) state = 0;
+		if (state == 0) state = d;
+		if (force >= 0) state = force;
+		if (state == 0) { WM_PUSH(0u, 1u); --i; --j; }
+		else if (state == 1 || state == 3) { WM_PUSH(2u, 1u); --i; }
+		else { WM_PUSH(1u, 1u); --j; }
+	}
+	if (i >= 0) WM_PUSH(2u, (uint32_t)(i + 1));
+	if (j >= 0) WM_PUSH(1u, (uint32_t)(j + 1));
+	if (cur_len) { if (n < cap) cig[n] = cur_len << 4 | cur_op; ++n; }
+#undef WM_PUSH
+	return n <= cap ? n : -n;
+}
+
+} // namespace wmk

@@ -1,0 +1,76 @@
+// simt.h — thin wave64 vocabulary used by the gfx950 kernels in this directory.
+//
+// On the device every "per-lane value" V<T> is just T and the helpers lower to single CDNA instructions
+// (DPP shifts, v_readlane, ballots). The kernels are written against this vocabulary so that the test
+// suite can also compile them against tests/simt_emu/simt.h, a host-side lock-step emulator of one
+// wavefront (test infrastructure only; never part of the product build, which always includes THIS file).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WM_DEV __device__ __forceinline__
+#define WM_IF(c) if (c) {
+#define WM_ELSE } else {
+#define WM_END }
+#define WM_EMU_ASSERT(x) ((void)0)
+
+namespace simt {
+
+template <class T> using V = T;
+using vbool = bool;
+
+WM_DEV int lane() { return (int)(threadIdx.x & 63u); }
+
+template <class T> WM_DEV T sel(bool c, T a, T b) { return c ? a : b; }
+template <class T, class U> WM_DEV T cast(U a) { return (T)a; }
+WM_DEV int vmax(int a, int b) { return a > b ? a : b; }
+WM_DEV int vmin(int a, int b) { return a < b ? a : b; }
+WM_DEV int vmax3(int a, int b, int c) { return vmax(vmax(a, b), c); }          // -> v_max3_i32
+WM_DEV int add3(int a, int b, int c) { return (int)((unsigned)a + (unsigned)b + (unsigned)c); } // -> v_add3_u32 (wrapping)
+WM_DEV int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }     // wrapping 32-bit add
+WM_DEV int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }     // wrapping 32-bit sub
+
+// value of lane-1 (lane 0 receives `fill`)
+WM_DEV int shr1(int x, int fill)
+{
+	int y = __shfl_up(x, 1, 64);
+	return lane() == 0 ? fill : y;
+}
+// lane j receives lane j+k (uniform k); lanes >= 64-k receive `fill`
+WM_DEV int shift_down(int x, int k, int fill)
+{
+	int y = __shfl_down(x, (unsigned)k, 64);
+	return lane() + k >= 64 ? fill : y;
+}
+WM_DEV int readlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+WM_DEV int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+WM_DEV long long uniform(long long x)
+{
+	unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32));
+	return (long long)((unsigned long long)hi << 32 | lo);
+}
+WM_DEV unsigned long long ballot(bool c) { return __ballot(c); }
+WM_DEV bool any(bool c) { return __any(c); }
+
+// wave-wide maximum of a 64-bit key (all lanes receive the result)
+WM_DEV long long wave_max_i64(long long k)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		long long t = __shfl_xor(k, o, 64);
+		k = t > k ? t : k;
+	}
+	return k;
+}
+WM_DEV int wave_sum_i32(int k)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) k += __shfl_xor(k, o, 64);
+	return k;
+}
+
+// memory (global or LDS pointers alike)
+template <class T> WM_DEV T gld(const T *p, long long i) { return p[i]; }
+template <class T> WM_DEV void gst(T *p, long long i, T v) { p[i] = v; }
+
+} // namespace simt

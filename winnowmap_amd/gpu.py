@@ -1,0 +1,134 @@
+"""ctypes binding of libwmgpu.so (include/wm_gpu.h). No fallback: if the HIP library is missing or no
+device is usable, every call raises."""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libwmgpu.so")
+
+
+class WmError(RuntimeError):
+    pass
+
+
+class KswScore(C.Structure):
+    _fields_ = [("match", C.c_int8), ("mismatch", C.c_int8), ("sc_ambi", C.c_int8),
+                ("q", C.c_int8), ("e", C.c_int8), ("q2", C.c_int8), ("e2", C.c_int8)]
+
+
+KSW_JOB_DTYPE = np.dtype([("q_off", np.uint32), ("t_off", np.uint32), ("qlen", np.int32), ("tlen", np.int32),
+                          ("w", np.int32), ("zdrop", np.int32), ("end_bonus", np.int32), ("flag", np.int32)])
+KSW_RES_DTYPE = np.dtype([("max", np.int32), ("zdropped", np.int32), ("max_q", np.int32), ("max_t", np.int32),
+                          ("mqe", np.int32), ("mqe_t", np.int32), ("mte", np.int32), ("mte_q", np.int32),
+                          ("score", np.int32), ("reach_end", np.int32), ("n_cigar", np.int32), ("cig_off", np.uint32)])
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WmError("libwmgpu.so is not built (run `python -m winnowmap_amd.build`); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.wm_last_error.restype = C.c_char_p
+        L.wm_ctx_create.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.wm_ctx_destroy.argtypes = [C.c_void_p]
+        L.wm_last_kernel_ms.restype = C.c_float
+        L.wm_last_kernel_ms.argtypes = [C.c_void_p]
+        L.wm_ksw_batch.argtypes = [C.c_void_p, C.POINTER(KswScore), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                   C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.wm_ksw_dev_prepare.argtypes = [C.c_void_p, C.POINTER(KswScore), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.wm_ksw_dev_run.argtypes = [C.c_void_p, C.c_void_p]
+        L.wm_ksw_dev_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.wm_ksw_dev_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.wm_ksw_dev_free.argtypes = [C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise WmError("libwmgpu error %d: %s" % (rc, lib().wm_last_error().decode()))
+
+
+class Context:
+    """One GPU context (HIP device + stream + HBM arena)."""
+
+    def __init__(self, device=0, arena_bytes=0):
+        self._h = C.c_void_p()
+        _chk(lib().wm_ctx_create(device, arena_bytes, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().wm_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- ksw -------------------------------------------------------------------------------------
+    def ksw_batch(self, score, jobs, seqs):
+        """jobs: structured array KSW_JOB_DTYPE; seqs: uint8 codes. Returns (results KSW_RES_DTYPE, cigar pool)."""
+        jobs = np.ascontiguousarray(jobs, KSW_JOB_DTYPE)
+        seqs = np.ascontiguousarray(seqs, np.uint8)
+        res = np.zeros(len(jobs), KSW_RES_DTYPE)
+        cap = int((jobs["qlen"].astype(np.int64) + jobs["tlen"] + 2).sum()) + 16
+        pool = np.zeros(cap, np.uint32)
+        used = C.c_size_t(0)
+        _chk(lib().wm_ksw_batch(self._h, C.byref(score), len(jobs), jobs.ctypes.data, seqs.ctypes.data, seqs.nbytes,
+                                res.ctypes.data, pool.ctypes.data, cap, C.byref(used)))
+        return res, pool[:used.value]
+
+    def ksw_prepare(self, score, jobs, seqs):
+        jobs = np.ascontiguousarray(jobs, KSW_JOB_DTYPE)
+        seqs = np.ascontiguousarray(seqs, np.uint8)
+        h = C.c_void_p()
+        _chk(lib().wm_ksw_dev_prepare(self._h, C.byref(score), len(jobs), jobs.ctypes.data, seqs.ctypes.data, seqs.nbytes, C.byref(h)))
+        return KswDevBatch(self, h, jobs)
+
+
+class KswDevBatch:
+    def __init__(self, ctx, h, jobs):
+        self.ctx, self._h, self.jobs = ctx, h, jobs
+
+    def run(self):
+        _chk(lib().wm_ksw_dev_run(self.ctx._h, self._h))
+
+    def stats(self):
+        cells, tbb, dp, bt = C.c_uint64(), C.c_uint64(), C.c_float(), C.c_float()
+        lib().wm_ksw_dev_stats(self._h, C.byref(cells), C.byref(tbb), C.byref(dp), C.byref(bt))
+        return dict(cells=cells.value, tb_bytes=tbb.value, dp_ms=dp.value, bt_ms=bt.value)
+
+    def fetch(self):
+        res = np.zeros(len(self.jobs), KSW_RES_DTYPE)
+        cap = int((self.jobs["qlen"].astype(np.int64) + self.jobs["tlen"] + 2).sum()) + 16
+        pool = np.zeros(cap, np.uint32)
+        used = C.c_size_t(0)
+        _chk(lib().wm_ksw_dev_fetch(self.ctx._h, self._h, res.ctypes.data, pool.ctypes.data, cap, C.byref(used)))
+        return res, pool[:used.value]
+
+    def free(self):
+        if self._h:
+            lib().wm_ksw_dev_free(self.ctx._h, self._h)
+            self._h = None
+
+
+def pack_jobs(pairs, w=751, zdrop=400, end_bonus=-1, flag=0):
+    """pairs: list of (query codes, target codes[, dict overrides]). Returns (jobs, seqs)."""
+    jobs = np.zeros(len(pairs), KSW_JOB_DTYPE)
+    chunks, off = [], 0
+    for i, p in enumerate(pairs):
+        q, t = np.asarray(p[0], np.uint8), np.asarray(p[1], np.uint8)
+        o = dict(w=w, zdrop=zdrop, end_bonus=end_bonus, flag=flag)
+        if len(p) > 2:
+            o.update(p[2])
+        jobs[i] = (off, off + len(q), len(q), len(t), o["w"], o["zdrop"], o["end_bonus"], o["flag"])
+        chunks += [q, t]
+        off += len(q) + len(t)
+    seqs = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
+    return jobs, seqs
