@@ -1,0 +1,163 @@
+// tests/host_harness/harness.cpp — TEST INFRASTRUCTURE ONLY.
+// Drives the product's HOST mapper (winnowmap_amd/csrc/host/*.cpp: index, MCAS fibers, hit/align glue) with a
+// DeviceOps implementation backed by the ORACLE (oracle/wm_oracle.c), so that the host logic can be compared with
+// the real reference end-to-end on a machine without a GPU. The product never links this file.
+#include "../../winnowmap_amd/csrc/host/wm_core.cpp"
+#include "../../winnowmap_amd/csrc/host/wm_index.cpp"
+#include "../../winnowmap_amd/csrc/host/wm_seqio.cpp"
+#include "../../winnowmap_amd/csrc/host/wm_hit.cpp"
+#include "../../winnowmap_amd/csrc/host/wm_align.cpp"
+#include "../../winnowmap_amd/csrc/host/wm_mapper.cpp"
+#include "../../oracle/wm_oracle.h"
+#include <fstream>
+
+using namespace wm;
+
+struct OracleOps : DeviceOps {
+	const Index *idx; wmo_bloom_t *bloom; const MapOpt *opt;
+	void sketch_batch(int w, int k, std::vector<SketchReq*> &reqs) override
+	{
+		for (SketchReq *r : reqs) {
+			std::vector<uint64_t> x(r->len + 8), y(r->len + 8);
+			int64_t n = wmo_sketch((const char*)r->seq, r->len, w, k, 0, bloom, x.data(), y.data(), r->len + 8);
+			r->mini.resize(n);
+			for (int64_t i = 0; i < n; ++i) r->mini[i].x = x[i], r->mini[i].y = y[i];
+		}
+	}
+	void seed_batch(std::vector<SeedReq*> &reqs) override
+	{   // collect_matches + collect_seed_hits restated for the test (src/map.c:97-130, 222-254)
+		for (SeedReq *r : reqs) {
+			int rep_st = 0, rep_en = 0, rep_len = 0;
+			std::vector<wmo128_t> a;
+			for (int i = 0; i < r->n_mini; ++i) {
+				const m128 &p = r->mini[i];
+				const uint32_t q_pos = (uint32_t)p.y, q_span = p.x & 0xff;
+				int t;
+				const uint64_t *cr = idx->get(p.x >> 8, &t);
+				if (t >= r->max_occ) {
+					int en = (q_pos >> 1) + 1, st = en - q_span;
+					if (st > rep_en) { rep_len += rep_en - rep_st; rep_st = st, rep_en = en; } else rep_en = en;
+					continue;
+				}
+				bool tandem = false;
+				if (i > 0 && p.x >> 8 == r->mini[i - 1].x >> 8) tandem = true;
+				if (i < r->n_mini - 1 && p.x >> 8 == r->mini[i + 1].x >> 8) tandem = true;
+				for (int k = 0; k < t; ++k) {
+					const uint64_t rr = cr[k];
+					const int32_t rpos = (uint32_t)rr >> 1;
+					const bool fwd = (rr & 1) == (q_pos & 1);
+					if ((r->flag & F_FOR_ONLY) && !fwd) continue;
+					if ((r->flag & F_REV_ONLY) && fwd) continue;
+					wmo128_t e;
+					if (fwd) { e.x = (rr & 0xffffffff00000000ULL) | (uint64_t)rpos; e.y = (uint64_t)q_span << 32 | q_pos >> 1; }
+					else { e.x = 1ULL << 63 | (rr & 0xffffffff00000000ULL) | (uint64_t)rpos; e.y = (uint64_t)q_span << 32 | (uint32_t)(r->qlen - ((q_pos >> 1) + 1 - q_span) - 1); }
+					if (tandem) e.y |= SEED_TANDEM;
+					a.push_back(e);
+				}
+			}
+			rep_len += rep_en - rep_st;
+			wmo_radix_sort_128x(a.data(), a.data() + a.size());
+			r->a.resize(a.size());
+			for (size_t i = 0; i < a.size(); ++i) r->a[i].x = a[i].x, r->a[i].y = a[i].y;
+			r->rep_len = rep_len;
+		}
+	}
+	void chain_batch(std::vector<ChainReq*> &reqs) override
+	{
+		for (ChainReq *r : reqs) {
+			const int64_t n = (int64_t)r->a.size();
+			std::vector<wmo128_t> b(n ? n : 1);
+			std::vector<uint64_t> u(n ? n : 1);
+			int n_u = 0;
+			int64_t n_v = wmo_chain_dp(r->max_dist_x, r->min_dist_x, r->max_dist_y, r->bw, r->max_skip, r->max_iter, r->min_cnt, r->min_sc, r->gap_scale,
+			                           n, (const wmo128_t*)r->a.data(), &n_u, u.data(), b.data());
+			r->u.assign(u.begin(), u.begin() + n_u);
+			r->a.resize(n_v);
+			for (int64_t i = 0; i < n_v; ++i) r->a[i].x = b[i].x, r->a[i].y = b[i].y;
+		}
+	}
+	void ksw_batch(const wm_ksw_score_t &sc, std::vector<KswReq*> &reqs) override
+	{
+		int8_t mat[25];
+		for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) mat[i * 5 + j] = (i == 4 || j == 4) ? sc.sc_ambi : i == j ? sc.match : sc.mismatch;
+		for (KswReq *r : reqs) {
+			wmo_ez_t ez;
+			std::vector<uint32_t> cig(r->q.size() + r->t.size() + 4);
+			wmo_ksw_extd2((int)r->q.size(), r->q.data(), (int)r->t.size(), r->t.data(), 5, mat, sc.q, sc.e, sc.q2, sc.e2, r->w, r->zdrop, r->end_bonus, r->flag, &ez, cig.data(), 0);
+			r->ez.max = ez.max; r->ez.zdropped = ez.zdropped; r->ez.max_q = ez.max_q; r->ez.max_t = ez.max_t; r->ez.mqe = ez.mqe; r->ez.mqe_t = ez.mqe_t;
+			r->ez.mte = ez.mte; r->ez.mte_q = ez.mte_q; r->ez.score = ez.score; r->ez.reach_end = ez.reach_end; r->ez.n_cigar = ez.n_cigar; r->ez.cig_off = 0;
+			r->cigar.assign(cig.begin(), cig.begin() + ez.n_cigar);
+		}
+	}
+};
+
+struct Harness { Index idx; wmo_bloom_t *bloom; };
+
+extern "C" {
+
+void *h_index_build(const char *fasta, const char *kmer_file, int k, int w, int n_threads)
+{
+	Harness *h = new Harness();
+	IdxOpt io; io.k = k; io.w = w;
+	std::string err;
+	if (index_build_from_fasta(io, fasta, kmer_file ? kmer_file : "", n_threads, h->idx, err) < 0) { fprintf(stderr, "h_index_build: %s\n", err.c_str()); delete h; return 0; }
+	std::vector<uint64_t> kms;
+	if (kmer_file && kmer_file[0]) { std::ifstream in(kmer_file); std::string km; uint64_t f; while (in >> km >> f) kms.push_back(wmo_encode_kmer(km.c_str(), (int)km.size())); }
+	h->bloom = wmo_bloom_new(kms.size());
+	for (uint64_t x : kms) wmo_bloom_insert(h->bloom, x);
+	return h;
+}
+uint64_t h_index_n_minimizers(void *hv) { return ((Harness*)hv)->idx.n_minimizers; }
+int h_index_get(void *hv, uint64_t minier, uint64_t *out, int cap)
+{
+	int n; const uint64_t *p = ((Harness*)hv)->idx.get(minier, &n);
+	for (int i = 0; i < n && i < cap; ++i) out[i] = p[i];
+	return n;
+}
+int64_t h_sketch(void *hv, const char *seq, int len, int w, int k, uint32_t rid, uint64_t *ox, uint64_t *oy, int64_t cap)
+{
+	std::vector<m128> v;
+	sketch(seq, len, w, k, rid, &((Harness*)hv)->idx.bloom, v);
+	for (size_t i = 0; i < v.size() && (int64_t)i < cap; ++i) ox[i] = v[i].x, oy[i] = v[i].y;
+	return (int64_t)v.size();
+}
+void h_radix_sort_128x(uint64_t *x, uint64_t *y, int64_t n)
+{
+	std::vector<m128> a(n);
+	for (int64_t i = 0; i < n; ++i) a[i].x = x[i], a[i].y = y[i];
+	radix_sort_128x(a.data(), a.data() + n);
+	for (int64_t i = 0; i < n; ++i) x[i] = a[i].x, y[i] = a[i].y;
+}
+int h_ll_i16(int qlen, const uint8_t *q, int tlen, const uint8_t *t, const int8_t *mat, int gapo, int gape, int *qe, int *te) { return ll_i16(qlen, q, tlen, t, mat, gapo, gape, qe, te); }
+
+// same output layout as refshim_map (oracle/ref_shim.cpp)
+int h_map(void *hv, const char *preset, int64_t flag_extra, const char *seq, int len, const char *name,
+          int32_t *hit_out, int hit_cap, uint32_t *cig_out, int64_t cig_cap, int64_t *n_cig_total, uint64_t *stats_out)
+{
+	Harness *h = (Harness*)hv;
+	IdxOpt io; MapOpt mo;
+	set_preset(0, io, mo);
+	if (preset && preset[0] && set_preset(preset, io, mo) < 0) return -1;
+	mo.flag |= flag_extra;
+	OracleOps ops; ops.idx = &h->idx; ops.bloom = h->bloom; ops.opt = &mo;
+	std::vector<ReadIn> reads(1);
+	reads[0].name = name; reads[0].seq.assign(seq, len);
+	std::vector<ReadOut> out;
+	MapStats st;
+	map_batch(h->idx, mo, &ops, reads, out, &st);
+	if (stats_out) { stats_out[0] = st.n_flush; stats_out[1] = st.n_ksw; stats_out[2] = st.n_chain; stats_out[3] = st.n_sketch; }
+	int64_t nc = 0;
+	const std::vector<Reg> &regs = out[0].regs;
+	for (size_t i = 0; i < regs.size() && (int)i < hit_cap; ++i) {
+		const Reg &r = regs[i];
+		int32_t *o = hit_out + 16 * i;
+		o[0] = r.rid; o[1] = r.rs; o[2] = r.re; o[3] = r.qs; o[4] = r.qe; o[5] = r.rev; o[6] = r.mapq; o[7] = r.has_p ? (int)r.cigar.size() : 0;
+		o[8] = r.score; o[9] = r.cnt; o[10] = r.mlen; o[11] = r.blen; o[12] = r.dp_score; o[13] = r.dp_max; o[14] = r.dp_max2;
+		o[15] = (r.parent == r.id) | r.inv << 1 | r.sam_pri << 2 | r.split << 3;
+		for (uint32_t c : r.cigar) { if (nc < cig_cap) cig_out[nc] = c; ++nc; }
+	}
+	*n_cig_total = nc;
+	return (int)regs.size();
+}
+
+} // extern "C"

@@ -1,0 +1,142 @@
+// wm_core.cpp — options/presets, exact-permutation sorts, small hashes (see wm_core.h for citations).
+#include "wm_core.h"
+#include <math.h>
+#include <algorithm>
+
+namespace wm {
+
+struct Nt4Table {
+	uint8_t t[256];
+	constexpr Nt4Table() : t()
+	{
+		for (int i = 0; i < 256; ++i) t[i] = i < 4 ? (uint8_t)i : 4;
+		t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = t['U'] = t['u'] = 3;
+	}
+};
+static constexpr Nt4Table g_nt4;
+const uint8_t *const nt4_table = g_nt4.t;
+
+void mapopt_init(MapOpt &o)
+{
+	o = MapOpt();
+	o.min_dp_max = o.min_chain_score * o.a;                                              // src/options.c:47
+	o.prefixIncrementFactor = (float)pow((o.maxPrefixLength - 1) * 1.0 / o.minPrefixLength, 0.5);   // :57
+	o.stage2_max_gap = o.maxPrefixLength;
+}
+
+int set_preset(const char *p, IdxOpt &io, MapOpt &mo)
+{
+	if (p == 0) { io = IdxOpt(); mapopt_init(mo); return 0; }
+	std::string s(p);
+	if (s == "map-ont") { io.flag = 0; io.k = 15; }
+	else if (s == "map-pb") {
+		io.flag = 0; io.k = 15;
+		mo.maxPrefixLength = mo.stage2_max_gap = 8000;
+		mo.suffixSampleOffset = mo.minPrefixLength = 1000;
+		mo.stage2_bw = 1000;
+		mo.prefixIncrementFactor = (float)pow((mo.maxPrefixLength - 1) * 1.0 / mo.minPrefixLength, 0.33);
+	} else if (s == "map-pb-clr") { mo.SVaware = false; }
+	else if (s == "asm5") { io.flag = 0; io.k = 19; mo.a = 1; mo.b = 19; mo.q = 39; mo.q2 = 81; mo.e = 3; mo.e2 = 1; mo.zdrop = mo.zdrop_inv = 200; mo.min_dp_max = 200; }
+	else if (s == "asm10") { io.flag = 0; io.k = 19; mo.a = 1; mo.b = 9; mo.q = 16; mo.q2 = 41; mo.e = 2; mo.e2 = 1; mo.zdrop = mo.zdrop_inv = 200; mo.min_dp_max = 200; }
+	else if (s == "asm20") { io.flag = 0; io.k = 19; mo.a = 1; mo.b = 4; mo.q = 6; mo.q2 = 26; mo.e = 2; mo.e2 = 1; mo.zdrop = mo.zdrop_inv = 200; mo.min_dp_max = 200; }
+	else return -1;                          // splice*/cdna presets belong to ksw_exts2 (out of scope)
+	return 0;
+}
+
+int check_opt(const IdxOpt &io, const MapOpt &mo, std::string &err)
+{
+	if (io.k <= 0 || io.w <= 0) { err = "-k and -w must be positive"; return -5; }
+	if (io.k > 28 || io.w >= 256) { err = "need k <= 28 and w < 256 (src/sketch.c:140)"; return -5; }
+	if (mo.best_n < 0) { err = "-N must be no less than 0"; return -4; }
+	if (mo.pri_ratio < 0.0f || mo.pri_ratio > 1.0f) { err = "-p must be within 0 and 1 (including 0 and 1)"; return -4; }
+	if ((mo.flag & F_FOR_ONLY) && (mo.flag & F_REV_ONLY)) { err = "--for-only and --rev-only can't be applied at the same time"; return -3; }
+	if (mo.e <= 0 || mo.q <= 0) { err = "-O and -E must be positive"; return -1; }
+	if ((mo.q != mo.q2 || mo.e != mo.e2) && !(mo.e > mo.e2 && mo.q + mo.e < mo.q2 + mo.e2)) { err = "dual gap penalties violating E1>E2 and O1+E1<O2+E2"; return -2; }
+	if ((mo.q + mo.e) + (mo.q2 + mo.e2) > 127) { err = "scoring system violating ({-O}+{-E})+({-O2}+{-E2}) <= 127"; return -1; }
+	if (mo.zdrop < mo.zdrop_inv) { err = "Z-drop should not be less than inversion-Z-drop"; return -5; }
+	if ((mo.flag & F_NO_PRINT_2ND) && (mo.flag & F_ALL_CHAINS)) { err = "-X/-P and --secondary=no can't be applied at the same time"; return -5; }
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// In-place MSD byte radix sort ("American flag"), 8-bit digits from the top byte, ranges of <= 64
+// elements finished by insertion sort. Ties end up in an order fixed by this exact swap sequence, which
+// downstream code (chain DP, region order) depends on — SURVEY.md Appendix G. Only the key is compared.
+// ------------------------------------------------------------------------------------------------
+template <class T, class KeyFn> struct FlagSort {
+	KeyFn key;
+	void insertion(T *b, T *e) const
+	{
+		for (T *i = b + 1; i < e; ++i) {
+			if (!(key(*i) < key(*(i - 1)))) continue;
+			T held = *i;
+			T *j = i;
+			while (j > b && key(held) < key(*(j - 1))) { *j = *(j - 1); --j; }
+			*j = held;
+		}
+	}
+	void pass(T *beg, T *end, int shift) const
+	{
+		size_t hist[256] = {0};
+		T *head[256], *tail[256];
+		for (T *i = beg; i != end; ++i) ++hist[key(*i) >> shift & 0xff];
+		T *cur = beg;
+		for (int d = 0; d < 256; ++d) { head[d] = cur; cur += hist[d]; tail[d] = cur; }
+		for (int d = 0; d < 256; ) {
+			if (head[d] == tail[d]) { ++d; continue; }
+			int dst = (int)(key(*head[d]) >> shift & 0xff);
+			if (dst == d) { ++head[d]; continue; }
+			T held = *head[d];
+			while (dst != d) {               // follow the displacement cycle until something for bucket d turns up
+				std::swap(held, *head[dst]);
+				++head[dst];
+				dst = (int)(key(held) >> shift & 0xff);
+			}
+			*head[d]++ = held;
+		}
+		if (shift == 0) return;
+		const int next = shift > 8 ? shift - 8 : 0;
+		cur = beg;
+		for (int d = 0; d < 256; ++d) {
+			T *stop = tail[d];
+			if (stop - cur > 64) pass(cur, stop, next);
+			else if (stop - cur > 1) insertion(cur, stop);
+			cur = stop;
+		}
+	}
+	void run(T *beg, T *end) const
+	{
+		if (end - beg <= 64) insertion(beg, end);
+		else pass(beg, end, 56);
+	}
+};
+struct KeyX { uint64_t operator()(const m128 &a) const { return a.x; } };
+struct KeyId { uint64_t operator()(uint64_t a) const { return a; } };
+void radix_sort_128x(m128 *beg, m128 *end) { FlagSort<m128, KeyX>().run(beg, end); }
+void radix_sort_64(uint64_t *beg, uint64_t *end) { FlagSort<uint64_t, KeyId>().run(beg, end); }
+
+uint64_t hash64_masked(uint64_t key, uint64_t mask)
+{
+	key = (~key + (key << 21)) & mask;
+	key = key ^ key >> 24;
+	key = (key * 265) & mask;               // key + (key<<3) + (key<<8)
+	key = key ^ key >> 14;
+	key = (key * 21) & mask;                // key + (key<<2) + (key<<4)
+	key = key ^ key >> 28;
+	key = (key + (key << 31)) & mask;
+	return key;
+}
+uint64_t hash64_full(uint64_t key) { return hash64_masked(key, ~0ULL); }
+uint32_t wang_hash32(uint32_t key)
+{
+	key += ~(key << 15); key ^= key >> 10; key += key << 3; key ^= key >> 6; key += ~(key << 11); key ^= key >> 16;
+	return key;
+}
+uint32_t x31_hash_string(const char *s)
+{
+	uint32_t h = (uint32_t)*s;
+	if (h) for (++s; *s; ++s) h = (h << 5) - h + (uint32_t)*s;
+	return h;
+}
+
+} // namespace wm

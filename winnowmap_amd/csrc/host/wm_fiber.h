@@ -1,0 +1,94 @@
+// wm_fiber.h — cooperative fibers + batching scheduler.
+//
+// The reference maps one read per thread with deeply data-dependent control flow (src/map.c:279-974: MCAS windows,
+// MAPQ-gated retries, chain splitting). Rewriting that as explicit state machines is error-prone, so each unit of
+// work (one stage-1 window position, one stage-2 pass) runs as a FIBER whose code reads sequentially; whenever it
+// needs a device operation it enqueues the request and yields. When every fiber is blocked the scheduler flushes the
+// queues as ONE batched device call per operation type and resumes the waiters. Thousands of reads in flight give
+// the kernels their batch sizes; the host code stays a straight restatement of the reference's semantics.
+#pragma once
+#include <ucontext.h>
+#include <functional>
+#include <deque>
+#include <vector>
+#include <memory>
+#include <stdlib.h>
+#include "wm_ops.h"
+
+namespace wm {
+
+class Scheduler {
+public:
+	Scheduler(DeviceOps *ops, const wm_ksw_score_t &sc, int w, int k) : ops_(ops), sc_(sc), w_(w), k_(k) {}
+	~Scheduler() { for (Fiber *f : pool_) { free(f->stack); delete f; } }
+
+	void spawn(std::function<void()> fn)
+	{
+		Fiber *f;
+		if (!pool_.empty()) { f = pool_.back(); pool_.pop_back(); }
+		else { f = new Fiber(); f->stack = (char*)malloc(kStack); }
+		f->fn = std::move(fn); f->done = false;
+		getcontext(&f->ctx);
+		f->ctx.uc_stack.ss_sp = f->stack; f->ctx.uc_stack.ss_size = kStack; f->ctx.uc_link = &main_;
+		const uintptr_t p = (uintptr_t)f;
+		makecontext(&f->ctx, (void (*)())&Scheduler::entry, 3, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32), 0);
+		f->owner = this;
+		ready_.push_back(f);
+		++live_;
+	}
+
+	// run until every fiber has finished
+	void run()
+	{
+		while (live_ > 0) {
+			while (!ready_.empty()) {
+				cur_ = ready_.front(); ready_.pop_front();
+				swapcontext(&main_, &cur_->ctx);
+				if (cur_->done) { cur_->fn = nullptr; pool_.push_back(cur_); --live_; }
+				cur_ = 0;
+			}
+			if (live_ == 0) break;
+			flush();
+		}
+	}
+
+	// ---- called from inside a fiber ----
+	void sketch(SketchReq &r) { q_sketch_.push_back(&r); wait(w_sketch_); }
+	void seed(SeedReq &r) { q_seed_.push_back(&r); wait(w_seed_); }
+	void chain(ChainReq &r) { q_chain_.push_back(&r); wait(w_chain_); }
+	void ksw(std::vector<KswReq> &rs) { if (rs.empty()) return; for (KswReq &r : rs) q_ksw_.push_back(&r); wait(w_ksw_); }
+
+	uint64_t n_flush = 0, n_ksw_jobs = 0, n_chain_jobs = 0, n_sketch_jobs = 0, n_seed_jobs = 0;
+
+private:
+	struct Fiber { ucontext_t ctx; char *stack; std::function<void()> fn; bool done; Scheduler *owner; };
+	static constexpr size_t kStack = 256 * 1024;
+	static void entry(unsigned lo, unsigned hi, unsigned)
+	{
+		Fiber *f = (Fiber*)((uintptr_t)lo | (uintptr_t)hi << 32);
+		f->fn();
+		f->done = true;                     // uc_link returns to the scheduler
+	}
+	void wait(std::vector<Fiber*> &w) { Fiber *me = cur_; w.push_back(me); swapcontext(&me->ctx, &main_); }
+	void wake(std::vector<Fiber*> &w) { for (Fiber *f : w) ready_.push_back(f); w.clear(); }
+	void flush()
+	{
+		++n_flush;
+		if (!q_sketch_.empty()) { n_sketch_jobs += q_sketch_.size(); ops_->sketch_batch(w_, k_, q_sketch_); q_sketch_.clear(); wake(w_sketch_); }
+		if (!q_seed_.empty()) { n_seed_jobs += q_seed_.size(); ops_->seed_batch(q_seed_); q_seed_.clear(); wake(w_seed_); }
+		if (!q_chain_.empty()) { n_chain_jobs += q_chain_.size(); ops_->chain_batch(q_chain_); q_chain_.clear(); wake(w_chain_); }
+		if (!q_ksw_.empty()) { n_ksw_jobs += q_ksw_.size(); ops_->ksw_batch(sc_, q_ksw_); q_ksw_.clear(); wake(w_ksw_); }
+	}
+	DeviceOps *ops_;
+	wm_ksw_score_t sc_;
+	int w_, k_;
+	ucontext_t main_;
+	Fiber *cur_ = 0;
+	size_t live_ = 0;
+	std::deque<Fiber*> ready_;
+	std::vector<Fiber*> pool_;
+	std::vector<SketchReq*> q_sketch_; std::vector<SeedReq*> q_seed_; std::vector<ChainReq*> q_chain_; std::vector<KswReq*> q_ksw_;
+	std::vector<Fiber*> w_sketch_, w_seed_, w_chain_, w_ksw_;
+};
+
+} // namespace wm

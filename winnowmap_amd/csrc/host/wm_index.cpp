@@ -1,0 +1,245 @@
+// wm_index.cpp — host-side sketching (index build; the per-read sketch runs on the GPU) and the flat index.
+#include "wm_index.h"
+#include <math.h>
+#include <stdio.h>
+#include <algorithm>
+#include <fstream>
+#include <thread>
+#include <atomic>
+#include <limits>
+
+namespace wm {
+
+// ---- bloom filter --------------------------------------------------------------------------------------
+void Bloom::init(uint64_t n_kmers)
+{   // compute_optimal_parameters (bloom_filter.hpp:108-160) with projected = max(n,1000), fpp = 0.001; the
+	// hash count is capped at 2 (src/index.c:414) but the table is sized for the unconstrained optimum
+	const double n = (double)(n_kmers > 1000 ? n_kmers : 1000);
+	double min_m = std::numeric_limits<double>::infinity();
+	for (double kk = 1.0; kk < 1000.0; kk += 1.0) {
+		const double m = (-kk * n) / std::log(1.0 - std::pow(0.001, 1.0 / kk));
+		if (m < min_m) min_m = m;
+	}
+	table_bits = (uint64_t)min_m;
+	if (table_bits % 8) table_bits += 8 - table_bits % 8;
+	// generate_unique_salt (:513-528) with random_seed_ = seed*0xA5A5A5A5+1 (:186), two salts, updated in place
+	const uint64_t seed = 0xA5A5A5A55A5A5A5AULL * 0xA5A5A5A5ULL + 1;
+	salt[0] = 0xAAAAAAAAu; salt[1] = 0x55555555u;
+	for (int i = 0; i < 2; ++i) salt[i] = salt[i] * salt[(i + 3) % 2] + (uint32_t)seed;
+	bits.assign(table_bits / 8, 0);
+	n_inserted = 0;
+}
+uint32_t Bloom::hash_ap8(uint64_t key, uint32_t h)
+{   // hash_ap (:551-608) for an 8-byte little-endian key: exactly one round of the 8-byte loop
+	const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+	return h ^ ((h << 7) ^ lo * (h >> 3) ^ (~((h << 11) + (hi ^ (h >> 5)))));
+}
+void Bloom::insert(uint64_t key)
+{
+	for (int i = 0; i < 2; ++i) {
+		const uint64_t bit = hash_ap8(key, salt[i]) % table_bits;
+		bits[bit >> 3] |= (uint8_t)(1u << (bit & 7));
+	}
+	++n_inserted;
+}
+bool Bloom::contains(uint64_t key) const
+{
+	if (table_bits == 0) return false;
+	for (int i = 0; i < 2; ++i) {
+		const uint64_t bit = hash_ap8(key, salt[i]) % table_bits;
+		if (!((bits[bit >> 3] >> (bit & 7)) & 1)) return false;
+	}
+	return true;
+}
+
+uint64_t encode_kmer(const char *s, int k)
+{
+	uint64_t fwd = 0, rev = 0;
+	for (int i = 0; i < k; ++i) {
+		const uint64_t c = nt4_table[(uint8_t)s[i]];
+		fwd = fwd << 2 | c;
+		rev = rev >> 2 | (3ULL ^ c) << (2 * (k - 1));
+	}
+	return fwd < rev ? fwd : rev;
+}
+
+static inline uint64_t fmix64(uint64_t h)
+{
+	h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ULL; h ^= h >> 33;
+	return h;
+}
+double minimizer_order(uint64_t kmer, bool down)
+{   // larger hash = smaller order = preferred; down-weighted k-mers use x^8 (three squarings) — no FMA here
+	const double x = (double)fmix64(kmer) * 1.0 / 18446744073709551616.0;
+	if (!down) return -1.0 * x;
+	const double x2 = x * x, x4 = x2 * x2;
+	return -1.0 * (x4 * x4);
+}
+
+// ---- robust weighted winnowing as a small streaming machine -----------------------------------------------
+namespace {
+struct Winnower {
+	static constexpr uint64_t NONE = ~0ULL;
+	int w, k;
+	uint64_t mask, top_shift, fwd = 0, rev = 0;
+	int run = 0, slot = 0, min_slot = 0;
+	uint64_t ring_x[256], ring_y[256], min_x = NONE, min_y = NONE;
+	double ring_o[256], min_o = 2.0;
+	const Bloom *bloom;
+	std::vector<m128> &out;
+	Winnower(int w_, int k_, const Bloom *b, std::vector<m128> &o) : w(w_), k(k_), mask((1ULL << 2 * k_) - 1), top_shift(2ULL * (k_ - 1)), bloom(b), out(o)
+	{
+		for (int j = 0; j < w; ++j) ring_x[j] = ring_y[j] = NONE, ring_o[j] = 2.0;
+	}
+	void emit() { m128 m = { min_x, min_y }; out.push_back(m); }
+	void push(uint32_t rid, uint32_t pos, int c)
+	{
+		uint64_t x = NONE, y = NONE;
+		double o = 2.0;
+		if (c < 4) {
+			fwd = (fwd << 2 | (uint64_t)c) & mask;
+			rev = rev >> 2 | (3ULL ^ (uint64_t)c) << top_shift;
+			if (fwd == rev) return;                            // strand-ambiguous k-mer: nothing happens at all
+			const int strand = fwd < rev ? 0 : 1;
+			if (++run >= k) {
+				const uint64_t km = strand ? rev : fwd;
+				x = hash64_masked(km, mask) << 8 | (uint64_t)k;
+				y = (uint64_t)rid << 32 | (uint64_t)pos << 1 | (uint64_t)strand;
+				o = minimizer_order(km, bloom && bloom->contains(km));
+			}
+		} else run = 0;
+		ring_x[slot] = x; ring_y[slot] = y; ring_o[slot] = o;
+		if (o < min_o) {                                          // strictly better: report the minimum it replaces
+			if (run >= w + k && min_x != NONE) emit();
+			min_x = x; min_y = y; min_o = o; min_slot = slot;
+		} else if (slot == min_slot) {                            // the minimum just fell out of the window
+			if (run >= w + k - 1 && min_x != NONE) emit();
+			min_x = min_y = NONE; min_o = 2.0;
+			for (int n = 1; n <= w; ++n) {                        // oldest to newest; the newest of equal orders wins
+				const int j = (slot + n) % w;
+				if (min_o >= ring_o[j]) { min_x = ring_x[j]; min_y = ring_y[j]; min_o = ring_o[j]; min_slot = j; }
+			}
+		}
+		if (++slot == w) slot = 0;
+	}
+	void finish() { if (min_x != NONE) emit(); }
+};
+}
+
+void sketch(const char *seq, int len, int w, int k, uint32_t rid, const Bloom *bloom, std::vector<m128> &out)
+{
+	Winnower wn(w, k, bloom, out);
+	for (int i = 0; i < len; ++i) wn.push(rid, (uint32_t)i, nt4_table[(uint8_t)seq[i]]);
+	wn.finish();
+}
+
+// ---- flat index ------------------------------------------------------------------------------------------
+const uint64_t *Index::get(uint64_t minier, int *n) const
+{
+	*n = 0;
+	if (hkey.empty()) return 0;
+	const uint64_t msk = ((uint64_t)1 << hbits) - 1;
+	for (uint64_t s = slot_of(minier, hbits);; s = (s + 1) & msk) {
+		if (hkey[s] == minier) { *n = (int)(uint32_t)hval[s]; return &P[hval[s] >> 32]; }
+		if (hkey[s] == ~0ULL) return 0;
+	}
+}
+
+int Index::getseq(uint32_t rid, uint32_t st, uint32_t en, uint8_t *out) const
+{
+	if (rid >= seq.size() || st >= seq[rid].len) return -1;
+	if (en > seq[rid].len) en = seq[rid].len;
+	const uint64_t o = seq[rid].offset;
+	for (uint64_t i = o + st; i < o + en; ++i) out[i - o - st] = (uint8_t)(S[i >> 3] >> ((i & 7) << 2) & 0xf);
+	return (int)(en - st);
+}
+
+int index_build(const IdxOpt &io, const std::vector<std::string> &names, const std::vector<std::string> &seqs,
+                const std::string &kmer_file, int n_threads, Index &ix, std::string &err)
+{
+	ix = Index();
+	ix.k = io.k; ix.w = io.w; ix.flag = io.flag;
+	// -W list: count the lines, size the filter, insert the canonical k-mers (src/index.c:388-434)
+	{
+		std::vector<uint64_t> kms;
+		std::string last;
+		if (!kmer_file.empty()) {
+			std::ifstream in(kmer_file);
+			std::string km;
+			uint64_t freq;
+			while (in >> km >> freq) { kms.push_back(encode_kmer(km.c_str(), (int)km.size())); last = km; }
+		}
+		if (!kms.empty() && (int)last.size() != io.k) { err = "input list of k-mers and winnowmap parameter k are inconsistent"; return -1; }
+		ix.bloom.init(kms.size());
+		for (uint64_t km : kms) ix.bloom.insert(km);
+	}
+	// sequences: names, offsets, 4-bit packing (src/index.c:316-339)
+	uint64_t sum = 0;
+	for (size_t i = 0; i < seqs.size(); ++i) {
+		RefSeq r; r.name = names[i]; r.offset = sum; r.len = (uint32_t)seqs[i].size();
+		ix.seq.push_back(r); sum += r.len;
+	}
+	ix.total_len = sum;
+	ix.S.assign((sum + 7) / 8 + 1, 0);
+	// sketch every contig (independent → one task per contig) and pack it
+	std::vector<std::vector<m128>> per(seqs.size());
+	std::atomic<size_t> next(0);
+	auto work = [&]() {
+		for (size_t i; (i = next.fetch_add(1)) < seqs.size();) {
+			const std::string &s = seqs[i];
+			if (!s.empty()) sketch(s.data(), (int)s.size(), io.w, io.k, (uint32_t)i, &ix.bloom, per[i]);
+		}
+	};
+	{
+		const int nt = std::max(1, std::min<int>(n_threads, (int)seqs.size()));
+		std::vector<std::thread> th;
+		for (int t = 1; t < nt; ++t) th.emplace_back(work);
+		work();
+		for (auto &t : th) t.join();
+	}
+	for (size_t i = 0; i < seqs.size(); ++i) {
+		const uint64_t o = ix.seq[i].offset;
+		for (uint64_t j = 0; j < seqs[i].size(); ++j) {
+			const uint64_t p = o + j;
+			ix.S[p >> 3] |= (uint32_t)nt4_table[(uint8_t)seqs[i][j]] << ((p & 7) << 2);
+		}
+	}
+	std::vector<m128> all;
+	size_t tot = 0;
+	for (auto &v : per) tot += v.size();
+	all.reserve(tot);
+	for (auto &v : per) { all.insert(all.end(), v.begin(), v.end()); std::vector<m128>().swap(v); }
+	ix.n_minimizers = all.size();
+	// group by minimizer key, positions ascending (src/index.c:200-252)
+	std::sort(all.begin(), all.end(), [](const m128 &a, const m128 &b) { return (a.x >> 8) != (b.x >> 8) ? (a.x >> 8) < (b.x >> 8) : a.y < b.y; });
+	size_t nk = 0;
+	for (size_t i = 0; i < all.size(); ++i) if (i == 0 || (all[i].x >> 8) != (all[i - 1].x >> 8)) ++nk;
+	ix.n_keys = nk;
+	ix.hbits = 4;
+	while (((uint64_t)1 << ix.hbits) < 2 * nk + 2) ++ix.hbits;
+	ix.hkey.assign((size_t)1 << ix.hbits, ~0ULL);
+	ix.hval.assign((size_t)1 << ix.hbits, 0);
+	ix.P.resize(all.size());
+	const uint64_t msk = ((uint64_t)1 << ix.hbits) - 1;
+	for (size_t i = 0; i < all.size();) {
+		size_t j = i;
+		const uint64_t key = all[i].x >> 8;
+		while (j < all.size() && (all[j].x >> 8) == key) { ix.P[j] = all[j].y; ++j; }
+		uint64_t s = Index::slot_of(key, ix.hbits);
+		while (ix.hkey[s] != ~0ULL) s = (s + 1) & msk;
+		ix.hkey[s] = key; ix.hval[s] = (uint64_t)i << 32 | (uint64_t)(j - i);
+		i = j;
+	}
+	return 0;
+}
+
+int index_build_from_fasta(const IdxOpt &io, const std::string &fasta, const std::string &kmer_file, int n_threads, Index &out, std::string &err)
+{
+	extern int read_fastx(const std::string &fn, std::vector<std::string> &names, std::vector<std::string> &seqs, std::vector<std::string> *quals, std::vector<std::string> *comments, std::string &err);
+	std::vector<std::string> names, seqs;
+	if (read_fastx(fasta, names, seqs, 0, 0, err) < 0) return -1;
+	if (seqs.empty()) { err = "no sequences in " + fasta; return -1; }
+	return index_build(io, names, seqs, kmer_file, n_threads, out, err);
+}
+
+} // namespace wm

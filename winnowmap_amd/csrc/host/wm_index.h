@@ -1,0 +1,51 @@
+// wm_index.h — reference index of the mapper, laid out flat so the same arrays are uploaded to HBM unchanged.
+// Mirrors mm_idx_t (src/minimap.h:66-77) / mm_idx_bucket_t (src/index.c:33-38) by behaviour: a minimizer key
+// maps to its reference positions in ascending order (src/index.c:88-105,239).
+#pragma once
+#include "wm_core.h"
+
+namespace wm {
+
+struct Bloom {                              // ext/bloom/bloom_filter.hpp as configured by src/index.c:411-423
+	uint64_t table_bits = 0;
+	uint32_t salt[2] = {0, 0};
+	std::vector<uint8_t> bits;
+	uint64_t n_inserted = 0;
+	void init(uint64_t n_kmers);
+	static uint32_t hash_ap8(uint64_t key, uint32_t h);
+	void insert(uint64_t key);
+	bool contains(uint64_t key) const;
+};
+
+uint64_t encode_kmer(const char *s, int k);                    // encodeKmer, src/index.c:362-376
+double minimizer_order(uint64_t kmer, bool down_weighted);     // applyWeight, src/sketch.c:70-89
+
+// mm_sketch (src/sketch.c:128-219), non-HPC. Appends to out.
+void sketch(const char *seq, int len, int w, int k, uint32_t rid, const Bloom *bloom, std::vector<m128> &out);
+
+struct RefSeq { std::string name; uint64_t offset; uint32_t len; };
+
+struct Index {
+	int k = 15, w = 50, flag = 0;
+	std::vector<RefSeq> seq;                // mm_idx_seq_t
+	std::vector<uint32_t> S;                // 4 bits per base, 8 per word (mm_seq4_set, src/mmpriv.h:29)
+	uint64_t total_len = 0;
+	// open-addressing table: slot i holds hkey[i] (UINT64_MAX = empty) and hval[i] = first<<32 | count into P
+	int hbits = 0;
+	std::vector<uint64_t> hkey, hval;
+	std::vector<uint64_t> P;                // rid<<32 | lastPos<<1 | strand, ascending within a key
+	Bloom bloom;
+	uint64_t n_minimizers = 0, n_keys = 0;
+
+	const uint64_t *get(uint64_t minier, int *n) const;            // mm_idx_get, src/index.c:88
+	int getseq(uint32_t rid, uint32_t st, uint32_t en, uint8_t *out) const;   // mm_idx_getseq, src/index.c:161
+	static uint64_t slot_of(uint64_t key, int hbits) { return (key * 0x9E3779B97F4A7C15ULL) >> (64 - hbits); }
+};
+
+// names/seqs: reference contigs (ASCII). kmer_file: the -W list ("kmer count" lines) or empty.
+// Returns 0, or -1 with err set (e.g. k-mer length mismatch, src/index.c:403-407).
+int index_build(const IdxOpt &io, const std::vector<std::string> &names, const std::vector<std::string> &seqs,
+                const std::string &kmer_file, int n_threads, Index &out, std::string &err);
+int index_build_from_fasta(const IdxOpt &io, const std::string &fasta, const std::string &kmer_file, int n_threads, Index &out, std::string &err);
+
+} // namespace wm

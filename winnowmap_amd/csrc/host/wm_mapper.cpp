@@ -1,0 +1,212 @@
+// wm_mapper.cpp — see wm_mapper.h.
+#include "wm_mapper.h"
+#include "wm_hit.h"
+#include "wm_align.h"
+#include "wm_fiber.h"
+#include <math.h>
+#include <algorithm>
+#include <tuple>
+
+namespace wm {
+
+namespace {
+
+struct Segment {                       // result of mapping one (sub)sequence: the body shared by stage 1, stage 2 and the fallback
+	std::vector<Reg> regs;
+	std::vector<m128> a;
+	int rep_len = 0;
+};
+
+inline uint32_t read_hash(const char *qname, int qlen, int seed)
+{   // src/map.c:355-357
+	uint32_t h = qname ? x31_hash_string(qname) : 0;
+	h ^= wang_hash32((uint32_t)qlen) + wang_hash32((uint32_t)seed);
+	return wang_hash32(h);
+}
+
+// chaining + region generation + alignment + MAPQ on a given sorted anchor set (src/map.c:375-430 and :880-933)
+void chain_and_align(Scheduler &sch, const Index &idx, const MapOpt &o, float gap_scale, const uint8_t *codes, int qlen, uint32_t hash,
+                     std::vector<m128> &&anchors, int rep_len, Segment &out, int *frag_gap)
+{
+	const int max_gap_qry = o.max_gap;
+	int max_gap_ref;
+	if (o.max_gap_ref > 0) max_gap_ref = o.max_gap_ref;
+	else if (o.max_frag_len > 0) { max_gap_ref = o.max_frag_len - qlen; if (max_gap_ref < o.max_gap) max_gap_ref = o.max_gap; }
+	else max_gap_ref = o.max_gap;
+	const int min_gap_ref = o.min_gap_ref < max_gap_ref ? o.min_gap_ref : max_gap_ref;
+	if (frag_gap) *frag_gap = max_gap_ref;
+
+	ChainReq cr;
+	cr.max_dist_x = max_gap_ref; cr.min_dist_x = min_gap_ref; cr.max_dist_y = max_gap_qry; cr.bw = o.bw;
+	cr.max_skip = o.max_chain_skip; cr.max_iter = o.max_chain_iter; cr.min_cnt = o.min_cnt; cr.min_sc = o.min_chain_score;
+	cr.gap_scale = gap_scale;
+	cr.a = std::move(anchors);
+	if (!cr.a.empty()) sch.chain(cr);
+	out.a = std::move(cr.a);
+	out.rep_len = rep_len;
+	out.regs = gen_regs(hash, qlen, (int)cr.u.size(), cr.u.data(), out.a.data());
+	// chain_post (src/map.c:256-265)
+	if (!(o.flag & F_ALL_CHAINS)) {
+		set_parent(o.mask_level, o.mask_len, out.regs, o.a * 2 + o.b, (o.flag & F_HARD_MLEVEL) != 0);
+		select_sub(o.pri_ratio, idx.k * 2, o.best_n, out.regs);
+		if (!(o.flag & (F_SPLICE | F_SR | F_NO_LJOIN))) join_long(o, qlen, out.regs, out.a.data());
+	}
+	// align_regs (src/map.c:267-277)
+	if (o.flag & F_CIGAR) {
+		align_skeleton(sch, o, idx, qlen, codes, out.regs, out.a.data());
+		if (!(o.flag & F_ALL_CHAINS)) {
+			set_parent(o.mask_level, o.mask_len, out.regs, o.a * 2 + o.b, (o.flag & F_HARD_MLEVEL) != 0);
+			select_sub(o.pri_ratio, idx.k * 2, o.best_n, out.regs);
+			set_sam_pri(out.regs);
+		}
+	}
+	set_mapq(out.regs, o.min_chain_score, o.a, rep_len, 0);
+}
+
+// sketch → seed: collect_minimizers + collect_seed_hits (src/map.c:69-84, 222-254)
+void sketch_and_seed(Scheduler &sch, const MapOpt &o, const uint8_t *codes, int len, std::vector<m128> &anchors, int *rep_len)
+{
+	SketchReq sk; sk.seq = codes; sk.len = len;
+	sch.sketch(sk);
+	SeedReq sd; sd.mini = sk.mini.data(); sd.n_mini = (int)sk.mini.size(); sd.qlen = len; sd.max_occ = o.mid_occ; sd.flag = o.flag;
+	if (sd.n_mini > 0) sch.seed(sd);
+	anchors = std::move(sd.a);
+	*rep_len = sd.rep_len;
+}
+
+struct ReadTask {
+	const ReadIn *in = 0;
+	ReadOut *out = 0;
+	std::vector<uint8_t> codes;
+	int qlen = 0;
+	std::vector<std::vector<m128>> collect;     // MCAS anchors per suffix position (collect_a, src/map.c:296)
+	std::vector<uint8_t> mapped;                 // seqMapped, src/map.c:310
+	int pending = 0;
+};
+
+// one stage-1 start position: grow the window to the right, then to the left, until a confident alignment appears
+void stage1_position(Scheduler &sch, const Index &idx, const MapOpt &opt, const MapOpt &o2, ReadTask &T, int sub_begin, int suffix_id)
+{
+	const int L = T.qlen;
+	const char *qname = T.in->name.c_str();
+	bool found = false;
+	for (int sub_len = o2.minPrefixLength; sub_len <= o2.maxPrefixLength; sub_len = (int)(sub_len * o2.prefixIncrementFactor)) {
+		for (int dir = 0; dir < 2; ++dir) {             // 0: bases to the right of sub_begin, 1: to the left (src/map.c:346, :518)
+			const int start = dir == 0 ? sub_begin : sub_begin - sub_len + 1;
+			if (dir == 0 ? (sub_begin + sub_len > L) : (start < 0)) continue;
+			Segment S;
+			std::vector<m128> anchors;
+			int rep_len = 0;
+			sketch_and_seed(sch, o2, T.codes.data() + start, sub_len, anchors, &rep_len);
+			chain_and_align(sch, idx, o2, opt.chain_gap_scale, T.codes.data() + start, sub_len, read_hash(qname, sub_len, o2.seed), std::move(anchors), rep_len, S, 0);
+			for (const Reg &r : S.regs) {
+				if ((int)r.mapq >= o2.min_mapq && r.blen >= o2.min_qcov * sub_len && r.cnt > 0) {
+					found = true;
+					std::vector<m128> &dst = T.collect[suffix_id];
+					dst.resize(r.cnt);
+					// shift the anchors of this chain from window to read coordinates (src/map.c:482-496, :655-668)
+					const uint64_t fwd_shift = (uint64_t)start;
+					const uint64_t rev_shift = dir == 0 ? (uint64_t)(L - sub_begin - sub_len) : (uint64_t)((L - 1) - sub_begin);
+					for (int i = 0; i < r.cnt; ++i) {
+						m128 t = S.a[i + r.as];
+						t.y += (t.x >> 63) ? rev_shift : fwd_shift;
+						dst[i] = t;
+					}
+					for (int i = start; i < start + sub_len; ++i) T.mapped[i] = 1;
+					break;
+				}
+			}
+			if (found || S.regs.empty()) goto done;
+		}
+	}
+done:
+	return;
+}
+
+void stage2(Scheduler &sch, const Index &idx, const MapOpt &opt, ReadTask &T)
+{
+	const int L = T.qlen;
+	const char *qname = T.in->name.c_str();
+	MapOpt o3 = opt;                                                   // src/map.c:709-717
+	o3.zdrop_inv = std::min(opt.zdrop_inv, opt.stage2_zdrop_inv);
+	o3.bw = std::max(opt.bw, opt.stage2_bw);
+	o3.max_gap = std::max(opt.max_gap, opt.stage2_max_gap);
+	const uint32_t hash = read_hash(qname, L, o3.seed);
+	std::vector<m128> a;
+	int rep_len = 0;   // NB: the reference leaves this uninitialised on the pure-MCAS path (src/map.c:281); 0 is our defined value
+	for (const auto &v : T.collect) a.insert(a.end(), v.begin(), v.end());
+	if (!a.empty()) {                                                  // merge, dedup, order (src/map.c:739-781)
+		std::sort(a.begin(), a.end(), [](const m128 &p, const m128 &q) { return std::tie(p.x, p.y) < std::tie(q.x, q.y); });
+		a.erase(std::unique(a.begin(), a.end(), [](const m128 &p, const m128 &q) { return p.x == q.x && p.y == q.y; }), a.end());
+		radix_sort_128x(a.data(), a.data() + a.size());
+		if ((int)a.size() < o3.min_cnt) a.clear();
+	}
+	size_t unmapped = 0;
+	for (int i = 0; i < L; ++i) unmapped += T.mapped[i] == 0;
+	if (!a.empty() && unmapped > 0) {                                  // seeds from the stretches stage 1 left unmapped (:786-846)
+		std::vector<uint8_t> masked(T.codes);
+		for (int i = 0; i < L; ++i) if (T.mapped[i]) masked[i] = 4;
+		std::vector<m128> rest;
+		sketch_and_seed(sch, o3, masked.data(), L, rest, &rep_len);
+		a.insert(a.end(), rest.begin(), rest.end());
+		radix_sort_128x(a.data(), a.data() + a.size());
+	}
+	if (a.empty()) {                                                   // plain minimap2-style mapping with the user's options (:849-865)
+		o3 = opt;
+		sketch_and_seed(sch, o3, T.codes.data(), L, a, &rep_len);
+	}
+	Segment S;
+	int frag_gap = 0;
+	chain_and_align(sch, idx, o3, opt.chain_gap_scale, T.codes.data(), L, hash, std::move(a), rep_len, S, &frag_gap);
+	T.out->regs = std::move(S.regs);
+	T.out->rep_len = rep_len;
+	T.out->frag_gap = frag_gap;
+}
+
+} // namespace
+
+void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::vector<ReadIn> &reads, std::vector<ReadOut> &out, MapStats *stats)
+{
+	out.assign(reads.size(), ReadOut());
+	wm_ksw_score_t sc;
+	sc.match = (int8_t)opt.a; sc.mismatch = (int8_t)-abs(opt.b); sc.sc_ambi = (int8_t)-abs(opt.sc_ambi);
+	sc.q = (int8_t)opt.q; sc.e = (int8_t)opt.e; sc.q2 = (int8_t)opt.q2; sc.e2 = (int8_t)opt.e2;
+	Scheduler sch(ops, sc, idx.w, idx.k);
+	MapOpt o2 = opt;                                                   // stage-1 options (src/map.c:300-302)
+	o2.best_n = std::max(5, o2.best_n);
+	std::vector<ReadTask> tasks(reads.size());
+	for (size_t i = 0; i < reads.size(); ++i) {
+		ReadTask &T = tasks[i];
+		T.in = &reads[i]; T.out = &out[i];
+		T.qlen = (int)reads[i].seq.size();
+		T.codes.resize(T.qlen);
+		for (int j = 0; j < T.qlen; ++j) T.codes[j] = nt4_table[(uint8_t)reads[i].seq[j]];
+		if (T.qlen == 0) continue;
+		if (opt.max_qlen > 0 && T.qlen > opt.max_qlen) continue;
+		const int off = o2.suffixSampleOffset;
+		const int n_pos = 1 + (int)ceil(T.qlen * 1.0 / off);
+		T.collect.assign(n_pos, std::vector<m128>());
+		T.mapped.assign(T.qlen, 0);
+		ReadTask *tp = &T;
+		if (o2.SVaware && T.qlen >= o2.SVawareMinReadLength) {
+			std::vector<std::pair<int, int>> pos;                       // (sub_begin, suffix_id), src/map.c:334-341
+			for (int sb = 0; sb < T.qlen + off - 1; sb += off) {
+				const int sid = sb / off;
+				int b = sb;
+				if (b >= T.qlen) b = T.qlen - 1;
+				pos.push_back(std::make_pair(b, sid));
+				if (b != sb) break;
+			}
+			T.pending = (int)pos.size();
+			for (auto p : pos)
+				sch.spawn([&sch, &idx, &opt, &o2, tp, p]() {
+					stage1_position(sch, idx, opt, o2, *tp, p.first, p.second);
+					if (--tp->pending == 0) sch.spawn([&sch, &idx, &opt, tp]() { stage2(sch, idx, opt, *tp); });
+				});
+		} else sch.spawn([&sch, &idx, &opt, tp]() { stage2(sch, idx, opt, *tp); });
+	}
+	sch.run();
+	if (stats) { stats->n_flush += sch.n_flush; stats->n_ksw += sch.n_ksw_jobs; stats->n_chain += sch.n_chain_jobs; stats->n_seed += sch.n_seed_jobs; stats->n_sketch += sch.n_sketch_jobs; }
+}
+
+} // namespace wm

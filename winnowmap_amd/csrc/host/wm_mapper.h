@@ -1,0 +1,19 @@
+// wm_mapper.h — per-read orchestration: Winnowmap2's two-stage MCAS procedure (mm_map_frag, src/map.c:279-974)
+// expressed as fibers over batched device operations (wm_fiber.h). This is the replacement of the
+// kt_for(worker_for) seam at src/map.c:1164: a whole mini-batch of reads is mapped at once.
+#pragma once
+#include "wm_core.h"
+#include "wm_index.h"
+#include "wm_ops.h"
+
+namespace wm {
+
+struct ReadIn { std::string name, seq, qual, comment; };        // mm_bseq1_t, src/bseq.h
+struct ReadOut { std::vector<Reg> regs; int rep_len = 0, frag_gap = 0; };
+
+struct MapStats { uint64_t n_flush = 0, n_ksw = 0, n_chain = 0, n_seed = 0, n_sketch = 0; };
+
+// Maps reads[i] → out[i] (out is resized). The caller chooses the batch (the reference uses ≤ 1 Gbase mini-batches).
+void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::vector<ReadIn> &reads, std::vector<ReadOut> &out, MapStats *stats = 0);
+
+} // namespace wm

@@ -1,0 +1,71 @@
+// wm_seqio.cpp — FASTA/FASTQ (optionally gzip) reader with the record semantics of the reference's kseq/bseq
+// layer (src/bseq.c:66-78, src/kseq.h): name = header up to the first blank, the rest is the comment,
+// multi-line sequences are concatenated, 'U'/'u' become 'T'/'t'. Plain host I/O.
+#include <zlib.h>
+#include <string>
+#include <vector>
+#include <string.h>
+
+namespace wm {
+
+namespace {
+struct GzLines {
+	gzFile fp;
+	std::vector<char> buf;
+	size_t pos = 0, end = 0;
+	bool eof = false;
+	explicit GzLines(gzFile f) : fp(f), buf(1 << 20) {}
+	bool getline(std::string &ln)
+	{
+		ln.clear();
+		for (;;) {
+			if (pos == end) {
+				if (eof) return !ln.empty();
+				int n = gzread(fp, buf.data(), (unsigned)buf.size());
+				if (n <= 0) { eof = true; return !ln.empty(); }
+				pos = 0; end = (size_t)n;
+			}
+			const char *s = buf.data() + pos;
+			const char *nl = (const char*)memchr(s, '\n', end - pos);
+			if (nl) { ln.append(s, nl - s); pos += (size_t)(nl - s) + 1; if (!ln.empty() && ln.back() == '\r') ln.pop_back(); return true; }
+			ln.append(s, end - pos);
+			pos = end;
+		}
+	}
+};
+}
+
+int read_fastx(const std::string &fn, std::vector<std::string> &names, std::vector<std::string> &seqs,
+               std::vector<std::string> *quals, std::vector<std::string> *comments, std::string &err)
+{
+	gzFile fp = fn == "-" ? gzdopen(0, "r") : gzopen(fn.c_str(), "r");
+	if (!fp) { err = "failed to open file '" + fn + "'"; return -1; }
+	GzLines in(fp);
+	std::string ln, pending;
+	bool have = in.getline(ln);
+	while (have) {
+		if (ln.empty() || (ln[0] != '>' && ln[0] != '@')) { have = in.getline(ln); continue; }
+		const bool fq = ln[0] == '@';
+		size_t sp = ln.find_first_of(" \t");
+		names.push_back(ln.substr(1, sp == std::string::npos ? std::string::npos : sp - 1));
+		if (comments) comments->push_back(sp == std::string::npos ? std::string() : ln.substr(sp + 1));
+		std::string seq, qual;
+		have = in.getline(ln);
+		while (have && !(ln.size() && (ln[0] == '>' || ln[0] == '+' || (ln[0] == '@' && !fq)))) {
+			if (fq && ln.size() && ln[0] == '@' && !seq.empty()) break;
+			for (char c : ln) if (c > ' ') seq.push_back(c);
+			have = in.getline(ln);
+		}
+		if (have && ln.size() && ln[0] == '+') {                 // quality block: as many characters as bases
+			have = in.getline(ln);
+			while (have && qual.size() < seq.size()) { qual += ln; have = in.getline(ln); }
+		}
+		for (char &c : seq) if (c == 'u' || c == 'U') --c;
+		seqs.push_back(std::move(seq));
+		if (quals) quals->push_back(std::move(qual));
+	}
+	gzclose(fp);
+	return (int)seqs.size();
+}
+
+} // namespace wm
