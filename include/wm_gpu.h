@@ -97,6 +97,54 @@ int wm_ksw_extd2(wm_ctx_t *ctx, int qlen, const uint8_t *query, int tlen, const 
                  const int8_t *mat, int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus,
                  int flag, wm_ksw_result_t *ez, uint32_t **cigar_out);
 
+/* ---- reference index ------------------------------------------------------------------------------ */
+/* Host-side build (mm_idx_gen, src/index.c:378; reads the -W list like src/index.c:388-434) and upload of the
+ * flat arrays (packed bases, key table, position runs, bloom bits) to HBM. kmer_file may be NULL/"". */
+typedef struct wm_index_s wm_index_t;
+int wm_index_build(const char *fasta, const char *kmer_file, int k, int w, int n_threads, wm_index_t **out);
+void wm_index_destroy(wm_index_t *idx);
+int wm_index_upload(wm_ctx_t *ctx, const wm_index_t *idx);
+int wm_index_n_seq(const wm_index_t *idx);
+const char *wm_index_seq_name(const wm_index_t *idx, int rid);
+int wm_index_seq_len(const wm_index_t *idx, int rid);
+uint64_t wm_index_n_minimizers(const wm_index_t *idx);
+/* mm_idx_get (src/mmpriv.h:71): pointer into index memory (never freed by the caller), *n = 0 when absent */
+const uint64_t *wm_index_get(const wm_index_t *idx, uint64_t minier, int *n);
+
+/* ---- sketch / seed / chain, batched (need wm_index_upload first) ------------------------------------ */
+/* mm_sketch of n sequences of 0..4 codes (rid = 0). Minimizers of sequence i: out[out_off[i] .. +counts[i]). */
+int wm_sketch_batch(wm_ctx_t *ctx, int n, const uint8_t *seqs, size_t seqs_bytes, const uint64_t *seq_off, const int32_t *len,
+                    wm128_t *out, size_t out_cap, uint64_t *out_off, int32_t *counts);
+/* collect_seed_hits: minimizers of job i are mini[mini_off[i] .. +n_mini[i]); anchors (sorted by x with the
+ * reference's radix_sort_128x permutation) go to out[out_off[i] .. +n_anchors[i]); rep_len as src/map.c:126. */
+int wm_seed_batch(wm_ctx_t *ctx, int n, const wm128_t *mini, const uint64_t *mini_off, const int32_t *n_mini, const int32_t *qlen,
+                  int max_occ, int64_t flag, wm128_t *out, size_t out_cap, uint64_t *out_off, int32_t *n_anchors, int32_t *rep_len);
+/* mm_chain_dp (src/mmpriv.h:73) for n anchor sets; chains of job i: u[u_off[i] .. +n_u[i]), anchors regrouped in
+ * place: a[a_off[i] .. +n_v[i]). */
+typedef struct { int32_t max_dist_x, min_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc; float gap_scale; } wm_chain_par_t;
+int wm_chain_batch(wm_ctx_t *ctx, int n, wm128_t *a, const uint64_t *a_off, const int32_t *n_a, const wm_chain_par_t *par,
+                   uint64_t *u, uint64_t *u_off, int32_t *n_u, int32_t *n_v);
+/* kernel time of the last sketch/seed/chain batch call (HIP events on the context stream), ms */
+float wm_last_aux_ms(const wm_ctx_t *ctx);
+
+/* ---- the mapper: replacement of kt_for(worker_for) (src/map.c:1164) ---------------------------------- */
+typedef struct wm_mapper_s wm_mapper_t;
+/* preset: NULL/"" or "map-ont" | "map-pb" | "map-pb-clr" | "asm5" | "asm10" | "asm20" (mm_set_opt, src/options.c:89);
+ * flag: mm_mapopt_t::flag bits to OR in (MM_F_CIGAR 0x4, MM_F_OUT_SAM 0x8, MM_F_OUT_CG 0x20, ...). */
+int wm_mapper_create(wm_ctx_t *ctx, const wm_index_t *idx, const char *preset, int64_t flag, wm_mapper_t **out);
+void wm_mapper_destroy(wm_mapper_t *m);
+/* Map n reads (ASCII). Output records (PAF, or SAM when MM_F_OUT_SAM) of all reads in input order are appended to
+ * an internal buffer returned through *text / *text_len (valid until the next call). hits (optional, 16 int32 per
+ * hit: rid rs re qs qe rev mapq n_cigar score cnt mlen blen dp_score dp_max dp_max2 flags) and their CIGARs are
+ * returned for tests; hit_first[i] = index of read i's first hit, hit_first[n] = total. */
+int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, const char *const *seqs, const int32_t *lens,
+                 const char **text, size_t *text_len, const int32_t **hits, const uint32_t **cigars, const int64_t **hit_first);
+/* counters of the last wm_map_reads call: [0] super-steps, [1] ksw jobs, [2] chain jobs, [3] seed jobs,
+ * [4] sketch jobs, [5] DP cells, [6] ksw kernel us, [7] aux kernel us, [8] read bases */
+int wm_mapper_stats(const wm_mapper_t *m, uint64_t *out9);
+/* SAM header lines (@SQ.., @PG) as mm_write_sam_hdr (src/format.c:118-139) */
+int wm_sam_header(const wm_index_t *idx, int argc, const char *const *argv, const char **text, size_t *text_len);
+
 #ifdef __cplusplus
 }
 #endif

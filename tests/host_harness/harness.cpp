@@ -8,6 +8,7 @@
 #include "../../winnowmap_amd/csrc/host/wm_hit.cpp"
 #include "../../winnowmap_amd/csrc/host/wm_align.cpp"
 #include "../../winnowmap_amd/csrc/host/wm_mapper.cpp"
+#include "../../winnowmap_amd/csrc/host/wm_chain.cpp"
 #include "../../oracle/wm_oracle.h"
 #include <fstream>
 
@@ -129,6 +130,30 @@ void h_radix_sort_128x(uint64_t *x, uint64_t *y, int64_t n)
 	for (int64_t i = 0; i < n; ++i) x[i] = a[i].x, y[i] = a[i].y;
 }
 int h_ll_i16(int qlen, const uint8_t *q, int tlen, const uint8_t *t, const int8_t *mat, int gapo, int gape, int *qe, int *te) { return ll_i16(qlen, q, tlen, t, mat, gapo, gape, qe, te); }
+
+int64_t h_chain_extract(int64_t n, const uint64_t *ax, const uint64_t *ay, const int32_t *f, const int32_t *p, const int32_t *v, int min_cnt, int min_sc,
+                        int *n_u, uint64_t *u_out, uint64_t *bx, uint64_t *by)
+{
+	std::vector<m128> a(n);
+	for (int64_t i = 0; i < n; ++i) a[i].x = ax[i], a[i].y = ay[i];
+	std::vector<uint64_t> u; std::vector<m128> b;
+	chain_extract(n, a.data(), f, p, v, min_cnt, min_sc, u, b);
+	*n_u = (int)u.size();
+	for (size_t i = 0; i < u.size(); ++i) u_out[i] = u[i];
+	for (size_t i = 0; i < b.size(); ++i) bx[i] = b[i].x, by[i] = b[i].y;
+	return (int64_t)b.size();
+}
+float h_avg_qspan(int64_t n, const uint64_t *ay) { std::vector<m128> a(n); for (int64_t i = 0; i < n; ++i) a[i].y = ay[i]; return chain_avg_qspan(n, a.data()); }
+void h_index_view(void *hv, const uint64_t **hkey, const uint64_t **hval, const uint64_t **P, int *hbits, uint64_t *nslots, uint64_t *np)
+{
+	Index &ix = ((Harness*)hv)->idx;
+	*hkey = ix.hkey.data(); *hval = ix.hval.data(); *P = ix.P.data(); *hbits = ix.hbits; *nslots = ix.hkey.size(); *np = ix.P.size();
+}
+void h_bloom_view(void *hv, uint32_t *table_bits, uint32_t *salts, const uint8_t **bits)
+{
+	Index &ix = ((Harness*)hv)->idx;
+	*table_bits = (uint32_t)ix.bloom.table_bits; salts[0] = ix.bloom.salt[0]; salts[1] = ix.bloom.salt[1]; *bits = ix.bloom.bits.data();
+}
 
 // same output layout as refshim_map (oracle/ref_shim.cpp)
 int h_map(void *hv, const char *preset, int64_t flag_extra, const char *seq, int len, const char *name,

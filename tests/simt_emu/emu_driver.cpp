@@ -4,6 +4,8 @@
 #include "simt.h"                    // the emulator (this directory is first on the include path)
 #include "ksw_kernel.h"              // winnowmap_amd/csrc
 #include "ksw_plan.h"
+#include "sketch_kernel.h"
+#include "seedchain_kernel.h"
 #include <vector>
 #include <algorithm>
 
@@ -38,13 +40,18 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 		klass = force_klass;
 	}
 	*klass_out = klass;
-	if (klass >= WM_KSW_GENERIC) return -2;
 	jb.n_col = n_col; jb.tb_off = 0; jb.klass = klass;
 	std::vector<uint8_t> tb((size_t)(qlen + tlen - 1) * n_col + 64, 0xEE);
 	wm_ksw_dres_t res;
 	memset(&res, 0, sizeof(res));
 	const int clip = klass >> 1 & 1, hasn = klass & 1;
-	switch (klass & ~3) {
+	if (klass >= WM_KSW_GENERIC) {
+		const int T = (tlen + 15) / 16 * 16;
+		std::vector<signed char> mem((size_t)7 * T + 64);
+		std::vector<int> Hm(T + 16);
+		simt::exec_mask() = ~0ull;
+		wmk::ksw_dp_generic<true>(sc, jb, seqs.data(), tb.data(), mem.data(), Hm.data(), &res);
+	} else switch (klass & ~3) {
 	case WM_KSW_B4: run_dp<4>(clip, hasn, sc, jb, seqs.data(), tb.data(), &res); break;
 	case WM_KSW_B8: run_dp<8>(clip, hasn, sc, jb, seqs.data(), tb.data(), &res); break;
 	default: run_dp<16>(clip, hasn, sc, jb, seqs.data(), tb.data(), &res); break;
@@ -58,6 +65,56 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 	ez_out[0] = res.max; ez_out[1] = res.zdropped; ez_out[2] = res.max_q; ez_out[3] = res.max_t; ez_out[4] = res.mqe;
 	ez_out[5] = res.mqe_t; ez_out[6] = res.mte; ez_out[7] = res.mte_q; ez_out[8] = res.score; ez_out[9] = res.reach_end;
 	return n;
+}
+
+
+// mm_sketch through the emulated sketch kernel: n sequences (codes) packed in seqs; returns per-sequence counts and minimizers
+int emu_sketch(int n, const uint8_t *seqs, const uint64_t *offs, const int32_t *lens, int w, int k, uint32_t table_bits, uint32_t salt0, uint32_t salt1,
+               const uint8_t *bloom_bits, uint64_t *ox, uint64_t *oy, const uint64_t *out_offs, const int32_t *caps, int32_t *counts)
+{
+	std::vector<wm_sketch_job_t> jobs(n);
+	uint64_t tot = 0;
+	for (int i = 0; i < n; ++i) { jobs[i].seq_off = offs[i]; jobs[i].len = lens[i]; jobs[i].out_off = out_offs[i]; jobs[i].cap = caps[i]; tot = std::max<uint64_t>(tot, out_offs[i] + caps[i]); }
+	std::vector<wm128_t> out(tot + 1);
+	wm_sketch_params_t P = { w, k, table_bits, salt0, salt1 };
+	std::vector<double> ro((size_t)w * 64);
+	std::vector<uint32_t> ry((size_t)w * 64);
+	for (int wv = 0; wv * 64 < n; ++wv) {
+		simt::exec_mask() = ~0ull;
+		wmk::sketch_wave(P, jobs.data(), n, wv, seqs, bloom_bits, ro.data(), ry.data(), out.data(), counts);
+	}
+	for (uint64_t i = 0; i < tot; ++i) ox[i] = out[i].x, oy[i] = out[i].y;
+	return 0;
+}
+
+// seed lookup on a flat index given as arrays
+int emu_seed(const uint64_t *hkey, const uint64_t *hval, const uint64_t *P, int hbits, const uint64_t *mx, const uint64_t *my, int n_mini, int qlen,
+             int max_occ, int flag, uint64_t *ax, uint64_t *ay, int cap, int32_t *res_out)
+{
+	wm_index_view_t ix = { hkey, hval, P, hbits, 0 };
+	std::vector<wm128_t> mini(n_mini + 1), anc(cap + 1);
+	for (int i = 0; i < n_mini; ++i) mini[i].x = mx[i], mini[i].y = my[i];
+	wm_seed_job_t jb = { 0, 0, n_mini, qlen, max_occ, cap, flag, 0 };
+	std::vector<int> occ(n_mini + 1);
+	wm_seed_res_t res = { 0, 0 };
+	simt::exec_mask() = ~0ull;
+	wmk::seed_wave(ix, jb, mini.data(), anc.data(), occ.data(), &res);
+	for (int i = 0; i < res.n_anchors && i < cap; ++i) ax[i] = anc[i].x, ay[i] = anc[i].y;
+	res_out[0] = res.n_anchors; res_out[1] = res.rep_len;
+	return 0;
+}
+
+// chain DP fill: returns f, p, v
+int emu_chain_fill(int64_t n, const uint64_t *ax, const uint64_t *ay, int max_dist_x, int min_dist_x, int max_dist_y, int bw, int max_skip, int max_iter,
+                   float avg_qspan, float gap_scale, int32_t *f, int32_t *p, int32_t *v)
+{
+	std::vector<wm128_t> a(n + 1);
+	for (int64_t i = 0; i < n; ++i) a[i].x = ax[i], a[i].y = ay[i];
+	wm_chain_job_t jb = { 0, (int)n, max_dist_x, min_dist_x, max_dist_y, bw, max_skip, max_iter, avg_qspan, gap_scale, 0 };
+	std::vector<int> t(n + 1);
+	simt::exec_mask() = ~0ull;
+	wmk::chain_wave(jb, a.data(), f, p, v, t.data());
+	return 0;
 }
 
 } // extern "C"

@@ -108,6 +108,7 @@ template <class T> V<T> shr1(const V<T> &x, T fill) { V<T> r; r.v[0] = fill; for
 template <class T> V<T> shr1(const V<T> &x, const V<T> &fill) { V<T> r; r.v[0] = fill.v[0]; for (int i = 1; i < WAVE; ++i) r.v[i] = x.v[i - 1]; return r; }
 template <class T> V<T> shift_down(const V<T> &x, int k, T fill) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = i + k < WAVE ? x.v[i + k] : fill; return r; }
 template <class T> V<T> shift_down(const V<T> &x, int k, const V<T> &fill) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = i + k < WAVE ? x.v[i + k] : fill.v[i]; return r; }
+template <class T> V<T> shr_n(const V<T> &x, int o) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = i >= o ? x.v[i - o] : x.v[i]; return r; }
 template <class T> T readlane(const V<T> &x, int l) { WM_EMU_ASSERT(l >= 0 && l < WAVE); return x.v[l]; }
 inline int readlane(int x, int) { return x; }
 template <class T> T uniform(const V<T> &x) { for (int i = 0; i < WAVE; ++i) if (on(i)) return x.v[i]; return x.v[0]; }
@@ -125,5 +126,14 @@ template <class T> T gld(const T *p, long long idx) { return p[idx]; }
 template <class T, class I> void gst(T *p, const V<I> &idx, const V<T> &v) { for (int i = 0; i < WAVE; ++i) if (on(i)) p[idx.v[i]] = v.v[i]; }
 template <class T, class I> void gst(T *p, const V<I> &idx, T v) { for (int i = 0; i < WAVE; ++i) if (on(i)) p[idx.v[i]] = v; }
 template <class T> void gst(T *p, long long idx, T v) { if (exec_mask()) p[idx] = v; }
+
+inline void mem_sync() {}
+template <class I> V<int> cld8(signed char *p, const V<I> &idx) { V<int> r(0); for (int i = 0; i < WAVE; ++i) if (on(i)) r.v[i] = p[idx.v[i]]; return r; }
+inline int cld8(signed char *p, long long idx) { return p[idx]; }
+template <class I> void cst8(signed char *p, const V<I> &idx, const V<int> &v) { for (int i = 0; i < WAVE; ++i) if (on(i)) p[idx.v[i]] = (signed char)v.v[i]; }
+template <class I> V<int> cld(int *p, const V<I> &idx) { return gld((const int*)p, idx); }
+inline int cld(int *p, long long idx) { return p[idx]; }
+template <class I> void cst(int *p, const V<I> &idx, const V<int> &v) { gst(p, idx, v); }
+inline void cst(int *p, long long idx, int v) { if (exec_mask()) p[idx] = v; }
 
 } // namespace simt

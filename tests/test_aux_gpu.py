@@ -1,0 +1,128 @@
+"""GPU parity of the sketch / seed / chain kernels (through the C-ABI) against the oracle."""
+import ctypes as C
+import tempfile
+import numpy as np
+import pytest
+import wmtest as W
+from winnowmap_amd import gpu, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    tmp = tempfile.mkdtemp()
+    ref = synth.make_reference(2, 300000, 3, repeat_frac=0.15)
+    synth.write_fasta(tmp + "/ref.fa", ref)
+    km, cnt = synth.repetitive_kmers(ref, 15)
+    synth.write_kmer_list(tmp + "/rep.txt", km, cnt, 15)
+    ctx = gpu.Context(0, 4 << 30)
+    idx = gpu.Index(tmp + "/ref.fa", tmp + "/rep.txt", k=15, w=50)
+    idx.upload(ctx)
+    L = gpu.lib()
+    L.wm_sketch_batch.argtypes = [C.c_void_p, C.c_int, W.u8p, C.c_size_t, W.u64p, W.i32p, C.c_void_p, C.c_size_t, W.u64p, W.i32p]
+    L.wm_seed_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, W.u64p, W.i32p, W.i32p, C.c_int, C.c_int64, C.c_void_p, C.c_size_t, W.u64p, W.i32p, W.i32p]
+    L.wm_chain_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, W.u64p, W.i32p, C.c_void_p, W.u64p, W.u64p, W.i32p, W.i32p]
+    L.wm_index_get.restype = C.POINTER(C.c_uint64)
+    L.wm_index_get.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_int)]
+    yield ctx, idx, ref, W.o_bloom(km), L
+    idx.close()
+    ctx.close()
+
+
+def _windows(ref):
+    rng = np.random.default_rng(4)
+    reads, _ = synth.make_reads(ref, 24, 15000, 5)
+    seqs = [r[st:st + 2000].copy() for r in reads for st in range(0, 15000, 2000)]
+    for it in range(40):
+        L, unit = int(rng.integers(100, 3000)), int(rng.integers(1, 13))
+        s = synth.mutate_codes(np.tile(rng.integers(0, 4, unit), L // unit + 1)[:L].astype(np.uint8), rng, 0.01, 0, 0)
+        for _ in range(int(rng.integers(0, 3))):
+            s[int(rng.integers(0, len(s)))] = 4
+        seqs.append(s)
+    return seqs + [reads[0], reads[1], np.array([0, 1, 2], np.uint8)]
+
+
+M128 = np.dtype([("x", np.uint64), ("y", np.uint64)])
+
+
+def test_sketch_seed_chain_kernels(env):
+    ctx, idx, ref, bloom, L = env
+    seqs = _windows(ref)
+    n = len(seqs)
+    lens = np.array([len(s) for s in seqs], np.int32)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    allseq = np.concatenate(seqs)
+    out = np.zeros(int(lens.sum()) + n, M128)
+    ooff = np.zeros(n, np.uint64)
+    cnt = np.zeros(n, np.int32)
+    assert L.wm_sketch_batch(ctx._h, n, allseq, allseq.nbytes, offs, lens, out.ctypes.data, len(out), ooff, cnt) == 0, L.wm_last_error()
+    minis = []
+    for i, s in enumerate(seqs):
+        ex, ey = W.o_sketch(bytes(s), 50, 15, rid=0, bloom=bloom)
+        g = out[int(ooff[i]):int(ooff[i]) + cnt[i]]
+        assert cnt[i] == len(ex) and np.array_equal(g["x"], ex) and np.array_equal(g["y"], ey), i
+        minis.append(g.copy())
+    # seed: compare with a restatement of collect_seed_hits over the product index + the oracle's sort
+    nm = np.array([len(m) for m in minis], np.int32)
+    moff = np.concatenate([[0], np.cumsum(nm)[:-1]]).astype(np.uint64)
+    allm = np.concatenate(minis)
+    cap = int(nm.sum()) * 64 + 1024
+    aout = np.zeros(cap, M128)
+    aoff = np.zeros(n, np.uint64)
+    na = np.zeros(n, np.int32)
+    rl = np.zeros(n, np.int32)
+    assert L.wm_seed_batch(ctx._h, n, allm.ctypes.data, moff, nm, lens, 5000, 0, aout.ctypes.data, cap, aoff, na, rl) == 0, L.wm_last_error()
+    anchors = []
+    for i, (s, m) in enumerate(zip(seqs, minis)):
+        ex, ey, rep_st, rep_en, rep = [], [], 0, 0, 0
+        for j in range(len(m)):
+            x, y = int(m["x"][j]), int(m["y"][j])
+            t = C.c_int()
+            p = L.wm_index_get(idx._h, x >> 8, C.byref(t))
+            qpos, span = y & 0xffffffff, x & 0xff
+            if t.value >= 5000:
+                en = (qpos >> 1) + 1
+                st = en - span
+                if st > rep_en:
+                    rep += rep_en - rep_st
+                    rep_st, rep_en = st, en
+                else:
+                    rep_en = en
+                continue
+            tand = (j > 0 and int(m["x"][j - 1]) >> 8 == x >> 8) or (j < len(m) - 1 and int(m["x"][j + 1]) >> 8 == x >> 8)
+            for q in range(t.value):
+                r = int(p[q])
+                rpos = (r & 0xffffffff) >> 1
+                if (r & 1) == (qpos & 1):
+                    X, Y = (r & 0xffffffff00000000) | rpos, span << 32 | qpos >> 1
+                else:
+                    X, Y = 1 << 63 | (r & 0xffffffff00000000) | rpos, span << 32 | (len(s) - ((qpos >> 1) + 1 - span) - 1)
+                if tand:
+                    Y |= 1 << 42
+                ex.append(X)
+                ey.append(Y)
+        rep += rep_en - rep_st
+        sx, sy = W.o_radix_sort_128x(np.array(ex, np.uint64), np.array(ey, np.uint64))
+        g = aout[int(aoff[i]):int(aoff[i]) + na[i]]
+        assert na[i] == len(sx) and np.array_equal(g["x"], sx) and np.array_equal(g["y"], sy) and rl[i] == rep, i
+        anchors.append(g.copy())
+    # chain: stage-1 and stage-2 parameter sets
+    PAR = np.dtype([("p", np.int32, 8), ("gs", np.float32)])
+    for prm in ((5000, 1000, 5000, 500), (16000, 1000, 16000, 2000)):
+        nz = [a for a in anchors if len(a) > 0]
+        na2 = np.array([len(a) for a in nz], np.int32)
+        aoff2 = np.concatenate([[0], np.cumsum(na2)[:-1]]).astype(np.uint64)
+        alla = np.concatenate(nz)
+        par = np.zeros(len(nz), PAR)
+        par["p"] = [prm[0], prm[1], prm[2], prm[3], 25, 5000, 3, 40]
+        par["gs"] = 1.0
+        u = np.zeros(len(alla) + 1, np.uint64)
+        uoff = np.zeros(len(nz), np.uint64)
+        nu = np.zeros(len(nz), np.int32)
+        nv = np.zeros(len(nz), np.int32)
+        assert L.wm_chain_batch(ctx._h, len(nz), alla.ctypes.data, aoff2, na2, par.ctypes.data, u, uoff, nu, nv) == 0, L.wm_last_error()
+        for i, a in enumerate(nz):
+            ou, obx, oby = W.o_chain_dp(a["x"], a["y"], max_dist_x=prm[0], min_dist_x=prm[1], max_dist_y=prm[2], bw=prm[3])
+            g = alla[int(aoff2[i]):int(aoff2[i]) + nv[i]]
+            assert np.array_equal(u[int(uoff[i]):int(uoff[i]) + nu[i]], ou) and np.array_equal(g["x"], obx) and np.array_equal(g["y"], oby), (i, prm)

@@ -18,11 +18,11 @@ def _newer(target, sources):
 
 
 def build_gpu(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "wm_gpu.h")]
+    srcs = [os.path.join(d, f) for d, _, fs in os.walk(CSRC) for f in fs] + [os.path.join(ROOT, "include", "wm_gpu.h")]
     if not force and not _newer(LIB, srcs):
         return LIB
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
-           "-Wno-unused-value", "-o", LIB, os.path.join(CSRC, "wm_gpu.hip")]
+           "-Wno-unused-value", "-o", LIB, os.path.join(CSRC, "wm_gpu.hip"), "-lz", "-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
@@ -46,7 +46,20 @@ def build_emu():
     return out
 
 
+def build_harness():
+    """tests/host_harness/libwm_harness.so: the product HOST mapper driven by oracle-backed device ops (tests only)."""
+    hd = os.path.join(ROOT, "tests", "host_harness")
+    out = os.path.join(hd, "libwm_harness.so")
+    srcs = [os.path.join(hd, "harness.cpp"), os.path.join(ROOT, "oracle", "wm_oracle.c")] + \
+           [os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host"))]
+    if _newer(out, srcs):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-o", out,
+                               os.path.join(hd, "harness.cpp"), os.path.join(ROOT, "oracle", "wm_oracle.c"), "-lz"])
+    return out
+
+
 if __name__ == "__main__":
     build_gpu(force="--force" in sys.argv, verbose=True)
     build_oracle()
     build_emu()
+    build_harness()

@@ -311,6 +311,189 @@ WM_DEV void ksw_dp_wave(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const u
 	WM_END
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Generic kernel for band hulls wider than the register window (> 1008 lanes; long gaps of stage 2, LONG_JOIN
+// segments of asm20): same machine, but the per-lane state lives in memory as int8 arrays indexed by the target
+// lane — `mem` points to 7*T bytes (u v x y x2 y2 s), `Hm` to T ints (exact mode only) — either LDS (T*7 fits) or a
+// global scratch slab. One wave sweeps the hull 64 lanes at a time; lane t only ever writes its own entries and gets
+// lane t-1's previous-row values from the neighbouring thread's registers, so there is no intra-row hazard. COH =
+// the arrays are in global memory and must bypass the per-CU L1 (another lane wrote them in the previous row).
+// ------------------------------------------------------------------------------------------------------
+template <bool COH> WM_DEV V<int> ld8(signed char *p, V<int> i) { return COH ? cld8(p, i) : cast<int>(gld(p, i)); }
+template <bool COH> WM_DEV void st8(signed char *p, V<int> i, V<int> v) { if (COH) cst8(p, i, v); else gst(p, i, cast<signed char>(v)); }
+template <bool COH> WM_DEV int ld8s(signed char *p, int i) { return COH ? cld8(p, (long long)i) : (int)gld(p, (long long)i); }
+template <bool COH> WM_DEV V<int> ld32(int *p, V<int> i) { return COH ? cld(p, i) : gld(p, i); }
+template <bool COH> WM_DEV void st32(int *p, V<int> i, V<int> v) { if (COH) cst(p, i, v); else gst(p, i, v); }
+template <bool COH> WM_DEV int ld32s(int *p, int i) { return COH ? cld(p, (long long)i) : gld(p, (long long)i); }
+
+template <bool COH>
+WM_DEV void ksw_dp_generic(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const uint8_t *__restrict__ seqs,
+                           uint8_t *__restrict__ tb_arena, signed char *mem, int *Hm, wm_ksw_dres_t *__restrict__ res)
+{
+	const int qlen = jb.qlen, tlen = jb.tlen, flag = jb.flag, zdrop = jb.zdrop;
+	const int w = jb.w < 0 ? (tlen > qlen ? tlen : qlen) : jb.w;
+	const bool approx = (flag & KSW_F_APPROX_MAX) != 0, right = (flag & KSW_F_RIGHT) != 0;
+	const uint8_t *query = seqs + jb.q_off, *target = seqs + jb.t_off;
+	uint8_t *tbp = tb_arena + jb.tb_off;
+	const int T = (tlen + 15) / 16 * 16;
+	signed char *u = mem, *v = u + T, *x = v + T, *y = x + T, *x2 = y + T, *y2 = x2 + T, *s = y2 + T;
+	const int q = sc.q, e = sc.e, q2 = sc.q2, e2 = sc.e2, qe = q + e, qe2 = q2 + e2;
+	const int Q = tb8(q), Q2 = tb8(q2), QE = tb8(qe), QE2 = tb8(qe2);
+	const int tS = right ? 0 : 4, tA = right ? 1 : 3, tB = 2, tA2 = right ? 3 : 1, tB2 = right ? 4 : 0;
+	const int hA = right ? tA - 1 : tA, hB = right ? tB - 1 : tB, hA2 = right ? tA2 - 1 : tA2, hB2 = right ? tB2 - 1 : tB2;
+	const int MCH = tb8(sc.match);
+	const int sc_n = sc.sc_ambi == 0 ? -e2 : sc.sc_ambi;
+	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+	const V<int> ln = lane();
+	// initial fill (src/ksw2_extd2_sse.c:99-112): the raw x/y bytes hold x+qe (resp. +qe2), so "-qe" is 0
+	for (int t0 = 0; t0 < T; t0 += 64) {
+		const V<int> t = ln + t0;
+		WM_IF(t < T)
+			st8<COH>(u, t, V<int>(-qe)); st8<COH>(v, t, V<int>(-qe)); st8<COH>(x, t, V<int>(0)); st8<COH>(y, t, V<int>(0));
+			st8<COH>(x2, t, V<int>(0)); st8<COH>(y2, t, V<int>(0)); st8<COH>(s, t, V<int>(0));
+			if (!approx) st32<COH>(Hm, t, V<int>(KSW_NEG_INF));
+		WM_END
+	}
+	mem_sync();
+	int ez_max = 0, ez_zdropped = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1;
+	int ez_mte = KSW_NEG_INF, ez_mte_q = -1, ez_score = KSW_NEG_INF;
+	int H0 = 0, last_H0_t = 0, last_st = -1, last_en = -1;
+	const int n_rows = qlen + tlen - 1;
+	for (int r = 0; r < n_rows; ++r) {
+		int st0 = 0, en0 = tlen - 1;
+		if (st0 < r - qlen + 1) st0 = r - qlen + 1;
+		if (en0 > r) en0 = r;
+		if (st0 < (r - w + 1) >> 1) st0 = (r - w + 1) >> 1;
+		if (en0 > (r + w) >> 1) en0 = (r + w) >> 1;
+		if (st0 > en0) { ez_zdropped = 1; break; }
+		const int st = st0 / 16 * 16, en = (en0 + 16) / 16 * 16 - 1;
+		const int sched = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
+		int x1b = 0, x21b = 0, v1b;                                         // raw bytes of lane st-1 (:141-151)
+		if (st > 0) {
+			if (st - 1 >= last_st && st - 1 <= last_en) { x1b = ld8s<COH>(x, st - 1); x21b = ld8s<COH>(x2, st - 1); v1b = ld8s<COH>(v, st - 1); }
+			else v1b = -qe;
+		} else v1b = sched;
+		if (en >= r) {                                                       // :152-155
+			WM_IF(ln == 0) st8<COH>(y, V<int>(r), V<int>(0)); st8<COH>(y2, V<int>(r), V<int>(0)); st8<COH>(u, V<int>(r), V<int>(sched)); WM_END
+		}
+		{   // score row: 16-byte chunks starting at st0 (:158-173); lanes >= T would spill into the next array and are never read
+			const int cend = st0 + (en0 - st0) / 16 * 16 + 15;
+			for (int t0 = st0; t0 <= cend; t0 += 64) {
+				const V<int> t = ln + t0;
+				WM_IF(t <= cend && t < T)
+					V<int> tc = 0, qc = 0;
+					WM_IF(t < tlen) tc = cast<int>(gld(target, t)); WM_END
+					const V<int> qi = V<int>(r) - t;
+					WM_IF(qi >= 0 && qi < qlen) qc = cast<int>(gld(query, qi)); WM_END
+					V<int> sv = sel(tc == qc, (int)sc.match, (int)sc.mismatch);
+					sv = sel((tc == 4) || (qc == 4), sc_n, sv);
+					st8<COH>(s, t, sv);
+				WM_END
+			}
+		}
+		mem_sync();
+		// sweep the hull; carry = previous-row values of the lane just below the current tile
+		V<int> cx = tb8(x1b) | tA, cv = tb8(v1b), cx2 = tb8(x21b) | tA2;
+		V<int> hcarry = KSW_NEG_INF;
+		if (!approx && st > 0) hcarry = ld32s<COH>(Hm, st - 1);
+		V<long long> key = (long long)(-0x7fffffffffffffffLL - 1);
+		const int en1 = st0 + (en0 - st0) / 4 * 4;
+		for (int t0 = st; t0 <= en; t0 += 64) {
+			const V<int> t = ln + t0;
+			const vbool act = t <= en;
+			V<int> ox = tA, ov = 0, ox2 = tA2, ou = 0, oy = tB, oy2 = tB2, os = tS, oh = KSW_NEG_INF;
+			WM_IF(act)
+				ou = ld8<COH>(u, t) << 24; ov = ld8<COH>(v, t) << 24;
+				ox = (ld8<COH>(x, t) << 24) | tA; oy = (ld8<COH>(y, t) << 24) | tB;
+				ox2 = (ld8<COH>(x2, t) << 24) | tA2; oy2 = (ld8<COH>(y2, t) << 24) | tB2;
+				os = (ld8<COH>(s, t) << 24) | tS;
+				if (!approx) oh = ld32<COH>(Hm, t);
+			WM_END
+			// lane-1 values of the previous row: neighbour thread, or the carry for lane 0
+			const V<int> x1 = sel(ln == 0, cx, shr_n(ox, 1)), v1 = sel(ln == 0, cv, shr_n(ov, 1)), x21 = sel(ln == 0, cx2, shr_n(ox2, 1));
+			const V<int> hl = sel(ln == 0, hcarry, shr_n(oh, 1));
+			cx = V<int>(readlane(ox, 63)); cv = V<int>(readlane(ov, 63)); cx2 = V<int>(readlane(ox2, 63)); hcarry = V<int>(readlane(oh, 63));
+			WM_IF(act)
+				V<int> a = add3(x1, v1, -QE), b = add3(oy, ou, -QE), a2 = add3(x21, v1, -QE2), b2 = add3(oy2, ou, -QE2);
+				V<int> zz = vmax3(vmax3(os, a, b), a2, b2);
+				V<int> z = vmin(zz & (int)0xff000000, MCH);
+				V<int> p = zz & 7;
+				const V<int> nu = wsub(z, v1), nv = wsub(z, ou);
+				V<int> tmp = wsub(z, Q), tmp2 = wsub(z, Q2);
+				a = wsub(a, tmp); b = wsub(b, tmp); a2 = wsub(a2, tmp2); b2 = wsub(b2, tmp2);
+				p = wadd(wadd(p, p), sel(a > hA, 1, 0));
+				p = wadd(wadd(p, p), sel(b > hB, 1, 0));
+				p = wadd(wadd(p, p), sel(a2 > hA2, 1, 0));
+				p = wadd(wadd(p, p), sel(b2 > hB2, 1, 0));
+				st8<COH>(u, t, nu >> 24); st8<COH>(v, t, nv >> 24);
+				st8<COH>(x, t, vmax(a, tA) >> 24); st8<COH>(y, t, vmax(b, tB) >> 24);
+				st8<COH>(x2, t, vmax(a2, tA2) >> 24); st8<COH>(y2, t, vmax(b2, tB2) >> 24);
+				gst(tbp + (size_t)r * jb.n_col, t - st, cast<uint8_t>(p));
+				if (!approx && r > 0) {
+					const V<int> v8 = nv >> 24, u8 = nu >> 24;
+					V<int> hn = oh + v8;
+					hn = sel(t == en0, en0 > 0 ? V<int>(hl + u8) : hn, hn);
+					const vbool inb = t >= st0 && t <= en0;
+					WM_IF(inb) st32<COH>(Hm, t, hn); WM_END
+					V<int> grp = sel(t == en0, 5, sel(t < en1, 4 - ((t - st0) & 3), 0));
+					V<int> pri = (grp << 20) | (0xfffff - t);
+					V<long long> k = cast<long long>(hn) * 4294967296LL + cast<long long>(pri);
+					key = sel(inb && k > key, k, key);
+				}
+				if (!approx && r == 0) {
+					WM_IF(t == 0)
+						const V<int> h0 = (nv >> 24) - qe;
+						st32<COH>(Hm, t, h0);
+						key = cast<long long>(h0) * 4294967296LL + (long long)((5 << 20) | 0xfffff);
+					WM_END
+				}
+			WM_END
+		}
+		mem_sync();
+		if (!approx) {
+			key = wave_max_i64(key);
+			const long long kk = uniform(key);
+			const int max_H = (int)(kk >> 32), pri = (int)(kk & 0xffffffffLL);
+			const int max_t = 0xfffff - (pri & 0xfffff);
+			if (en0 == tlen - 1) { const int h = ld32s<COH>(Hm, en0); if (h > ez_mte) ez_mte = h, ez_mte_q = r - en; }
+			if (r - st0 == qlen - 1) { const int h = ld32s<COH>(Hm, st0); if (h > ez_mqe) ez_mqe = h, ez_mqe_t = st0; }
+			if (max_H > ez_max) {
+				ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
+			} else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
+				const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+				if (zdrop >= 0 && ez_max - max_H > zdrop + l * e2) { ez_zdropped = 1; break; }
+			}
+			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = ld32s<COH>(Hm, tlen - 1);
+		} else {
+			if (r > 0) {
+				const bool in0 = last_H0_t >= st0 && last_H0_t <= en0, in1 = last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0;
+				if (in0 && in1) {
+					const int d0 = ld8s<COH>(v, last_H0_t), d1 = ld8s<COH>(u, last_H0_t + 1);
+					if (d0 > d1) H0 += d0;
+					else H0 += d1, ++last_H0_t;
+				} else if (in0) H0 += ld8s<COH>(v, last_H0_t);
+				else { ++last_H0_t; H0 += ld8s<COH>(u, last_H0_t); }
+			} else H0 = ld8s<COH>(v, 0) - qe, last_H0_t = 0;
+			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = H0;
+		}
+		last_st = st, last_en = en;
+	}
+	int bt_i = -1, bt_j = -1, reach_end = 0;
+	if (!ez_zdropped && !(flag & KSW_F_EXTZ_ONLY)) bt_i = tlen - 1, bt_j = qlen - 1;
+	else if (!ez_zdropped && (flag & KSW_F_EXTZ_ONLY) && ez_mqe + jb.end_bonus > ez_max) reach_end = 1, bt_i = ez_mqe_t, bt_j = qlen - 1;
+	else if (ez_max_t >= 0 && ez_max_q >= 0) bt_i = ez_max_t, bt_j = ez_max_q;
+	WM_IF(ln == 0)
+		wm_ksw_dres_t o;
+		o.max = ez_max; o.zdropped = ez_zdropped; o.max_q = ez_max_q; o.max_t = ez_max_t;
+		o.mqe = ez_mqe; o.mqe_t = ez_mqe_t; o.mte = ez_mte; o.mte_q = ez_mte_q;
+		o.score = ez_score; o.reach_end = reach_end; o.n_cigar = 0; o.bt_i = bt_i; o.bt_j = bt_j;
+		*res = o;
+	WM_END
+}
+
 // ------------------------------------------------------------------------------------------------------
 // ksw_backtrack (src/ksw2.h:119-151, is_rot = 1, min_intron_len = 0): ONE thread walks the traceback of one
 // alignment and emits run-length CIGAR ops in backtrack order into cig[0..cap); the gather step reverses

@@ -1,0 +1,210 @@
+// seedchain_kernel.h — seed lookup/expansion and the chaining DP fill on gfx950 (one wavefront per window).
+//
+//  seed_wave   : for every query minimizer, probe the flat index in HBM (open addressing, one 16-B slot + the
+//                position run), drop over-represented minimizers (occ >= mid_occ, accumulating rep_len exactly as
+//                collect_matches does), mark tandem seeds, and expand to anchors in minimizer order with a wave
+//                prefix sum. The unstable radix_sort_128x that follows in the reference is applied by the caller
+//                (its tie permutation is inherently sequential).
+//  chain_wave  : mm_chain_dp's score fill. Anchor i is processed sequentially (f[i] depends on earlier f), but its
+//                predecessor scan j = i-1 … st runs 64 at a time: every lane scores one j (integer + the reference's
+//                fp64 gap cost), the "t[] marks" are scattered and re-read (marks only flow from larger to smaller
+//                j, so scatter-then-read inside a tile is exact), and the sequential max_f / n_skip / break
+//                automaton (src/chain.c:79-86) is replayed over two 64-bit ballots with a prefix max.
+//                f, p, v are returned; chain extraction (:93-165) is O(n) bookkeeping done by the caller.
+#pragma once
+#ifndef WM_DEV
+#error "include simt.h before seedchain_kernel.h"
+#endif
+#include "wm_internal.h"
+
+namespace wmk {
+using namespace simt;
+
+WM_DEV void seed_wave(const wm_index_view_t ix, const wm_seed_job_t jb, const wm128_t *mini_pool, wm128_t *anchor_pool,
+                      int *occ_scratch /* n_mini ints */, wm_seed_res_t *res)
+{
+	const V<int> ln = lane();
+	const uint64_t *mini = (const uint64_t*)(mini_pool + jb.mini_off);
+	uint64_t *outp = (uint64_t*)(anchor_pool + jb.out_off);
+	const uint64_t hmask = ((uint64_t)1 << ix.hbits) - 1;
+	const bool strand_filter = (jb.flag & (0x100000 | 0x200000)) != 0;
+	int base = 0;                                        // anchors written so far
+	for (int m0 = 0; m0 < jb.n_mini; m0 += 64) {
+		const V<int> m = ln + m0;
+		const vbool have = m < jb.n_mini;
+		V<uint64_t> mx = (uint64_t)0, my = (uint64_t)0, first = (uint64_t)0;
+		V<int> cnt = 0;
+		WM_IF(have)
+			mx = gld(mini, m * 2); my = gld(mini, m * 2 + 1);
+			const V<uint64_t> key = mx >> 8;
+			V<uint64_t> s = (key * (uint64_t)0x9E3779B97F4A7C15ULL) >> (64 - ix.hbits);
+			vbool probing = s == s;                      // true
+			for (int guard = 0; guard < (1 << 20) && any(probing); ++guard) {
+				WM_IF(probing)
+					V<uint64_t> hk = gld(ix.hkey, s);
+					WM_IF(hk == key)
+						V<uint64_t> hv = gld(ix.hval, s);
+						cnt = cast<int>(hv & (uint64_t)0xffffffffu); first = hv >> 32;
+					WM_END
+					probing = (hk != key) && (hk != ~(uint64_t)0);
+					s = (s + (uint64_t)1) & hmask;
+				WM_END
+			}
+			cst(occ_scratch, m, cnt);
+		WM_END
+		// occurrence filter + (optional) strand filter decide how many anchors each minimizer contributes
+		V<int> emit = sel(have && cnt < jb.max_occ, cnt, 0);
+		WM_IF(strand_filter && emit > 0)
+			V<int> kept = 0;
+			const V<int> qstrand = cast<int>(my & (uint64_t)1);
+			for (int h = 0; h < jb.max_occ && any(emit > h); ++h)
+				WM_IF(emit > h)
+					const V<int> rstrand = cast<int>(gld(ix.P, first + (uint64_t)h) & (uint64_t)1);
+					const vbool fwd = rstrand == qstrand;
+					kept = kept + sel((fwd && !(jb.flag & 0x200000)) || (!fwd && !(jb.flag & 0x100000)), 1, 0);
+				WM_END
+			emit = kept;
+		WM_END
+		// exclusive prefix sum across the tile
+		V<int> incl = emit;
+		for (int o = 1; o < 64; o <<= 1) incl = incl + sel(ln >= o, shr_n(incl, o), 0);
+		const V<int> excl = incl - emit;
+		const int tile_total = readlane(incl, 63);
+		WM_IF(emit > 0)
+			const V<uint32_t> q_pos = cast<uint32_t>(my), q_span = cast<uint32_t>(mx & (uint64_t)0xff);
+			// tandem: the neighbouring minimizer (in the whole list) has the same key (src/map.c:121-122)
+			vbool tandem = q_pos != q_pos;               // false
+			WM_IF(m > 0) tandem = tandem || ((gld(mini, (m - 1) * 2) >> 8) == (mx >> 8)); WM_END
+			WM_IF(m < jb.n_mini - 1) tandem = tandem || ((gld(mini, (m + 1) * 2) >> 8) == (mx >> 8)); WM_END
+			V<int> w = base + excl;
+			for (int h = 0; h < jb.max_occ && any(cnt > h); ++h)
+				WM_IF(cnt > h)
+					const V<uint64_t> r = gld(ix.P, first + (uint64_t)h);
+					const V<uint64_t> rpos = (r & (uint64_t)0xffffffffu) >> 1;
+					const vbool fwd = cast<uint32_t>(r & (uint64_t)1) == (q_pos & 1u);
+					vbool keep = rpos == rpos;
+					if (strand_filter) keep = (fwd && !(jb.flag & 0x200000)) || (!fwd && !(jb.flag & 0x100000));
+					WM_IF(keep)
+						V<uint64_t> ax = (r & (uint64_t)0xffffffff00000000ULL) | rpos;
+						V<uint64_t> ay = cast<uint64_t>(q_span) << 32;
+						WM_IF(fwd) ay = ay | cast<uint64_t>(q_pos >> 1); WM_ELSE
+							ax = ax | ((uint64_t)1 << 63);
+							ay = ay | cast<uint64_t>(cast<uint32_t>(V<int>(jb.qlen) - cast<int>((q_pos >> 1) + 1u - q_span) - 1));
+						WM_END
+						ay = sel(tandem, ay | ((uint64_t)1 << 42), ay);
+						WM_IF(w < jb.cap) gst(outp, w * 2, ax); gst(outp, w * 2 + 1, ay); WM_END
+						w = w + 1;
+					WM_END
+				WM_END
+		WM_END
+		base += tile_total;
+	}
+	// rep_len: sequential over the minimizers (src/map.c:111-116,126); uniform code, one result
+	int rep_st = 0, rep_en = 0, rep_len = 0;
+	for (int m = 0; m < jb.n_mini; ++m) {
+		const int t = cld(occ_scratch, (long long)m);
+		if (t >= jb.max_occ) {
+			const uint64_t mx = gld(mini, (long long)m * 2), my = gld(mini, (long long)m * 2 + 1);
+			const int en = (int)((uint32_t)my >> 1) + 1, st = en - (int)(mx & 0xff);
+			if (st > rep_en) { rep_len += rep_en - rep_st; rep_st = st; rep_en = en; }
+			else rep_en = en;
+		}
+	}
+	rep_len += rep_en - rep_st;
+	WM_IF(ln == 0)
+		gst(&res->n_anchors, 0LL, base);
+		gst(&res->rep_len, 0LL, rep_len);
+	WM_END
+}
+
+// 31 - clz for v > 0 (ilog2_32, src/chain.c:15-20)
+WM_DEV V<int> ilog2_pos(V<int> v)
+{
+	V<int> r = 0;
+	r = sel(v >= (1 << 16), r + 16, r); v = sel(v >= (1 << 16), v >> 16, v);
+	r = sel(v >= (1 << 8), r + 8, r);   v = sel(v >= (1 << 8), v >> 8, v);
+	r = sel(v >= (1 << 4), r + 4, r);   v = sel(v >= (1 << 4), v >> 4, v);
+	r = sel(v >= (1 << 2), r + 2, r);   v = sel(v >= (1 << 2), v >> 2, v);
+	r = sel(v >= 2, r + 1, r);
+	return r;
+}
+
+// f, p, v, t: n ints each (global scratch or LDS). a: anchors sorted by x.
+WM_DEV void chain_wave(const wm_chain_job_t jb, const wm128_t *anchor_pool, int *f, int *p, int *v, int *t)
+{
+	const V<int> ln = lane();
+	const uint64_t *a = (const uint64_t*)(anchor_pool + jb.a_off);
+	const int n = jb.n;
+	for (int i0 = 0; i0 < n; i0 += 64) WM_IF(ln + i0 < n) cst(t, ln + i0, V<int>(0)); WM_END
+	long long st = 0;
+	for (int i = 0; i < n; ++i) {
+		const uint64_t ri = gld(a, (long long)i * 2), yi = gld(a, (long long)i * 2 + 1);
+		const int qi = (int)(uint32_t)yi, span = (int)(yi >> 32 & 0xff);
+		int max_f = span, n_skip = 0;
+		long long max_j = -1;
+		while (st < i && ri > gld(a, st * 2) + (uint64_t)jb.max_dist_x) ++st;                       // :50
+		if (i - st > jb.max_iter)                                                                  // :51-55
+			while (i - st > jb.max_iter && ri > gld(a, st * 2) + (uint64_t)jb.min_dist_x) ++st;
+		bool stop = false;
+		for (long long hi = (long long)i - 1; hi >= st && !stop; hi -= 64) {
+			const V<long long> j = V<long long>(hi) - cast<long long>(ln);                          // lane 0 = first visited
+			const vbool in = j >= st;
+			V<int> sc = 0, pj = -1;
+			vbool valid = in && !in;                                                               // false
+			WM_IF(in)
+				const V<uint64_t> xj = gld(a, j * 2LL), yj = gld(a, j * 2LL + 1LL);
+				const V<long long> dr = cast<long long>(V<uint64_t>(ri) - xj);
+				const V<int> dq = V<int>(qi) - cast<int>(cast<uint32_t>(yj));
+				valid = !(dr == 0LL || dq <= 0) && !(dq > jb.max_dist_y || dq > jb.max_dist_x);    // :60-61
+				const V<long long> dql = cast<long long>(dq);
+				const V<int> dd = cast<int>(sel(dr > dql, dr - dql, dql - dr));
+				valid = valid && !(dd > jb.bw);                                                    // :63
+				const V<int> drc = cast<int>(sel(dr > (long long)0x7fffffff, V<long long>(0x7fffffff), dr));
+				const V<int> md = vmin(dq, drc);
+				V<int> s0 = vmin(md, V<int>(span));                                                // :65-66
+				const V<int> lg = sel(dd > 0, ilog2_pos(dd), 0);
+				const V<double> lin = cast<double>(dd) * .01 * (double)jb.avg_qspan;
+				const V<int> gc = cast<int>(lin) + (lg >> 1);                                      // :76
+				s0 = s0 - cast<int>(cast<double>(gc) * (double)jb.gap_scale + .499);               // :77
+				sc = s0 + cld(f, j);
+				pj = cld(p, j);
+			WM_END
+			// marks: every scored predecessor marks ITS predecessor (src/chain.c:86); scatter, then read own mark
+			WM_IF(valid && pj >= 0) cst(t, pj, V<int>(i)); WM_END
+			V<int> tj = 0;
+			WM_IF(valid) tj = cld(t, j); WM_END
+			// running maximum before each lane (strict improvement test of :79)
+			V<int> key = sel(valid, sc, V<int>(-0x7fffffff - 1));
+			V<int> pm = key;
+			for (int o = 1; o < 64; o <<= 1) pm = vmax(pm, sel(ln >= o, shr_n(pm, o), V<int>(-0x7fffffff - 1)));
+			const V<int> before = vmax(sel(ln >= 1, shr_n(pm, 1), V<int>(-0x7fffffff - 1)), V<int>(max_f));
+			const vbool improve = valid && sc > before;
+			const vbool marked = valid && !improve && tj == i;
+			uint64_t I = ballot(improve), M = ballot(marked);
+			// replay n_skip over the events in visiting order
+			int brk = 64;
+			uint64_t ev = I | M;
+			while (ev) {
+				const int l = __builtin_ctzll(ev);
+				ev &= ev - 1;
+				if (I >> l & 1) { if (n_skip > 0) --n_skip; }
+				else if (++n_skip > jb.max_skip) { brk = l; break; }
+			}
+			uint64_t Ib = brk < 64 ? I & (((uint64_t)1 << brk) - 1) : I;
+			if (Ib) {
+				const int l = 63 - __builtin_clzll(Ib);
+				max_f = readlane(sc, l);
+				max_j = hi - l;
+			}
+			if (brk < 64) stop = true;
+		}
+		WM_IF(ln == 0)
+			cst(f, (long long)i, max_f); cst(p, (long long)i, (int)max_j);
+			int vi = max_f;
+			if (max_j >= 0) { const int vm = cld(v, max_j); if (vm > max_f) vi = vm; }
+			cst(v, (long long)i, vi);
+		WM_END
+	}
+}
+
+} // namespace wmk

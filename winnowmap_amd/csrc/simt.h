@@ -42,6 +42,8 @@ WM_DEV int shift_down(int x, int k, int fill)
 	int y = __shfl_down(x, (unsigned)k, 64);
 	return lane() + k >= 64 ? fill : y;
 }
+// value of lane-o for a uniform o (lanes < o receive their own value; callers mask them)
+WM_DEV int shr_n(int x, int o) { return __shfl_up(x, (unsigned)o, 64); }
 WM_DEV int readlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
 WM_DEV int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 WM_DEV long long uniform(long long x)
@@ -72,5 +74,13 @@ WM_DEV int wave_sum_i32(int k)
 // memory (global or LDS pointers alike)
 template <class T> WM_DEV T gld(const T *p, long long i) { return p[i]; }
 template <class T> WM_DEV void gst(T *p, long long i, T v) { p[i] = v; }
+
+// "coherent" scratch accessors: data written by one lane and read by another lane of the SAME wave through global
+// memory must not be served from a stale L1 line, so these go to L2 (relaxed agent-scope atomics = sc1 accesses).
+WM_DEV void mem_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+WM_DEV int cld8(signed char *p, long long i) { return (int)__hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+WM_DEV void cst8(signed char *p, long long i, int v) { __hip_atomic_store(p + i, (signed char)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+WM_DEV int cld(int *p, long long i) { return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+WM_DEV void cst(int *p, long long i, int v) { __hip_atomic_store(p + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 } // namespace simt

@@ -1,0 +1,163 @@
+// sketch_kernel.h — weighted robust-winnowing minimizers (mm_sketch, src/sketch.c:128-219, non-HPC) on gfx950.
+//
+// Mapping: ONE LANE per (sub)sequence — stage 1 of Winnowmap2 sketches ~9 windows per read, so a mini-batch holds
+// 10^4..10^6 independent sequences and the machine fills with thread-level parallelism; the winnowing automaton
+// itself is inherently sequential (the choice among equal-order k-mers depends on history) and is
+// reproduced step by step. Per lane and window slot the ring keeps the fp64 order and (pos<<1|strand); the 2k-bit
+// key of an emitted minimizer is rebuilt from the k bases ending at its position, so the ring needs 12 B/slot/lane
+// (w=50: 38 KB of LDS per wave, slot-major so that lanes hit distinct banks).
+//
+// fp64 order: x = (double)fmix64(kmer) * 2^-64, -x or -(x^8 by three squarings) when the bloom filter holds the
+// k-mer (src/sketch.c:70-89). Compiled with -ffp-contract=off; there is no add, so nothing can fuse anyway.
+#pragma once
+#ifndef WM_DEV
+#error "include simt.h before sketch_kernel.h"
+#endif
+#include "wm_internal.h"
+
+namespace wmk {
+using namespace simt;
+
+WM_DEV V<uint64_t> sk_hash64(V<uint64_t> key, uint64_t mask)
+{   // src/sketch.c:53-63
+	key = (~key + (key << 21)) & mask;
+	key = key ^ (key >> 24);
+	key = (key + (key << 3) + (key << 8)) & mask;
+	key = key ^ (key >> 14);
+	key = (key + (key << 2) + (key << 4)) & mask;
+	key = key ^ (key >> 28);
+	key = (key + (key << 31)) & mask;
+	return key;
+}
+WM_DEV V<uint64_t> sk_fmix64(V<uint64_t> h)
+{   // src/sketch.c:43-51
+	h = h ^ (h >> 33); h = h * (uint64_t)0xff51afd7ed558ccdULL;
+	h = h ^ (h >> 33); h = h * (uint64_t)0xc4ceb9fe1a85ec53ULL;
+	h = h ^ (h >> 33);
+	return h;
+}
+WM_DEV V<uint32_t> sk_bloom_hash(V<uint64_t> key, uint32_t salt)
+{   // bloom_filter.hpp hash_ap, one 8-byte round
+	V<uint32_t> lo = cast<uint32_t>(key), hi = cast<uint32_t>(key >> 32), h = salt;
+	h = h ^ ((h << 7) ^ (lo * (h >> 3)) ^ (~((h << 11) + (hi ^ (h >> 5)))));
+	return h;
+}
+
+// jobs[j]: sequence of 0..4 codes at seqs+seq_off (len bytes); minimizers go to out[out_off .. out_off+cap) and
+// counts[j] receives how many the reference would emit (may exceed cap: the host then retries with a larger slot).
+// ring_o / ring_y: w*64 entries each (LDS, or global scratch for very large w).
+WM_DEV void sketch_wave(const wm_sketch_params_t P, const wm_sketch_job_t *jobs, int n_jobs, int wave_id, const uint8_t *seqs,
+                        const uint8_t *bloom_bits, double *ring_o, uint32_t *ring_y, wm128_t *out, int *counts)
+{
+	const int w = P.w, k = P.k;
+	const uint64_t mask = (1ULL << 2 * k) - 1, top = 2ULL * (uint64_t)(k - 1);
+	const V<int> ln = lane();
+	const V<int> job = ln + wave_id * 64;
+	const vbool have = job < n_jobs;
+	V<int> len = 0, cap = 0;
+	V<long long> soff = 0, ooff = 0;
+	WM_IF(have)
+		len = gld(&jobs[0].len, job * (int)(sizeof(wm_sketch_job_t) / 4));
+		cap = gld(&jobs[0].cap, job * (int)(sizeof(wm_sketch_job_t) / 4));
+		soff = cast<long long>(gld(&jobs[0].seq_off, job * (int)(sizeof(wm_sketch_job_t) / 8)));
+		ooff = cast<long long>(gld(&jobs[0].out_off, job * (int)(sizeof(wm_sketch_job_t) / 8)));
+	WM_END
+	// uniform trip count = longest sequence in this wave
+	int max_len = 0;
+	for (int l = 0; l < 64; ++l) { const int v = readlane(len, l); max_len = v > max_len ? v : max_len; }
+
+	V<uint64_t> fw = (uint64_t)0, rc = (uint64_t)0;
+	V<int> run = 0, slot = 0, min_slot = 0, n_out = 0;
+	V<double> min_o = 2.0;
+	V<int> min_y = -1;                         // pos<<1|strand of the current minimum, -1 = none
+	for (int j = 0; j < w; ++j) { gst(ring_o, ln + j * 64, V<double>(2.0)); gst(ring_y, ln + j * 64, V<uint32_t>(0xffffffffu)); }
+
+	for (int i = 0; i < max_len; ++i) {
+		WM_IF(have && len > i)
+			V<int> c = cast<int>(gld(seqs, soff + (long long)i));
+			V<double> co = 2.0;
+			V<int> cy = -1;
+			vbool skip = c < 0;                // false
+			WM_IF(c < 4)
+				fw = ((fw << 2) | cast<uint64_t>(c)) & mask;
+				rc = (rc >> 2) | ((cast<uint64_t>(c) ^ (uint64_t)3) << (int)top);
+				skip = fw == rc;               // strand-ambiguous k-mer: the whole step is skipped (src/sketch.c:166)
+				WM_IF(!skip)
+					V<int> strand = sel(fw < rc, 0, 1);
+					run = run + 1;
+					WM_IF(run >= k)
+						V<uint64_t> km = sel(strand == 1, rc, fw);
+						// bloom probe: two hashes, bit = h % table_bits (32-bit: table_bits < 2^32 checked by the host)
+						V<uint32_t> h0 = sk_bloom_hash(km, P.salt0) % P.table_bits, h1 = sk_bloom_hash(km, P.salt1) % P.table_bits;
+						V<int> b0 = cast<int>(gld(bloom_bits, h0 >> 3)) >> cast<int>(h0 & 7u), b1 = cast<int>(gld(bloom_bits, h1 >> 3)) >> cast<int>(h1 & 7u);
+						vbool down = ((b0 & b1) & 1) == 1;
+						V<double> x = cast<double>(sk_fmix64(km)) * 1.0 / 18446744073709551616.0;
+						V<double> x2 = x * x, x4 = x2 * x2;
+						co = sel(down, -1.0 * (x4 * x4), -1.0 * x);
+						cy = (V<int>(i) << 1) | strand;
+					WM_END
+				WM_END
+			WM_ELSE
+				run = 0;
+			WM_END
+			WM_IF(!skip)
+				gst(ring_o, ln + slot * 64, co);
+				gst(ring_y, ln + slot * 64, cast<uint32_t>(cy));
+				vbool better = co < min_o, leaving = !better && (slot == min_slot);
+				vbool emit = min_y >= 0 && ((better && run >= w + k) || (leaving && run >= w + k - 1));
+				WM_IF(emit)                    // rebuild the key of the minimum from the k bases that end at its position
+					V<int> pos = min_y >> 1, strand = min_y & 1;
+					V<uint64_t> f2 = (uint64_t)0, r2 = (uint64_t)0;
+					for (int t = 0; t < k; ++t) {
+						V<uint64_t> cc = cast<uint64_t>(gld(seqs, soff + cast<long long>(pos - (k - 1) + t)));
+						f2 = ((f2 << 2) | cc) & mask;
+						r2 = (r2 >> 2) | ((cc ^ (uint64_t)3) << (int)top);
+					}
+					V<uint64_t> km = sel(strand == 1, r2, f2);
+					WM_IF(n_out < cap)
+						V<long long> o = (ooff + cast<long long>(n_out)) * 2LL;
+						gst((uint64_t*)out, o, (sk_hash64(km, mask) << 8) | (uint64_t)k);
+						gst((uint64_t*)out, o + 1LL, cast<uint64_t>(min_y));      // rid = 0; the host adds rid<<32 where needed
+					WM_END
+					n_out = n_out + 1;
+				WM_END
+				WM_IF(better)
+					min_o = co; min_y = cy; min_slot = slot;
+				WM_END
+				WM_IF(leaving)                 // rescan the window oldest → newest; >= keeps the newest of equal orders
+					min_o = 2.0; min_y = -1;
+					for (int n = 1; n <= w; ++n) {
+						V<int> jj = slot + n;
+						jj = sel(jj >= w, jj - w, jj);
+						V<double> o = gld(ring_o, ln + jj * 64);
+						vbool take = min_o >= o;
+						min_o = sel(take, o, min_o);
+						min_y = sel(take, cast<int>(gld(ring_y, ln + jj * 64)), min_y);
+						min_slot = sel(take, jj, min_slot);
+					}
+				WM_END
+				slot = slot + 1;
+				slot = sel(slot == w, 0, slot);
+			WM_END
+		WM_END
+	}
+	WM_IF(have && min_y >= 0)              // flush the last minimum (src/sketch.c:208-214)
+		V<int> pos = min_y >> 1, strand = min_y & 1;
+		V<uint64_t> f2 = (uint64_t)0, r2 = (uint64_t)0;
+		for (int t = 0; t < k; ++t) {
+			V<uint64_t> cc = cast<uint64_t>(gld(seqs, soff + cast<long long>(pos - (k - 1) + t)));
+			f2 = ((f2 << 2) | cc) & mask;
+			r2 = (r2 >> 2) | ((cc ^ (uint64_t)3) << (int)top);
+		}
+		V<uint64_t> km = sel(strand == 1, r2, f2);
+		WM_IF(n_out < cap)
+			V<long long> o = (ooff + cast<long long>(n_out)) * 2LL;
+			gst((uint64_t*)out, o, (sk_hash64(km, mask) << 8) | (uint64_t)k);
+			gst((uint64_t*)out, o + 1LL, cast<uint64_t>(min_y));
+		WM_END
+		n_out = n_out + 1;
+	WM_END
+	WM_IF(have) gst(counts, job, n_out); WM_END
+}
+
+} // namespace wmk

@@ -13,6 +13,8 @@
 #include "simt.h"
 #include "ksw_kernel.h"
 #include "ksw_plan.h"
+#include "sketch_kernel.h"
+#include "seedchain_kernel.h"
 
 // ======================================================================================================
 // kernels
@@ -24,6 +26,19 @@ __global__ __launch_bounds__(64) void ksw_dp_kernel(wm_ksw_score_t sc, const wm_
 {
 	const int j = order[blockIdx.x];
 	wmk::ksw_dp_wave<B, CLIP, HASN>(sc, jobs[j], seqs, tb, res + j);
+}
+
+// generic class: per-lane state in a global scratch slab (7*T int8 + T int32 per job), one wave per alignment
+__global__ __launch_bounds__(64) void ksw_generic_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
+                                                          const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, uint8_t *scratch,
+                                                          const uint64_t *__restrict__ scratch_off, wm_ksw_dres_t *__restrict__ res)
+{
+	const int j = order[blockIdx.x];
+	const wm_ksw_djob_t jb = jobs[j];
+	const int T = (jb.tlen + 15) / 16 * 16;
+	signed char *mem = (signed char*)(scratch + scratch_off[blockIdx.x]);
+	int *Hm = (int*)(mem + (size_t)8 * T);
+	wmk::ksw_dp_generic<true>(sc, jb, seqs, tb, mem, Hm, res + j);
 }
 
 // one thread per alignment: walk the traceback, write run-length ops (backtrack order) into the job's slot
@@ -94,7 +109,13 @@ struct wm_ctx_s {
 	uint8_t *arena;
 	size_t arena_bytes, arena_used;
 	hipEvent_t ev[4];
-	float last_ms;
+	float last_ms, aux_ms;
+	// flat index in HBM (wm_index_upload)
+	uint64_t *d_hkey, *d_hval, *d_P;
+	uint8_t *d_bloom;
+	int hbits;
+	wm_sketch_params_t skp;
+	bool have_index;
 };
 
 struct wm_ksw_dev_batch_s {
@@ -104,6 +125,7 @@ struct wm_ksw_dev_batch_s {
 	std::vector<int> order[WM_KSW_NCLASS];      // job indices per class, largest first
 	std::vector<int> degenerate;                // jobs the reference returns from early (src/ksw2_extd2_sse.c:68,92)
 	// device pointers (inside the arena)
+	uint8_t *d_gscratch; uint64_t *d_goff; std::vector<uint64_t> goff;
 	wm_ksw_djob_t *d_jobs; int *d_order; uint8_t *d_seqs, *d_tb; wm_ksw_dres_t *d_res; uint32_t *d_cig, *d_off, *d_total, *d_pool; int *d_err;
 	size_t pool_cap, arena_mark;
 	uint64_t cells, tb_bytes;
@@ -138,7 +160,7 @@ extern "C" int wm_ctx_create(int device, size_t arena_bytes, wm_ctx_t **out)
 	HIPCHK(hipMalloc((void**)&c->arena, arena_bytes));
 	HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 	for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
-	c->arena_used = 0; c->last_ms = 0;
+	c->arena_used = 0; c->last_ms = 0; c->aux_ms = 0; c->have_index = false; c->d_hkey = c->d_hval = c->d_P = 0; c->d_bloom = 0;
 	*out = c;
 	return WM_OK;
 }
@@ -151,6 +173,7 @@ extern "C" void wm_ctx_destroy(wm_ctx_t *c)
 	for (int i = 0; i < 4; ++i) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream);
 	hipFree(c->arena);
+	if (c->have_index) { hipFree(c->d_hkey); hipFree(c->d_hval); hipFree(c->d_P); hipFree(c->d_bloom); }
 	delete c;
 }
 
@@ -206,7 +229,6 @@ extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int 
 		if ((size_t)s.q_off + s.qlen > seqs_bytes || (size_t)s.t_off + s.tlen > seqs_bytes) { delete b; return set_err(WM_EINVAL, "job %d: sequence offsets outside seqs", i); }
 		int n_col;
 		d.klass = wm_ksw_classify(s.qlen, s.tlen, s.w, wm_ksw_has_n(seqs + s.q_off, s.qlen) | wm_ksw_has_n(seqs + s.t_off, s.tlen), &n_col);
-		if (d.klass >= WM_KSW_GENERIC) { delete b; return set_err(WM_EINVAL, "job %d: band hull of %d lanes exceeds the register kernels (generic kernel not built yet)", i, n_col); }
 		d.n_col = n_col;
 		d.tb_off = tb_off;
 		const uint64_t rows = (uint64_t)s.qlen + s.tlen - 1;
@@ -233,6 +255,13 @@ extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int 
 	b->pool_cap = cig_off + 16;
 	b->d_pool = (uint32_t*)arena_take(c, b->pool_cap * 4);
 	b->d_tb = (uint8_t*)arena_take(c, tb_off + 64);
+	{   // scratch slabs of the generic class: 8*T bytes (7 int8 arrays, padded) + 4*T for H
+		uint64_t go = 0;
+		for (int j : b->order[WM_KSW_GENERIC]) { const uint64_t T = ((uint64_t)b->jobs[j].tlen + 15) / 16 * 16; b->goff.push_back(go); go += 12 * T + 256; }
+		b->d_gscratch = (uint8_t*)arena_take(c, go + 256);
+		b->d_goff = (uint64_t*)arena_take(c, b->goff.size() * 8 + 64);
+		if (!b->d_gscratch || !b->d_goff) b->d_tb = 0;
+	}
 	if (!b->d_jobs || !b->d_order || !b->d_res || !b->d_off || !b->d_total || !b->d_err || !b->d_seqs || !b->d_cig || !b->d_pool || !b->d_tb) {
 		c->arena_used = b->arena_mark;
 		delete b;
@@ -244,6 +273,7 @@ extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int 
 	HIPCHK(hipMemcpyAsync(b->d_jobs, b->jobs.data(), n_jobs * sizeof(wm_ksw_djob_t), hipMemcpyHostToDevice, c->stream));
 	if (!ord.empty()) HIPCHK(hipMemcpyAsync(b->d_order, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipMemcpyAsync(b->d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream));
+	if (!b->goff.empty()) HIPCHK(hipMemcpyAsync(b->d_goff, b->goff.data(), b->goff.size() * 8, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	*out = b;
 	return WM_OK;
@@ -275,6 +305,9 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		}
 		off += nk;
 	}
+	if (!b->order[WM_KSW_GENERIC].empty())
+		hipLaunchKernelGGL(ksw_generic_kernel, dim3((int)b->order[WM_KSW_GENERIC].size()), dim3(64), 0, c->stream, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb,
+		                   b->d_gscratch, b->d_goff, b->d_res);
 	HIPCHK(hipEventRecord(c->ev[1], c->stream));
 	hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, b->d_jobs, b->d_tb, b->d_res, b->d_cig, b->d_err);
 	hipLaunchKernelGGL(ksw_scan_kernel, dim3(1), dim3(1024), 0, c->stream, n, b->d_res, b->d_off, b->d_total);
@@ -379,5 +412,431 @@ extern "C" int wm_ksw_extd2(wm_ctx_t *c, int qlen, const uint8_t *query, int tle
 	int rc = wm_ksw_batch(c, &sc, 1, &jb, seqs.data(), seqs.size(), ez, cig, cap, &used);
 	if (rc) { free(cig); *cigar_out = 0; return rc; }
 	*cigar_out = cig;
+	return WM_OK;
+}
+
+// ======================================================================================================
+// sketch / seed / chain kernels and their batched entry points
+// ======================================================================================================
+#include "host/wm_core.cpp"
+#include "host/wm_index.cpp"
+#include "host/wm_seqio.cpp"
+#include "host/wm_hit.cpp"
+#include "host/wm_chain.cpp"
+#include "host/wm_align.cpp"
+#include "host/wm_mapper.cpp"
+#include "host/wm_format.cpp"
+
+struct wm_index_s { wm::Index ix; };
+
+__global__ __launch_bounds__(64) void sketch_kernel(wm_sketch_params_t P, const wm_sketch_job_t *jobs, int n_jobs, const uint8_t *seqs,
+                                                     const uint8_t *bloom, wm128_t *out, int *counts)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	double *ring_o = (double*)smem;
+	uint32_t *ring_y = (uint32_t*)(smem + (size_t)P.w * 64 * sizeof(double));
+	wmk::sketch_wave(P, jobs, n_jobs, blockIdx.x, seqs, bloom, ring_o, ring_y, out, counts);
+}
+
+__global__ __launch_bounds__(64) void seed_kernel(wm_index_view_t ix, const wm_seed_job_t *jobs, const wm128_t *mini, wm128_t *anchors,
+                                                   int *occ_scratch, const uint64_t *occ_off, wm_seed_res_t *res)
+{
+	const int j = blockIdx.x;
+	wmk::seed_wave(ix, jobs[j], mini, anchors, occ_scratch + occ_off[j], res + j);
+}
+
+__global__ __launch_bounds__(64) void chain_kernel(const wm_chain_job_t *jobs, const int *order, const wm128_t *anchors, int *fpvt)
+{
+	const int j = order[blockIdx.x];
+	const wm_chain_job_t jb = jobs[j];
+	int *f = fpvt + jb.a_off * 4, *p = f + jb.n, *v = p + jb.n, *t = v + jb.n;
+	wmk::chain_wave(jb, anchors, f, p, v, t);
+}
+
+extern "C" float wm_last_aux_ms(const wm_ctx_t *c) { return c ? c->aux_ms : 0.f; }
+
+extern "C" int wm_index_build(const char *fasta, const char *kmer_file, int k, int w, int n_threads, wm_index_t **out)
+{
+	*out = 0;
+	wm::IdxOpt io; io.k = k; io.w = w;
+	wm::MapOpt mo; std::string err;
+	if (wm::check_opt(io, mo, err) < 0) return set_err(WM_EINVAL, "%s", err.c_str());
+	wm_index_t *h = new wm_index_t();
+	if (wm::index_build_from_fasta(io, fasta, kmer_file ? kmer_file : "", n_threads, h->ix, err) < 0) { delete h; return set_err(WM_EINVAL, "%s", err.c_str()); }
+	*out = h;
+	return WM_OK;
+}
+extern "C" void wm_index_destroy(wm_index_t *h) { delete h; }
+extern "C" int wm_index_n_seq(const wm_index_t *h) { return (int)h->ix.seq.size(); }
+extern "C" const char *wm_index_seq_name(const wm_index_t *h, int rid) { return h->ix.seq[rid].name.c_str(); }
+extern "C" int wm_index_seq_len(const wm_index_t *h, int rid) { return (int)h->ix.seq[rid].len; }
+extern "C" uint64_t wm_index_n_minimizers(const wm_index_t *h) { return h->ix.n_minimizers; }
+extern "C" const uint64_t *wm_index_get(const wm_index_t *h, uint64_t minier, int *n) { return h->ix.get(minier, n); }
+
+extern "C" int wm_index_upload(wm_ctx_t *c, const wm_index_t *h)
+{
+	if (!c || !h) return set_err(WM_EINVAL, "null argument");
+	HIPCHK(hipSetDevice(c->device));
+	const wm::Index &ix = h->ix;
+	if (ix.bloom.table_bits >= ((uint64_t)1 << 32)) return set_err(WM_EINVAL, "bloom table of %llu bits not supported on device", (unsigned long long)ix.bloom.table_bits);
+	if (c->have_index) { hipFree(c->d_hkey); hipFree(c->d_hval); hipFree(c->d_P); hipFree(c->d_bloom); c->have_index = false; }
+	HIPCHK(hipMalloc((void**)&c->d_hkey, ix.hkey.size() * 8 + 8));
+	HIPCHK(hipMalloc((void**)&c->d_hval, ix.hval.size() * 8 + 8));
+	HIPCHK(hipMalloc((void**)&c->d_P, ix.P.size() * 8 + 8));
+	HIPCHK(hipMalloc((void**)&c->d_bloom, ix.bloom.bits.size() + 8));
+	HIPCHK(hipMemcpy(c->d_hkey, ix.hkey.data(), ix.hkey.size() * 8, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(c->d_hval, ix.hval.data(), ix.hval.size() * 8, hipMemcpyHostToDevice));
+	if (!ix.P.empty()) HIPCHK(hipMemcpy(c->d_P, ix.P.data(), ix.P.size() * 8, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(c->d_bloom, ix.bloom.bits.data(), ix.bloom.bits.size(), hipMemcpyHostToDevice));
+	c->hbits = ix.hbits;
+	c->skp.w = ix.w; c->skp.k = ix.k; c->skp.table_bits = (uint32_t)ix.bloom.table_bits; c->skp.salt0 = ix.bloom.salt[0]; c->skp.salt1 = ix.bloom.salt[1];
+	c->have_index = true;
+	return WM_OK;
+}
+
+struct ArenaMark { wm_ctx_t *c; size_t m; ArenaMark(wm_ctx_t *c_) : c(c_), m(c_->arena_used) {} ~ArenaMark() { c->arena_used = m; } };
+
+extern "C" int wm_sketch_batch(wm_ctx_t *c, int n, const uint8_t *seqs, size_t seqs_bytes, const uint64_t *seq_off, const int32_t *len,
+                               wm128_t *out, size_t out_cap, uint64_t *out_off, int32_t *counts)
+{
+	if (!c || !c->have_index) return set_err(WM_EINVAL, "wm_index_upload has not been called on this context");
+	if (n <= 0) return WM_OK;
+	HIPCHK(hipSetDevice(c->device));
+	const int w = c->skp.w;
+	const size_t lds = (size_t)w * 64 * 12;
+	if (lds > 160 * 1024) return set_err(WM_EINVAL, "window w=%d needs %zu B of LDS per wave (max 160 KB)", w, lds);
+	static bool attr_set = false;
+	if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)sketch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+	// first try a slot of len/4+16 minimizers per sequence (typical density is 2/(w+1)); retry the rare overflow at full size
+	std::vector<wm_sketch_job_t> jobs(n);
+	std::vector<int> todo(n);
+	for (int i = 0; i < n; ++i) todo[i] = i;
+	size_t used = 0;
+	float ms_total = 0;
+	for (int round = 0; round < 2 && !todo.empty(); ++round) {
+		ArenaMark mark(c);
+		std::vector<wm_sketch_job_t> jb(todo.size());
+		uint64_t tot = 0;
+		for (size_t t = 0; t < todo.size(); ++t) {
+			const int i = todo[t];
+			jb[t].seq_off = seq_off[i]; jb[t].len = len[i];
+			jb[t].cap = round == 0 ? len[i] / 4 + 16 : len[i] + 1;
+			jb[t].out_off = tot; tot += jb[t].cap;
+		}
+		wm_sketch_job_t *d_jobs = (wm_sketch_job_t*)arena_take(c, jb.size() * sizeof(wm_sketch_job_t));
+		uint8_t *d_seqs = (uint8_t*)arena_take(c, seqs_bytes + 64);
+		wm128_t *d_out = (wm128_t*)arena_take(c, (tot + 1) * sizeof(wm128_t));
+		int *d_cnt = (int*)arena_take(c, jb.size() * 4 + 64);
+		if (!d_jobs || !d_seqs || !d_out || !d_cnt) return set_err(WM_ENOMEM, "sketch batch does not fit the arena");
+		HIPCHK(hipMemcpyAsync(d_jobs, jb.data(), jb.size() * sizeof(wm_sketch_job_t), hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipEventRecord(c->ev[0], c->stream));
+		hipLaunchKernelGGL(sketch_kernel, dim3(((int)jb.size() + 63) / 64), dim3(64), lds, c->stream, c->skp, d_jobs, (int)jb.size(), d_seqs, c->d_bloom, d_out, d_cnt);
+		HIPCHK(hipEventRecord(c->ev[1], c->stream));
+		std::vector<int> cnt(jb.size());
+		std::vector<wm128_t> tmp(tot + 1);
+		HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt, jb.size() * 4, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipMemcpyAsync(tmp.data(), d_out, tot * sizeof(wm128_t), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+		HIPCHK(hipGetLastError());
+		float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); ms_total += ms;
+		std::vector<int> again;
+		for (size_t t = 0; t < todo.size(); ++t) {
+			const int i = todo[t];
+			if (cnt[t] > jb[t].cap) { again.push_back(i); continue; }
+			if (used + cnt[t] > out_cap) return set_err(WM_ENOMEM, "minimizer output pool too small");
+			out_off[i] = used; counts[i] = cnt[t];
+			memcpy(out + used, tmp.data() + jb[t].out_off, (size_t)cnt[t] * sizeof(wm128_t));
+			used += cnt[t];
+		}
+		todo.swap(again);
+	}
+	c->aux_ms = ms_total;
+	return WM_OK;
+}
+
+extern "C" int wm_seed_batch(wm_ctx_t *c, int n, const wm128_t *mini, const uint64_t *mini_off, const int32_t *n_mini, const int32_t *qlen,
+                             int max_occ, int64_t flag, wm128_t *out, size_t out_cap, uint64_t *out_off, int32_t *n_anchors, int32_t *rep_len)
+{
+	if (!c || !c->have_index) return set_err(WM_EINVAL, "wm_index_upload has not been called on this context");
+	if (n <= 0) return WM_OK;
+	HIPCHK(hipSetDevice(c->device));
+	// pass 1 on the host side of the boundary: how many anchors each job can produce is unknown until the lookup,
+	// so run with a generous slot and retry the overflowing jobs with the exact size the kernel reports
+	std::vector<int> todo(n);
+	for (int i = 0; i < n; ++i) todo[i] = i;
+	std::vector<int> want(n);
+	for (int i = 0; i < n; ++i) want[i] = n_mini[i] * 4 + 64;
+	size_t used = 0;
+	float ms_total = 0;
+	uint64_t mini_total = 0;
+	for (int i = 0; i < n; ++i) mini_total = std::max<uint64_t>(mini_total, mini_off[i] + n_mini[i]);
+	for (int round = 0; round < 3 && !todo.empty(); ++round) {
+		ArenaMark mark(c);
+		std::vector<wm_seed_job_t> jb(todo.size());
+		std::vector<uint64_t> occ_off(todo.size());
+		uint64_t tot = 0, occ_tot = 0;
+		for (size_t t = 0; t < todo.size(); ++t) {
+			const int i = todo[t];
+			jb[t].mini_off = mini_off[i]; jb[t].n_mini = n_mini[i]; jb[t].qlen = qlen[i]; jb[t].max_occ = max_occ; jb[t].cap = want[i];
+			jb[t].flag = (int32_t)(flag & (0x100000 | 0x200000)); jb[t].pad = 0;
+			jb[t].out_off = tot; tot += want[i];
+			occ_off[t] = occ_tot; occ_tot += n_mini[i];
+		}
+		wm_seed_job_t *d_jobs = (wm_seed_job_t*)arena_take(c, jb.size() * sizeof(wm_seed_job_t));
+		uint64_t *d_occ_off = (uint64_t*)arena_take(c, jb.size() * 8 + 64);
+		wm128_t *d_mini = (wm128_t*)arena_take(c, (mini_total + 1) * sizeof(wm128_t));
+		wm128_t *d_out = (wm128_t*)arena_take(c, (tot + 1) * sizeof(wm128_t));
+		int *d_occ = (int*)arena_take(c, (occ_tot + 1) * 4);
+		wm_seed_res_t *d_res = (wm_seed_res_t*)arena_take(c, jb.size() * sizeof(wm_seed_res_t) + 64);
+		if (!d_jobs || !d_occ_off || !d_mini || !d_out || !d_occ || !d_res) return set_err(WM_ENOMEM, "seed batch does not fit the arena");
+		HIPCHK(hipMemcpyAsync(d_jobs, jb.data(), jb.size() * sizeof(wm_seed_job_t), hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(d_occ_off, occ_off.data(), jb.size() * 8, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(d_mini, mini, mini_total * sizeof(wm128_t), hipMemcpyHostToDevice, c->stream));
+		wm_index_view_t ix = { c->d_hkey, c->d_hval, c->d_P, c->hbits, 0 };
+		HIPCHK(hipEventRecord(c->ev[0], c->stream));
+		hipLaunchKernelGGL(seed_kernel, dim3((int)jb.size()), dim3(64), 0, c->stream, ix, d_jobs, d_mini, d_out, d_occ, d_occ_off, d_res);
+		HIPCHK(hipEventRecord(c->ev[1], c->stream));
+		std::vector<wm_seed_res_t> res(jb.size());
+		std::vector<wm128_t> tmp(tot + 1);
+		HIPCHK(hipMemcpyAsync(res.data(), d_res, jb.size() * sizeof(wm_seed_res_t), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipMemcpyAsync(tmp.data(), d_out, tot * sizeof(wm128_t), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+		HIPCHK(hipGetLastError());
+		float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); ms_total += ms;
+		std::vector<int> again;
+		for (size_t t = 0; t < todo.size(); ++t) {
+			const int i = todo[t];
+			if (res[t].n_anchors > jb[t].cap) { want[i] = res[t].n_anchors; again.push_back(i); continue; }
+			if (used + res[t].n_anchors > out_cap) return set_err(WM_ENOMEM, "anchor output pool too small");
+			out_off[i] = used; n_anchors[i] = res[t].n_anchors; rep_len[i] = res[t].rep_len;
+			memcpy(out + used, tmp.data() + jb[t].out_off, (size_t)res[t].n_anchors * sizeof(wm128_t));
+			// the reference's in-place unstable radix sort (src/map.c:252); its tie permutation is sequential by nature
+			wm::radix_sort_128x(out + used, out + used + res[t].n_anchors);
+			used += res[t].n_anchors;
+		}
+		todo.swap(again);
+	}
+	if (!todo.empty()) return set_err(WM_EINTERNAL, "seed retry did not converge");
+	c->aux_ms = ms_total;
+	return WM_OK;
+}
+
+extern "C" int wm_chain_batch(wm_ctx_t *c, int n, wm128_t *a, const uint64_t *a_off, const int32_t *n_a, const wm_chain_par_t *par,
+                              uint64_t *u, uint64_t *u_off, int32_t *n_u, int32_t *n_v)
+{
+	if (!c) return set_err(WM_EINVAL, "null context");
+	if (n <= 0) return WM_OK;
+	HIPCHK(hipSetDevice(c->device));
+	ArenaMark mark(c);
+	uint64_t tot = 0;
+	for (int i = 0; i < n; ++i) tot = std::max<uint64_t>(tot, a_off[i] + n_a[i]);
+	std::vector<wm_chain_job_t> jb(n);
+	std::vector<int> order(n);
+	for (int i = 0; i < n; ++i) {
+		jb[i].a_off = a_off[i]; jb[i].n = n_a[i];
+		jb[i].max_dist_x = par[i].max_dist_x; jb[i].min_dist_x = par[i].min_dist_x; jb[i].max_dist_y = par[i].max_dist_y; jb[i].bw = par[i].bw;
+		jb[i].max_skip = par[i].max_skip; jb[i].max_iter = par[i].max_iter; jb[i].gap_scale = par[i].gap_scale; jb[i].pad = 0;
+		jb[i].avg_qspan = n_a[i] > 0 ? wm::chain_avg_qspan(n_a[i], a + a_off[i]) : 0.f;
+		order[i] = i;
+	}
+	std::sort(order.begin(), order.end(), [&](int x, int y) { return n_a[x] != n_a[y] ? n_a[x] > n_a[y] : x < y; });
+	wm_chain_job_t *d_jobs = (wm_chain_job_t*)arena_take(c, (size_t)n * sizeof(wm_chain_job_t));
+	int *d_order = (int*)arena_take(c, (size_t)n * 4 + 64);
+	wm128_t *d_a = (wm128_t*)arena_take(c, (tot + 1) * sizeof(wm128_t));
+	int *d_fpvt = (int*)arena_take(c, (tot + 1) * 16);
+	if (!d_jobs || !d_order || !d_a || !d_fpvt) return set_err(WM_ENOMEM, "chain batch does not fit the arena");
+	HIPCHK(hipMemcpyAsync(d_jobs, jb.data(), (size_t)n * sizeof(wm_chain_job_t), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(d_a, a, tot * sizeof(wm128_t), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipEventRecord(c->ev[0], c->stream));
+	hipLaunchKernelGGL(chain_kernel, dim3(n), dim3(64), 0, c->stream, d_jobs, d_order, d_a, d_fpvt);
+	HIPCHK(hipEventRecord(c->ev[1], c->stream));
+	std::vector<int> fpvt((tot + 1) * 4);
+	HIPCHK(hipMemcpyAsync(fpvt.data(), d_fpvt, tot * 16, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventElapsedTime(&c->aux_ms, c->ev[0], c->ev[1]));
+	// chain extraction (src/chain.c:93-165): O(n) bookkeeping on the fill's f/p/v
+	uint64_t uo = 0;
+	std::vector<uint64_t> uu;
+	std::vector<wm::m128> bb;
+	for (int i = 0; i < n; ++i) {
+		const int *f = fpvt.data() + a_off[i] * 4, *p = f + n_a[i], *v = p + n_a[i];
+		wm::chain_extract(n_a[i], a + a_off[i], f, p, v, par[i].min_cnt, par[i].min_sc, uu, bb);
+		u_off[i] = uo; n_u[i] = (int)uu.size(); n_v[i] = (int)bb.size();
+		for (size_t k = 0; k < uu.size(); ++k) u[uo + k] = uu[k];
+		uo += uu.size();
+		if (!bb.empty()) memcpy(a + a_off[i], bb.data(), bb.size() * sizeof(wm128_t));
+	}
+	return WM_OK;
+}
+
+// ======================================================================================================
+// GpuOps: the product implementation of the mapper's device operations
+// ======================================================================================================
+struct GpuOps : wm::DeviceOps {
+	wm_ctx_t *c;
+	uint64_t cells = 0;
+	double ksw_us = 0, aux_us = 0;
+	std::string error;
+	void fail(const char *what) { if (error.empty()) error = std::string(what) + ": " + g_err; }
+	void sketch_batch(int, int, std::vector<wm::SketchReq*> &reqs) override
+	{
+		const int n = (int)reqs.size();
+		std::vector<uint64_t> off(n), ooff(n);
+		std::vector<int32_t> len(n), cnt(n);
+		size_t tot = 0;
+		for (int i = 0; i < n; ++i) { off[i] = tot; len[i] = reqs[i]->len; tot += reqs[i]->len; }
+		std::vector<uint8_t> seqs(tot + 1);
+		for (int i = 0; i < n; ++i) memcpy(seqs.data() + off[i], reqs[i]->seq, reqs[i]->len);
+		std::vector<wm128_t> out(tot + n + 1);
+		if (wm_sketch_batch(c, n, seqs.data(), tot, off.data(), len.data(), out.data(), out.size(), ooff.data(), cnt.data())) { fail("sketch"); return; }
+		aux_us += c->aux_ms * 1e3;
+		for (int i = 0; i < n; ++i) reqs[i]->mini.assign(out.begin() + ooff[i], out.begin() + ooff[i] + cnt[i]);
+	}
+	void seed_batch(std::vector<wm::SeedReq*> &reqs) override
+	{
+		const int n = (int)reqs.size();
+		// one launch per (max_occ, flag) class; in practice a single class
+		std::vector<uint64_t> moff(n), ooff(n);
+		std::vector<int32_t> nm(n), ql(n), na(n), rl(n);
+		size_t tot = 0;
+		for (int i = 0; i < n; ++i) { moff[i] = tot; nm[i] = reqs[i]->n_mini; ql[i] = reqs[i]->qlen; tot += reqs[i]->n_mini; }
+		std::vector<wm128_t> mini(tot + 1);
+		for (int i = 0; i < n; ++i) memcpy(mini.data() + moff[i], reqs[i]->mini, (size_t)reqs[i]->n_mini * sizeof(wm128_t));
+		size_t cap = tot * 8 + 1024;
+		for (int attempt = 0; attempt < 6; ++attempt) {
+			std::vector<wm128_t> out(cap);
+			const int rc = wm_seed_batch(c, n, mini.data(), moff.data(), nm.data(), ql.data(), reqs[0]->max_occ, reqs[0]->flag, out.data(), out.size(), ooff.data(), na.data(), rl.data());
+			if (rc == WM_ENOMEM && strstr(g_err, "anchor output pool")) { cap *= 8; continue; }
+			if (rc) { fail("seed"); return; }
+			aux_us += c->aux_ms * 1e3;
+			for (int i = 0; i < n; ++i) { reqs[i]->a.assign(out.begin() + ooff[i], out.begin() + ooff[i] + na[i]); reqs[i]->rep_len = rl[i]; }
+			return;
+		}
+		fail("seed (anchor pool)");
+	}
+	void chain_batch(std::vector<wm::ChainReq*> &reqs) override
+	{
+		const int n = (int)reqs.size();
+		std::vector<uint64_t> aoff(n), uoff(n);
+		std::vector<int32_t> na(n), nu(n), nv(n);
+		std::vector<wm_chain_par_t> par(n);
+		size_t tot = 0;
+		for (int i = 0; i < n; ++i) {
+			aoff[i] = tot; na[i] = (int)reqs[i]->a.size(); tot += reqs[i]->a.size();
+			wm::ChainReq &r = *reqs[i];
+			par[i] = { r.max_dist_x, r.min_dist_x, r.max_dist_y, r.bw, r.max_skip, r.max_iter, r.min_cnt, r.min_sc, r.gap_scale };
+		}
+		std::vector<wm128_t> a(tot + 1);
+		std::vector<uint64_t> u(tot + 1);
+		for (int i = 0; i < n; ++i) memcpy(a.data() + aoff[i], reqs[i]->a.data(), reqs[i]->a.size() * sizeof(wm128_t));
+		if (wm_chain_batch(c, n, a.data(), aoff.data(), na.data(), par.data(), u.data(), uoff.data(), nu.data(), nv.data())) { fail("chain"); return; }
+		aux_us += c->aux_ms * 1e3;
+		for (int i = 0; i < n; ++i) {
+			reqs[i]->u.assign(u.begin() + uoff[i], u.begin() + uoff[i] + nu[i]);
+			reqs[i]->a.assign(a.begin() + aoff[i], a.begin() + aoff[i] + nv[i]);
+		}
+	}
+	void ksw_batch(const wm_ksw_score_t &sc, std::vector<wm::KswReq*> &reqs) override
+	{
+		const int n = (int)reqs.size();
+		std::vector<wm_ksw_job_t> jobs(n);
+		size_t tot = 0, cap = 16;
+		for (int i = 0; i < n; ++i) {
+			wm::KswReq &r = *reqs[i];
+			jobs[i].q_off = (uint32_t)tot; tot += r.q.size();
+			jobs[i].t_off = (uint32_t)tot; tot += r.t.size();
+			jobs[i].qlen = (int)r.q.size(); jobs[i].tlen = (int)r.t.size();
+			jobs[i].w = r.w; jobs[i].zdrop = r.zdrop; jobs[i].end_bonus = r.end_bonus; jobs[i].flag = r.flag;
+			cap += r.q.size() + r.t.size() + 2;
+			uint64_t band; wm_ksw_cells(jobs[i].qlen, jobs[i].tlen, jobs[i].w, &band); cells += band;
+		}
+		if (tot >= ((size_t)1 << 32)) { error = "ksw batch exceeds 4 GB of sequence"; return; }
+		std::vector<uint8_t> seqs(tot + 1);
+		for (int i = 0; i < n; ++i) {
+			memcpy(seqs.data() + jobs[i].q_off, reqs[i]->q.data(), reqs[i]->q.size());
+			memcpy(seqs.data() + jobs[i].t_off, reqs[i]->t.data(), reqs[i]->t.size());
+		}
+		std::vector<wm_ksw_result_t> res(n);
+		std::vector<uint32_t> pool(cap);
+		size_t used = 0;
+		if (wm_ksw_batch(c, &sc, n, jobs.data(), seqs.data(), tot, res.data(), pool.data(), cap, &used)) { fail("ksw"); return; }
+		ksw_us += c->last_ms * 1e3;
+		for (int i = 0; i < n; ++i) {
+			reqs[i]->ez = res[i];
+			reqs[i]->cigar.assign(pool.begin() + res[i].cig_off, pool.begin() + res[i].cig_off + res[i].n_cigar);
+		}
+	}
+};
+
+struct wm_mapper_s {
+	wm_ctx_t *c; const wm_index_t *idx;
+	wm::IdxOpt io; wm::MapOpt mo;
+	std::string text;
+	std::vector<int32_t> hits; std::vector<uint32_t> cigars; std::vector<int64_t> first;
+	uint64_t stats[9];
+};
+
+extern "C" int wm_mapper_create(wm_ctx_t *c, const wm_index_t *idx, const char *preset, int64_t flag, wm_mapper_t **out)
+{
+	*out = 0;
+	if (!c || !idx) return set_err(WM_EINVAL, "null argument");
+	if (!c->have_index) return set_err(WM_EINVAL, "wm_index_upload has not been called on this context");
+	wm_mapper_t *m = new wm_mapper_t();
+	m->c = c; m->idx = idx;
+	wm::set_preset(0, m->io, m->mo);
+	if (preset && preset[0] && wm::set_preset(preset, m->io, m->mo) < 0) { delete m; return set_err(WM_EINVAL, "unknown preset '%s'", preset); }
+	m->mo.flag |= flag;
+	m->io.k = idx->ix.k; m->io.w = idx->ix.w;
+	std::string err;
+	if (wm::check_opt(m->io, m->mo, err) < 0) { delete m; return set_err(WM_EINVAL, "%s", err.c_str()); }
+	memset(m->stats, 0, sizeof(m->stats));
+	*out = m;
+	return WM_OK;
+}
+extern "C" void wm_mapper_destroy(wm_mapper_t *m) { delete m; }
+
+extern "C" int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, const char *const *seqs, const int32_t *lens,
+                            const char **text, size_t *text_len, const int32_t **hits, const uint32_t **cigars, const int64_t **hit_first)
+{
+	std::vector<wm::ReadIn> reads(n);
+	uint64_t bases = 0;
+	for (int i = 0; i < n; ++i) { reads[i].name = names[i]; reads[i].seq.assign(seqs[i], lens[i]); bases += lens[i]; }
+	std::vector<wm::ReadOut> out;
+	GpuOps ops; ops.c = m->c;
+	wm::MapStats st;
+	wm::map_batch(m->idx->ix, m->mo, &ops, reads, out, &st);
+	if (!ops.error.empty()) return set_err(WM_ENODEV, "%s", ops.error.c_str());
+	m->text.clear(); m->hits.clear(); m->cigars.clear(); m->first.assign(n + 1, 0);
+	for (int i = 0; i < n; ++i) {
+		wm::write_read(m->text, m->idx->ix, reads[i], out[i], m->mo.flag);
+		m->first[i] = (int64_t)(m->hits.size() / 16);
+		for (const wm::Reg &r : out[i].regs) {
+			const int32_t o[16] = { r.rid, r.rs, r.re, r.qs, r.qe, (int32_t)r.rev, (int32_t)r.mapq, r.has_p ? (int32_t)r.cigar.size() : 0, r.score, r.cnt, r.mlen, r.blen,
+			                        r.dp_score, r.dp_max, r.dp_max2, (int32_t)((r.parent == r.id) | r.inv << 1 | r.sam_pri << 2 | r.split << 3) };
+			m->hits.insert(m->hits.end(), o, o + 16);
+			m->cigars.insert(m->cigars.end(), r.cigar.begin(), r.cigar.end());
+		}
+	}
+	m->first[n] = (int64_t)(m->hits.size() / 16);
+	m->stats[0] = st.n_flush; m->stats[1] = st.n_ksw; m->stats[2] = st.n_chain; m->stats[3] = st.n_seed; m->stats[4] = st.n_sketch;
+	m->stats[5] = ops.cells; m->stats[6] = (uint64_t)ops.ksw_us; m->stats[7] = (uint64_t)ops.aux_us; m->stats[8] = bases;
+	if (text) *text = m->text.data();
+	if (text_len) *text_len = m->text.size();
+	if (hits) *hits = m->hits.data();
+	if (cigars) *cigars = m->cigars.data();
+	if (hit_first) *hit_first = m->first.data();
+	return WM_OK;
+}
+extern "C" int wm_mapper_stats(const wm_mapper_t *m, uint64_t *out9) { memcpy(out9, m->stats, sizeof(m->stats)); return WM_OK; }
+
+extern "C" int wm_sam_header(const wm_index_t *idx, int argc, const char *const *argv, const char **text, size_t *text_len)
+{
+	static thread_local std::string s;
+	s.clear();
+	wm::write_sam_header(s, idx->ix, argc, argv);
+	*text = s.data(); *text_len = s.size();
 	return WM_OK;
 }

@@ -20,3 +20,40 @@ typedef struct {
 	int32_t n_cigar;
 	int32_t bt_i, bt_j;   // backtrack start cell (-1: no backtrack)
 } wm_ksw_dres_t;
+
+// ---- sketch ----
+typedef struct {
+	uint64_t seq_off;     // offset of the 0..4 codes inside the batch sequence arena
+	uint64_t out_off;     // first minimizer slot of this job in the output pool
+	int32_t len, cap;     // sequence length; capacity of the output slot
+} wm_sketch_job_t;
+
+typedef struct {
+	int32_t w, k;
+	uint32_t table_bits;  // bloom geometry (0 bits never happens: the reference always allocates >= 14384)
+	uint32_t salt0, salt1;
+} wm_sketch_params_t;
+
+// ---- seed lookup (collect_matches + expansion of collect_seed_hits, src/map.c:97-130, 222-251) ----
+typedef struct {
+	uint64_t mini_off;    // first minimizer (wm128_t) of this job in the minimizer pool
+	uint64_t out_off;     // first anchor slot in the anchor pool
+	int32_t n_mini, qlen;
+	int32_t max_occ, cap; // occurrence cut-off (mid_occ); capacity of the anchor slot
+	int32_t flag, pad;    // MM_F_FOR_ONLY / MM_F_REV_ONLY bits
+} wm_seed_job_t;
+
+typedef struct { int32_t n_anchors, rep_len; } wm_seed_res_t;
+
+typedef struct {          // flat index view in HBM (host/wm_index.h)
+	const uint64_t *hkey, *hval, *P;
+	int32_t hbits, pad;
+} wm_index_view_t;
+
+// ---- chain DP fill (mm_chain_dp, src/chain.c:45-90) ----
+typedef struct {
+	uint64_t a_off;       // first anchor of this job in the anchor pool (sorted by x)
+	int32_t n, max_dist_x, min_dist_x, max_dist_y, bw, max_skip, max_iter;
+	float avg_qspan, gap_scale;
+	int32_t pad;
+} wm_chain_job_t;

@@ -132,3 +132,95 @@ def pack_jobs(pairs, w=751, zdrop=400, end_bonus=-1, flag=0):
         off += len(q) + len(t)
     seqs = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
     return jobs, seqs
+
+
+# ---- index + mapper ------------------------------------------------------------------------------------
+def _bind_map(L):
+    if getattr(L, "_wm_map_bound", False):
+        return
+    L.wm_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.wm_index_destroy.argtypes = [C.c_void_p]
+    L.wm_index_upload.argtypes = [C.c_void_p, C.c_void_p]
+    L.wm_index_n_seq.argtypes = [C.c_void_p]
+    L.wm_index_seq_name.restype = C.c_char_p
+    L.wm_index_seq_name.argtypes = [C.c_void_p, C.c_int]
+    L.wm_index_seq_len.argtypes = [C.c_void_p, C.c_int]
+    L.wm_index_n_minimizers.restype = C.c_uint64
+    L.wm_index_n_minimizers.argtypes = [C.c_void_p]
+    L.wm_mapper_create.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(C.c_void_p)]
+    L.wm_mapper_destroy.argtypes = [C.c_void_p]
+    L.wm_map_reads.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p,
+                               C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.wm_mapper_stats.argtypes = [C.c_void_p, C.c_void_p]
+    L.wm_sam_header.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
+    L.wm_last_aux_ms.restype = C.c_float
+    L.wm_last_aux_ms.argtypes = [C.c_void_p]
+    L._wm_map_bound = True
+
+
+class Index:
+    """Reference index (host build, mm_idx_gen semantics); `upload(ctx)` copies the flat arrays to HBM."""
+
+    def __init__(self, fasta, kmer_file=None, k=15, w=50, n_threads=8):
+        L = lib()
+        _bind_map(L)
+        self._h = C.c_void_p()
+        _chk(L.wm_index_build(os.fsencode(fasta), os.fsencode(kmer_file) if kmer_file else None, k, w, n_threads, C.byref(self._h)))
+
+    def upload(self, ctx):
+        _chk(lib().wm_index_upload(ctx._h, self._h))
+
+    @property
+    def n_minimizers(self):
+        return int(lib().wm_index_n_minimizers(self._h))
+
+    def names(self):
+        L = lib()
+        return [L.wm_index_seq_name(self._h, i).decode() for i in range(L.wm_index_n_seq(self._h))]
+
+    def close(self):
+        if self._h:
+            lib().wm_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+MM_F_CIGAR, MM_F_OUT_SAM, MM_F_OUT_CG = 0x4, 0x8, 0x20
+STAT_NAMES = ("super_steps", "ksw_jobs", "chain_jobs", "seed_jobs", "sketch_jobs", "dp_cells", "ksw_kernel_us", "aux_kernel_us", "read_bases")
+
+
+class Mapper:
+    """The batched replacement of kt_for(worker_for) (src/map.c:1164): maps a list of reads in one call."""
+
+    def __init__(self, ctx, index, preset="map-ont", flag=MM_F_CIGAR | MM_F_OUT_CG):
+        L = lib()
+        _bind_map(L)
+        self.ctx, self.index = ctx, index
+        self._h = C.c_void_p()
+        _chk(L.wm_mapper_create(ctx._h, index._h, preset.encode() if preset else None, flag, C.byref(self._h)))
+
+    def map(self, names, seqs):
+        """names: list of str/bytes; seqs: list of bytes (ASCII). Returns (text, hits[n_hits,16], cigars, first[n+1])."""
+        L = lib()
+        n = len(seqs)
+        nm = (C.c_char_p * n)(*[x if isinstance(x, bytes) else x.encode() for x in names])
+        sq = (C.c_char_p * n)(*seqs)
+        lens = np.array([len(s) for s in seqs], np.int32)
+        text, tlen = C.c_char_p(), C.c_size_t()
+        hits, cig, first = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _chk(L.wm_map_reads(self._h, n, nm, sq, lens.ctypes.data, C.byref(text), C.byref(tlen), C.byref(hits), C.byref(cig), C.byref(first)))
+        fa = np.ctypeslib.as_array(C.cast(first, C.POINTER(C.c_int64)), shape=(n + 1,)).copy()
+        nh = int(fa[n])
+        ha = np.ctypeslib.as_array(C.cast(hits, C.POINTER(C.c_int32)), shape=(nh, 16)).copy() if nh else np.zeros((0, 16), np.int32)
+        nc = int(ha[:, 7].sum()) if nh else 0
+        ca = np.ctypeslib.as_array(C.cast(cig, C.POINTER(C.c_uint32)), shape=(nc,)).copy() if nc else np.zeros(0, np.uint32)
+        return C.string_at(text, tlen.value), ha, ca, fa
+
+    def stats(self):
+        a = np.zeros(9, np.uint64)
+        lib().wm_mapper_stats(self._h, a.ctypes.data)
+        return dict(zip(STAT_NAMES, (int(x) for x in a)))
+
+    def close(self):
+        if self._h:
+            lib().wm_mapper_destroy(self._h)
+            self._h = C.c_void_p()
