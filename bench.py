@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""bench.py — mapped Gbp/s of the seed→chain→align hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL; see the contract in the task statement)
+
+Workload (BASELINE.json configs[1]): 15 kb ONT-profile reads (3 % sub, 3 % ins, 4 % del, 1 % of
+reads with one SV) against a 250 Mb synthetic reference (25 contigs x 10 Mb, 10 % repeat families incl. 171-bp
+satellite arrays), `-W` list = canonical 15-mers above the 0.9998-distinct threshold, preset map-ont, CIGARs on.
+A STEP = one batch of reads (--reads-per-step per rank) through the full path: sketch → seed → chain → ksw kernels with
+the host MCAS glue in between; reads shard across ranks (weak scaling: per-GPU work is fixed), no data-path collective.
+The reference index is built by rank 0 and broadcast with RCCL (torch.distributed "nccl") as flat arrays.
+
+`value` = read bases of all ranks mapped in the timed steps / wall time, inputs resident on the host as the C-ABI takes
+host buffers for reads (the PCIe-inclusive figure is therefore what is reported).
+`roofline`: dominant kernel = ksw_dp (1 B of traceback per DP cell is > 99 % of the path's algorithmic bytes);
+achieved = DP cells of the timed steps ÷ the kernels' summed duration (HIP events on their streams).
+`cpu_baseline`: the REAL reference (oracle/_ref/winnowmap_ref, built from /root/reference) mapping a bounded sample of
+the same reads against the same reference on this host with -t <all cores>; mapping-phase wall time only.
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from winnowmap_amd import gpu, synth  # noqa: E402
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def make_workload(ref_mb, tmp):
+    n_contigs = max(1, int(round(ref_mb / 10.0)))
+    clen = int(ref_mb * 1e6 / n_contigs)
+    t0 = time.time()
+    ref = synth.make_reference(n_contigs, clen, 3, repeat_frac=0.10)
+    fa = os.path.join(tmp, "ref.fa")
+    synth.write_fasta(fa, ref, prefix="ctg")
+    kf = os.path.join(tmp, "repetitive_k15.txt")
+    n_k = gpu.write_repetitive_kmers(fa, 15, kf)
+    log("reference %d x %d bp, -W list %d k-mers (%.1fs)" % (n_contigs, clen, n_k, time.time() - t0))
+    return ref, fa, kf
+
+
+def cpu_reference_baseline(fa, kf, reads, tmp, n_cores):
+    """Map a bounded sample with the real reference binary; mapping phase = Real time − 'loaded/built the index' stamp."""
+    binp = os.path.join(ROOT, "oracle", "_ref", "winnowmap_ref")
+    if not os.path.exists(binp):
+        return None
+    rq = os.path.join(tmp, "sample.fa")
+    with open(rq, "wb") as f:
+        for i, s in enumerate(reads):
+            f.write(b">s%d\n" % i)
+            f.write(s)
+            f.write(b"\n")
+    t0 = time.time()
+    p = subprocess.run([binp, "-t", str(n_cores), "-W", kf, "-ax", "map-ont", fa, rq], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    wall = time.time() - t0
+    err = p.stderr.decode(errors="ignore")
+    m_idx = re.search(r"\[M::main::([0-9.]+)\*[0-9.]+\] loaded/built the index", err)
+    m_end = re.search(r"Real time: ([0-9.]+) sec", err)
+    if p.returncode != 0 or not m_idx or not m_end:
+        log("reference baseline failed (rc=%d)" % p.returncode)
+        return None
+    t_map = float(m_end.group(1)) - float(m_idx.group(1))
+    bases = sum(len(s) for s in reads)
+    log("reference CPU baseline: %d reads, index %.1fs, mapping %.2fs on %d threads (wall %.1fs)" % (len(reads), float(m_idx.group(1)), t_map, n_cores, wall))
+    return {"value": bases / t_map / 1e9, "unit": "Gbp/s", "cores": n_cores, "kind": "reference",
+            "sample": "%d x 15 kb reads of the same workload, winnowmap_ref -t %d -W -ax map-ont, mapping phase %.2f s (index build %.1f s excluded)" % (len(reads), n_cores, t_map, float(m_idx.group(1)))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads-per-step", type=int, default=int(os.environ.get("WM_BENCH_READS", 4096)))
+    ap.add_argument("--ref-mb", type=float, default=float(os.environ.get("WM_BENCH_REF_MB", 250)))
+    ap.add_argument("--read-len", type=int, default=15000)
+    ap.add_argument("--threads", type=int, default=int(os.environ.get("WM_BENCH_THREADS", 0)))
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("WM_BENCH_CPU_SAMPLE", 4096)))
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
+    n_cores = os.cpu_count() or 1
+    n_threads = args.threads or max(1, min(32, n_cores // max(1, world) // 2))
+    tmp = tempfile.mkdtemp(prefix="wmbench_")
+
+    # ---- reference + index: rank 0 builds, RCCL broadcasts the flat arrays ----
+    t0 = time.time()
+    if rank == 0:
+        ref, fa, kf = make_workload(args.ref_mb, tmp)
+        idx = gpu.Index(fa, kf, k=15, w=50, n_threads=min(64, n_cores))
+        log("index: %d minimizers (%.1fs)" % (idx.n_minimizers, time.time() - t0))
+    if world > 1:
+        dev = torch.device("cuda", local)
+        if rank == 0:
+            sizes, arrs = idx.export_arrays()
+            st = torch.from_numpy(sizes.astype(np.int64)).to(dev)
+        else:
+            st = torch.zeros(9, dtype=torch.int64, device=dev)
+        dist.broadcast(st, 0)
+        sizes_b = st.cpu().numpy().astype(np.uint64)
+        n = [int(sizes_b[0]), int(sizes_b[1]), int(sizes_b[1]), int(sizes_b[2]), int(sizes_b[3]), 2 * int(sizes_b[4]), int(sizes_b[5])]
+        dts = (np.uint32, np.uint64, np.uint64, np.uint64, np.uint8, np.uint64, np.uint8)
+        recv = []
+        for i, (m, dt) in enumerate(zip(n, dts)):
+            nbytes = max(m, 1) * np.dtype(dt).itemsize
+            if rank == 0:
+                t = torch.from_numpy(arrs[i].view(np.uint8)).to(dev)
+            else:
+                t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            dist.broadcast(t, 0)                      # RCCL over xGMI
+            recv.append(t.cpu().numpy().view(dt))
+        if rank != 0:
+            idx = gpu.Index.from_arrays(sizes_b, recv)
+        # every rank regenerates the (seeded) reference only to draw its reads from it
+        if rank != 0:
+            n_contigs = max(1, int(round(args.ref_mb / 10.0)))
+            ref = synth.make_reference(n_contigs, int(args.ref_mb * 1e6 / n_contigs), 3, repeat_frac=0.10)
+    ctx = gpu.Context(local, (6 << 30) if n_threads > 1 else (24 << 30))
+    idx.upload(ctx)
+    mapper = gpu.Mapper(ctx, idx, "map-ont", gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
+    if n_threads > 1:
+        mapper.set_threads(n_threads, 6 << 30)
+
+    # ---- reads: a fresh batch per step, generated before the clock starts ----
+    t1 = time.time()
+    n_steps = args.warmup + args.steps
+    reads, _ = synth.make_reads(ref, n_steps * args.reads_per_step, args.read_len, 4 + 1000 * rank, profile="ont", sv_frac=0.01)
+    seqs = [synth.codes_to_ascii(r) for r in reads]
+    names = [("r%d_%d" % (rank, i)).encode() for i in range(len(seqs))]
+    batches = [(names[i * args.reads_per_step:(i + 1) * args.reads_per_step], seqs[i * args.reads_per_step:(i + 1) * args.reads_per_step]) for i in range(n_steps)]
+    log("rank %d: %d reads generated (%.1fs), %d host threads" % (rank, len(seqs), time.time() - t1, n_threads))
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for b in batches[:args.warmup]:
+        mapper.map(*b)
+    sync()
+    t_start = time.time()
+    cells = ksw_us = aux_us = bases = hits = 0
+    for b in batches[args.warmup:]:
+        text, h, _, _ = mapper.map(*b)
+        st = mapper.stats()
+        cells += st["dp_cells"]; ksw_us += st["ksw_kernel_us"]; aux_us += st["aux_kernel_us"]; bases += st["read_bases"]; hits += len(h)
+    sync()
+    elapsed = time.time() - t_start
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tb = torch.tensor([bases, cells], dtype=torch.float64, device=torch.device("cuda", local))
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        total_bases = float(tb[0].item())
+    else:
+        total_bases = float(bases)
+
+    if rank == 0:
+        value = total_bases / elapsed / 1e9
+        ach = cells / max(ksw_us, 1) / 1e3            # bytes (=cells) per microsecond → GB/s
+        out = {
+            "metric": "mapped Gbp/s", "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int8", "data": "synthetic",
+            "config": {"workload": "%d x %d bp ONT-profile reads per step per GPU vs %.0f Mb synthetic reference (10%% repeats), -W repetitive_k15.txt -x map-ont, CIGAR on"
+                                   % (args.reads_per_step, args.read_len, args.ref_mb),
+                       "reads_per_step_per_gpu": args.reads_per_step, "read_len": args.read_len, "ref_mb": args.ref_mb, "host_threads": n_threads,
+                       "reads_per_s": total_bases / args.read_len / elapsed, "hits": hits, "parallelism": "reads sharded over %d rank(s), index broadcast" % world},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                         "kernel": "ksw_dp_kernel<B,CLIP,HASN> (+ksw_generic)", "algorithmic_bytes": "1 B traceback per DP cell",
+                         "dp_cells": cells, "ksw_kernel_s": ksw_us / 1e6, "aux_kernel_s": aux_us / 1e6, "gcups": cells / max(ksw_us, 1) / 1e3},
+        }
+        if world == 1:
+            sample = [s for _, ss in batches[args.warmup:] for s in ss][:args.cpu_sample]
+            try:
+                out["cpu_baseline"] = cpu_reference_baseline(fa, kf, sample, tmp, n_cores)
+            except Exception as e:  # noqa: BLE001
+                log("cpu baseline error:", e)
+                out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

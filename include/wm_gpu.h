@@ -11,9 +11,10 @@
  *                           with q2=q, e2=e (equivalence validated in tests).
  *   wm_sketch_batch       ← mm_sketch       src/mmpriv.h:61  (src/sketch.c:128-219) incl. the bloom
  *                           down-weighting of applyWeight src/sketch.c:70-89.
- *   wm_seed_chain_batch   ← collect_seed_hits src/map.c:222-254 (mm_idx_get src/index.c:88,
- *                           radix_sort_128x src/ksort.h:101-151) + mm_chain_dp src/mmpriv.h:73
- *                           (src/chain.c:22-167).
+ *   wm_seed_batch         ← collect_seed_hits src/map.c:222-254 (mm_idx_get src/index.c:88,
+ *                           radix_sort_128x src/ksort.h:101-151)
+ *   wm_chain_batch        ← mm_chain_dp src/mmpriv.h:73 (src/chain.c:22-167)
+ *   wm_map_reads          ← kt_for(worker_for) → mm_map_frag, src/map.c:1164, 1008, 279-974
  *   wm_index_upload       ← the in-memory mm_idx_t (src/minimap.h:66-77) flattened for HBM.
  *
  * Batched forms do not exist in the reference; they are what the replacement of
@@ -111,6 +112,17 @@ uint64_t wm_index_n_minimizers(const wm_index_t *idx);
 /* mm_idx_get (src/mmpriv.h:71): pointer into index memory (never freed by the caller), *n = 0 when absent */
 const uint64_t *wm_index_get(const wm_index_t *idx, uint64_t minier, int *n);
 
+/* The `-W` list of a FASTA (canonical k-mers above the 0.9998-distinct count threshold, README.md:29-30): what
+ * `meryl count k=15` + `meryl print greater-than distinct=0.9998` produce; meryl cannot be built offline. */
+int wm_write_repetitive_kmers(const char *fasta, int k, double distinct, const char *out_path, uint64_t *n_out);
+/* Flat-array export / import (multi-GPU: one rank builds, RCCL broadcasts the arrays, the others import).
+ * Call wm_index_export with S == NULL to obtain sizes9 = {|S| u32, |hkey|=|hval| u64, |P| u64, |bloom| bytes,
+ * n_seq, name bytes, packed k/w/hbits/flag, bloom bits, bloom salts}; seq_meta holds (offset, len) per sequence. */
+int wm_index_export(const wm_index_t *idx, uint64_t *sizes9, uint32_t *S, uint64_t *hkey, uint64_t *hval, uint64_t *P, uint8_t *bloom,
+                    uint64_t *seq_meta, char *names);
+int wm_index_import(const uint64_t *sizes9, const uint32_t *S, const uint64_t *hkey, const uint64_t *hval, const uint64_t *P, const uint8_t *bloom,
+                    const uint64_t *seq_meta, const char *names, wm_index_t **out);
+
 /* ---- sketch / seed / chain, batched (need wm_index_upload first) ------------------------------------ */
 /* mm_sketch of n sequences of 0..4 codes (rid = 0). Minimizers of sequence i: out[out_off[i] .. +counts[i]). */
 int wm_sketch_batch(wm_ctx_t *ctx, int n, const uint8_t *seqs, size_t seqs_bytes, const uint64_t *seq_off, const int32_t *len,
@@ -133,6 +145,8 @@ typedef struct wm_mapper_s wm_mapper_t;
  * flag: mm_mapopt_t::flag bits to OR in (MM_F_CIGAR 0x4, MM_F_OUT_SAM 0x8, MM_F_OUT_CG 0x20, ...). */
 int wm_mapper_create(wm_ctx_t *ctx, const wm_index_t *idx, const char *preset, int64_t flag, wm_mapper_t **out);
 void wm_mapper_destroy(wm_mapper_t *m);
+/* host parallelism: n_threads scheduler threads, each with its own HIP stream + arena slice (0 = same size as ctx) */
+int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena_bytes_per_thread);
 /* Map n reads (ASCII). Output records (PAF, or SAM when MM_F_OUT_SAM) of all reads in input order are appended to
  * an internal buffer returned through *text / *text_len (valid until the next call). hits (optional, 16 int32 per
  * hit: rid rs re qs qe rev mapq n_cigar score cnt mlen blen dp_score dp_max dp_max2 flags) and their CIGARs are

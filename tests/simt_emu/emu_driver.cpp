@@ -111,9 +111,13 @@ int emu_chain_fill(int64_t n, const uint64_t *ax, const uint64_t *ay, int max_di
 	std::vector<wm128_t> a(n + 1);
 	for (int64_t i = 0; i < n; ++i) a[i].x = ax[i], a[i].y = ay[i];
 	wm_chain_job_t jb = { 0, (int)n, max_dist_x, min_dist_x, max_dist_y, bw, max_skip, max_iter, avg_qspan, gap_scale, 0 };
-	std::vector<int> t(n + 1);
+	// test hook: bits 16.. of max_skip choose the LDS window (default 4096) so that wrap-around can be exercised on small inputs
+	int W = 4096;
+	if (max_skip >> 16) { W = max_skip >> 16; jb.max_skip &= 0xffff; }
+	std::vector<int> gt(n + 1), sf(W), sp(W), sv(W), stt(W);
+	std::vector<uint64_t> sx(W), sy(W);
 	simt::exec_mask() = ~0ull;
-	wmk::chain_wave(jb, a.data(), f, p, v, t.data());
+	wmk::chain_wave(jb, a.data(), W, sx.data(), sy.data(), sf.data(), sp.data(), sv.data(), stt.data(), f, p, v, gt.data());
 	return 0;
 }
 

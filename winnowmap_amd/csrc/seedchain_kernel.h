@@ -129,82 +129,132 @@ WM_DEV V<int> ilog2_pos(V<int> v)
 	return r;
 }
 
-// f, p, v, t: n ints each (global scratch or LDS). a: anchors sorted by x.
-WM_DEV void chain_wave(const wm_chain_job_t jb, const wm128_t *anchor_pool, int *f, int *p, int *v, int *t)
+// LDS holds a circular window of the W most recent anchors (W a power of two): their x, y and f, p, v, t — 32 B per
+// anchor — so every dependent access of the sequential part is an LDS round trip. f, p, v are also written through
+// to the global result slab gf/gp/gv (and marks to gt) so that predecessors older than the window, which the
+// reference may still visit when min_dist_x relaxes max_iter inside dense repeats (src/chain.c:51-55), are served
+// from global memory (L1-bypassing loads). For n <= W nothing ever leaves the window.
+WM_DEV void chain_wave(const wm_chain_job_t jb, const wm128_t *anchor_pool, int W, uint64_t *sx, uint64_t *sy, int *sf, int *sp, int *sv, int *st_,
+                       int *gf, int *gp, int *gv, int *gt)
 {
 	const V<int> ln = lane();
 	const uint64_t *a = (const uint64_t*)(anchor_pool + jb.a_off);
 	const int n = jb.n;
-	for (int i0 = 0; i0 < n; i0 += 64) WM_IF(ln + i0 < n) cst(t, ln + i0, V<int>(0)); WM_END
+	const long long wm = (long long)W - 1;
+	const bool wraps = n > W;
+	if (wraps)
+		for (int i0 = 0; i0 < n; i0 += 64) WM_IF(ln + i0 < n) cst(gt, cast<long long>(ln) + (long long)i0, V<int>(0)); WM_END
 	long long st = 0;
 	for (int i = 0; i < n; ++i) {
-		const uint64_t ri = gld(a, (long long)i * 2), yi = gld(a, (long long)i * 2 + 1);
+		if ((i & 63) == 0) {                                  // stage the next 64 anchors (evicts anchors i-W .. i-W+63)
+			const V<long long> k = cast<long long>(ln) + (long long)i;
+			WM_IF(k < (long long)n)
+				gst(sx, k & wm, gld(a, k * 2LL)); gst(sy, k & wm, gld(a, k * 2LL + 1LL)); gst(st_, k & wm, V<int>(0));
+			WM_END
+			mem_sync();
+		}
+		const long long lo = (long long)(i & ~63) + 64 - W;   // anchors >= lo are resident in LDS
+		const uint64_t ri = gld(sx, (long long)i & wm), yi = gld(sy, (long long)i & wm);
 		const int qi = (int)(uint32_t)yi, span = (int)(yi >> 32 & 0xff);
 		int max_f = span, n_skip = 0;
 		long long max_j = -1;
-		while (st < i && ri > gld(a, st * 2) + (uint64_t)jb.max_dist_x) ++st;                       // :50
-		if (i - st > jb.max_iter)                                                                  // :51-55
-			while (i - st > jb.max_iter && ri > gld(a, st * 2) + (uint64_t)jb.min_dist_x) ++st;
+		while (st < i && ri > (st >= lo ? gld(sx, st & wm) : gld(a, st * 2)) + (uint64_t)jb.max_dist_x) ++st;             // :50
+		if (i - st > jb.max_iter)                                                                                          // :51-55
+			while (i - st > jb.max_iter && ri > (st >= lo ? gld(sx, st & wm) : gld(a, st * 2)) + (uint64_t)jb.min_dist_x) ++st;
 		bool stop = false;
-		for (long long hi = (long long)i - 1; hi >= st && !stop; hi -= 64) {
-			const V<long long> j = V<long long>(hi) - cast<long long>(ln);                          // lane 0 = first visited
-			const vbool in = j >= st;
-			V<int> sc = 0, pj = -1;
-			vbool valid = in && !in;                                                               // false
-			WM_IF(in)
-				const V<uint64_t> xj = gld(a, j * 2LL), yj = gld(a, j * 2LL + 1LL);
-				const V<long long> dr = cast<long long>(V<uint64_t>(ri) - xj);
-				const V<int> dq = V<int>(qi) - cast<int>(cast<uint32_t>(yj));
-				valid = !(dr == 0LL || dq <= 0) && !(dq > jb.max_dist_y || dq > jb.max_dist_x);    // :60-61
-				const V<long long> dql = cast<long long>(dq);
-				const V<int> dd = cast<int>(sel(dr > dql, dr - dql, dql - dr));
-				valid = valid && !(dd > jb.bw);                                                    // :63
-				const V<int> drc = cast<int>(sel(dr > (long long)0x7fffffff, V<long long>(0x7fffffff), dr));
-				const V<int> md = vmin(dq, drc);
-				V<int> s0 = vmin(md, V<int>(span));                                                // :65-66
-				const V<int> lg = sel(dd > 0, ilog2_pos(dd), 0);
-				const V<double> lin = cast<double>(dd) * .01 * (double)jb.avg_qspan;
-				const V<int> gc = cast<int>(lin) + (lg >> 1);                                      // :76
-				s0 = s0 - cast<int>(cast<double>(gc) * (double)jb.gap_scale + .499);               // :77
-				sc = s0 + cld(f, j);
-				pj = cld(p, j);
-			WM_END
-			// marks: every scored predecessor marks ITS predecessor (src/chain.c:86); scatter, then read own mark
-			WM_IF(valid && pj >= 0) cst(t, pj, V<int>(i)); WM_END
-			V<int> tj = 0;
-			WM_IF(valid) tj = cld(t, j); WM_END
-			// running maximum before each lane (strict improvement test of :79)
-			V<int> key = sel(valid, sc, V<int>(-0x7fffffff - 1));
-			V<int> pm = key;
-			for (int o = 1; o < 64; o <<= 1) pm = vmax(pm, sel(ln >= o, shr_n(pm, o), V<int>(-0x7fffffff - 1)));
-			const V<int> before = vmax(sel(ln >= 1, shr_n(pm, 1), V<int>(-0x7fffffff - 1)), V<int>(max_f));
-			const vbool improve = valid && sc > before;
-			const vbool marked = valid && !improve && tj == i;
-			uint64_t I = ballot(improve), M = ballot(marked);
-			// replay n_skip over the events in visiting order
-			int brk = 64;
-			uint64_t ev = I | M;
-			while (ev) {
-				const int l = __builtin_ctzll(ev);
-				ev &= ev - 1;
-				if (I >> l & 1) { if (n_skip > 0) --n_skip; }
-				else if (++n_skip > jb.max_skip) { brk = l; break; }
+		// U tiles (64 predecessors each) are scored together so that their memory latencies overlap; the sequential
+		// automaton is then replayed tile by tile. Marks of a later tile never target an earlier one (p[j] < j), and
+		// marks written for tiles behind a break are harmless (they are only compared with this i).
+		constexpr int U = 4;
+		for (long long hi0 = (long long)i - 1; hi0 >= st && !stop; hi0 -= 64 * U) {
+			V<int> sc[U], tj[U];
+			vbool valid[U];
+			V<long long> jj[U];
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+				const V<long long> j = V<long long>(hi0 - 64 * u) - cast<long long>(ln);            // lane 0 = first visited
+				jj[u] = j;
+				const vbool in = j >= st, res = j >= lo;
+				V<int> pj = -1, fj = 0;
+				V<uint64_t> xj = (uint64_t)0, yj = (uint64_t)0;
+				sc[u] = 0; tj[u] = 0;
+				valid[u] = in && !in;                                                              // false
+				WM_IF(in && res) xj = gld(sx, j & wm); yj = gld(sy, j & wm); fj = gld(sf, j & wm); pj = gld(sp, j & wm); WM_END
+				WM_IF(in && !res) xj = gld(a, j * 2LL); yj = gld(a, j * 2LL + 1LL); fj = cld(gf, j); pj = cld(gp, j); WM_END
+				WM_IF(in)
+					const V<long long> dr = cast<long long>(V<uint64_t>(ri) - xj);
+					const V<int> dq = V<int>(qi) - cast<int>(cast<uint32_t>(yj));
+					vbool ok = !(dr == 0LL || dq <= 0) && !(dq > jb.max_dist_y || dq > jb.max_dist_x);   // :60-61
+					const V<long long> dql = cast<long long>(dq);
+					const V<int> dd = cast<int>(sel(dr > dql, dr - dql, dql - dr));
+					ok = ok && !(dd > jb.bw);                                                      // :63
+					const V<int> drc = cast<int>(sel(dr > (long long)0x7fffffff, V<long long>(0x7fffffff), dr));
+					const V<int> md = vmin(dq, drc);
+					V<int> s0 = vmin(md, V<int>(span));                                            // :65-66
+					const V<int> lg = sel(dd > 0, ilog2_pos(dd), 0);
+					const V<double> lin = cast<double>(dd) * .01 * (double)jb.avg_qspan;
+					const V<int> gc = cast<int>(lin) + (lg >> 1);                                  // :76
+					s0 = s0 - cast<int>(cast<double>(gc) * (double)jb.gap_scale + .499);           // :77
+					sc[u] = s0 + fj;
+					valid[u] = ok;
+				WM_END
+				// marks (src/chain.c:86): a scored predecessor marks ITS predecessor, if that one can still be visited
+				const V<long long> pjl = cast<long long>(pj);
+				WM_IF(valid[u] && pj >= 0 && pjl >= lo) gst(st_, pjl & wm, V<int>(i)); WM_END
+				WM_IF(valid[u] && pj >= 0 && pjl < lo && pjl >= st) cst(gt, pjl, V<int>(i)); WM_END
 			}
-			uint64_t Ib = brk < 64 ? I & (((uint64_t)1 << brk) - 1) : I;
-			if (Ib) {
-				const int l = 63 - __builtin_clzll(Ib);
-				max_f = readlane(sc, l);
-				max_j = hi - l;
+			mem_sync();
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+				const vbool res = jj[u] >= lo;
+				WM_IF(valid[u] && res) tj[u] = gld(st_, jj[u] & wm); WM_END
+				WM_IF(valid[u] && !res) tj[u] = cld(gt, jj[u]); WM_END
 			}
-			if (brk < 64) stop = true;
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+				if (stop || hi0 - 64 * u < st) break;
+				const long long hi = hi0 - 64 * u;
+				// does any lane beat the running maximum? (strict improvement test of :79 needs the maximum BEFORE each lane)
+				const V<int> key = sel(valid[u], sc[u], V<int>(-0x7fffffff - 1));
+				uint64_t I = 0;
+				if (ballot(key > max_f)) {
+					V<int> pm = key;
+					for (int o = 1; o < 64; o <<= 1) pm = vmax(pm, sel(ln >= o, shr_n(pm, o), V<int>(-0x7fffffff - 1)));
+					const V<int> before = vmax(sel(ln >= 1, shr_n(pm, 1), V<int>(-0x7fffffff - 1)), V<int>(max_f));
+					I = ballot(valid[u] && sc[u] > before);
+				}
+				const uint64_t M = ballot(valid[u] && tj[u] == i) & ~I;
+				int brk = 64;                                  // replay n_skip over the events in visiting order
+				uint64_t ev = I | M;
+				while (ev) {
+					const int l = __builtin_ctzll(ev);
+					ev &= ev - 1;
+					if (I >> l & 1) { if (n_skip > 0) --n_skip; }
+					else if (++n_skip > jb.max_skip) { brk = l; break; }
+				}
+				const uint64_t Ib = brk < 64 ? I & (((uint64_t)1 << brk) - 1) : I;
+				if (Ib) {
+					const int l = 63 - __builtin_clzll(Ib);
+					max_f = readlane(sc[u], l);
+					max_j = hi - l;
+				}
+				if (brk < 64) stop = true;
+			}
 		}
+		int vi = max_f;
+		if (max_j >= 0) { const int vm = max_j >= lo ? gld(sv, max_j & wm) : cld(gv, max_j); if (vm > max_f) vi = vm; }
 		WM_IF(ln == 0)
-			cst(f, (long long)i, max_f); cst(p, (long long)i, (int)max_j);
-			int vi = max_f;
-			if (max_j >= 0) { const int vm = cld(v, max_j); if (vm > max_f) vi = vm; }
-			cst(v, (long long)i, vi);
+			const V<long long> ii = (long long)i;
+			gst(sf, ii & wm, V<int>(max_f)); gst(sp, ii & wm, V<int>((int)max_j)); gst(sv, ii & wm, V<int>(vi));
+			if (wraps) { cst(gf, ii, V<int>(max_f)); cst(gp, ii, V<int>((int)max_j)); cst(gv, ii, V<int>(vi)); }
 		WM_END
+		mem_sync();
 	}
+	if (!wraps)                                                // everything stayed in the window: one coalesced copy-out
+		for (int i0 = 0; i0 < n; i0 += 64) {
+			const V<long long> k = cast<long long>(ln) + (long long)i0;
+			WM_IF(k < (long long)n) gst(gf, k, gld(sf, k)); gst(gp, k, gld(sp, k)); gst(gv, k, gld(sv, k)); WM_END
+		}
 }
 
 } // namespace wmk

@@ -10,6 +10,7 @@
 #include <vector>
 #include <algorithm>
 #include <numeric>
+#include <thread>
 #include "simt.h"
 #include "ksw_kernel.h"
 #include "ksw_plan.h"
@@ -115,7 +116,7 @@ struct wm_ctx_s {
 	uint8_t *d_bloom;
 	int hbits;
 	wm_sketch_params_t skp;
-	bool have_index;
+	bool have_index, owns_index;
 };
 
 struct wm_ksw_dev_batch_s {
@@ -160,7 +161,7 @@ extern "C" int wm_ctx_create(int device, size_t arena_bytes, wm_ctx_t **out)
 	HIPCHK(hipMalloc((void**)&c->arena, arena_bytes));
 	HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 	for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
-	c->arena_used = 0; c->last_ms = 0; c->aux_ms = 0; c->have_index = false; c->d_hkey = c->d_hval = c->d_P = 0; c->d_bloom = 0;
+	c->arena_used = 0; c->last_ms = 0; c->aux_ms = 0; c->have_index = false; c->owns_index = false; c->d_hkey = c->d_hval = c->d_P = 0; c->d_bloom = 0;
 	*out = c;
 	return WM_OK;
 }
@@ -173,7 +174,7 @@ extern "C" void wm_ctx_destroy(wm_ctx_t *c)
 	for (int i = 0; i < 4; ++i) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream);
 	hipFree(c->arena);
-	if (c->have_index) { hipFree(c->d_hkey); hipFree(c->d_hval); hipFree(c->d_P); hipFree(c->d_bloom); }
+	if (c->have_index && c->owns_index) { hipFree(c->d_hkey); hipFree(c->d_hval); hipFree(c->d_P); hipFree(c->d_bloom); }
 	delete c;
 }
 
@@ -426,6 +427,7 @@ extern "C" int wm_ksw_extd2(wm_ctx_t *c, int qlen, const uint8_t *query, int tle
 #include "host/wm_align.cpp"
 #include "host/wm_mapper.cpp"
 #include "host/wm_format.cpp"
+#include "host/wm_kmers.cpp"
 
 struct wm_index_s { wm::Index ix; };
 
@@ -445,12 +447,16 @@ __global__ __launch_bounds__(64) void seed_kernel(wm_index_view_t ix, const wm_s
 	wmk::seed_wave(ix, jobs[j], mini, anchors, occ_scratch + occ_off[j], res + j);
 }
 
-__global__ __launch_bounds__(64) void chain_kernel(const wm_chain_job_t *jobs, const int *order, const wm128_t *anchors, int *fpvt)
+// chain DP fill: one wave per anchor set, LDS window of W anchors (32 B each), results written through to fpvt
+__global__ __launch_bounds__(64) void chain_kernel(const wm_chain_job_t *jobs, const int *order, const wm128_t *anchors, int *fpvt, int W)
 {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int j = order[blockIdx.x];
 	const wm_chain_job_t jb = jobs[j];
-	int *f = fpvt + jb.a_off * 4, *p = f + jb.n, *v = p + jb.n, *t = v + jb.n;
-	wmk::chain_wave(jb, anchors, f, p, v, t);
+	uint64_t *sx = (uint64_t*)smem, *sy = sx + W;
+	int *sf = (int*)(sy + W), *sp = sf + W, *sv = sp + W, *st = sv + W;
+	int *gf = fpvt + jb.a_off * 4, *gp = gf + jb.n, *gv = gp + jb.n, *gt = gv + jb.n;
+	wmk::chain_wave(jb, anchors, W, sx, sy, sf, sp, sv, st, gf, gp, gv, gt);
 }
 
 extern "C" float wm_last_aux_ms(const wm_ctx_t *c) { return c ? c->aux_ms : 0.f; }
@@ -467,6 +473,52 @@ extern "C" int wm_index_build(const char *fasta, const char *kmer_file, int k, i
 	return WM_OK;
 }
 extern "C" void wm_index_destroy(wm_index_t *h) { delete h; }
+
+namespace wm { int write_repetitive_kmers(const std::vector<std::string> &seqs, int k, double distinct, const std::string &out_path, uint64_t *n_out, std::string &err); }
+// the -W list of a FASTA file (what `meryl count k=15` + `meryl print greater-than distinct=0.9998` would give)
+extern "C" int wm_write_repetitive_kmers(const char *fasta, int k, double distinct, const char *out_path, uint64_t *n_out)
+{
+	std::vector<std::string> names, seqs; std::string err;
+	if (wm::read_fastx(fasta, names, seqs, 0, 0, err) < 0) return set_err(WM_EINVAL, "%s", err.c_str());
+	if (wm::write_repetitive_kmers(seqs, k, distinct, out_path, n_out, err) < 0) return set_err(WM_EINVAL, "%s", err.c_str());
+	return WM_OK;
+}
+
+// flat-array export / import of an index: what travels over RCCL when one rank builds and the others receive
+// (sizes first, then the caller allocates and calls again with the buffers).
+extern "C" int wm_index_export(const wm_index_t *h, uint64_t *sizes9, uint32_t *S, uint64_t *hkey, uint64_t *hval, uint64_t *P, uint8_t *bloom, uint64_t *seq_meta, char *names)
+{
+	const wm::Index &ix = h->ix;
+	size_t name_bytes = 0;
+	for (auto &r : ix.seq) name_bytes += r.name.size() + 1;
+	sizes9[0] = ix.S.size(); sizes9[1] = ix.hkey.size(); sizes9[2] = ix.P.size(); sizes9[3] = ix.bloom.bits.size(); sizes9[4] = ix.seq.size(); sizes9[5] = name_bytes;
+	sizes9[6] = (uint64_t)ix.k | (uint64_t)ix.w << 8 | (uint64_t)ix.hbits << 16 | (uint64_t)ix.flag << 24;
+	sizes9[7] = ix.bloom.table_bits; sizes9[8] = (uint64_t)ix.bloom.salt[0] | (uint64_t)ix.bloom.salt[1] << 32;
+	if (!S) return WM_OK;
+	memcpy(S, ix.S.data(), ix.S.size() * 4); memcpy(hkey, ix.hkey.data(), ix.hkey.size() * 8); memcpy(hval, ix.hval.data(), ix.hval.size() * 8);
+	if (!ix.P.empty()) memcpy(P, ix.P.data(), ix.P.size() * 8);
+	memcpy(bloom, ix.bloom.bits.data(), ix.bloom.bits.size());
+	char *q = names;
+	for (size_t i = 0; i < ix.seq.size(); ++i) { seq_meta[2 * i] = ix.seq[i].offset; seq_meta[2 * i + 1] = ix.seq[i].len; memcpy(q, ix.seq[i].name.c_str(), ix.seq[i].name.size() + 1); q += ix.seq[i].name.size() + 1; }
+	return WM_OK;
+}
+extern "C" int wm_index_import(const uint64_t *sizes9, const uint32_t *S, const uint64_t *hkey, const uint64_t *hval, const uint64_t *P, const uint8_t *bloom,
+                               const uint64_t *seq_meta, const char *names, wm_index_t **out)
+{
+	wm_index_t *h = new wm_index_t();
+	wm::Index &ix = h->ix;
+	ix.k = (int)(sizes9[6] & 0xff); ix.w = (int)(sizes9[6] >> 8 & 0xff); ix.hbits = (int)(sizes9[6] >> 16 & 0xff); ix.flag = (int)(sizes9[6] >> 24);
+	ix.S.assign(S, S + sizes9[0]); ix.hkey.assign(hkey, hkey + sizes9[1]); ix.hval.assign(hval, hval + sizes9[1]); ix.P.assign(P, P + sizes9[2]);
+	ix.bloom.table_bits = sizes9[7]; ix.bloom.salt[0] = (uint32_t)sizes9[8]; ix.bloom.salt[1] = (uint32_t)(sizes9[8] >> 32); ix.bloom.bits.assign(bloom, bloom + sizes9[3]);
+	const char *q = names;
+	ix.total_len = 0;
+	for (uint64_t i = 0; i < sizes9[4]; ++i) { wm::RefSeq r; r.offset = seq_meta[2 * i]; r.len = (uint32_t)seq_meta[2 * i + 1]; r.name = q; q += r.name.size() + 1; ix.total_len += r.len; ix.seq.push_back(r); }
+	ix.n_minimizers = ix.P.size();
+	ix.n_keys = 0;
+	for (uint64_t kk : ix.hkey) ix.n_keys += kk != ~0ULL;
+	*out = h;
+	return WM_OK;
+}
 extern "C" int wm_index_n_seq(const wm_index_t *h) { return (int)h->ix.seq.size(); }
 extern "C" const char *wm_index_seq_name(const wm_index_t *h, int rid) { return h->ix.seq[rid].name.c_str(); }
 extern "C" int wm_index_seq_len(const wm_index_t *h, int rid) { return (int)h->ix.seq[rid].len; }
@@ -479,7 +531,8 @@ extern "C" int wm_index_upload(wm_ctx_t *c, const wm_index_t *h)
 	HIPCHK(hipSetDevice(c->device));
 	const wm::Index &ix = h->ix;
 	if (ix.bloom.table_bits >= ((uint64_t)1 << 32)) return set_err(WM_EINVAL, "bloom table of %llu bits not supported on device", (unsigned long long)ix.bloom.table_bits);
-	if (c->have_index) { hipFree(c->d_hkey); hipFree(c->d_hval); hipFree(c->d_P); hipFree(c->d_bloom); c->have_index = false; }
+	if (c->have_index && c->owns_index) { hipFree(c->d_hkey); hipFree(c->d_hval); hipFree(c->d_P); hipFree(c->d_bloom); }
+	c->have_index = false;
 	HIPCHK(hipMalloc((void**)&c->d_hkey, ix.hkey.size() * 8 + 8));
 	HIPCHK(hipMalloc((void**)&c->d_hval, ix.hval.size() * 8 + 8));
 	HIPCHK(hipMalloc((void**)&c->d_P, ix.P.size() * 8 + 8));
@@ -490,7 +543,7 @@ extern "C" int wm_index_upload(wm_ctx_t *c, const wm_index_t *h)
 	HIPCHK(hipMemcpy(c->d_bloom, ix.bloom.bits.data(), ix.bloom.bits.size(), hipMemcpyHostToDevice));
 	c->hbits = ix.hbits;
 	c->skp.w = ix.w; c->skp.k = ix.k; c->skp.table_bits = (uint32_t)ix.bloom.table_bits; c->skp.salt0 = ix.bloom.salt[0]; c->skp.salt1 = ix.bloom.salt[1];
-	c->have_index = true;
+	c->have_index = true; c->owns_index = true;
 	return WM_OK;
 }
 
@@ -505,8 +558,7 @@ extern "C" int wm_sketch_batch(wm_ctx_t *c, int n, const uint8_t *seqs, size_t s
 	const int w = c->skp.w;
 	const size_t lds = (size_t)w * 64 * 12;
 	if (lds > 160 * 1024) return set_err(WM_EINVAL, "window w=%d needs %zu B of LDS per wave (max 160 KB)", w, lds);
-	static bool attr_set = false;
-	if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)sketch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+	HIPCHK(hipFuncSetAttribute((const void*)sketch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	// first try a slot of len/4+16 minimizers per sequence (typical density is 2/(w+1)); retry the rare overflow at full size
 	std::vector<wm_sketch_job_t> jobs(n);
 	std::vector<int> todo(n);
@@ -650,7 +702,18 @@ extern "C" int wm_chain_batch(wm_ctx_t *c, int n, wm128_t *a, const uint64_t *a_
 	HIPCHK(hipMemcpyAsync(d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipMemcpyAsync(d_a, a, tot * sizeof(wm128_t), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipEventRecord(c->ev[0], c->stream));
-	hipLaunchKernelGGL(chain_kernel, dim3(n), dim3(64), 0, c->stream, d_jobs, d_order, d_a, d_fpvt);
+	{   // size classes by anchor count (order is sorted by n descending): LDS footprint = 32 B * W
+		HIPCHK(hipFuncSetAttribute((const void*)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		const int caps[3] = { 4096, 1024, 256 };
+		int b = 0;
+		for (int k = 0; k < 3; ++k) {
+			const int lo = k < 2 ? caps[k + 1] : 0;          // class k holds n > lo (class 0 also takes every n > 4096: the window wraps)
+			int e = b;
+			while (e < n && n_a[order[e]] > lo) ++e;
+			if (e > b) hipLaunchKernelGGL(chain_kernel, dim3(e - b), dim3(64), (size_t)caps[k] * 32, c->stream, d_jobs, d_order + b, d_a, d_fpvt, caps[k]);
+			b = e;
+		}
+	}
 	HIPCHK(hipEventRecord(c->ev[1], c->stream));
 	std::vector<int> fpvt((tot + 1) * 4);
 	HIPCHK(hipMemcpyAsync(fpvt.data(), d_fpvt, tot * 16, hipMemcpyDeviceToHost, c->stream));
@@ -773,6 +836,7 @@ struct GpuOps : wm::DeviceOps {
 
 struct wm_mapper_s {
 	wm_ctx_t *c; const wm_index_t *idx;
+	std::vector<wm_ctx_t*> workers;        // extra contexts (own stream + arena slice) for host threads 1..T-1
 	wm::IdxOpt io; wm::MapOpt mo;
 	std::string text;
 	std::vector<int32_t> hits; std::vector<uint32_t> cigars; std::vector<int64_t> first;
@@ -796,7 +860,25 @@ extern "C" int wm_mapper_create(wm_ctx_t *c, const wm_index_t *idx, const char *
 	*out = m;
 	return WM_OK;
 }
-extern "C" void wm_mapper_destroy(wm_mapper_t *m) { delete m; }
+extern "C" void wm_mapper_destroy(wm_mapper_t *m) { if (m) { for (wm_ctx_t *w : m->workers) wm_ctx_destroy(w); delete m; } }
+
+// Host parallelism: n_threads scheduler threads, each with its own HIP stream and arena slice, map disjoint subsets of
+// a batch concurrently (kernels of different streams overlap on the GPU; the index in HBM is shared).
+extern "C" int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena_bytes_per_thread)
+{
+	if (n_threads < 1) return set_err(WM_EINVAL, "n_threads < 1");
+	for (wm_ctx_t *w : m->workers) wm_ctx_destroy(w);
+	m->workers.clear();
+	for (int t = 1; t < n_threads; ++t) {
+		wm_ctx_t *w = 0;
+		const int rc = wm_ctx_create(m->c->device, arena_bytes_per_thread ? arena_bytes_per_thread : m->c->arena_bytes, &w);
+		if (rc) return rc;
+		w->d_hkey = m->c->d_hkey; w->d_hval = m->c->d_hval; w->d_P = m->c->d_P; w->d_bloom = m->c->d_bloom; w->hbits = m->c->hbits; w->skp = m->c->skp;
+		w->have_index = true; w->owns_index = false;
+		m->workers.push_back(w);
+	}
+	return WM_OK;
+}
 
 extern "C" int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, const char *const *seqs, const int32_t *lens,
                             const char **text, size_t *text_len, const int32_t **hits, const uint32_t **cigars, const int64_t **hit_first)
@@ -804,11 +886,34 @@ extern "C" int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, con
 	std::vector<wm::ReadIn> reads(n);
 	uint64_t bases = 0;
 	for (int i = 0; i < n; ++i) { reads[i].name = names[i]; reads[i].seq.assign(seqs[i], lens[i]); bases += lens[i]; }
-	std::vector<wm::ReadOut> out;
-	GpuOps ops; ops.c = m->c;
+	std::vector<wm::ReadOut> out(n);
+	const int T = (int)m->workers.size() + 1;
+	std::vector<GpuOps> ops(T);
+	std::vector<wm::MapStats> sts(T);
+	std::vector<std::vector<wm::ReadIn>> part(T);
+	std::vector<std::vector<wm::ReadOut>> pout(T);
+	std::vector<std::vector<int>> which(T);
+	for (int i = 0; i < n; ++i) { which[i % T].push_back(i); part[i % T].push_back(std::move(reads[i])); }
+	auto work = [&](int t) {
+		ops[t].c = t == 0 ? m->c : m->workers[t - 1];
+		hipSetDevice(ops[t].c->device);
+		wm::map_batch(m->idx->ix, m->mo, &ops[t], part[t], pout[t], &sts[t]);
+	};
+	{
+		std::vector<std::thread> th;
+		for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+		work(0);
+		for (auto &x : th) x.join();
+	}
 	wm::MapStats st;
-	wm::map_batch(m->idx->ix, m->mo, &ops, reads, out, &st);
-	if (!ops.error.empty()) return set_err(WM_ENODEV, "%s", ops.error.c_str());
+	GpuOps tot; tot.c = m->c;
+	for (int t = 0; t < T; ++t) {
+		if (!ops[t].error.empty()) return set_err(WM_ENODEV, "%s", ops[t].error.c_str());
+		for (size_t k = 0; k < which[t].size(); ++k) { out[which[t][k]] = std::move(pout[t][k]); reads[which[t][k]] = std::move(part[t][k]); }
+		st.n_flush = std::max(st.n_flush, sts[t].n_flush); st.n_ksw += sts[t].n_ksw; st.n_chain += sts[t].n_chain; st.n_seed += sts[t].n_seed; st.n_sketch += sts[t].n_sketch;
+		tot.cells += ops[t].cells; tot.ksw_us += ops[t].ksw_us; tot.aux_us += ops[t].aux_us;
+	}
+	GpuOps &opsr = tot;
 	m->text.clear(); m->hits.clear(); m->cigars.clear(); m->first.assign(n + 1, 0);
 	for (int i = 0; i < n; ++i) {
 		wm::write_read(m->text, m->idx->ix, reads[i], out[i], m->mo.flag);
@@ -822,7 +927,7 @@ extern "C" int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, con
 	}
 	m->first[n] = (int64_t)(m->hits.size() / 16);
 	m->stats[0] = st.n_flush; m->stats[1] = st.n_ksw; m->stats[2] = st.n_chain; m->stats[3] = st.n_seed; m->stats[4] = st.n_sketch;
-	m->stats[5] = ops.cells; m->stats[6] = (uint64_t)ops.ksw_us; m->stats[7] = (uint64_t)ops.aux_us; m->stats[8] = bases;
+	m->stats[5] = opsr.cells; m->stats[6] = (uint64_t)opsr.ksw_us; m->stats[7] = (uint64_t)opsr.aux_us; m->stats[8] = bases;
 	if (text) *text = m->text.data();
 	if (text_len) *text_len = m->text.size();
 	if (hits) *hits = m->hits.data();

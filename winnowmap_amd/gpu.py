@@ -149,23 +149,62 @@ def _bind_map(L):
     L.wm_index_n_minimizers.argtypes = [C.c_void_p]
     L.wm_mapper_create.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(C.c_void_p)]
     L.wm_mapper_destroy.argtypes = [C.c_void_p]
+    L.wm_mapper_set_threads.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
     L.wm_map_reads.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p,
                                C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.wm_mapper_stats.argtypes = [C.c_void_p, C.c_void_p]
     L.wm_sam_header.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
     L.wm_last_aux_ms.restype = C.c_float
     L.wm_last_aux_ms.argtypes = [C.c_void_p]
+    L.wm_write_repetitive_kmers.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_char_p, C.POINTER(C.c_uint64)]
+    L.wm_index_export.argtypes = [C.c_void_p] + [C.c_void_p] * 8
+    L.wm_index_import.argtypes = [C.c_void_p] * 8 + [C.POINTER(C.c_void_p)]
     L._wm_map_bound = True
+
+
+def write_repetitive_kmers(fasta, k, out_path, distinct=0.9998):
+    """Write the -W list of `fasta` (see include/wm_gpu.h). Returns the number of k-mers written."""
+    L = lib()
+    _bind_map(L)
+    n = C.c_uint64()
+    _chk(L.wm_write_repetitive_kmers(os.fsencode(fasta), k, distinct, os.fsencode(out_path), C.byref(n)))
+    return int(n.value)
+
+
+_EXPORT_DTYPES = (np.uint32, np.uint64, np.uint64, np.uint64, np.uint8, np.uint64, np.uint8)
 
 
 class Index:
     """Reference index (host build, mm_idx_gen semantics); `upload(ctx)` copies the flat arrays to HBM."""
 
-    def __init__(self, fasta, kmer_file=None, k=15, w=50, n_threads=8):
+    def __init__(self, fasta=None, kmer_file=None, k=15, w=50, n_threads=8, _handle=None):
         L = lib()
         _bind_map(L)
         self._h = C.c_void_p()
+        if _handle is not None:
+            self._h = _handle
+            return
         _chk(L.wm_index_build(os.fsencode(fasta), os.fsencode(kmer_file) if kmer_file else None, k, w, n_threads, C.byref(self._h)))
+
+    def export_arrays(self):
+        """(sizes9, [S, hkey, hval, P, bloom, seq_meta, names]) as numpy arrays — the payload of the RCCL broadcast."""
+        L = lib()
+        sizes = np.zeros(9, np.uint64)
+        _chk(L.wm_index_export(self._h, sizes.ctypes.data, None, None, None, None, None, None, None))
+        n = [int(sizes[0]), int(sizes[1]), int(sizes[1]), int(sizes[2]), int(sizes[3]), 2 * int(sizes[4]), int(sizes[5])]
+        arrs = [np.zeros(max(m, 1), dt) for m, dt in zip(n, _EXPORT_DTYPES)]
+        _chk(L.wm_index_export(self._h, sizes.ctypes.data, *[a.ctypes.data for a in arrs]))
+        return sizes, arrs
+
+    @staticmethod
+    def from_arrays(sizes, arrs):
+        L = lib()
+        _bind_map(L)
+        h = C.c_void_p()
+        arrs = [np.ascontiguousarray(a, dt) for a, dt in zip(arrs, _EXPORT_DTYPES)]
+        sizes = np.ascontiguousarray(sizes, np.uint64)
+        _chk(L.wm_index_import(sizes.ctypes.data, *[a.ctypes.data for a in arrs], C.byref(h)))
+        return Index(_handle=h)
 
     def upload(self, ctx):
         _chk(lib().wm_index_upload(ctx._h, self._h))
@@ -197,6 +236,9 @@ class Mapper:
         self.ctx, self.index = ctx, index
         self._h = C.c_void_p()
         _chk(L.wm_mapper_create(ctx._h, index._h, preset.encode() if preset else None, flag, C.byref(self._h)))
+
+    def set_threads(self, n_threads, arena_bytes_per_thread=0):
+        _chk(lib().wm_mapper_set_threads(self._h, n_threads, arena_bytes_per_thread))
 
     def map(self, names, seqs):
         """names: list of str/bytes; seqs: list of bytes (ASCII). Returns (text, hits[n_hits,16], cigars, first[n+1])."""
