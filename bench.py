@@ -31,6 +31,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")   # before HIP initialises (see winnowmap_amd/__init__.py)
 from winnowmap_amd import gpu, synth  # noqa: E402
 
 

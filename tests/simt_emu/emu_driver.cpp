@@ -8,6 +8,7 @@
 #include "seedchain_kernel.h"
 #include <vector>
 #include <algorithm>
+#include <thread>
 
 template <int B> static void run_dp(int clip, int hasn, const wm_ksw_score_t &sc, const wm_ksw_djob_t &jb, const uint8_t *seqs, uint8_t *tb, wm_ksw_dres_t *res)
 {
@@ -117,7 +118,24 @@ int emu_chain_fill(int64_t n, const uint64_t *ax, const uint64_t *ay, int max_di
 	std::vector<int> gt(n + 1), sf(W), sp(W), sv(W), stt(W);
 	std::vector<uint64_t> sx(W), sy(W);
 	simt::exec_mask() = ~0ull;
-	wmk::chain_wave(jb, a.data(), W, sx.data(), sy.data(), sf.data(), sp.data(), sv.data(), stt.data(), f, p, v, gt.data());
+	if (max_iter >> 24) {              // test hook: bits 24.. of max_iter = number of cooperating waves (chain_block)
+		const int NWV = max_iter >> 24;
+		jb.max_iter &= 0xffffff;
+		std::vector<int> pub(NWV * 69 + 16);
+		pthread_barrier_t bar;
+		pthread_barrier_init(&bar, 0, NWV);
+		simt::block_barrier() = &bar;
+		std::vector<std::thread> th;
+		for (int w = 0; w < NWV; ++w)
+			th.emplace_back([&, w]() {
+				simt::wave_slot() = w; simt::exec_mask() = ~0ull;
+				wmk::chain_block(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), sv.data(), stt.data(), pub.data(), f, p, v, gt.data());
+			});
+		for (auto &t : th) t.join();
+		simt::block_barrier() = 0;
+		pthread_barrier_destroy(&bar);
+	} else
+		wmk::chain_wave(jb, a.data(), W, sx.data(), sy.data(), sf.data(), sp.data(), sv.data(), stt.data(), f, p, v, gt.data());
 	return 0;
 }
 

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
+#include <pthread.h>
 
 #define WM_SIMT_EMU 1
 #define WM_DEV inline
@@ -74,6 +75,13 @@ struct MaskScope {
 #define WM_ELSE } _wm_ms.flip(); if (_wm_ms.some()) {
 #define WM_END } }
 
+// multi-wave workgroups: the driver runs one host thread per wave and installs a shared barrier
+inline int &wave_slot() { static thread_local int w = 0; return w; }
+inline pthread_barrier_t *&block_barrier() { static pthread_barrier_t *b = 0; return b; }
+inline int wave_in_block() { return wave_slot(); }
+inline void block_sync() { if (block_barrier()) pthread_barrier_wait(block_barrier()); }
+inline void lds_sync() {}
+inline void block_sync_lds() { block_sync(); }
 inline V<int> lane() { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = i; return r; }
 
 template <class T> V<T> sel(const vbool &c, const V<T> &a, const V<T> &b) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }

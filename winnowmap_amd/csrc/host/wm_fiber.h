@@ -13,6 +13,8 @@
 #include <vector>
 #include <memory>
 #include <stdlib.h>
+#include <stdio.h>
+#include <chrono>
 #include "wm_ops.h"
 
 namespace wm {
@@ -74,11 +76,23 @@ private:
 	void flush()
 	{
 		++n_flush;
+		static const bool trace = getenv("WM_TRACE") != 0;
+		auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+		const double t0 = now();
+		const size_t n0 = q_sketch_.size(), n1 = q_seed_.size(), n2 = q_chain_.size(), n3 = q_ksw_.size();
 		if (!q_sketch_.empty()) { n_sketch_jobs += q_sketch_.size(); ops_->sketch_batch(w_, k_, q_sketch_); q_sketch_.clear(); wake(w_sketch_); }
+		const double t1 = now();
 		if (!q_seed_.empty()) { n_seed_jobs += q_seed_.size(); ops_->seed_batch(q_seed_); q_seed_.clear(); wake(w_seed_); }
+		const double t2 = now();
 		if (!q_chain_.empty()) { n_chain_jobs += q_chain_.size(); ops_->chain_batch(q_chain_); q_chain_.clear(); wake(w_chain_); }
+		const double t3 = now();
 		if (!q_ksw_.empty()) { n_ksw_jobs += q_ksw_.size(); ops_->ksw_batch(sc_, q_ksw_); q_ksw_.clear(); wake(w_ksw_); }
+		const double t4 = now();
+		if (trace) fprintf(stderr, "[flush %3llu] host %.1f ms | sketch %zu: %.1f ms | seed %zu: %.1f ms | chain %zu: %.1f ms | ksw %zu: %.1f ms\n",
+		                   (unsigned long long)n_flush, t0 - t_last_, n0, t1 - t0, n1, t2 - t1, n2, t3 - t2, n3, t4 - t3);
+		t_last_ = now();
 	}
+	double t_last_ = 0;
 	DeviceOps *ops_;
 	wm_ksw_score_t sc_;
 	int w_, k_;

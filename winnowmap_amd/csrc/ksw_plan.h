@@ -17,23 +17,24 @@ static inline int wm_ksw_ncol(int qlen, int tlen, int w)
 	return ((n + 15) / 16 + 1) * 16;
 }
 
-// number of hull cells the DP visits (rows x 16-aligned hull width) = traceback bytes written
+// DP cells inside the band (O(1) when the band never clips, else one pass over the target) and an estimate of the
+// 16-aligned hull cells = traceback bytes written
 static inline uint64_t wm_ksw_cells(int qlen, int tlen, int w, uint64_t *band_cells)
 {
 	if (w < 0) w = tlen > qlen ? tlen : qlen;
-	uint64_t hull = 0, band = 0;
-	for (int r = 0; r < qlen + tlen - 1; ++r) {
-		int st = 0, en = tlen - 1;
-		if (st < r - qlen + 1) st = r - qlen + 1;
-		if (en > r) en = r;
-		if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
-		if (en > (r + w) >> 1) en = (r + w) >> 1;
-		if (st > en) break;
-		band += (uint64_t)(en - st + 1);
-		hull += (uint64_t)((en + 16) / 16 * 16 - st / 16 * 16);
+	uint64_t band;
+	if (w >= qlen && w >= tlen) band = (uint64_t)qlen * tlen;
+	else {
+		band = 0;
+		for (int i = 0; i < tlen; ++i) {             // row i of the target: query columns j with |i - j| within the band
+			int lo = i - w, hi = i + w - 1;
+			if (lo < 0) lo = 0;
+			if (hi > qlen - 1) hi = qlen - 1;
+			if (hi >= lo) band += (uint64_t)(hi - lo + 1);
+		}
 	}
 	if (band_cells) *band_cells = band;
-	return hull;
+	return band + (uint64_t)16 * (uint64_t)(qlen + tlen - 1);
 }
 
 static inline int wm_ksw_has_n(const uint8_t *s, int n)

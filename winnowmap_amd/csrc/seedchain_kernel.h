@@ -151,7 +151,7 @@ WM_DEV void chain_wave(const wm_chain_job_t jb, const wm128_t *anchor_pool, int 
 			WM_IF(k < (long long)n)
 				gst(sx, k & wm, gld(a, k * 2LL)); gst(sy, k & wm, gld(a, k * 2LL + 1LL)); gst(st_, k & wm, V<int>(0));
 			WM_END
-			mem_sync();
+			lds_sync();
 		}
 		const long long lo = (long long)(i & ~63) + 64 - W;   // anchors >= lo are resident in LDS
 		const uint64_t ri = gld(sx, (long long)i & wm), yi = gld(sy, (long long)i & wm);
@@ -170,6 +170,7 @@ WM_DEV void chain_wave(const wm_chain_job_t jb, const wm128_t *anchor_pool, int 
 			V<int> sc[U], tj[U];
 			vbool valid[U];
 			V<long long> jj[U];
+			bool any_far = false;
 #pragma unroll
 			for (int u = 0; u < U; ++u) {
 				const V<long long> j = V<long long>(hi0 - 64 * u) - cast<long long>(ln);            // lane 0 = first visited
@@ -201,9 +202,11 @@ WM_DEV void chain_wave(const wm_chain_job_t jb, const wm128_t *anchor_pool, int 
 				// marks (src/chain.c:86): a scored predecessor marks ITS predecessor, if that one can still be visited
 				const V<long long> pjl = cast<long long>(pj);
 				WM_IF(valid[u] && pj >= 0 && pjl >= lo) gst(st_, pjl & wm, V<int>(i)); WM_END
-				WM_IF(valid[u] && pj >= 0 && pjl < lo && pjl >= st) cst(gt, pjl, V<int>(i)); WM_END
+				const vbool far_mark = valid[u] && pj >= 0 && pjl < lo && pjl >= st;
+				WM_IF(far_mark) cst(gt, pjl, V<int>(i)); WM_END
+				any_far = any_far || any(far_mark);
 			}
-			mem_sync();
+			if (any_far) mem_sync(); else lds_sync();             // global marks must reach L2 before they are re-read
 #pragma unroll
 			for (int u = 0; u < U; ++u) {
 				const vbool res = jj[u] >= lo;
@@ -246,12 +249,145 @@ WM_DEV void chain_wave(const wm_chain_job_t jb, const wm128_t *anchor_pool, int 
 		WM_IF(ln == 0)
 			const V<long long> ii = (long long)i;
 			gst(sf, ii & wm, V<int>(max_f)); gst(sp, ii & wm, V<int>((int)max_j)); gst(sv, ii & wm, V<int>(vi));
-			if (wraps) { cst(gf, ii, V<int>(max_f)); cst(gp, ii, V<int>((int)max_j)); cst(gv, ii, V<int>(vi)); }
+			if (wraps) { cst(gf, ii, V<int>(max_f)); cst(gp, ii, V<int>((int)max_j)); cst(gv, ii, V<int>(vi)); }   // write-through, not waited for
 		WM_END
-		mem_sync();
+		lds_sync();
 	}
 	if (!wraps)                                                // everything stayed in the window: one coalesced copy-out
 		for (int i0 = 0; i0 < n; i0 += 64) {
+			const V<long long> k = cast<long long>(ln) + (long long)i0;
+			WM_IF(k < (long long)n) gst(gf, k, gld(sf, k)); gst(gp, k, gld(sp, k)); gst(gv, k, gld(sv, k)); WM_END
+		}
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// chain_block: the same fill for LARGE anchor sets (satellite arrays: 10^4..10^6 anchors, up to max_iter = 5000
+// predecessors per anchor). A workgroup of NWV wavefronts shares one LDS window; every step scores NWV*64 predecessors
+// of anchor i (wave w takes tile w), so the serial latency per anchor drops by ~NWV. Cross-wave dependencies are the
+// marks (barrier after the scatter), the running maximum (each wave publishes its tile maximum) and the n_skip/break
+// automaton, which every wave replays redundantly from the published ballots so that all waves agree without a
+// broadcast. pub: NWV * (2 + 64 + 2) ints of LDS.
+// ------------------------------------------------------------------------------------------------------
+WM_DEV void chain_block(const wm_chain_job_t jb, const wm128_t *anchor_pool, int NWV, int W, uint64_t *sx, uint64_t *sy, int *sf, int *sp, int *sv, int *st_,
+                        int *pub, int *gf, int *gp, int *gv, int *gt)
+{
+	const V<int> ln = lane();
+	const int wv = wave_in_block();
+	const uint64_t *a = (const uint64_t*)(anchor_pool + jb.a_off);
+	const int n = jb.n;
+	const long long wm = (long long)W - 1;
+	const bool wraps = n > W;
+	int *pub_tmax = pub, *pub_mask = pub + NWV, *pub_sc = pub + NWV * 5;      // tile max | I lo,hi,M lo,hi per wave | 64 scores per wave
+	if (wraps)
+		for (int i0 = wv * 64; i0 < n; i0 += 64 * NWV) WM_IF(ln + i0 < n) cst(gt, cast<long long>(ln) + (long long)i0, V<int>(0)); WM_END
+	long long st = 0;
+	for (int i = 0; i < n; ++i) {
+		if ((i & 63) == 0) {
+			block_sync_lds();
+			if (wv == 0) {
+				const V<long long> k = cast<long long>(ln) + (long long)i;
+				WM_IF(k < (long long)n)
+					gst(sx, k & wm, gld(a, k * 2LL)); gst(sy, k & wm, gld(a, k * 2LL + 1LL)); gst(st_, k & wm, V<int>(0));
+				WM_END
+			}
+			block_sync_lds();
+		}
+		const long long lo = (long long)(i & ~63) + 64 - W;
+		const uint64_t ri = gld(sx, (long long)i & wm), yi = gld(sy, (long long)i & wm);
+		const int qi = (int)(uint32_t)yi, span = (int)(yi >> 32 & 0xff);
+		int max_f = span, n_skip = 0;
+		long long max_j = -1;
+		while (st < i && ri > (st >= lo ? gld(sx, st & wm) : gld(a, st * 2)) + (uint64_t)jb.max_dist_x) ++st;
+		if (i - st > jb.max_iter)
+			while (i - st > jb.max_iter && ri > (st >= lo ? gld(sx, st & wm) : gld(a, st * 2)) + (uint64_t)jb.min_dist_x) ++st;
+		bool stop = false;
+		for (long long hi0 = (long long)i - 1; hi0 >= st && !stop; hi0 -= 64LL * NWV) {
+			const long long hi = hi0 - 64LL * wv;                                                   // this wave's tile
+			const V<long long> j = V<long long>(hi) - cast<long long>(ln);
+			const vbool in = j >= st, res = j >= lo;
+			V<int> sc = 0, pj = -1, fj = 0, tj = 0;
+			V<uint64_t> xj = (uint64_t)0, yj = (uint64_t)0;
+			vbool valid = in && !in;
+			WM_IF(in && res) xj = gld(sx, j & wm); yj = gld(sy, j & wm); fj = gld(sf, j & wm); pj = gld(sp, j & wm); WM_END
+			WM_IF(in && !res) xj = gld(a, j * 2LL); yj = gld(a, j * 2LL + 1LL); fj = cld(gf, j); pj = cld(gp, j); WM_END
+			WM_IF(in)
+				const V<long long> dr = cast<long long>(V<uint64_t>(ri) - xj);
+				const V<int> dq = V<int>(qi) - cast<int>(cast<uint32_t>(yj));
+				vbool ok = !(dr == 0LL || dq <= 0) && !(dq > jb.max_dist_y || dq > jb.max_dist_x);
+				const V<long long> dql = cast<long long>(dq);
+				const V<int> dd = cast<int>(sel(dr > dql, dr - dql, dql - dr));
+				ok = ok && !(dd > jb.bw);
+				const V<int> drc = cast<int>(sel(dr > (long long)0x7fffffff, V<long long>(0x7fffffff), dr));
+				const V<int> md = vmin(dq, drc);
+				V<int> s0 = vmin(md, V<int>(span));
+				const V<int> lg = sel(dd > 0, ilog2_pos(dd), 0);
+				const V<double> lin = cast<double>(dd) * .01 * (double)jb.avg_qspan;
+				const V<int> gc = cast<int>(lin) + (lg >> 1);
+				s0 = s0 - cast<int>(cast<double>(gc) * (double)jb.gap_scale + .499);
+				sc = s0 + fj;
+				valid = ok;
+			WM_END
+			const V<long long> pjl = cast<long long>(pj);
+			WM_IF(valid && pj >= 0 && pjl >= lo) gst(st_, pjl & wm, V<int>(i)); WM_END
+			const vbool far_mark = valid && pj >= 0 && pjl < lo && pjl >= st;
+			WM_IF(far_mark) cst(gt, pjl, V<int>(i)); WM_END
+			if (any(far_mark)) mem_sync();
+			// publish this tile's maximum so that later tiles know the running maximum before them
+			const V<int> key = sel(valid, sc, V<int>(-0x7fffffff - 1));
+			V<int> pm = key;
+			for (int o = 1; o < 64; o <<= 1) pm = vmax(pm, sel(ln >= o, shr_n(pm, o), V<int>(-0x7fffffff - 1)));
+			WM_IF(ln == 63) gst(pub_tmax, V<int>(wv), pm); WM_END
+			block_sync_lds();                                                                      // marks + tile maxima visible
+			WM_IF(valid && res) tj = gld(st_, j & wm); WM_END
+			WM_IF(valid && !res) tj = cld(gt, j); WM_END
+			int run_max = max_f;
+			for (int w2 = 0; w2 < wv; ++w2) { const int tm = gld(pub_tmax, (long long)w2); run_max = tm > run_max ? tm : run_max; }
+			const V<int> before = vmax(sel(ln >= 1, shr_n(pm, 1), V<int>(-0x7fffffff - 1)), V<int>(run_max));
+			const uint64_t I = ballot(valid && sc > before);
+			const uint64_t M = ballot(valid && tj == i) & ~I;
+			WM_IF(ln == 0)
+				gst(pub_mask, V<int>(wv * 4), V<int>((int)(uint32_t)I)); gst(pub_mask, V<int>(wv * 4 + 1), V<int>((int)(uint32_t)(I >> 32)));
+				gst(pub_mask, V<int>(wv * 4 + 2), V<int>((int)(uint32_t)M)); gst(pub_mask, V<int>(wv * 4 + 3), V<int>((int)(uint32_t)(M >> 32)));
+			WM_END
+			gst(pub_sc, ln + wv * 64, sc);
+			block_sync_lds();                                                                      // ballots + scores visible
+			for (int w2 = 0; w2 < NWV && !stop; ++w2) {                                            // every wave replays all tiles
+				const long long hw = hi0 - 64LL * w2;
+				if (hw < st) break;
+				const uint64_t Iw = (uint64_t)(uint32_t)gld(pub_mask, (long long)w2 * 4) | (uint64_t)(uint32_t)gld(pub_mask, (long long)w2 * 4 + 1) << 32;
+				const uint64_t Mw = (uint64_t)(uint32_t)gld(pub_mask, (long long)w2 * 4 + 2) | (uint64_t)(uint32_t)gld(pub_mask, (long long)w2 * 4 + 3) << 32;
+				int brk = 64;
+				uint64_t ev = Iw | Mw;
+				while (ev) {
+					const int l = __builtin_ctzll(ev);
+					ev &= ev - 1;
+					if (Iw >> l & 1) { if (n_skip > 0) --n_skip; }
+					else if (++n_skip > jb.max_skip) { brk = l; break; }
+				}
+				const uint64_t Ib = brk < 64 ? Iw & (((uint64_t)1 << brk) - 1) : Iw;
+				if (Ib) {
+					const int l = 63 - __builtin_clzll(Ib);
+					max_f = gld(pub_sc, (long long)w2 * 64 + l);
+					max_j = hw - l;
+				}
+				if (brk < 64) stop = true;
+			}
+			block_sync_lds();                                                                      // pub area may be overwritten by the next step
+		}
+		int vi = max_f;
+		if (max_j >= 0) { const int vm = max_j >= lo ? gld(sv, max_j & wm) : cld(gv, max_j); if (vm > max_f) vi = vm; }
+		if (wv == 0) {
+			WM_IF(ln == 0)
+				const V<long long> ii = (long long)i;
+				gst(sf, ii & wm, V<int>(max_f)); gst(sp, ii & wm, V<int>((int)max_j)); gst(sv, ii & wm, V<int>(vi));
+				if (wraps) { cst(gf, ii, V<int>(max_f)); cst(gp, ii, V<int>((int)max_j)); cst(gv, ii, V<int>(vi)); }
+			WM_END
+		}
+		block_sync_lds();
+	}
+	if (!wraps)
+		for (int i0 = wv * 64; i0 < n; i0 += 64 * NWV) {
 			const V<long long> k = cast<long long>(ln) + (long long)i0;
 			WM_IF(k < (long long)n) gst(gf, k, gld(sf, k)); gst(gp, k, gld(sp, k)); gst(gv, k, gld(sv, k)); WM_END
 		}

@@ -20,6 +20,12 @@ template <class T> using V = T;
 using vbool = bool;
 
 WM_DEV int lane() { return (int)(threadIdx.x & 63u); }
+WM_DEV int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+WM_DEV void block_sync() { __syncthreads(); }
+// LDS-only ordering: DS operations of a wave complete in order, so cross-lane LDS traffic only needs the counter wait
+// (and a compiler barrier); outstanding GLOBAL stores are deliberately not waited for.
+WM_DEV void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+WM_DEV void block_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <class T> WM_DEV T sel(bool c, T a, T b) { return c ? a : b; }
 template <class T, class U> WM_DEV T cast(U a) { return (T)a; }

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <numeric>
 #include <thread>
+#include <chrono>
 #include "simt.h"
 #include "ksw_kernel.h"
 #include "ksw_plan.h"
@@ -111,6 +112,7 @@ struct wm_ctx_s {
 	size_t arena_bytes, arena_used;
 	hipEvent_t ev[4];
 	float last_ms, aux_ms;
+	uint64_t acc_cells; double t_prep, t_run, t_fetch;
 	// flat index in HBM (wm_index_upload)
 	uint64_t *d_hkey, *d_hval, *d_P;
 	uint8_t *d_bloom;
@@ -180,6 +182,7 @@ extern "C" void wm_ctx_destroy(wm_ctx_t *c)
 
 extern "C" float wm_last_kernel_ms(const wm_ctx_t *c) { return c ? c->last_ms : 0.f; }
 
+static inline double now_ms();
 static void *arena_take(wm_ctx_t *c, size_t bytes)
 {
 	size_t a = (c->arena_used + 255) & ~(size_t)255;
@@ -370,6 +373,7 @@ extern "C" int wm_ksw_batch(wm_ctx_t *c, const wm_ksw_score_t *sc, int n_jobs, c
 	if (!c) return set_err(WM_EINVAL, "null context");
 	size_t used = 0;
 	int i0 = 0;
+	float kms = 0;
 	const size_t budget = (size_t)(c->arena_bytes * 0.8);
 	while (i0 < n_jobs || (n_jobs == 0 && i0 == 0)) {
 		int i1 = i0;
@@ -382,11 +386,15 @@ extern "C" int wm_ksw_batch(wm_ctx_t *c, const wm_ksw_score_t *sc, int n_jobs, c
 			need += t; ++i1;
 		}
 		wm_ksw_dev_batch_t *b = 0;
+		const double ta = now_ms();
 		int rc = wm_ksw_dev_prepare(c, sc, i1 - i0, jobs + i0, seqs, seqs_bytes, &b);
 		if (rc) return rc;
+		const double tb_ = now_ms();
 		rc = wm_ksw_dev_run(c, b);
+		const double tc = now_ms();
 		size_t u = 0;
 		if (!rc) rc = wm_ksw_dev_fetch(c, b, results + i0, cigar_pool + used, cigar_cap - used, &u);
+		c->acc_cells += b->cells; c->t_prep += tb_ - ta; c->t_run += tc - tb_; c->t_fetch += now_ms() - tc; kms += b->dp_ms + b->bt_ms;
 		wm_ksw_dev_free(c, b);
 		if (rc) { if (cigar_used) *cigar_used = used + u; return rc; }
 		for (int i = i0; i < i1; ++i) results[i].cig_off += (uint32_t)used;
@@ -395,6 +403,7 @@ extern "C" int wm_ksw_batch(wm_ctx_t *c, const wm_ksw_score_t *sc, int n_jobs, c
 		if (n_jobs == 0) break;
 	}
 	if (cigar_used) *cigar_used = used;
+	c->last_ms = kms;
 	return WM_OK;
 }
 
@@ -457,6 +466,19 @@ __global__ __launch_bounds__(64) void chain_kernel(const wm_chain_job_t *jobs, c
 	int *sf = (int*)(sy + W), *sp = sf + W, *sv = sp + W, *st = sv + W;
 	int *gf = fpvt + jb.a_off * 4, *gp = gf + jb.n, *gv = gp + jb.n, *gt = gv + jb.n;
 	wmk::chain_wave(jb, anchors, W, sx, sy, sf, sp, sv, st, gf, gp, gv, gt);
+}
+
+// large anchor sets: NWV waves cooperate on one job (chain_block); LDS = 32 B * W window + publish area
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void chain_kernel_block(const wm_chain_job_t *jobs, const int *order, const wm128_t *anchors, int *fpvt, int W)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int j = order[blockIdx.x];
+	const wm_chain_job_t jb = jobs[j];
+	uint64_t *sx = (uint64_t*)smem, *sy = sx + W;
+	int *sf = (int*)(sy + W), *sp = sf + W, *sv = sp + W, *st = sv + W, *pub = st + W;
+	int *gf = fpvt + jb.a_off * 4, *gp = gf + jb.n, *gv = gp + jb.n, *gt = gv + jb.n;
+	wmk::chain_block(jb, anchors, NWV, W, sx, sy, sf, sp, sv, st, pub, gf, gp, gv, gt);
 }
 
 extern "C" float wm_last_aux_ms(const wm_ctx_t *c) { return c ? c->aux_ms : 0.f; }
@@ -704,13 +726,18 @@ extern "C" int wm_chain_batch(wm_ctx_t *c, int n, wm128_t *a, const uint64_t *a_
 	HIPCHK(hipEventRecord(c->ev[0], c->stream));
 	{   // size classes by anchor count (order is sorted by n descending): LDS footprint = 32 B * W
 		HIPCHK(hipFuncSetAttribute((const void*)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		constexpr int NWV = 8;
+		HIPCHK(hipFuncSetAttribute((const void*)chain_kernel_block<NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		const int caps[3] = { 4096, 1024, 256 };
 		int b = 0;
 		for (int k = 0; k < 3; ++k) {
 			const int lo = k < 2 ? caps[k + 1] : 0;          // class k holds n > lo (class 0 also takes every n > 4096: the window wraps)
 			int e = b;
 			while (e < n && n_a[order[e]] > lo) ++e;
-			if (e > b) hipLaunchKernelGGL(chain_kernel, dim3(e - b), dim3(64), (size_t)caps[k] * 32, c->stream, d_jobs, d_order + b, d_a, d_fpvt, caps[k]);
+			if (e > b) {
+				if (k == 0) hipLaunchKernelGGL(chain_kernel_block<NWV>, dim3(e - b), dim3(64 * NWV), (size_t)caps[0] * 32 + NWV * 69 * 4 + 64, c->stream, d_jobs, d_order + b, d_a, d_fpvt, caps[0]);
+				else hipLaunchKernelGGL(chain_kernel, dim3(e - b), dim3(64), (size_t)caps[k] * 32, c->stream, d_jobs, d_order + b, d_a, d_fpvt, caps[k]);
+			}
 			b = e;
 		}
 	}
@@ -738,10 +765,12 @@ extern "C" int wm_chain_batch(wm_ctx_t *c, int n, wm128_t *a, const uint64_t *a_
 // ======================================================================================================
 // GpuOps: the product implementation of the mapper's device operations
 // ======================================================================================================
+static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct GpuOps : wm::DeviceOps {
 	wm_ctx_t *c;
 	uint64_t cells = 0;
 	double ksw_us = 0, aux_us = 0;
+	double t_pack = 0, t_prep = 0, t_run = 0, t_fetch = 0, t_unpack = 0, t_sketch = 0, t_seed = 0, t_chain = 0;
 	std::string error;
 	void fail(const char *what) { if (error.empty()) error = std::string(what) + ": " + g_err; }
 	void sketch_batch(int, int, std::vector<wm::SketchReq*> &reqs) override
@@ -754,7 +783,9 @@ struct GpuOps : wm::DeviceOps {
 		std::vector<uint8_t> seqs(tot + 1);
 		for (int i = 0; i < n; ++i) memcpy(seqs.data() + off[i], reqs[i]->seq, reqs[i]->len);
 		std::vector<wm128_t> out(tot + n + 1);
+		const double ts = now_ms();
 		if (wm_sketch_batch(c, n, seqs.data(), tot, off.data(), len.data(), out.data(), out.size(), ooff.data(), cnt.data())) { fail("sketch"); return; }
+		t_sketch += now_ms() - ts;
 		aux_us += c->aux_ms * 1e3;
 		for (int i = 0; i < n; ++i) reqs[i]->mini.assign(out.begin() + ooff[i], out.begin() + ooff[i] + cnt[i]);
 	}
@@ -771,9 +802,11 @@ struct GpuOps : wm::DeviceOps {
 		size_t cap = tot * 8 + 1024;
 		for (int attempt = 0; attempt < 6; ++attempt) {
 			std::vector<wm128_t> out(cap);
+			const double ts = now_ms();
 			const int rc = wm_seed_batch(c, n, mini.data(), moff.data(), nm.data(), ql.data(), reqs[0]->max_occ, reqs[0]->flag, out.data(), out.size(), ooff.data(), na.data(), rl.data());
 			if (rc == WM_ENOMEM && strstr(g_err, "anchor output pool")) { cap *= 8; continue; }
 			if (rc) { fail("seed"); return; }
+			t_seed += now_ms() - ts;
 			aux_us += c->aux_ms * 1e3;
 			for (int i = 0; i < n; ++i) { reqs[i]->a.assign(out.begin() + ooff[i], out.begin() + ooff[i] + na[i]); reqs[i]->rep_len = rl[i]; }
 			return;
@@ -795,7 +828,9 @@ struct GpuOps : wm::DeviceOps {
 		std::vector<wm128_t> a(tot + 1);
 		std::vector<uint64_t> u(tot + 1);
 		for (int i = 0; i < n; ++i) memcpy(a.data() + aoff[i], reqs[i]->a.data(), reqs[i]->a.size() * sizeof(wm128_t));
+		const double ts = now_ms();
 		if (wm_chain_batch(c, n, a.data(), aoff.data(), na.data(), par.data(), u.data(), uoff.data(), nu.data(), nv.data())) { fail("chain"); return; }
+		t_chain += now_ms() - ts;
 		aux_us += c->aux_ms * 1e3;
 		for (int i = 0; i < n; ++i) {
 			reqs[i]->u.assign(u.begin() + uoff[i], u.begin() + uoff[i] + nu[i]);
@@ -804,6 +839,7 @@ struct GpuOps : wm::DeviceOps {
 	}
 	void ksw_batch(const wm_ksw_score_t &sc, std::vector<wm::KswReq*> &reqs) override
 	{
+		const double t0 = now_ms();
 		const int n = (int)reqs.size();
 		std::vector<wm_ksw_job_t> jobs(n);
 		size_t tot = 0, cap = 16;
@@ -814,7 +850,6 @@ struct GpuOps : wm::DeviceOps {
 			jobs[i].qlen = (int)r.q.size(); jobs[i].tlen = (int)r.t.size();
 			jobs[i].w = r.w; jobs[i].zdrop = r.zdrop; jobs[i].end_bonus = r.end_bonus; jobs[i].flag = r.flag;
 			cap += r.q.size() + r.t.size() + 2;
-			uint64_t band; wm_ksw_cells(jobs[i].qlen, jobs[i].tlen, jobs[i].w, &band); cells += band;
 		}
 		if (tot >= ((size_t)1 << 32)) { error = "ksw batch exceeds 4 GB of sequence"; return; }
 		std::vector<uint8_t> seqs(tot + 1);
@@ -825,12 +860,17 @@ struct GpuOps : wm::DeviceOps {
 		std::vector<wm_ksw_result_t> res(n);
 		std::vector<uint32_t> pool(cap);
 		size_t used = 0;
+		const double t1 = now_ms();
+		c->acc_cells = 0; c->t_prep = c->t_run = c->t_fetch = 0;
 		if (wm_ksw_batch(c, &sc, n, jobs.data(), seqs.data(), tot, res.data(), pool.data(), cap, &used)) { fail("ksw"); return; }
+		const double t2 = now_ms();
 		ksw_us += c->last_ms * 1e3;
+		cells += c->acc_cells;
 		for (int i = 0; i < n; ++i) {
 			reqs[i]->ez = res[i];
 			reqs[i]->cigar.assign(pool.begin() + res[i].cig_off, pool.begin() + res[i].cig_off + res[i].n_cigar);
 		}
+		t_pack += t1 - t0; t_unpack += now_ms() - t2; t_prep += c->t_prep; t_run += c->t_run; t_fetch += c->t_fetch;
 	}
 };
 
@@ -914,6 +954,11 @@ extern "C" int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, con
 		tot.cells += ops[t].cells; tot.ksw_us += ops[t].ksw_us; tot.aux_us += ops[t].aux_us;
 	}
 	GpuOps &opsr = tot;
+	if (getenv("WM_TRACE")) {
+		double a[8] = {0};
+		for (int t = 0; t < T; ++t) { a[0] += ops[t].t_pack; a[1] += ops[t].t_prep; a[2] += ops[t].t_run; a[3] += ops[t].t_fetch; a[4] += ops[t].t_unpack; a[5] += ops[t].t_sketch; a[6] += ops[t].t_seed; a[7] += ops[t].t_chain; }
+		fprintf(stderr, "[ops, sum over %d threads, ms] ksw: pack %.0f prepare %.0f run %.0f fetch %.0f unpack %.0f | sketch %.0f seed %.0f chain %.0f\n", T, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
+	}
 	m->text.clear(); m->hits.clear(); m->cigars.clear(); m->first.assign(n + 1, 0);
 	for (int i = 0; i < n; ++i) {
 		wm::write_read(m->text, m->idx->ix, reads[i], out[i], m->mo.flag);
