@@ -226,6 +226,8 @@ DEF_RADIX(wmo_radix_sort_64, uint64_t, KEY64)
  * ---------------------------------------------------------------------------------------------- */
 static int ilog2_u32(uint32_t v) { int l = -1; while (v) { v >>= 1; ++l; } return l; } /* :15-20 (table form) */
 
+int64_t wmo_chain_stat[4]; /* diagnostics only: predecessors visited, sum of (i-st), max (i-st), 64-wide tiles touched */
+
 int64_t wmo_chain_dp(int max_dist_x, int min_dist_x, int max_dist_y, int bw, int max_skip, int max_iter,
                      int min_cnt, int min_sc, float gap_scale, int64_t n, const wmo128_t *a,
                      int *n_u_, uint64_t *u, wmo128_t *b)
@@ -248,8 +250,10 @@ int64_t wmo_chain_dp(int max_dist_x, int min_dist_x, int max_dist_y, int bw, int
 		while (st < i && ri > a[st].x + (uint64_t)max_dist_x) ++st;   /* :50 */
 		if (i - st > max_iter)                                         /* Winnowmap window relaxation :51-55 */
 			while (i - st > max_iter && ri > a[st].x + (uint64_t)min_dist_x) ++st;
+		wmo_chain_stat[1] += i - st; if (i - st > wmo_chain_stat[2]) wmo_chain_stat[2] = i - st;
 		for (j = i - 1; j >= st; --j) {
 			int64_t dr = (int64_t)(ri - a[j].x);
+			++wmo_chain_stat[0]; if (((i - 1 - j) & 63) == 0) ++wmo_chain_stat[3];
 			int32_t dq = qi - (int32_t)a[j].y, dd, sc, lg, gc;
 			if (dr == 0 || dq <= 0) continue;                          /* :60 */
 			if (dq > max_dist_y || dq > max_dist_x) continue;          /* :61 */

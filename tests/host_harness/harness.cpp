@@ -70,8 +70,18 @@ struct OracleOps : DeviceOps {
 			std::vector<wmo128_t> b(n ? n : 1);
 			std::vector<uint64_t> u(n ? n : 1);
 			int n_u = 0;
+			if (const char *dp = getenv("WM_CHAIN_DUMP")) {    // probes: append the job (n, 8 ints + gap_scale, anchors) to a file
+				FILE *fp = fopen(dp, "ab");
+				int64_t hdr[2] = { n, 0 };
+				int32_t par[10] = { r->max_dist_x, r->min_dist_x, r->max_dist_y, r->bw, r->max_skip, r->max_iter, r->min_cnt, r->min_sc, 0, 0 };
+				memcpy(&par[8], &r->gap_scale, 4);
+				fwrite(hdr, 8, 2, fp); fwrite(par, 4, 10, fp); fwrite(r->a.data(), 16, n, fp); fclose(fp);
+			}
+			extern int64_t wmo_chain_stat[4];
+			wmo_chain_stat[0] = wmo_chain_stat[1] = wmo_chain_stat[2] = wmo_chain_stat[3] = 0;
 			int64_t n_v = wmo_chain_dp(r->max_dist_x, r->min_dist_x, r->max_dist_y, r->bw, r->max_skip, r->max_iter, r->min_cnt, r->min_sc, r->gap_scale,
 			                           n, (const wmo128_t*)r->a.data(), &n_u, u.data(), b.data());
+			if (getenv("WM_CHAIN_STATS")) fprintf(stderr, "CHAINJOB %lld %lld %lld %lld %lld\n", (long long)n, (long long)wmo_chain_stat[0], (long long)wmo_chain_stat[1], (long long)wmo_chain_stat[2], (long long)wmo_chain_stat[3]);
 			r->u.assign(u.begin(), u.begin() + n_u);
 			r->a.resize(n_v);
 			for (int64_t i = 0; i < n_v; ++i) r->a[i].x = b[i].x, r->a[i].y = b[i].y;

@@ -115,7 +115,7 @@ int emu_chain_fill(int64_t n, const uint64_t *ax, const uint64_t *ay, int max_di
 	// test hook: bits 16.. of max_skip choose the LDS window (default 4096) so that wrap-around can be exercised on small inputs
 	int W = 4096;
 	if (max_skip >> 16) { W = max_skip >> 16; jb.max_skip &= 0xffff; }
-	std::vector<int> gt(n + 1), sf(W), sp(W), sv(W), stt(W);
+	std::vector<int> gt(n + 1), sf(W), sp(W), stt(W);
 	std::vector<uint64_t> sx(W), sy(W);
 	simt::exec_mask() = ~0ull;
 	if (max_iter >> 24) {              // test hook: bits 24.. of max_iter = number of cooperating waves (chain_block)
@@ -129,13 +129,14 @@ int emu_chain_fill(int64_t n, const uint64_t *ax, const uint64_t *ay, int max_di
 		for (int w = 0; w < NWV; ++w)
 			th.emplace_back([&, w]() {
 				simt::wave_slot() = w; simt::exec_mask() = ~0ull;
-				wmk::chain_block(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), sv.data(), stt.data(), pub.data(), f, p, v, gt.data());
+				wmk::chain_block(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
 			});
 		for (auto &t : th) t.join();
 		simt::block_barrier() = 0;
 		pthread_barrier_destroy(&bar);
 	} else
-		wmk::chain_wave(jb, a.data(), W, sx.data(), sy.data(), sf.data(), sp.data(), sv.data(), stt.data(), f, p, v, gt.data());
+		wmk::chain_wave(jb, a.data(), W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), f, p, gt.data());
+	for (int64_t i = 0; i < n; ++i) v[i] = p[i] >= 0 && v[p[i]] > f[i] ? v[p[i]] : f[i];   // the peak score is derived by the caller (as wm_chain_batch does)
 	return 0;
 }
 

@@ -126,6 +126,9 @@ inline uint64_t ballot(bool c) { return c ? exec_mask() : 0; }
 inline bool any(const vbool &c) { return ballot(c) != 0; }
 inline bool any(bool c) { return c && exec_mask(); }
 inline V<long long> wave_max_i64(const V<long long> &k) { WM_EMU_ASSERT(exec_mask() == ~0ull); long long m = k.v[0]; for (int i = 1; i < WAVE; ++i) if (k.v[i] > m) m = k.v[i]; return V<long long>(m); }
+inline V<int> wave_scan_max(const V<int> &k) { WM_EMU_ASSERT(exec_mask() == ~0ull); V<int> r = k; for (int i = 1; i < WAVE; ++i) r.v[i] = r.v[i - 1] > k.v[i] ? r.v[i - 1] : k.v[i]; return r; }
+inline V<int> wave_scan_min(const V<int> &k) { WM_EMU_ASSERT(exec_mask() == ~0ull); V<int> r = k; for (int i = 1; i < WAVE; ++i) r.v[i] = r.v[i - 1] < k.v[i] ? r.v[i - 1] : k.v[i]; return r; }
+inline V<int> wave_scan_add(const V<int> &k) { WM_EMU_ASSERT(exec_mask() == ~0ull); V<int> r = k; for (int i = 1; i < WAVE; ++i) r.v[i] = r.v[i - 1] + k.v[i]; return r; }
 inline V<int> wave_sum_i32(const V<int> &k) { WM_EMU_ASSERT(exec_mask() == ~0ull); int s = 0; for (int i = 0; i < WAVE; ++i) s += k.v[i]; return V<int>(s); }
 
 // ---- memory -----------------------------------------------------------------------------------------

@@ -129,13 +129,159 @@ WM_DEV V<int> ilog2_pos(V<int> v)
 	return r;
 }
 
-// LDS holds a circular window of the W most recent anchors (W a power of two): their x, y and f, p, v, t — 32 B per
-// anchor — so every dependent access of the sequential part is an LDS round trip. f, p, v are also written through
-// to the global result slab gf/gp/gv (and marks to gt) so that predecessors older than the window, which the
-// reference may still visit when min_dist_x relaxes max_iter inside dense repeats (src/chain.c:51-55), are served
-// from global memory (L1-bypassing loads). For n <= W nothing ever leaves the window.
-WM_DEV void chain_wave(const wm_chain_job_t jb, const wm128_t *anchor_pool, int W, uint64_t *sx, uint64_t *sy, int *sf, int *sp, int *sv, int *st_,
-                       int *gf, int *gp, int *gv, int *gt)
+// LDS holds a circular window of the W most recent anchors (W a power of two >= 128): their x, y and f, p, t — 28 B per
+// anchor — so every dependent access of the sequential part is an LDS round trip. When the anchor set is larger than the
+// window, finished f, p are copied to the global result slab gf/gp one 64-anchor tile at a time (never per anchor: an
+// outstanding global store would stall the next anchor's s_waitcnt vmcnt), so that predecessors older than the window —
+// which the reference may still visit when min_dist_x relaxes max_iter inside dense repeats (src/chain.c:51-55) — are
+// served from global memory (L1-bypassing loads; marks for them go to gt). For n <= W nothing ever leaves the window.
+// The peak score v[] (src/chain.c:89) is a function of f and p only and is not needed by the fill: the caller derives it.
+
+// advance st over the sorted x: the two scalar loops of src/chain.c:50-55, 64 candidates per LDS round trip
+WM_DEV long long chain_advance_st(long long st, long long i, uint64_t ri, uint64_t dist, long long keep_iter /* <0: no iteration clause */,
+                                  long long lo, long long wm, const uint64_t *sx, const uint64_t *a)
+{
+	const V<int> ln = lane();
+	for (;;) {
+		if (st >= i || (keep_iter >= 0 && i - st <= keep_iter)) return st;
+		const V<long long> k = cast<long long>(ln) + st;
+		V<uint64_t> xk = ~(uint64_t)0;
+		const vbool in = k < i;
+		WM_IF(in && k >= lo) xk = gld(sx, k & wm); WM_END
+		WM_IF(in && k < lo) xk = gld(a, k * 2LL); WM_END
+		vbool go = in && V<uint64_t>(ri) > xk + dist;
+		if (keep_iter >= 0) go = go && (V<long long>(i) - k > keep_iter);
+		const uint64_t stay = ~ballot(go);                    // first lane that does not advance ends the run (conditions are monotone in k)
+		if (stay) return st + __builtin_ctzll(stay);
+		st += 64;
+	}
+}
+
+// copy the finished anchors [from, to) of the window to the global slab (tile flush; all lanes)
+WM_DEV void chain_flush_tile(long long from, long long to, long long wm, const int *sf, const int *sp, int *gf, int *gp)
+{
+	const V<long long> k = cast<long long>(lane()) + from;
+	WM_IF(k < to) cst(gf, k, gld(sf, k & wm)); cst(gp, k, gld(sp, k & wm)); WM_END
+	mem_sync();
+}
+
+// running state of one anchor's predecessor scan (uniform across the wave)
+struct chain_scan_t { int max_f, n_skip; long long max_j; bool stop; };
+
+// One tile's share of the sequential automaton of src/chain.c:79-86, without a scalar replay:
+//   improvement lanes I : score > every earlier visited score and > the running max  (inclusive max scan, shifted by one)
+//   marked lanes      M : t[j] == i and not I
+//   n_skip is a counter that saturates at 0 on I and grows on M: n_k = S_k + max(n_0, -min_{m<=k} S_m) with S the
+//   prefix sum of (-1 on I, +1 on M) (the Lindley recursion), so a prefix sum and a prefix min give it for all 64 lanes;
+//   the scan stops at the first lane with n_k > max_skip.
+WM_DEV void chain_tile_resolve(const vbool valid, const V<int> sc, const V<int> tj, int i, long long hi, int max_skip, chain_scan_t &cs)
+{
+	const V<int> NEG = -0x7fffffff - 1;
+	const V<int> key = sel(valid, sc, NEG);
+	vbool isI = valid && !valid;
+	if (ballot(key > cs.max_f)) {
+		const V<int> incl = wave_scan_max(key);
+		const V<int> before = vmax(shr1(incl, NEG), V<int>(cs.max_f));
+		isI = valid && sc > before;
+	}
+	const vbool isM = valid && tj == i && !isI;
+	const uint64_t I = ballot(isI);
+	if (!(I | ballot(isM))) return;
+	const V<int> d = sel(isI, V<int>(-1), sel(isM, V<int>(1), V<int>(0)));
+	const V<int> S = wave_scan_add(d);
+	const V<int> mn = wave_scan_min(S);
+	const V<int> nk = S + vmax(V<int>(cs.n_skip), V<int>(0) - mn);
+	const uint64_t B = ballot(nk > max_skip);
+	const int brk = B ? __builtin_ctzll(B) : 64;
+	const uint64_t Ib = brk < 64 ? I & (((uint64_t)1 << brk) - 1) : I;
+	if (Ib) {
+		const int l = 63 - __builtin_clzll(Ib);
+		cs.max_f = readlane(sc, l);
+		cs.max_j = hi - l;
+	}
+	if (brk < 64) cs.stop = true; else cs.n_skip = readlane(nk, 63);
+}
+
+// score of predecessor j for anchor (ri, qi, span): src/chain.c:57-78
+WM_DEV void chain_score(const wm_chain_job_t &jb, uint64_t ri, int qi, int span, const V<uint64_t> xj, const V<uint64_t> yj, const V<int> fj, V<int> &sc, vbool &ok)
+{
+	const V<long long> dr = cast<long long>(V<uint64_t>(ri) - xj);
+	const V<int> dq = V<int>(qi) - cast<int>(cast<uint32_t>(yj));
+	ok = !(dr == 0LL || dq <= 0) && !(dq > jb.max_dist_y || dq > jb.max_dist_x);                 // :60-61
+	const V<long long> dql = cast<long long>(dq);
+	const V<int> dd = cast<int>(sel(dr > dql, dr - dql, dql - dr));
+	ok = ok && !(dd > jb.bw);                                                                      // :63
+	const V<int> drc = cast<int>(sel(dr > (long long)0x7fffffff, V<long long>(0x7fffffff), dr));
+	const V<int> md = vmin(dq, drc);
+	V<int> s0 = vmin(md, V<int>(span));                                                            // :65-66
+	const V<int> lg = sel(dd > 0, ilog2_pos(dd), 0);
+	const V<double> lin = cast<double>(dd) * .01 * (double)jb.avg_qspan;
+	const V<int> gc = cast<int>(lin) + (lg >> 1);                                                  // :76
+	s0 = s0 - cast<int>(cast<double>(gc) * (double)jb.gap_scale + .499);                           // :77
+	sc = s0 + fj;
+}
+
+// U tiles (64 predecessors each) are scored together so that their memory latencies overlap; the automaton is then
+// resolved tile by tile. Marks of a later tile never target an earlier one (p[j] < j), and marks written for tiles
+// behind a break are harmless (they are only compared with this i).
+template <int U>
+WM_DEV void chain_group(const wm_chain_job_t &jb, long long hi0, long long st, long long lo, long long wm, int i, uint64_t ri, int qi, int span,
+                        const uint64_t *a, const uint64_t *sx, const uint64_t *sy, const int *sf, const int *sp, int *st_, int *gf, int *gp, int *gt, chain_scan_t &cs)
+{
+	const V<int> ln = lane();
+	V<int> sc[U], tj[U];
+	vbool valid[U];
+	V<long long> jj[U];
+	bool any_far = false;
+#pragma unroll
+	for (int u = 0; u < U; ++u) {
+		const V<long long> j = V<long long>(hi0 - 64 * u) - cast<long long>(ln);                  // lane 0 = first visited
+		jj[u] = j;
+		const vbool in = j >= st, res = j >= lo;
+		V<int> pj = -1, fj = 0;
+		V<uint64_t> xj = (uint64_t)0, yj = (uint64_t)0;
+		sc[u] = 0; tj[u] = 0;
+		valid[u] = in && !in;                                                                      // false
+		if (hi0 - 64 * u - 63 >= lo) {                                                             // whole tile resident (the common case)
+			WM_IF(in) xj = gld(sx, j & wm); yj = gld(sy, j & wm); fj = gld(sf, j & wm); pj = gld(sp, j & wm); WM_END
+		} else {
+			WM_IF(in && res) xj = gld(sx, j & wm); yj = gld(sy, j & wm); fj = gld(sf, j & wm); pj = gld(sp, j & wm); WM_END
+			WM_IF(in && !res) xj = gld(a, j * 2LL); yj = gld(a, j * 2LL + 1LL); fj = cld(gf, j); pj = cld(gp, j); WM_END
+		}
+		WM_IF(in)
+			vbool ok = in;
+			chain_score(jb, ri, qi, span, xj, yj, fj, sc[u], ok);
+			valid[u] = ok;
+		WM_END
+		// marks (src/chain.c:86): a scored predecessor marks ITS predecessor, if that one can still be visited
+		const V<long long> pjl = cast<long long>(pj);
+		WM_IF(valid[u] && pj >= 0 && pjl >= lo) gst(st_, pjl & wm, V<int>(i)); WM_END
+		if (st < lo) {
+			const vbool far_mark = valid[u] && pj >= 0 && pjl < lo && pjl >= st;
+			WM_IF(far_mark) cst(gt, pjl, V<int>(i)); WM_END
+			any_far = any_far || any(far_mark);
+		}
+	}
+	if (any_far) mem_sync(); else lds_sync();                                                      // global marks must reach L2 before they are re-read
+#pragma unroll
+	for (int u = 0; u < U; ++u) {
+		if (hi0 - 64 * u - 63 >= lo) {
+			WM_IF(valid[u]) tj[u] = gld(st_, jj[u] & wm); WM_END
+		} else {
+			const vbool res = jj[u] >= lo;
+			WM_IF(valid[u] && res) tj[u] = gld(st_, jj[u] & wm); WM_END
+			WM_IF(valid[u] && !res) tj[u] = cld(gt, jj[u]); WM_END
+		}
+	}
+#pragma unroll
+	for (int u = 0; u < U; ++u) {
+		if (cs.stop || hi0 - 64 * u < st) break;
+		chain_tile_resolve(valid[u], sc[u], tj[u], i, hi0 - 64 * u, jb.max_skip, cs);
+	}
+}
+
+WM_DEV void chain_wave(const wm_chain_job_t jb, const wm128_t *anchor_pool, int W, uint64_t *sx, uint64_t *sy, int *sf, int *sp, int *st_,
+                       int *gf, int *gp, int *gt)
 {
 	const V<int> ln = lane();
 	const uint64_t *a = (const uint64_t*)(anchor_pool + jb.a_off);
@@ -147,6 +293,7 @@ WM_DEV void chain_wave(const wm_chain_job_t jb, const wm128_t *anchor_pool, int 
 	long long st = 0;
 	for (int i = 0; i < n; ++i) {
 		if ((i & 63) == 0) {                                  // stage the next 64 anchors (evicts anchors i-W .. i-W+63)
+			if (wraps && i > 0) chain_flush_tile((long long)i - 64, (long long)i, wm, sf, sp, gf, gp);
 			const V<long long> k = cast<long long>(ln) + (long long)i;
 			WM_IF(k < (long long)n)
 				gst(sx, k & wm, gld(a, k * 2LL)); gst(sy, k & wm, gld(a, k * 2LL + 1LL)); gst(st_, k & wm, V<int>(0));
@@ -156,107 +303,26 @@ WM_DEV void chain_wave(const wm_chain_job_t jb, const wm128_t *anchor_pool, int 
 		const long long lo = (long long)(i & ~63) + 64 - W;   // anchors >= lo are resident in LDS
 		const uint64_t ri = gld(sx, (long long)i & wm), yi = gld(sy, (long long)i & wm);
 		const int qi = (int)(uint32_t)yi, span = (int)(yi >> 32 & 0xff);
-		int max_f = span, n_skip = 0;
-		long long max_j = -1;
-		while (st < i && ri > (st >= lo ? gld(sx, st & wm) : gld(a, st * 2)) + (uint64_t)jb.max_dist_x) ++st;             // :50
-		if (i - st > jb.max_iter)                                                                                          // :51-55
-			while (i - st > jb.max_iter && ri > (st >= lo ? gld(sx, st & wm) : gld(a, st * 2)) + (uint64_t)jb.min_dist_x) ++st;
-		bool stop = false;
-		// U tiles (64 predecessors each) are scored together so that their memory latencies overlap; the sequential
-		// automaton is then replayed tile by tile. Marks of a later tile never target an earlier one (p[j] < j), and
-		// marks written for tiles behind a break are harmless (they are only compared with this i).
-		constexpr int U = 4;
-		for (long long hi0 = (long long)i - 1; hi0 >= st && !stop; hi0 -= 64 * U) {
-			V<int> sc[U], tj[U];
-			vbool valid[U];
-			V<long long> jj[U];
-			bool any_far = false;
-#pragma unroll
-			for (int u = 0; u < U; ++u) {
-				const V<long long> j = V<long long>(hi0 - 64 * u) - cast<long long>(ln);            // lane 0 = first visited
-				jj[u] = j;
-				const vbool in = j >= st, res = j >= lo;
-				V<int> pj = -1, fj = 0;
-				V<uint64_t> xj = (uint64_t)0, yj = (uint64_t)0;
-				sc[u] = 0; tj[u] = 0;
-				valid[u] = in && !in;                                                              // false
-				WM_IF(in && res) xj = gld(sx, j & wm); yj = gld(sy, j & wm); fj = gld(sf, j & wm); pj = gld(sp, j & wm); WM_END
-				WM_IF(in && !res) xj = gld(a, j * 2LL); yj = gld(a, j * 2LL + 1LL); fj = cld(gf, j); pj = cld(gp, j); WM_END
-				WM_IF(in)
-					const V<long long> dr = cast<long long>(V<uint64_t>(ri) - xj);
-					const V<int> dq = V<int>(qi) - cast<int>(cast<uint32_t>(yj));
-					vbool ok = !(dr == 0LL || dq <= 0) && !(dq > jb.max_dist_y || dq > jb.max_dist_x);   // :60-61
-					const V<long long> dql = cast<long long>(dq);
-					const V<int> dd = cast<int>(sel(dr > dql, dr - dql, dql - dr));
-					ok = ok && !(dd > jb.bw);                                                      // :63
-					const V<int> drc = cast<int>(sel(dr > (long long)0x7fffffff, V<long long>(0x7fffffff), dr));
-					const V<int> md = vmin(dq, drc);
-					V<int> s0 = vmin(md, V<int>(span));                                            // :65-66
-					const V<int> lg = sel(dd > 0, ilog2_pos(dd), 0);
-					const V<double> lin = cast<double>(dd) * .01 * (double)jb.avg_qspan;
-					const V<int> gc = cast<int>(lin) + (lg >> 1);                                  // :76
-					s0 = s0 - cast<int>(cast<double>(gc) * (double)jb.gap_scale + .499);           // :77
-					sc[u] = s0 + fj;
-					valid[u] = ok;
-				WM_END
-				// marks (src/chain.c:86): a scored predecessor marks ITS predecessor, if that one can still be visited
-				const V<long long> pjl = cast<long long>(pj);
-				WM_IF(valid[u] && pj >= 0 && pjl >= lo) gst(st_, pjl & wm, V<int>(i)); WM_END
-				const vbool far_mark = valid[u] && pj >= 0 && pjl < lo && pjl >= st;
-				WM_IF(far_mark) cst(gt, pjl, V<int>(i)); WM_END
-				any_far = any_far || any(far_mark);
-			}
-			if (any_far) mem_sync(); else lds_sync();             // global marks must reach L2 before they are re-read
-#pragma unroll
-			for (int u = 0; u < U; ++u) {
-				const vbool res = jj[u] >= lo;
-				WM_IF(valid[u] && res) tj[u] = gld(st_, jj[u] & wm); WM_END
-				WM_IF(valid[u] && !res) tj[u] = cld(gt, jj[u]); WM_END
-			}
-#pragma unroll
-			for (int u = 0; u < U; ++u) {
-				if (stop || hi0 - 64 * u < st) break;
-				const long long hi = hi0 - 64 * u;
-				// does any lane beat the running maximum? (strict improvement test of :79 needs the maximum BEFORE each lane)
-				const V<int> key = sel(valid[u], sc[u], V<int>(-0x7fffffff - 1));
-				uint64_t I = 0;
-				if (ballot(key > max_f)) {
-					V<int> pm = key;
-					for (int o = 1; o < 64; o <<= 1) pm = vmax(pm, sel(ln >= o, shr_n(pm, o), V<int>(-0x7fffffff - 1)));
-					const V<int> before = vmax(sel(ln >= 1, shr_n(pm, 1), V<int>(-0x7fffffff - 1)), V<int>(max_f));
-					I = ballot(valid[u] && sc[u] > before);
-				}
-				const uint64_t M = ballot(valid[u] && tj[u] == i) & ~I;
-				int brk = 64;                                  // replay n_skip over the events in visiting order
-				uint64_t ev = I | M;
-				while (ev) {
-					const int l = __builtin_ctzll(ev);
-					ev &= ev - 1;
-					if (I >> l & 1) { if (n_skip > 0) --n_skip; }
-					else if (++n_skip > jb.max_skip) { brk = l; break; }
-				}
-				const uint64_t Ib = brk < 64 ? I & (((uint64_t)1 << brk) - 1) : I;
-				if (Ib) {
-					const int l = 63 - __builtin_clzll(Ib);
-					max_f = readlane(sc[u], l);
-					max_j = hi - l;
-				}
-				if (brk < 64) stop = true;
-			}
+		chain_scan_t cs = { span, 0, -1, false };
+		st = chain_advance_st(st, i, ri, (uint64_t)jb.max_dist_x, -1, lo, wm, sx, a);                                      // :50
+		if (i - st > jb.max_iter) st = chain_advance_st(st, i, ri, (uint64_t)jb.min_dist_x, jb.max_iter, lo, wm, sx, a);    // :51-55
+		long long hi0 = (long long)i - 1;
+		if (hi0 >= st) {                                      // most scans end inside their first tile: score it alone, then four at a time
+			chain_group<1>(jb, hi0, st, lo, wm, i, ri, qi, span, a, sx, sy, sf, sp, st_, gf, gp, gt, cs);
+			for (hi0 -= 64; hi0 >= st && !cs.stop; hi0 -= 64 * 4)
+				chain_group<4>(jb, hi0, st, lo, wm, i, ri, qi, span, a, sx, sy, sf, sp, st_, gf, gp, gt, cs);
 		}
-		int vi = max_f;
-		if (max_j >= 0) { const int vm = max_j >= lo ? gld(sv, max_j & wm) : cld(gv, max_j); if (vm > max_f) vi = vm; }
 		WM_IF(ln == 0)
 			const V<long long> ii = (long long)i;
-			gst(sf, ii & wm, V<int>(max_f)); gst(sp, ii & wm, V<int>((int)max_j)); gst(sv, ii & wm, V<int>(vi));
-			if (wraps) { cst(gf, ii, V<int>(max_f)); cst(gp, ii, V<int>((int)max_j)); cst(gv, ii, V<int>(vi)); }   // write-through, not waited for
+			gst(sf, ii & wm, V<int>(cs.max_f)); gst(sp, ii & wm, V<int>((int)cs.max_j));
 		WM_END
 		lds_sync();
 	}
-	if (!wraps)                                                // everything stayed in the window: one coalesced copy-out
+	if (wraps) chain_flush_tile((long long)((n - 1) & ~63), (long long)n, wm, sf, sp, gf, gp);
+	else                                                       // everything stayed in the window: one coalesced copy-out
 		for (int i0 = 0; i0 < n; i0 += 64) {
 			const V<long long> k = cast<long long>(ln) + (long long)i0;
-			WM_IF(k < (long long)n) gst(gf, k, gld(sf, k)); gst(gp, k, gld(sp, k)); gst(gv, k, gld(sv, k)); WM_END
+			WM_IF(k < (long long)n) gst(gf, k, gld(sf, k)); gst(gp, k, gld(sp, k)); WM_END
 		}
 }
 
@@ -269,8 +335,8 @@ WM_DEV void chain_wave(const wm_chain_job_t jb, const wm128_t *anchor_pool, int 
 // automaton, which every wave replays redundantly from the published ballots so that all waves agree without a
 // broadcast. pub: NWV * (2 + 64 + 2) ints of LDS.
 // ------------------------------------------------------------------------------------------------------
-WM_DEV void chain_block(const wm_chain_job_t jb, const wm128_t *anchor_pool, int NWV, int W, uint64_t *sx, uint64_t *sy, int *sf, int *sp, int *sv, int *st_,
-                        int *pub, int *gf, int *gp, int *gv, int *gt)
+WM_DEV void chain_block(const wm_chain_job_t jb, const wm128_t *anchor_pool, int NWV, int W, uint64_t *sx, uint64_t *sy, int *sf, int *sp, int *st_,
+                        int *pub, int *gf, int *gp, int *gt)
 {
 	const V<int> ln = lane();
 	const int wv = wave_in_block();
@@ -286,6 +352,7 @@ WM_DEV void chain_block(const wm_chain_job_t jb, const wm128_t *anchor_pool, int
 		if ((i & 63) == 0) {
 			block_sync_lds();
 			if (wv == 0) {
+				if (wraps && i > 0) chain_flush_tile((long long)i - 64, (long long)i, wm, sf, sp, gf, gp);
 				const V<long long> k = cast<long long>(ln) + (long long)i;
 				WM_IF(k < (long long)n)
 					gst(sx, k & wm, gld(a, k * 2LL)); gst(sy, k & wm, gld(a, k * 2LL + 1LL)); gst(st_, k & wm, V<int>(0));
@@ -298,9 +365,8 @@ WM_DEV void chain_block(const wm_chain_job_t jb, const wm128_t *anchor_pool, int
 		const int qi = (int)(uint32_t)yi, span = (int)(yi >> 32 & 0xff);
 		int max_f = span, n_skip = 0;
 		long long max_j = -1;
-		while (st < i && ri > (st >= lo ? gld(sx, st & wm) : gld(a, st * 2)) + (uint64_t)jb.max_dist_x) ++st;
-		if (i - st > jb.max_iter)
-			while (i - st > jb.max_iter && ri > (st >= lo ? gld(sx, st & wm) : gld(a, st * 2)) + (uint64_t)jb.min_dist_x) ++st;
+		st = chain_advance_st(st, i, ri, (uint64_t)jb.max_dist_x, -1, lo, wm, sx, a);
+		if (i - st > jb.max_iter) st = chain_advance_st(st, i, ri, (uint64_t)jb.min_dist_x, jb.max_iter, lo, wm, sx, a);
 		bool stop = false;
 		for (long long hi0 = (long long)i - 1; hi0 >= st && !stop; hi0 -= 64LL * NWV) {
 			const long long hi = hi0 - 64LL * wv;                                                   // this wave's tile
@@ -309,8 +375,13 @@ WM_DEV void chain_block(const wm_chain_job_t jb, const wm128_t *anchor_pool, int
 			V<int> sc = 0, pj = -1, fj = 0, tj = 0;
 			V<uint64_t> xj = (uint64_t)0, yj = (uint64_t)0;
 			vbool valid = in && !in;
-			WM_IF(in && res) xj = gld(sx, j & wm); yj = gld(sy, j & wm); fj = gld(sf, j & wm); pj = gld(sp, j & wm); WM_END
-			WM_IF(in && !res) xj = gld(a, j * 2LL); yj = gld(a, j * 2LL + 1LL); fj = cld(gf, j); pj = cld(gp, j); WM_END
+			const bool all_res = hi - 63 >= lo;                                                     // whole tile resident (the common case)
+			if (all_res) {
+				WM_IF(in) xj = gld(sx, j & wm); yj = gld(sy, j & wm); fj = gld(sf, j & wm); pj = gld(sp, j & wm); WM_END
+			} else {
+				WM_IF(in && res) xj = gld(sx, j & wm); yj = gld(sy, j & wm); fj = gld(sf, j & wm); pj = gld(sp, j & wm); WM_END
+				WM_IF(in && !res) xj = gld(a, j * 2LL); yj = gld(a, j * 2LL + 1LL); fj = cld(gf, j); pj = cld(gp, j); WM_END
+			}
 			WM_IF(in)
 				const V<long long> dr = cast<long long>(V<uint64_t>(ri) - xj);
 				const V<int> dq = V<int>(qi) - cast<int>(cast<uint32_t>(yj));
@@ -330,17 +401,22 @@ WM_DEV void chain_block(const wm_chain_job_t jb, const wm128_t *anchor_pool, int
 			WM_END
 			const V<long long> pjl = cast<long long>(pj);
 			WM_IF(valid && pj >= 0 && pjl >= lo) gst(st_, pjl & wm, V<int>(i)); WM_END
-			const vbool far_mark = valid && pj >= 0 && pjl < lo && pjl >= st;
-			WM_IF(far_mark) cst(gt, pjl, V<int>(i)); WM_END
-			if (any(far_mark)) mem_sync();
+			if (st < lo) {
+				const vbool far_mark = valid && pj >= 0 && pjl < lo && pjl >= st;
+				WM_IF(far_mark) cst(gt, pjl, V<int>(i)); WM_END
+				if (any(far_mark)) mem_sync();
+			}
 			// publish this tile's maximum so that later tiles know the running maximum before them
 			const V<int> key = sel(valid, sc, V<int>(-0x7fffffff - 1));
 			V<int> pm = key;
 			for (int o = 1; o < 64; o <<= 1) pm = vmax(pm, sel(ln >= o, shr_n(pm, o), V<int>(-0x7fffffff - 1)));
 			WM_IF(ln == 63) gst(pub_tmax, V<int>(wv), pm); WM_END
 			block_sync_lds();                                                                      // marks + tile maxima visible
-			WM_IF(valid && res) tj = gld(st_, j & wm); WM_END
-			WM_IF(valid && !res) tj = cld(gt, j); WM_END
+			if (all_res) { WM_IF(valid) tj = gld(st_, j & wm); WM_END }
+			else {
+				WM_IF(valid && res) tj = gld(st_, j & wm); WM_END
+				WM_IF(valid && !res) tj = cld(gt, j); WM_END
+			}
 			int run_max = max_f;
 			for (int w2 = 0; w2 < wv; ++w2) { const int tm = gld(pub_tmax, (long long)w2); run_max = tm > run_max ? tm : run_max; }
 			const V<int> before = vmax(sel(ln >= 1, shr_n(pm, 1), V<int>(-0x7fffffff - 1)), V<int>(run_max));
@@ -375,21 +451,19 @@ WM_DEV void chain_block(const wm_chain_job_t jb, const wm128_t *anchor_pool, int
 			}
 			block_sync_lds();                                                                      // pub area may be overwritten by the next step
 		}
-		int vi = max_f;
-		if (max_j >= 0) { const int vm = max_j >= lo ? gld(sv, max_j & wm) : cld(gv, max_j); if (vm > max_f) vi = vm; }
 		if (wv == 0) {
 			WM_IF(ln == 0)
 				const V<long long> ii = (long long)i;
-				gst(sf, ii & wm, V<int>(max_f)); gst(sp, ii & wm, V<int>((int)max_j)); gst(sv, ii & wm, V<int>(vi));
-				if (wraps) { cst(gf, ii, V<int>(max_f)); cst(gp, ii, V<int>((int)max_j)); cst(gv, ii, V<int>(vi)); }
+				gst(sf, ii & wm, V<int>(max_f)); gst(sp, ii & wm, V<int>((int)max_j));
 			WM_END
 		}
 		block_sync_lds();
 	}
-	if (!wraps)
+	if (wraps) { if (wv == 0) chain_flush_tile((long long)((n - 1) & ~63), (long long)n, wm, sf, sp, gf, gp); }
+	else
 		for (int i0 = wv * 64; i0 < n; i0 += 64 * NWV) {
 			const V<long long> k = cast<long long>(ln) + (long long)i0;
-			WM_IF(k < (long long)n) gst(gf, k, gld(sf, k)); gst(gp, k, gld(sp, k)); gst(gv, k, gld(sv, k)); WM_END
+			WM_IF(k < (long long)n) gst(gf, k, gld(sf, k)); gst(gp, k, gld(sp, k)); WM_END
 		}
 }
 

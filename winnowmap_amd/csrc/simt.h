@@ -36,12 +36,31 @@ WM_DEV int add3(int a, int b, int c) { return (int)((unsigned)a + (unsigned)b + 
 WM_DEV int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }     // wrapping 32-bit add
 WM_DEV int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }     // wrapping 32-bit sub
 
-// value of lane-1 (lane 0 receives `fill`)
-WM_DEV int shr1(int x, int fill)
-{
-	int y = __shfl_up(x, 1, 64);
-	return lane() == 0 ? fill : y;
+// DPP cross-lane moves (gfx9 encodings): one VALU operation each, no LDS crossbar round trip.
+// Lanes without a source lane (or in a row that row_mask disables) receive `old`.
+template <int CTRL, int ROW_MASK> WM_DEV int dpp_mov(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, ROW_MASK, 0xf, false); }
+// value of lane-1 (lane 0 receives `fill`): wave_shr:1
+WM_DEV int shr1(int x, int fill) { return dpp_mov<0x138, 0xf>(fill, x); }
+// inclusive wave scans: row_shr:1,2,4,8 inside the 16-lane rows, then row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3)
+#define WM_SCAN(NAME, OP, ID) \
+WM_DEV int NAME(int x) \
+{ \
+	int t; \
+	t = dpp_mov<0x111, 0xf>(ID, x); x = OP(x, t); \
+	t = dpp_mov<0x112, 0xf>(ID, x); x = OP(x, t); \
+	t = dpp_mov<0x114, 0xf>(ID, x); x = OP(x, t); \
+	t = dpp_mov<0x118, 0xf>(ID, x); x = OP(x, t); \
+	t = dpp_mov<0x142, 0xa>(ID, x); x = OP(x, t); \
+	t = dpp_mov<0x143, 0xc>(ID, x); x = OP(x, t); \
+	return x; \
 }
+WM_DEV int scan_op_max(int a, int b) { return a > b ? a : b; }
+WM_DEV int scan_op_min(int a, int b) { return a < b ? a : b; }
+WM_DEV int scan_op_add(int a, int b) { return a + b; }
+WM_SCAN(wave_scan_max, scan_op_max, (-0x7fffffff - 1))
+WM_SCAN(wave_scan_min, scan_op_min, 0x7fffffff)
+WM_SCAN(wave_scan_add, scan_op_add, 0)
+#undef WM_SCAN
 // lane j receives lane j+k (uniform k); lanes >= 64-k receive `fill`
 WM_DEV int shift_down(int x, int k, int fill)
 {

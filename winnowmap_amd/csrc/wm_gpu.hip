@@ -463,9 +463,9 @@ __global__ __launch_bounds__(64) void chain_kernel(const wm_chain_job_t *jobs, c
 	const int j = order[blockIdx.x];
 	const wm_chain_job_t jb = jobs[j];
 	uint64_t *sx = (uint64_t*)smem, *sy = sx + W;
-	int *sf = (int*)(sy + W), *sp = sf + W, *sv = sp + W, *st = sv + W;
-	int *gf = fpvt + jb.a_off * 4, *gp = gf + jb.n, *gv = gp + jb.n, *gt = gv + jb.n;
-	wmk::chain_wave(jb, anchors, W, sx, sy, sf, sp, sv, st, gf, gp, gv, gt);
+	int *sf = (int*)(sy + W), *sp = sf + W, *st = sp + W;
+	int *gf = fpvt + jb.a_off * 4, *gp = gf + jb.n, *gt = gp + 2 * (size_t)jb.n;      // slab per job: f | p | v (host) | t
+	wmk::chain_wave(jb, anchors, W, sx, sy, sf, sp, st, gf, gp, gt);
 }
 
 // large anchor sets: NWV waves cooperate on one job (chain_block); LDS = 32 B * W window + publish area
@@ -476,11 +476,12 @@ __global__ __launch_bounds__(64 * NWV) void chain_kernel_block(const wm_chain_jo
 	const int j = order[blockIdx.x];
 	const wm_chain_job_t jb = jobs[j];
 	uint64_t *sx = (uint64_t*)smem, *sy = sx + W;
-	int *sf = (int*)(sy + W), *sp = sf + W, *sv = sp + W, *st = sv + W, *pub = st + W;
-	int *gf = fpvt + jb.a_off * 4, *gp = gf + jb.n, *gv = gp + jb.n, *gt = gv + jb.n;
-	wmk::chain_block(jb, anchors, NWV, W, sx, sy, sf, sp, sv, st, pub, gf, gp, gv, gt);
+	int *sf = (int*)(sy + W), *sp = sf + W, *st = sp + W, *pub = st + W;
+	int *gf = fpvt + jb.a_off * 4, *gp = gf + jb.n, *gt = gp + 2 * (size_t)jb.n;
+	wmk::chain_block(jb, anchors, NWV, W, sx, sy, sf, sp, st, pub, gf, gp, gt);
 }
 
+static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 extern "C" float wm_last_aux_ms(const wm_ctx_t *c) { return c ? c->aux_ms : 0.f; }
 
 extern "C" int wm_index_build(const char *fasta, const char *kmer_file, int k, int w, int n_threads, wm_index_t **out)
@@ -703,6 +704,8 @@ extern "C" int wm_chain_batch(wm_ctx_t *c, int n, wm128_t *a, const uint64_t *a_
 	if (n <= 0) return WM_OK;
 	HIPCHK(hipSetDevice(c->device));
 	ArenaMark mark(c);
+	static const bool trace = getenv("WM_TRACE") != 0;
+	const double tt0 = trace ? now_ms() : 0;
 	uint64_t tot = 0;
 	for (int i = 0; i < n; ++i) tot = std::max<uint64_t>(tot, a_off[i] + n_a[i]);
 	std::vector<wm_chain_job_t> jb(n);
@@ -723,11 +726,17 @@ extern "C" int wm_chain_batch(wm_ctx_t *c, int n, wm128_t *a, const uint64_t *a_
 	HIPCHK(hipMemcpyAsync(d_jobs, jb.data(), (size_t)n * sizeof(wm_chain_job_t), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipMemcpyAsync(d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipMemcpyAsync(d_a, a, tot * sizeof(wm128_t), hipMemcpyHostToDevice, c->stream));
+	const double tt1 = trace ? now_ms() : 0;
 	HIPCHK(hipEventRecord(c->ev[0], c->stream));
 	{   // size classes by anchor count (order is sorted by n descending): LDS footprint = 32 B * W
 		HIPCHK(hipFuncSetAttribute((const void*)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		constexpr int NWV = 8;
 		HIPCHK(hipFuncSetAttribute((const void*)chain_kernel_block<NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		// tuning hooks (probes only): window of the largest class, and whether it runs the multi-wave kernel
+		static const int big_w = getenv("WM_CHAIN_BIG_W") ? atoi(getenv("WM_CHAIN_BIG_W")) : 4096;
+		static const int use_block = getenv("WM_CHAIN_BLOCK") ? atoi(getenv("WM_CHAIN_BLOCK")) : 1;
+		const int big_W = getenv("WM_CHAIN_TUNE") ? (getenv("WM_CHAIN_BIG_W") ? atoi(getenv("WM_CHAIN_BIG_W")) : 4096) : big_w;
+		const int blk = getenv("WM_CHAIN_TUNE") ? (getenv("WM_CHAIN_BLOCK") ? atoi(getenv("WM_CHAIN_BLOCK")) : 1) : use_block;
 		const int caps[3] = { 4096, 1024, 256 };
 		int b = 0;
 		for (int k = 0; k < 3; ++k) {
@@ -735,37 +744,43 @@ extern "C" int wm_chain_batch(wm_ctx_t *c, int n, wm128_t *a, const uint64_t *a_
 			int e = b;
 			while (e < n && n_a[order[e]] > lo) ++e;
 			if (e > b) {
-				if (k == 0) hipLaunchKernelGGL(chain_kernel_block<NWV>, dim3(e - b), dim3(64 * NWV), (size_t)caps[0] * 32 + NWV * 69 * 4 + 64, c->stream, d_jobs, d_order + b, d_a, d_fpvt, caps[0]);
-				else hipLaunchKernelGGL(chain_kernel, dim3(e - b), dim3(64), (size_t)caps[k] * 32, c->stream, d_jobs, d_order + b, d_a, d_fpvt, caps[k]);
+				if (k == 0 && blk) hipLaunchKernelGGL(chain_kernel_block<NWV>, dim3(e - b), dim3(64 * NWV), (size_t)big_W * 28 + NWV * 69 * 4 + 64, c->stream, d_jobs, d_order + b, d_a, d_fpvt, big_W);
+				else if (k == 0) hipLaunchKernelGGL(chain_kernel, dim3(e - b), dim3(64), (size_t)big_W * 28, c->stream, d_jobs, d_order + b, d_a, d_fpvt, big_W);
+				else hipLaunchKernelGGL(chain_kernel, dim3(e - b), dim3(64), (size_t)caps[k] * 28, c->stream, d_jobs, d_order + b, d_a, d_fpvt, caps[k]);
 			}
 			b = e;
 		}
 	}
 	HIPCHK(hipEventRecord(c->ev[1], c->stream));
+	const double tt2 = trace ? now_ms() : 0;
 	std::vector<int> fpvt((tot + 1) * 4);
 	HIPCHK(hipMemcpyAsync(fpvt.data(), d_fpvt, tot * 16, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventElapsedTime(&c->aux_ms, c->ev[0], c->ev[1]));
+	const double tt3 = trace ? now_ms() : 0;
 	// chain extraction (src/chain.c:93-165): O(n) bookkeeping on the fill's f/p/v
 	uint64_t uo = 0;
 	std::vector<uint64_t> uu;
 	std::vector<wm::m128> bb;
 	for (int i = 0; i < n; ++i) {
-		const int *f = fpvt.data() + a_off[i] * 4, *p = f + n_a[i], *v = p + n_a[i];
+		const int *f = fpvt.data() + a_off[i] * 4, *p = f + n_a[i];
+		int *v = fpvt.data() + a_off[i] * 4 + 2 * (size_t)n_a[i];
+		for (int k = 0; k < n_a[i]; ++k) v[k] = p[k] >= 0 && v[p[k]] > f[k] ? v[p[k]] : f[k];          // peak score, src/chain.c:89
 		wm::chain_extract(n_a[i], a + a_off[i], f, p, v, par[i].min_cnt, par[i].min_sc, uu, bb);
 		u_off[i] = uo; n_u[i] = (int)uu.size(); n_v[i] = (int)bb.size();
 		for (size_t k = 0; k < uu.size(); ++k) u[uo + k] = uu[k];
 		uo += uu.size();
 		if (!bb.empty()) memcpy(a + a_off[i], bb.data(), bb.size() * sizeof(wm128_t));
 	}
+	if (trace) fprintf(stderr, "[chain_batch] n=%d anchors=%llu prep+h2d %.2f launch %.2f wait %.2f (kernel %.2f) extract %.2f ms\n", n, (unsigned long long)tot,
+	                   tt1 - tt0, tt2 - tt1, tt3 - tt2, c->aux_ms, now_ms() - tt3);
 	return WM_OK;
 }
 
 // ======================================================================================================
 // GpuOps: the product implementation of the mapper's device operations
 // ======================================================================================================
-static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct GpuOps : wm::DeviceOps {
 	wm_ctx_t *c;
 	uint64_t cells = 0;
