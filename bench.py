@@ -102,7 +102,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
     n_cores = os.cpu_count() or 1
-    n_threads = args.threads or max(1, min(32, n_cores // max(1, world) // 2))
+    n_threads = args.threads or max(1, min(64, n_cores // max(1, world) // 2))
     tmp = tempfile.mkdtemp(prefix="wmbench_")
 
     # ---- reference + index: rank 0 builds, RCCL broadcasts the flat arrays ----
@@ -137,11 +137,12 @@ def main():
         if rank != 0:
             n_contigs = max(1, int(round(args.ref_mb / 10.0)))
             ref = synth.make_reference(n_contigs, int(args.ref_mb * 1e6 / n_contigs), 3, repeat_frac=0.10)
-    ctx = gpu.Context(local, (6 << 30) if n_threads > 1 else (24 << 30))
+    arena = int(os.environ.get("WM_BENCH_ARENA_GB", 48)) << 30   # per group; 288 GB of HBM per GPU
+    ctx = gpu.Context(local, arena)
     idx.upload(ctx)
     mapper = gpu.Mapper(ctx, idx, "map-ont", gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
     if n_threads > 1:
-        mapper.set_threads(n_threads, 6 << 30)
+        mapper.set_threads(n_threads, arena)
 
     # ---- reads: a fresh batch per step, generated before the clock starts ----
     t1 = time.time()

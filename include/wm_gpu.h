@@ -145,8 +145,10 @@ typedef struct wm_mapper_s wm_mapper_t;
  * flag: mm_mapopt_t::flag bits to OR in (MM_F_CIGAR 0x4, MM_F_OUT_SAM 0x8, MM_F_OUT_CG 0x20, ...). */
 int wm_mapper_create(wm_ctx_t *ctx, const wm_index_t *idx, const char *preset, int64_t flag, wm_mapper_t **out);
 void wm_mapper_destroy(wm_mapper_t *m);
-/* host parallelism: n_threads scheduler threads, each with its own HIP stream + arena slice (0 = same size as ctx) */
-int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena_bytes_per_thread);
+/* host parallelism (the reference's -t): n_threads host threads run the per-read glue; they are organised in groups
+ * (2 by default, env WM_GROUPS) that each share one device batch per operation on their own HIP stream + arena slice
+ * (arena_bytes_per_group; 0 = same size as ctx). */
+int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena_bytes_per_group);
 /* Map n reads (ASCII). Output records (PAF, or SAM when MM_F_OUT_SAM) of all reads in input order are appended to
  * an internal buffer returned through *text / *text_len (valid until the next call). hits (optional, 16 int32 per
  * hit: rid rs re qs qe rev mapq n_cigar score cnt mlen blen dp_score dp_max dp_max2 flags) and their CIGARs are

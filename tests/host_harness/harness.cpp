@@ -93,6 +93,7 @@ struct OracleOps : DeviceOps {
 		for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) mat[i * 5 + j] = (i == 4 || j == 4) ? sc.sc_ambi : i == j ? sc.match : sc.mismatch;
 		for (KswReq *r : reqs) {
 			wmo_ez_t ez;
+			if (getenv("WM_KSW_STATS")) fprintf(stderr, "KSWJOB %d %d %d %d %d\n", (int)r->q.size(), (int)r->t.size(), r->w, r->zdrop, r->flag);
 			std::vector<uint32_t> cig(r->q.size() + r->t.size() + 4);
 			wmo_ksw_extd2((int)r->q.size(), r->q.data(), (int)r->t.size(), r->t.data(), 5, mat, sc.q, sc.e, sc.q2, sc.e2, r->w, r->zdrop, r->end_bonus, r->flag, &ez, cig.data(), 0);
 			r->ez.max = ez.max; r->ez.zdropped = ez.zdropped; r->ez.max_q = ez.max_q; r->ez.max_t = ez.max_t; r->ez.mqe = ez.mqe; r->ez.mqe_t = ez.mqe_t;
@@ -193,6 +194,37 @@ int h_map(void *hv, const char *preset, int64_t flag_extra, const char *seq, int
 	}
 	*n_cig_total = nc;
 	return (int)regs.size();
+}
+
+// several reads at once on a team of `n_threads` schedulers; hits of read i start at hit_first[i] (16 ints each)
+int h_map_many(void *hv, const char *preset, int64_t flag_extra, int n, const char *const *seqs, const int *lens, int n_threads,
+               int32_t *hit_out, int hit_cap, int64_t *hit_first, uint32_t *cig_out, int64_t cig_cap, int64_t *n_cig_total)
+{
+	Harness *h = (Harness*)hv;
+	IdxOpt io; MapOpt mo;
+	set_preset(0, io, mo);
+	if (preset && preset[0] && set_preset(preset, io, mo) < 0) return -1;
+	mo.flag |= flag_extra;
+	OracleOps ops; ops.idx = &h->idx; ops.bloom = h->bloom; ops.opt = &mo;
+	std::vector<ReadIn> reads(n);
+	for (int i = 0; i < n; ++i) { reads[i].name = "read" + std::to_string(i); reads[i].seq.assign(seqs[i], lens[i]); }
+	std::vector<ReadOut> out;
+	map_batch(h->idx, mo, &ops, reads, out, 0, n_threads);
+	int64_t nc = 0; int nh = 0;
+	for (int k = 0; k < n; ++k) {
+		hit_first[k] = nh;
+		for (const Reg &r : out[k].regs) {
+			if (nh >= hit_cap) return -2;
+			int32_t *o = hit_out + 16 * (size_t)nh++;
+			o[0] = r.rid; o[1] = r.rs; o[2] = r.re; o[3] = r.qs; o[4] = r.qe; o[5] = r.rev; o[6] = r.mapq; o[7] = r.has_p ? (int)r.cigar.size() : 0;
+			o[8] = r.score; o[9] = r.cnt; o[10] = r.mlen; o[11] = r.blen; o[12] = r.dp_score; o[13] = r.dp_max; o[14] = r.dp_max2;
+			o[15] = (r.parent == r.id) | r.inv << 1 | r.sam_pri << 2 | r.split << 3;
+			for (uint32_t c : r.cigar) { if (nc < cig_cap) cig_out[nc] = c; ++nc; }
+		}
+	}
+	hit_first[n] = nh;
+	*n_cig_total = nc;
+	return nh;
 }
 
 } // extern "C"

@@ -37,7 +37,8 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 	jb.q_off = 0; jb.t_off = qlen; jb.qlen = qlen; jb.tlen = tlen; jb.w = w; jb.zdrop = zdrop; jb.end_bonus = end_bonus; jb.flag = flag;
 	int n_col, klass = wm_ksw_classify(qlen, tlen, w, wm_ksw_has_n(query, qlen) | wm_ksw_has_n(target, tlen), &n_col);
 	if (force_klass >= 0) {
-		if ((force_klass & ~3) < (klass & ~3)) return -1; // window too small for this job
+		if (force_klass < WM_KSW_BLOCK && (force_klass & ~3) < (klass & ~3)) return -1; // window too small for this job
+		if (force_klass == WM_KSW_BLOCK && klass > WM_KSW_BLOCK) return -1;
 		klass = force_klass;
 	}
 	*klass_out = klass;
@@ -46,7 +47,22 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 	wm_ksw_dres_t res;
 	memset(&res, 0, sizeof(res));
 	const int clip = klass >> 1 & 1, hasn = klass & 1;
-	if (klass >= WM_KSW_GENERIC) {
+	if (klass == WM_KSW_BLOCK) {
+		constexpr int NWV = WM_KSW_BLK_NWV, K = WM_KSW_BLK_K, WN = WM_KSW_BLK_WN;
+		std::vector<int> W0(WN, 0x5a5a5a5a), W1(WN, 0x5a5a5a5a), Hm(WN, 0x5a5a5a5a), pub(2 * NWV + 8);   // LDS starts as garbage
+		pthread_barrier_t bar;
+		pthread_barrier_init(&bar, 0, NWV);
+		simt::block_barrier() = &bar;
+		std::vector<std::thread> th;
+		for (int w = 0; w < NWV; ++w)
+			th.emplace_back([&, w]() {
+				simt::wave_slot() = w; simt::exec_mask() = ~0ull;
+				wmk::ksw_dp_block<NWV, K>(sc, jb, seqs.data(), tb.data(), W0.data(), W1.data(), Hm.data(), WN, pub.data(), &res);
+			});
+		for (auto &t : th) t.join();
+		simt::block_barrier() = 0;
+		pthread_barrier_destroy(&bar);
+	} else if (klass >= WM_KSW_GENERIC) {
 		const int T = (tlen + 15) / 16 * 16;
 		std::vector<signed char> mem((size_t)7 * T + 64);
 		std::vector<int> Hm(T + 16);

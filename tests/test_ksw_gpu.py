@@ -96,3 +96,23 @@ def test_round_trip_property_full_size(ctx):
                 score -= min(4 + 2 * l, 24 + l); ti += l
         assert qi == len(c["q"]) and ti == len(c["t"])
         assert score == int(res[i]["score"]), (i, score, int(res[i]["score"]))
+
+
+def test_wide_band_jobs_block_and_generic_kernels(ctx):
+    # hulls wider than the register window: stage-2 gap fills (w = 3001 -> multi-wave LDS kernel) and one job whose
+    # hull exceeds even that (global-scratch generic kernel)
+    from winnowmap_amd import synth
+    rng = np.random.default_rng(21)
+    cases = []
+    for it in range(14):
+        tl = int(rng.integers(1100, 2800))
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        q = synth.mutate_codes(t, rng, 0.04, 0.04, 0.05) if it % 4 else rng.integers(0, 4, int(rng.integers(1100, 2200))).astype(np.uint8)
+        if it % 5 == 1:
+            q[int(rng.integers(0, len(q)))] = 4
+        cases.append(dict(q=q, t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=[3001, 1500, 3001, 2000][it % 4], zdrop=[400, 200, -1][it % 3],
+                          end_bonus=-1, flag=kswcases.FLAGS[it % 6]))
+    t = rng.integers(0, 4, 3400).astype(np.uint8)
+    cases.append(dict(q=synth.mutate_codes(t, rng, 0.03, 0.03, 0.03), t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=-1, zdrop=400, end_bonus=-1, flag=0x08))
+    bad = _run_group(ctx, cases)
+    assert not bad, bad[:3]

@@ -11,7 +11,7 @@ tmp = tempfile.mkdtemp()
 ref = synth.make_reference(max(1, int(ref_mb / 10)), 10_000_000 if ref_mb >= 10 else int(ref_mb * 1e6), 3, repeat_frac=0.1)
 synth.write_fasta(tmp + "/ref.fa", ref)
 t1 = time.time()
-ctx = gpu.Context(0, (24 << 30) if len(sys.argv) <= 4 or int(sys.argv[4]) <= 1 else (6 << 30))
+ctx = gpu.Context(0, 48 << 30)
 kf = None
 if len(sys.argv) > 3 and sys.argv[3] == "W":
     tk = time.time()
@@ -30,7 +30,7 @@ print("gen ref %.1fs, index %.1fs (%d minimizers), reads %.1fs" % (t1 - t0, t2 -
 m = gpu.Mapper(ctx, idx, "map-ont", gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
 nth = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 if nth > 1:
-    m.set_threads(nth, 6 << 30)
+    m.set_threads(nth, 48 << 30)
 for rep in range(2):
     t4 = time.time()
     text, hits, cig, first = m.map(names, seqs)

@@ -6,6 +6,8 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <thread>
+#include <atomic>
 #include "../../../include/wm_gpu.h"
 
 namespace wm {
@@ -87,5 +89,19 @@ uint32_t wang_hash32(uint32_t key);                                   // __ac_Wa
 uint32_t x31_hash_string(const char *s);                              // __ac_X31_hash_string, src/khash.h
 
 extern const uint8_t *const nt4_table;                                  // seq_nt4_table, src/sketch.c:19-36
+
+// host-side helper: fn(i) for i in [0, n) on up to n_threads threads (dynamic chunks); used for packing / unpacking batches
+template <class F> inline void parallel_for(int n_threads, size_t n, F fn)
+{
+	if (n_threads <= 1 || n < 2) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+	const size_t T = (size_t)n_threads < n ? (size_t)n_threads : n;
+	const size_t chunk = n / (T * 8) > 0 ? n / (T * 8) : 1;
+	std::atomic<size_t> next(0);
+	auto body = [&]() { for (;;) { const size_t b = next.fetch_add(chunk); if (b >= n) break; const size_t e = b + chunk < n ? b + chunk : n; for (size_t i = b; i < e; ++i) fn(i); } };
+	std::vector<std::thread> th;
+	for (size_t t = 1; t < T; ++t) th.emplace_back(body);
+	body();
+	for (auto &x : th) x.join();
+}
 
 } // namespace wm

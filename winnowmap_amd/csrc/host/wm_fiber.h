@@ -15,13 +15,29 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <chrono>
+#include <pthread.h>
 #include "wm_ops.h"
 
 namespace wm {
 
+class Scheduler;
+
+// A TEAM of schedulers, one per host thread, that share their device batches: every member runs its own fibers (the
+// host glue of its reads) in parallel with the others; when all members have nothing runnable they meet at a barrier,
+// member 0 issues ONE batched device call per operation type for the whole team, and everybody resumes its waiters.
+// Host work scales with the threads while the kernels still see the batch of the whole team.
+struct SchedTeam {
+	explicit SchedTeam(int n) : n_(n) { pthread_barrier_init(&bar_, 0, (unsigned)n); }
+	~SchedTeam() { pthread_barrier_destroy(&bar_); }
+	int n_;
+	pthread_barrier_t bar_;
+	std::vector<Scheduler*> members;
+	bool done = false;
+};
+
 class Scheduler {
 public:
-	Scheduler(DeviceOps *ops, const wm_ksw_score_t &sc, int w, int k) : ops_(ops), sc_(sc), w_(w), k_(k) {}
+	Scheduler(DeviceOps *ops, const wm_ksw_score_t &sc, int w, int k, SchedTeam *team = 0, int rank = 0) : ops_(ops), sc_(sc), w_(w), k_(k), team_(team), rank_(rank) {}
 	~Scheduler() { for (Fiber *f : pool_) { free(f->stack); delete f; } }
 
 	void spawn(std::function<void()> fn)
@@ -39,18 +55,20 @@ public:
 		++live_;
 	}
 
-	// run until every fiber has finished
+	// run until every fiber (of the whole team, if there is one) has finished
 	void run()
 	{
-		while (live_ > 0) {
+		for (;;) {
 			while (!ready_.empty()) {
 				cur_ = ready_.front(); ready_.pop_front();
 				swapcontext(&main_, &cur_->ctx);
 				if (cur_->done) { cur_->fn = nullptr; pool_.push_back(cur_); --live_; }
 				cur_ = 0;
 			}
-			if (live_ == 0) break;
-			flush();
+			if (!team_) {
+				if (live_ == 0) break;
+				flush();
+			} else if (!team_round()) break;
 		}
 	}
 
@@ -73,6 +91,29 @@ private:
 	}
 	void wait(std::vector<Fiber*> &w) { Fiber *me = cur_; w.push_back(me); swapcontext(&me->ctx, &main_); }
 	void wake(std::vector<Fiber*> &w) { for (Fiber *f : w) ready_.push_back(f); w.clear(); }
+	bool team_round()
+	{
+		pthread_barrier_wait(&team_->bar_);                            // every member is blocked or finished
+		if (rank_ == 0) {
+			size_t live = 0;
+			for (Scheduler *m : team_->members) live += m->live_;
+			team_->done = live == 0;
+			if (!team_->done) {                                          // gather everybody's requests into this member's queues
+				for (Scheduler *m : team_->members) {
+					if (m == this) continue;
+					q_sketch_.insert(q_sketch_.end(), m->q_sketch_.begin(), m->q_sketch_.end()); m->q_sketch_.clear();
+					q_seed_.insert(q_seed_.end(), m->q_seed_.begin(), m->q_seed_.end()); m->q_seed_.clear();
+					q_chain_.insert(q_chain_.end(), m->q_chain_.begin(), m->q_chain_.end()); m->q_chain_.clear();
+					q_ksw_.insert(q_ksw_.end(), m->q_ksw_.begin(), m->q_ksw_.end()); m->q_ksw_.clear();
+				}
+				flush();
+			}
+		}
+		pthread_barrier_wait(&team_->bar_);                            // results are in the requests
+		if (team_->done) return false;
+		if (rank_ != 0) { wake(w_sketch_); wake(w_seed_); wake(w_chain_); wake(w_ksw_); }
+		return true;
+	}
 	void flush()
 	{
 		++n_flush;
@@ -96,6 +137,8 @@ private:
 	DeviceOps *ops_;
 	wm_ksw_score_t sc_;
 	int w_, k_;
+	SchedTeam *team_;
+	int rank_;
 	ucontext_t main_;
 	Fiber *cur_ = 0;
 	size_t live_ = 0;

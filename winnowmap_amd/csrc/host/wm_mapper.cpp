@@ -1,5 +1,7 @@
 // wm_mapper.cpp — see wm_mapper.h.
 #include "wm_mapper.h"
+#include <thread>
+#include <memory>
 #include "wm_hit.h"
 #include "wm_align.h"
 #include "wm_fiber.h"
@@ -165,48 +167,71 @@ void stage2(Scheduler &sch, const Index &idx, const MapOpt &opt, ReadTask &T)
 
 } // namespace
 
-void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::vector<ReadIn> &reads, std::vector<ReadOut> &out, MapStats *stats)
+namespace {
+// create the fibers of one read on scheduler `sch` (stage-1 positions, then stage 2; src/map.c:304-341)
+void spawn_read(Scheduler &sch, const Index &idx, const MapOpt &opt, const MapOpt &o2, ReadTask &T)
+{
+	T.codes.resize(T.qlen);
+	for (int j = 0; j < T.qlen; ++j) T.codes[j] = nt4_table[(uint8_t)T.in->seq[j]];
+	if (T.qlen == 0) return;
+	if (opt.max_qlen > 0 && T.qlen > opt.max_qlen) return;
+	const int off = o2.suffixSampleOffset;
+	const int n_pos = 1 + (int)ceil(T.qlen * 1.0 / off);
+	T.collect.assign(n_pos, std::vector<m128>());
+	T.mapped.assign(T.qlen, 0);
+	ReadTask *tp = &T;
+	Scheduler *sp = &sch;
+	const Index *ip = &idx; const MapOpt *op = &opt, *o2p = &o2;
+	if (o2.SVaware && T.qlen >= o2.SVawareMinReadLength) {
+		std::vector<std::pair<int, int>> pos;                           // (sub_begin, suffix_id), src/map.c:334-341
+		for (int sb = 0; sb < T.qlen + off - 1; sb += off) {
+			const int sid = sb / off;
+			int b = sb;
+			if (b >= T.qlen) b = T.qlen - 1;
+			pos.push_back(std::make_pair(b, sid));
+			if (b != sb) break;
+		}
+		T.pending = (int)pos.size();
+		for (auto p : pos)
+			sch.spawn([sp, ip, op, o2p, tp, p]() {
+				stage1_position(*sp, *ip, *op, *o2p, *tp, p.first, p.second);
+				if (--tp->pending == 0) sp->spawn([sp, ip, op, tp]() { stage2(*sp, *ip, *op, *tp); });
+			});
+	} else sch.spawn([sp, ip, op, tp]() { stage2(*sp, *ip, *op, *tp); });
+}
+} // namespace
+
+void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::vector<ReadIn> &reads, std::vector<ReadOut> &out, MapStats *stats, int n_threads)
 {
 	out.assign(reads.size(), ReadOut());
 	wm_ksw_score_t sc;
 	sc.match = (int8_t)opt.a; sc.mismatch = (int8_t)-abs(opt.b); sc.sc_ambi = (int8_t)-abs(opt.sc_ambi);
 	sc.q = (int8_t)opt.q; sc.e = (int8_t)opt.e; sc.q2 = (int8_t)opt.q2; sc.e2 = (int8_t)opt.e2;
-	Scheduler sch(ops, sc, idx.w, idx.k);
 	MapOpt o2 = opt;                                                   // stage-1 options (src/map.c:300-302)
 	o2.best_n = std::max(5, o2.best_n);
 	std::vector<ReadTask> tasks(reads.size());
-	for (size_t i = 0; i < reads.size(); ++i) {
-		ReadTask &T = tasks[i];
-		T.in = &reads[i]; T.out = &out[i];
-		T.qlen = (int)reads[i].seq.size();
-		T.codes.resize(T.qlen);
-		for (int j = 0; j < T.qlen; ++j) T.codes[j] = nt4_table[(uint8_t)reads[i].seq[j]];
-		if (T.qlen == 0) continue;
-		if (opt.max_qlen > 0 && T.qlen > opt.max_qlen) continue;
-		const int off = o2.suffixSampleOffset;
-		const int n_pos = 1 + (int)ceil(T.qlen * 1.0 / off);
-		T.collect.assign(n_pos, std::vector<m128>());
-		T.mapped.assign(T.qlen, 0);
-		ReadTask *tp = &T;
-		if (o2.SVaware && T.qlen >= o2.SVawareMinReadLength) {
-			std::vector<std::pair<int, int>> pos;                       // (sub_begin, suffix_id), src/map.c:334-341
-			for (int sb = 0; sb < T.qlen + off - 1; sb += off) {
-				const int sid = sb / off;
-				int b = sb;
-				if (b >= T.qlen) b = T.qlen - 1;
-				pos.push_back(std::make_pair(b, sid));
-				if (b != sb) break;
-			}
-			T.pending = (int)pos.size();
-			for (auto p : pos)
-				sch.spawn([&sch, &idx, &opt, &o2, tp, p]() {
-					stage1_position(sch, idx, opt, o2, *tp, p.first, p.second);
-					if (--tp->pending == 0) sch.spawn([&sch, &idx, &opt, tp]() { stage2(sch, idx, opt, *tp); });
-				});
-		} else sch.spawn([&sch, &idx, &opt, tp]() { stage2(sch, idx, opt, *tp); });
+	for (size_t i = 0; i < reads.size(); ++i) { tasks[i].in = &reads[i]; tasks[i].out = &out[i]; tasks[i].qlen = (int)reads[i].seq.size(); }
+	if (n_threads <= 1) {
+		Scheduler sch(ops, sc, idx.w, idx.k);
+		for (ReadTask &T : tasks) spawn_read(sch, idx, opt, o2, T);
+		sch.run();
+		if (stats) { stats->n_flush += sch.n_flush; stats->n_ksw += sch.n_ksw_jobs; stats->n_chain += sch.n_chain_jobs; stats->n_seed += sch.n_seed_jobs; stats->n_sketch += sch.n_sketch_jobs; }
+		return;
 	}
-	sch.run();
-	if (stats) { stats->n_flush += sch.n_flush; stats->n_ksw += sch.n_ksw_jobs; stats->n_chain += sch.n_chain_jobs; stats->n_seed += sch.n_seed_jobs; stats->n_sketch += sch.n_sketch_jobs; }
+	// a team of schedulers: read i belongs to member i % T (all fibers of a read stay on one thread); device batches are shared
+	const int T = n_threads;
+	SchedTeam team(T);
+	std::vector<std::unique_ptr<Scheduler>> sch(T);
+	for (int t = 0; t < T; ++t) { sch[t].reset(new Scheduler(ops, sc, idx.w, idx.k, &team, t)); team.members.push_back(sch[t].get()); }
+	auto work = [&](int t) {
+		for (size_t i = t; i < tasks.size(); i += T) spawn_read(*sch[t], idx, opt, o2, tasks[i]);
+		sch[t]->run();
+	};
+	std::vector<std::thread> th;
+	for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+	work(0);
+	for (auto &x : th) x.join();
+	if (stats) { Scheduler &s0 = *sch[0]; stats->n_flush += s0.n_flush; stats->n_ksw += s0.n_ksw_jobs; stats->n_chain += s0.n_chain_jobs; stats->n_seed += s0.n_seed_jobs; stats->n_sketch += s0.n_sketch_jobs; }
 }
 
 } // namespace wm

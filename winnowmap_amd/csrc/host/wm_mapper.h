@@ -14,6 +14,7 @@ struct ReadOut { std::vector<Reg> regs; int rep_len = 0, frag_gap = 0; };
 struct MapStats { uint64_t n_flush = 0, n_ksw = 0, n_chain = 0, n_seed = 0, n_sketch = 0; };
 
 // Maps reads[i] → out[i] (out is resized). The caller chooses the batch (the reference uses ≤ 1 Gbase mini-batches).
-void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::vector<ReadIn> &reads, std::vector<ReadOut> &out, MapStats *stats = 0);
+// n_threads > 1: the host glue of the reads runs on that many threads (a SchedTeam); device batches span the whole team.
+void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::vector<ReadIn> &reads, std::vector<ReadOut> &out, MapStats *stats = 0, int n_threads = 1);
 
 } // namespace wm

@@ -495,6 +495,207 @@ WM_DEV void ksw_dp_generic(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, cons
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Block kernel for band hulls wider than the register window but narrow enough for LDS (the stage-2 gap fills of
+// map-ont / map-pb: w = 3001, hull <= 3040 lanes): NWV wavefronts share ONE alignment. The per-lane state of the
+// same machine lives in LDS as two packed words per lane (u|v|x|y and x2|y2|s, raw int8 bytes; x,y,x2,y2 biased by
+// their gap-open+extend cost as in the generic kernel) plus an int32 H (exact-max mode), in a circular window of Wn
+// lanes (Wn a power of two > hull + 64; a lane enters and leaves the hull exactly once, so slots are recycled and a
+// lane that was never computed is substituted by its initial value instead of being pre-filled).
+// Row r: every wave LOADS its K tiles (own words + the words of lane t-1, previous-row values) | barrier | computes,
+// stores, publishes the values the scalar bookkeeping needs (row maximum, H at en0 / st0, the approximate-max
+// track) | barrier | all waves replay the same scalar bookkeeping from the published values, so they stay in step.
+// ------------------------------------------------------------------------------------------------------
+template <int NWV, int K>
+WM_DEV void ksw_dp_block(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb_arena,
+                         int *W0, int *W1, int *Hm, int Wn, int *pub, wm_ksw_dres_t *__restrict__ res)
+{
+	const int qlen = jb.qlen, tlen = jb.tlen, flag = jb.flag, zdrop = jb.zdrop;
+	const int w = jb.w < 0 ? (tlen > qlen ? tlen : qlen) : jb.w;
+	const bool approx = (flag & KSW_F_APPROX_MAX) != 0, right = (flag & KSW_F_RIGHT) != 0;
+	const uint8_t *query = seqs + jb.q_off, *target = seqs + jb.t_off;
+	uint8_t *tbp = tb_arena + jb.tb_off;
+	const int wmask = Wn - 1;
+	const int q = sc.q, e = sc.e, q2 = sc.q2, e2 = sc.e2, qe = q + e, qe2 = q2 + e2;
+	const int Q = tb8(q), Q2 = tb8(q2), QE = tb8(qe), QE2 = tb8(qe2);
+	const int tS = right ? 0 : 4, tA = right ? 1 : 3, tB = 2, tA2 = right ? 3 : 1, tB2 = right ? 4 : 0;
+	const int hA = right ? tA - 1 : tA, hB = right ? tB - 1 : tB, hA2 = right ? tA2 - 1 : tA2, hB2 = right ? tB2 - 1 : tB2;
+	const int MCH = tb8(sc.match);
+	const int sc_n = sc.sc_ambi == 0 ? -e2 : sc.sc_ambi;
+	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+	const V<int> ln = lane();
+	const int wv = wave_in_block();
+	const int INIT0 = (int)(((unsigned)(-qe) & 0xffu) | ((unsigned)(-qe) & 0xffu) << 8);      // u = v = -qe, x = y = 0 (biased)
+	int *pub_key = pub, *pub_val = pub + 2 * NWV;                                             // wave maxima (lo,hi) | h_en0, h_st0, d0, d1
+
+	int ez_max = 0, ez_zdropped = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1;
+	int ez_mte = KSW_NEG_INF, ez_mte_q = -1, ez_score = KSW_NEG_INF;
+	int H0 = 0, last_H0_t = 0, last_st = -1, last_en = -1, w1_hi = -1;
+	const int n_rows = qlen + tlen - 1;
+	for (int r = 0; r < n_rows; ++r) {
+		int st0 = 0, en0 = tlen - 1;
+		if (st0 < r - qlen + 1) st0 = r - qlen + 1;
+		if (en0 > r) en0 = r;
+		if (st0 < (r - w + 1) >> 1) st0 = (r - w + 1) >> 1;
+		if (en0 > (r + w) >> 1) en0 = (r + w) >> 1;
+		if (st0 > en0) { ez_zdropped = 1; break; }
+		const int st = st0 / 16 * 16, en = (en0 + 16) / 16 * 16 - 1;
+		const int sched = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
+		const int cend = st0 + (en0 - st0) / 16 * 16 + 15;               // last lane of the rewritten score chunks (:158-173)
+		const int top = en > cend ? en : cend;
+		const int en1 = st0 + (en0 - st0) / 4 * 4;
+		WM_EMU_ASSERT(top - st + 1 <= 64 * NWV * K);
+
+		// ---- loads: own state and the previous-row state of lane t-1 ------------------------------------
+		V<int> o0[K], o1[K], oh[K], n0[K], n1[K], nh[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const V<int> t = ln + (st + 64 * (wv + NWV * k));
+			o0[k] = INIT0; o1[k] = 0; oh[k] = KSW_NEG_INF; n0[k] = INIT0; n1[k] = 0; nh[k] = KSW_NEG_INF;
+			if (st + 64 * (wv + NWV * k) > top) continue;
+			WM_IF(t <= top)
+				WM_IF(t <= last_en) o0[k] = gld(W0, t & wmask); if (!approx) oh[k] = gld(Hm, t & wmask); WM_END
+				WM_IF(t <= w1_hi) o1[k] = gld(W1, t & wmask); WM_END
+				const V<int> tm = t - 1;
+				WM_IF(tm >= last_st && tm <= last_en) n0[k] = gld(W0, tm & wmask); n1[k] = gld(W1, tm & wmask); WM_END
+				if (!approx) { WM_IF(tm >= 0 && tm <= last_en) nh[k] = gld(Hm, tm & wmask); WM_END }
+			WM_END
+		}
+		block_sync_lds();
+
+		// ---- compute, store, publish ------------------------------------------------------------------------
+		V<long long> key = (long long)(-0x7fffffffffffffffLL - 1);
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const int tile0 = st + 64 * (wv + NWV * k);
+			if (tile0 > top) continue;
+			const V<int> t = ln + tile0;
+			// score of this row for the lanes inside the rewritten chunks; the others keep their old score byte
+			V<int> s8 = (o1[k] << 8) >> 24;
+			WM_IF(t >= st0 && t <= cend)
+				V<int> tc = 0, qc = 0;
+				WM_IF(t < tlen) tc = cast<int>(gld(target, t)); WM_END
+				const V<int> qi = V<int>(r) - t;
+				WM_IF(qi >= 0 && qi < qlen) qc = cast<int>(gld(query, qi)); WM_END
+				s8 = sel(tc == qc, (int)sc.match, (int)sc.mismatch);
+				s8 = sel((tc == 4) || (qc == 4), sc_n, s8);
+			WM_END
+			WM_IF(t > en && t <= cend)                                   // score-only lanes above the hull: x2 = y2 = initial
+				gst(W1, t & wmask, (o1[k] & 0xffff) | ((s8 & 0xff) << 16));
+			WM_END
+			WM_IF(t <= en)
+				V<int> ou = o0[k] << 24, ov = (o0[k] << 16) & (int)0xff000000;
+				V<int> oy = (o0[k] & (int)0xff000000) | tB, oy2 = ((o1[k] << 16) & (int)0xff000000) | tB2;
+				WM_IF(t == r)                                             // first column / first row boundary (:152-155)
+					oy = tB; oy2 = tB2; ou = tb8(sched);
+				WM_END
+				const V<int> os = (s8 << 24) | tS;
+				V<int> x1 = ((n0[k] << 8) & (int)0xff000000) | tA, v1 = (n0[k] << 16) & (int)0xff000000, x21 = (n1[k] << 24) | tA2;
+				WM_IF(t == 0) x1 = tA; x21 = tA2; v1 = tb8(sched); WM_END    // :141-151 (st == 0)
+				V<int> a = add3(x1, v1, -QE), b = add3(oy, ou, -QE), a2 = add3(x21, v1, -QE2), b2 = add3(oy2, ou, -QE2);
+				V<int> zz = vmax3(vmax3(os, a, b), a2, b2);
+				V<int> z = vmin(zz & (int)0xff000000, MCH);
+				V<int> p = zz & 7;
+				const V<int> nu = wsub(z, v1), nv = wsub(z, ou);
+				V<int> tmp = wsub(z, Q), tmp2 = wsub(z, Q2);
+				a = wsub(a, tmp); b = wsub(b, tmp); a2 = wsub(a2, tmp2); b2 = wsub(b2, tmp2);
+				p = wadd(wadd(p, p), sel(a > hA, 1, 0));
+				p = wadd(wadd(p, p), sel(b > hB, 1, 0));
+				p = wadd(wadd(p, p), sel(a2 > hA2, 1, 0));
+				p = wadd(wadd(p, p), sel(b2 > hB2, 1, 0));
+				const V<int> nx = vmax(a, tA), ny = vmax(b, tB), nx2 = vmax(a2, tA2), ny2 = vmax(b2, tB2);
+				const V<int> w0n = cast<int>((cast<unsigned>(nu) >> 24) | ((cast<unsigned>(nv) >> 24) << 8) | ((cast<unsigned>(nx) >> 24) << 16) | (cast<unsigned>(ny) & 0xff000000u));
+				const V<int> w1n = cast<int>((cast<unsigned>(nx2) >> 24) | ((cast<unsigned>(ny2) >> 24) << 8)) | ((s8 & 0xff) << 16);
+				gst(W0, t & wmask, w0n); gst(W1, t & wmask, w1n);
+				gst(tbp + (size_t)r * jb.n_col, t - st, cast<uint8_t>(p));
+				if (!approx) {
+					V<int> hkeep = oh[k];                                  // every hull lane re-stores H so that "lane <= last_en" implies a valid slot
+					if (r > 0) {
+						const V<int> v8 = nv >> 24, u8 = nu >> 24;
+						V<int> hn = oh[k] + v8;
+						hn = sel(t == en0, en0 > 0 ? V<int>(nh[k] + u8) : hn, hn);
+						const vbool inb = t >= st0 && t <= en0;
+						hkeep = sel(inb, hn, hkeep);
+						WM_IF(inb)
+							WM_IF(t == en0) gst(pub_val, V<int>(0), hn); WM_END
+							WM_IF(t == st0) gst(pub_val, V<int>(1), hn); WM_END
+						WM_END
+						V<int> grp = sel(t == en0, 5, sel(t < en1, 4 - ((t - st0) & 3), 0));
+						V<int> pri = (grp << 20) | (0xfffff - t);
+						V<long long> kk = cast<long long>(hn) * 4294967296LL + cast<long long>(pri);
+						key = sel(inb && kk > key, kk, key);
+					} else {
+						WM_IF(t == 0)
+							const V<int> h0 = (nv >> 24) - qe;
+							hkeep = h0;
+							gst(pub_val, V<int>(0), h0); gst(pub_val, V<int>(1), h0);
+							key = cast<long long>(h0) * 4294967296LL + (long long)((5 << 20) | 0xfffff);
+						WM_END
+					}
+					gst(Hm, t & wmask, hkeep);
+				} else {
+					WM_IF(t == last_H0_t) gst(pub_val, V<int>(2), nv >> 24); WM_END
+					WM_IF(t == last_H0_t + 1) gst(pub_val, V<int>(3), nu >> 24); WM_END
+				}
+			WM_END
+		}
+		if (!approx) {
+			key = wave_max_i64(key);
+			const long long kk = uniform(key);
+			WM_IF(ln == 0) gst(pub_key, V<int>(2 * wv), V<int>((int)(unsigned)(kk & 0xffffffffLL))); gst(pub_key, V<int>(2 * wv + 1), V<int>((int)(kk >> 32))); WM_END
+		}
+		block_sync_lds();
+
+		// ---- scalar bookkeeping, identical in every wave ----------------------------------------------------
+		if (!approx) {
+			long long kk = -0x7fffffffffffffffLL - 1;
+			for (int w2 = 0; w2 < NWV; ++w2) {
+				const long long k2 = (long long)(((unsigned long long)(unsigned)gld(pub_key, (long long)(2 * w2 + 1)) << 32) | (unsigned)gld(pub_key, (long long)(2 * w2)));
+				if (k2 > kk) kk = k2;
+			}
+			const int max_H = (int)(kk >> 32), pri = (int)(kk & 0xffffffffLL);
+			const int max_t = 0xfffff - (pri & 0xfffff);
+			if (en0 == tlen - 1) { const int h = gld(pub_val, 0LL); if (h > ez_mte) ez_mte = h, ez_mte_q = r - en; }
+			if (r - st0 == qlen - 1) { const int h = gld(pub_val, 1LL); if (h > ez_mqe) ez_mqe = h, ez_mqe_t = st0; }
+			if (max_H > ez_max) {
+				ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
+			} else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
+				const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+				if (zdrop >= 0 && ez_max - max_H > zdrop + l * e2) { ez_zdropped = 1; break; }
+			}
+			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = gld(pub_val, 0LL);
+		} else {
+			if (r > 0) {
+				const bool in0 = last_H0_t >= st0 && last_H0_t <= en0, in1 = last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0;
+				if (in0 && in1) {
+					const int d0 = gld(pub_val, 2LL), d1 = gld(pub_val, 3LL);
+					if (d0 > d1) H0 += d0;
+					else H0 += d1, ++last_H0_t;
+				} else if (in0) H0 += gld(pub_val, 2LL);
+				else { ++last_H0_t; H0 += gld(pub_val, 3LL); }
+			} else H0 = gld(pub_val, 2LL) - qe, last_H0_t = 0;
+			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = H0;
+		}
+		last_st = st, last_en = en;
+		if (top > w1_hi) w1_hi = top;
+	}
+	int bt_i = -1, bt_j = -1, reach_end = 0;
+	if (!ez_zdropped && !(flag & KSW_F_EXTZ_ONLY)) bt_i = tlen - 1, bt_j = qlen - 1;
+	else if (!ez_zdropped && (flag & KSW_F_EXTZ_ONLY) && ez_mqe + jb.end_bonus > ez_max) reach_end = 1, bt_i = ez_mqe_t, bt_j = qlen - 1;
+	else if (ez_max_t >= 0 && ez_max_q >= 0) bt_i = ez_max_t, bt_j = ez_max_q;
+	if (wv == 0) {
+		WM_IF(ln == 0)
+			wm_ksw_dres_t o;
+			o.max = ez_max; o.zdropped = ez_zdropped; o.max_q = ez_max_q; o.max_t = ez_max_t;
+			o.mqe = ez_mqe; o.mqe_t = ez_mqe_t; o.mte = ez_mte; o.mte_q = ez_mte_q;
+			o.score = ez_score; o.reach_end = reach_end; o.n_cigar = 0; o.bt_i = bt_i; o.bt_j = bt_j;
+			*res = o;
+		WM_END
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
 // ksw_backtrack (src/ksw2.h:119-151, is_rot = 1, min_intron_len = 0): ONE thread walks the traceback of one
 // alignment and emits run-length CIGAR ops in backtrack order into cig[0..cap); the gather step reverses
 // them unless KSW_EZ_REV_CIGAR. Row r covers lanes [st(r), en(r)] (recomputed here from the band formula).

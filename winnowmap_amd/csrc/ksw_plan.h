@@ -4,9 +4,11 @@
 #include <stdint.h>
 #include "wm_internal.h"
 
-enum {            // klass = B-index*4 + CLIP*2 + HASN  for the register kernels; 12 = generic LDS kernel
-	WM_KSW_B4 = 0, WM_KSW_B8 = 4, WM_KSW_B16 = 8, WM_KSW_GENERIC = 12, WM_KSW_NCLASS = 13
+enum {            // klass = B-index*4 + CLIP*2 + HASN  for the register kernels; 12 = multi-wave LDS kernel; 13 = generic (global scratch)
+	WM_KSW_B4 = 0, WM_KSW_B8 = 4, WM_KSW_B16 = 8, WM_KSW_BLOCK = 12, WM_KSW_GENERIC = 13, WM_KSW_NCLASS = 14
 };
+// geometry of the block kernel (ksw_dp_block<NWV, K>): NWV waves x K tiles x 64 lanes per row, LDS window of WN lanes
+enum { WM_KSW_BLK_NWV = 8, WM_KSW_BLK_K = 6, WM_KSW_BLK_WN = 4096 };
 
 // row pitch of the traceback in bytes: 16 * n_col_ of src/ksw2_extd2_sse.c:84-86
 static inline int wm_ksw_ncol(int qlen, int tlen, int w)
@@ -53,6 +55,7 @@ static inline int wm_ksw_classify(int qlen, int tlen, int w, int has_n, int *n_c
 	if (n_col <= 64 * 4 - 16) k = WM_KSW_B4;
 	else if (n_col <= 64 * 8 - 16) k = WM_KSW_B8;
 	else if (n_col <= 64 * 16 - 16) k = WM_KSW_B16;
+	else if (n_col + 16 <= 64 * WM_KSW_BLK_NWV * WM_KSW_BLK_K) { *n_col_out = n_col; return WM_KSW_BLOCK; }
 	else { *n_col_out = n_col; return WM_KSW_GENERIC; }
 	*n_col_out = n_col;
 	return k + clip * 2 + (has_n ? 1 : 0);

@@ -12,6 +12,9 @@
 #include <numeric>
 #include <thread>
 #include <chrono>
+#include <atomic>
+#include "host/wm_core.h"
+static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #include "simt.h"
 #include "ksw_kernel.h"
 #include "ksw_plan.h"
@@ -41,6 +44,15 @@ __global__ __launch_bounds__(64) void ksw_generic_kernel(wm_ksw_score_t sc, cons
 	signed char *mem = (signed char*)(scratch + scratch_off[blockIdx.x]);
 	int *Hm = (int*)(mem + (size_t)8 * T);
 	wmk::ksw_dp_generic<true>(sc, jb, seqs, tb, mem, Hm, res + j);
+}
+
+// block class: NWV waves per alignment, per-lane state in an LDS window (ksw_dp_block)
+__global__ __launch_bounds__(64 * WM_KSW_BLK_NWV) void ksw_block_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
+                                                                         const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res)
+{
+	__shared__ int W0[WM_KSW_BLK_WN], W1[WM_KSW_BLK_WN], Hm[WM_KSW_BLK_WN], pub[2 * WM_KSW_BLK_NWV + 8];
+	const int j = order[blockIdx.x];
+	wmk::ksw_dp_block<WM_KSW_BLK_NWV, WM_KSW_BLK_K>(sc, jobs[j], seqs, tb, W0, W1, Hm, WM_KSW_BLK_WN, pub, res + j);
 }
 
 // one thread per alignment: walk the traceback, write run-length ops (backtrack order) into the job's slot
@@ -119,6 +131,7 @@ struct wm_ctx_s {
 	int hbits;
 	wm_sketch_params_t skp;
 	bool have_index, owns_index;
+	int host_threads;                           // threads the batched entry points may use for their host-side packing / sorting
 };
 
 struct wm_ksw_dev_batch_s {
@@ -163,7 +176,7 @@ extern "C" int wm_ctx_create(int device, size_t arena_bytes, wm_ctx_t **out)
 	HIPCHK(hipMalloc((void**)&c->arena, arena_bytes));
 	HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 	for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
-	c->arena_used = 0; c->last_ms = 0; c->aux_ms = 0; c->have_index = false; c->owns_index = false; c->d_hkey = c->d_hval = c->d_P = 0; c->d_bloom = 0;
+	c->arena_used = 0; c->last_ms = 0; c->aux_ms = 0; c->host_threads = 1; c->have_index = false; c->owns_index = false; c->d_hkey = c->d_hval = c->d_P = 0; c->d_bloom = 0;
 	*out = c;
 	return WM_OK;
 }
@@ -221,27 +234,38 @@ extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int 
 	if (sc.sc_ambi < min_sc) min_sc = sc.sc_ambi;
 	const bool never = -min_sc > 2 * (sc.q + sc.e);
 	uint64_t tb_off = 0, cig_off = 0;
-	std::vector<uint64_t> cells(n_jobs, 0);
-	for (int i = 0; i < n_jobs; ++i) {
+	std::vector<uint64_t> cells(n_jobs, 0), bands(n_jobs, 0);
+	std::atomic<int> bad(-1), bad_kind(0);
+	wm::parallel_for(c->host_threads, (size_t)n_jobs, [&](size_t i) {          // per-job classification (scans both sequences for N)
 		const wm_ksw_job_t &s = jobs[i];
 		wm_ksw_djob_t &d = b->jobs[i];
 		memset(&d, 0, sizeof(d));
 		d.q_off = s.q_off; d.t_off = s.t_off; d.qlen = s.qlen; d.tlen = s.tlen;
 		d.w = s.w; d.zdrop = s.zdrop; d.end_bonus = s.end_bonus; d.flag = s.flag;
-		if (s.flag & (0x01 | 0x04 | 0x10 | 0x100 | 0x200 | 0x400)) { delete b; return set_err(WM_EINVAL, "job %d: KSW_EZ_SCORE_ONLY/GENERIC_SC/APPROX_DROP/SPLICE flags are not used by the mapper (src/align.c) and not supported", i); }
-		if (s.qlen <= 0 || s.tlen <= 0 || never) { d.klass = -1; b->degenerate.push_back(i); continue; }           // :68,:92
-		if ((size_t)s.q_off + s.qlen > seqs_bytes || (size_t)s.t_off + s.tlen > seqs_bytes) { delete b; return set_err(WM_EINVAL, "job %d: sequence offsets outside seqs", i); }
+		if (s.flag & (0x01 | 0x04 | 0x10 | 0x100 | 0x200 | 0x400)) { bad = (int)i; bad_kind = 1; d.klass = -1; return; }
+		if (s.qlen <= 0 || s.tlen <= 0 || never) { d.klass = -1; return; }                                                 // :68,:92
+		if ((size_t)s.q_off + s.qlen > seqs_bytes || (size_t)s.t_off + s.tlen > seqs_bytes) { bad = (int)i; bad_kind = 2; d.klass = -1; return; }
 		int n_col;
 		d.klass = wm_ksw_classify(s.qlen, s.tlen, s.w, wm_ksw_has_n(seqs + s.q_off, s.qlen) | wm_ksw_has_n(seqs + s.t_off, s.tlen), &n_col);
 		d.n_col = n_col;
+		cells[i] = wm_ksw_cells(s.qlen, s.tlen, s.w, &bands[i]);
+	});
+	if (bad >= 0) {
+		const int i = bad, kind = bad_kind;
+		delete b;
+		return kind == 1 ? set_err(WM_EINVAL, "job %d: KSW_EZ_SCORE_ONLY/GENERIC_SC/APPROX_DROP/SPLICE flags are not used by the mapper (src/align.c) and not supported", i)
+		                 : set_err(WM_EINVAL, "job %d: sequence offsets outside seqs", i);
+	}
+	for (int i = 0; i < n_jobs; ++i) {
+		const wm_ksw_job_t &s = jobs[i];
+		wm_ksw_djob_t &d = b->jobs[i];
+		if (d.klass < 0) { b->degenerate.push_back(i); continue; }
 		d.tb_off = tb_off;
 		const uint64_t rows = (uint64_t)s.qlen + s.tlen - 1;
-		tb_off += (rows * n_col + 15) & ~(uint64_t)15;
+		tb_off += (rows * d.n_col + 15) & ~(uint64_t)15;
 		d.cig_off = (uint32_t)cig_off; d.cig_cap = s.qlen + s.tlen + 2;
 		cig_off += d.cig_cap;
-		uint64_t band;
-		cells[i] = wm_ksw_cells(s.qlen, s.tlen, s.w, &band);
-		b->cells += band; b->tb_bytes += cells[i];
+		b->cells += bands[i]; b->tb_bytes += cells[i];
 		b->order[d.klass].push_back(i);
 	}
 	for (int k = 0; k < WM_KSW_NCLASS; ++k)
@@ -298,9 +322,24 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	}
 	HIPCHK(hipEventRecord(c->ev[0], c->stream));
 	int off = 0;
+	static const bool trace_k = getenv("WM_TRACE_KSW") != 0;          // per-class timing (serialises the launches)
+	auto class_done = [&](int k, double t0) {
+		if (!trace_k) return;
+		hipStreamSynchronize(c->stream);
+		const std::vector<int> &o = b->order[k];
+		const wm_ksw_djob_t &big = b->jobs[o[0]];
+		fprintf(stderr, "[ksw class %2d] jobs %zu  %.2f ms  largest q=%d t=%d w=%d flag=0x%x n_col=%d\n", k, o.size(), now_ms() - t0, big.qlen, big.tlen, big.w, big.flag, big.n_col);
+	};
 	for (int k = 0; k < WM_KSW_GENERIC; ++k) {
 		const int nk = (int)b->order[k].size();
 		if (nk == 0) continue;
+		const double tk0 = trace_k ? now_ms() : 0;
+		struct Done { decltype(class_done) &f; int k; double t; ~Done() { f(k, t); } } done_guard{ class_done, k, tk0 };
+		if (k == WM_KSW_BLOCK) {
+			hipLaunchKernelGGL(ksw_block_kernel, dim3(nk), dim3(64 * WM_KSW_BLK_NWV), 0, c->stream, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res);
+			off += nk;
+			continue;
+		}
 		const int clip = k >> 1 & 1, hasn = k & 1;
 		switch (k & ~3) {
 		case WM_KSW_B4: launch_dp<4>(clip, hasn, nk, c->stream, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
@@ -309,9 +348,11 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		}
 		off += nk;
 	}
+	const double tg0 = trace_k ? now_ms() : 0;
 	if (!b->order[WM_KSW_GENERIC].empty())
 		hipLaunchKernelGGL(ksw_generic_kernel, dim3((int)b->order[WM_KSW_GENERIC].size()), dim3(64), 0, c->stream, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb,
 		                   b->d_gscratch, b->d_goff, b->d_res);
+	if (!b->order[WM_KSW_GENERIC].empty()) class_done(WM_KSW_GENERIC, tg0);
 	HIPCHK(hipEventRecord(c->ev[1], c->stream));
 	hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, b->d_jobs, b->d_tb, b->d_res, b->d_cig, b->d_err);
 	hipLaunchKernelGGL(ksw_scan_kernel, dim3(1), dim3(1024), 0, c->stream, n, b->d_res, b->d_off, b->d_total);
@@ -481,7 +522,6 @@ __global__ __launch_bounds__(64 * NWV) void chain_kernel_block(const wm_chain_jo
 	wmk::chain_block(jb, anchors, NWV, W, sx, sy, sf, sp, st, pub, gf, gp, gt);
 }
 
-static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 extern "C" float wm_last_aux_ms(const wm_ctx_t *c) { return c ? c->aux_ms : 0.f; }
 
 extern "C" int wm_index_build(const char *fasta, const char *kmer_file, int k, int w, int n_threads, wm_index_t **out)
@@ -680,16 +720,22 @@ extern "C" int wm_seed_batch(wm_ctx_t *c, int n, const wm128_t *mini, const uint
 		HIPCHK(hipGetLastError());
 		float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); ms_total += ms;
 		std::vector<int> again;
+		std::vector<size_t> done_t;
 		for (size_t t = 0; t < todo.size(); ++t) {
 			const int i = todo[t];
 			if (res[t].n_anchors > jb[t].cap) { want[i] = res[t].n_anchors; again.push_back(i); continue; }
 			if (used + res[t].n_anchors > out_cap) return set_err(WM_ENOMEM, "anchor output pool too small");
 			out_off[i] = used; n_anchors[i] = res[t].n_anchors; rep_len[i] = res[t].rep_len;
-			memcpy(out + used, tmp.data() + jb[t].out_off, (size_t)res[t].n_anchors * sizeof(wm128_t));
-			// the reference's in-place unstable radix sort (src/map.c:252); its tie permutation is sequential by nature
-			wm::radix_sort_128x(out + used, out + used + res[t].n_anchors);
 			used += res[t].n_anchors;
+			done_t.push_back(t);
 		}
+		wm::parallel_for(c->host_threads, done_t.size(), [&](size_t k) {
+			const size_t t = done_t[k];
+			wm128_t *dst = out + out_off[todo[t]];
+			memcpy(dst, tmp.data() + jb[t].out_off, (size_t)res[t].n_anchors * sizeof(wm128_t));
+			// the reference's in-place unstable radix sort (src/map.c:252); its tie permutation is sequential by nature
+			wm::radix_sort_128x(dst, dst + res[t].n_anchors);
+		});
 		todo.swap(again);
 	}
 	if (!todo.empty()) return set_err(WM_EINTERNAL, "seed retry did not converge");
@@ -710,13 +756,13 @@ extern "C" int wm_chain_batch(wm_ctx_t *c, int n, wm128_t *a, const uint64_t *a_
 	for (int i = 0; i < n; ++i) tot = std::max<uint64_t>(tot, a_off[i] + n_a[i]);
 	std::vector<wm_chain_job_t> jb(n);
 	std::vector<int> order(n);
-	for (int i = 0; i < n; ++i) {
+	wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 		jb[i].a_off = a_off[i]; jb[i].n = n_a[i];
 		jb[i].max_dist_x = par[i].max_dist_x; jb[i].min_dist_x = par[i].min_dist_x; jb[i].max_dist_y = par[i].max_dist_y; jb[i].bw = par[i].bw;
 		jb[i].max_skip = par[i].max_skip; jb[i].max_iter = par[i].max_iter; jb[i].gap_scale = par[i].gap_scale; jb[i].pad = 0;
 		jb[i].avg_qspan = n_a[i] > 0 ? wm::chain_avg_qspan(n_a[i], a + a_off[i]) : 0.f;
-		order[i] = i;
-	}
+		order[i] = (int)i;
+	});
 	std::sort(order.begin(), order.end(), [&](int x, int y) { return n_a[x] != n_a[y] ? n_a[x] > n_a[y] : x < y; });
 	wm_chain_job_t *d_jobs = (wm_chain_job_t*)arena_take(c, (size_t)n * sizeof(wm_chain_job_t));
 	int *d_order = (int*)arena_take(c, (size_t)n * 4 + 64);
@@ -760,18 +806,21 @@ extern "C" int wm_chain_batch(wm_ctx_t *c, int n, wm128_t *a, const uint64_t *a_
 	HIPCHK(hipEventElapsedTime(&c->aux_ms, c->ev[0], c->ev[1]));
 	const double tt3 = trace ? now_ms() : 0;
 	// chain extraction (src/chain.c:93-165): O(n) bookkeeping on the fill's f/p/v
-	uint64_t uo = 0;
-	std::vector<uint64_t> uu;
-	std::vector<wm::m128> bb;
-	for (int i = 0; i < n; ++i) {
+	std::vector<std::vector<uint64_t>> uus(n);
+	wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 		const int *f = fpvt.data() + a_off[i] * 4, *p = f + n_a[i];
 		int *v = fpvt.data() + a_off[i] * 4 + 2 * (size_t)n_a[i];
 		for (int k = 0; k < n_a[i]; ++k) v[k] = p[k] >= 0 && v[p[k]] > f[k] ? v[p[k]] : f[k];          // peak score, src/chain.c:89
-		wm::chain_extract(n_a[i], a + a_off[i], f, p, v, par[i].min_cnt, par[i].min_sc, uu, bb);
-		u_off[i] = uo; n_u[i] = (int)uu.size(); n_v[i] = (int)bb.size();
-		for (size_t k = 0; k < uu.size(); ++k) u[uo + k] = uu[k];
-		uo += uu.size();
+		std::vector<wm::m128> bb;
+		wm::chain_extract(n_a[i], a + a_off[i], f, p, v, par[i].min_cnt, par[i].min_sc, uus[i], bb);
+		n_u[i] = (int)uus[i].size(); n_v[i] = (int)bb.size();
 		if (!bb.empty()) memcpy(a + a_off[i], bb.data(), bb.size() * sizeof(wm128_t));
+	});
+	uint64_t uo = 0;
+	for (int i = 0; i < n; ++i) {
+		u_off[i] = uo;
+		for (size_t k = 0; k < uus[i].size(); ++k) u[uo + k] = uus[i][k];
+		uo += uus[i].size();
 	}
 	if (trace) fprintf(stderr, "[chain_batch] n=%d anchors=%llu prep+h2d %.2f launch %.2f wait %.2f (kernel %.2f) extract %.2f ms\n", n, (unsigned long long)tot,
 	                   tt1 - tt0, tt2 - tt1, tt3 - tt2, c->aux_ms, now_ms() - tt3);
@@ -796,13 +845,13 @@ struct GpuOps : wm::DeviceOps {
 		size_t tot = 0;
 		for (int i = 0; i < n; ++i) { off[i] = tot; len[i] = reqs[i]->len; tot += reqs[i]->len; }
 		std::vector<uint8_t> seqs(tot + 1);
-		for (int i = 0; i < n; ++i) memcpy(seqs.data() + off[i], reqs[i]->seq, reqs[i]->len);
+		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { memcpy(seqs.data() + off[i], reqs[i]->seq, reqs[i]->len); });
 		std::vector<wm128_t> out(tot + n + 1);
 		const double ts = now_ms();
 		if (wm_sketch_batch(c, n, seqs.data(), tot, off.data(), len.data(), out.data(), out.size(), ooff.data(), cnt.data())) { fail("sketch"); return; }
 		t_sketch += now_ms() - ts;
 		aux_us += c->aux_ms * 1e3;
-		for (int i = 0; i < n; ++i) reqs[i]->mini.assign(out.begin() + ooff[i], out.begin() + ooff[i] + cnt[i]);
+		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { reqs[i]->mini.assign(out.begin() + ooff[i], out.begin() + ooff[i] + cnt[i]); });
 	}
 	void seed_batch(std::vector<wm::SeedReq*> &reqs) override
 	{
@@ -813,7 +862,7 @@ struct GpuOps : wm::DeviceOps {
 		size_t tot = 0;
 		for (int i = 0; i < n; ++i) { moff[i] = tot; nm[i] = reqs[i]->n_mini; ql[i] = reqs[i]->qlen; tot += reqs[i]->n_mini; }
 		std::vector<wm128_t> mini(tot + 1);
-		for (int i = 0; i < n; ++i) memcpy(mini.data() + moff[i], reqs[i]->mini, (size_t)reqs[i]->n_mini * sizeof(wm128_t));
+		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { memcpy(mini.data() + moff[i], reqs[i]->mini, (size_t)reqs[i]->n_mini * sizeof(wm128_t)); });
 		size_t cap = tot * 8 + 1024;
 		for (int attempt = 0; attempt < 6; ++attempt) {
 			std::vector<wm128_t> out(cap);
@@ -823,7 +872,7 @@ struct GpuOps : wm::DeviceOps {
 			if (rc) { fail("seed"); return; }
 			t_seed += now_ms() - ts;
 			aux_us += c->aux_ms * 1e3;
-			for (int i = 0; i < n; ++i) { reqs[i]->a.assign(out.begin() + ooff[i], out.begin() + ooff[i] + na[i]); reqs[i]->rep_len = rl[i]; }
+			wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { reqs[i]->a.assign(out.begin() + ooff[i], out.begin() + ooff[i] + na[i]); reqs[i]->rep_len = rl[i]; });
 			return;
 		}
 		fail("seed (anchor pool)");
@@ -842,15 +891,15 @@ struct GpuOps : wm::DeviceOps {
 		}
 		std::vector<wm128_t> a(tot + 1);
 		std::vector<uint64_t> u(tot + 1);
-		for (int i = 0; i < n; ++i) memcpy(a.data() + aoff[i], reqs[i]->a.data(), reqs[i]->a.size() * sizeof(wm128_t));
+		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { memcpy(a.data() + aoff[i], reqs[i]->a.data(), reqs[i]->a.size() * sizeof(wm128_t)); });
 		const double ts = now_ms();
 		if (wm_chain_batch(c, n, a.data(), aoff.data(), na.data(), par.data(), u.data(), uoff.data(), nu.data(), nv.data())) { fail("chain"); return; }
 		t_chain += now_ms() - ts;
 		aux_us += c->aux_ms * 1e3;
-		for (int i = 0; i < n; ++i) {
+		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 			reqs[i]->u.assign(u.begin() + uoff[i], u.begin() + uoff[i] + nu[i]);
 			reqs[i]->a.assign(a.begin() + aoff[i], a.begin() + aoff[i] + nv[i]);
-		}
+		});
 	}
 	void ksw_batch(const wm_ksw_score_t &sc, std::vector<wm::KswReq*> &reqs) override
 	{
@@ -868,10 +917,10 @@ struct GpuOps : wm::DeviceOps {
 		}
 		if (tot >= ((size_t)1 << 32)) { error = "ksw batch exceeds 4 GB of sequence"; return; }
 		std::vector<uint8_t> seqs(tot + 1);
-		for (int i = 0; i < n; ++i) {
+		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 			memcpy(seqs.data() + jobs[i].q_off, reqs[i]->q.data(), reqs[i]->q.size());
 			memcpy(seqs.data() + jobs[i].t_off, reqs[i]->t.data(), reqs[i]->t.size());
-		}
+		});
 		std::vector<wm_ksw_result_t> res(n);
 		std::vector<uint32_t> pool(cap);
 		size_t used = 0;
@@ -881,17 +930,18 @@ struct GpuOps : wm::DeviceOps {
 		const double t2 = now_ms();
 		ksw_us += c->last_ms * 1e3;
 		cells += c->acc_cells;
-		for (int i = 0; i < n; ++i) {
+		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 			reqs[i]->ez = res[i];
 			reqs[i]->cigar.assign(pool.begin() + res[i].cig_off, pool.begin() + res[i].cig_off + res[i].n_cigar);
-		}
+		});
 		t_pack += t1 - t0; t_unpack += now_ms() - t2; t_prep += c->t_prep; t_run += c->t_run; t_fetch += c->t_fetch;
 	}
 };
 
 struct wm_mapper_s {
 	wm_ctx_t *c; const wm_index_t *idx;
-	std::vector<wm_ctx_t*> workers;        // extra contexts (own stream + arena slice) for host threads 1..T-1
+	std::vector<wm_ctx_t*> workers;        // extra contexts (own stream + arena slice) for groups 1..G-1
+	int n_threads = 1;
 	wm::IdxOpt io; wm::MapOpt mo;
 	std::string text;
 	std::vector<int32_t> hits; std::vector<uint32_t> cigars; std::vector<int64_t> first;
@@ -917,19 +967,26 @@ extern "C" int wm_mapper_create(wm_ctx_t *c, const wm_index_t *idx, const char *
 }
 extern "C" void wm_mapper_destroy(wm_mapper_t *m) { if (m) { for (wm_ctx_t *w : m->workers) wm_ctx_destroy(w); delete m; } }
 
-// Host parallelism: n_threads scheduler threads, each with its own HIP stream and arena slice, map disjoint subsets of
-// a batch concurrently (kernels of different streams overlap on the GPU; the index in HBM is shared).
-extern "C" int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena_bytes_per_thread)
+// Host parallelism: n_threads host threads in G groups. A group is a SchedTeam (wm_fiber.h): its threads run the host
+// glue of the group's reads in parallel and share ONE device batch per operation and round, issued on the group's own
+// HIP stream + arena slice. Two or more groups keep the GPU busy while another group is in its host phase.
+extern "C" int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena_bytes_per_group)
 {
 	if (n_threads < 1) return set_err(WM_EINVAL, "n_threads < 1");
 	for (wm_ctx_t *w : m->workers) wm_ctx_destroy(w);
 	m->workers.clear();
-	for (int t = 1; t < n_threads; ++t) {
+	int G = getenv("WM_GROUPS") ? atoi(getenv("WM_GROUPS")) : (n_threads >= 8 ? 2 : 1);
+	if (G < 1) G = 1;
+	if (G > n_threads) G = n_threads;
+	m->n_threads = n_threads;
+	m->c->host_threads = std::max(1, n_threads / G);
+	for (int g = 1; g < G; ++g) {
 		wm_ctx_t *w = 0;
-		const int rc = wm_ctx_create(m->c->device, arena_bytes_per_thread ? arena_bytes_per_thread : m->c->arena_bytes, &w);
+		const int rc = wm_ctx_create(m->c->device, arena_bytes_per_group ? arena_bytes_per_group : m->c->arena_bytes, &w);
 		if (rc) return rc;
 		w->d_hkey = m->c->d_hkey; w->d_hval = m->c->d_hval; w->d_P = m->c->d_P; w->d_bloom = m->c->d_bloom; w->hbits = m->c->hbits; w->skp = m->c->skp;
 		w->have_index = true; w->owns_index = false;
+		w->host_threads = m->c->host_threads;
 		m->workers.push_back(w);
 	}
 	return WM_OK;
@@ -949,10 +1006,11 @@ extern "C" int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, con
 	std::vector<std::vector<wm::ReadOut>> pout(T);
 	std::vector<std::vector<int>> which(T);
 	for (int i = 0; i < n; ++i) { which[i % T].push_back(i); part[i % T].push_back(std::move(reads[i])); }
+	const int team = std::max(1, m->n_threads / T);
 	auto work = [&](int t) {
 		ops[t].c = t == 0 ? m->c : m->workers[t - 1];
 		hipSetDevice(ops[t].c->device);
-		wm::map_batch(m->idx->ix, m->mo, &ops[t], part[t], pout[t], &sts[t]);
+		wm::map_batch(m->idx->ix, m->mo, &ops[t], part[t], pout[t], &sts[t], team);
 	};
 	{
 		std::vector<std::thread> th;
@@ -972,7 +1030,7 @@ extern "C" int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, con
 	if (getenv("WM_TRACE")) {
 		double a[8] = {0};
 		for (int t = 0; t < T; ++t) { a[0] += ops[t].t_pack; a[1] += ops[t].t_prep; a[2] += ops[t].t_run; a[3] += ops[t].t_fetch; a[4] += ops[t].t_unpack; a[5] += ops[t].t_sketch; a[6] += ops[t].t_seed; a[7] += ops[t].t_chain; }
-		fprintf(stderr, "[ops, sum over %d threads, ms] ksw: pack %.0f prepare %.0f run %.0f fetch %.0f unpack %.0f | sketch %.0f seed %.0f chain %.0f\n", T, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
+		fprintf(stderr, "[ops, sum over %d groups, ms] ksw: pack %.0f prepare %.0f run %.0f fetch %.0f unpack %.0f | sketch %.0f seed %.0f chain %.0f\n", T, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
 	}
 	m->text.clear(); m->hits.clear(); m->cigars.clear(); m->first.assign(n + 1, 0);
 	for (int i = 0; i < n; ++i) {
