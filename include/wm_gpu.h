@@ -146,7 +146,7 @@ typedef struct wm_mapper_s wm_mapper_t;
 int wm_mapper_create(wm_ctx_t *ctx, const wm_index_t *idx, const char *preset, int64_t flag, wm_mapper_t **out);
 void wm_mapper_destroy(wm_mapper_t *m);
 /* host parallelism (the reference's -t): n_threads host threads run the per-read glue; they are organised in groups
- * (2 by default, env WM_GROUPS) that each share one device batch per operation on their own HIP stream + arena slice
+ * (4 from 32 threads up, else 2 from 8 up; env WM_GROUPS) that each share one device batch per operation on their own HIP stream + arena slice
  * (arena_bytes_per_group; 0 = same size as ctx). */
 int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena_bytes_per_group);
 /* Map n reads (ASCII). Output records (PAF, or SAM when MM_F_OUT_SAM) of all reads in input order are appended to
@@ -158,6 +158,10 @@ int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, const char *co
 /* counters of the last wm_map_reads call: [0] super-steps, [1] ksw jobs, [2] chain jobs, [3] seed jobs,
  * [4] sketch jobs, [5] DP cells, [6] ksw kernel us, [7] aux kernel us, [8] read bases */
 int wm_mapper_stats(const wm_mapper_t *m, uint64_t *out9);
+/* per ksw kernel class (B4/B8/B16 x CLIP x HASN register kernels, the two multi-wave LDS kernels, the generic kernel) since
+ * wm_mapper_create: out[3k] = summed launch durations (ms, HIP events on the launching stream), out[3k+1] = DP cells,
+ * out[3k+2] = launches. cap = doubles available in out; *n_classes receives the class count. Feeds bench.py's roofline. */
+int wm_mapper_kernel_stats(const wm_mapper_t *m, double *out, int cap, int *n_classes);
 /* SAM header lines (@SQ.., @PG) as mm_write_sam_hdr (src/format.c:118-139) */
 int wm_sam_header(const wm_index_t *idx, int argc, const char *const *argv, const char **text, size_t *text_len);
 

@@ -35,29 +35,38 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 	wm_ksw_djob_t jb;
 	memset(&jb, 0, sizeof(jb));
 	jb.q_off = 0; jb.t_off = qlen; jb.qlen = qlen; jb.tlen = tlen; jb.w = w; jb.zdrop = zdrop; jb.end_bonus = end_bonus; jb.flag = flag;
+	bool emu_blk3_small = false;
+	if (force_klass == 114) { emu_blk3_small = true; force_klass = WM_KSW_BLOCK3; }
 	int n_col, klass = wm_ksw_classify(qlen, tlen, w, wm_ksw_has_n(query, qlen) | wm_ksw_has_n(target, tlen), &n_col);
 	if (force_klass >= 0) {
 		if (force_klass < WM_KSW_BLOCK && (force_klass & ~3) < (klass & ~3)) return -1; // window too small for this job
-		if (force_klass == WM_KSW_BLOCK && klass > WM_KSW_BLOCK) return -1;
+		if (force_klass >= WM_KSW_BLOCK && force_klass <= WM_KSW_BLOCK3 && klass > force_klass) return -1;
 		klass = force_klass;
 	}
 	*klass_out = klass;
+	if (emu_blk3_small && n_col + 16 > 128 * WM_KSW_BLK_MAXC) return -1;
 	jb.n_col = n_col; jb.tb_off = 0; jb.klass = klass;
 	std::vector<uint8_t> tb((size_t)(qlen + tlen - 1) * n_col + 64, 0xEE);
 	wm_ksw_dres_t res;
 	memset(&res, 0, sizeof(res));
 	const int clip = klass >> 1 & 1, hasn = klass & 1;
-	if (klass == WM_KSW_BLOCK) {
-		constexpr int NWV = WM_KSW_BLK_NWV, K = WM_KSW_BLK_K, WN = WM_KSW_BLK_WN;
-		std::vector<int> W0(WN, 0x5a5a5a5a), W1(WN, 0x5a5a5a5a), Hm(WN, 0x5a5a5a5a), pub(2 * NWV + 8);   // LDS starts as garbage
+	if (klass == WM_KSW_BLOCK || klass == WM_KSW_BLOCK2 || klass == WM_KSW_BLOCK3) {
+		constexpr int NWV = WM_KSW_BLK_NWV;
+		const int WN = klass == WM_KSW_BLOCK ? WM_KSW_BLK_WN : klass == WM_KSW_BLOCK2 ? WM_KSW_BLK2_WN : (int)wm_ksw_blk3_wn(tlen);
+		std::vector<int> W0(WN, 0x5a5a5a5a), W1(WN, 0x5a5a5a5a), Hm(WN, 0x5a5a5a5a), pub(WM_KSW_BLK_PUB);   // the state starts as garbage
+		const int nw = klass == WM_KSW_BLOCK3 && emu_blk3_small ? 2 : NWV;
 		pthread_barrier_t bar;
-		pthread_barrier_init(&bar, 0, NWV);
+		pthread_barrier_init(&bar, 0, nw);
 		simt::block_barrier() = &bar;
 		std::vector<std::thread> th;
-		for (int w = 0; w < NWV; ++w)
+		for (int w = 0; w < nw; ++w)
 			th.emplace_back([&, w]() {
 				simt::wave_slot() = w; simt::exec_mask() = ~0ull;
-				wmk::ksw_dp_block<NWV, K>(sc, jb, seqs.data(), tb.data(), W0.data(), W1.data(), Hm.data(), WN, pub.data(), &res);
+				const uint8_t *q_ = seqs.data() + jb.q_off, *t_ = seqs.data() + jb.t_off;
+				if (klass == WM_KSW_BLOCK) wmk::ksw_dp_block<NWV, WM_KSW_BLK_K, false>(sc, jb, q_, t_, tb.data(), W0.data(), W1.data(), Hm.data(), WN, pub.data(), &res);
+				else if (klass == WM_KSW_BLOCK2) wmk::ksw_dp_block<NWV, WM_KSW_BLK2_K, false>(sc, jb, q_, t_, tb.data(), W0.data(), W1.data(), Hm.data(), WN, pub.data(), &res);
+				else if (emu_blk3_small) wmk::ksw_dp_block<2, 1, true>(sc, jb, q_, t_, tb.data(), W0.data(), W1.data(), Hm.data(), WN, pub.data(), &res);
+				else wmk::ksw_dp_block<NWV, WM_KSW_BLK2_K, true>(sc, jb, q_, t_, tb.data(), W0.data(), W1.data(), Hm.data(), WN, pub.data(), &res);
 			});
 		for (auto &t : th) t.join();
 		simt::block_barrier() = 0;

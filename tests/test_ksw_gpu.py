@@ -112,7 +112,8 @@ def test_wide_band_jobs_block_and_generic_kernels(ctx):
             q[int(rng.integers(0, len(q)))] = 4
         cases.append(dict(q=q, t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=[3001, 1500, 3001, 2000][it % 4], zdrop=[400, 200, -1][it % 3],
                           end_bonus=-1, flag=kswcases.FLAGS[it % 6]))
-    t = rng.integers(0, 4, 3400).astype(np.uint8)
-    cases.append(dict(q=synth.mutate_codes(t, rng, 0.03, 0.03, 0.03), t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=-1, zdrop=400, end_bonus=-1, flag=0x08))
+    for tl, fl in ((3400, 0x08), (7600, 0x08), (7300, 0x40)):       # unbanded: LDS kernel with the 8192-lane window, then the global-state kernel
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        cases.append(dict(q=synth.mutate_codes(t, rng, 0.03, 0.03, 0.03), t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=-1, zdrop=400, end_bonus=-1, flag=fl))
     bad = _run_group(ctx, cases)
     assert not bad, bad[:3]

@@ -1,0 +1,21 @@
+#!/bin/bash
+# usage: tools/prof_bench.sh <tag> [bench args...]
+# 1) plain bench.py run (the JSON line), 2) the same command under rocprofv3 --kernel-trace --stats,
+# 3) (optional, PMC=1) separate --pmc passes for HBM traffic of the ksw kernels. Everything lands in gpurun_out/prof_<tag>/;
+# tools/prof_summary.py turns the .db files into profiles/<tag>.txt.
+TAG=${1:-r01_bench}; shift
+export TMPDIR=/tmp
+ROOT=$PWD
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+python bench.py "$@" > $OUT/bench.json 2> $OUT/bench.log
+tail -3 $OUT/bench.log; cat $OUT/bench.json
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python $ROOT/bench.py "$@" > $OUT/bench_prof.json 2> $OUT/bench_prof.log )
+cat $OUT/bench_prof.json
+if [ "${PMC:-0}" = "1" ]; then
+  # HBM traffic (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE, in their own passes, no trace domains)
+  # (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950; a reduced batch keeps the serialised counter runs short)
+  ( cd /tmp && WM_BENCH_CPU_SAMPLE=0 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc1 -o bench -- python $ROOT/bench.py --steps 1 --warmup 0 --reads-per-step 1024 > $OUT/pmc1.log 2>&1 )
+  ( cd /tmp && WM_BENCH_CPU_SAMPLE=0 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc2 -o bench -- python $ROOT/bench.py --steps 1 --warmup 0 --reads-per-step 1024 > $OUT/pmc2.log 2>&1 )
+fi
+cd $ROOT && python tools/prof_summary.py $TAG gpurun_out/prof_$TAG > /dev/null && cp profiles/$TAG.txt $OUT/ && head -30 profiles/$TAG.txt

@@ -501,18 +501,26 @@ WM_DEV void ksw_dp_generic(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, cons
 // their gap-open+extend cost as in the generic kernel) plus an int32 H (exact-max mode), in a circular window of Wn
 // lanes (Wn a power of two > hull + 64; a lane enters and leaves the hull exactly once, so slots are recycled and a
 // lane that was never computed is substituted by its initial value instead of being pre-filled).
+// The two code strings are staged in LDS as well when they fit (a global byte load per lane and row would put a
+// full memory round trip on the critical path of every row).
 // Row r: every wave LOADS its K tiles (own words + the words of lane t-1, previous-row values) | barrier | computes,
 // stores, publishes the values the scalar bookkeeping needs (row maximum, H at en0 / st0, the approximate-max
 // track) | barrier | all waves replay the same scalar bookkeeping from the published values, so they stay in step.
 // ------------------------------------------------------------------------------------------------------
-template <int NWV, int K>
-WM_DEV void ksw_dp_block(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb_arena,
+// Hulls wider than one sweep of the block (CH = 64*NWV*K lanes) are processed in CHUNKS of CH lanes per row: the only
+// cross-chunk dependency is the previous-row state of the lane just below a chunk, which one lane per chunk boundary
+// saves (into `pub`) at the start of the row, before anybody has stored. GLOBAL = the state window lives in a global
+// scratch slab instead of LDS (hulls beyond what LDS holds; all waves of a block share one CU's L1, so a workgroup
+// barrier with a memory fence orders their accesses).
+template <int NWV, int K, bool GLOBAL>
+WM_DEV void ksw_dp_block(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const uint8_t *query, const uint8_t *target, uint8_t *__restrict__ tb_arena,
                          int *W0, int *W1, int *Hm, int Wn, int *pub, wm_ksw_dres_t *__restrict__ res)
 {
+	constexpr int CH = 64 * NWV * K, MAXC = 16;
+	// query / target: the job's two code strings (the kernel stages them in LDS when they fit, else they are the global copies)
 	const int qlen = jb.qlen, tlen = jb.tlen, flag = jb.flag, zdrop = jb.zdrop;
 	const int w = jb.w < 0 ? (tlen > qlen ? tlen : qlen) : jb.w;
 	const bool approx = (flag & KSW_F_APPROX_MAX) != 0, right = (flag & KSW_F_RIGHT) != 0;
-	const uint8_t *query = seqs + jb.q_off, *target = seqs + jb.t_off;
 	uint8_t *tbp = tb_arena + jb.tb_off;
 	const int wmask = Wn - 1;
 	const int q = sc.q, e = sc.e, q2 = sc.q2, e2 = sc.e2, qe = q + e, qe2 = q2 + e2;
@@ -527,7 +535,7 @@ WM_DEV void ksw_dp_block(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 	const V<int> ln = lane();
 	const int wv = wave_in_block();
 	const int INIT0 = (int)(((unsigned)(-qe) & 0xffu) | ((unsigned)(-qe) & 0xffu) << 8);      // u = v = -qe, x = y = 0 (biased)
-	int *pub_key = pub, *pub_val = pub + 2 * NWV;                                             // wave maxima (lo,hi) | h_en0, h_st0, d0, d1
+	int *pub_key = pub, *pub_val = pub + 2 * NWV, *pub_bnd = pub + 2 * NWV + 8;                // wave maxima (lo,hi) | h_en0, h_st0, d0, d1 | chunk boundaries (3 ints each)
 
 	int ez_max = 0, ez_zdropped = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1;
 	int ez_mte = KSW_NEG_INF, ez_mte_q = -1, ez_score = KSW_NEG_INF;
@@ -545,15 +553,28 @@ WM_DEV void ksw_dp_block(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 		const int cend = st0 + (en0 - st0) / 16 * 16 + 15;               // last lane of the rewritten score chunks (:158-173)
 		const int top = en > cend ? en : cend;
 		const int en1 = st0 + (en0 - st0) / 4 * 4;
-		WM_EMU_ASSERT(top - st + 1 <= 64 * NWV * K);
+		const int n_chunks = (top - st + CH) / CH;
+		WM_EMU_ASSERT(n_chunks <= MAXC);
+		if (n_chunks > 1 && wv == 0) {                                     // previous-row state just below every later chunk
+			const V<int> tm = st + (ln + 1) * CH - 1;
+			WM_IF(ln < n_chunks - 1)
+				V<int> b0 = INIT0, b1 = 0, bh = KSW_NEG_INF;
+				WM_IF(tm >= last_st && tm <= last_en) b0 = gld(W0, tm & wmask); b1 = gld(W1, tm & wmask); WM_END
+				if (!approx) { WM_IF(tm <= last_en) bh = gld(Hm, tm & wmask); WM_END }
+				gst(pub_bnd, ln * 3, b0); gst(pub_bnd, ln * 3 + 1, b1); gst(pub_bnd, ln * 3 + 2, bh);
+			WM_END
+		}
+		V<long long> key = (long long)(-0x7fffffffffffffffLL - 1);
+		for (int ch = 0; ch < n_chunks; ++ch) {
+		const int cst = st + ch * CH;                                      // first lane of this chunk
 
 		// ---- loads: own state and the previous-row state of lane t-1 ------------------------------------
 		V<int> o0[K], o1[K], oh[K], n0[K], n1[K], nh[K];
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
-			const V<int> t = ln + (st + 64 * (wv + NWV * k));
+			const V<int> t = ln + (cst + 64 * (wv + NWV * k));
 			o0[k] = INIT0; o1[k] = 0; oh[k] = KSW_NEG_INF; n0[k] = INIT0; n1[k] = 0; nh[k] = KSW_NEG_INF;
-			if (st + 64 * (wv + NWV * k) > top) continue;
+			if (cst + 64 * (wv + NWV * k) > top) continue;
 			WM_IF(t <= top)
 				WM_IF(t <= last_en) o0[k] = gld(W0, t & wmask); if (!approx) oh[k] = gld(Hm, t & wmask); WM_END
 				WM_IF(t <= w1_hi) o1[k] = gld(W1, t & wmask); WM_END
@@ -562,13 +583,15 @@ WM_DEV void ksw_dp_block(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 				if (!approx) { WM_IF(tm >= 0 && tm <= last_en) nh[k] = gld(Hm, tm & wmask); WM_END }
 			WM_END
 		}
-		block_sync_lds();
+		if (GLOBAL) block_sync(); else block_sync_lds();
+		if (ch > 0 && wv == 0) {                                           // the chunk's first lane takes the saved boundary
+			WM_IF(ln == 0) n0[0] = gld(pub_bnd, V<int>((ch - 1) * 3)); n1[0] = gld(pub_bnd, V<int>((ch - 1) * 3 + 1)); nh[0] = gld(pub_bnd, V<int>((ch - 1) * 3 + 2)); WM_END
+		}
 
 		// ---- compute, store, publish ------------------------------------------------------------------------
-		V<long long> key = (long long)(-0x7fffffffffffffffLL - 1);
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
-			const int tile0 = st + 64 * (wv + NWV * k);
+			const int tile0 = cst + 64 * (wv + NWV * k);
 			if (tile0 > top) continue;
 			const V<int> t = ln + tile0;
 			// score of this row for the lanes inside the rewritten chunks; the others keep their old score byte
@@ -640,12 +663,13 @@ WM_DEV void ksw_dp_block(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 				}
 			WM_END
 		}
+		}   // chunks
 		if (!approx) {
 			key = wave_max_i64(key);
 			const long long kk = uniform(key);
 			WM_IF(ln == 0) gst(pub_key, V<int>(2 * wv), V<int>((int)(unsigned)(kk & 0xffffffffLL))); gst(pub_key, V<int>(2 * wv + 1), V<int>((int)(kk >> 32))); WM_END
 		}
-		block_sync_lds();
+		if (GLOBAL) block_sync(); else block_sync_lds();
 
 		// ---- scalar bookkeeping, identical in every wave ----------------------------------------------------
 		if (!approx) {

@@ -4,11 +4,21 @@
 #include <stdint.h>
 #include "wm_internal.h"
 
-enum {            // klass = B-index*4 + CLIP*2 + HASN  for the register kernels; 12 = multi-wave LDS kernel; 13 = generic (global scratch)
-	WM_KSW_B4 = 0, WM_KSW_B8 = 4, WM_KSW_B16 = 8, WM_KSW_BLOCK = 12, WM_KSW_GENERIC = 13, WM_KSW_NCLASS = 14
+enum {            // klass = B-index*4 + CLIP*2 + HASN  for the register kernels; 12, 13 = multi-wave LDS kernels; 14 = multi-wave kernel with its state in global scratch;
+	                  // 15 = single-wave generic kernel (global scratch, any size)
+	WM_KSW_B4 = 0, WM_KSW_B8 = 4, WM_KSW_B16 = 8, WM_KSW_BLOCK = 12, WM_KSW_BLOCK2 = 13, WM_KSW_BLOCK3 = 14, WM_KSW_GENERIC = 15, WM_KSW_NCLASS = 16
 };
-// geometry of the block kernel (ksw_dp_block<NWV, K>): NWV waves x K tiles x 64 lanes per row, LDS window of WN lanes
-enum { WM_KSW_BLK_NWV = 8, WM_KSW_BLK_K = 6, WM_KSW_BLK_WN = 4096 };
+// geometry of the block kernels (ksw_dp_block<NWV, K>): NWV waves x K tiles x 64 lanes per row, LDS window of WN lanes
+enum { WM_KSW_BLK_NWV = 16, WM_KSW_BLK_K = 3, WM_KSW_BLK_WN = 4096,        // hulls up to 3072 lanes (w = 3001: stage-2 fills of map-ont / map-pb)
+       WM_KSW_BLK2_K = 7, WM_KSW_BLK2_WN = 8192 };                         // hulls up to 7168 lanes (unbanded fills across structural variants)
+// bytes of LDS left for the staged sequences next to the state window (160 KB per CU, one block per CU for these classes)
+enum { WM_KSW_BLK_SEQ_LDS = 96 * 1024, WM_KSW_BLK2_SEQ_LDS = 48 * 1024, WM_KSW_BLK3_SEQ_LDS = 128 * 1024 };
+enum { WM_KSW_BLK_MAXC = 16, WM_KSW_BLK_PUB = 2 * 16 + 8 + 3 * 16 };      // chunks per row at most; ints of the publish area
+// lanes of the state window of a BLOCK3 job (power of two covering every lane index the kernel can touch)
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline uint64_t wm_ksw_blk3_wn(int tlen) { uint64_t n = 1024; while (n < (uint64_t)tlen + 80) n <<= 1; return n; }
 
 // row pitch of the traceback in bytes: 16 * n_col_ of src/ksw2_extd2_sse.c:84-86
 static inline int wm_ksw_ncol(int qlen, int tlen, int w)
@@ -56,6 +66,8 @@ static inline int wm_ksw_classify(int qlen, int tlen, int w, int has_n, int *n_c
 	else if (n_col <= 64 * 8 - 16) k = WM_KSW_B8;
 	else if (n_col <= 64 * 16 - 16) k = WM_KSW_B16;
 	else if (n_col + 16 <= 64 * WM_KSW_BLK_NWV * WM_KSW_BLK_K) { *n_col_out = n_col; return WM_KSW_BLOCK; }
+	else if (n_col + 16 <= 64 * WM_KSW_BLK_NWV * WM_KSW_BLK2_K) { *n_col_out = n_col; return WM_KSW_BLOCK2; }
+	else if (n_col + 16 <= 64 * WM_KSW_BLK_NWV * WM_KSW_BLK2_K * WM_KSW_BLK_MAXC) { *n_col_out = n_col; return WM_KSW_BLOCK3; }
 	else { *n_col_out = n_col; return WM_KSW_GENERIC; }
 	*n_col_out = n_col;
 	return k + clip * 2 + (has_n ? 1 : 0);

@@ -46,13 +46,31 @@ __global__ __launch_bounds__(64) void ksw_generic_kernel(wm_ksw_score_t sc, cons
 	wmk::ksw_dp_generic<true>(sc, jb, seqs, tb, mem, Hm, res + j);
 }
 
-// block class: NWV waves per alignment, per-lane state in an LDS window (ksw_dp_block)
+// block classes: NWV waves per alignment (ksw_dp_block). The per-lane state window is in LDS (BLOCK, BLOCK2) or in a global
+// scratch slab of 3*WN ints per job (BLOCK3: any hull up to 16 sweeps per row); dynamic LDS = [state window,] publish
+// area, then the staged sequences (if they fit in seq_cap bytes)
+template <int K, int WN>
 __global__ __launch_bounds__(64 * WM_KSW_BLK_NWV) void ksw_block_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
-                                                                         const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res)
+                                                                         const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res, int seq_cap,
+                                                                         int *gstate, const uint64_t *__restrict__ gstate_off)
 {
-	__shared__ int W0[WM_KSW_BLK_WN], W1[WM_KSW_BLK_WN], Hm[WM_KSW_BLK_WN], pub[2 * WM_KSW_BLK_NWV + 8];
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	constexpr bool GLOBAL = WN == 0;
 	const int j = order[blockIdx.x];
-	wmk::ksw_dp_block<WM_KSW_BLK_NWV, WM_KSW_BLK_K>(sc, jobs[j], seqs, tb, W0, W1, Hm, WM_KSW_BLK_WN, pub, res + j);
+	const wm_ksw_djob_t jb = jobs[j];
+	const int wn = GLOBAL ? (int)wm_ksw_blk3_wn(jb.tlen) : WN;
+	int *W0 = GLOBAL ? gstate + gstate_off[blockIdx.x] : (int*)smem, *W1 = W0 + wn, *Hm = W1 + wn;
+	int *pub = GLOBAL ? (int*)smem : Hm + wn;
+	uint8_t *sq = (uint8_t*)(pub + WM_KSW_BLK_PUB);
+	const int qpad = (jb.qlen + 15) & ~15;
+	if (qpad + jb.tlen <= seq_cap) {
+		uint8_t *st = sq + qpad;
+		for (int i = threadIdx.x; i < jb.qlen; i += blockDim.x) sq[i] = seqs[jb.q_off + i];
+		for (int i = threadIdx.x; i < jb.tlen; i += blockDim.x) st[i] = seqs[jb.t_off + i];
+		__syncthreads();
+		wmk::ksw_dp_block<WM_KSW_BLK_NWV, K, GLOBAL>(sc, jb, sq, st, tb, W0, W1, Hm, wn, pub, res + j);
+	} else
+		wmk::ksw_dp_block<WM_KSW_BLK_NWV, K, GLOBAL>(sc, jb, seqs + jb.q_off, seqs + jb.t_off, tb, W0, W1, Hm, wn, pub, res + j);
 }
 
 // one thread per alignment: walk the traceback, write run-length ops (backtrack order) into the job's slot
@@ -120,6 +138,10 @@ static int set_err(int code, const char *fmt, ...)
 struct wm_ctx_s {
 	int device;
 	hipStream_t stream;
+	hipStream_t kstream[4];                     // side streams: kernel classes of one batch run concurrently
+	hipEvent_t kev[5];
+	hipEvent_t cev[WM_KSW_NCLASS][2];           // per-class start/stop (on the stream the class was launched on)
+	double k_ms[WM_KSW_NCLASS]; uint64_t k_cells[WM_KSW_NCLASS], k_launches[WM_KSW_NCLASS];   // accumulated per kernel class
 	uint8_t *arena;
 	size_t arena_bytes, arena_used;
 	hipEvent_t ev[4];
@@ -142,9 +164,11 @@ struct wm_ksw_dev_batch_s {
 	std::vector<int> degenerate;                // jobs the reference returns from early (src/ksw2_extd2_sse.c:68,92)
 	// device pointers (inside the arena)
 	uint8_t *d_gscratch; uint64_t *d_goff; std::vector<uint64_t> goff;
+	uint8_t *d_b3state; uint64_t *d_b3off; std::vector<uint64_t> b3off;
 	wm_ksw_djob_t *d_jobs; int *d_order; uint8_t *d_seqs, *d_tb; wm_ksw_dres_t *d_res; uint32_t *d_cig, *d_off, *d_total, *d_pool; int *d_err;
 	size_t pool_cap, arena_mark;
 	uint64_t cells, tb_bytes;
+	uint64_t class_cells[WM_KSW_NCLASS];
 	float dp_ms, bt_ms;
 	uint32_t total_ops;
 };
@@ -175,6 +199,9 @@ extern "C" int wm_ctx_create(int device, size_t arena_bytes, wm_ctx_t **out)
 	c->arena_bytes = arena_bytes;
 	HIPCHK(hipMalloc((void**)&c->arena, arena_bytes));
 	HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	for (int i = 0; i < 4; ++i) HIPCHK(hipStreamCreateWithFlags(&c->kstream[i], hipStreamNonBlocking));
+	for (int i = 0; i < 5; ++i) HIPCHK(hipEventCreateWithFlags(&c->kev[i], hipEventDisableTiming));
+	for (int k = 0; k < WM_KSW_NCLASS; ++k) { HIPCHK(hipEventCreate(&c->cev[k][0])); HIPCHK(hipEventCreate(&c->cev[k][1])); c->k_ms[k] = 0; c->k_cells[k] = c->k_launches[k] = 0; }
 	for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
 	c->arena_used = 0; c->last_ms = 0; c->aux_ms = 0; c->host_threads = 1; c->have_index = false; c->owns_index = false; c->d_hkey = c->d_hval = c->d_P = 0; c->d_bloom = 0;
 	*out = c;
@@ -188,6 +215,9 @@ extern "C" void wm_ctx_destroy(wm_ctx_t *c)
 	hipStreamSynchronize(c->stream);
 	for (int i = 0; i < 4; ++i) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream);
+	for (int i = 0; i < 4; ++i) hipStreamDestroy(c->kstream[i]);
+	for (int i = 0; i < 5; ++i) hipEventDestroy(c->kev[i]);
+	for (int k = 0; k < WM_KSW_NCLASS; ++k) { hipEventDestroy(c->cev[k][0]); hipEventDestroy(c->cev[k][1]); }
 	hipFree(c->arena);
 	if (c->have_index && c->owns_index) { hipFree(c->d_hkey); hipFree(c->d_hval); hipFree(c->d_P); hipFree(c->d_bloom); }
 	delete c;
@@ -226,6 +256,7 @@ extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int 
 	HIPCHK(hipSetDevice(c->device));
 	wm_ksw_dev_batch_t *b = new wm_ksw_dev_batch_t();
 	b->n_jobs = n_jobs; b->sc = sc; b->cells = b->tb_bytes = 0; b->dp_ms = b->bt_ms = 0; b->total_ops = 0;
+	memset(b->class_cells, 0, sizeof(b->class_cells));
 	b->arena_mark = c->arena_used;
 	b->jobs.resize(n_jobs);
 	// the reference returns before doing anything when a mismatch can never be seen (:92)
@@ -266,6 +297,7 @@ extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int 
 		d.cig_off = (uint32_t)cig_off; d.cig_cap = s.qlen + s.tlen + 2;
 		cig_off += d.cig_cap;
 		b->cells += bands[i]; b->tb_bytes += cells[i];
+		b->class_cells[d.klass] += bands[i];
 		b->order[d.klass].push_back(i);
 	}
 	for (int k = 0; k < WM_KSW_NCLASS; ++k)
@@ -289,6 +321,11 @@ extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int 
 		b->d_gscratch = (uint8_t*)arena_take(c, go + 256);
 		b->d_goff = (uint64_t*)arena_take(c, b->goff.size() * 8 + 64);
 		if (!b->d_gscratch || !b->d_goff) b->d_tb = 0;
+		uint64_t so = 0;                               // BLOCK3: 3 * WN ints per job
+		for (int j : b->order[WM_KSW_BLOCK3]) { b->b3off.push_back(so); so += 3 * wm_ksw_blk3_wn(b->jobs[j].tlen); }
+		b->d_b3state = (uint8_t*)arena_take(c, so * 4 + 256);
+		b->d_b3off = (uint64_t*)arena_take(c, b->b3off.size() * 8 + 64);
+		if (!b->d_b3state || !b->d_b3off) b->d_tb = 0;
 	}
 	if (!b->d_jobs || !b->d_order || !b->d_res || !b->d_off || !b->d_total || !b->d_err || !b->d_seqs || !b->d_cig || !b->d_pool || !b->d_tb) {
 		c->arena_used = b->arena_mark;
@@ -302,6 +339,7 @@ extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int 
 	if (!ord.empty()) HIPCHK(hipMemcpyAsync(b->d_order, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipMemcpyAsync(b->d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream));
 	if (!b->goff.empty()) HIPCHK(hipMemcpyAsync(b->d_goff, b->goff.data(), b->goff.size() * 8, hipMemcpyHostToDevice, c->stream));
+	if (!b->b3off.empty()) HIPCHK(hipMemcpyAsync(b->d_b3off, b->b3off.data(), b->b3off.size() * 8, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	*out = b;
 	return WM_OK;
@@ -330,29 +368,64 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		const wm_ksw_djob_t &big = b->jobs[o[0]];
 		fprintf(stderr, "[ksw class %2d] jobs %zu  %.2f ms  largest q=%d t=%d w=%d flag=0x%x n_col=%d\n", k, o.size(), now_ms() - t0, big.qlen, big.tlen, big.w, big.flag, big.n_col);
 	};
-	for (int k = 0; k < WM_KSW_GENERIC; ++k) {
+	// the size classes are independent: spread them over the side streams so that one class's long jobs overlap the others
+	int n_nonempty = 0, used_mask = 0, rr = 0;
+	for (int k = 0; k < WM_KSW_NCLASS; ++k) n_nonempty += !b->order[k].empty();
+	const bool fan = n_nonempty > 1 && !trace_k;
+	if (fan) HIPCHK(hipEventRecord(c->kev[4], c->stream));
+	hipStream_t ks = c->stream;
+	auto next_stream = [&]() {
+		if (!fan) return;
+		const int si = rr++ & 3;
+		ks = c->kstream[si];
+		if (!(used_mask >> si & 1)) { hipStreamWaitEvent(ks, c->kev[4], 0); used_mask |= 1 << si; }
+	};
+	int offs[WM_KSW_NCLASS + 1];
+	offs[0] = 0;
+	for (int k = 0; k < WM_KSW_NCLASS; ++k) offs[k + 1] = offs[k] + (int)b->order[k].size();
+	// launch order: the classes with the longest single jobs first
+	int lorder[WM_KSW_NCLASS], nl = 0;
+	lorder[nl++] = WM_KSW_GENERIC; lorder[nl++] = WM_KSW_BLOCK3; lorder[nl++] = WM_KSW_BLOCK2; lorder[nl++] = WM_KSW_BLOCK;
+	for (int k = WM_KSW_BLOCK - 1; k >= 0; --k) lorder[nl++] = k;
+	for (int li = 0; li < nl; ++li) {
+		const int k = lorder[li];
 		const int nk = (int)b->order[k].size();
 		if (nk == 0) continue;
+		off = offs[k];
+		next_stream();
 		const double tk0 = trace_k ? now_ms() : 0;
-		struct Done { decltype(class_done) &f; int k; double t; ~Done() { f(k, t); } } done_guard{ class_done, k, tk0 };
-		if (k == WM_KSW_BLOCK) {
-			hipLaunchKernelGGL(ksw_block_kernel, dim3(nk), dim3(64 * WM_KSW_BLK_NWV), 0, c->stream, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res);
-			off += nk;
+		hipEventRecord(c->cev[k][0], ks);
+		struct Done { decltype(class_done) &f; int k; double t; hipEvent_t e; hipStream_t s; ~Done() { hipEventRecord(e, s); f(k, t); } } done_guard{ class_done, k, tk0, c->cev[k][1], ks };
+		if (k == WM_KSW_BLOCK || k == WM_KSW_BLOCK2 || k == WM_KSW_BLOCK3) {
+			const size_t fixed = (size_t)WM_KSW_BLK_PUB * 4;
+			if (k == WM_KSW_BLOCK) {
+				const size_t lds = (size_t)WM_KSW_BLK_WN * 12 + fixed + WM_KSW_BLK_SEQ_LDS;
+				HIPCHK(hipFuncSetAttribute((const void*)ksw_block_kernel<WM_KSW_BLK_K, WM_KSW_BLK_WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+				hipLaunchKernelGGL((ksw_block_kernel<WM_KSW_BLK_K, WM_KSW_BLK_WN>), dim3(nk), dim3(64 * WM_KSW_BLK_NWV), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, (int)WM_KSW_BLK_SEQ_LDS, (int*)0, (const uint64_t*)0);
+			} else if (k == WM_KSW_BLOCK2) {
+				const size_t lds = (size_t)WM_KSW_BLK2_WN * 12 + fixed + WM_KSW_BLK2_SEQ_LDS;
+				HIPCHK(hipFuncSetAttribute((const void*)ksw_block_kernel<WM_KSW_BLK2_K, WM_KSW_BLK2_WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+				hipLaunchKernelGGL((ksw_block_kernel<WM_KSW_BLK2_K, WM_KSW_BLK2_WN>), dim3(nk), dim3(64 * WM_KSW_BLK_NWV), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, (int)WM_KSW_BLK2_SEQ_LDS, (int*)0, (const uint64_t*)0);
+			} else {
+				const size_t lds = fixed + WM_KSW_BLK3_SEQ_LDS;
+				HIPCHK(hipFuncSetAttribute((const void*)ksw_block_kernel<WM_KSW_BLK2_K, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+				hipLaunchKernelGGL((ksw_block_kernel<WM_KSW_BLK2_K, 0>), dim3(nk), dim3(64 * WM_KSW_BLK_NWV), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, (int)WM_KSW_BLK3_SEQ_LDS, (int*)b->d_b3state, b->d_b3off);
+			}
+			continue;
+		}
+		if (k == WM_KSW_GENERIC) {
+			hipLaunchKernelGGL(ksw_generic_kernel, dim3(nk), dim3(64), 0, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_gscratch, b->d_goff, b->d_res);
 			continue;
 		}
 		const int clip = k >> 1 & 1, hasn = k & 1;
 		switch (k & ~3) {
-		case WM_KSW_B4: launch_dp<4>(clip, hasn, nk, c->stream, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
-		case WM_KSW_B8: launch_dp<8>(clip, hasn, nk, c->stream, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
-		default: launch_dp<16>(clip, hasn, nk, c->stream, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
+		case WM_KSW_B4: launch_dp<4>(clip, hasn, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
+		case WM_KSW_B8: launch_dp<8>(clip, hasn, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
+		default: launch_dp<16>(clip, hasn, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
 		}
-		off += nk;
 	}
-	const double tg0 = trace_k ? now_ms() : 0;
-	if (!b->order[WM_KSW_GENERIC].empty())
-		hipLaunchKernelGGL(ksw_generic_kernel, dim3((int)b->order[WM_KSW_GENERIC].size()), dim3(64), 0, c->stream, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb,
-		                   b->d_gscratch, b->d_goff, b->d_res);
-	if (!b->order[WM_KSW_GENERIC].empty()) class_done(WM_KSW_GENERIC, tg0);
+	for (int si = 0; si < 4; ++si)
+		if (used_mask >> si & 1) { HIPCHK(hipEventRecord(c->kev[si], c->kstream[si])); HIPCHK(hipStreamWaitEvent(c->stream, c->kev[si], 0)); }
 	HIPCHK(hipEventRecord(c->ev[1], c->stream));
 	hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, b->d_jobs, b->d_tb, b->d_res, b->d_cig, b->d_err);
 	hipLaunchKernelGGL(ksw_scan_kernel, dim3(1), dim3(1024), 0, c->stream, n, b->d_res, b->d_off, b->d_total);
@@ -363,6 +436,11 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	HIPCHK(hipEventElapsedTime(&b->dp_ms, c->ev[0], c->ev[1]));
 	HIPCHK(hipEventElapsedTime(&b->bt_ms, c->ev[1], c->ev[2]));
 	c->last_ms = b->dp_ms + b->bt_ms;
+	for (int k = 0; k < WM_KSW_NCLASS; ++k)
+		if (!b->order[k].empty()) {
+			float ms = 0;
+			if (hipEventElapsedTime(&ms, c->cev[k][0], c->cev[k][1]) == hipSuccess) { c->k_ms[k] += ms; c->k_cells[k] += b->class_cells[k]; c->k_launches[k] += 1; }
+		}
 	int err = 0;
 	HIPCHK(hipMemcpy(&err, b->d_err, 4, hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(&b->total_ops, b->d_total, 4, hipMemcpyDeviceToHost));
@@ -975,7 +1053,7 @@ extern "C" int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena
 	if (n_threads < 1) return set_err(WM_EINVAL, "n_threads < 1");
 	for (wm_ctx_t *w : m->workers) wm_ctx_destroy(w);
 	m->workers.clear();
-	int G = getenv("WM_GROUPS") ? atoi(getenv("WM_GROUPS")) : (n_threads >= 8 ? 2 : 1);
+	int G = getenv("WM_GROUPS") ? atoi(getenv("WM_GROUPS")) : (n_threads >= 32 ? 4 : n_threads >= 8 ? 2 : 1);
 	if (G < 1) G = 1;
 	if (G > n_threads) G = n_threads;
 	m->n_threads = n_threads;
@@ -1054,6 +1132,19 @@ extern "C" int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, con
 	return WM_OK;
 }
 extern "C" int wm_mapper_stats(const wm_mapper_t *m, uint64_t *out9) { memcpy(out9, m->stats, sizeof(m->stats)); return WM_OK; }
+// per ksw kernel class (ksw_plan.h) since the mapper was created: out[3*k] = summed launch durations in ms (HIP events on the
+// launching stream), out[3*k+1] = DP cells, out[3*k+2] = launches; n_classes receives WM_KSW_NCLASS
+extern "C" int wm_mapper_kernel_stats(const wm_mapper_t *m, double *out, int cap, int *n_classes)
+{
+	if (n_classes) *n_classes = WM_KSW_NCLASS;
+	if (cap < 3 * WM_KSW_NCLASS) return set_err(WM_EINVAL, "need room for %d doubles", 3 * WM_KSW_NCLASS);
+	for (int k = 0; k < WM_KSW_NCLASS; ++k) {
+		double ms = m->c->k_ms[k], cells = (double)m->c->k_cells[k], ln = (double)m->c->k_launches[k];
+		for (const wm_ctx_t *w : m->workers) { ms += w->k_ms[k]; cells += (double)w->k_cells[k]; ln += (double)w->k_launches[k]; }
+		out[3 * k] = ms; out[3 * k + 1] = cells; out[3 * k + 2] = ln;
+	}
+	return WM_OK;
+}
 
 extern "C" int wm_sam_header(const wm_index_t *idx, int argc, const char *const *argv, const char **text, size_t *text_len)
 {

@@ -262,6 +262,14 @@ class Mapper:
         lib().wm_mapper_stats(self._h, a.ctypes.data)
         return dict(zip(STAT_NAMES, (int(x) for x in a)))
 
+    def kernel_stats(self):
+        """per ksw kernel class: dict class -> (ms, cells, launches)"""
+        out = np.zeros(3 * 32, np.float64)
+        n = C.c_int()
+        lib().wm_mapper_kernel_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        _chk(lib().wm_mapper_kernel_stats(self._h, out.ctypes.data, len(out), C.byref(n)))
+        return {k: (float(out[3 * k]), float(out[3 * k + 1]), int(out[3 * k + 2])) for k in range(n.value)}
+
     def close(self):
         if self._h:
             lib().wm_mapper_destroy(self._h)
