@@ -91,7 +91,8 @@ struct OracleOps : DeviceOps {
 	{
 		int8_t mat[25];
 		for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) mat[i * 5 + j] = (i == 4 || j == 4) ? sc.sc_ambi : i == j ? sc.match : sc.mismatch;
-		for (KswReq *r : reqs) {
+		wm::parallel_for(8, reqs.size(), [&](size_t ri) {            // (borrows the scheduler team's threads when there is a team)
+			KswReq *r = reqs[ri];
 			wmo_ez_t ez;
 			if (getenv("WM_KSW_STATS")) fprintf(stderr, "KSWJOB %d %d %d %d %d\n", (int)r->q.size(), (int)r->t.size(), r->w, r->zdrop, r->flag);
 			std::vector<uint32_t> cig(r->q.size() + r->t.size() + 4);
@@ -99,7 +100,7 @@ struct OracleOps : DeviceOps {
 			r->ez.max = ez.max; r->ez.zdropped = ez.zdropped; r->ez.max_q = ez.max_q; r->ez.max_t = ez.max_t; r->ez.mqe = ez.mqe; r->ez.mqe_t = ez.mqe_t;
 			r->ez.mte = ez.mte; r->ez.mte_q = ez.mte_q; r->ez.score = ez.score; r->ez.reach_end = ez.reach_end; r->ez.n_cigar = ez.n_cigar; r->ez.cig_off = 0;
 			r->cigar.assign(cig.begin(), cig.begin() + ez.n_cigar);
-		}
+		});
 	}
 };
 

@@ -54,7 +54,7 @@ def build_harness():
            [os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host"))]
     if _newer(out, srcs):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-o", out,
-                               os.path.join(hd, "harness.cpp"), os.path.join(ROOT, "oracle", "wm_oracle.c"), "-lz"])
+                               os.path.join(hd, "harness.cpp"), os.path.join(ROOT, "oracle", "wm_oracle.c"), "-lz", "-pthread"])
     return out
 
 

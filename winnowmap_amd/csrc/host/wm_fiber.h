@@ -33,6 +33,8 @@ struct SchedTeam {
 	pthread_barrier_t bar_;
 	std::vector<Scheduler*> members;
 	bool done = false;
+	ParallelExec exec;                                             // members 1.. lend themselves to member 0 during the device phase
+	uint64_t round = 0;
 };
 
 class Scheduler {
@@ -58,13 +60,18 @@ public:
 	// run until every fiber (of the whole team, if there is one) has finished
 	void run()
 	{
+		static const bool trace2 = getenv("WM_TRACE2") != 0;
 		for (;;) {
+			const auto tb0 = std::chrono::steady_clock::now();
+			size_t n_run = 0;
 			while (!ready_.empty()) {
 				cur_ = ready_.front(); ready_.pop_front();
 				swapcontext(&main_, &cur_->ctx);
 				if (cur_->done) { cur_->fn = nullptr; pool_.push_back(cur_); --live_; }
 				cur_ = 0;
+				++n_run;
 			}
+			if (trace2 && n_run) fprintf(stderr, "[member %d] ran %zu fiber slices in %.2f ms\n", rank_, n_run, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count());
 			if (!team_) {
 				if (live_ == 0) break;
 				flush();
@@ -94,6 +101,7 @@ private:
 	bool team_round()
 	{
 		pthread_barrier_wait(&team_->bar_);                            // every member is blocked or finished
+		const uint64_t round = ++my_round_;
 		if (rank_ == 0) {
 			size_t live = 0;
 			for (Scheduler *m : team_->members) live += m->live_;
@@ -106,9 +114,14 @@ private:
 					q_chain_.insert(q_chain_.end(), m->q_chain_.begin(), m->q_chain_.end()); m->q_chain_.clear();
 					q_ksw_.insert(q_ksw_.end(), m->q_ksw_.begin(), m->q_ksw_.end()); m->q_ksw_.clear();
 				}
+				team_->exec.wait_servers(team_->n_ - 1);
+				tl_parallel_exec() = &team_->exec;
 				flush();
+				tl_parallel_exec() = 0;
 			}
-		}
+			team_->exec.close(round);
+		} else
+			team_->exec.serve(round);                                    // help with the host side of the batched calls until they are done
 		pthread_barrier_wait(&team_->bar_);                            // results are in the requests
 		if (team_->done) return false;
 		if (rank_ != 0) { wake(w_sketch_); wake(w_seed_); wake(w_chain_); wake(w_ksw_); }
@@ -139,6 +152,7 @@ private:
 	int w_, k_;
 	SchedTeam *team_;
 	int rank_;
+	uint64_t my_round_ = 0;
 	ucontext_t main_;
 	Fiber *cur_ = 0;
 	size_t live_ = 0;

@@ -507,6 +507,26 @@ WM_DEV void ksw_dp_generic(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, cons
 // stores, publishes the values the scalar bookkeeping needs (row maximum, H at en0 / st0, the approximate-max
 // track) | barrier | all waves replay the same scalar bookkeeping from the published values, so they stay in step.
 // ------------------------------------------------------------------------------------------------------
+// one DP cell in the top-byte representation (src/ksw2_extd2_sse.c:205-311): inputs are the previous-row values, outputs the
+// new u, v, x, y, x2, y2 (top byte) and the traceback byte
+struct ksw_cell_cst_t { int Q, Q2, QE, QE2, MCH, tA, tB, tA2, tB2, hA, hB, hA2, hB2; };
+WM_DEV void ksw_cell(const ksw_cell_cst_t &c, const V<int> os, const V<int> x1, const V<int> v1, const V<int> x21, const V<int> oy, const V<int> ou, const V<int> oy2,
+                     V<int> &nu, V<int> &nv, V<int> &nx, V<int> &ny, V<int> &nx2, V<int> &ny2, V<int> &p)
+{
+	V<int> a = add3(x1, v1, -c.QE), b = add3(oy, ou, -c.QE), a2 = add3(x21, v1, -c.QE2), b2 = add3(oy2, ou, -c.QE2);
+	const V<int> zz = vmax3(vmax3(os, a, b), a2, b2);
+	const V<int> z = vmin(zz & (int)0xff000000, c.MCH);
+	p = zz & 7;
+	nu = wsub(z, v1); nv = wsub(z, ou);
+	const V<int> tmp = wsub(z, c.Q), tmp2 = wsub(z, c.Q2);
+	a = wsub(a, tmp); b = wsub(b, tmp); a2 = wsub(a2, tmp2); b2 = wsub(b2, tmp2);
+	p = wadd(wadd(p, p), sel(a > c.hA, 1, 0));
+	p = wadd(wadd(p, p), sel(b > c.hB, 1, 0));
+	p = wadd(wadd(p, p), sel(a2 > c.hA2, 1, 0));
+	p = wadd(wadd(p, p), sel(b2 > c.hB2, 1, 0));
+	nx = vmax(a, c.tA); ny = vmax(b, c.tB); nx2 = vmax(a2, c.tA2); ny2 = vmax(b2, c.tB2);
+}
+
 // Hulls wider than one sweep of the block (CH = 64*NWV*K lanes) are processed in CHUNKS of CH lanes per row: the only
 // cross-chunk dependency is the previous-row state of the lane just below a chunk, which one lane per chunk boundary
 // saves (into `pub`) at the start of the row, before anybody has stored. GLOBAL = the state window lives in a global
@@ -528,7 +548,9 @@ WM_DEV void ksw_dp_block(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 	const int tS = right ? 0 : 4, tA = right ? 1 : 3, tB = 2, tA2 = right ? 3 : 1, tB2 = right ? 4 : 0;
 	const int hA = right ? tA - 1 : tA, hB = right ? tB - 1 : tB, hA2 = right ? tA2 - 1 : tA2, hB2 = right ? tB2 - 1 : tB2;
 	const int MCH = tb8(sc.match);
+	const ksw_cell_cst_t cc = { Q, Q2, QE, QE2, MCH, tA, tB, tA2, tB2, hA, hB, hA2, hB2 };
 	const int sc_n = sc.sc_ambi == 0 ? -e2 : sc.sc_ambi;
+	const int MCHs = (int)sc.match, MISs = (int)sc.mismatch;
 	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
 	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
 	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
@@ -574,7 +596,14 @@ WM_DEV void ksw_dp_block(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 		for (int k = 0; k < K; ++k) {
 			const V<int> t = ln + (cst + 64 * (wv + NWV * k));
 			o0[k] = INIT0; o1[k] = 0; oh[k] = KSW_NEG_INF; n0[k] = INIT0; n1[k] = 0; nh[k] = KSW_NEG_INF;
-			if (cst + 64 * (wv + NWV * k) > top) continue;
+			const int tl0 = cst + 64 * (wv + NWV * k);
+			if (tl0 > top) continue;
+			if (tl0 - 1 >= last_st && tl0 + 63 <= last_en && tl0 > 0) {  // interior tile: every slot it touches holds valid state
+				o0[k] = gld(W0, t & wmask); o1[k] = gld(W1, t & wmask);
+				n0[k] = gld(W0, (t - 1) & wmask); n1[k] = gld(W1, (t - 1) & wmask);
+				if (!approx) { oh[k] = gld(Hm, t & wmask); nh[k] = gld(Hm, (t - 1) & wmask); }
+				continue;
+			}
 			WM_IF(t <= top)
 				WM_IF(t <= last_en) o0[k] = gld(W0, t & wmask); if (!approx) oh[k] = gld(Hm, t & wmask); WM_END
 				WM_IF(t <= w1_hi) o1[k] = gld(W1, t & wmask); WM_END
@@ -594,6 +623,28 @@ WM_DEV void ksw_dp_block(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 			const int tile0 = cst + 64 * (wv + NWV * k);
 			if (tile0 > top) continue;
 			const V<int> t = ln + tile0;
+			if (r > 0 && tile0 > st0 && tile0 + 63 < en1 && !(approx && last_H0_t + 1 >= tile0 && last_H0_t <= tile0 + 63)) {
+				// interior tile: all 64 lanes are plain in-band cells (no boundary, no band edge, no published lane)
+				const V<int> tc = cast<int>(gld(target, t)), qc = cast<int>(gld(query, V<int>(r) - t));
+				V<int> s8i = sel(tc == qc, MCHs, MISs);
+				s8i = sel((tc == 4) || (qc == 4), sc_n, s8i);
+				const V<int> ou = o0[k] << 24, oy = (o0[k] & (int)0xff000000) | tB, oy2 = ((o1[k] << 16) & (int)0xff000000) | tB2;
+				const V<int> x1 = ((n0[k] << 8) & (int)0xff000000) | tA, v1 = (n0[k] << 16) & (int)0xff000000, x21 = (n1[k] << 24) | tA2;
+				V<int> nu, nv, nx, ny, nx2, ny2, p;
+				ksw_cell(cc, (s8i << 24) | tS, x1, v1, x21, oy, ou, oy2, nu, nv, nx, ny, nx2, ny2, p);
+				const V<int> w0n = cast<int>((cast<unsigned>(nu) >> 24) | ((cast<unsigned>(nv) >> 24) << 8) | ((cast<unsigned>(nx) >> 24) << 16) | (cast<unsigned>(ny) & 0xff000000u));
+				const V<int> w1n = cast<int>((cast<unsigned>(nx2) >> 24) | ((cast<unsigned>(ny2) >> 24) << 8)) | ((s8i & 0xff) << 16);
+				gst(W0, t & wmask, w0n); gst(W1, t & wmask, w1n);
+				gst(tbp + (size_t)r * jb.n_col, t - st, cast<uint8_t>(p));
+				if (!approx) {
+					const V<int> hn = oh[k] + (nv >> 24);
+					gst(Hm, t & wmask, hn);
+					const V<int> pri = ((4 - ((t - st0) & 3)) << 20) | (0xfffff - t);
+					const V<long long> kk = cast<long long>(hn) * 4294967296LL + cast<long long>(pri);
+					key = sel(kk > key, kk, key);
+				}
+				continue;
+			}
 			// score of this row for the lanes inside the rewritten chunks; the others keep their old score byte
 			V<int> s8 = (o1[k] << 8) >> 24;
 			WM_IF(t >= st0 && t <= cend)
@@ -616,18 +667,8 @@ WM_DEV void ksw_dp_block(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 				const V<int> os = (s8 << 24) | tS;
 				V<int> x1 = ((n0[k] << 8) & (int)0xff000000) | tA, v1 = (n0[k] << 16) & (int)0xff000000, x21 = (n1[k] << 24) | tA2;
 				WM_IF(t == 0) x1 = tA; x21 = tA2; v1 = tb8(sched); WM_END    // :141-151 (st == 0)
-				V<int> a = add3(x1, v1, -QE), b = add3(oy, ou, -QE), a2 = add3(x21, v1, -QE2), b2 = add3(oy2, ou, -QE2);
-				V<int> zz = vmax3(vmax3(os, a, b), a2, b2);
-				V<int> z = vmin(zz & (int)0xff000000, MCH);
-				V<int> p = zz & 7;
-				const V<int> nu = wsub(z, v1), nv = wsub(z, ou);
-				V<int> tmp = wsub(z, Q), tmp2 = wsub(z, Q2);
-				a = wsub(a, tmp); b = wsub(b, tmp); a2 = wsub(a2, tmp2); b2 = wsub(b2, tmp2);
-				p = wadd(wadd(p, p), sel(a > hA, 1, 0));
-				p = wadd(wadd(p, p), sel(b > hB, 1, 0));
-				p = wadd(wadd(p, p), sel(a2 > hA2, 1, 0));
-				p = wadd(wadd(p, p), sel(b2 > hB2, 1, 0));
-				const V<int> nx = vmax(a, tA), ny = vmax(b, tB), nx2 = vmax(a2, tA2), ny2 = vmax(b2, tB2);
+				V<int> nu, nv, nx, ny, nx2, ny2, p;
+				ksw_cell(cc, os, x1, v1, x21, oy, ou, oy2, nu, nv, nx, ny, nx2, ny2, p);
 				const V<int> w0n = cast<int>((cast<unsigned>(nu) >> 24) | ((cast<unsigned>(nv) >> 24) << 8) | ((cast<unsigned>(nx) >> 24) << 16) | (cast<unsigned>(ny) & 0xff000000u));
 				const V<int> w1n = cast<int>((cast<unsigned>(nx2) >> 24) | ((cast<unsigned>(ny2) >> 24) << 8)) | ((s8 & 0xff) << 16);
 				gst(W0, t & wmask, w0n); gst(W1, t & wmask, w1n);

@@ -1073,10 +1073,14 @@ extern "C" int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena
 extern "C" int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, const char *const *seqs, const int32_t *lens,
                             const char **text, size_t *text_len, const int32_t **hits, const uint32_t **cigars, const int64_t **hit_first)
 {
+	static const bool trace_m = getenv("WM_TRACE") != 0;
+	const double tm0 = now_ms();
 	std::vector<wm::ReadIn> reads(n);
 	uint64_t bases = 0;
-	for (int i = 0; i < n; ++i) { reads[i].name = names[i]; reads[i].seq.assign(seqs[i], lens[i]); bases += lens[i]; }
+	for (int i = 0; i < n; ++i) bases += lens[i];
+	wm::parallel_for(m->n_threads, (size_t)n, [&](size_t i) { reads[i].name = names[i]; reads[i].seq.assign(seqs[i], lens[i]); });
 	std::vector<wm::ReadOut> out(n);
+	const double tm1 = now_ms();
 	const int T = (int)m->workers.size() + 1;
 	std::vector<GpuOps> ops(T);
 	std::vector<wm::MapStats> sts(T);
@@ -1110,18 +1114,32 @@ extern "C" int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, con
 		for (int t = 0; t < T; ++t) { a[0] += ops[t].t_pack; a[1] += ops[t].t_prep; a[2] += ops[t].t_run; a[3] += ops[t].t_fetch; a[4] += ops[t].t_unpack; a[5] += ops[t].t_sketch; a[6] += ops[t].t_seed; a[7] += ops[t].t_chain; }
 		fprintf(stderr, "[ops, sum over %d groups, ms] ksw: pack %.0f prepare %.0f run %.0f fetch %.0f unpack %.0f | sketch %.0f seed %.0f chain %.0f\n", T, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
 	}
-	m->text.clear(); m->hits.clear(); m->cigars.clear(); m->first.assign(n + 1, 0);
+	const double tm2 = now_ms();
+	// output records: formatted per read in parallel, then laid out in input order
+	std::vector<std::string> texts(n);
+	std::vector<size_t> toff(n + 1, 0), coff(n + 1, 0);
+	m->first.assign(n + 1, 0);
+	wm::parallel_for(m->n_threads, (size_t)n, [&](size_t i) { wm::write_read(texts[i], m->idx->ix, reads[i], out[i], m->mo.flag); });
 	for (int i = 0; i < n; ++i) {
-		wm::write_read(m->text, m->idx->ix, reads[i], out[i], m->mo.flag);
-		m->first[i] = (int64_t)(m->hits.size() / 16);
+		toff[i + 1] = toff[i] + texts[i].size();
+		m->first[i + 1] = m->first[i] + (int64_t)out[i].regs.size();
+		size_t nc = 0;
+		for (const wm::Reg &r : out[i].regs) nc += r.cigar.size();
+		coff[i + 1] = coff[i] + nc;
+	}
+	m->text.resize(toff[n]); m->hits.resize((size_t)m->first[n] * 16); m->cigars.resize(coff[n]);
+	wm::parallel_for(m->n_threads, (size_t)n, [&](size_t i) {
+		if (!texts[i].empty()) memcpy(&m->text[toff[i]], texts[i].data(), texts[i].size());
+		int32_t *ho = m->hits.data() + (size_t)m->first[i] * 16;
+		uint32_t *co = m->cigars.data() + coff[i];
 		for (const wm::Reg &r : out[i].regs) {
 			const int32_t o[16] = { r.rid, r.rs, r.re, r.qs, r.qe, (int32_t)r.rev, (int32_t)r.mapq, r.has_p ? (int32_t)r.cigar.size() : 0, r.score, r.cnt, r.mlen, r.blen,
 			                        r.dp_score, r.dp_max, r.dp_max2, (int32_t)((r.parent == r.id) | r.inv << 1 | r.sam_pri << 2 | r.split << 3) };
-			m->hits.insert(m->hits.end(), o, o + 16);
-			m->cigars.insert(m->cigars.end(), r.cigar.begin(), r.cigar.end());
+			memcpy(ho, o, sizeof(o)); ho += 16;
+			if (!r.cigar.empty()) { memcpy(co, r.cigar.data(), r.cigar.size() * 4); co += r.cigar.size(); }
 		}
-	}
-	m->first[n] = (int64_t)(m->hits.size() / 16);
+	});
+	if (trace_m) fprintf(stderr, "[map_reads] n=%d ingest %.1f ms, map %.1f ms, format %.1f ms\n", n, tm1 - tm0, tm2 - tm1, now_ms() - tm2);
 	m->stats[0] = st.n_flush; m->stats[1] = st.n_ksw; m->stats[2] = st.n_chain; m->stats[3] = st.n_seed; m->stats[4] = st.n_sketch;
 	m->stats[5] = opsr.cells; m->stats[6] = (uint64_t)opsr.ksw_us; m->stats[7] = (uint64_t)opsr.aux_us; m->stats[8] = bases;
 	if (text) *text = m->text.data();
