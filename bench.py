@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")   # before HIP initialises (see winnowmap_amd/__init__.py)
 from winnowmap_amd import gpu, synth  # noqa: E402
+from winnowmap_amd import dist as wmdist  # noqa: E402
 
 
 def log(*a):
@@ -102,7 +103,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
     n_cores = os.cpu_count() or 1
-    n_threads = args.threads or max(1, min(64, n_cores // max(1, world) // 2))
+    n_threads = args.threads or max(1, min(64, n_cores // max(1, world)))
     tmp = tempfile.mkdtemp(prefix="wmbench_")
 
     # ---- reference + index: rank 0 builds, RCCL broadcasts the flat arrays ----
@@ -113,26 +114,7 @@ def main():
         log("index: %d minimizers (%.1fs)" % (idx.n_minimizers, time.time() - t0))
     if world > 1:
         dev = torch.device("cuda", local)
-        if rank == 0:
-            sizes, arrs = idx.export_arrays()
-            st = torch.from_numpy(sizes.astype(np.int64)).to(dev)
-        else:
-            st = torch.zeros(9, dtype=torch.int64, device=dev)
-        dist.broadcast(st, 0)
-        sizes_b = st.cpu().numpy().astype(np.uint64)
-        n = [int(sizes_b[0]), int(sizes_b[1]), int(sizes_b[1]), int(sizes_b[2]), int(sizes_b[3]), 2 * int(sizes_b[4]), int(sizes_b[5])]
-        dts = (np.uint32, np.uint64, np.uint64, np.uint64, np.uint8, np.uint64, np.uint8)
-        recv = []
-        for i, (m, dt) in enumerate(zip(n, dts)):
-            nbytes = max(m, 1) * np.dtype(dt).itemsize
-            if rank == 0:
-                t = torch.from_numpy(arrs[i].view(np.uint8)).to(dev)
-            else:
-                t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            dist.broadcast(t, 0)                      # RCCL over xGMI
-            recv.append(t.cpu().numpy().view(dt))
-        if rank != 0:
-            idx = gpu.Index.from_arrays(sizes_b, recv)
+        idx = wmdist.broadcast_index(idx if rank == 0 else None, rank, dist, dev)      # RCCL over xGMI, one broadcast per flat array
         # every rank regenerates the (seeded) reference only to draw its reads from it
         if rank != 0:
             n_contigs = max(1, int(round(args.ref_mb / 10.0)))
@@ -172,12 +154,9 @@ def main():
     elapsed = time.time() - t_start
     ks1 = mapper.kernel_stats()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tb = torch.tensor([bases, cells], dtype=torch.float64, device=torch.device("cuda", local))
-        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
-        total_bases = float(tb[0].item())
+        dev = torch.device("cuda", local)
+        elapsed = wmdist.max_over_ranks(elapsed, dist, dev)
+        total_bases = wmdist.sum_over_ranks([bases], dist, dev)[0]
     else:
         total_bases = float(bases)
 

@@ -12,6 +12,9 @@ from winnowmap_amd import build
 def emu():
     E = C.CDLL(build.build_emu())
     E.emu_ksw_extd2.argtypes = [C.c_int, W.u8p, C.c_int, W.u8p, W.i8p] + [C.c_int] * 9 + [W.i32p, W.u32p, C.c_int, C.POINTER(C.c_int)]
+    E.emu_sketch.argtypes = [C.c_int, W.u8p, W.u64p, W.i32p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, W.u64p, W.u64p, W.u64p, W.i32p, W.i32p]
+    E.emu_seed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, W.u64p, W.u64p, C.c_int, C.c_int, C.c_int, C.c_int, W.u64p, W.u64p, C.c_int, W.i32p]
+    E.emu_chain_fill.argtypes = [C.c_int64, W.u64p, W.u64p] + [C.c_int] * 6 + [C.c_float, C.c_float, W.i32p, W.i32p, W.i32p]
     return E
 
 
@@ -38,3 +41,145 @@ def test_ksw_emulated_kernel_matches_oracle(emu, seed):
             assert [int(x) for x in ez] == [o[k] for k in W.EZ_FIELDS], (klass, c["flag"], c["w"])
             assert np.array_equal(cig, o["cigar"])
     assert len(seen) >= 6
+
+
+def test_block_ksw_kernels_match_oracle(emu):
+    """The multi-wave kernels (LDS window 4096 / 8192, and the global-state variant incl. a small geometry that forces
+    many chunks per row) on forced small cases and on natively wide bands."""
+    from winnowmap_amd import synth
+    cases = kswcases.make_cases(5, 24, max_len=400)
+    rng = np.random.default_rng(9)
+    for it in range(3):
+        tl = int(rng.integers(1100, 1700))
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        q = synth.mutate_codes(t, rng, 0.04, 0.04, 0.05) if it else rng.integers(0, 4, 1200).astype(np.uint8)
+        cases.append(dict(q=q, t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=[3001, 1500, 3001][it], zdrop=[400, 200, -1][it], end_bonus=-1, flag=[0x08, 0x40, 0xC2][it]))
+    n_run = 0
+    for c in cases:
+        o = W.o_ksw_extd2(c["q"], c["t"], mat=W.simple_mat(c["a"], c["b"], 1), q=c["q_"], e=c["e"], q2=c["q2"], e2=c["e2"],
+                          w=c["w"], zdrop=c["zdrop"], end_bonus=c["end_bonus"], flag=c["flag"])
+        for force in (12, 13, 14, 114):
+            n, ez, cig, klass = emu_ksw(emu, c, force)
+            if n < 0:
+                continue
+            n_run += 1
+            assert [int(x) for x in ez] == [o[k] for k in W.EZ_FIELDS], (force, len(c["q"]), len(c["t"]), c["flag"], c["w"])
+            assert np.array_equal(cig, o["cigar"])
+    assert n_run > 80
+
+
+@pytest.fixture(scope="module")
+def small_index():
+    """a host-built index (product code, via the test harness) + its bloom filter, and windows of reads to sketch"""
+    import tempfile
+    from winnowmap_amd import synth
+    H = C.CDLL(build.build_harness())
+    H.h_index_build.restype = C.c_void_p
+    H.h_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+    vp = C.POINTER(C.c_uint64)
+    H.h_index_view.argtypes = [C.c_void_p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    H.h_bloom_view.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint8))]
+    H.h_chain_extract.restype = C.c_int64
+    H.h_chain_extract.argtypes = [C.c_int64, W.u64p, W.u64p, W.i32p, W.i32p, W.i32p, C.c_int, C.c_int, C.POINTER(C.c_int), W.u64p, W.u64p, W.u64p]
+    H.h_avg_qspan.restype = C.c_float
+    H.h_avg_qspan.argtypes = [C.c_int64, W.u64p]
+    H.h_index_get.argtypes = [C.c_void_p, C.c_uint64, W.u64p, C.c_int]
+    d = tempfile.mkdtemp()
+    ref = synth.make_reference(2, 200000, 3, repeat_frac=0.15)
+    synth.write_fasta(d + "/ref.fa", ref)
+    km, cnt = synth.repetitive_kmers(ref, 15)
+    synth.write_kmer_list(d + "/rep.txt", km, cnt, 15)
+    h = H.h_index_build((d + "/ref.fa").encode(), (d + "/rep.txt").encode(), 15, 50, 4)
+    hk, hv, P = vp(), vp(), vp()
+    hb = C.c_int(); ns = C.c_uint64(); npz = C.c_uint64()
+    H.h_index_view(h, C.byref(hk), C.byref(hv), C.byref(P), C.byref(hb), C.byref(ns), C.byref(npz))
+    tb = C.c_uint32(); salts = (C.c_uint32 * 2)(); bb = C.POINTER(C.c_uint8)()
+    H.h_bloom_view(h, C.byref(tb), salts, C.byref(bb))
+    reads, _ = synth.make_reads(ref, 6, 15000, 5)
+    return dict(H=H, h=h, hk=hk, hv=hv, P=P, hbits=hb.value, tb=tb.value, salts=(salts[0], salts[1]), bloom_bits=bb, bloom=W.o_bloom(km), reads=reads, synth=synth)
+
+
+def test_sketch_kernel_emulated_matches_oracle(emu, small_index):
+    S = small_index
+    rng = np.random.default_rng(4)
+    seqs = [r[st:st + 2000].copy() for r in S["reads"][:3] for st in range(0, 14000, 4000)]
+    for it in range(12):                      # low-complexity / periodic sequences, some with N
+        L, unit = int(rng.integers(100, 2500)), int(rng.integers(1, 13))
+        s = np.tile(rng.integers(0, 4, unit), L // unit + 1)[:L].astype(np.uint8)
+        s = S["synth"].mutate_codes(s, rng, 0.01, 0, 0)
+        for _ in range(int(rng.integers(0, 3))):
+            s[int(rng.integers(0, len(s)))] = 4
+        seqs.append(s)
+    seqs += [S["reads"][0], np.array([0, 1, 2], np.uint8)]
+    lens = np.array([len(s) for s in seqs], np.int32)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    caps = (lens // 4 + 16).astype(np.int32)
+    ooffs = np.concatenate([[0], np.cumsum(caps)[:-1]]).astype(np.uint64)
+    ox = np.zeros(int(caps.sum()), np.uint64); oy = np.zeros(int(caps.sum()), np.uint64); counts = np.zeros(len(seqs), np.int32)
+    emu.emu_sketch(len(seqs), np.concatenate(seqs), offs, lens, 50, 15, S["tb"], S["salts"][0], S["salts"][1], C.cast(S["bloom_bits"], C.c_void_p), ox, oy, ooffs, caps, counts)
+    for i, s in enumerate(seqs):
+        ex, ey = W.o_sketch(bytes(s), 50, 15, rid=0, bloom=S["bloom"])
+        n = counts[i]
+        assert n == len(ex), (i, n, len(ex))
+        assert np.array_equal(ox[int(ooffs[i]):int(ooffs[i]) + n], ex) and np.array_equal(oy[int(ooffs[i]):int(ooffs[i]) + n], ey)
+
+
+def _expected_anchors(S, mx, my, qlen, max_occ=5000):
+    """collect_seed_hits restated in numpy/python on the product index (src/map.c:97-130,222-254)"""
+    H, h = S["H"], S["h"]
+    ex, ey = [], []
+    buf = np.zeros(6000, np.uint64)
+    rep_st = rep_en = rep = 0
+    for i, (x, y) in enumerate(zip(mx, my)):
+        t = H.h_index_get(h, int(x) >> 8, buf, 6000)
+        qpos = int(y) & 0xffffffff; span = int(x) & 0xff
+        if t >= max_occ:
+            en = (qpos >> 1) + 1; st = en - span
+            if st > rep_en:
+                rep += rep_en - rep_st; rep_st, rep_en = st, en
+            else:
+                rep_en = en
+            continue
+        tand = (i > 0 and int(mx[i - 1]) >> 8 == int(x) >> 8) or (i < len(mx) - 1 and int(mx[i + 1]) >> 8 == int(x) >> 8)
+        for r in buf[:t]:
+            r = int(r); rpos = (r & 0xffffffff) >> 1
+            if (r & 1) == (qpos & 1):
+                X = (r & 0xffffffff00000000) | rpos; Y = span << 32 | qpos >> 1
+            else:
+                X = 1 << 63 | (r & 0xffffffff00000000) | rpos; Y = span << 32 | (qlen - ((qpos >> 1) + 1 - span) - 1)
+            if tand:
+                Y |= 1 << 42
+            ex.append(X); ey.append(Y)
+    rep += rep_en - rep_st
+    return np.array(ex, np.uint64), np.array(ey, np.uint64), rep
+
+
+def test_seed_and_chain_kernels_emulated_match_oracle(emu, small_index):
+    S = small_index
+    H = S["H"]
+    windows = [r[st:st + 2000].copy() for r in S["reads"][:2] for st in range(0, 14000, 3500)] + [S["reads"][2], S["reads"][3]]
+    n_chain = 0
+    for wi, s in enumerate(windows):
+        mx, my = W.o_sketch(bytes(s), 50, 15, bloom=S["bloom"])
+        cap = 200000
+        ax = np.zeros(cap, np.uint64); ay = np.zeros(cap, np.uint64); res = np.zeros(2, np.int32)
+        emu.emu_seed(C.cast(S["hk"], C.c_void_p), C.cast(S["hv"], C.c_void_p), C.cast(S["P"], C.c_void_p), S["hbits"], mx, my, len(mx), len(s), 5000, 0, ax, ay, cap, res)
+        n = res[0]
+        ax, ay = ax[:n], ay[:n]
+        ex, ey, rep = _expected_anchors(S, mx, my, len(s))
+        assert np.array_equal(ax, ex) and np.array_equal(ay, ey) and res[1] == rep
+        if n == 0:
+            continue
+        sx, sy = W.o_radix_sort_128x(ax, ay)
+        avg = H.h_avg_qspan(n, sy)
+        prm = [dict(max_dist_x=5000, min_dist_x=1000, max_dist_y=5000, bw=500), dict(max_dist_x=16000, min_dist_x=1000, max_dist_y=16000, bw=2000)][wi % 2]
+        ou, obx, oby = W.o_chain_dp(sx, sy, **prm)
+        # (window, waves): single wave in-window; single wave with a 128-anchor window (wrap + global fallback); 4 and 8 cooperating waves
+        for win, nwv in ((0, 0), (128, 0), (128, 4), (0, 8)):
+            fa = np.zeros(n, np.int32); pa = np.zeros(n, np.int32); va = np.zeros(n, np.int32)
+            emu.emu_chain_fill(n, sx, sy, prm["max_dist_x"], prm["min_dist_x"], prm["max_dist_y"], prm["bw"], 25 | (win << 16), 5000 | (nwv << 24), avg, 1.0, fa, pa, va)
+            u = np.zeros(n, np.uint64); bx = np.zeros(n, np.uint64); by = np.zeros(n, np.uint64); nu = C.c_int()
+            nv = H.h_chain_extract(n, sx, sy, fa, pa, va, 3, 40, C.byref(nu), u, bx, by)
+            assert np.array_equal(u[:nu.value], ou) and np.array_equal(bx[:nv], obx) and np.array_equal(by[:nv], oby), (wi, n, win, nwv)
+            n_chain += 1
+    assert n_chain >= 24

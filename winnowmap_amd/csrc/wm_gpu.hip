@@ -14,6 +14,17 @@
 #include <chrono>
 #include <atomic>
 #include "host/wm_core.h"
+// large staging buffers: no value-initialisation (a std::vector would memset hundreds of MB per batch)
+template <class T> struct UBuf {
+	T *p; size_t n;
+	explicit UBuf(size_t n_) : p((T*)malloc((n_ ? n_ : 1) * sizeof(T))), n(n_) { if (!p) abort(); }
+	~UBuf() { free(p); }
+	UBuf(const UBuf&) = delete; UBuf &operator=(const UBuf&) = delete;
+	T *data() { return p; } const T *data() const { return p; }
+	size_t size() const { return n; }
+	T &operator[](size_t i) { return p[i]; } const T &operator[](size_t i) const { return p[i]; }
+	T *begin() { return p; } T *end() { return p + n; }
+};
 static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #include "simt.h"
 #include "ksw_kernel.h"
@@ -700,7 +711,7 @@ extern "C" int wm_sketch_batch(wm_ctx_t *c, int n, const uint8_t *seqs, size_t s
 	const size_t lds = (size_t)w * 64 * 12;
 	if (lds > 160 * 1024) return set_err(WM_EINVAL, "window w=%d needs %zu B of LDS per wave (max 160 KB)", w, lds);
 	HIPCHK(hipFuncSetAttribute((const void*)sketch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	// first try a slot of len/4+16 minimizers per sequence (typical density is 2/(w+1)); retry the rare overflow at full size
+	// first try a slot of len/8+16 minimizers per sequence (typical density is 2/(w+1)); retry the rare overflow at full size
 	std::vector<wm_sketch_job_t> jobs(n);
 	std::vector<int> todo(n);
 	for (int i = 0; i < n; ++i) todo[i] = i;
@@ -713,7 +724,7 @@ extern "C" int wm_sketch_batch(wm_ctx_t *c, int n, const uint8_t *seqs, size_t s
 		for (size_t t = 0; t < todo.size(); ++t) {
 			const int i = todo[t];
 			jb[t].seq_off = seq_off[i]; jb[t].len = len[i];
-			jb[t].cap = round == 0 ? len[i] / 4 + 16 : len[i] + 1;
+			jb[t].cap = round == 0 ? len[i] / 8 + 16 : len[i] + 1;
 			jb[t].out_off = tot; tot += jb[t].cap;
 		}
 		wm_sketch_job_t *d_jobs = (wm_sketch_job_t*)arena_take(c, jb.size() * sizeof(wm_sketch_job_t));
@@ -727,7 +738,7 @@ extern "C" int wm_sketch_batch(wm_ctx_t *c, int n, const uint8_t *seqs, size_t s
 		hipLaunchKernelGGL(sketch_kernel, dim3(((int)jb.size() + 63) / 64), dim3(64), lds, c->stream, c->skp, d_jobs, (int)jb.size(), d_seqs, c->d_bloom, d_out, d_cnt);
 		HIPCHK(hipEventRecord(c->ev[1], c->stream));
 		std::vector<int> cnt(jb.size());
-		std::vector<wm128_t> tmp(tot + 1);
+		UBuf<wm128_t> tmp(tot + 1);
 		HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt, jb.size() * 4, hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(hipMemcpyAsync(tmp.data(), d_out, tot * sizeof(wm128_t), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(hipStreamSynchronize(c->stream));
@@ -791,7 +802,7 @@ extern "C" int wm_seed_batch(wm_ctx_t *c, int n, const wm128_t *mini, const uint
 		hipLaunchKernelGGL(seed_kernel, dim3((int)jb.size()), dim3(64), 0, c->stream, ix, d_jobs, d_mini, d_out, d_occ, d_occ_off, d_res);
 		HIPCHK(hipEventRecord(c->ev[1], c->stream));
 		std::vector<wm_seed_res_t> res(jb.size());
-		std::vector<wm128_t> tmp(tot + 1);
+		UBuf<wm128_t> tmp(tot + 1);
 		HIPCHK(hipMemcpyAsync(res.data(), d_res, jb.size() * sizeof(wm_seed_res_t), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(hipMemcpyAsync(tmp.data(), d_out, tot * sizeof(wm128_t), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(hipStreamSynchronize(c->stream));
@@ -877,7 +888,7 @@ extern "C" int wm_chain_batch(wm_ctx_t *c, int n, wm128_t *a, const uint64_t *a_
 	}
 	HIPCHK(hipEventRecord(c->ev[1], c->stream));
 	const double tt2 = trace ? now_ms() : 0;
-	std::vector<int> fpvt((tot + 1) * 4);
+	UBuf<int> fpvt((tot + 1) * 4);
 	HIPCHK(hipMemcpyAsync(fpvt.data(), d_fpvt, tot * 16, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	HIPCHK(hipGetLastError());
@@ -922,11 +933,21 @@ struct GpuOps : wm::DeviceOps {
 		std::vector<int32_t> len(n), cnt(n);
 		size_t tot = 0;
 		for (int i = 0; i < n; ++i) { off[i] = tot; len[i] = reqs[i]->len; tot += reqs[i]->len; }
-		std::vector<uint8_t> seqs(tot + 1);
+		UBuf<uint8_t> seqs(tot + 1);
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { memcpy(seqs.data() + off[i], reqs[i]->seq, reqs[i]->len); });
-		std::vector<wm128_t> out(tot + n + 1);
+		UBuf<wm128_t> out(tot / 8 + (size_t)17 * n + 64);          // wm_sketch_batch tries len/8 + 16 slots per sequence first
 		const double ts = now_ms();
-		if (wm_sketch_batch(c, n, seqs.data(), tot, off.data(), len.data(), out.data(), out.size(), ooff.data(), cnt.data())) { fail("sketch"); return; }
+		int rc = wm_sketch_batch(c, n, seqs.data(), tot, off.data(), len.data(), out.data(), out.size(), ooff.data(), cnt.data());
+		if (rc == WM_ENOMEM && strstr(g_err, "minimizer output pool")) {   // pathological density: redo with one slot per base
+			UBuf<wm128_t> big(tot + n + 1);
+			rc = wm_sketch_batch(c, n, seqs.data(), tot, off.data(), len.data(), big.data(), big.size(), ooff.data(), cnt.data());
+			if (rc) { fail("sketch"); return; }
+			t_sketch += now_ms() - ts;
+			aux_us += c->aux_ms * 1e3;
+			wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { reqs[i]->mini.assign(big.begin() + ooff[i], big.begin() + ooff[i] + cnt[i]); });
+			return;
+		}
+		if (rc) { fail("sketch"); return; }
 		t_sketch += now_ms() - ts;
 		aux_us += c->aux_ms * 1e3;
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { reqs[i]->mini.assign(out.begin() + ooff[i], out.begin() + ooff[i] + cnt[i]); });
@@ -939,11 +960,11 @@ struct GpuOps : wm::DeviceOps {
 		std::vector<int32_t> nm(n), ql(n), na(n), rl(n);
 		size_t tot = 0;
 		for (int i = 0; i < n; ++i) { moff[i] = tot; nm[i] = reqs[i]->n_mini; ql[i] = reqs[i]->qlen; tot += reqs[i]->n_mini; }
-		std::vector<wm128_t> mini(tot + 1);
+		UBuf<wm128_t> mini(tot + 1);
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { memcpy(mini.data() + moff[i], reqs[i]->mini, (size_t)reqs[i]->n_mini * sizeof(wm128_t)); });
 		size_t cap = tot * 8 + 1024;
 		for (int attempt = 0; attempt < 6; ++attempt) {
-			std::vector<wm128_t> out(cap);
+			UBuf<wm128_t> out(cap);
 			const double ts = now_ms();
 			const int rc = wm_seed_batch(c, n, mini.data(), moff.data(), nm.data(), ql.data(), reqs[0]->max_occ, reqs[0]->flag, out.data(), out.size(), ooff.data(), na.data(), rl.data());
 			if (rc == WM_ENOMEM && strstr(g_err, "anchor output pool")) { cap *= 8; continue; }
@@ -967,8 +988,8 @@ struct GpuOps : wm::DeviceOps {
 			wm::ChainReq &r = *reqs[i];
 			par[i] = { r.max_dist_x, r.min_dist_x, r.max_dist_y, r.bw, r.max_skip, r.max_iter, r.min_cnt, r.min_sc, r.gap_scale };
 		}
-		std::vector<wm128_t> a(tot + 1);
-		std::vector<uint64_t> u(tot + 1);
+		UBuf<wm128_t> a(tot + 1);
+		UBuf<uint64_t> u(tot + 1);
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { memcpy(a.data() + aoff[i], reqs[i]->a.data(), reqs[i]->a.size() * sizeof(wm128_t)); });
 		const double ts = now_ms();
 		if (wm_chain_batch(c, n, a.data(), aoff.data(), na.data(), par.data(), u.data(), uoff.data(), nu.data(), nv.data())) { fail("chain"); return; }
@@ -994,13 +1015,13 @@ struct GpuOps : wm::DeviceOps {
 			cap += r.q.size() + r.t.size() + 2;
 		}
 		if (tot >= ((size_t)1 << 32)) { error = "ksw batch exceeds 4 GB of sequence"; return; }
-		std::vector<uint8_t> seqs(tot + 1);
+		UBuf<uint8_t> seqs(tot + 1);
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 			memcpy(seqs.data() + jobs[i].q_off, reqs[i]->q.data(), reqs[i]->q.size());
 			memcpy(seqs.data() + jobs[i].t_off, reqs[i]->t.data(), reqs[i]->t.size());
 		});
 		std::vector<wm_ksw_result_t> res(n);
-		std::vector<uint32_t> pool(cap);
+		UBuf<uint32_t> pool(cap);
 		size_t used = 0;
 		const double t1 = now_ms();
 		c->acc_cells = 0; c->t_prep = c->t_run = c->t_fetch = 0;

@@ -1,0 +1,56 @@
+"""Multi-GPU plumbing (one process per GPU, torch.distributed; backend "nccl" = RCCL on ROCm, "gloo" in the CPU tests).
+
+The mapping path shards by READS and needs no data-path collective; the only exchange is the one-off
+broadcast of the flat index arrays from the rank that built it."""
+import numpy as np
+
+_EXPORT_DTYPES = (np.uint32, np.uint64, np.uint64, np.uint64, np.uint8, np.uint64, np.uint8)
+
+
+def export_lengths(sizes):
+    """element counts of the 7 exported arrays (S, hkey, hval, P, bloom, seq_meta, names) from the 9 header sizes"""
+    s = [int(x) for x in sizes]
+    return [s[0], s[1], s[1], s[2], s[3], 2 * s[4], s[5]]
+
+
+def broadcast_index(idx, rank, dist, device):
+    """rank 0 passes its gpu.Index, the others None; every rank returns an Index with identical content.
+    One broadcast for the 9-entry size header, then one per flat array (bytes)."""
+    import torch
+    from . import gpu
+    if rank == 0:
+        sizes, arrs = idx.export_arrays()
+        st = torch.from_numpy(sizes.astype(np.int64)).to(device)
+    else:
+        st = torch.zeros(9, dtype=torch.int64, device=device)
+    dist.broadcast(st, 0)
+    sizes_b = st.cpu().numpy().astype(np.uint64)
+    recv = []
+    for i, (m, dt) in enumerate(zip(export_lengths(sizes_b), _EXPORT_DTYPES)):
+        nbytes = max(m, 1) * np.dtype(dt).itemsize
+        if rank == 0:
+            t = torch.from_numpy(arrs[i].view(np.uint8)).to(device)
+        else:
+            t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        dist.broadcast(t, 0)
+        recv.append(t.cpu().numpy().view(dt))
+    return idx if rank == 0 else gpu.Index.from_arrays(sizes_b, recv)
+
+
+def shard(n, rank, world):
+    """indices of the reads rank `rank` maps (round-robin: balances long reads after the reference's length sort, src/map.c:1124-1143)"""
+    return list(range(rank, n, world))
+
+
+def max_over_ranks(value, dist, device):
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(values, dist, device):
+    import torch
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]
