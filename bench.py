@@ -169,9 +169,24 @@ def main():
         names = {0: "ksw_dp_kernel<4,...>", 4: "ksw_dp_kernel<8,...>", 8: "ksw_dp_kernel<16,...>", 12: "ksw_block_kernel<3,4096>", 13: "ksw_block_kernel<7,8192>", 14: "ksw_block_kernel<7,0>", 15: "ksw_generic_kernel"}
         kname = names[dom & ~3] if dom < 12 else names[dom]
         if dom < 12:
-            kname = kname.replace("...", "%d,%d" % (dom >> 1 & 1, dom & 1))
+            kname = class_name(dom)
         ach = d_cells / max(d_ms, 1e-9) / 1e6       # 1 B of traceback per DP cell: bytes per ms / 1e6 = GB/s
         all_ms = sum(v[0] for v in cls.values()); all_cells = sum(v[1] for v in cls.values())
+
+        def class_name(k):
+            if k >= 12:
+                return names[k]
+            return names[k & ~3].replace("...", "%s,%s" % ("true" if k >> 1 & 1 else "false", "true" if k & 1 else "false"))
+        classes = {class_name(k): {"ms": round(v[0], 3), "cells": v[1], "launches": v[2]} for k, v in cls.items() if v[2] > 0}
+        # HBM traffic per DP cell of each kernel, measured in separate rocprofv3 --pmc passes (tools/pmc_ratio.py → profiles/)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_bytes_per_cell.json")) as f:
+                pmc = json.load(f)
+            if class_name(dom) in pmc["bytes_per_cell"]:
+                traffic = pmc["bytes_per_cell"][class_name(dom)] * d_cells / max(1, d_launch)
+        except Exception:  # noqa: BLE001
+            pmc = None
         out = {
             "metric": "mapped Gbp/s", "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -180,7 +195,8 @@ def main():
                                    % (args.reads_per_step, args.read_len, args.ref_mb),
                        "reads_per_step_per_gpu": args.reads_per_step, "read_len": args.read_len, "ref_mb": args.ref_mb, "host_threads": n_threads,
                        "reads_per_s": total_bases / args.read_len / elapsed, "hits": hits, "parallelism": "reads sharded over %d rank(s), index broadcast" % world},
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
+                         "traffic_source": (pmc or {}).get("source") if traffic is not None else None, "classes": classes,
                          "kernel": kname, "algorithmic_bytes": "1 B traceback per DP cell (sequence bytes are < 1 %)",
                          "launches": d_launch, "avg_launch_ms": d_ms / max(1, d_launch), "cells_per_launch": d_cells / max(1, d_launch),
                          "gcups_dominant": d_cells / max(d_ms, 1e-9) / 1e6, "gcups_all_ksw_classes": all_cells / max(all_ms, 1e-9) / 1e6,

@@ -1,0 +1,41 @@
+"""HBM bytes per DP cell of every ksw kernel from the two rocprofv3 --pmc passes of tools/prof_bench.sh
+(FETCH_SIZE and WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled on gfx950 as MI355X_MICROARCH.md prescribes) and the
+per-class cell counts that bench.py printed in the same runs. Writes profiles/pmc_bytes_per_cell.json.
+usage: pmc_ratio.py gpurun_out/prof_<tag>"""
+import sqlite3, sys, os, json, glob, collections, re
+
+src = sys.argv[1]
+
+
+def counters(d, name):
+    f = glob.glob(os.path.join(src, d, "*.db"))[0]
+    db = sqlite3.connect(f)
+    agg = collections.defaultdict(float)
+    for k, v in db.execute("select kernel_name, value from counters_collection where counter_name = ?", (name,)):
+        agg[k] += v
+    return agg
+
+
+def classes(log):
+    m = re.search(r'\{"metric".*\}', open(os.path.join(src, log)).read())
+    return json.loads(m.group(0))["roofline"]["classes"]
+
+
+def key(kernel_name):        # "void ksw_dp_kernel<16, true, false>(...)" -> "ksw_dp_kernel<16,true,false>"
+    m = re.search(r"(ksw_[a-z_]+kernel(<[^>]*>)?)", kernel_name)
+    return m.group(1).replace(" ", "") if m else None
+
+
+fetch, write = counters("pmc1", "FETCH_SIZE"), counters("pmc2", "WRITE_SIZE")
+c1, c2 = classes("pmc1.log"), classes("pmc2.log")
+out = {}
+for kn in set(list(fetch) + list(write)):
+    k = key(kn)
+    if not k or k not in c1 or k not in c2 or not c1[k]["cells"]:
+        continue
+    rd = 2.0 * fetch.get(kn, 0.0) * 1024 / c1[k]["cells"]
+    wr = write.get(kn, 0.0) * 1024 / c2[k]["cells"]
+    out[k] = rd + wr
+    print("%-36s read %.3f B/cell  write %.3f B/cell  (algorithmic: 1 B/cell written)" % (k, rd, wr))
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --steps 1 --warmup 0 --reads-per-step 1024 (%s), FETCH_SIZE x2 (gfx950), KiB units" % os.path.basename(src.rstrip("/")),
+           "bytes_per_cell": out}, open("profiles/pmc_bytes_per_cell.json", "w"), indent=1)
