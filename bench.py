@@ -80,6 +80,55 @@ def cpu_reference_baseline(fa, kf, reads, tmp, n_cores):
             "sample": "%d x 15 kb reads of the same workload, winnowmap_ref -t %d -W -ax map-ont, mapping phase %.2f s (index build %.1f s excluded)" % (len(reads), n_cores, t_map, float(m_idx.group(1)))}
 
 
+KSW_CLASS_NAMES = {0: "ksw_dp_kernel<4,...>", 4: "ksw_dp_kernel<8,...>", 8: "ksw_dp_kernel<16,...>", 12: "ksw_multi_kernel", 13: "ksw_block_kernel<7,8192>",
+                   14: "ksw_block_kernel<7,0>", 15: "ksw_generic_kernel"}
+
+
+def ksw_class_name(k):
+    if k >= 12:
+        return KSW_CLASS_NAMES[k]
+    return KSW_CLASS_NAMES[k & ~3].replace("...", "%s,%s" % ("true" if k >> 1 & 1 else "false", "true" if k & 1 else "false"))
+
+
+def make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1):
+    """The JSON line (without cpu_baseline). ks0/ks1: Mapper.kernel_stats() before/after the timed region."""
+    value = total_bases / elapsed / 1e9
+    # dominant kernel = the ksw class with the largest summed launch time in the timed region (HIP events on its stream)
+    cls = {k: (ks1[k][0] - ks0[k][0], ks1[k][1] - ks0[k][1], ks1[k][2] - ks0[k][2]) for k in ks1}
+    dom = max(cls, key=lambda k: cls[k][0])
+    d_ms, d_cells, d_launch = cls[dom]
+    kname = ksw_class_name(dom)
+    ach = d_cells / max(d_ms, 1e-9) / 1e6       # 1 B of traceback per DP cell: bytes per ms / 1e6 = GB/s
+    all_ms = sum(v[0] for v in cls.values())
+    all_cells = sum(v[1] for v in cls.values())
+    classes = {ksw_class_name(k): {"ms": round(v[0], 3), "cells": v[1], "launches": v[2]} for k, v in cls.items() if v[2] > 0}
+    # HBM traffic per DP cell of each kernel, measured in separate rocprofv3 --pmc passes (tools/pmc_ratio.py -> profiles/)
+    traffic = None
+    pmc = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_bytes_per_cell.json")) as f:
+            pmc = json.load(f)
+        if kname in pmc["bytes_per_cell"]:
+            traffic = pmc["bytes_per_cell"][kname] * d_cells / max(1, d_launch)
+    except Exception:  # noqa: BLE001
+        pmc = None
+    return {
+        "metric": "mapped Gbp/s", "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int8", "data": "synthetic",
+        "config": {"workload": "%d x %d bp ONT-profile reads per step per GPU vs %.0f Mb synthetic reference (10%% repeats), -W repetitive_k15.txt -x map-ont, CIGAR on"
+                               % (args.reads_per_step, args.read_len, args.ref_mb),
+                   "reads_per_step_per_gpu": args.reads_per_step, "read_len": args.read_len, "ref_mb": args.ref_mb, "host_threads": n_threads,
+                   "reads_per_s": total_bases / args.read_len / elapsed, "hits": hits, "parallelism": "reads sharded over %d rank(s), index broadcast" % world},
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
+                     "traffic_source": (pmc or {}).get("source") if traffic is not None else None, "classes": classes,
+                     "kernel": kname, "algorithmic_bytes": "1 B traceback per DP cell (sequence bytes are < 1 %)",
+                     "launches": d_launch, "avg_launch_ms": d_ms / max(1, d_launch), "cells_per_launch": d_cells / max(1, d_launch),
+                     "gcups_dominant": d_cells / max(d_ms, 1e-9) / 1e6, "gcups_all_ksw_classes": all_cells / max(all_ms, 1e-9) / 1e6,
+                     "note": "int8 DP is VALU-issue bound (about 33 lane-ops per cell), not HBM bound; launch durations include overlap with other streams"},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,7 +146,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("WM_BENCH_FORCE_DIST"):     # (the env switch lets a 1-GPU box exercise the RCCL code path)
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -112,7 +161,7 @@ def main():
         ref, fa, kf = make_workload(args.ref_mb, tmp)
         idx = gpu.Index(fa, kf, k=15, w=50, n_threads=min(64, n_cores))
         log("index: %d minimizers (%.1fs)" % (idx.n_minimizers, time.time() - t0))
-    if world > 1:
+    if dist is not None:
         dev = torch.device("cuda", local)
         idx = wmdist.broadcast_index(idx if rank == 0 else None, rank, dist, dev)      # RCCL over xGMI, one broadcast per flat array
         # every rank regenerates the (seeded) reference only to draw its reads from it
@@ -161,47 +210,7 @@ def main():
         total_bases = float(bases)
 
     if rank == 0:
-        value = total_bases / elapsed / 1e9
-        # dominant kernel = the ksw class with the largest summed launch time in the timed region (HIP events on its stream)
-        cls = {k: (ks1[k][0] - ks0[k][0], ks1[k][1] - ks0[k][1], ks1[k][2] - ks0[k][2]) for k in ks1}
-        dom = max(cls, key=lambda k: cls[k][0])
-        d_ms, d_cells, d_launch = cls[dom]
-        names = {0: "ksw_dp_kernel<4,...>", 4: "ksw_dp_kernel<8,...>", 8: "ksw_dp_kernel<16,...>", 12: "ksw_block_kernel<3,4096>", 13: "ksw_block_kernel<7,8192>", 14: "ksw_block_kernel<7,0>", 15: "ksw_generic_kernel"}
-        kname = names[dom & ~3] if dom < 12 else names[dom]
-        if dom < 12:
-            kname = class_name(dom)
-        ach = d_cells / max(d_ms, 1e-9) / 1e6       # 1 B of traceback per DP cell: bytes per ms / 1e6 = GB/s
-        all_ms = sum(v[0] for v in cls.values()); all_cells = sum(v[1] for v in cls.values())
-
-        def class_name(k):
-            if k >= 12:
-                return names[k]
-            return names[k & ~3].replace("...", "%s,%s" % ("true" if k >> 1 & 1 else "false", "true" if k & 1 else "false"))
-        classes = {class_name(k): {"ms": round(v[0], 3), "cells": v[1], "launches": v[2]} for k, v in cls.items() if v[2] > 0}
-        # HBM traffic per DP cell of each kernel, measured in separate rocprofv3 --pmc passes (tools/pmc_ratio.py → profiles/)
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_bytes_per_cell.json")) as f:
-                pmc = json.load(f)
-            if class_name(dom) in pmc["bytes_per_cell"]:
-                traffic = pmc["bytes_per_cell"][class_name(dom)] * d_cells / max(1, d_launch)
-        except Exception:  # noqa: BLE001
-            pmc = None
-        out = {
-            "metric": "mapped Gbp/s", "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int8", "data": "synthetic",
-            "config": {"workload": "%d x %d bp ONT-profile reads per step per GPU vs %.0f Mb synthetic reference (10%% repeats), -W repetitive_k15.txt -x map-ont, CIGAR on"
-                                   % (args.reads_per_step, args.read_len, args.ref_mb),
-                       "reads_per_step_per_gpu": args.reads_per_step, "read_len": args.read_len, "ref_mb": args.ref_mb, "host_threads": n_threads,
-                       "reads_per_s": total_bases / args.read_len / elapsed, "hits": hits, "parallelism": "reads sharded over %d rank(s), index broadcast" % world},
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
-                         "traffic_source": (pmc or {}).get("source") if traffic is not None else None, "classes": classes,
-                         "kernel": kname, "algorithmic_bytes": "1 B traceback per DP cell (sequence bytes are < 1 %)",
-                         "launches": d_launch, "avg_launch_ms": d_ms / max(1, d_launch), "cells_per_launch": d_cells / max(1, d_launch),
-                         "gcups_dominant": d_cells / max(d_ms, 1e-9) / 1e6, "gcups_all_ksw_classes": all_cells / max(all_ms, 1e-9) / 1e6,
-                         "note": "int8 DP is VALU-issue bound (about 33 lane-ops per cell), not HBM bound; launch durations include overlap with other streams"},
-        }
+        out = make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1)
         if world == 1 and args.cpu_sample > 0:
             sample = [s for _, ss in batches[args.warmup:] for s in ss][:args.cpu_sample]
             try:

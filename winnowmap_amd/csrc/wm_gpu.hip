@@ -84,6 +84,28 @@ __global__ __launch_bounds__(64 * WM_KSW_BLK_NWV) void ksw_block_kernel(wm_ksw_s
 		wmk::ksw_dp_block<WM_KSW_BLK_NWV, K, GLOBAL>(sc, jb, seqs + jb.q_off, seqs + jb.t_off, tb, W0, W1, Hm, wn, pub, res + j);
 }
 
+// BLOCK class: 16 waves per alignment, state in registers (ksw_dp_multi<4,16>); dynamic LDS = exchange areas, then the staged
+// sequences (if they fit in seq_cap bytes)
+__global__ __launch_bounds__(64 * WM_KSW_BLK_NWV) void ksw_multi_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
+                                                                         const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res, int seq_cap)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	typedef wmk::ksw_multi_lds<WM_KSW_MULTI_B, WM_KSW_BLK_NWV> L;
+	int *lds = (int*)smem;
+	uint8_t *sq = (uint8_t*)(lds + L::INTS);
+	const int j = order[blockIdx.x];
+	const wm_ksw_djob_t jb = jobs[j];
+	const int qpad = (jb.qlen + 15) & ~15;
+	if (qpad + jb.tlen <= seq_cap) {
+		uint8_t *st = sq + qpad;
+		for (int i = threadIdx.x; i < jb.qlen; i += blockDim.x) sq[i] = seqs[jb.q_off + i];
+		for (int i = threadIdx.x; i < jb.tlen; i += blockDim.x) st[i] = seqs[jb.t_off + i];
+		__syncthreads();
+		wmk::ksw_dp_multi<WM_KSW_MULTI_B, WM_KSW_BLK_NWV, true, true>(sc, jb, sq, st, tb, lds, res + j);
+	} else
+		wmk::ksw_dp_multi<WM_KSW_MULTI_B, WM_KSW_BLK_NWV, true, true>(sc, jb, seqs + jb.q_off, seqs + jb.t_off, tb, lds, res + j);
+}
+
 // one thread per alignment: walk the traceback, write run-length ops (backtrack order) into the job's slot
 __global__ __launch_bounds__(64) void ksw_backtrack_kernel(int n, const wm_ksw_djob_t *__restrict__ jobs, const uint8_t *__restrict__ tb,
                                                             wm_ksw_dres_t *__restrict__ res, uint32_t *__restrict__ cig_scratch, int *__restrict__ err)
@@ -410,9 +432,10 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		if (k == WM_KSW_BLOCK || k == WM_KSW_BLOCK2 || k == WM_KSW_BLOCK3) {
 			const size_t fixed = (size_t)WM_KSW_BLK_PUB * 4;
 			if (k == WM_KSW_BLOCK) {
-				const size_t lds = (size_t)WM_KSW_BLK_WN * 12 + fixed + WM_KSW_BLK_SEQ_LDS;
-				HIPCHK(hipFuncSetAttribute((const void*)ksw_block_kernel<WM_KSW_BLK_K, WM_KSW_BLK_WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-				hipLaunchKernelGGL((ksw_block_kernel<WM_KSW_BLK_K, WM_KSW_BLK_WN>), dim3(nk), dim3(64 * WM_KSW_BLK_NWV), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, (int)WM_KSW_BLK_SEQ_LDS, (int*)0, (const uint64_t*)0);
+				const int seq_cap = 64 * 1024;
+				const size_t lds = (size_t)wmk::ksw_multi_lds<WM_KSW_MULTI_B, WM_KSW_BLK_NWV>::INTS * 4 + seq_cap;
+				HIPCHK(hipFuncSetAttribute((const void*)ksw_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+				hipLaunchKernelGGL(ksw_multi_kernel, dim3(nk), dim3(64 * WM_KSW_BLK_NWV), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, seq_cap);
 			} else if (k == WM_KSW_BLOCK2) {
 				const size_t lds = (size_t)WM_KSW_BLK2_WN * 12 + fixed + WM_KSW_BLK2_SEQ_LDS;
 				HIPCHK(hipFuncSetAttribute((const void*)ksw_block_kernel<WM_KSW_BLK2_K, WM_KSW_BLK2_WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
