@@ -19,6 +19,15 @@ template <int B> static void run_dp(int clip, int hasn, const wm_ksw_score_t &sc
 	else wmk::ksw_dp_wave<B, false, false>(sc, jb, seqs, tb, res);
 }
 
+template <int B> static void run_dp_striped(int clip, int hasn, const wm_ksw_score_t &sc, const wm_ksw_djob_t &jb, const uint8_t *seqs, uint8_t *tb, wm_ksw_dres_t *res)
+{
+	simt::exec_mask() = ~0ull;
+	if (clip && hasn) wmk::ksw_dp_striped<B, true, true>(sc, jb, seqs, tb, res);
+	else if (clip) wmk::ksw_dp_striped<B, true, false>(sc, jb, seqs, tb, res);
+	else if (hasn) wmk::ksw_dp_striped<B, false, true>(sc, jb, seqs, tb, res);
+	else wmk::ksw_dp_striped<B, false, false>(sc, jb, seqs, tb, res);
+}
+
 extern "C" {
 
 // force_klass < 0: choose like the product host; otherwise use that class (to exercise CLIP/HASN variants on any input)
@@ -35,7 +44,9 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 	wm_ksw_djob_t jb;
 	memset(&jb, 0, sizeof(jb));
 	jb.q_off = 0; jb.t_off = qlen; jb.qlen = qlen; jb.tlen = tlen; jb.w = w; jb.zdrop = zdrop; jb.end_bonus = end_bonus; jb.flag = flag;
-	bool emu_blk3_small = false, emu_blk_lds = false;
+	bool emu_blk3_small = false, emu_blk_lds = false, emu_blocked = false;
+	if (force_klass >= 200 && force_klass < 212) { emu_blocked = true; force_klass -= 200; }   // 200+k: the blocked-layout register kernel of class k
+	if (force_klass == -2) { emu_blocked = true; force_klass = -1; }
 	if (force_klass == 112) { emu_blk_lds = true; force_klass = WM_KSW_BLOCK; }
 	if (force_klass == 114) { emu_blk3_small = true; force_klass = WM_KSW_BLOCK3; }
 	int n_col, klass = wm_ksw_classify(qlen, tlen, w, wm_ksw_has_n(query, qlen) | wm_ksw_has_n(target, tlen), &n_col);
@@ -80,10 +91,14 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 		std::vector<int> Hm(T + 16);
 		simt::exec_mask() = ~0ull;
 		wmk::ksw_dp_generic<true>(sc, jb, seqs.data(), tb.data(), mem.data(), Hm.data(), &res);
-	} else switch (klass & ~3) {
+	} else if (emu_blocked) switch (klass & ~3) {
 	case WM_KSW_B4: run_dp<4>(clip, hasn, sc, jb, seqs.data(), tb.data(), &res); break;
 	case WM_KSW_B8: run_dp<8>(clip, hasn, sc, jb, seqs.data(), tb.data(), &res); break;
 	default: run_dp<16>(clip, hasn, sc, jb, seqs.data(), tb.data(), &res); break;
+	} else switch (klass & ~3) {
+	case WM_KSW_B4: run_dp_striped<4>(clip, hasn, sc, jb, seqs.data(), tb.data(), &res); break;
+	case WM_KSW_B8: run_dp_striped<8>(clip, hasn, sc, jb, seqs.data(), tb.data(), &res); break;
+	default: run_dp_striped<16>(clip, hasn, sc, jb, seqs.data(), tb.data(), &res); break;
 	}
 	int n = 0;
 	if (res.bt_i >= 0) {

@@ -116,6 +116,7 @@ template <class T> V<T> shr1(const V<T> &x, T fill) { V<T> r; r.v[0] = fill; for
 template <class T> V<T> shr1(const V<T> &x, const V<T> &fill) { V<T> r; r.v[0] = fill.v[0]; for (int i = 1; i < WAVE; ++i) r.v[i] = x.v[i - 1]; return r; }
 template <class T> V<T> shift_down(const V<T> &x, int k, T fill) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = i + k < WAVE ? x.v[i + k] : fill; return r; }
 template <class T> V<T> shift_down(const V<T> &x, int k, const V<T> &fill) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = i + k < WAVE ? x.v[i + k] : fill.v[i]; return r; }
+template <class T> V<T> rot_down(const V<T> &x, int k) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = x.v[(i + k) & (WAVE - 1)]; return r; }
 template <class T> V<T> shr_n(const V<T> &x, int o) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = i >= o ? x.v[i - o] : x.v[i]; return r; }
 template <class T> T readlane(const V<T> &x, int l) { WM_EMU_ASSERT(l >= 0 && l < WAVE); return x.v[l]; }
 inline int readlane(int x, int) { return x; }
@@ -127,6 +128,7 @@ inline bool any(const vbool &c) { return ballot(c) != 0; }
 inline bool any(bool c) { return c && exec_mask(); }
 inline V<long long> wave_max_i64(const V<long long> &k) { WM_EMU_ASSERT(exec_mask() == ~0ull); long long m = k.v[0]; for (int i = 1; i < WAVE; ++i) if (k.v[i] > m) m = k.v[i]; return V<long long>(m); }
 inline V<int> wave_scan_max(const V<int> &k) { WM_EMU_ASSERT(exec_mask() == ~0ull); V<int> r = k; for (int i = 1; i < WAVE; ++i) r.v[i] = r.v[i - 1] > k.v[i] ? r.v[i - 1] : k.v[i]; return r; }
+inline int wave_max_i32(const V<int> &k) { WM_EMU_ASSERT(exec_mask() == ~0ull); int m = k.v[0]; for (int i = 1; i < WAVE; ++i) if (k.v[i] > m) m = k.v[i]; return m; }
 inline V<int> wave_scan_min(const V<int> &k) { WM_EMU_ASSERT(exec_mask() == ~0ull); V<int> r = k; for (int i = 1; i < WAVE; ++i) r.v[i] = r.v[i - 1] < k.v[i] ? r.v[i - 1] : k.v[i]; return r; }
 inline V<int> wave_scan_add(const V<int> &k) { WM_EMU_ASSERT(exec_mask() == ~0ull); V<int> r = k; for (int i = 1; i < WAVE; ++i) r.v[i] = r.v[i - 1] + k.v[i]; return r; }
 inline V<int> wave_sum_i32(const V<int> &k) { WM_EMU_ASSERT(exec_mask() == ~0ull); int s = 0; for (int i = 0; i < WAVE; ++i) s += k.v[i]; return V<int>(s); }

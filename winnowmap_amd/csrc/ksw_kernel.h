@@ -528,6 +528,275 @@ WM_DEV void ksw_cell(const ksw_cell_cst_t &c, const V<int> os, const V<int> x1, 
 }
 
 // ------------------------------------------------------------------------------------------------------
+// ksw_dp_striped: the register-resident machine with a STRIPED lane layout — thread j holds lanes base + 64*i + j
+// (i = 0..B-1, "chunk" i = 64 consecutive lanes). A row only executes the chunks that intersect the hull, so the
+// work follows the hull width (which ramps up and down along an alignment) instead of the window capacity 64*B;
+// chunks are processed from the top one down, so a chunk still sees the previous-row values of the chunk below
+// (lane 63 of chunk i-1 is the left neighbour of lane 0 of chunk i; inside a chunk the neighbour is one DPP shift).
+// The window re-base (hull start +16 lanes) rotates every register by 16 threads and carries the low 16 threads of
+// chunk i+1 into chunk i. Packed characters: byte k of word w belongs to chunk 4w+k.
+// The exact row maximum is found as a 32-bit wave maximum followed by a ballot of the lanes that reach it; the
+// reference's SIMD tie rule (src/ksw2_extd2_sse.c:315-358) is only evaluated when more than one lane ties.
+// ------------------------------------------------------------------------------------------------------
+template <int B> WM_DEV int get_lane_striped(const V<int> (&a)[B], int base, int t)
+{
+	const int o = t - base, jr = o & 63, ir = o >> 6;
+	WM_EMU_ASSERT(o >= 0 && o < 64 * B);
+	int r = 0;
+#pragma unroll
+	for (int i = 0; i < B; ++i)
+		if (ir == i) r = readlane(a[i], jr);
+	return r;
+}
+
+// rotate an array of chunk registers down by 16 lanes; the last chunk's top 16 threads receive `fresh`
+template <int B> WM_DEV void rebase_striped(V<int> (&a)[B], const V<int> fresh, const vbool low48)
+{
+	V<int> cur = rot_down(a[0], 16);
+#pragma unroll
+	for (int i = 0; i < B; ++i) {
+		const V<int> nxt = i + 1 < B ? rot_down(a[i + 1 < B ? i + 1 : i], 16) : fresh;
+		a[i] = sel(low48, cur, nxt);
+		cur = nxt;
+	}
+}
+
+template <int B, bool CLIP, bool HASN>
+WM_DEV void ksw_dp_striped(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const uint8_t *__restrict__ seqs,
+                           uint8_t *__restrict__ tb_arena, wm_ksw_dres_t *__restrict__ res)
+{
+	constexpr int NW = B / 4;
+	static_assert(B == 4 || B == 8 || B == 16, "B");
+	const int qlen = jb.qlen, tlen = jb.tlen, flag = jb.flag, zdrop = jb.zdrop;
+	const int w = jb.w < 0 ? (tlen > qlen ? tlen : qlen) : jb.w;
+	const bool approx = (flag & KSW_F_APPROX_MAX) != 0, right = (flag & KSW_F_RIGHT) != 0;
+	const uint8_t *query = seqs + jb.q_off, *target = seqs + jb.t_off;
+	uint8_t *tbp = tb_arena + jb.tb_off;
+	const int q = sc.q, e = sc.e, q2 = sc.q2, e2 = sc.e2, qe = q + e, qe2 = q2 + e2;
+	const int Q = tb8(q), Q2 = tb8(q2), QE = tb8(qe), QE2 = tb8(qe2);
+	const int tS = right ? 0 : 4, tA = right ? 1 : 3, tB = 2, tA2 = right ? 3 : 1, tB2 = right ? 4 : 0;
+	const int hA = right ? tA - 1 : tA, hB = right ? tB - 1 : tB, hA2 = right ? tA2 - 1 : tA2, hB2 = right ? tB2 - 1 : tB2;
+	const int MCH = tb8(sc.match), MCHt = MCH | tS, MISt = tb8(sc.mismatch) | tS;
+	const int NNt = tb8(sc.sc_ambi == 0 ? -e2 : sc.sc_ambi) | tS;
+	const ksw_cell_cst_t cc = { Q, Q2, QE, QE2, MCH, tA, tB, tA2, tB2, hA, hB, hA2, hB2 };
+	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+
+	const V<int> ln = lane();
+	const vbool low48 = ln < 48;
+	int base = 0;
+	V<int> U[B], Vv[B], X[B], Y[B], X2[B], Y2[B], S[B], H[B];
+	V<int> TP[NW], QP[NW];
+#pragma unroll
+	for (int i = 0; i < B; ++i) {
+		U[i] = tb8(-qe); Vv[i] = tb8(-qe); X[i] = tA; Y[i] = tB; X2[i] = tA2; Y2[i] = tB2;
+		S[i] = tS; H[i] = KSW_NEG_INF;
+	}
+#pragma unroll
+	for (int wd = 0; wd < NW; ++wd) {
+		V<int> pk = 0;
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			const V<int> t = ln + 64 * (wd * 4 + b);
+			V<int> c = 0;
+			WM_IF(t < tlen) c = cast<int>(gld(target, t)); WM_END
+			pk = pk | (c << (8 * b));
+		}
+		TP[wd] = pk; QP[wd] = 0;
+	}
+
+	int ez_max = 0, ez_zdropped = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1;
+	int ez_mte = KSW_NEG_INF, ez_mte_q = -1, ez_score = KSW_NEG_INF;
+	int H0 = 0, last_H0_t = 0, Hbelow = KSW_NEG_INF;
+	const int n_rows = qlen + tlen - 1;
+
+	for (int r = 0; r < n_rows; ++r) {
+		int st0 = 0, en0 = tlen - 1;
+		if (st0 < r - qlen + 1) st0 = r - qlen + 1;
+		if (en0 > r) en0 = r;
+		if (st0 < (r - w + 1) >> 1) st0 = (r - w + 1) >> 1;
+		if (en0 > (r + w) >> 1) en0 = (r + w) >> 1;
+		if (st0 > en0) { ez_zdropped = 1; break; }
+		const int st = st0 / 16 * 16, en = (en0 + 16) / 16 * 16 - 1;
+		const int sched = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
+
+		// previous-row values of lane st-1 for the first lane of the hull (src/ksw2_extd2_sse.c:141-151): constants unless the
+		// hull start just moved up, in which case lane st-1 is old chunk 0, thread 15
+		int f_x = tA, f_v = st == 0 ? tb8(sched) : tb8(-qe), f_x2 = tA2;
+		if (st > base) {
+			WM_EMU_ASSERT(st == base + 16);
+			f_x = readlane(X[0], 15); f_v = readlane(Vv[0], 15); f_x2 = readlane(X2[0], 15);
+			Hbelow = readlane(H[0], 15);
+			rebase_striped<B>(U, V<int>(tb8(-qe)), low48); rebase_striped<B>(Vv, V<int>(tb8(-qe)), low48);
+			rebase_striped<B>(X, V<int>(tA), low48); rebase_striped<B>(Y, V<int>(tB), low48);
+			rebase_striped<B>(X2, V<int>(tA2), low48); rebase_striped<B>(Y2, V<int>(tB2), low48);
+			if (CLIP) rebase_striped<B>(S, V<int>(tS), low48);
+			if (!approx) rebase_striped<B>(H, V<int>(KSW_NEG_INF), low48);
+			{   // packed characters: the fresh top 16 lanes take target codes from memory and the query codes of row r-1
+				const V<int> tnew = ln + (st + 64 * (B - 1));
+				V<int> c = 0, d = 0;
+				WM_IF(!low48)
+					WM_IF(tnew < tlen) c = cast<int>(gld(target, tnew)); WM_END
+					const V<int> qi = (r - 1) - tnew;
+					WM_IF(qi >= 0 && qi < qlen) d = cast<int>(gld(query, qi)); WM_END
+				WM_END
+				V<int> rt[NW], rq[NW];
+#pragma unroll
+				for (int wd = 0; wd < NW; ++wd) { rt[wd] = rot_down(TP[wd], 16); rq[wd] = rot_down(QP[wd], 16); }
+#pragma unroll
+				for (int wd = 0; wd < NW; ++wd) {
+					const V<int> nt = wd + 1 < NW ? rt[wd + 1 < NW ? wd + 1 : wd] : c, nq = wd + 1 < NW ? rq[wd + 1 < NW ? wd + 1 : wd] : d;
+					const V<int> ct = cast<int>((cast<unsigned>(rt[wd]) >> 8) | (cast<unsigned>(nt) << 24));
+					const V<int> cq = cast<int>((cast<unsigned>(rq[wd]) >> 8) | (cast<unsigned>(nq) << 24));
+					TP[wd] = sel(low48, rt[wd], ct); QP[wd] = sel(low48, rq[wd], cq);
+				}
+			}
+			base = st;
+		}
+
+		// ---- advance the query codes to row r: every lane takes the code of lane t-1 (one thread down; thread 0 of chunk i
+		//      takes thread 63 of chunk i-1; the first lane of the window takes query[r - base]) --------------------------------
+		{
+			const int qi0 = r - base;
+			const int newc = qi0 >= 0 && qi0 < qlen ? (int)gld(query, qi0) : 0;
+			int q63[NW];
+#pragma unroll
+			for (int wd = 0; wd < NW; ++wd) q63[wd] = readlane(QP[wd], 63);
+#pragma unroll
+			for (int wd = 0; wd < NW; ++wd) {
+				const int fill = (int)(((unsigned)q63[wd] << 8) | (wd ? (unsigned)q63[wd ? wd - 1 : 0] >> 24 : (unsigned)newc));
+				QP[wd] = shr1(QP[wd], fill);
+			}
+		}
+
+		// ---- first-column / first-row boundary of lane r (src/ksw2_extd2_sse.c:152-155) --------------------------------------------
+		if (en >= r) {
+			const int o = r - base, jr = o & 63, ir = o >> 6;
+			WM_EMU_ASSERT(o >= 0 && o < 64 * B);
+			WM_IF(ln == jr)
+#pragma unroll
+				for (int i = 0; i < B; ++i)
+					if (ir == i) { Y[i] = tB; Y2[i] = tB2; U[i] = tb8(sched); }
+			WM_END
+		}
+
+		const int cend = st0 + (en0 - st0) / 16 * 16 + 15;         // last lane of the rewritten score chunks (:158-173)
+		const int NI = ((en - base) >> 6) + 1;                       // chunks that intersect the hull
+		const int NS = CLIP ? ((((cend > en ? cend : en) - base) >> 6) + 1) : NI;
+		WM_EMU_ASSERT(NS <= B);
+		V<int> hmax = KSW_NEG_INF;
+		uint8_t *trow = tbp + (size_t)r * jb.n_col + (base - st);
+
+#pragma unroll
+		for (int i = B - 1; i >= 0; --i) {
+			if (i >= NS) continue;
+			const int c0 = base + 64 * i;
+			const V<int> t = ln + c0;
+			// match/mismatch scores; with CLIP the score row is persistent and only [st0, cend] is rewritten
+			const int wd = i >> 2, sh = 8 * (i & 3);
+			const V<int> tc = (TP[wd] >> sh) & 0xff, qc = (QP[wd] >> sh) & 0xff;
+			V<int> sv = sel(tc == qc, MCHt, MISt);
+			if (HASN) sv = sel((tc == 4) || (qc == 4), NNt, sv);
+			if (CLIP) { S[i] = sel(t >= st0 && t <= cend, sv, S[i]); sv = S[i]; }
+			if (i >= NI) continue;
+			// previous-row values of lane t-1
+			const V<int> x1 = shr1(X[i], i ? readlane(X[i ? i - 1 : 0], 63) : f_x);
+			const V<int> v1 = shr1(Vv[i], i ? readlane(Vv[i ? i - 1 : 0], 63) : f_v);
+			const V<int> x21 = shr1(X2[i], i ? readlane(X2[i ? i - 1 : 0], 63) : f_x2);
+			V<int> hl = KSW_NEG_INF;
+			if (!approx) hl = shr1(H[i], i ? readlane(H[i ? i - 1 : 0], 63) : Hbelow);
+			const V<int> ou = U[i];
+			WM_IF(t <= en)
+				V<int> nu, nv, nx, ny, nx2, ny2, p;
+				ksw_cell(cc, sv, x1, v1, x21, Y[i], ou, Y2[i], nu, nv, nx, ny, nx2, ny2, p);
+				U[i] = nu; Vv[i] = nv; X[i] = nx; Y[i] = ny; X2[i] = nx2; Y2[i] = ny2;
+				gst(trow, t - base, cast<uint8_t>(p));
+			WM_END
+			if (!approx && r > 0) {
+				if (c0 >= st0 && c0 + 63 < en0) {                 // chunk strictly inside the band: every lane is a plain update
+					H[i] = H[i] + (Vv[i] >> 24);
+					hmax = vmax(hmax, H[i]);
+				} else {
+					const V<int> v8 = Vv[i] >> 24, u8 = U[i] >> 24;
+					V<int> hn = H[i] + v8;
+					hn = sel(t == en0, en0 > 0 ? V<int>(hl + u8) : hn, hn);
+					const vbool inb = t >= st0 && t <= en0;
+					H[i] = sel(inb, hn, H[i]);
+					hmax = vmax(hmax, sel(inb, H[i], V<int>(KSW_NEG_INF)));
+				}
+			}
+		}
+
+		if (!approx) {   // ---- exact max: 32-bit wave maximum, then the lanes that reach it ---------------------------------
+			int max_H, max_t;
+			if (r > 0) {
+				max_H = wave_max_i32(hmax);
+				const int en1 = st0 + (en0 - st0) / 4 * 4;
+				int best_pri = -1;
+				max_t = en0;
+#pragma unroll
+				for (int i = 0; i < B; ++i) {
+					if (i >= NI) continue;
+					const int c0 = base + 64 * i;
+					if (c0 > en0 || c0 + 63 < st0) continue;
+					const int lo = st0 > c0 ? st0 - c0 : 0, hi = en0 - c0 < 63 ? en0 - c0 : 63;
+					const uint64_t band = (hi == 63 ? ~(uint64_t)0 : (((uint64_t)1 << (hi + 1)) - 1)) & ~(((uint64_t)1 << lo) - 1);
+					uint64_t m = ballot(H[i] == max_H) & band;
+					while (m) {                                   // priority on ties: en0, then residue groups 0..3 of [st0,en1), then the tail
+						const int tt = c0 + __builtin_ctzll(m);
+						m &= m - 1;
+						const int grp = tt == en0 ? 5 : tt < en1 ? 4 - ((tt - st0) & 3) : 0;
+						const int pri = (grp << 20) | (0xfffff - tt);
+						if (pri > best_pri) best_pri = pri, max_t = tt;
+					}
+				}
+			} else {
+				WM_IF(ln == 0) H[0] = (Vv[0] >> 24) - qe; WM_END
+				max_H = readlane(H[0], 0); max_t = 0;
+			}
+			if (en0 == tlen - 1) { const int h = get_lane_striped<B>(H, base, en0); if (h > ez_mte) ez_mte = h, ez_mte_q = r - en; }
+			if (r - st0 == qlen - 1) { const int h = get_lane_striped<B>(H, base, st0); if (h > ez_mqe) ez_mqe = h, ez_mqe_t = st0; }
+			if (max_H > ez_max) {
+				ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
+			} else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
+				const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+				if (zdrop >= 0 && ez_max - max_H > zdrop + l * e2) { ez_zdropped = 1; break; }
+			}
+			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = get_lane_striped<B>(H, base, tlen - 1);
+		} else {        // ---- approximate max: follow one diagonal-ish track (:359-375) ----------------------------------
+			if (r > 0) {
+				const bool in0 = last_H0_t >= st0 && last_H0_t <= en0, in1 = last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0;
+				if (in0 && in1) {
+					const int d0 = get_lane_striped<B>(Vv, base, last_H0_t) >> 24, d1 = get_lane_striped<B>(U, base, last_H0_t + 1) >> 24;
+					if (d0 > d1) H0 += d0;
+					else H0 += d1, ++last_H0_t;
+				} else if (in0) {
+					H0 += get_lane_striped<B>(Vv, base, last_H0_t) >> 24;
+				} else {
+					++last_H0_t;
+					H0 += get_lane_striped<B>(U, base, last_H0_t) >> 24;
+				}
+			} else H0 = (readlane(Vv[0], 0) >> 24) - qe, last_H0_t = 0;
+			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = H0;
+		}
+	}
+
+	int bt_i = -1, bt_j = -1, reach_end = 0;
+	if (!ez_zdropped && !(flag & KSW_F_EXTZ_ONLY)) bt_i = tlen - 1, bt_j = qlen - 1;
+	else if (!ez_zdropped && (flag & KSW_F_EXTZ_ONLY) && ez_mqe + jb.end_bonus > ez_max) reach_end = 1, bt_i = ez_mqe_t, bt_j = qlen - 1;
+	else if (ez_max_t >= 0 && ez_max_q >= 0) bt_i = ez_max_t, bt_j = ez_max_q;
+	WM_IF(ln == 0)
+		wm_ksw_dres_t o;
+		o.max = ez_max; o.zdropped = ez_zdropped; o.max_q = ez_max_q; o.max_t = ez_max_t;
+		o.mqe = ez_mqe; o.mqe_t = ez_mqe_t; o.mte = ez_mte; o.mte_q = ez_mte_q;
+		o.score = ez_score; o.reach_end = reach_end; o.n_cigar = 0; o.bt_i = bt_i; o.bt_j = bt_j;
+		*res = o;
+	WM_END
+}
+
+
+// ------------------------------------------------------------------------------------------------------
 // ksw_dp_multi: the SAME register-resident machine as ksw_dp_wave, spread over NWV wavefronts of one workgroup: global
 // thread J = 64*wave + lane holds lanes base+B*J .. base+B*J+B-1, so the window is 64*NWV*B lanes (16 waves x 4 = 4096:
 // the stage-2 fills and whole-read extensions of map-ont / map-pb with w = 3001) and a row costs every SIMD only its

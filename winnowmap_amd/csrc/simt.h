@@ -67,6 +67,10 @@ WM_DEV int shift_down(int x, int k, int fill)
 	int y = __shfl_down(x, (unsigned)k, 64);
 	return lane() + k >= 64 ? fill : y;
 }
+// lane j receives lane (j+k) & 63 (uniform k): a rotation through the LDS crossbar (ds_bpermute, no memory)
+WM_DEV int rot_down(int x, int k) { return __shfl(x, (int)((threadIdx.x + (unsigned)k) & 63u), 64); }
+// wave-wide maximum (all lanes receive it)
+WM_DEV int wave_max_i32(int x) { return __builtin_amdgcn_readlane(wave_scan_max(x), 63); }
 // value of lane-o for a uniform o (lanes < o receive their own value; callers mask them)
 WM_DEV int shr_n(int x, int o) { return __shfl_up(x, (unsigned)o, 64); }
 WM_DEV int readlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }

@@ -44,6 +44,16 @@ __global__ __launch_bounds__(64) void ksw_dp_kernel(wm_ksw_score_t sc, const wm_
 	wmk::ksw_dp_wave<B, CLIP, HASN>(sc, jobs[j], seqs, tb, res + j);
 }
 
+// the same classes with the striped lane layout (work follows the hull width): the default
+template <int B, bool CLIP, bool HASN>
+__global__ __launch_bounds__(64) void ksw_dps_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs,
+                                                     const int *__restrict__ order, const uint8_t *__restrict__ seqs,
+                                                     uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res)
+{
+	const int j = order[blockIdx.x];
+	wmk::ksw_dp_striped<B, CLIP, HASN>(sc, jobs[j], seqs, tb, res + j);
+}
+
 // generic class: per-lane state in a global scratch slab (7*T int8 + T int32 per job), one wave per alignment
 __global__ __launch_bounds__(64) void ksw_generic_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
                                                           const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, uint8_t *scratch,
@@ -271,10 +281,18 @@ template <int B> static void launch_dp(int clip, int hasn, int n, hipStream_t s,
                                        const uint8_t *seqs, uint8_t *tb, wm_ksw_dres_t *res)
 {
 	dim3 g(n), b(64);
-	if (clip && hasn) hipLaunchKernelGGL((ksw_dp_kernel<B, true, true>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
-	else if (clip) hipLaunchKernelGGL((ksw_dp_kernel<B, true, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
-	else if (hasn) hipLaunchKernelGGL((ksw_dp_kernel<B, false, true>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
-	else hipLaunchKernelGGL((ksw_dp_kernel<B, false, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
+	static const bool blocked = getenv("WM_KSW_BLOCKED") != 0;        // A/B switch: the older blocked-layout kernel
+	if (blocked) {
+		if (clip && hasn) hipLaunchKernelGGL((ksw_dp_kernel<B, true, true>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
+		else if (clip) hipLaunchKernelGGL((ksw_dp_kernel<B, true, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
+		else if (hasn) hipLaunchKernelGGL((ksw_dp_kernel<B, false, true>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
+		else hipLaunchKernelGGL((ksw_dp_kernel<B, false, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
+		return;
+	}
+	if (clip && hasn) hipLaunchKernelGGL((ksw_dps_kernel<B, true, true>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
+	else if (clip) hipLaunchKernelGGL((ksw_dps_kernel<B, true, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
+	else if (hasn) hipLaunchKernelGGL((ksw_dps_kernel<B, false, true>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
+	else hipLaunchKernelGGL((ksw_dps_kernel<B, false, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
 }
 
 extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs, const wm_ksw_job_t *jobs,
