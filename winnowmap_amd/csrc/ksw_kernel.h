@@ -1042,41 +1042,50 @@ WM_DEV void ksw_dp_multi(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 				gst(trow, J * NW + wd, cast<uint32_t>(pk[wd]));
 		WM_END
 
-		if (!approx) {   // ---- exact max with the reference's SIMD tie rule; H of en0 / st0 published by their owners ------
-			V<long long> key = (long long)(-0x7fffffffffffffffLL - 1);
+		const int wbase = base + B * 64 * wv;                 // first lane of this wave
+		if (!approx) {   // ---- exact max: per-wave 32-bit maximum, tie rule only among the lanes that reach it -------------------
+			long long kk = -0x7fffffffffffffffLL - 1;
 			if (r > 0) {
 				const int en1 = st0 + (en0 - st0) / 4 * 4;
+				V<int> hmax = KSW_NEG_INF;
 #pragma unroll
 				for (int i = B - 1; i >= 0; --i) {
-					V<int> t = t0 + i, v8 = Vv[i] >> 24, u8 = U[i] >> 24;
-					V<int> hl = i ? H[i - 1] : HL;
+					const V<int> t = t0 + i, v8 = Vv[i] >> 24, u8 = U[i] >> 24;
+					const V<int> hl = i ? H[i - 1] : HL;
 					V<int> hn = H[i] + v8;
 					hn = sel(t == en0, en0 > 0 ? V<int>(hl + u8) : hn, hn);
-					H[i] = sel(t >= st0 && t <= en0, hn, H[i]);
-					V<int> grp = sel(t == en0, 5, sel(t < en1, 4 - ((t - st0) & 3), 0));
-					V<int> pri = (grp << 20) | (0xfffff - t);
-					V<long long> k = cast<long long>(H[i]) * 4294967296LL + cast<long long>(pri);
-					key = sel(t >= st0 && t <= en0 && k > key, k, key);
+					const vbool inb = t >= st0 && t <= en0;
+					H[i] = sel(inb, hn, H[i]);
+					hmax = vmax(hmax, sel(inb, H[i], V<int>(KSW_NEG_INF)));
+				}
+				const int hm = wave_max_i32(hmax);
+				if (hm > KSW_NEG_INF) {
+					int best_pri = -1;
+#pragma unroll
+					for (int i = 0; i < B; ++i) {
+						const V<int> t = t0 + i;
+						uint64_t m = ballot(t >= st0 && t <= en0 && H[i] == hm);
+						while (m) {                                   // priority on ties: en0, residue groups 0..3 of [st0,en1), then the tail
+							const int tt = wbase + B * __builtin_ctzll(m) + i;
+							m &= m - 1;
+							const int grp = tt == en0 ? 5 : tt < en1 ? 4 - ((tt - st0) & 3) : 0;
+							const int pri = (grp << 20) | (0xfffff - tt);
+							if (pri > best_pri) best_pri = pri;
+						}
+					}
+					if (best_pri >= 0) kk = (long long)hm * 4294967296LL + (long long)best_pri;
 				}
 			} else {
 				WM_IF(J == 0) H[0] = (Vv[0] >> 24) - qe; WM_END
-				V<long long> k = cast<long long>(H[0]) * 4294967296LL + (long long)((5 << 20) | 0xfffff);
-				key = sel(J == 0, k, key);
+				if (wv == 0) kk = (long long)readlane(H[0], 0) * 4294967296LL + (long long)((5 << 20) | 0xfffff);
 			}
-#pragma unroll
-			for (int i = 0; i < B; ++i) {
-				WM_IF(t0 + i == en0) gst(pubr, V<int>(2 * NWV + 0), H[i]); WM_END
-				WM_IF(t0 + i == st0) gst(pubr, V<int>(2 * NWV + 1), H[i]); WM_END
-			}
-			key = wave_max_i64(key);
-			const long long kk = uniform(key);
+			// H of lanes en0 / st0 for the mte / mqe bookkeeping: published by the wave that owns them
+			if (en0 >= wbase && en0 < wbase + 64 * B) { const int h = get_lane<B>(H, wbase, en0); WM_IF(ln == 0) gst(pubr, V<int>(2 * NWV + 0), V<int>(h)); WM_END }
+			if (st0 >= wbase && st0 < wbase + 64 * B) { const int h = get_lane<B>(H, wbase, st0); WM_IF(ln == 0) gst(pubr, V<int>(2 * NWV + 1), V<int>(h)); WM_END }
 			WM_IF(ln == 0) gst(pubr, V<int>(2 * wv), V<int>((int)(unsigned)(kk & 0xffffffffLL))); gst(pubr, V<int>(2 * wv + 1), V<int>((int)(kk >> 32))); WM_END
 		} else {         // ---- approximate max: the owners of lanes last_H0_t / last_H0_t+1 publish v / u ---------------------
-#pragma unroll
-			for (int i = 0; i < B; ++i) {
-				WM_IF(t0 + i == last_H0_t) gst(pubr, V<int>(2 * NWV + 2), Vv[i] >> 24); WM_END
-				WM_IF(t0 + i == last_H0_t + 1) gst(pubr, V<int>(2 * NWV + 3), U[i] >> 24); WM_END
-			}
+			if (last_H0_t >= wbase && last_H0_t < wbase + 64 * B) { const int d = get_lane<B>(Vv, wbase, last_H0_t) >> 24; WM_IF(ln == 0) gst(pubr, V<int>(2 * NWV + 2), V<int>(d)); WM_END }
+			if (last_H0_t + 1 >= wbase && last_H0_t + 1 < wbase + 64 * B) { const int d = get_lane<B>(U, wbase, last_H0_t + 1) >> 24; WM_IF(ln == 0) gst(pubr, V<int>(2 * NWV + 3), V<int>(d)); WM_END }
 		}
 		// the next row's cross-wave neighbour values
 		WM_IF(ln == 63)

@@ -9,7 +9,7 @@ enum {            // klass = B-index*4 + CLIP*2 + HASN  for the register kernels
 	WM_KSW_B4 = 0, WM_KSW_B8 = 4, WM_KSW_B16 = 8, WM_KSW_BLOCK = 12, WM_KSW_BLOCK2 = 13, WM_KSW_BLOCK3 = 14, WM_KSW_GENERIC = 15, WM_KSW_NCLASS = 16
 };
 // geometry of the block kernels (ksw_dp_block<NWV, K>): NWV waves x K tiles x 64 lanes per row, LDS window of WN lanes
-enum { WM_KSW_MULTI_B = 4,                                                // BLOCK: register-resident multi-wave kernel ksw_dp_multi<4, 16>: hulls up to 4080 lanes
+enum { WM_KSW_MULTI_B = 8, WM_KSW_MULTI_NWV = 8,                          // BLOCK: register-resident multi-wave kernel ksw_dp_multi<8, 8>: hulls up to 4080 lanes
        WM_KSW_BLK_NWV = 16, WM_KSW_BLK_K = 3, WM_KSW_BLK_WN = 4096,        // (LDS-state kernel at the same size: kept for tests)
        WM_KSW_BLK2_K = 7, WM_KSW_BLK2_WN = 8192 };                         // hulls up to 7168 lanes (unbanded fills across structural variants)
 // bytes of LDS left for the staged sequences next to the state window (160 KB per CU, one block per CU for these classes)
@@ -66,7 +66,7 @@ static inline int wm_ksw_classify(int qlen, int tlen, int w, int has_n, int *n_c
 	if (n_col <= 64 * 4 - 16) k = WM_KSW_B4;
 	else if (n_col <= 64 * 8 - 16) k = WM_KSW_B8;
 	else if (n_col <= 64 * 16 - 16) k = WM_KSW_B16;
-	else if (n_col + 16 <= 64 * WM_KSW_BLK_NWV * WM_KSW_MULTI_B) { *n_col_out = n_col; return WM_KSW_BLOCK; }
+	else if (n_col + 16 <= 64 * WM_KSW_MULTI_NWV * WM_KSW_MULTI_B) { *n_col_out = n_col; return WM_KSW_BLOCK; }
 	else if (n_col + 16 <= 64 * WM_KSW_BLK_NWV * WM_KSW_BLK2_K) { *n_col_out = n_col; return WM_KSW_BLOCK2; }
 	else if (n_col + 16 <= 64 * WM_KSW_BLK_NWV * WM_KSW_BLK2_K * WM_KSW_BLK_MAXC) { *n_col_out = n_col; return WM_KSW_BLOCK3; }
 	else { *n_col_out = n_col; return WM_KSW_GENERIC; }
