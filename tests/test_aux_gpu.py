@@ -126,3 +126,46 @@ def test_sketch_seed_chain_kernels(env):
             ou, obx, oby = W.o_chain_dp(a["x"], a["y"], max_dist_x=prm[0], min_dist_x=prm[1], max_dist_y=prm[2], bw=prm[3])
             g = alla[int(aoff2[i]):int(aoff2[i]) + nv[i]]
             assert np.array_equal(u[int(uoff[i]):int(uoff[i]) + nu[i]], ou) and np.array_equal(g["x"], obx) and np.array_equal(g["y"], oby), (i, prm)
+
+
+def test_chain_large_sparse_and_dense_anchor_sets(env):
+    """n > 1024: the one-wave kernel with a wrapping 1024-anchor window (sparse) and the multi-wave kernel (dense arrays)."""
+    ctx, idx, ref, bloom, L = env
+    rng = np.random.default_rng(17)
+    sets = []
+    # sparse: a long colinear chain with jitter, ~1 anchor per 40 bp, plus random noise anchors
+    n = 6000
+    xs = np.sort(rng.integers(0, 250000, n)).astype(np.uint64)
+    ys = (xs.astype(np.int64) + rng.integers(-30, 30, n)).clip(0, None).astype(np.uint64)
+    noise = rng.random(n) < 0.2
+    ys[noise] = rng.integers(0, 250000, int(noise.sum())).astype(np.uint64)
+    sets.append((xs, ys | np.uint64(15 << 32)))
+    # dense: a 171-bp tandem repeat: every query position hits every copy -> thousands of predecessors within max_dist_x
+    qpos = np.arange(40, 4000, 57)
+    rpos = np.arange(1000, 9000, 171)
+    X, Y = np.meshgrid(rpos, qpos)
+    xs = X.ravel().astype(np.uint64) + rng.integers(0, 3, X.size).astype(np.uint64)
+    ys = Y.ravel().astype(np.uint64)
+    o = np.argsort(xs, kind="stable")
+    sets.append((xs[o], ys[o] | np.uint64(15 << 32)))
+    PAR = np.dtype([("p", np.int32, 8), ("gs", np.float32)])
+    for prm in ((5000, 1000, 5000, 500), (16000, 1000, 16000, 2000)):
+        parts = []
+        for x, y in sets:
+            sx, sy = W.o_radix_sort_128x(x, y)
+            a = np.zeros(len(sx), M128)
+            a["x"], a["y"] = sx, sy
+            parts.append(a)
+        na2 = np.array([len(a) for a in parts], np.int32)
+        aoff2 = np.concatenate([[0], np.cumsum(na2)[:-1]]).astype(np.uint64)
+        alla = np.concatenate(parts)
+        par = np.zeros(len(parts), PAR)
+        par["p"] = [prm[0], prm[1], prm[2], prm[3], 25, 5000, 3, 40]
+        par["gs"] = 1.0
+        u = np.zeros(len(alla) + 1, np.uint64); uoff = np.zeros(len(parts), np.uint64)
+        nu = np.zeros(len(parts), np.int32); nv = np.zeros(len(parts), np.int32)
+        assert L.wm_chain_batch(ctx._h, len(parts), alla.ctypes.data, aoff2, na2, par.ctypes.data, u, uoff, nu, nv) == 0, L.wm_last_error()
+        for i, a in enumerate(parts):
+            ou, obx, oby = W.o_chain_dp(a["x"], a["y"], max_dist_x=prm[0], min_dist_x=prm[1], max_dist_y=prm[2], bw=prm[3])
+            g = alla[int(aoff2[i]):int(aoff2[i]) + nv[i]]
+            assert np.array_equal(u[int(uoff[i]):int(uoff[i]) + nu[i]], ou) and np.array_equal(g["x"], obx) and np.array_equal(g["y"], oby), (i, prm)

@@ -893,7 +893,25 @@ extern "C" int wm_chain_batch(wm_ctx_t *c, int n, wm128_t *a, const uint64_t *a_
 		jb[i].avg_qspan = n_a[i] > 0 ? wm::chain_avg_qspan(n_a[i], a + a_off[i]) : 0.f;
 		order[i] = (int)i;
 	});
-	std::sort(order.begin(), order.end(), [&](int x, int y) { return n_a[x] != n_a[y] ? n_a[x] > n_a[y] : x < y; });
+	// jobs larger than the small windows: DENSE if a sample of anchors has more than ~900 predecessors within max_dist_x (satellite
+	// arrays, no -W list) -> multi-wave kernel with the 4096-anchor window; otherwise one wave with a 1024-anchor window
+	std::vector<uint8_t> dense(n, 0);
+	wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
+		const int m = n_a[i];
+		if (m <= 1024) return;
+		const wm128_t *aa = a + a_off[i];
+		int64_t worst = 0;
+		for (int s = 1; s <= 32; ++s) {
+			const int64_t k = (int64_t)m * s / 33;
+			const uint64_t lim = aa[k].x > (uint64_t)par[i].max_dist_x ? aa[k].x - (uint64_t)par[i].max_dist_x : 0;
+			int64_t lo = 0, hi = k;                        // first anchor with x >= lim
+			while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (aa[mid].x < lim) lo = mid + 1; else hi = mid; }
+			if (k - lo > worst) worst = k - lo;
+		}
+		dense[i] = worst > 900;
+	});
+	auto klass_of = [&](int i) { return n_a[i] > 1024 ? (dense[i] ? 0 : 1) : n_a[i] > 256 ? 2 : 3; };
+	std::sort(order.begin(), order.end(), [&](int x, int y) { const int kx = klass_of(x), ky = klass_of(y); return kx != ky ? kx < ky : n_a[x] != n_a[y] ? n_a[x] > n_a[y] : x < y; });
 	wm_chain_job_t *d_jobs = (wm_chain_job_t*)arena_take(c, (size_t)n * sizeof(wm_chain_job_t));
 	int *d_order = (int*)arena_take(c, (size_t)n * 4 + 64);
 	wm128_t *d_a = (wm128_t*)arena_take(c, (tot + 1) * sizeof(wm128_t));
@@ -913,16 +931,14 @@ extern "C" int wm_chain_batch(wm_ctx_t *c, int n, wm128_t *a, const uint64_t *a_
 		static const int use_block = getenv("WM_CHAIN_BLOCK") ? atoi(getenv("WM_CHAIN_BLOCK")) : 1;
 		const int big_W = getenv("WM_CHAIN_TUNE") ? (getenv("WM_CHAIN_BIG_W") ? atoi(getenv("WM_CHAIN_BIG_W")) : 4096) : big_w;
 		const int blk = getenv("WM_CHAIN_TUNE") ? (getenv("WM_CHAIN_BLOCK") ? atoi(getenv("WM_CHAIN_BLOCK")) : 1) : use_block;
-		const int caps[3] = { 4096, 1024, 256 };
+		(void)big_W; (void)blk;
 		int b = 0;
-		for (int k = 0; k < 3; ++k) {
-			const int lo = k < 2 ? caps[k + 1] : 0;          // class k holds n > lo (class 0 also takes every n > 4096: the window wraps)
+		for (int k = 0; k < 4; ++k) {                        // 0 dense (8 waves, W 4096) | 1 large sparse (1 wave, W 1024) | 2 n <= 1024 | 3 n <= 256
 			int e = b;
-			while (e < n && n_a[order[e]] > lo) ++e;
+			while (e < n && klass_of(order[e]) == k) ++e;
 			if (e > b) {
-				if (k == 0 && blk) hipLaunchKernelGGL(chain_kernel_block<NWV>, dim3(e - b), dim3(64 * NWV), (size_t)big_W * 28 + NWV * 69 * 4 + 64, c->stream, d_jobs, d_order + b, d_a, d_fpvt, big_W);
-				else if (k == 0) hipLaunchKernelGGL(chain_kernel, dim3(e - b), dim3(64), (size_t)big_W * 28, c->stream, d_jobs, d_order + b, d_a, d_fpvt, big_W);
-				else hipLaunchKernelGGL(chain_kernel, dim3(e - b), dim3(64), (size_t)caps[k] * 28, c->stream, d_jobs, d_order + b, d_a, d_fpvt, caps[k]);
+				if (k == 0) hipLaunchKernelGGL(chain_kernel_block<NWV>, dim3(e - b), dim3(64 * NWV), (size_t)4096 * 28 + NWV * 69 * 4 + 64, c->stream, d_jobs, d_order + b, d_a, d_fpvt, 4096);
+				else hipLaunchKernelGGL(chain_kernel, dim3(e - b), dim3(64), (size_t)(k == 3 ? 256 : 1024) * 28, c->stream, d_jobs, d_order + b, d_a, d_fpvt, k == 3 ? 256 : 1024);
 			}
 			b = e;
 		}
