@@ -14,11 +14,22 @@
 #include <chrono>
 #include <atomic>
 #include "host/wm_core.h"
-// large staging buffers: no value-initialisation (a std::vector would memset hundreds of MB per batch)
+// large staging buffers: no value-initialisation (a std::vector would memset hundreds of MB per batch). When a context is
+// given, the buffer comes from that context's PINNED host slab (LIFO bump allocation): device copies to/from pinned memory run
+// at full PCIe rate and truly asynchronously, pageable memory is bounced through the runtime's staging buffers.
+struct wm_ctx_s;
+static void *pin_take(wm_ctx_s *c, size_t bytes, size_t *mark);
+static void pin_release(wm_ctx_s *c, size_t mark);
 template <class T> struct UBuf {
-	T *p; size_t n;
-	explicit UBuf(size_t n_) : p((T*)malloc((n_ ? n_ : 1) * sizeof(T))), n(n_) { if (!p) abort(); }
-	~UBuf() { free(p); }
+	T *p; size_t n; wm_ctx_s *c; size_t mark; bool pinned;
+	explicit UBuf(size_t n_, wm_ctx_s *c_ = 0) : p(0), n(n_), c(c_), mark(0), pinned(false)
+	{
+		const size_t bytes = (n_ ? n_ : 1) * sizeof(T);
+		if (c) { p = (T*)pin_take(c, bytes, &mark); pinned = p != 0; }
+		if (!p) p = (T*)malloc(bytes);
+		if (!p) abort();
+	}
+	~UBuf() { if (pinned) pin_release(c, mark); else free(p); }
 	UBuf(const UBuf&) = delete; UBuf &operator=(const UBuf&) = delete;
 	T *data() { return p; } const T *data() const { return p; }
 	size_t size() const { return n; }
@@ -197,7 +208,24 @@ struct wm_ctx_s {
 	wm_sketch_params_t skp;
 	bool have_index, owns_index;
 	int host_threads;                           // threads the batched entry points may use for their host-side packing / sorting
+	uint8_t *pin; size_t pin_bytes, pin_used;   // pinned host slab for staging (allocated on first use)
 };
+
+static void *pin_take(wm_ctx_s *c, size_t bytes, size_t *mark)
+{
+	if (!c->pin) {
+		if (c->pin_bytes == (size_t)-1) return 0;                        // allocation failed before: stay pageable
+		const size_t want = (size_t)(getenv("WM_PINNED_MB") ? atoll(getenv("WM_PINNED_MB")) : 3072) << 20;
+		if (want == 0 || hipHostMalloc((void**)&c->pin, want, hipHostMallocDefault) != hipSuccess) { c->pin = 0; c->pin_bytes = (size_t)-1; (void)hipGetLastError(); return 0; }
+		c->pin_bytes = want; c->pin_used = 0;
+	}
+	const size_t off = (c->pin_used + 255) & ~(size_t)255;
+	if (off + bytes > c->pin_bytes) return 0;
+	*mark = c->pin_used;
+	c->pin_used = off + bytes;
+	return c->pin + off;
+}
+static void pin_release(wm_ctx_s *c, size_t mark) { c->pin_used = mark; }
 
 struct wm_ksw_dev_batch_s {
 	int n_jobs;
@@ -246,7 +274,7 @@ extern "C" int wm_ctx_create(int device, size_t arena_bytes, wm_ctx_t **out)
 	for (int i = 0; i < 5; ++i) HIPCHK(hipEventCreateWithFlags(&c->kev[i], hipEventDisableTiming));
 	for (int k = 0; k < WM_KSW_NCLASS; ++k) { HIPCHK(hipEventCreate(&c->cev[k][0])); HIPCHK(hipEventCreate(&c->cev[k][1])); c->k_ms[k] = 0; c->k_cells[k] = c->k_launches[k] = 0; }
 	for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
-	c->arena_used = 0; c->last_ms = 0; c->aux_ms = 0; c->host_threads = 1; c->have_index = false; c->owns_index = false; c->d_hkey = c->d_hval = c->d_P = 0; c->d_bloom = 0;
+	c->arena_used = 0; c->last_ms = 0; c->aux_ms = 0; c->host_threads = 1; c->pin = 0; c->pin_bytes = c->pin_used = 0; c->have_index = false; c->owns_index = false; c->d_hkey = c->d_hval = c->d_P = 0; c->d_bloom = 0;
 	*out = c;
 	return WM_OK;
 }
@@ -258,6 +286,7 @@ extern "C" void wm_ctx_destroy(wm_ctx_t *c)
 	hipStreamSynchronize(c->stream);
 	for (int i = 0; i < 4; ++i) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream);
+	if (c->pin) hipHostFree(c->pin);
 	for (int i = 0; i < 4; ++i) hipStreamDestroy(c->kstream[i]);
 	for (int i = 0; i < 5; ++i) hipEventDestroy(c->kev[i]);
 	for (int k = 0; k < WM_KSW_NCLASS; ++k) { hipEventDestroy(c->cev[k][0]); hipEventDestroy(c->cev[k][1]); }
@@ -779,7 +808,7 @@ extern "C" int wm_sketch_batch(wm_ctx_t *c, int n, const uint8_t *seqs, size_t s
 		hipLaunchKernelGGL(sketch_kernel, dim3(((int)jb.size() + 63) / 64), dim3(64), lds, c->stream, c->skp, d_jobs, (int)jb.size(), d_seqs, c->d_bloom, d_out, d_cnt);
 		HIPCHK(hipEventRecord(c->ev[1], c->stream));
 		std::vector<int> cnt(jb.size());
-		UBuf<wm128_t> tmp(tot + 1);
+		UBuf<wm128_t> tmp(tot + 1, c);
 		HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt, jb.size() * 4, hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(hipMemcpyAsync(tmp.data(), d_out, tot * sizeof(wm128_t), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(hipStreamSynchronize(c->stream));
@@ -811,7 +840,7 @@ extern "C" int wm_seed_batch(wm_ctx_t *c, int n, const wm128_t *mini, const uint
 	std::vector<int> todo(n);
 	for (int i = 0; i < n; ++i) todo[i] = i;
 	std::vector<int> want(n);
-	for (int i = 0; i < n; ++i) want[i] = n_mini[i] * 4 + 64;
+	for (int i = 0; i < n; ++i) want[i] = n_mini[i] * 2 + 32;
 	size_t used = 0;
 	float ms_total = 0;
 	uint64_t mini_total = 0;
@@ -843,7 +872,7 @@ extern "C" int wm_seed_batch(wm_ctx_t *c, int n, const wm128_t *mini, const uint
 		hipLaunchKernelGGL(seed_kernel, dim3((int)jb.size()), dim3(64), 0, c->stream, ix, d_jobs, d_mini, d_out, d_occ, d_occ_off, d_res);
 		HIPCHK(hipEventRecord(c->ev[1], c->stream));
 		std::vector<wm_seed_res_t> res(jb.size());
-		UBuf<wm128_t> tmp(tot + 1);
+		UBuf<wm128_t> tmp(tot + 1, c);
 		HIPCHK(hipMemcpyAsync(res.data(), d_res, jb.size() * sizeof(wm_seed_res_t), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(hipMemcpyAsync(tmp.data(), d_out, tot * sizeof(wm128_t), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(hipStreamSynchronize(c->stream));
@@ -945,7 +974,7 @@ extern "C" int wm_chain_batch(wm_ctx_t *c, int n, wm128_t *a, const uint64_t *a_
 	}
 	HIPCHK(hipEventRecord(c->ev[1], c->stream));
 	const double tt2 = trace ? now_ms() : 0;
-	UBuf<int> fpvt((tot + 1) * 4);
+	UBuf<int> fpvt((tot + 1) * 4, c);
 	HIPCHK(hipMemcpyAsync(fpvt.data(), d_fpvt, tot * 16, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	HIPCHK(hipGetLastError());
@@ -990,9 +1019,9 @@ struct GpuOps : wm::DeviceOps {
 		std::vector<int32_t> len(n), cnt(n);
 		size_t tot = 0;
 		for (int i = 0; i < n; ++i) { off[i] = tot; len[i] = reqs[i]->len; tot += reqs[i]->len; }
-		UBuf<uint8_t> seqs(tot + 1);
+		UBuf<uint8_t> seqs(tot + 1, c);
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { memcpy(seqs.data() + off[i], reqs[i]->seq, reqs[i]->len); });
-		UBuf<wm128_t> out(tot / 8 + (size_t)17 * n + 64);          // wm_sketch_batch tries len/8 + 16 slots per sequence first
+		UBuf<wm128_t> out(tot / 8 + (size_t)17 * n + 64, c);          // wm_sketch_batch tries len/8 + 16 slots per sequence first
 		const double ts = now_ms();
 		int rc = wm_sketch_batch(c, n, seqs.data(), tot, off.data(), len.data(), out.data(), out.size(), ooff.data(), cnt.data());
 		if (rc == WM_ENOMEM && strstr(g_err, "minimizer output pool")) {   // pathological density: redo with one slot per base
@@ -1017,7 +1046,7 @@ struct GpuOps : wm::DeviceOps {
 		std::vector<int32_t> nm(n), ql(n), na(n), rl(n);
 		size_t tot = 0;
 		for (int i = 0; i < n; ++i) { moff[i] = tot; nm[i] = reqs[i]->n_mini; ql[i] = reqs[i]->qlen; tot += reqs[i]->n_mini; }
-		UBuf<wm128_t> mini(tot + 1);
+		UBuf<wm128_t> mini(tot + 1, c);
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { memcpy(mini.data() + moff[i], reqs[i]->mini, (size_t)reqs[i]->n_mini * sizeof(wm128_t)); });
 		size_t cap = tot * 8 + 1024;
 		for (int attempt = 0; attempt < 6; ++attempt) {
@@ -1045,7 +1074,7 @@ struct GpuOps : wm::DeviceOps {
 			wm::ChainReq &r = *reqs[i];
 			par[i] = { r.max_dist_x, r.min_dist_x, r.max_dist_y, r.bw, r.max_skip, r.max_iter, r.min_cnt, r.min_sc, r.gap_scale };
 		}
-		UBuf<wm128_t> a(tot + 1);
+		UBuf<wm128_t> a(tot + 1, c);
 		UBuf<uint64_t> u(tot + 1);
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { memcpy(a.data() + aoff[i], reqs[i]->a.data(), reqs[i]->a.size() * sizeof(wm128_t)); });
 		const double ts = now_ms();
@@ -1072,13 +1101,13 @@ struct GpuOps : wm::DeviceOps {
 			cap += r.q.size() + r.t.size() + 2;
 		}
 		if (tot >= ((size_t)1 << 32)) { error = "ksw batch exceeds 4 GB of sequence"; return; }
-		UBuf<uint8_t> seqs(tot + 1);
+		UBuf<uint8_t> seqs(tot + 1, c);
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 			memcpy(seqs.data() + jobs[i].q_off, reqs[i]->q.data(), reqs[i]->q.size());
 			memcpy(seqs.data() + jobs[i].t_off, reqs[i]->t.data(), reqs[i]->t.size());
 		});
 		std::vector<wm_ksw_result_t> res(n);
-		UBuf<uint32_t> pool(cap);
+		UBuf<uint32_t> pool(cap, c);
 		size_t used = 0;
 		const double t1 = now_ms();
 		c->acc_cells = 0; c->t_prep = c->t_run = c->t_fetch = 0;
