@@ -80,7 +80,7 @@ def cpu_reference_baseline(fa, kf, reads, tmp, n_cores):
             "sample": "%d x 15 kb reads of the same workload, winnowmap_ref -t %d -W -ax map-ont, mapping phase %.2f s (index build %.1f s excluded)" % (len(reads), n_cores, t_map, float(m_idx.group(1)))}
 
 
-KSW_CLASS_NAMES = {0: "ksw_dp_kernel<4,...>", 4: "ksw_dp_kernel<8,...>", 8: "ksw_dp_kernel<16,...>", 12: "ksw_multi_kernel", 13: "ksw_block_kernel<7,8192>",
+KSW_CLASS_NAMES = {0: "ksw_dp_kernel<4,...>", 4: "ksw_dp_kernel<8,...>", 8: "ksw_dp_kernel<16,...>", 12: "ksw_multi_kernel<8>", 13: "ksw_multi_kernel<16>",
                    14: "ksw_block_kernel<7,0>", 15: "ksw_generic_kernel"}
 
 
@@ -152,7 +152,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
     n_cores = os.cpu_count() or 1
-    n_threads = args.threads or max(1, min(64, n_cores // max(1, world)))
+    # host threads per rank: more than ~48 per process LOSES throughput on the 2 x 128-thread host (measured), 24-48 are equivalent
+    n_threads = args.threads or max(1, min(32, int(0.75 * n_cores / max(1, world))))
     tmp = tempfile.mkdtemp(prefix="wmbench_")
 
     # ---- reference + index: rank 0 builds, RCCL broadcasts the flat arrays ----

@@ -67,7 +67,7 @@ static inline int wm_ksw_classify(int qlen, int tlen, int w, int has_n, int *n_c
 	else if (n_col <= 64 * 8 - 16) k = WM_KSW_B8;
 	else if (n_col <= 64 * 16 - 16) k = WM_KSW_B16;
 	else if (n_col + 16 <= 64 * WM_KSW_MULTI_NWV * WM_KSW_MULTI_B) { *n_col_out = n_col; return WM_KSW_BLOCK; }
-	else if (n_col + 16 <= 64 * WM_KSW_BLK_NWV * WM_KSW_BLK2_K) { *n_col_out = n_col; return WM_KSW_BLOCK2; }
+	else if (n_col + 16 <= 64 * 2 * WM_KSW_MULTI_NWV * WM_KSW_MULTI_B) { *n_col_out = n_col; return WM_KSW_BLOCK2; }   // ksw_dp_multi<8,16>: 8192 lanes
 	else if (n_col + 16 <= 64 * WM_KSW_BLK_NWV * WM_KSW_BLK2_K * WM_KSW_BLK_MAXC) { *n_col_out = n_col; return WM_KSW_BLOCK3; }
 	else { *n_col_out = n_col; return WM_KSW_GENERIC; }
 	*n_col_out = n_col;

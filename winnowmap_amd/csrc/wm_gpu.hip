@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64) void ksw_dp_kernel(wm_ksw_score_t sc, const wm_
 
 // the same classes with the striped lane layout (work follows the hull width): the default
 template <int B, bool CLIP, bool HASN>
-__global__ __launch_bounds__(64) void ksw_dps_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(B == 16 ? 3 : 4))) void ksw_dps_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs,
                                                      const int *__restrict__ order, const uint8_t *__restrict__ seqs,
                                                      uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res)
 {
@@ -105,13 +105,14 @@ __global__ __launch_bounds__(64 * WM_KSW_BLK_NWV) void ksw_block_kernel(wm_ksw_s
 		wmk::ksw_dp_block<WM_KSW_BLK_NWV, K, GLOBAL>(sc, jb, seqs + jb.q_off, seqs + jb.t_off, tb, W0, W1, Hm, wn, pub, res + j);
 }
 
-// BLOCK class: 8 waves per alignment, state in registers (ksw_dp_multi<8,8>); dynamic LDS = exchange areas, then the staged
+// BLOCK / BLOCK2 classes: 8 / 16 waves per alignment, state in registers (ksw_dp_multi<8,NWV>: 4096 / 8192 lanes); dynamic LDS = exchange areas, then the staged
 // sequences (if they fit in seq_cap bytes)
-__global__ __launch_bounds__(64 * WM_KSW_MULTI_NWV) void ksw_multi_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void ksw_multi_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
                                                                          const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res, int seq_cap)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	typedef wmk::ksw_multi_lds<WM_KSW_MULTI_B, WM_KSW_MULTI_NWV> L;
+	typedef wmk::ksw_multi_lds<WM_KSW_MULTI_B, NWV> L;
 	int *lds = (int*)smem;
 	uint8_t *sq = (uint8_t*)(lds + L::INTS);
 	const int j = order[blockIdx.x];
@@ -122,9 +123,9 @@ __global__ __launch_bounds__(64 * WM_KSW_MULTI_NWV) void ksw_multi_kernel(wm_ksw
 		for (int i = threadIdx.x; i < jb.qlen; i += blockDim.x) sq[i] = seqs[jb.q_off + i];
 		for (int i = threadIdx.x; i < jb.tlen; i += blockDim.x) st[i] = seqs[jb.t_off + i];
 		__syncthreads();
-		wmk::ksw_dp_multi<WM_KSW_MULTI_B, WM_KSW_MULTI_NWV, true, true>(sc, jb, sq, st, tb, lds, res + j);
+		wmk::ksw_dp_multi<WM_KSW_MULTI_B, NWV, true, true>(sc, jb, sq, st, tb, lds, res + j);
 	} else
-		wmk::ksw_dp_multi<WM_KSW_MULTI_B, WM_KSW_MULTI_NWV, true, true>(sc, jb, seqs + jb.q_off, seqs + jb.t_off, tb, lds, res + j);
+		wmk::ksw_dp_multi<WM_KSW_MULTI_B, NWV, true, true>(sc, jb, seqs + jb.q_off, seqs + jb.t_off, tb, lds, res + j);
 }
 
 // one thread per alignment: walk the traceback, write run-length ops (backtrack order) into the job's slot
@@ -481,12 +482,13 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 			if (k == WM_KSW_BLOCK) {
 				const int seq_cap = 64 * 1024;
 				const size_t lds = (size_t)wmk::ksw_multi_lds<WM_KSW_MULTI_B, WM_KSW_MULTI_NWV>::INTS * 4 + seq_cap;
-				HIPCHK(hipFuncSetAttribute((const void*)ksw_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-				hipLaunchKernelGGL(ksw_multi_kernel, dim3(nk), dim3(64 * WM_KSW_MULTI_NWV), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, seq_cap);
+				HIPCHK(hipFuncSetAttribute((const void*)ksw_multi_kernel<WM_KSW_MULTI_NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+				hipLaunchKernelGGL(ksw_multi_kernel<WM_KSW_MULTI_NWV>, dim3(nk), dim3(64 * WM_KSW_MULTI_NWV), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, seq_cap);
 			} else if (k == WM_KSW_BLOCK2) {
-				const size_t lds = (size_t)WM_KSW_BLK2_WN * 12 + fixed + WM_KSW_BLK2_SEQ_LDS;
-				HIPCHK(hipFuncSetAttribute((const void*)ksw_block_kernel<WM_KSW_BLK2_K, WM_KSW_BLK2_WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-				hipLaunchKernelGGL((ksw_block_kernel<WM_KSW_BLK2_K, WM_KSW_BLK2_WN>), dim3(nk), dim3(64 * WM_KSW_BLK_NWV), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, (int)WM_KSW_BLK2_SEQ_LDS, (int*)0, (const uint64_t*)0);
+				const int seq_cap = 64 * 1024;
+				const size_t lds = (size_t)wmk::ksw_multi_lds<WM_KSW_MULTI_B, 2 * WM_KSW_MULTI_NWV>::INTS * 4 + seq_cap;
+				HIPCHK(hipFuncSetAttribute((const void*)ksw_multi_kernel<2 * WM_KSW_MULTI_NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+				hipLaunchKernelGGL(ksw_multi_kernel<2 * WM_KSW_MULTI_NWV>, dim3(nk), dim3(64 * 2 * WM_KSW_MULTI_NWV), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, seq_cap);
 			} else {
 				const size_t lds = fixed + WM_KSW_BLK3_SEQ_LDS;
 				HIPCHK(hipFuncSetAttribute((const void*)ksw_block_kernel<WM_KSW_BLK2_K, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
