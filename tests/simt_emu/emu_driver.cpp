@@ -28,6 +28,23 @@ template <int B> static void run_dp_striped(int clip, int hasn, const wm_ksw_sco
 	else wmk::ksw_dp_striped<B, false, false>(sc, jb, seqs, tb, res);
 }
 
+template <int CPW, int NWV> static void run_smulti(const wm_ksw_score_t &sc, const wm_ksw_djob_t &jb, const uint8_t *seqs, uint8_t *tb, wm_ksw_dres_t *res)
+{
+	std::vector<int> lds(wmk::ksw_smulti_lds<CPW, NWV>::INTS, 0x5a5a5a5a);
+	pthread_barrier_t bar;
+	pthread_barrier_init(&bar, 0, NWV);
+	simt::block_barrier() = &bar;
+	std::vector<std::thread> th;
+	for (int w = 0; w < NWV; ++w)
+		th.emplace_back([&, w]() {
+			simt::wave_slot() = w; simt::exec_mask() = ~0ull;
+			wmk::ksw_dp_smulti<CPW, NWV, true, true>(sc, jb, seqs + jb.q_off, seqs + jb.t_off, tb, lds.data(), res);
+		});
+	for (auto &t : th) t.join();
+	simt::block_barrier() = 0;
+	pthread_barrier_destroy(&bar);
+}
+
 extern "C" {
 
 // force_klass < 0: choose like the product host; otherwise use that class (to exercise CLIP/HASN variants on any input)
@@ -45,6 +62,8 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 	memset(&jb, 0, sizeof(jb));
 	jb.q_off = 0; jb.t_off = qlen; jb.qlen = qlen; jb.tlen = tlen; jb.w = w; jb.zdrop = zdrop; jb.end_bonus = end_bonus; jb.flag = flag;
 	bool emu_blk3_small = false, emu_blk_lds = false, emu_blocked = false;
+	int emu_smulti = 0;                                          // 301: <4,4> (1024 lanes)  302: <4,16> (4096)  303: <8,16> (8192)  304: <2,2> (256, many re-bases per chunk)
+	if (force_klass >= 301 && force_klass <= 304) { emu_smulti = force_klass; force_klass = -1; }
 	if (force_klass >= 200 && force_klass < 212) { emu_blocked = true; force_klass -= 200; }   // 200+k: the blocked-layout register kernel of class k
 	if (force_klass == -2) { emu_blocked = true; force_klass = -1; }
 	if (force_klass == 112) { emu_blk_lds = true; force_klass = WM_KSW_BLOCK; }
@@ -63,7 +82,14 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 	wm_ksw_dres_t res;
 	memset(&res, 0, sizeof(res));
 	const int clip = klass >> 1 & 1, hasn = klass & 1;
-	if (klass == WM_KSW_BLOCK || klass == WM_KSW_BLOCK2 || klass == WM_KSW_BLOCK3) {
+	if (emu_smulti) {
+		const int cap = emu_smulti == 301 ? 1024 : emu_smulti == 302 ? 4096 : emu_smulti == 303 ? 8192 : 256;
+		if (n_col + 16 > cap) return -1;
+		if (emu_smulti == 301) run_smulti<4, 4>(sc, jb, seqs.data(), tb.data(), &res);
+		else if (emu_smulti == 302) run_smulti<4, 16>(sc, jb, seqs.data(), tb.data(), &res);
+		else if (emu_smulti == 303) run_smulti<8, 16>(sc, jb, seqs.data(), tb.data(), &res);
+		else run_smulti<2, 2>(sc, jb, seqs.data(), tb.data(), &res);
+	} else if (klass == WM_KSW_BLOCK || klass == WM_KSW_BLOCK2 || klass == WM_KSW_BLOCK3) {
 		constexpr int NWV = WM_KSW_BLK_NWV;
 		const int WN = klass == WM_KSW_BLOCK ? WM_KSW_BLK_WN : klass == WM_KSW_BLOCK2 ? WM_KSW_BLK2_WN : (int)wm_ksw_blk3_wn(tlen);
 		std::vector<int> W0(WN, 0x5a5a5a5a), W1(WN, 0x5a5a5a5a), Hm(WN, 0x5a5a5a5a), pub(WM_KSW_BLK_PUB);   // the state starts as garbage

@@ -58,7 +58,7 @@ def test_block_ksw_kernels_match_oracle(emu):
     for c in cases:
         o = W.o_ksw_extd2(c["q"], c["t"], mat=W.simple_mat(c["a"], c["b"], 1), q=c["q_"], e=c["e"], q2=c["q2"], e2=c["e2"],
                           w=c["w"], zdrop=c["zdrop"], end_bonus=c["end_bonus"], flag=c["flag"])
-        for force in (12, 112, 13, 113, 14, 114):
+        for force in (12, 112, 13, 113, 14, 114, 301, 302, 304):
             n, ez, cig, klass = emu_ksw(emu, c, force)
             if n < 0:
                 continue

@@ -128,6 +128,17 @@ __global__ __launch_bounds__(64 * NWV) void ksw_multi_kernel(wm_ksw_score_t sc, 
 		wmk::ksw_dp_multi<WM_KSW_MULTI_B, NWV, true, true>(sc, jb, seqs + jb.q_off, seqs + jb.t_off, tb, lds, res + j);
 }
 
+// striped multi-wave kernels (ksw_dp_smulti<CPW,NWV>): <4,4> for hulls up to 1008 lanes (the B=16 classes), <4,16> BLOCK, <8,16> BLOCK2
+template <int CPW, int NWV>
+__global__ __launch_bounds__(64 * NWV) void ksw_smulti_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
+                                                               const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res)
+{
+	__shared__ int lds[wmk::ksw_smulti_lds<CPW, NWV>::INTS];
+	const int j = order[blockIdx.x];
+	const wm_ksw_djob_t jb = jobs[j];
+	wmk::ksw_dp_smulti<CPW, NWV, true, true>(sc, jb, seqs + jb.q_off, seqs + jb.t_off, tb, lds, res + j);
+}
+
 // one thread per alignment: walk the traceback, write run-length ops (backtrack order) into the job's slot
 __global__ __launch_bounds__(64) void ksw_backtrack_kernel(int n, const wm_ksw_djob_t *__restrict__ jobs, const uint8_t *__restrict__ tb,
                                                             wm_ksw_dres_t *__restrict__ res, uint32_t *__restrict__ cig_scratch, int *__restrict__ err)
@@ -477,6 +488,20 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		const double tk0 = trace_k ? now_ms() : 0;
 		hipEventRecord(c->cev[k][0], ks);
 		struct Done { decltype(class_done) &f; int k; double t; hipEvent_t e; hipStream_t s; ~Done() { hipEventRecord(e, s); f(k, t); } } done_guard{ class_done, k, tk0, c->cev[k][1], ks };
+		static const int smulti = getenv("WM_KSW_SMULTI") ? atoi(getenv("WM_KSW_SMULTI")) : 0;     // experiment switch (bit 0: B=16 classes, 1: BLOCK, 2: BLOCK2):
+		// the striped multi-wave kernels cut per-job latency but cost more VALU work in total, and the mapper is VALU-throughput bound -> off by default
+		if ((smulti & 1) && k >= WM_KSW_B16 && k < WM_KSW_BLOCK) {
+			hipLaunchKernelGGL((ksw_smulti_kernel<4, 4>), dim3(nk), dim3(256), 0, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res);
+			continue;
+		}
+		if ((smulti & 2) && k == WM_KSW_BLOCK) {
+			hipLaunchKernelGGL((ksw_smulti_kernel<4, 16>), dim3(nk), dim3(1024), 0, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res);
+			continue;
+		}
+		if ((smulti & 4) && k == WM_KSW_BLOCK2) {
+			hipLaunchKernelGGL((ksw_smulti_kernel<8, 16>), dim3(nk), dim3(1024), 0, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res);
+			continue;
+		}
 		if (k == WM_KSW_BLOCK || k == WM_KSW_BLOCK2 || k == WM_KSW_BLOCK3) {
 			const size_t fixed = (size_t)WM_KSW_BLK_PUB * 4;
 			if (k == WM_KSW_BLOCK) {
