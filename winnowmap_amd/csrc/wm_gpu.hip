@@ -490,6 +490,10 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		struct Done { decltype(class_done) &f; int k; double t; hipEvent_t e; hipStream_t s; ~Done() { hipEventRecord(e, s); f(k, t); } } done_guard{ class_done, k, tk0, c->cev[k][1], ks };
 		static const int smulti = getenv("WM_KSW_SMULTI") ? atoi(getenv("WM_KSW_SMULTI")) : 0;     // experiment switch (bit 0: B=16 classes, 1: BLOCK, 2: BLOCK2):
 		// the striped multi-wave kernels cut per-job latency but cost more VALU work in total, and the mapper is VALU-throughput bound -> off by default
+		if ((smulti & 8) && k >= WM_KSW_B16 && k < WM_KSW_BLOCK) {                 // two waves x 8 chunks
+			hipLaunchKernelGGL((ksw_smulti_kernel<8, 2>), dim3(nk), dim3(128), 0, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res);
+			continue;
+		}
 		if ((smulti & 1) && k >= WM_KSW_B16 && k < WM_KSW_BLOCK) {
 			hipLaunchKernelGGL((ksw_smulti_kernel<4, 4>), dim3(nk), dim3(256), 0, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res);
 			continue;
