@@ -80,7 +80,7 @@ def cpu_reference_baseline(fa, kf, reads, tmp, n_cores):
             "sample": "%d x 15 kb reads of the same workload, winnowmap_ref -t %d -W -ax map-ont, mapping phase %.2f s (index build %.1f s excluded)" % (len(reads), n_cores, t_map, float(m_idx.group(1)))}
 
 
-KSW_CLASS_NAMES = {0: "ksw_dp_kernel<4,...>", 4: "ksw_dp_kernel<8,...>", 8: "ksw_dp_kernel<16,...>", 12: "ksw_multi_kernel<8>", 13: "ksw_multi_kernel<16>",
+KSW_CLASS_NAMES = {0: "ksw_dps_kernel<4,...>", 4: "ksw_dps_kernel<8,...>", 8: "ksw_dps_kernel<16,...>", 12: "ksw_multi_kernel<8>", 13: "ksw_multi_kernel<16>",
                    14: "ksw_block_kernel<7,0>", 15: "ksw_generic_kernel"}
 
 

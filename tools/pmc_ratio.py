@@ -18,7 +18,8 @@ def counters(d, name):
 
 def classes(log):
     m = re.search(r'\{"metric".*\}', open(os.path.join(src, log)).read())
-    return json.loads(m.group(0))["roofline"]["classes"]
+    cl = json.loads(m.group(0))["roofline"]["classes"]
+    return {k.replace("ksw_dp_kernel<", "ksw_dps_kernel<"): v for k, v in cl.items()}      # (older logs named the striped kernels ksw_dp_kernel)
 
 
 def key(kernel_name):        # "void ksw_dp_kernel<16, true, false>(...)" -> "ksw_dp_kernel<16,true,false>"
