@@ -7,7 +7,8 @@
 Workload (BASELINE.json configs[1]): 15 kb ONT-profile reads (3 % sub, 3 % ins, 4 % del, 1 % of
 reads with one SV) against a 250 Mb synthetic reference (25 contigs x 10 Mb, 10 % repeat families incl. 171-bp
 satellite arrays), `-W` list = canonical 15-mers above the 0.9998-distinct threshold, preset map-ont, CIGARs on.
-A STEP = one batch of reads (--reads-per-step per rank) through the full path: sketch → seed → chain → ksw kernels with
+A STEP = one mini-batch of reads (--reads-per-step per rank; default 65 536 x 15 kb = 0.98 Gbase, the reference's own
+mini-batch size `-K 1G`, src/options.c:50) through the full path: sketch → seed → chain → ksw kernels with
 the host MCAS glue in between; reads shard across ranks (weak scaling: per-GPU work is fixed), no data-path collective.
 The reference index is built by rank 0 and broadcast with RCCL (torch.distributed "nccl") as flat arrays.
 
@@ -134,7 +135,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads-per-step", type=int, default=int(os.environ.get("WM_BENCH_READS", 16384)))
+    ap.add_argument("--reads-per-step", type=int, default=int(os.environ.get("WM_BENCH_READS", 65536)))
     ap.add_argument("--ref-mb", type=float, default=float(os.environ.get("WM_BENCH_REF_MB", 250)))
     ap.add_argument("--read-len", type=int, default=15000)
     ap.add_argument("--threads", type=int, default=int(os.environ.get("WM_BENCH_THREADS", 0)))
