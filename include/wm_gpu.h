@@ -146,7 +146,7 @@ typedef struct wm_mapper_s wm_mapper_t;
 int wm_mapper_create(wm_ctx_t *ctx, const wm_index_t *idx, const char *preset, int64_t flag, wm_mapper_t **out);
 void wm_mapper_destroy(wm_mapper_t *m);
 /* host parallelism (the reference's -t): n_threads host threads run the per-read glue; they are organised in groups
- * (4 from 32 threads up, else 2 from 8 up; env WM_GROUPS) that each share one device batch per operation on their own HIP stream + arena slice
+ * (4 from 16 threads up, else 2 from 8 up; env WM_GROUPS) that each share one device batch per operation on their own HIP stream + arena slice
  * (arena_bytes_per_group; 0 = same size as ctx). */
 int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena_bytes_per_group);
 /* Map n reads (ASCII). Output records (PAF, or SAM when MM_F_OUT_SAM) of all reads in input order are appended to

@@ -1191,7 +1191,7 @@ extern "C" int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena
 	if (n_threads < 1) return set_err(WM_EINVAL, "n_threads < 1");
 	for (wm_ctx_t *w : m->workers) wm_ctx_destroy(w);
 	m->workers.clear();
-	int G = getenv("WM_GROUPS") ? atoi(getenv("WM_GROUPS")) : (n_threads >= 32 ? 4 : n_threads >= 8 ? 2 : 1);
+	int G = getenv("WM_GROUPS") ? atoi(getenv("WM_GROUPS")) : (n_threads >= 16 ? 4 : n_threads >= 8 ? 2 : 1);
 	if (G < 1) G = 1;
 	if (G > n_threads) G = n_threads;
 	m->n_threads = n_threads;
