@@ -25,3 +25,17 @@ def compare(name, hits, cigars, first):
     bad = np.nonzero((h != gh).any(axis=1))[0]
     assert len(bad) == 0, (name, "first differing hit", int(bad[0]), h[bad[0]].tolist(), gh[bad[0]].tolist())
     assert np.array_equal(cigars, gc), (name, "CIGAR ops differ")
+
+
+def edge_case_reads(reads):
+    """Reads the MCAS procedure treats specially (empty, < k, all N, N runs, unrelated, around the 10 kb MCAS gate, chimeric,
+    lower case), derived from the golden 'ont' reads."""
+    from winnowmap_amd import synth
+    rng = np.random.default_rng(77)
+    base = reads[0]
+    junk = synth.codes_to_ascii(rng.integers(0, 4, 12000).astype(np.uint8))
+    with_n = bytearray(reads[1])
+    with_n[3000:3400] = b"N" * 400
+    with_n[9000] = ord("N")
+    return [b"", b"ACGT", b"ACGTACGTACGTAC", b"N" * 500, b"N" * 12000, junk[:3000], junk, base[:9999], base[:10000], base[:10001],
+            base[2000:4500], bytes(with_n), base[:7000] + junk[:6000], reads[2].lower()]

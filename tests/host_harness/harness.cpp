@@ -9,6 +9,7 @@
 #include "../../winnowmap_amd/csrc/host/wm_align.cpp"
 #include "../../winnowmap_amd/csrc/host/wm_mapper.cpp"
 #include "../../winnowmap_amd/csrc/host/wm_chain.cpp"
+#include "../../winnowmap_amd/csrc/host/wm_format.cpp"
 #include "../../oracle/wm_oracle.h"
 #include <fstream>
 
@@ -226,6 +227,27 @@ int h_map_many(void *hv, const char *preset, int64_t flag_extra, int n, const ch
 	hit_first[n] = nh;
 	*n_cig_total = nc;
 	return nh;
+}
+
+// formatted records (PAF, or SAM with MM_F_OUT_SAM in flag_extra) of several reads; returns the text length (or -needed)
+int64_t h_map_text(void *hv, const char *preset, int64_t flag_extra, int n, const char *const *names, const char *const *seqs, const int *lens, int n_threads,
+                   char *out, int64_t cap)
+{
+	Harness *h = (Harness*)hv;
+	IdxOpt io; MapOpt mo;
+	set_preset(0, io, mo);
+	if (preset && preset[0] && set_preset(preset, io, mo) < 0) return -1;
+	mo.flag |= flag_extra;
+	OracleOps ops; ops.idx = &h->idx; ops.bloom = h->bloom; ops.opt = &mo;
+	std::vector<ReadIn> reads(n);
+	for (int i = 0; i < n; ++i) { reads[i].name = names[i]; reads[i].seq.assign(seqs[i], lens[i]); }
+	std::vector<ReadOut> outv;
+	map_batch(h->idx, mo, &ops, reads, outv, 0, n_threads);
+	std::string text;
+	for (int i = 0; i < n; ++i) write_read(text, h->idx, reads[i], outv[i], mo.flag);
+	if ((int64_t)text.size() > cap) return -(int64_t)text.size();
+	memcpy(out, text.data(), text.size());
+	return (int64_t)text.size();
 }
 
 } // extern "C"

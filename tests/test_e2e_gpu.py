@@ -55,3 +55,36 @@ def test_batching_is_order_independent(ctx):
     assert all_text == one and all_text.count(b"\n") >= len(reads)
     m.close()
     idx.close()
+
+
+def test_edge_case_reads_match_reference_library(ctx):
+    """Empty / tiny / all-N / unrelated / chimeric reads and reads around the 10 kb MCAS gate, in one batch with several host
+    threads, against the prebuilt reference library (oracle/_ref; skipped when it was not built)."""
+    import ctypes as C
+    import wmtest as W
+    if not W.have_ref():
+        pytest.skip("oracle/_ref not built")
+    R = W.ref()
+    tmp = tempfile.mkdtemp()
+    preset, fa, kf, k, reads = E.make_golden.inputs("ont", tmp)
+    cases = E.edge_case_reads(reads)
+    idx = gpu.Index(fa, kf, k=k, w=50, n_threads=8)
+    idx.upload(ctx)
+    m = gpu.Mapper(ctx, idx, preset, gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
+    m.set_threads(8, 2 << 30)
+    text, hits, cigars, first = m.map(["q%d" % i for i in range(len(cases))], cases)
+    mi = R.refshim_idx_build(fa.encode(), (kf or "").encode(), k, 50, 4)
+    opt = R.refshim_mapopt(preset.encode(), 0x4 | 0x20, mi)
+    co = 0
+    for ci, s in enumerate(cases):
+        rh = np.zeros(16 * 256, np.int32); rc = np.zeros(2000000, np.uint32); rnc = C.c_int64()
+        rn = R.refshim_map(mi, opt, s, len(s), b"q", rh, 256, rc, len(rc), C.byref(rnc))
+        a = hits[int(first[ci]):int(first[ci + 1])].copy(); b = rh[:16 * rn].reshape(-1, 16).copy()
+        assert len(a) == rn, (ci, len(s), len(a), rn)
+        a[:, 6] = 0; b[:, 6] = 0
+        assert np.array_equal(a, b), (ci, len(s))
+        nc = int(a[:, 7].sum()) if len(a) else 0
+        assert nc == rnc.value and np.array_equal(cigars[co:co + nc], rc[:nc]), (ci, len(s))
+        co += nc
+    m.close()
+    idx.close()

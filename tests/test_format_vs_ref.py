@@ -1,0 +1,67 @@
+"""PAF / SAM TEXT parity: the product's output formatting (host/wm_format.cpp on the host mapper driven by oracle-backed
+ops) against the text the REAL reference binary prints for the same reads (oracle/_ref/winnowmap_ref, built by
+oracle/Makefile). Masked: MAPQ and the rl:i tag (the reference computes them from an uninitialised rep_len,
+src/map.c:281) and the @PG line."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+import numpy as np
+import pytest
+import wmtest as W
+import e2e_common as E
+from winnowmap_amd import build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "winnowmap_ref")
+pytestmark = pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/winnowmap_ref not built")
+
+
+def _mask(line, sam):
+    f = line.rstrip("\n").split("\t")
+    if sam:
+        if line.startswith("@"):
+            return None if line.startswith("@PG") else line.rstrip("\n")
+        f[4] = "*"                                   # MAPQ
+    else:
+        f[11] = "*"
+    f = [x for x in f if not x.startswith("rl:i:")]
+    if sam:                                          # SA:Z carries the MAPQ of the other pieces
+        f = [";".join(",".join(p.split(",")[:4] + ["*"] + p.split(",")[5:]) for p in x[5:].split(";") if p) if x.startswith("SA:Z:") else x for x in f]
+    return "\t".join(f)
+
+
+@pytest.mark.parametrize("name,sam", [("ont_short", False), ("ont_short", True), ("hifi", False), ("ont", True)])
+def test_text_records_match_reference_binary(name, sam):
+    H = C.CDLL(build.build_harness())
+    H.h_index_build.restype = C.c_void_p
+    H.h_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+    H.h_map_text.restype = C.c_int64
+    H.h_map_text.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), W.i32p, C.c_int, C.c_char_p, C.c_int64]
+    tmp = tempfile.mkdtemp()
+    preset, fa, kf, k, reads = E.make_golden.inputs(name, tmp)
+    reads = reads[:8]
+    rq = os.path.join(tmp, "reads.fa")
+    with open(rq, "wb") as f:
+        for i, s in enumerate(reads):
+            f.write(b">read%d\n" % i + s + b"\n")
+    cmd = [REF_BIN, "-t", "2"] + (["-W", kf] if kf else []) + (["-ax", preset] if sam else ["-cx", preset]) + [fa, rq]
+    ref_txt = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
+    h = H.h_index_build(fa.encode(), (kf or "").encode(), k, 50, 4)
+    n = len(reads)
+    # the reference maps and prints a mini-batch longest read first, ties by higher input index (std::greater on (length, index),
+    # src/map.c:1124-1143); the boundary receives the batch in that order
+    order = sorted(range(n), key=lambda i: (len(reads[i]), i), reverse=True)
+    names = (C.c_char_p * n)(*[b"read%d" % i for i in order])
+    seqs = (C.c_char_p * n)(*[reads[i] for i in order])
+    lens = np.array([len(reads[i]) for i in order], np.int32)
+    buf = C.create_string_buffer(64 << 20)
+    flag = 0x4 | (0x8 if sam else 0x20)              # MM_F_CIGAR | MM_F_OUT_SAM / MM_F_OUT_CG (what -a / -c set, src/main.c)
+    m = H.h_map_text(h, preset.encode(), flag, n, names, seqs, lens, 2, buf, len(buf))
+    assert m >= 0
+    ours = buf.raw[:m].decode()
+    a = [x for x in (_mask(l, sam) for l in ref_txt.splitlines()) if x is not None and not x.startswith("@")]
+    b = [x for x in (_mask(l, sam) for l in ours.splitlines()) if x is not None]
+    assert len(a) == len(b), (len(a), len(b))
+    for x, y in zip(a, b):
+        assert x == y, "\nref : %s\nours: %s" % (x[:600], y[:600])
