@@ -157,6 +157,11 @@ int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, const char *co
                  const char **text, size_t *text_len, const int32_t **hits, const uint32_t **cigars, const int64_t **hit_first);
 /* counters of the last wm_map_reads call: [0] super-steps, [1] ksw jobs, [2] chain jobs, [3] seed jobs,
  * [4] sketch jobs, [5] DP cells, [6] ksw kernel us, [7] aux kernel us, [8] read bases */
+/* The file-level loop: replacement of mm_map_file / mm_map_file_frag (src/map.c:1226-1268, src/minimap.h:372-374) for
+ * single-segment reads. Reads FASTA/FASTQ (optionally gzip) mini-batches of mini_batch_bases bases (0 = 1 Gbase, src/options.c:50),
+ * orders each mini-batch like src/map.c:1124-1143, maps it and writes PAF/SAM records to out_path ("-" = stdout); reading,
+ * mapping and writing overlap. stats (optional, 6 doubles): reads, bases, mini-batches, seconds reading / mapping / writing. */
+int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *out_path, int64_t mini_batch_bases, double *stats);
 int wm_mapper_stats(const wm_mapper_t *m, uint64_t *out9);
 /* per ksw kernel class (B4/B8/B16 x CLIP x HASN register kernels, the two multi-wave LDS kernels, the generic kernel) since
  * wm_mapper_create: out[3k] = summed launch durations (ms, HIP events on the launching stream), out[3k+1] = DP cells,

@@ -10,6 +10,7 @@
 #include "../../winnowmap_amd/csrc/host/wm_mapper.cpp"
 #include "../../winnowmap_amd/csrc/host/wm_chain.cpp"
 #include "../../winnowmap_amd/csrc/host/wm_format.cpp"
+#include "../../winnowmap_amd/csrc/host/wm_pipeline.cpp"
 #include "../../oracle/wm_oracle.h"
 #include <fstream>
 
@@ -248,6 +249,30 @@ int64_t h_map_text(void *hv, const char *preset, int64_t flag_extra, int n, cons
 	if ((int64_t)text.size() > cap) return -(int64_t)text.size();
 	memcpy(out, text.data(), text.size());
 	return (int64_t)text.size();
+}
+
+// the file-level pipeline (host/wm_pipeline.cpp) over oracle-backed ops: FASTA/FASTQ(.gz) -> PAF/SAM file
+int h_map_file(void *hv, const char *preset, int64_t flag_extra, const char *reads_path, const char *out_path, int64_t mini_batch_bases, int n_threads, double *stats)
+{
+	Harness *h = (Harness*)hv;
+	IdxOpt io; MapOpt mo;
+	set_preset(0, io, mo);
+	if (preset && preset[0] && set_preset(preset, io, mo) < 0) return -1;
+	mo.flag |= flag_extra;
+	OracleOps ops; ops.idx = &h->idx; ops.bloom = h->bloom; ops.opt = &mo;
+	FILE *out = fopen(out_path, "wb");
+	if (!out) return -2;
+	std::string err;
+	FileStats fs;
+	const int rc = map_file(reads_path, mini_batch_bases, (mo.flag & 0x8) != 0, [&](std::vector<ReadIn> &batch, std::string &text) {
+		std::vector<ReadOut> outv;
+		map_batch(h->idx, mo, &ops, batch, outv, 0, n_threads);
+		for (size_t i = 0; i < batch.size(); ++i) write_read(text, h->idx, batch[i], outv[i], mo.flag);
+		return 0;
+	}, out, &fs, err);
+	fclose(out);
+	if (stats) { stats[0] = (double)fs.n_reads; stats[1] = (double)fs.n_bases; stats[2] = (double)fs.n_batches; }
+	return rc;
 }
 
 } // extern "C"

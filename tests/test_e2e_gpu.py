@@ -88,3 +88,37 @@ def test_edge_case_reads_match_reference_library(ctx):
         co += nc
     m.close()
     idx.close()
+
+
+def test_map_file_pipeline(ctx):
+    """wm_map_file: FASTA -> PAF through overlapped reader / mapper / writer; equals mapping the same mini-batches directly."""
+    import os
+    tmp = tempfile.mkdtemp()
+    preset, fa, kf, k, reads = E.make_golden.inputs("ont_short", tmp)
+    reads = [r[:4000 + 137 * i] for i, r in enumerate(reads)]             # different lengths: the per-batch order matters
+    rq = os.path.join(tmp, "reads.fa")
+    with open(rq, "wb") as f:
+        for i, s in enumerate(reads):
+            f.write(b">read%d\n" % i + s + b"\n")
+    idx = gpu.Index(fa, kf, k=k, w=50)
+    idx.upload(ctx)
+    m = gpu.Mapper(ctx, idx, preset, gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
+    m.set_threads(4, 2 << 30)
+    K = 20000
+    outp = os.path.join(tmp, "out.paf")
+    st = m.map_file(rq, outp, K)
+    assert st["reads"] == len(reads) and st["batches"] >= 3
+    expect = b""
+    i = 0
+    while i < len(reads):                                                 # the reader's mini-batches, each longest read first
+        j, bases = i, 0
+        while j < len(reads):
+            bases += len(reads[j]); j += 1
+            if bases >= K:
+                break
+        order = sorted(range(i, j), key=lambda t: (len(reads[t]), t), reverse=True)
+        expect += m.map(["read%d" % t for t in order], [reads[t] for t in order])[0]
+        i = j
+    assert open(outp, "rb").read() == expect and expect.count(b"\n") >= len(reads)
+    m.close()
+    idx.close()

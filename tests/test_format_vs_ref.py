@@ -65,3 +65,40 @@ def test_text_records_match_reference_binary(name, sam):
     assert len(a) == len(b), (len(a), len(b))
     for x, y in zip(a, b):
         assert x == y, "\nref : %s\nours: %s" % (x[:600], y[:600])
+
+
+@pytest.mark.parametrize("sam,gz", [(False, False), (True, True)])
+def test_file_pipeline_matches_reference_binary_output(sam, gz):
+    """The file-level loop (reader -> mapper -> writer over mini-batches, host/wm_pipeline.cpp): the OUTPUT FILE for a FASTQ of
+    reads of different lengths, cut into several mini-batches (-K), equals what the reference binary prints."""
+    import gzip
+    H = C.CDLL(build.build_harness())
+    H.h_index_build.restype = C.c_void_p
+    H.h_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+    H.h_map_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p, C.c_int64, C.c_int, C.c_void_p]
+    tmp = tempfile.mkdtemp()
+    preset, fa, kf, k, reads = E.make_golden.inputs("ont", tmp)
+    rng = np.random.default_rng(5)
+    recs = []
+    for i, s in enumerate(reads[:10]):
+        s = s[:int(rng.integers(3000, len(s)))] if i % 3 else s            # different lengths: the per-batch sort matters
+        recs.append((b"rd%d" % i, s, bytes(rng.integers(33, 74, len(s)).astype(np.uint8))))
+    rq = os.path.join(tmp, "reads.fq" + (".gz" if gz else ""))
+    data = b"".join(b"@" + n + b" some comment\n" + s + b"\n+\n" + q + b"\n" for n, s, q in recs)
+    with (gzip.open(rq, "wb") if gz else open(rq, "wb")) as f:
+        f.write(data)
+    K = 40000                                                              # ~3 reads per mini-batch
+    cmd = [REF_BIN, "-t", "2", "-K", str(K)] + (["-W", kf] if kf else []) + (["-ax", preset] if sam else ["-cx", preset]) + [fa, rq]
+    ref_txt = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
+    h = H.h_index_build(fa.encode(), (kf or "").encode(), k, 50, 4)
+    outp = os.path.join(tmp, "ours.txt")
+    st = np.zeros(6, np.float64)
+    flag = 0x4 | (0x8 if sam else 0x20)
+    assert H.h_map_file(h, preset.encode(), flag, rq.encode(), outp.encode(), K, 2, st.ctypes.data) == 0
+    assert st[0] == len(recs) and st[2] >= 3
+    ours = open(outp).read()
+    a = [x for x in (_mask(l, sam) for l in ref_txt.splitlines()) if x is not None and not x.startswith("@")]
+    b = [x for x in (_mask(l, sam) for l in ours.splitlines()) if x is not None]
+    assert len(a) == len(b), (len(a), len(b))
+    for x, y in zip(a, b):
+        assert x == y, "\nref : %s\nours: %s" % (x[:600], y[:600])

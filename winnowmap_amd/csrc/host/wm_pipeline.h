@@ -1,0 +1,31 @@
+// wm_pipeline.h — the file-level loop around the mapper: mm_map_file_frag's three pipeline steps (read a mini-batch, map it,
+// write its records; src/map.c:1107-1224) with the steps genuinely overlapped (the reference forces them to run one at a
+// time, src/map.c:1259): a reader thread parses batch i+1 and a writer thread prints batch i-1 while batch i is on the GPU.
+#pragma once
+#include <functional>
+#include <stdio.h>
+#include "wm_mapper.h"
+
+namespace wm {
+
+class FastxReader {                      // FASTA/FASTQ, optionally gzip (src/bseq.c, src/kseq.h record semantics)
+public:
+	FastxReader();
+	~FastxReader();
+	int open(const std::string &fn, std::string &err);
+	int next_batch(int64_t max_bases, bool with_qual, std::vector<ReadIn> &out);
+	void close();
+private:
+	struct Impl;
+	Impl *p_;
+};
+
+struct FileStats { uint64_t n_reads = 0, n_bases = 0, n_batches = 0; double t_read = 0, t_map = 0, t_write = 0; };
+
+// map_fn(batch, text): maps the reads of one mini-batch IN THE GIVEN ORDER and appends their records to text; returns 0 / error.
+// Each mini-batch is ordered longest read first (ties: later read first) exactly like src/map.c:1124-1143, so the output
+// file equals the reference's.
+typedef std::function<int(std::vector<ReadIn> &batch, std::string &text)> MapFn;
+int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_qual, const MapFn &map_fn, FILE *out, FileStats *st, std::string &err);
+
+} // namespace wm

@@ -668,6 +668,7 @@ extern "C" int wm_ksw_extd2(wm_ctx_t *c, int qlen, const uint8_t *query, int tle
 #include "host/wm_mapper.cpp"
 #include "host/wm_format.cpp"
 #include "host/wm_kmers.cpp"
+#include "host/wm_pipeline.cpp"
 
 struct wm_index_s { wm::Index ix; };
 
@@ -1208,15 +1209,31 @@ extern "C" int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena
 	return WM_OK;
 }
 
+static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double tm0);
+
 extern "C" int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, const char *const *seqs, const int32_t *lens,
                             const char **text, size_t *text_len, const int32_t **hits, const uint32_t **cigars, const int64_t **hit_first)
 {
-	static const bool trace_m = getenv("WM_TRACE") != 0;
 	const double tm0 = now_ms();
 	std::vector<wm::ReadIn> reads(n);
-	uint64_t bases = 0;
-	for (int i = 0; i < n; ++i) bases += lens[i];
 	wm::parallel_for(m->n_threads, (size_t)n, [&](size_t i) { reads[i].name = names[i]; reads[i].seq.assign(seqs[i], lens[i]); });
+	const int rc = map_reads_impl(m, reads, tm0);
+	if (rc) return rc;
+	if (text) *text = m->text.data();
+	if (text_len) *text_len = m->text.size();
+	if (hits) *hits = m->hits.data();
+	if (cigars) *cigars = m->cigars.data();
+	if (hit_first) *hit_first = m->first.data();
+	return WM_OK;
+}
+
+// maps `reads` in the given order; results land in m->text / hits / cigars / first / stats
+static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double tm0)
+{
+	static const bool trace_m = getenv("WM_TRACE") != 0;
+	const int n = (int)reads.size();
+	uint64_t bases = 0;
+	for (int i = 0; i < n; ++i) bases += reads[i].seq.size();
 	std::vector<wm::ReadOut> out(n);
 	const double tm1 = now_ms();
 	const int T = (int)m->workers.size() + 1;
@@ -1280,13 +1297,31 @@ extern "C" int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, con
 	if (trace_m) fprintf(stderr, "[map_reads] n=%d ingest %.1f ms, map %.1f ms, format %.1f ms\n", n, tm1 - tm0, tm2 - tm1, now_ms() - tm2);
 	m->stats[0] = st.n_flush; m->stats[1] = st.n_ksw; m->stats[2] = st.n_chain; m->stats[3] = st.n_seed; m->stats[4] = st.n_sketch;
 	m->stats[5] = opsr.cells; m->stats[6] = (uint64_t)opsr.ksw_us; m->stats[7] = (uint64_t)opsr.aux_us; m->stats[8] = bases;
-	if (text) *text = m->text.data();
-	if (text_len) *text_len = m->text.size();
-	if (hits) *hits = m->hits.data();
-	if (cigars) *cigars = m->cigars.data();
-	if (hit_first) *hit_first = m->first.data();
 	return WM_OK;
 }
+
+// The file-level loop (mm_map_file, src/map.c:1226-1268): reads FASTA/FASTQ(.gz) mini-batches of `mini_batch_bases` (0 = the
+// reference's default 1 Gbase), maps them and writes the records to out_path ("-" = stdout), reader / mapper / writer
+// overlapped. Every mini-batch is ordered like the reference orders it, so the file equals the reference's output.
+// stats (optional, 6 doubles): reads, bases, batches, seconds spent reading / mapping / writing.
+extern "C" int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *out_path, int64_t mini_batch_bases, double *stats)
+{
+	FILE *out = strcmp(out_path, "-") == 0 ? stdout : fopen(out_path, "wb");
+	if (!out) return set_err(WM_EINVAL, "cannot open '%s' for writing", out_path);
+	std::string err;
+	wm::FileStats fs;
+	const bool with_qual = (m->mo.flag & 0x8) != 0;                    // SAM output prints QUAL
+	const int rc = wm::map_file(reads_path, mini_batch_bases, with_qual, [&](std::vector<wm::ReadIn> &batch, std::string &text) {
+		const int r = map_reads_impl(m, batch, now_ms());
+		if (r == 0) text.swap(m->text);
+		return r;
+	}, out, &fs, err);
+	if (out != stdout) fclose(out);
+	if (stats) { stats[0] = (double)fs.n_reads; stats[1] = (double)fs.n_bases; stats[2] = (double)fs.n_batches; stats[3] = fs.t_read; stats[4] = fs.t_map; stats[5] = fs.t_write; }
+	if (rc) return g_err[0] ? rc : set_err(WM_EINVAL, "%s", err.c_str());
+	return WM_OK;
+}
+
 extern "C" int wm_mapper_stats(const wm_mapper_t *m, uint64_t *out9) { memcpy(out9, m->stats, sizeof(m->stats)); return WM_OK; }
 // per ksw kernel class (ksw_plan.h) since the mapper was created: out[3*k] = summed launch durations in ms (HIP events on the
 // launching stream), out[3*k+1] = DP cells, out[3*k+2] = launches; n_classes receives WM_KSW_NCLASS

@@ -262,6 +262,14 @@ class Mapper:
         lib().wm_mapper_stats(self._h, a.ctypes.data)
         return dict(zip(STAT_NAMES, (int(x) for x in a)))
 
+    def map_file(self, reads_path, out_path, mini_batch_bases=0):
+        """FASTA/FASTQ(.gz) -> PAF/SAM file, mini-batch pipeline (wm_map_file). Returns the stats dict."""
+        L = lib()
+        L.wm_map_file.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int64, C.c_void_p]
+        st = np.zeros(6, np.float64)
+        _chk(L.wm_map_file(self._h, reads_path.encode(), out_path.encode(), mini_batch_bases, st.ctypes.data))
+        return dict(zip(("reads", "bases", "batches", "t_read", "t_map", "t_write"), (float(x) for x in st)))
+
     def kernel_stats(self):
         """per ksw kernel class: dict class -> (ms, cells, launches)"""
         out = np.zeros(3 * 32, np.float64)
