@@ -192,13 +192,13 @@ def main():
         torch.cuda.synchronize()
 
     for b in batches[:args.warmup]:
-        mapper.map(*b)
+        mapper.map(*b, copy_text=False)
     sync()
     ks0 = mapper.kernel_stats()
     t_start = time.time()
     cells = ksw_us = aux_us = bases = hits = 0
     for b in batches[args.warmup:]:
-        text, h, _, _ = mapper.map(*b)
+        text_len, h, _, _ = mapper.map(*b, copy_text=False)       # the records stay in the library's buffer (no Python copy)
         st = mapper.stats()
         cells += st["dp_cells"]; ksw_us += st["ksw_kernel_us"]; aux_us += st["aux_kernel_us"]; bases += st["read_bases"]; hits += len(h)
     sync()

@@ -240,8 +240,9 @@ class Mapper:
     def set_threads(self, n_threads, arena_bytes_per_thread=0):
         _chk(lib().wm_mapper_set_threads(self._h, n_threads, arena_bytes_per_thread))
 
-    def map(self, names, seqs):
-        """names: list of str/bytes; seqs: list of bytes (ASCII). Returns (text, hits[n_hits,16], cigars, first[n+1])."""
+    def map(self, names, seqs, copy_text=True):
+        """names: list of str/bytes; seqs: list of bytes (ASCII). Returns (text, hits[n_hits,16], cigars, first[n+1]).
+        copy_text=False returns the text LENGTH instead of a Python copy of the records (they stay in the library's buffer)."""
         L = lib()
         n = len(seqs)
         nm = (C.c_char_p * n)(*[x if isinstance(x, bytes) else x.encode() for x in names])
@@ -253,6 +254,8 @@ class Mapper:
         fa = np.ctypeslib.as_array(C.cast(first, C.POINTER(C.c_int64)), shape=(n + 1,)).copy()
         nh = int(fa[n])
         ha = np.ctypeslib.as_array(C.cast(hits, C.POINTER(C.c_int32)), shape=(nh, 16)).copy() if nh else np.zeros((0, 16), np.int32)
+        if not copy_text:
+            return tlen.value, ha, None, fa
         nc = int(ha[:, 7].sum()) if nh else 0
         ca = np.ctypeslib.as_array(C.cast(cig, C.POINTER(C.c_uint32)), shape=(nc,)).copy() if nc else np.zeros(0, np.uint32)
         return C.string_at(text, tlen.value), ha, ca, fa
