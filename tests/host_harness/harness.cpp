@@ -213,6 +213,7 @@ int h_map_many(void *hv, const char *preset, int64_t flag_extra, int n, const ch
 	for (int i = 0; i < n; ++i) { reads[i].name = "read" + std::to_string(i); reads[i].seq.assign(seqs[i], lens[i]); }
 	std::vector<ReadOut> out;
 	map_batch(h->idx, mo, &ops, reads, out, 0, n_threads);
+	if (prof_on()) prof_report(stderr);
 	int64_t nc = 0; int nh = 0;
 	for (int k = 0; k < n; ++k) {
 		hit_first[k] = nh;

@@ -298,7 +298,8 @@ static void fix_cigar(Reg &r, const uint8_t *qseq, const uint8_t *tseq, int *qsh
 }
 
 static void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int q, int e)
-{   // mm_update_extra, src/align.c:240-286 (no =/X rewriting: MM_F_EQX is applied at output time if requested)
+{
+	WM_PROF("align.update_extra");   // mm_update_extra, src/align.c:240-286 (no =/X rewriting: MM_F_EQX is applied at output time if requested)
 	if (!r.has_p) return;
 	int qshift, tshift;
 	fix_cigar(r, qseq, tseq, &qshift, &tshift);
@@ -356,6 +357,7 @@ struct RegAln {
 
 static inline std::vector<uint8_t> ref_codes(const Index &idx, int rid, int st, int en)
 {
+	WM_PROF("align.ref_codes");
 	std::vector<uint8_t> t(en > st ? en - st : 0);
 	if (en > st) idx.getseq(rid, st, en, t.data());
 	return t;
@@ -363,6 +365,7 @@ static inline std::vector<uint8_t> ref_codes(const Index &idx, int rid, int st, 
 
 static void plan_reg(const AlnEnv &E, RegAln &A, m128 *a, std::vector<KswReq> &jobs)
 {
+	WM_PROF("align.plan_reg");
 	const MapOpt &opt = *E.opt;
 	const Index &mi = *E.idx;
 	Reg &r = A.r;
@@ -478,6 +481,7 @@ static void plan_reg(const AlnEnv &E, RegAln &A, m128 *a, std::vector<KswReq> &j
 // after the first pass: which fills need the exact second pass (src/align.c:736-737)
 static void judge_reg(const AlnEnv &E, RegAln &A, const std::vector<KswReq> &jobs, std::vector<KswReq> &redo)
 {
+	WM_PROF("align.judge_reg");
 	if (A.empty) return;
 	A.redo_code.assign(A.fills.size(), 0);
 	for (size_t k = 0; k < A.fills.size(); ++k) {
@@ -495,6 +499,7 @@ static void judge_reg(const AlnEnv &E, RegAln &A, const std::vector<KswReq> &job
 
 static void finish_reg(const AlnEnv &E, RegAln &A, m128 *a, const std::vector<KswReq> &jobs, const std::vector<KswReq> &redo)
 {
+	WM_PROF("align.finish_reg");
 	if (A.empty) return;
 	const MapOpt &opt = *E.opt;
 	Reg &r = A.r;

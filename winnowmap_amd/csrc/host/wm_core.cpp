@@ -139,4 +139,18 @@ uint32_t x31_hash_string(const char *s)
 	return h;
 }
 
+std::vector<ProfSlot> &prof_slots() { static std::vector<ProfSlot> v; return v; }
+std::mutex &prof_mutex() { static std::mutex m; return m; }
+int prof_region(const char *name)
+{
+	std::lock_guard<std::mutex> g(prof_mutex());
+	prof_slots().push_back(ProfSlot{ name, 0.0, 0 });
+	return (int)prof_slots().size() - 1;
+}
+void prof_report(FILE *f)
+{
+	std::lock_guard<std::mutex> g(prof_mutex());
+	for (const ProfSlot &s : prof_slots()) fprintf(f, "[prof] %-28s %10.2f ms  %10llu calls\n", s.name, s.ms, (unsigned long long)s.n);
+}
+
 } // namespace wm

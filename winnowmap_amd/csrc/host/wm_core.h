@@ -11,6 +11,9 @@
 #include <mutex>
 #include <condition_variable>
 #include <functional>
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
 #include "../../../include/wm_gpu.h"
 
 namespace wm {
@@ -164,5 +167,20 @@ template <class F> inline void parallel_for(int n_threads, size_t n, F fn)
 	body();
 	for (auto &x : th) x.join();
 }
+
+// ---- optional host-side profile (env WM_PROF=1): per-thread time accumulated per named region, printed by prof_report().
+//      Regions must not contain a fiber yield.
+struct ProfSlot { const char *name; double ms; uint64_t n; };
+inline bool prof_on() { static const bool on = getenv("WM_PROF") != 0; return on; }
+std::vector<ProfSlot> &prof_slots();
+std::mutex &prof_mutex();
+struct ProfScope {
+	int id; std::chrono::steady_clock::time_point t0;
+	explicit ProfScope(int id_) : id(id_) { if (id >= 0) t0 = std::chrono::steady_clock::now(); }
+	~ProfScope() { if (id >= 0) { const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); std::lock_guard<std::mutex> g(prof_mutex()); prof_slots()[id].ms += ms; prof_slots()[id].n += 1; } }
+};
+int prof_region(const char *name);
+void prof_report(FILE *f);
+#define WM_PROF(name) static const int wm_prof_id = wm::prof_on() ? wm::prof_region(name) : -1; wm::ProfScope wm_prof_scope(wm_prof_id)   /* one per block */
 
 } // namespace wm

@@ -39,6 +39,7 @@ void reg_set_coor(Reg &r, int32_t qlen, const m128 *a)
 
 std::vector<Reg> gen_regs(uint32_t hash, int qlen, int n_u, const uint64_t *u, const m128 *a)
 {
+	WM_PROF("hit.gen_regs");
 	std::vector<Reg> regs;
 	if (n_u == 0) return regs;
 	// order chains by (score, per-read pseudo-random tie-break); the sort is the unstable reference one
@@ -49,9 +50,9 @@ std::vector<Reg> gen_regs(uint32_t hash, int qlen, int n_u, const uint64_t *u, c
 		z[i].y = (uint64_t)k << 32 | (uint32_t)(int32_t)u[i];
 		k += (int32_t)u[i];
 	}
-	radix_sort_128x(z.data(), z.data() + n_u);
+	{ WM_PROF("hit.gen_regs.sort"); radix_sort_128x(z.data(), z.data() + n_u); }
 	std::reverse(z.begin(), z.end());
-	regs.resize(n_u);
+	{ WM_PROF("hit.gen_regs.resize"); regs.resize(n_u); }
 	for (int i = 0; i < n_u; ++i) {
 		Reg &r = regs[i];
 		r.id = i;
@@ -87,6 +88,7 @@ void split_reg(Reg &r, Reg &r2, int n, int qlen, const m128 *a)
 
 void set_parent(float mask_level, int mask_len, std::vector<Reg> &r, int sub_diff, int hard_mask_level)
 {
+	WM_PROF("hit.set_parent");
 	const int n = (int)r.size();
 	if (n <= 0) return;
 	for (int i = 0; i < n; ++i) r[i].id = i;
@@ -150,6 +152,7 @@ void set_parent(float mask_level, int mask_len, std::vector<Reg> &r, int sub_dif
 
 void hit_sort(std::vector<Reg> &r)
 {
+	WM_PROF("hit.hit_sort");
 	const int n = (int)r.size();
 	if (n <= 1) return;
 	std::vector<m128> aux;
@@ -198,6 +201,7 @@ void sync_regs(std::vector<Reg> &r)
 
 void select_sub(float pri_ratio, int min_diff, int best_n, std::vector<Reg> &r)
 {
+	WM_PROF("hit.select_sub");
 	if (!(pri_ratio > 0.0f) || r.empty()) return;
 	const int n = (int)r.size();
 	int k = 0, n_2nd = 0;
@@ -251,6 +255,7 @@ int squeeze_a(std::vector<Reg> &r, m128 *a)
 
 void join_long(const MapOpt &opt, int qlen, std::vector<Reg> &r, m128 *a)
 {
+	WM_PROF("hit.join_long");
 	const int n = (int)r.size();
 	if (n < 2) return;
 	squeeze_a(r, a);
@@ -315,6 +320,7 @@ static void set_inv_mapq(std::vector<Reg> &r)
 
 void set_mapq(std::vector<Reg> &r, int min_chain_sc, int match_sc, int rep_len, int is_sr)
 {
+	WM_PROF("hit.set_mapq");
 	static const float q_coef = 40.0f;
 	if (r.empty()) return;
 	int64_t sum_sc = 0;

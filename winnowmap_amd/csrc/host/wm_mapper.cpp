@@ -171,8 +171,9 @@ namespace {
 // create the fibers of one read on scheduler `sch` (stage-1 positions, then stage 2; src/map.c:304-341)
 void spawn_read(Scheduler &sch, const Index &idx, const MapOpt &opt, const MapOpt &o2, ReadTask &T)
 {
+	{ WM_PROF("map.encode_read");
 	T.codes.resize(T.qlen);
-	for (int j = 0; j < T.qlen; ++j) T.codes[j] = nt4_table[(uint8_t)T.in->seq[j]];
+	for (int j = 0; j < T.qlen; ++j) T.codes[j] = nt4_table[(uint8_t)T.in->seq[j]]; }
 	if (T.qlen == 0) return;
 	if (opt.max_qlen > 0 && T.qlen > opt.max_qlen) return;
 	const int off = o2.suffixSampleOffset;
