@@ -102,3 +102,36 @@ def test_file_pipeline_matches_reference_binary_output(sam, gz):
     assert len(a) == len(b), (len(a), len(b))
     for x, y in zip(a, b):
         assert x == y, "\nref : %s\nours: %s" % (x[:600], y[:600])
+
+
+@pytest.mark.parametrize("opt,flag,sam", [("--cs", 0x40, False), ("--cs=long", 0x40 | 0x800, False), ("--MD", 0x1000000, True), ("--cs", 0x40, True)])
+def test_cs_and_md_tags_match_reference_binary(opt, flag, sam):
+    H = C.CDLL(build.build_harness())
+    H.h_index_build.restype = C.c_void_p
+    H.h_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+    H.h_map_text.restype = C.c_int64
+    H.h_map_text.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), W.i32p, C.c_int, C.c_char_p, C.c_int64]
+    tmp = tempfile.mkdtemp()
+    preset, fa, kf, k, reads = E.make_golden.inputs("ont", tmp)
+    reads = reads[:6]
+    reads[1] = reads[1][:5000] + b"N" * 3 + reads[1][5003:]                # ambiguous bases inside an alignment
+    rq = os.path.join(tmp, "reads.fa")
+    with open(rq, "wb") as f:
+        for i, s_ in enumerate(reads):
+            f.write(b">read%d\n" % i + s_ + b"\n")
+    cmd = [REF_BIN, "-t", "2", "-W", kf, "-ax" if sam else "-cx", preset, opt, fa, rq]
+    ref_txt = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
+    h = H.h_index_build(fa.encode(), kf.encode(), k, 50, 4)
+    n = len(reads)
+    order = sorted(range(n), key=lambda i: (len(reads[i]), i), reverse=True)
+    names = (C.c_char_p * n)(*[b"read%d" % i for i in order])
+    seqs = (C.c_char_p * n)(*[reads[i] for i in order])
+    lens = np.array([len(reads[i]) for i in order], np.int32)
+    buf = C.create_string_buffer(128 << 20)
+    m = H.h_map_text(h, preset.encode(), 0x4 | (0x8 if sam else 0x20) | flag, n, names, seqs, lens, 2, buf, len(buf))
+    assert m >= 0
+    a = [x for x in (_mask(l, sam) for l in ref_txt.splitlines()) if x is not None and not x.startswith("@")]
+    b = [x for x in (_mask(l, sam) for l in buf.raw[:m].decode().splitlines()) if x is not None]
+    assert len(a) == len(b) and any(("cs:Z:" in x or "MD:Z:" in x) for x in a)
+    for x, y in zip(a, b):
+        assert x == y, "\nref : %s\nours: %s" % (x[:300], y[:300])

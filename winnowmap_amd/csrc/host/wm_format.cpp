@@ -47,6 +47,68 @@ static void write_tags(std::string &s, const Reg &r)
 	if (r.split) { s += "\tzd:i:"; put_int(s, r.split); }
 }
 
+// cs:Z / MD:Z tags (write_cs_or_MD, src/format.c:140-231): walk the CIGAR over the aligned target / query codes
+static void write_cs_or_md(std::string &s, const Index &idx, const ReadIn &t, const Reg &r, int64_t flag)
+{
+	if (!r.has_p) return;
+	const int ql = r.qe - r.qs, tl = r.re - r.rs;
+	std::vector<uint8_t> tseq(tl > 0 ? tl : 1), qseq(ql > 0 ? ql : 1);
+	if (tl > 0) idx.getseq(r.rid, r.rs, r.re, tseq.data());
+	for (int i = r.qs; i < r.qe; ++i) {
+		const uint8_t c = nt4_table[(uint8_t)t.seq[i]];
+		if (!r.rev) qseq[i - r.qs] = c;
+		else qseq[r.qe - i - 1] = c >= 4 ? 4 : 3 - c;
+	}
+	static const char *lower = "acgtn", *upper = "ACGTN";
+	int q_off = 0, t_off = 0;
+	if (flag & F_OUT_MD) {
+		s += "\tMD:Z:";
+		int run = 0;
+		for (uint32_t c : r.cigar) {
+			const int op = c & 0xf, len = (int)(c >> 4);
+			if (op == 0 || op == 7 || op == 8) {
+				for (int j = 0; j < len; ++j) {
+					if (qseq[q_off + j] != tseq[t_off + j]) { put_int(s, run); s += upper[tseq[t_off + j]]; run = 0; }
+					else ++run;
+				}
+				q_off += len; t_off += len;
+			} else if (op == 1) q_off += len;
+			else if (op == 2) {
+				put_int(s, run); s += '^';
+				for (int j = 0; j < len; ++j) s += upper[tseq[t_off + j]];
+				run = 0; t_off += len;
+			} else if (op == 3) t_off += len;
+		}
+		if (run > 0) put_int(s, run);
+		return;
+	}
+	const bool long_form = (flag & F_OUT_CS_LONG) != 0;
+	s += "\tcs:Z:";
+	for (uint32_t c : r.cigar) {
+		const int op = c & 0xf, len = (int)(c >> 4);
+		if (op == 0 || op == 7 || op == 8) {
+			int run = 0;
+			auto flush = [&](int end) {                                    // identical stretch ending before position `end`
+				if (run == 0) return;
+				if (long_form) { s += '='; for (int j = end - run; j < end; ++j) s += upper[qseq[q_off + j]]; }
+				else { s += ':'; put_int(s, run); }
+				run = 0;
+			};
+			for (int j = 0; j < len; ++j) {
+				if (qseq[q_off + j] != tseq[t_off + j]) { flush(j); s += '*'; s += lower[tseq[t_off + j]]; s += lower[qseq[q_off + j]]; }
+				else ++run;
+			}
+			flush(len);
+			q_off += len; t_off += len;
+		} else if (op == 1) { s += '+'; for (int j = 0; j < len; ++j) s += lower[qseq[q_off + j]]; q_off += len; }
+		else if (op == 2) { s += '-'; for (int j = 0; j < len; ++j) s += lower[tseq[t_off + j]]; t_off += len; }
+		else {                                                             // intron (splice mode only)
+			s += '~'; s += lower[tseq[t_off]]; s += lower[tseq[t_off + 1]]; put_int(s, len); s += lower[tseq[t_off + len - 2]]; s += lower[tseq[t_off + len - 1]];
+			t_off += len;
+		}
+	}
+}
+
 static void write_paf(std::string &s, const Index &idx, const ReadIn &t, const Reg *r, int64_t flag, int rep_len)
 {   // mm_write_paf3, src/format.c:308-334
 	const int l_seq = (int)t.seq.size();
@@ -65,6 +127,7 @@ static void write_paf(std::string &s, const Index &idx, const ReadIn &t, const R
 		s += "\tcg:Z:";
 		for (uint32_t c : r->cigar) { put_int(s, c >> 4); s += "MIDNSHP=XB"[c & 0xf]; }
 	}
+	if (r->has_p && (flag & (F_OUT_CS | F_OUT_MD))) write_cs_or_md(s, idx, t, *r, flag);
 	if ((flag & F_COPY_COMMENT) && !t.comment.empty()) { s += '\t'; s += t.comment; }
 }
 
@@ -161,6 +224,7 @@ static void write_sam(std::string &s, const Index &idx, const ReadIn &t, const s
 				}
 			}
 		}
+		if (r->has_p && (flag_opt & (F_OUT_CS | F_OUT_MD))) write_cs_or_md(s, idx, t, *r, flag_opt);
 		if (cigar_in_tag) {
 			const uint32_t clip0 = r->rev ? l_seq - r->qe : r->qs, clip1 = r->rev ? r->qs : l_seq - r->qe;
 			const int cc = (flag & 0x800) && !(flag_opt & F_SOFTCLIP) ? 5 : 4;
