@@ -24,7 +24,6 @@ print("jobs %d anchors %d  n>4096: %d jobs %d anchors; 1024<n<=4096: %d jobs" % 
 ctx = gpu.Context(0, 8 << 30)
 L = gpu.lib()
 L.wm_chain_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, W.u64p, W.i32p, C.c_void_p, W.u64p, W.u64p, W.i32p, W.i32p]
-os.environ["WM_CHAIN_TUNE"] = "1"
 
 
 def run(sel, label, check=False):
@@ -55,14 +54,8 @@ def run(sel, label, check=False):
 
 big = np.nonzero(na > 4096)[0]
 one = big[np.argsort(-na[big])[:1]]
-ref_out = None
-for blk, w in ((1, 4096), (0, 4096), (0, 2048), (0, 1024), (0, 512), (1, 1024), (1, 512)):
-    os.environ["WM_CHAIN_BLOCK"] = str(blk); os.environ["WM_CHAIN_BIG_W"] = str(w)
-    r = run(big, "n>4096  block=%d W=%d" % (blk, w), check=True)
-    if ref_out is None: ref_out = r
-    else: assert all(np.array_equal(x, y) for x, y in zip(r, ref_out)), "results differ between configurations"
-    run(one, "  largest (n=%d) block=%d W=%d" % (na[one[0]], blk, w))
-os.environ["WM_CHAIN_BLOCK"] = "0"; os.environ["WM_CHAIN_BIG_W"] = "1024"
-run(np.arange(len(jobs)), "all jobs, block=0 W=1024")
+run(big, "n>4096", check=True)
+run(one, "  largest (n=%d)" % na[one[0]])
+run(np.arange(len(jobs)), "all jobs")
 run(np.nonzero(na <= 256)[0], "n<=256")
 t0 = time.time(); a = jobs[one[0]][2]; W.o_chain_dp(a["x"], a["y"]); print("oracle (1 core) largest job n=%d: %.1f ms" % (na[one[0]], (time.time() - t0) * 1e3))

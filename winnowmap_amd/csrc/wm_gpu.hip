@@ -688,7 +688,7 @@ __global__ __launch_bounds__(64) void seed_kernel(wm_index_view_t ix, const wm_s
 	wmk::seed_wave(ix, jobs[j], mini, anchors, occ_scratch + occ_off[j], res + j);
 }
 
-// chain DP fill: one wave per anchor set, LDS window of W anchors (32 B each), results written through to fpvt
+// chain DP fill: one wave per anchor set, LDS window of W anchors (28 B each: x, y, f, p, t); f and p go to fpvt
 __global__ __launch_bounds__(64) void chain_kernel(const wm_chain_job_t *jobs, const int *order, const wm128_t *anchors, int *fpvt, int W)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(64) void chain_kernel(const wm_chain_job_t *jobs, c
 	wmk::chain_wave(jb, anchors, W, sx, sy, sf, sp, st, gf, gp, gt);
 }
 
-// large anchor sets: NWV waves cooperate on one job (chain_block); LDS = 32 B * W window + publish area
+// large anchor sets: NWV waves cooperate on one job (chain_block); LDS = 28 B * W window + publish area
 template <int NWV>
 __global__ __launch_bounds__(64 * NWV) void chain_kernel_block(const wm_chain_job_t *jobs, const int *order, const wm128_t *anchors, int *fpvt, int W)
 {
@@ -983,16 +983,10 @@ extern "C" int wm_chain_batch(wm_ctx_t *c, int n, wm128_t *a, const uint64_t *a_
 	HIPCHK(hipMemcpyAsync(d_a, a, tot * sizeof(wm128_t), hipMemcpyHostToDevice, c->stream));
 	const double tt1 = trace ? now_ms() : 0;
 	HIPCHK(hipEventRecord(c->ev[0], c->stream));
-	{   // size classes by anchor count (order is sorted by n descending): LDS footprint = 32 B * W
+	{   // classes (order is grouped by class, largest jobs first inside a class): LDS footprint = 28 B * W
 		HIPCHK(hipFuncSetAttribute((const void*)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		constexpr int NWV = 8;
 		HIPCHK(hipFuncSetAttribute((const void*)chain_kernel_block<NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		// tuning hooks (probes only): window of the largest class, and whether it runs the multi-wave kernel
-		static const int big_w = getenv("WM_CHAIN_BIG_W") ? atoi(getenv("WM_CHAIN_BIG_W")) : 4096;
-		static const int use_block = getenv("WM_CHAIN_BLOCK") ? atoi(getenv("WM_CHAIN_BLOCK")) : 1;
-		const int big_W = getenv("WM_CHAIN_TUNE") ? (getenv("WM_CHAIN_BIG_W") ? atoi(getenv("WM_CHAIN_BIG_W")) : 4096) : big_w;
-		const int blk = getenv("WM_CHAIN_TUNE") ? (getenv("WM_CHAIN_BLOCK") ? atoi(getenv("WM_CHAIN_BLOCK")) : 1) : use_block;
-		(void)big_W; (void)blk;
 		int b = 0;
 		for (int k = 0; k < 4; ++k) {                        // 0 dense (8 waves, W 4096) | 1 large sparse (1 wave, W 1024) | 2 n <= 1024 | 3 n <= 256
 			int e = b;
