@@ -104,6 +104,11 @@ int wm_ksw_extd2(wm_ctx_t *ctx, int qlen, const uint8_t *query, int tlen, const 
 typedef struct wm_index_s wm_index_t;
 int wm_index_build(const char *fasta, const char *kmer_file, int k, int w, int n_threads, wm_index_t **out);
 void wm_index_destroy(wm_index_t *idx);
+/* The reference's index file ("MMI\2": winnowmap -d, mm_idx_dump / mm_idx_load, src/index.c:515-608). Files written here load in
+ * the reference and vice versa. The reference does not store its bloom filter; wm_index_save appends it as a trailer the reference
+ * skips, and wm_index_load rebuilds it from kmer_file (the -W list, may be NULL) when the file has none. */
+int wm_index_save(const wm_index_t *idx, const char *path);
+int wm_index_load(const char *path, const char *kmer_file, wm_index_t **out);
 int wm_index_upload(wm_ctx_t *ctx, const wm_index_t *idx);
 int wm_index_n_seq(const wm_index_t *idx);
 const char *wm_index_seq_name(const wm_index_t *idx, int rid);

@@ -30,6 +30,9 @@ void *refshim_idx_build(const char *fasta, const char *kmer_file, int k, int w, 
 	return mi;
 }
 void refshim_idx_destroy(void *mi) { mm_idx_destroy((mm_idx_t*)mi); }
+// src/index.c:515-608 mm_idx_dump / mm_idx_load (the CLI's -d is disabled in this fork, the library functions are intact)
+int refshim_idx_dump(void *mi, const char *path) { FILE *fp = fopen(path, "wb"); if (!fp) return -1; mm_idx_dump(fp, (mm_idx_t*)mi); fclose(fp); return 0; }
+void *refshim_idx_load(const char *path) { FILE *fp = fopen(path, "rb"); if (!fp) return 0; mm_idx_t *mi = mm_idx_load(fp); fclose(fp); return mi; }
 int refshim_idx_nseq(void *mi) { return ((mm_idx_t*)mi)->n_seq; }
 int refshim_idx_seqlen(void *mi, int rid) { return ((mm_idx_t*)mi)->seq[rid].len; }
 int refshim_idx_getseq(void *mi, uint32_t rid, uint32_t st, uint32_t en, uint8_t *out) { return mm_idx_getseq((mm_idx_t*)mi, rid, st, en, out); }

@@ -169,6 +169,20 @@ void h_bloom_view(void *hv, uint32_t *table_bits, uint32_t *salts, const uint8_t
 	*table_bits = (uint32_t)ix.bloom.table_bits; salts[0] = ix.bloom.salt[0]; salts[1] = ix.bloom.salt[1]; *bits = ix.bloom.bits.data();
 }
 
+// index files in the reference's format
+int h_index_save_mmi(void *hv, const char *path) { std::string err; return index_save_mmi(((Harness*)hv)->idx, path, err); }
+void *h_index_load_mmi(const char *path, const char *kmer_file)
+{
+	Harness *h = new Harness();
+	std::string err;
+	if (index_load_mmi(path, kmer_file ? kmer_file : "", h->idx, err) < 0) { fprintf(stderr, "%s\n", err.c_str()); delete h; return 0; }
+	std::vector<uint64_t> kms;                                        // the oracle-backed sketch op uses the oracle's own filter
+	if (kmer_file && kmer_file[0]) { std::ifstream in(kmer_file); std::string km; uint64_t f; while (in >> km >> f) kms.push_back(wmo_encode_kmer(km.c_str(), (int)km.size())); }
+	h->bloom = wmo_bloom_new(kms.size());
+	for (uint64_t x : kms) wmo_bloom_insert(h->bloom, x);
+	return h;
+}
+
 // same output layout as refshim_map (oracle/ref_shim.cpp)
 int h_map(void *hv, const char *preset, int64_t flag_extra, const char *seq, int len, const char *name,
           int32_t *hit_out, int hit_cap, uint32_t *cig_out, int64_t cig_cap, int64_t *n_cig_total, uint64_t *stats_out)

@@ -209,8 +209,14 @@ int index_build(const IdxOpt &io, const std::vector<std::string> &names, const s
 	for (auto &v : per) tot += v.size();
 	all.reserve(tot);
 	for (auto &v : per) { all.insert(all.end(), v.begin(), v.end()); std::vector<m128>().swap(v); }
+	index_table_from_minimizers(ix, all);
+	return 0;
+}
+
+// (key, position) records -> the flat table: grouped by minimizer key, positions ascending (src/index.c:200-252)
+void index_table_from_minimizers(Index &ix, std::vector<m128> &all)
+{
 	ix.n_minimizers = all.size();
-	// group by minimizer key, positions ascending (src/index.c:200-252)
 	std::sort(all.begin(), all.end(), [](const m128 &a, const m128 &b) { return (a.x >> 8) != (b.x >> 8) ? (a.x >> 8) < (b.x >> 8) : a.y < b.y; });
 	size_t nk = 0;
 	for (size_t i = 0; i < all.size(); ++i) if (i == 0 || (all[i].x >> 8) != (all[i - 1].x >> 8)) ++nk;
@@ -229,6 +235,136 @@ int index_build(const IdxOpt &io, const std::vector<std::string> &names, const s
 		while (ix.hkey[s] != ~0ULL) s = (s + 1) & msk;
 		ix.hkey[s] = key; ix.hval[s] = (uint64_t)i << 32 | (uint64_t)(j - i);
 		i = j;
+	}
+}
+
+// ---- the reference's index file ("MMI\2", mm_idx_dump / mm_idx_load, src/index.c:515-608) --------------------------------
+// header: magic, u32 w k b n_seq flag | per sequence: u8 name length, name, u32 length | per bucket i < 2^b: u32 n, n x u64
+// positions, u32 n_keys, n_keys x (u64 key = minier >> b << 1 | singleton, u64 val = position | start << 32 | count) | packed
+// 4-bit bases. The reference does not store its bloom filter (it must be given -W again); we append an optional trailer
+// "WMB1" with ours, which the reference's reader skips (it stops at the first block that is not an index part).
+static const int MMI_B = 14;
+
+int index_save_mmi(const Index &ix, const std::string &path, std::string &err)
+{
+	FILE *fp = fopen(path.c_str(), "wb");
+	if (!fp) { err = "cannot write '" + path + "'"; return -1; }
+	const uint32_t hdr[5] = { (uint32_t)ix.w, (uint32_t)ix.k, (uint32_t)MMI_B, (uint32_t)ix.seq.size(), (uint32_t)ix.flag };
+	fwrite("MMI\2", 1, 4, fp);
+	fwrite(hdr, 4, 5, fp);
+	for (const RefSeq &r : ix.seq) {
+		const uint8_t l = (uint8_t)std::min<size_t>(r.name.size(), 255);
+		fwrite(&l, 1, 1, fp);
+		fwrite(r.name.data(), 1, l, fp);
+		fwrite(&r.len, 4, 1, fp);
+	}
+	// distribute the keys over the 2^b buckets
+	const uint64_t mask = ((uint64_t)1 << MMI_B) - 1;
+	std::vector<std::vector<uint64_t>> slots((size_t)1 << MMI_B);        // table slots per bucket
+	for (size_t s = 0; s < ix.hkey.size(); ++s) if (ix.hkey[s] != ~0ULL) slots[ix.hkey[s] & mask].push_back(s);
+	std::vector<uint64_t> p, kv;
+	for (size_t b = 0; b < slots.size(); ++b) {
+		p.clear(); kv.clear();
+		std::sort(slots[b].begin(), slots[b].end(), [&](uint64_t x, uint64_t y) { return ix.hkey[x] < ix.hkey[y]; });
+		for (uint64_t s : slots[b]) {
+			const uint64_t first = ix.hval[s] >> 32, cnt = ix.hval[s] & 0xffffffffu, key = ix.hkey[s] >> MMI_B << 1;
+			if (cnt == 1) { kv.push_back(key | 1); kv.push_back(ix.P[first]); }
+			else { kv.push_back(key); kv.push_back((uint64_t)p.size() << 32 | cnt); for (uint64_t k = 0; k < cnt; ++k) p.push_back(ix.P[first + k]); }
+		}
+		const uint32_t n = (uint32_t)p.size(), size = (uint32_t)(kv.size() / 2);
+		fwrite(&n, 4, 1, fp);
+		fwrite(p.data(), 8, n, fp);
+		fwrite(&size, 4, 1, fp);
+		fwrite(kv.data(), 8, kv.size(), fp);
+	}
+	fwrite(ix.S.data(), 4, (ix.total_len + 7) / 8, fp);
+	{   // trailer: the bloom filter
+		const uint64_t t[4] = { ix.bloom.table_bits, (uint64_t)ix.bloom.salt[0] | (uint64_t)ix.bloom.salt[1] << 32, ix.bloom.n_inserted, (uint64_t)ix.bloom.bits.size() };
+		fwrite("WMB1", 1, 4, fp);
+		fwrite(t, 8, 4, fp);
+		fwrite(ix.bloom.bits.data(), 1, ix.bloom.bits.size(), fp);
+	}
+	const bool ok = fflush(fp) == 0 && !ferror(fp);
+	fclose(fp);
+	if (!ok) { err = "write error on '" + path + "'"; return -1; }
+	return 0;
+}
+
+// kmer_file: the -W list to rebuild the bloom filter from when the file has no trailer (an index written by the reference);
+// empty = keep an empty filter (no down-weighting of the READS' minimizers)
+int index_load_mmi(const std::string &path, const std::string &kmer_file, Index &ix, std::string &err)
+{
+	FILE *fp = fopen(path.c_str(), "rb");
+	if (!fp) { err = "cannot read '" + path + "'"; return -1; }
+	auto bad = [&](const char *what) { err = std::string("'") + path + "': " + what; fclose(fp); return -1; };
+	char magic[4];
+	uint32_t hdr[5];
+	if (fread(magic, 1, 4, fp) != 4 || memcmp(magic, "MMI\2", 4) != 0) return bad("not an MMI\\2 index");
+	if (fread(hdr, 4, 5, fp) != 5) return bad("truncated header");
+	ix = Index();
+	ix.w = (int)hdr[0]; ix.k = (int)hdr[1]; ix.flag = (int)hdr[4];
+	const int b = (int)hdr[2];
+	if (b < 1 || b > 28) return bad("bad bucket bits");
+	uint64_t sum = 0;
+	for (uint32_t i = 0; i < hdr[3]; ++i) {
+		uint8_t l;
+		RefSeq r;
+		if (fread(&l, 1, 1, fp) != 1) return bad("truncated sequence table");
+		r.name.resize(l);
+		if (l && fread(&r.name[0], 1, l, fp) != l) return bad("truncated sequence table");
+		if (fread(&r.len, 4, 1, fp) != 1) return bad("truncated sequence table");
+		r.offset = sum; sum += r.len;
+		ix.seq.push_back(r);
+	}
+	ix.total_len = sum;
+	std::vector<m128> all;
+	std::vector<uint64_t> p, kv;
+	for (uint64_t bi = 0; bi < ((uint64_t)1 << b); ++bi) {
+		uint32_t n, size;
+		if (fread(&n, 4, 1, fp) != 1) return bad("truncated bucket");
+		p.resize(n);
+		if (n && fread(p.data(), 8, n, fp) != n) return bad("truncated bucket");
+		if (fread(&size, 4, 1, fp) != 1) return bad("truncated bucket");
+		kv.resize((size_t)size * 2);
+		if (size && fread(kv.data(), 8, kv.size(), fp) != kv.size()) return bad("truncated bucket");
+		for (uint32_t j = 0; j < size; ++j) {
+			const uint64_t key = kv[2 * j], val = kv[2 * j + 1];
+			const uint64_t minier = (key >> 1) << b | bi;
+			if (key & 1) { m128 e; e.x = minier << 8; e.y = val; all.push_back(e); }
+			else {
+				const uint64_t st = val >> 32, cnt = val & 0xffffffffu;
+				if (st + cnt > n) return bad("corrupt bucket");
+				for (uint64_t k = 0; k < cnt; ++k) { m128 e; e.x = minier << 8; e.y = p[st + k]; all.push_back(e); }
+			}
+		}
+	}
+	ix.S.assign((sum + 7) / 8 + 1, 0);
+	if (!(ix.flag & 2) && fread(ix.S.data(), 4, (sum + 7) / 8, fp) != (sum + 7) / 8) return bad("truncated sequence");   // MM_I_NO_SEQ = 2
+	index_table_from_minimizers(ix, all);
+	// bloom filter: our trailer, else rebuild from the -W list
+	char tg[4];
+	bool have_bloom = false;
+	if (fread(tg, 1, 4, fp) == 4 && memcmp(tg, "WMB1", 4) == 0) {
+		uint64_t t[4];
+		if (fread(t, 8, 4, fp) != 4) return bad("truncated bloom trailer");
+		ix.bloom.table_bits = t[0]; ix.bloom.salt[0] = (uint32_t)t[1]; ix.bloom.salt[1] = (uint32_t)(t[1] >> 32); ix.bloom.n_inserted = t[2];
+		ix.bloom.bits.resize(t[3]);
+		if (t[3] && fread(ix.bloom.bits.data(), 1, t[3], fp) != t[3]) return bad("truncated bloom trailer");
+		have_bloom = true;
+	}
+	fclose(fp);
+	if (!have_bloom) {
+		std::vector<uint64_t> kms;
+		std::string last;
+		if (!kmer_file.empty()) {
+			std::ifstream in(kmer_file);
+			std::string km;
+			uint64_t freq;
+			while (in >> km >> freq) { kms.push_back(encode_kmer(km.c_str(), (int)km.size())); last = km; }
+		}
+		if (!kms.empty() && (int)last.size() != ix.k) { err = "input list of k-mers and the index's k are inconsistent"; return -1; }
+		ix.bloom.init(kms.size());
+		for (uint64_t km : kms) ix.bloom.insert(km);
 	}
 	return 0;
 }

@@ -48,4 +48,9 @@ int index_build(const IdxOpt &io, const std::vector<std::string> &names, const s
                 const std::string &kmer_file, int n_threads, Index &out, std::string &err);
 int index_build_from_fasta(const IdxOpt &io, const std::string &fasta, const std::string &kmer_file, int n_threads, Index &out, std::string &err);
 
+void index_table_from_minimizers(Index &ix, std::vector<m128> &all);
+// the reference's index file format (winnowmap -d): written by either program, read by either program
+int index_save_mmi(const Index &ix, const std::string &path, std::string &err);
+int index_load_mmi(const std::string &path, const std::string &kmer_file, Index &ix, std::string &err);
+
 } // namespace wm

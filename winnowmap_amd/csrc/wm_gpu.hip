@@ -728,6 +728,24 @@ extern "C" int wm_index_build(const char *fasta, const char *kmer_file, int k, i
 }
 extern "C" void wm_index_destroy(wm_index_t *h) { delete h; }
 
+// the reference's index file ("MMI\2", winnowmap -d; src/index.c:515-608): interchangeable in both directions
+extern "C" int wm_index_save(const wm_index_t *h, const char *path)
+{
+	std::string err;
+	if (!h) return set_err(WM_EINVAL, "null index");
+	if (wm::index_save_mmi(h->ix, path, err) < 0) return set_err(WM_EINVAL, "%s", err.c_str());
+	return WM_OK;
+}
+extern "C" int wm_index_load(const char *path, const char *kmer_file, wm_index_t **out)
+{
+	*out = 0;
+	std::string err;
+	wm_index_t *h = new wm_index_t();
+	if (wm::index_load_mmi(path, kmer_file ? kmer_file : "", h->ix, err) < 0) { delete h; return set_err(WM_EINVAL, "%s", err.c_str()); }
+	*out = h;
+	return WM_OK;
+}
+
 namespace wm { int write_repetitive_kmers(const std::vector<std::string> &seqs, int k, double distinct, const std::string &out_path, uint64_t *n_out, std::string &err); }
 // the -W list of a FASTA file (what `meryl count k=15` + `meryl print greater-than distinct=0.9998` would give)
 extern "C" int wm_write_repetitive_kmers(const char *fasta, int k, double distinct, const char *out_path, uint64_t *n_out)

@@ -206,6 +206,21 @@ class Index:
         _chk(L.wm_index_import(sizes.ctypes.data, *[a.ctypes.data for a in arrs], C.byref(h)))
         return Index(_handle=h)
 
+    def save(self, path):
+        """write the reference's MMI index file format"""
+        L = lib()
+        L.wm_index_save.argtypes = [C.c_void_p, C.c_char_p]
+        _chk(L.wm_index_save(self._h, path.encode()))
+
+    @staticmethod
+    def load(path, kmer_file=None):
+        L = lib()
+        _bind_map(L)
+        L.wm_index_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        h = C.c_void_p()
+        _chk(L.wm_index_load(path.encode(), kmer_file.encode() if kmer_file else None, C.byref(h)))
+        return Index(_handle=h)
+
     def upload(self, ctx):
         _chk(lib().wm_index_upload(ctx._h, self._h))
 
