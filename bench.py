@@ -180,10 +180,13 @@ def main():
     # ---- reads: a fresh batch per step, generated before the clock starts ----
     t1 = time.time()
     n_steps = args.warmup + args.steps
-    reads, _ = synth.make_reads(ref, n_steps * args.reads_per_step, args.read_len, 4 + 1000 * rank, profile="ont", sv_frac=0.01)
+    n_distinct = min(n_steps, int(os.environ.get("WM_BENCH_DISTINCT_BATCHES", 4)))   # later steps cycle through these (mapping is stateless)
+    reads, _ = synth.make_reads(ref, n_distinct * args.reads_per_step, args.read_len, 4 + 1000 * rank, profile="ont", sv_frac=0.01)
     seqs = [synth.codes_to_ascii(r) for r in reads]
+    del reads
     names = [("r%d_%d" % (rank, i)).encode() for i in range(len(seqs))]
-    batches = [(names[i * args.reads_per_step:(i + 1) * args.reads_per_step], seqs[i * args.reads_per_step:(i + 1) * args.reads_per_step]) for i in range(n_steps)]
+    distinct = [(names[i * args.reads_per_step:(i + 1) * args.reads_per_step], seqs[i * args.reads_per_step:(i + 1) * args.reads_per_step]) for i in range(n_distinct)]
+    batches = [distinct[i % n_distinct] for i in range(n_steps)]
     log("rank %d: %d reads generated (%.1fs), %d host threads" % (rank, len(seqs), time.time() - t1, n_threads))
 
     def sync():
