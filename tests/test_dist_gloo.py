@@ -67,3 +67,73 @@ def test_index_broadcast_and_read_sharding_world2():
     assert sorted(m0 + m1) == list(range(37)) and not set(m0) & set(m1)
     assert t0 == t1 == 2.0                                   # max over ranks
     assert s0 == s1 == [37.0, 300.0]                         # sum over ranks
+
+
+def _map_worker(rank, world, port, tmp, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    import e2e_common as E
+    import wmtest as W
+    from winnowmap_amd import gpu, build
+    from winnowmap_amd import dist as wmdist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    preset, fa, kf, k, reads = E.make_golden.inputs("ont_short", os.path.join(tmp, "r%d" % rank))   # (seeded: every rank regenerates the same reads)
+    idx = gpu.Index(fa, kf, k=k, w=50, n_threads=2) if rank == 0 else None
+    idx = wmdist.broadcast_index(idx, rank, dist, torch.device("cpu"))
+    # the received index drives the HOST mapper of this rank (oracle-backed device ops: no GPU here) on this rank's shard of the reads
+    mmi = os.path.join(tmp, "rank%d.mmi" % rank)
+    idx.save(mmi)
+    H = C.CDLL(build.build_harness())
+    H.h_index_load_mmi.restype = C.c_void_p
+    H.h_index_load_mmi.argtypes = [C.c_char_p, C.c_char_p]
+    H.h_map.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_int, C.c_char_p, W.i32p, C.c_int, W.u32p, C.c_int64, C.POINTER(C.c_int64), W.u64p]
+    h = H.h_index_load_mmi(mmi.encode(), b"")
+    out = {}
+    for i in wmdist.shard(len(reads), rank, world):
+        s = reads[i]
+        ho = np.zeros(16 * 256, np.int32); co = np.zeros(2000000, np.uint32); nc = C.c_int64(); st = np.zeros(4, np.uint64)
+        n = H.h_map(h, preset.encode(), 0x4 | 0x20, s, len(s), ("read%d" % i).encode(), ho, 256, co, len(co), C.byref(nc), st)
+        out[i] = (ho[:16 * n].reshape(-1, 16).copy(), co[:nc.value].copy())
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_mapping_with_broadcast_index_world2():
+    """world_size 2: rank 0 builds the index, gloo broadcasts it, each rank maps its shard with the received index; the union
+    of the shards equals the reference's golden result for the whole batch."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import e2e_common as E
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    tmp = tempfile.mkdtemp()
+    for r in range(2):
+        os.makedirs(os.path.join(tmp, "r%d" % r))
+    port = _free_port()
+    ps = [ctx.Process(target=_map_worker, args=(r, 2, port, tmp, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict()
+    for _ in ps:
+        rank, out = q.get(timeout=600)
+        res.update(out)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    gh, gc, gf = E.golden("ont_short")
+    assert sorted(res) == list(range(len(gf) - 1))
+    co = 0
+    for i in range(len(gf) - 1):
+        hits, cig = res[i]
+        want = gh[gf[i]:gf[i + 1]]
+        hits[:, 6] = 0
+        assert np.array_equal(hits, want), i
+        nc = int(want[:, 7].sum())
+        assert np.array_equal(cig, gc[co:co + nc]), i
+        co += nc
