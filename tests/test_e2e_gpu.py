@@ -122,3 +122,47 @@ def test_map_file_pipeline(ctx):
     assert open(outp, "rb").read() == expect and expect.count(b"\n") >= len(reads)
     m.close()
     idx.close()
+
+
+def test_workload_scale_properties(ctx):
+    """Size-independent properties on a bench-shaped batch (2048 x 15 kb ONT reads vs 20 Mb with repeats, -W, several host
+    threads and groups): every CIGAR consumes exactly its query and reference intervals, intervals are inside the sequences,
+    the primary hit of (almost) every read lands on its true origin and strand, and mapping the batch twice is deterministic."""
+    from winnowmap_amd import synth
+    import os
+    tmp = tempfile.mkdtemp()
+    ref = synth.make_reference(2, 10_000_000, 3, repeat_frac=0.10)
+    fa = os.path.join(tmp, "ref.fa")
+    synth.write_fasta(fa, ref, prefix="ctg")
+    kf = os.path.join(tmp, "rep.txt")
+    assert gpu.write_repetitive_kmers(fa, 15, kf) > 0
+    idx = gpu.Index(fa, kf, k=15, w=50, n_threads=16)
+    idx.upload(ctx)
+    m = gpu.Mapper(ctx, idx, "map-ont", gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
+    m.set_threads(16, 6 << 30)
+    reads, truth = synth.make_reads(ref, 2048, 15000, 4, profile="ont", sv_frac=0.01)
+    seqs = [synth.codes_to_ascii(r) for r in reads]
+    names = ["r%d" % i for i in range(len(seqs))]
+    text, hits, cigars, first = m.map(names, seqs)
+    text2, hits2, cigars2, first2 = m.map(names, seqs)
+    assert text == text2 and np.array_equal(hits, hits2) and np.array_equal(cigars, cigars2)
+    # CIGAR consistency
+    ops = cigars & 0xf
+    lens = (cigars >> 4).astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(hits[:, 7])])
+    cq = np.concatenate([[0], np.cumsum(np.where(np.isin(ops, (0, 1, 7, 8)), lens, 0))])
+    cr = np.concatenate([[0], np.cumsum(np.where(np.isin(ops, (0, 2, 3, 7, 8)), lens, 0))])
+    qc, rc = cq[off[1:]] - cq[off[:-1]], cr[off[1:]] - cr[off[:-1]]
+    has = hits[:, 7] > 0
+    assert np.array_equal(qc[has], (hits[:, 4] - hits[:, 3])[has]) and np.array_equal(rc[has], (hits[:, 2] - hits[:, 1])[has])
+    assert (hits[:, 3] >= 0).all() and (hits[:, 4] <= 15000).all() and (hits[:, 1] >= 0).all() and (hits[:, 2] <= 10_000_000).all()
+    # recall against the generator's truth: the first (primary) hit of a read overlaps its origin on the right strand
+    ok = 0
+    for i, (ci, st, strand) in enumerate(truth):
+        if first[i + 1] == first[i]:
+            continue
+        h = hits[first[i]]
+        ok += int(h[0] == ci and h[5] == strand and h[1] < st + 17000 and h[2] > st)
+    assert ok >= 0.97 * len(truth), ok
+    m.close()
+    idx.close()
