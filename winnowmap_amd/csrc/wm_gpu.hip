@@ -392,8 +392,24 @@ extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int 
 		b->class_cells[d.klass] += bands[i];
 		b->order[d.klass].push_back(i);
 	}
-	for (int k = 0; k < WM_KSW_NCLASS; ++k)
-		std::sort(b->order[k].begin(), b->order[k].end(), [&](int x, int y) { return cells[x] != cells[y] ? cells[x] > cells[y] : x < y; });
+	// inside a class the largest jobs go first (they bound the kernel's duration). Only the coarse order matters, so this is a
+	// stable counting sort on a 7-bit logarithmic size key (exponent + 1 mantissa bit), not a comparison sort of ~10^6 jobs
+	{
+		auto size_key = [&](int j) { const uint64_t v = cells[j] | 1; const int e = 63 - __builtin_clzll(v); return 2 * e + (int)(e > 0 ? (v >> (e - 1)) & 1 : 0); };
+		std::vector<int> tmp;
+		for (int k = 0; k < WM_KSW_NCLASS; ++k) {
+			std::vector<int> &o = b->order[k];
+			if (o.size() < 2) continue;
+			int cnt[130];
+			memset(cnt, 0, sizeof(cnt));
+			for (int j : o) ++cnt[size_key(j)];
+			int pos[130], acc = 0;
+			for (int kk = 129; kk >= 0; --kk) { pos[kk] = acc; acc += cnt[kk]; }      // descending keys
+			tmp.resize(o.size());
+			for (int j : o) tmp[pos[size_key(j)]++] = j;
+			o.swap(tmp);
+		}
+	}
 	// device buffers
 	const size_t nj = n_jobs > 0 ? n_jobs : 1;
 	b->d_jobs = (wm_ksw_djob_t*)arena_take(c, nj * sizeof(wm_ksw_djob_t));
