@@ -3,7 +3,8 @@ import numpy as np
 from winnowmap_amd import synth
 
 FLAGS = [0x08, 0x00, 0x40, 0xC2, 0x42, 0x80]          # combinations used by src/align.c (+ two extras)
-PRESETS = [(2, 4, 4, 2, 24, 1), (1, 4, 6, 2, 26, 1), (2, 4, 4, 2, 4, 2)]   # (a,b,q,e,q2,e2): map-ont, asm20, single-affine
+PRESETS = [(2, 4, 4, 2, 24, 1), (1, 4, 6, 2, 26, 1), (2, 4, 4, 2, 4, 2),   # (a,b,q,e,q2,e2): map-ont, asm20, single-affine,
+           (1, 19, 39, 3, 81, 1), (1, 9, 16, 2, 41, 1)]                       # asm5, asm10 (src/options.c:104-111; large penalties: int8 wrap-around)
 
 
 def make_cases(seed, n, max_len=700, preset=None):
@@ -23,7 +24,7 @@ def make_cases(seed, n, max_len=700, preset=None):
             q[rng.integers(0, len(q))] = 4
         if it % 11 == 0:
             t[rng.integers(0, len(t))] = 4
-        pr = PRESETS[it % 3] if preset is None else PRESETS[preset]
+        pr = PRESETS[it % len(PRESETS)] if preset is None else PRESETS[preset]
         out.append(dict(q=q, t=t, a=pr[0], b=pr[1], q_=pr[2], e=pr[3], q2=pr[4], e2=pr[5],
                         w=[751, 3001, 50, 10, 200, -1, 5][it % 7], zdrop=[400, 200, 25, 50, -1][it % 5],
                         end_bonus=[-1, 10, 0][it % 3], flag=FLAGS[it % 6]))

@@ -33,7 +33,7 @@ def test_ksw_emulated_kernel_matches_oracle(emu, seed):
     for c in kswcases.make_cases(seed, 90, max_len=600):
         o = W.o_ksw_extd2(c["q"], c["t"], mat=W.simple_mat(c["a"], c["b"], 1), q=c["q_"], e=c["e"], q2=c["q2"], e2=c["e2"],
                           w=c["w"], zdrop=c["zdrop"], end_bonus=c["end_bonus"], flag=c["flag"])
-        for force in (-1, 3, 7, 11):          # host's choice, then the CLIP+HASN variant of every window size
+        for force in (-1, 3, 7, 11, 203, 211):   # host's choice, the CLIP+HASN variant of every window size, and the blocked-layout kernel
             n, ez, cig, klass = emu_ksw(emu, c, force)
             if n < 0:
                 continue

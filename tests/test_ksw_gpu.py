@@ -33,7 +33,7 @@ def _run_group(ctx, cases):
     return bad
 
 
-@pytest.mark.parametrize("preset", [0, 1, 2])
+@pytest.mark.parametrize("preset", [0, 1, 2, 3, 4])
 def test_random_cases_all_flags(ctx, preset):
     cases = kswcases.make_cases(100 + preset, 240, max_len=900, preset=preset)
     bad = _run_group(ctx, cases)
