@@ -122,6 +122,7 @@ void *h_index_build(const char *fasta, const char *kmer_file, int k, int w, int 
 	for (uint64_t x : kms) wmo_bloom_insert(h->bloom, x);
 	return h;
 }
+int h_getseq(void *hv, uint32_t rid, uint32_t st, uint32_t en, uint8_t *out) { return ((Harness*)hv)->idx.getseq(rid, st, en, out); }
 uint64_t h_index_n_minimizers(void *hv) { return ((Harness*)hv)->idx.n_minimizers; }
 int h_index_get(void *hv, uint64_t minier, uint64_t *out, int cap)
 {

@@ -150,7 +150,20 @@ int Index::getseq(uint32_t rid, uint32_t st, uint32_t en, uint8_t *out) const
 	if (rid >= seq.size() || st >= seq[rid].len) return -1;
 	if (en > seq[rid].len) en = seq[rid].len;
 	const uint64_t o = seq[rid].offset;
-	for (uint64_t i = o + st; i < o + en; ++i) out[i - o - st] = (uint8_t)(S[i >> 3] >> ((i & 7) << 2) & 0xf);
+	uint64_t i = o + st;
+	const uint64_t e = o + en;
+	uint8_t *d = out;
+	for (; i < e && (i & 7); ++i) *d++ = (uint8_t)(S[i >> 3] >> ((i & 7) << 2) & 0xf);         // up to a word boundary
+	for (; i + 8 <= e; i += 8, d += 8) {                                                     // one packed word = 8 bases
+		const uint32_t wv = S[i >> 3];
+		const uint64_t lo = wv & 0xffffu, hi = wv >> 16;
+		// spread the 4 nibbles of a half word into 4 bytes
+		uint64_t a = (lo | lo << 8) & 0x00ff00ffULL; a = (a | a << 4) & 0x0f0f0f0fULL;
+		uint64_t b = (hi | hi << 8) & 0x00ff00ffULL; b = (b | b << 4) & 0x0f0f0f0fULL;
+		const uint64_t v = a | b << 32;
+		memcpy(d, &v, 8);
+	}
+	for (; i < e; ++i) *d++ = (uint8_t)(S[i >> 3] >> ((i & 7) << 2) & 0xf);
 	return (int)(en - st);
 }
 

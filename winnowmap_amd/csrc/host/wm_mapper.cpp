@@ -136,13 +136,14 @@ void stage2(Scheduler &sch, const Index &idx, const MapOpt &opt, ReadTask &T)
 	const uint32_t hash = read_hash(qname, L, o3.seed);
 	std::vector<m128> a;
 	int rep_len = 0;   // NB: the reference leaves this uninitialised on the pure-MCAS path (src/map.c:281); 0 is our defined value
+	{ WM_PROF("map.stage2_merge");
 	for (const auto &v : T.collect) a.insert(a.end(), v.begin(), v.end());
 	if (!a.empty()) {                                                  // merge, dedup, order (src/map.c:739-781)
 		std::sort(a.begin(), a.end(), [](const m128 &p, const m128 &q) { return std::tie(p.x, p.y) < std::tie(q.x, q.y); });
 		a.erase(std::unique(a.begin(), a.end(), [](const m128 &p, const m128 &q) { return p.x == q.x && p.y == q.y; }), a.end());
 		radix_sort_128x(a.data(), a.data() + a.size());
 		if ((int)a.size() < o3.min_cnt) a.clear();
-	}
+	} }
 	size_t unmapped = 0;
 	for (int i = 0; i < L; ++i) unmapped += T.mapped[i] == 0;
 	if (!a.empty() && unmapped > 0) {                                  // seeds from the stretches stage 1 left unmapped (:786-846)
