@@ -16,8 +16,12 @@ The reference index is built by rank 0 and broadcast with RCCL (torch.distribute
 host buffers for reads (the PCIe-inclusive figure is therefore what is reported).
 `roofline`: dominant kernel = ksw_dp (1 B of traceback per DP cell is > 99 % of the path's algorithmic bytes);
 achieved = DP cells of the timed steps ÷ the kernels' summed duration (HIP events on their streams).
-`cpu_baseline`: the REAL reference (oracle/_ref/winnowmap_ref, built from /root/reference) mapping a bounded sample of
-the same reads against the same reference on this host with -t <all cores>; mapping-phase wall time only.
+`cpu_baseline`: the REAL reference (oracle/_ref/winnowmap_ref, built from /root/reference) mapping ONE FULL STEP of the
+same reads against the same reference on this host, swept over thread counts; the BEST mapping-phase rate is reported.
+`parity`: the reference's PAF records for that step are diffed against ours for the same reads (every column and tag
+except MAPQ / rl:i, see winnowmap_amd/parity.py); outside the timed region.
+`--config 3` switches to BASELINE config 3 (50 000 x 20 kb HiFi reads, map-pb); config 2 stays the default.
+`--gpus N` without a torch.distributed environment re-launches itself under torch.distributed.run with N ranks.
 """
 import argparse
 import json
@@ -35,6 +39,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")   # before HIP initialises (see winnowmap_amd/__init__.py)
 from winnowmap_amd import gpu, synth  # noqa: E402
 from winnowmap_amd import dist as wmdist  # noqa: E402
+from winnowmap_amd import parity as wmparity  # noqa: E402
 
 
 def log(*a):
@@ -54,31 +59,92 @@ def make_workload(ref_mb, tmp):
     return ref, fa, kf
 
 
-def cpu_reference_baseline(fa, kf, reads, tmp, n_cores):
-    """Map a bounded sample with the real reference binary; mapping phase = Real time − 'loaded/built the index' stamp."""
+CONFIGS = {
+    # BASELINE.json configs[1] / configs[2]: reads per step = the reference's 1-Gbase mini-batch (-K 1G)
+    2: {"preset": "map-ont", "profile": "ont", "read_len": 15000, "reads_per_step": 65536, "sv_frac": 0.01, "seed": 4, "label": "ONT-profile"},
+    3: {"preset": "map-pb", "profile": "hifi", "read_len": 20000, "reads_per_step": 50000, "sv_frac": 0.0, "seed": 5, "label": "HiFi-profile"},
+}
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def run_reference(fa, kf, rq, preset, n_threads, out_path, sam=False):
+    """One run of the real reference binary; -> (mapping-phase seconds, index seconds, wall seconds) or None.
+    Mapping phase = 'Real time' (src/main.c:441) − the 'loaded/built the index' stamp (src/main.c:401)."""
     binp = os.path.join(ROOT, "oracle", "_ref", "winnowmap_ref")
-    if not os.path.exists(binp):
-        return None
-    rq = os.path.join(tmp, "sample.fa")
-    with open(rq, "wb") as f:
-        for i, s in enumerate(reads):
-            f.write(b">s%d\n" % i)
-            f.write(s)
-            f.write(b"\n")
+    cmd = [binp, "-t", str(n_threads), "-W", kf, "-ax" if sam else "-cx", preset, fa, rq]
     t0 = time.time()
-    p = subprocess.run([binp, "-t", str(n_cores), "-W", kf, "-ax", "map-ont", fa, rq], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    with open(out_path, "wb") as fo:
+        p = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE)
     wall = time.time() - t0
     err = p.stderr.decode(errors="ignore")
     m_idx = re.search(r"\[M::main::([0-9.]+)\*[0-9.]+\] loaded/built the index", err)
     m_end = re.search(r"Real time: ([0-9.]+) sec", err)
     if p.returncode != 0 or not m_idx or not m_end:
-        log("reference baseline failed (rc=%d)" % p.returncode)
+        log("reference run failed (rc=%d): %s" % (p.returncode, err[-300:]))
         return None
-    t_map = float(m_end.group(1)) - float(m_idx.group(1))
-    bases = sum(len(s) for s in reads)
-    log("reference CPU baseline: %d reads, index %.1fs, mapping %.2fs on %d threads (wall %.1fs)" % (len(reads), float(m_idx.group(1)), t_map, n_cores, wall))
-    return {"value": bases / t_map / 1e9, "unit": "Gbp/s", "cores": n_cores, "kind": "reference",
-            "sample": "%d x 15 kb reads of the same workload, winnowmap_ref -t %d -W -ax map-ont, mapping phase %.2f s (index build %.1f s excluded)" % (len(reads), n_cores, t_map, float(m_idx.group(1)))}
+    return float(m_end.group(1)) - float(m_idx.group(1)), float(m_idx.group(1)), wall
+
+
+def write_reads_fasta(path, names, seqs):
+    with open(path, "wb") as f:
+        for n, s in zip(names, seqs):
+            f.write(b">" + n + b"\n")
+            f.write(s)
+            f.write(b"\n")
+
+
+def cpu_thread_candidates(n_cores):
+    """Thread counts of the baseline sweep: WM_BENCH_CPU_THREADS="64,128" overrides; default = the two best of the full sweep
+    recorded in profiles/ (tools/cpu_sweep.py) if it was made on a host of this size, else {cores/2, cores}."""
+    env = os.environ.get("WM_BENCH_CPU_THREADS")
+    if env:
+        return [int(x) for x in env.split(",") if x]
+    try:
+        with open(os.path.join(ROOT, "profiles", "cpu_sweep.json")) as f:
+            sw = json.load(f)
+        if sw.get("host_threads") == n_cores and sw.get("best_threads"):
+            return [int(x) for x in sw["best_threads"][:2]]
+    except Exception:  # noqa: BLE001
+        pass
+    return sorted({max(1, n_cores // 2), n_cores})
+
+
+def cpu_reference_baseline(fa, kf, names, seqs, preset, tmp, n_cores):
+    """Map one full step with the real reference binary (PAF + CIGAR, like the timed GPU path) at each candidate thread
+    count; report the BEST mapping-phase rate. Returns (cpu_baseline dict, path of the reference's PAF)."""
+    binp = os.path.join(ROOT, "oracle", "_ref", "winnowmap_ref")
+    if not os.path.exists(binp):
+        return None, None
+    rq = os.path.join(tmp, "step.fa")
+    write_reads_fasta(rq, names, seqs)
+    bases = sum(len(s) for s in seqs)
+    best = None
+    table = []
+    for t in cpu_thread_candidates(n_cores):
+        outp = os.path.join(tmp, "ref_t%d.paf" % t)
+        r = run_reference(fa, kf, rq, preset, t, outp)
+        if r is None:
+            continue
+        table.append({"threads": t, "map_s": round(r[0], 3), "gbps": bases / r[0] / 1e9})
+        log("reference CPU baseline: %d reads, -t %d: index %.1fs, mapping %.2fs (wall %.1fs) = %.4f Gbp/s" % (len(seqs), t, r[1], r[0], r[2], bases / r[0] / 1e9))
+        if best is None or r[0] < best[0]:
+            best = (r[0], t, outp, r[1])
+    if best is None:
+        return None, None
+    t_map, t_best, outp, t_idx = best
+    return {"value": bases / t_map / 1e9, "unit": "Gbp/s", "cores": t_best, "kind": "reference", "cpu": cpu_model(), "host_threads": n_cores, "sweep": table,
+            "sample": "one full step (%d reads, %.2f Gbase) of the same workload, winnowmap_ref -t %d -W -cx %s (PAF+CIGAR as in the timed GPU path), "
+                      "mapping phase %.2f s = best of the -t sweep (index build %.1f s excluded)" % (len(seqs), bases / 1e9, t_best, preset, t_map, t_idx)}, outp
 
 
 KSW_CLASS_NAMES = {0: "ksw_dps_kernel<4,...>", 4: "ksw_dps_kernel<8,...>", 8: "ksw_dps_kernel<16,...>", 12: "ksw_multi_kernel<8>", 13: "ksw_multi_kernel<16>",
@@ -117,8 +183,8 @@ def make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1):
         "metric": "mapped Gbp/s", "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int8", "data": "synthetic",
-        "config": {"workload": "%d x %d bp ONT-profile reads per step per GPU vs %.0f Mb synthetic reference (10%% repeats), -W repetitive_k15.txt -x map-ont, CIGAR on"
-                               % (args.reads_per_step, args.read_len, args.ref_mb),
+        "config": {"workload": "BASELINE config %d: %d x %d bp %s reads per step per GPU vs %.0f Mb synthetic reference (10%% repeats), -W repetitive_k15.txt -x %s, CIGAR on"
+                               % (args.config, args.reads_per_step, args.read_len, CONFIGS[args.config]["label"], args.ref_mb, CONFIGS[args.config]["preset"]),
                    "reads_per_step_per_gpu": args.reads_per_step, "read_len": args.read_len, "ref_mb": args.ref_mb, "host_threads": n_threads,
                    "reads_per_s": total_bases / args.read_len / elapsed, "hits": hits, "parallelism": "reads sharded over %d rank(s), index broadcast" % world},
         "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
@@ -135,33 +201,50 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads-per-step", type=int, default=int(os.environ.get("WM_BENCH_READS", 65536)))
+    ap.add_argument("--config", type=int, default=int(os.environ.get("WM_BENCH_CONFIG", 2)), choices=sorted(CONFIGS))
+    ap.add_argument("--reads-per-step", type=int, default=int(os.environ.get("WM_BENCH_READS", 0)))
     ap.add_argument("--ref-mb", type=float, default=float(os.environ.get("WM_BENCH_REF_MB", 250)))
-    ap.add_argument("--read-len", type=int, default=15000)
+    ap.add_argument("--read-len", type=int, default=0)
     ap.add_argument("--threads", type=int, default=int(os.environ.get("WM_BENCH_THREADS", 0)))
-    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("WM_BENCH_CPU_SAMPLE", 4096)))
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("WM_BENCH_CPU_SAMPLE", -1)),
+                    help="reads of the CPU baseline / parity leg: -1 = one full step, 0 = skip the leg")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    args.reads_per_step = args.reads_per_step or cfg["reads_per_step"]
+    args.read_len = args.read_len or cfg["read_len"]
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (one per GPU) — never run 1 rank and call it N
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit("bench.py: --gpus %d requested but %d GPU(s) are visible on this box" % (args.gpus, have))
+        sys.exit(wmdist.launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or plainly and let bench.py launch the ranks)" % (args.gpus, world, args.gpus))
     import torch
     dist = None
     if world > 1 or os.environ.get("WM_BENCH_FORCE_DIST"):     # (the env switch lets a 1-GPU box exercise the RCCL code path)
         import torch.distributed as dist
+        if torch.cuda.device_count() <= local:
+            sys.exit("bench.py: rank %d has no GPU %d (%d visible)" % (rank, local, torch.cuda.device_count()))
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl"
     n_cores = os.cpu_count() or 1
-    # host threads per rank: more than ~48 per process LOSES throughput on the 2 x 128-thread host (measured), 24-48 are equivalent
-    n_threads = args.threads or max(1, min(32, int(0.75 * n_cores / max(1, world))))
+    # host threads per rank: the ranks of one node share its cores — divide them explicitly
+    n_threads = args.threads or wmdist.host_threads_per_rank(n_cores, world)
     tmp = tempfile.mkdtemp(prefix="wmbench_")
 
     # ---- reference + index: rank 0 builds, RCCL broadcasts the flat arrays ----
     t0 = time.time()
     if rank == 0:
         ref, fa, kf = make_workload(args.ref_mb, tmp)
-        idx = gpu.Index(fa, kf, k=15, w=50, n_threads=min(64, n_cores))
+        idx = gpu.Index(fa, kf, k=15, w=50, n_threads=min(64, n_cores))      # map-ont and map-pb: k=15, w=50 (src/options.c:94-103)
         log("index: %d minimizers (%.1fs)" % (idx.n_minimizers, time.time() - t0))
     if dist is not None:
         dev = torch.device("cuda", local)
@@ -173,7 +256,7 @@ def main():
     arena = int(os.environ.get("WM_BENCH_ARENA_GB", 48)) << 30   # per group; 288 GB of HBM per GPU
     ctx = gpu.Context(local, arena)
     idx.upload(ctx)
-    mapper = gpu.Mapper(ctx, idx, "map-ont", gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
+    mapper = gpu.Mapper(ctx, idx, cfg["preset"], gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
     if n_threads > 1:
         mapper.set_threads(n_threads, arena)
 
@@ -181,7 +264,7 @@ def main():
     t1 = time.time()
     n_steps = args.warmup + args.steps
     n_distinct = min(n_steps, int(os.environ.get("WM_BENCH_DISTINCT_BATCHES", 4)))   # later steps cycle through these (mapping is stateless)
-    reads, _ = synth.make_reads(ref, n_distinct * args.reads_per_step, args.read_len, 4 + 1000 * rank, profile="ont", sv_frac=0.01)
+    reads, _ = synth.make_reads(ref, n_distinct * args.reads_per_step, args.read_len, cfg["seed"] + 1000 * rank, profile=cfg["profile"], sv_frac=cfg["sv_frac"])
     seqs = [synth.codes_to_ascii(r) for r in reads]
     del reads
     names = [("r%d_%d" % (rank, i)).encode() for i in range(len(seqs))]
@@ -216,13 +299,28 @@ def main():
 
     if rank == 0:
         out = make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1)
-        if world == 1 and args.cpu_sample > 0:
-            sample = [s for _, ss in batches[args.warmup:] for s in ss][:args.cpu_sample]
+        if dist is not None:
+            out["config"]["rccl_world_size"] = dist.get_world_size()
+        if world == 1 and args.cpu_sample != 0:
+            # one full step (the first timed batch) through the REAL reference on this host's cores: CPU baseline + parity
+            bn, bs = batches[args.warmup]
+            if args.cpu_sample > 0:
+                bn, bs = bn[:args.cpu_sample], bs[:args.cpu_sample]
             try:
-                out["cpu_baseline"] = cpu_reference_baseline(fa, kf, sample, tmp, n_cores)
+                out["cpu_baseline"], ref_paf = cpu_reference_baseline(fa, kf, bn, bs, cfg["preset"], tmp, n_cores)
+                if ref_paf:
+                    t2 = time.time()
+                    ours, _, _, _ = mapper.map(bn, bs, copy_text=True)
+                    with open(ref_paf, "rb") as f:
+                        d = wmparity.diff_texts(f.read(), ours, sam=False)
+                    out["parity"] = {"reads": len(bs), "reads_with_hits": d["reads"], "hits": d["hits"], "mismatches": d["mismatches"],
+                                     "compared": "PAF records incl. cg:Z CIGAR and all tags vs winnowmap_ref on the same reads; MAPQ and rl:i masked (reference UB, src/map.c:281)"}
+                    if d["examples"]:
+                        out["parity"]["examples"] = d["examples"]
+                    log("parity: %d reads, %d hits, %d mismatching reads (%.1fs)" % (len(bs), d["hits"], d["mismatches"], time.time() - t2))
             except Exception as e:  # noqa: BLE001
-                log("cpu baseline error:", e)
-                out["cpu_baseline"] = None
+                log("cpu baseline / parity error:", repr(e))
+                out.setdefault("cpu_baseline", None)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

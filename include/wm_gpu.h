@@ -167,6 +167,9 @@ int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, const char *co
  * orders each mini-batch like src/map.c:1124-1143, maps it and writes PAF/SAM records to out_path ("-" = stdout); reading,
  * mapping and writing overlap. stats (optional, 6 doubles): reads, bases, mini-batches, seconds reading / mapping / writing. */
 int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *out_path, int64_t mini_batch_bases, double *stats);
+/* argv of the calling front end: with MM_F_OUT_SAM, wm_map_file starts the file with the @SQ lines and the @PG line carrying this
+ * command line, as mm_write_sam_hdr does before mapping (src/format.c:118-139, src/main.c:393). Optional (no CL: field without it). */
+int wm_mapper_set_cmdline(wm_mapper_t *m, int argc, const char *const *argv);
 int wm_mapper_stats(const wm_mapper_t *m, uint64_t *out9);
 /* per ksw kernel class (B4/B8/B16 x CLIP x HASN register kernels, the two multi-wave LDS kernels, the generic kernel) since
  * wm_mapper_create: out[3k] = summed launch durations (ms, HIP events on the launching stream), out[3k+1] = DP cells,

@@ -137,3 +137,16 @@ def test_sharded_mapping_with_broadcast_index_world2():
         nc = int(want[:, 7].sum())
         assert np.array_equal(cig, gc[co:co + nc]), i
         co += nc
+
+
+def test_launcher_starts_n_ranks():
+    """bench.py's own launcher (winnowmap_amd.dist.launch_ranks, used for a plain `python bench.py --gpus N`): N ranks come up
+    with WORLD_SIZE == N and distinct LOCAL_RANKs; the host threads are divided between them."""
+    sys.path.insert(0, ROOT)
+    from winnowmap_amd import dist as wmdist
+    tmp = tempfile.mkdtemp()
+    rc = wmdist.launch_ranks(2, [os.path.join(ROOT, "tests", "dist_probe.py"), tmp])
+    assert rc == 0
+    seen = sorted(open(os.path.join(tmp, f)).read().split() for f in os.listdir(tmp))
+    assert seen == [["0", "2", "0"], ["1", "2", "1"]]
+    assert wmdist.host_threads_per_rank(256, 1) == 32 and wmdist.host_threads_per_rank(256, 8) == 24 and wmdist.host_threads_per_rank(4, 8) == 1

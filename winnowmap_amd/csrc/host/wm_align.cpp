@@ -1,6 +1,5 @@
 // wm_align.cpp — see wm_align.h.
 #include "wm_align.h"
-#include <assert.h>
 #include <math.h>
 #include <algorithm>
 #include <list>
@@ -262,7 +261,7 @@ static void fix_cigar(Reg &r, const uint8_t *qseq, const uint8_t *tseq, int *qsh
 			if (op == 1) qoff += len; else toff += len;
 		} else if (op == 3) toff += len;
 	}
-	assert(qoff == r.qe - r.qs && toff == r.re - r.rs);
+	WM_INVARIANT(qoff == r.qe - r.qs && toff == r.re - r.rs);
 	for (uint32_t k = 0; k + 2 < cg.size(); ++k) {                     // 5I6D7I → one I and one D
 		if ((cg[k] & 0xf) > 0 && (cg[k] & 0xf) + (cg[k + 1] & 0xf) == 3) {
 			uint32_t l, s[3] = {0, 0, 0};
@@ -336,7 +335,7 @@ static void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const
 		} else if (op == 3) toff += len;
 	}
 	r.dp_max = max;
-	assert(qoff == r.qe - r.qs && toff == r.re - r.rs);
+	WM_INVARIANT(qoff == r.qe - r.qs && toff == r.re - r.rs);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -441,7 +440,7 @@ static void plan_reg(const AlnEnv &E, RegAln &A, m128 *a, std::vector<KswReq> &j
 		if (re0 - r.re > max_ext) re0 = r.re + max_ext;
 		if (qe0 - r.qe > max_ext) qe0 = r.qe + max_ext;
 	}
-	assert(re0 > rs0);
+	WM_INVARIANT(re0 > rs0);
 	A.rs0 = rs0, A.qs0 = qs0, A.re0 = re0, A.qe0 = qe0;
 	const uint8_t *qs_strand = E.qseq0[A.rev];
 
@@ -552,7 +551,7 @@ static void finish_reg(const AlnEnv &E, RegAln &A, m128 *a, const std::vector<Ks
 			qe1 = A.qe + (j.ez.reach_end ? A.qe0 - A.qe : j.ez.max_q + 1);
 		}
 	}
-	assert(qe1 <= qlen);
+	WM_INVARIANT(qe1 <= qlen);
 	r.rs = rs1, r.re = re1;
 	if (A.rev) r.qs = qlen - qe1, r.qe = qlen - qs1;
 	else r.qs = qs1, r.qe = qe1;

@@ -1,5 +1,8 @@
 // wm_core.cpp — options/presets, exact-permutation sorts, small hashes (see wm_core.h for citations).
 #include "wm_core.h"
+#include <mutex>
+#include <string.h>
+#include <string>
 #include <math.h>
 #include <algorithm>
 
@@ -151,6 +154,22 @@ void prof_report(FILE *f)
 {
 	std::lock_guard<std::mutex> g(prof_mutex());
 	for (const ProfSlot &s : prof_slots()) fprintf(f, "[prof] %-28s %10.2f ms  %10llu calls\n", s.name, s.ms, (unsigned long long)s.n);
+}
+
+
+static std::mutex g_ie_mu;
+static std::string g_ie_msg;
+void note_internal_error(const char *expr, const char *file, int line)
+{
+	std::lock_guard<std::mutex> lk(g_ie_mu);
+	if (g_ie_msg.empty()) { const char *b = strrchr(file, '/'); g_ie_msg = std::string("internal invariant violated: ") + expr + " (" + (b ? b + 1 : file) + ":" + std::to_string(line) + ")"; }
+}
+bool take_internal_error(std::string &msg)
+{
+	std::lock_guard<std::mutex> lk(g_ie_mu);
+	if (g_ie_msg.empty()) return false;
+	msg.swap(g_ie_msg); g_ie_msg.clear();
+	return true;
 }
 
 } // namespace wm

@@ -99,6 +99,13 @@ extern const uint8_t *const nt4_table;                                  // seq_n
 // A pool of already-running threads that a batched operation may borrow (the scheduler team's members, idle while
 // member 0 issues the device calls): run(n, fn) executes fn(i) for i in [0, n) on the caller plus every thread
 // currently inside serve().
+// Library code never aborts (include/wm_gpu.h: "integer return codes"): a violated internal invariant — the places where the
+// reference has assert() (src/align.c:166, :282, :645, :782) — is recorded here (first one wins) and surfaced by the C-ABI entry
+// point as WM_EINTERNAL after the batch.
+void note_internal_error(const char *expr, const char *file, int line);
+bool take_internal_error(std::string &msg);          // true + message if one was recorded since the last call; clears it
+#define WM_INVARIANT(x) do { if (!(x)) ::wm::note_internal_error(#x, __FILE__, __LINE__); } while (0)
+
 class ParallelExec {
 public:
 	void run(size_t n, const std::function<void(size_t)> &fn)

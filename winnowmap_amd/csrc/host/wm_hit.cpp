@@ -1,7 +1,6 @@
 // wm_hit.cpp — see wm_hit.h. Host glue between the chaining kernel and the alignment kernels.
 #include "wm_hit.h"
 #include <math.h>
-#include <assert.h>
 #include <algorithm>
 
 namespace wm {

@@ -290,7 +290,7 @@ int index_save_mmi(const Index &ix, const std::string &path, std::string &err)
 		fwrite(&size, 4, 1, fp);
 		fwrite(kv.data(), 8, kv.size(), fp);
 	}
-	fwrite(ix.S.data(), 4, (ix.total_len + 7) / 8, fp);
+	if (!(ix.flag & 2)) fwrite(ix.S.data(), 4, (ix.total_len + 7) / 8, fp);      // MM_I_NO_SEQ: the reference's loader expects no S then (src/index.c:601)
 	{   // trailer: the bloom filter
 		const uint64_t t[4] = { ix.bloom.table_bits, (uint64_t)ix.bloom.salt[0] | (uint64_t)ix.bloom.salt[1] << 32, ix.bloom.n_inserted, (uint64_t)ix.bloom.bits.size() };
 		fwrite("WMB1", 1, 4, fp);
@@ -355,7 +355,7 @@ int index_load_mmi(const std::string &path, const std::string &kmer_file, Index 
 	if (!(ix.flag & 2) && fread(ix.S.data(), 4, (sum + 7) / 8, fp) != (sum + 7) / 8) return bad("truncated sequence");   // MM_I_NO_SEQ = 2
 	index_table_from_minimizers(ix, all);
 	// bloom filter: our trailer, else rebuild from the -W list
-	char tg[4];
+	char tg[4] = {0, 0, 0, 0};
 	bool have_bloom = false;
 	if (fread(tg, 1, 4, fp) == 4 && memcmp(tg, "WMB1", 4) == 0) {
 		uint64_t t[4];
@@ -364,7 +364,9 @@ int index_load_mmi(const std::string &path, const std::string &kmer_file, Index 
 		ix.bloom.bits.resize(t[3]);
 		if (t[3] && fread(ix.bloom.bits.data(), 1, t[3], fp) != t[3]) return bad("truncated bloom trailer");
 		have_bloom = true;
-	}
+	} else if (memcmp(tg, "MMI\2", 4) == 0 && !feof(fp))
+		// `winnowmap -d` concatenates one "MMI\2" part per -I batch of the reference (src/index.c:515-608 called per part, src/main.c)
+		return bad("multi-part index files are not supported (the reference was split by -I; rebuild with a larger -I)");
 	fclose(fp);
 	if (!have_bloom) {
 		std::vector<uint64_t> kms;

@@ -38,9 +38,14 @@ int write_repetitive_kmers(const std::vector<std::string> &seqs, int k, double d
 		std::sort(kmers.begin(), kmers.end());
 		for (size_t i = 0; i < kmers.size();) { size_t j = i; while (j < kmers.size() && kmers[j] == kmers[i]) ++j; uniq.push_back(std::make_pair(kmers[i], (uint32_t)(j - i))); bump((uint32_t)(j - i)); i = j; }
 	}
+	// threshold exactly as merylOp-nextMer.C:103-115: the target is TRUNCATED to an integer and only count values that occur are visited
 	uint64_t cum = 0, thr = 0;
-	const double target = distinct * (double)n_distinct;
-	for (size_t c = 0; c < hist.size(); ++c) { cum += hist[c]; if ((double)cum >= target) { thr = c; break; } }
+	const uint64_t target = (uint64_t)(distinct * (double)n_distinct);
+	for (size_t c = 1; c < hist.size(); ++c) {
+		if (hist[c] == 0) continue;
+		cum += hist[c];
+		if (cum >= target) { thr = c; break; }
+	}
 	FILE *fp = fopen(out_path.c_str(), "w");
 	if (!fp) { err = "cannot write " + out_path; return -1; }
 	uint64_t n = 0;

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <memory>
+#include <atomic>
 
 namespace wm {
 
@@ -31,8 +32,10 @@ int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_
 	Slot<std::string> to_write;
 	FileStats fs;
 	int rc = 0;
+	std::atomic<bool> stop(false), io_error(false);
 	std::thread reader([&]() {
 		for (;;) {
+			if (stop.load()) break;                                            // mapper or writer failed: stop parsing the input
 			const double t0 = now_s();
 			std::unique_ptr<Batch> b(new Batch());
 			if (rd.next_batch(mini_batch_bases, with_qual, *b) == 0) break;
@@ -52,17 +55,19 @@ int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_
 			std::unique_ptr<std::string> t = to_write.take();
 			if (!t) break;
 			const double t0 = now_s();
-			if (!t->empty()) fwrite(t->data(), 1, t->size(), out);
+			// a full disk / closed pipe must not yield a silently truncated file (the reference aborts in mm_err_puts)
+			if (!io_error.load() && !t->empty() && fwrite(t->data(), 1, t->size(), out) != t->size()) { io_error = true; stop = true; }
 			fs.t_write += now_s() - t0;
 		}
-		fflush(out);
+		if (fflush(out) != 0 || ferror(out)) io_error = true;
 	});
 	for (;;) {
 		std::unique_ptr<Batch> b = to_map.take();
 		if (!b) break;
 		const double t0 = now_s();
 		std::unique_ptr<std::string> text(new std::string());
-		if (rc == 0) rc = map_fn(*b, *text);                               // after an error: keep draining the reader
+		if (rc == 0 && !io_error.load()) rc = map_fn(*b, *text);          // after an error: drain what the reader already queued
+		if (rc != 0) stop = true;
 		fs.t_map += now_s() - t0;
 		fs.n_batches += 1; fs.n_reads += b->size();
 		for (const ReadIn &r : *b) fs.n_bases += r.seq.size();
@@ -73,6 +78,7 @@ int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_
 	writer.join();
 	if (st) *st = fs;
 	if (rc) err = "mapping failed";
+	else if (io_error.load()) { err = "write error on the output file"; rc = -2; }
 	return rc;
 }
 

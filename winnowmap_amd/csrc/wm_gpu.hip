@@ -1191,6 +1191,7 @@ struct wm_mapper_s {
 	std::string text;
 	std::vector<int32_t> hits; std::vector<uint32_t> cigars; std::vector<int64_t> first;
 	uint64_t stats[9];
+	std::vector<std::string> cmdline;      // argv of the front end, for the @PG line of SAM files (wm_mapper_set_cmdline)
 };
 
 extern "C" int wm_mapper_create(wm_ctx_t *c, const wm_index_t *idx, const char *preset, int64_t flag, wm_mapper_t **out)
@@ -1283,6 +1284,7 @@ static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double
 		work(0);
 		for (auto &x : th) x.join();
 	}
+	{ std::string ie; if (wm::take_internal_error(ie)) return set_err(WM_EINTERNAL, "%s", ie.c_str()); }
 	wm::MapStats st;
 	GpuOps tot; tot.c = m->c;
 	for (int t = 0; t < T; ++t) {
@@ -1332,11 +1334,26 @@ static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double
 // reference's default 1 Gbase), maps them and writes the records to out_path ("-" = stdout), reader / mapper / writer
 // overlapped. Every mini-batch is ordered like the reference orders it, so the file equals the reference's output.
 // stats (optional, 6 doubles): reads, bases, batches, seconds spent reading / mapping / writing.
+extern "C" int wm_mapper_set_cmdline(wm_mapper_t *m, int argc, const char *const *argv)
+{
+	if (!m || argc < 0 || (argc > 0 && !argv)) return set_err(WM_EINVAL, "bad argument");
+	m->cmdline.assign(argv, argv + argc);
+	return WM_OK;
+}
+
 extern "C" int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *out_path, int64_t mini_batch_bases, double *stats)
 {
+	g_err[0] = 0;
 	FILE *out = strcmp(out_path, "-") == 0 ? stdout : fopen(out_path, "wb");
 	if (!out) return set_err(WM_EINVAL, "cannot open '%s' for writing", out_path);
 	std::string err;
+	if (m->mo.flag & 0x8) {                                            // MM_F_OUT_SAM: @SQ / @PG lines first (mm_write_sam_hdr, src/main.c:393)
+		std::string hdr;
+		std::vector<const char*> av;
+		for (const std::string &a : m->cmdline) av.push_back(a.c_str());
+		wm::write_sam_header(hdr, m->idx->ix, (int)av.size(), av.data());
+		if (fwrite(hdr.data(), 1, hdr.size(), out) != hdr.size()) { if (out != stdout) fclose(out); return set_err(WM_EINVAL, "write error on '%s'", out_path); }
+	}
 	wm::FileStats fs;
 	const bool with_qual = (m->mo.flag & 0x8) != 0;                    // SAM output prints QUAL
 	const int rc = wm::map_file(reads_path, mini_batch_bases, with_qual, [&](std::vector<wm::ReadIn> &batch, std::string &text) {

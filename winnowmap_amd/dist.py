@@ -54,3 +54,28 @@ def sum_over_ranks(values, dist, device):
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [float(x) for x in t.tolist()]
+
+
+def host_threads_per_rank(n_cores, world):
+    """Host threads one rank's mapper uses: the ranks of a node share its cores, so they are divided explicitly
+    (0.75 of the hardware threads over the ranks, at most 32 per rank — more per process does not pay)."""
+    return max(1, min(32, int(0.75 * n_cores / max(1, world))))
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, script_argv, port=None, env=None):
+    """Run `script_argv` as n ranks of one node under torch.distributed.run (rendezvous on 127.0.0.1); returns its exit code.
+    bench.py uses this when it is started plainly with --gpus N; the gloo tests drive the same launcher on CPU."""
+    import subprocess
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port or free_port())] + list(script_argv)
+    return subprocess.call(cmd, env=env)

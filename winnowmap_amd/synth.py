@@ -135,10 +135,11 @@ def repetitive_kmers(contigs, k, distinct=0.9998):
     uniq, cnt = np.unique(km, return_counts=True)
     if len(uniq) == 0:
         return uniq, cnt
-    hist = np.bincount(cnt)
-    cum = np.cumsum(hist)
-    target = distinct * len(uniq)
-    thr = int(np.searchsorted(cum, target, side="left"))
+    # merylOp-nextMer.C:103-115: integer (truncated) target, walk the count values that occur, first cumulative count >= target
+    vals, occ = np.unique(cnt, return_counts=True)
+    cum = np.cumsum(occ)
+    target = int(distinct * len(uniq))
+    thr = int(vals[int(np.searchsorted(cum, target, side="left"))])
     sel = cnt > thr
     return uniq[sel], cnt[sel]
 
