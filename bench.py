@@ -104,19 +104,13 @@ def write_reads_fasta(path, names, seqs):
 
 
 def cpu_thread_candidates(n_cores):
-    """Thread counts of the baseline sweep: WM_BENCH_CPU_THREADS="64,128" overrides; default = the two best of the full sweep
-    recorded in profiles/ (tools/cpu_sweep.py) if it was made on a host of this size, else {cores/2, cores}."""
+    """Thread counts of the baseline sweep: WM_BENCH_CPU_THREADS="16,32" overrides; default = the usable cores (container quota) and
+    twice that — the two best points of the full sweep on the GPU boxes (profiles/r02_cpu_sweep_c2*.txt: the reference is fastest
+    at -t 16..32 under the 16-CPU quota and slows down steadily beyond)."""
     env = os.environ.get("WM_BENCH_CPU_THREADS")
     if env:
         return [int(x) for x in env.split(",") if x]
-    try:
-        with open(os.path.join(ROOT, "profiles", "cpu_sweep.json")) as f:
-            sw = json.load(f)
-        if sw.get("host_threads") == n_cores and sw.get("best_threads"):
-            return [int(x) for x in sw["best_threads"][:2]]
-    except Exception:  # noqa: BLE001
-        pass
-    return sorted({max(1, n_cores // 2), n_cores})
+    return sorted({n_cores, 2 * n_cores})
 
 
 def cpu_reference_baseline(fa, kf, names, seqs, preset, tmp, n_cores):
@@ -142,7 +136,7 @@ def cpu_reference_baseline(fa, kf, names, seqs, preset, tmp, n_cores):
     if best is None:
         return None, None
     t_map, t_best, outp, t_idx = best
-    return {"value": bases / t_map / 1e9, "unit": "Gbp/s", "cores": t_best, "kind": "reference", "cpu": cpu_model(), "host_threads": n_cores, "sweep": table,
+    return {"value": bases / t_map / 1e9, "unit": "Gbp/s", "cores": t_best, "kind": "reference", "cpu": cpu_model(), "hardware_threads": os.cpu_count(), "usable_cores": n_cores, "sweep": table,
             "sample": "one full step (%d reads, %.2f Gbase) of the same workload, winnowmap_ref -t %d -W -cx %s (PAF+CIGAR as in the timed GPU path), "
                       "mapping phase %.2f s = best of the -t sweep (index build %.1f s excluded)" % (len(seqs), bases / 1e9, t_best, preset, t_map, t_idx)}, outp
 
@@ -235,7 +229,7 @@ def main():
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl"
-    n_cores = os.cpu_count() or 1
+    n_cores = wmdist.available_cores()       # hardware threads, affinity and the container CPU quota
     # host threads per rank: the ranks of one node share its cores — divide them explicitly
     n_threads = args.threads or wmdist.host_threads_per_rank(n_cores, world)
     tmp = tempfile.mkdtemp(prefix="wmbench_")

@@ -18,6 +18,7 @@ using namespace wm;
 
 struct OracleOps : DeviceOps {
 	const Index *idx; wmo_bloom_t *bloom; const MapOpt *opt;
+	int max_inflight() const override { return 64; }             // stateless CPU calls: any number may run at once
 	void sketch_batch(int w, int k, std::vector<SketchReq*> &reqs) override
 	{
 		for (SketchReq *r : reqs) {
@@ -93,7 +94,7 @@ struct OracleOps : DeviceOps {
 	{
 		int8_t mat[25];
 		for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) mat[i * 5 + j] = (i == 4 || j == 4) ? sc.sc_ambi : i == j ? sc.match : sc.mismatch;
-		wm::parallel_for(8, reqs.size(), [&](size_t ri) {            // (borrows the scheduler team's threads when there is a team)
+		wm::parallel_for(4, reqs.size(), [&](size_t ri) {
 			KswReq *r = reqs[ri];
 			wmo_ez_t ez;
 			if (getenv("WM_KSW_STATS")) fprintf(stderr, "KSWJOB %d %d %d %d %d\n", (int)r->q.size(), (int)r->t.size(), r->w, r->zdrop, r->flag);

@@ -3,6 +3,7 @@
 // exposes them through a C ABI for ctypes, so kernel logic can be checked against the oracle on a CPU.
 #include "simt.h"                    // the emulator (this directory is first on the include path)
 #include "ksw_kernel.h"              // winnowmap_amd/csrc
+#include "ksw_packed_kernel.h"
 #include "ksw_plan.h"
 #include "sketch_kernel.h"
 #include "seedchain_kernel.h"
@@ -10,39 +11,21 @@
 #include <algorithm>
 #include <thread>
 
-template <int B> static void run_dp(int clip, int hasn, const wm_ksw_score_t &sc, const wm_ksw_djob_t &jb, const uint8_t *seqs, uint8_t *tb, wm_ksw_dres_t *res)
+template <int BP> static void run_dpp(int variant, const wm_ksw_score_t &sc, const wm_ksw_djob_t &jb, const uint8_t *seqs, uint8_t *tb, wm_ksw_dres_t *res)
 {
 	simt::exec_mask() = ~0ull;
-	if (clip && hasn) wmk::ksw_dp_wave<B, true, true>(sc, jb, seqs, tb, res);
-	else if (clip) wmk::ksw_dp_wave<B, true, false>(sc, jb, seqs, tb, res);
-	else if (hasn) wmk::ksw_dp_wave<B, false, true>(sc, jb, seqs, tb, res);
-	else wmk::ksw_dp_wave<B, false, false>(sc, jb, seqs, tb, res);
-}
-
-template <int B> static void run_dp_striped(int clip, int hasn, const wm_ksw_score_t &sc, const wm_ksw_djob_t &jb, const uint8_t *seqs, uint8_t *tb, wm_ksw_dres_t *res)
-{
-	simt::exec_mask() = ~0ull;
-	if (clip && hasn) wmk::ksw_dp_striped<B, true, true>(sc, jb, seqs, tb, res);
-	else if (clip) wmk::ksw_dp_striped<B, true, false>(sc, jb, seqs, tb, res);
-	else if (hasn) wmk::ksw_dp_striped<B, false, true>(sc, jb, seqs, tb, res);
-	else wmk::ksw_dp_striped<B, false, false>(sc, jb, seqs, tb, res);
-}
-
-template <int CPW, int NWV> static void run_smulti(const wm_ksw_score_t &sc, const wm_ksw_djob_t &jb, const uint8_t *seqs, uint8_t *tb, wm_ksw_dres_t *res)
-{
-	std::vector<int> lds(wmk::ksw_smulti_lds<CPW, NWV>::INTS, 0x5a5a5a5a);
-	pthread_barrier_t bar;
-	pthread_barrier_init(&bar, 0, NWV);
-	simt::block_barrier() = &bar;
-	std::vector<std::thread> th;
-	for (int w = 0; w < NWV; ++w)
-		th.emplace_back([&, w]() {
-			simt::wave_slot() = w; simt::exec_mask() = ~0ull;
-			wmk::ksw_dp_smulti<CPW, NWV, true, true>(sc, jb, seqs + jb.q_off, seqs + jb.t_off, tb, lds.data(), res);
-		});
-	for (auto &t : th) t.join();
-	simt::block_barrier() = 0;
-	pthread_barrier_destroy(&bar);
+	const bool exact = variant & 4, clip = variant & 2, hasn = variant & 1;
+	if (exact) {
+		if (clip && hasn) wmk::ksw_dp_packed<BP, true, true, true>(sc, jb, seqs, tb, res);
+		else if (clip) wmk::ksw_dp_packed<BP, true, false, true>(sc, jb, seqs, tb, res);
+		else if (hasn) wmk::ksw_dp_packed<BP, false, true, true>(sc, jb, seqs, tb, res);
+		else wmk::ksw_dp_packed<BP, false, false, true>(sc, jb, seqs, tb, res);
+	} else {
+		if (clip && hasn) wmk::ksw_dp_packed<BP, true, true, false>(sc, jb, seqs, tb, res);
+		else if (clip) wmk::ksw_dp_packed<BP, true, false, false>(sc, jb, seqs, tb, res);
+		else if (hasn) wmk::ksw_dp_packed<BP, false, true, false>(sc, jb, seqs, tb, res);
+		else wmk::ksw_dp_packed<BP, false, false, false>(sc, jb, seqs, tb, res);
+	}
 }
 
 extern "C" {
@@ -61,35 +44,33 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 	wm_ksw_djob_t jb;
 	memset(&jb, 0, sizeof(jb));
 	jb.q_off = 0; jb.t_off = qlen; jb.qlen = qlen; jb.tlen = tlen; jb.w = w; jb.zdrop = zdrop; jb.end_bonus = end_bonus; jb.flag = flag;
-	bool emu_blk3_small = false, emu_blk_lds = false, emu_blocked = false;
-	int emu_smulti = 0;                                          // 301: <4,4> (1024 lanes)  302: <4,16> (4096)  303: <8,16> (8192)  304: <2,2> (256, many re-bases per chunk)
-	if (force_klass >= 301 && force_klass <= 304) { emu_smulti = force_klass; force_klass = -1; }
-	if (force_klass >= 200 && force_klass < 212) { emu_blocked = true; force_klass -= 200; }   // 200+k: the blocked-layout register kernel of class k
-	if (force_klass == -2) { emu_blocked = true; force_klass = -1; }
-	if (force_klass == 112) { emu_blk_lds = true; force_klass = WM_KSW_BLOCK; }
-	if (force_klass == 113) { emu_blk_lds = true; force_klass = WM_KSW_BLOCK2; }
-	if (force_klass == 114) { emu_blk3_small = true; force_klass = WM_KSW_BLOCK3; }
-	int n_col, klass = wm_ksw_classify(qlen, tlen, w, wm_ksw_has_n(query, qlen) | wm_ksw_has_n(target, tlen), &n_col);
+	bool emu_blk3_small = false, emu_blk_lds = false, emu_bp2 = false;
+	// force_klass: -1 = choose like the product host; 0..23 = that register class (window and CLIP / HASN bits as given, EXACT always follows
+	// the job's flag); 100 + (CLIP*2 + HASN) = the 2-pair window (256 lanes: many re-bases and pair boundaries on small inputs; tests only);
+	// 24..27 = that wide class; 124 / 125 = the LDS-state block kernel at the BLOCK / BLOCK2 size; 126 = BLOCK3 with a small geometry
+	if (force_klass >= 100 && force_klass < 104) { emu_bp2 = true; force_klass = WM_KSW_P4 + (force_klass - 100); }
+	if (force_klass == 124) { emu_blk_lds = true; force_klass = WM_KSW_BLOCK; }
+	if (force_klass == 125) { emu_blk_lds = true; force_klass = WM_KSW_BLOCK2; }
+	if (force_klass == 126) { emu_blk3_small = true; force_klass = WM_KSW_BLOCK3; }
+	int n_col, klass = wm_ksw_classify(qlen, tlen, w, wm_ksw_has_n(query, qlen) | wm_ksw_has_n(target, tlen), flag, &n_col);
 	if (force_klass >= 0) {
-		if (force_klass < WM_KSW_BLOCK && (force_klass & ~3) < (klass & ~3)) return -1; // window too small for this job
-		if (force_klass >= WM_KSW_BLOCK && force_klass <= WM_KSW_BLOCK3 && klass > force_klass) return -1;
-		klass = force_klass;
+		if (force_klass < WM_KSW_BLOCK) {
+			if (klass >= WM_KSW_BLOCK || (force_klass & ~7) < (klass & ~7)) return -1;      // window too small for this job
+			if ((klass & 3) & ~(force_klass & 3)) return -1;                               // the job needs CLIP / HASN and the forced variant lacks it
+			klass = (force_klass & ~4) | (klass & 4);
+		} else {
+			if (force_klass <= WM_KSW_BLOCK3 && klass > force_klass) return -1;
+			klass = force_klass;
+		}
 	}
+	if (emu_bp2 && n_col > 128 * 2 - 16) return -1;
 	*klass_out = klass;
 	if (emu_blk3_small && n_col + 16 > 128 * WM_KSW_BLK_MAXC) return -1;
 	jb.n_col = n_col; jb.tb_off = 0; jb.klass = klass;
 	std::vector<uint8_t> tb((size_t)(qlen + tlen - 1) * n_col + 64, 0xEE);
 	wm_ksw_dres_t res;
 	memset(&res, 0, sizeof(res));
-	const int clip = klass >> 1 & 1, hasn = klass & 1;
-	if (emu_smulti) {
-		const int cap = emu_smulti == 301 ? 1024 : emu_smulti == 302 ? 4096 : emu_smulti == 303 ? 8192 : 256;
-		if (n_col + 16 > cap) return -1;
-		if (emu_smulti == 301) run_smulti<4, 4>(sc, jb, seqs.data(), tb.data(), &res);
-		else if (emu_smulti == 302) run_smulti<4, 16>(sc, jb, seqs.data(), tb.data(), &res);
-		else if (emu_smulti == 303) run_smulti<8, 16>(sc, jb, seqs.data(), tb.data(), &res);
-		else run_smulti<2, 2>(sc, jb, seqs.data(), tb.data(), &res);
-	} else if (klass == WM_KSW_BLOCK || klass == WM_KSW_BLOCK2 || klass == WM_KSW_BLOCK3) {
+	if (klass == WM_KSW_BLOCK || klass == WM_KSW_BLOCK2 || klass == WM_KSW_BLOCK3) {
 		constexpr int NWV = WM_KSW_BLK_NWV;
 		const int WN = klass == WM_KSW_BLOCK ? WM_KSW_BLK_WN : klass == WM_KSW_BLOCK2 ? WM_KSW_BLK2_WN : (int)wm_ksw_blk3_wn(tlen);
 		std::vector<int> W0(WN, 0x5a5a5a5a), W1(WN, 0x5a5a5a5a), Hm(WN, 0x5a5a5a5a), pub(WM_KSW_BLK_PUB);   // the state starts as garbage
@@ -119,14 +100,11 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 		std::vector<int> Hm(T + 16);
 		simt::exec_mask() = ~0ull;
 		wmk::ksw_dp_generic<true>(sc, jb, seqs.data(), tb.data(), mem.data(), Hm.data(), &res);
-	} else if (emu_blocked) switch (klass & ~3) {
-	case WM_KSW_B4: run_dp<4>(clip, hasn, sc, jb, seqs.data(), tb.data(), &res); break;
-	case WM_KSW_B8: run_dp<8>(clip, hasn, sc, jb, seqs.data(), tb.data(), &res); break;
-	default: run_dp<16>(clip, hasn, sc, jb, seqs.data(), tb.data(), &res); break;
-	} else switch (klass & ~3) {
-	case WM_KSW_B4: run_dp_striped<4>(clip, hasn, sc, jb, seqs.data(), tb.data(), &res); break;
-	case WM_KSW_B8: run_dp_striped<8>(clip, hasn, sc, jb, seqs.data(), tb.data(), &res); break;
-	default: run_dp_striped<16>(clip, hasn, sc, jb, seqs.data(), tb.data(), &res); break;
+	} else if (emu_bp2) run_dpp<2>(klass & 7, sc, jb, seqs.data(), tb.data(), &res);
+	else switch (klass & ~7) {
+	case WM_KSW_P4: run_dpp<4>(klass & 7, sc, jb, seqs.data(), tb.data(), &res); break;
+	case WM_KSW_P8: run_dpp<8>(klass & 7, sc, jb, seqs.data(), tb.data(), &res); break;
+	default: run_dpp<16>(klass & 7, sc, jb, seqs.data(), tb.data(), &res); break;
 	}
 	int n = 0;
 	if (res.bt_i >= 0) {

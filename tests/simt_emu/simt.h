@@ -110,6 +110,53 @@ inline int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
 inline V<int> add3(const V<int> &a, const V<int> &b, int c) { return wadd(wadd(a, b), c); }
 inline V<int> add3(const V<int> &a, const V<int> &b, const V<int> &c) { return wadd(wadd(a, b), c); }
 
+// ---- packed 2 x 16-bit (the device versions are single VOP3P instructions) ---------------------------------------------
+inline int pk2(int lo, int hi) { return (int)(((unsigned)hi & 0xffffu) << 16 | ((unsigned)lo & 0xffffu)); }
+inline int s_lo(int a) { return (int)(short)(a & 0xffff); }
+inline int s_hi(int a) { return (int)(short)((unsigned)a >> 16); }
+inline int u_lo(int a) { return a & 0xffff; }
+inline int u_hi(int a) { return (int)((unsigned)a >> 16); }
+inline int sat16(int v) { return v > 32767 ? 32767 : v < -32768 ? -32768 : v; }
+inline int pk_add(int a, int b) { return pk2(u_lo(a) + u_lo(b), u_hi(a) + u_hi(b)); }
+inline int pk_sub(int a, int b) { return pk2(u_lo(a) - u_lo(b), u_hi(a) - u_hi(b)); }
+inline int pk_max(int a, int b) { return pk2(s_lo(a) > s_lo(b) ? s_lo(a) : s_lo(b), s_hi(a) > s_hi(b) ? s_hi(a) : s_hi(b)); }
+inline int pk_min(int a, int b) { return pk2(s_lo(a) < s_lo(b) ? s_lo(a) : s_lo(b), s_hi(a) < s_hi(b) ? s_hi(a) : s_hi(b)); }
+inline int pk_minu(int a, int b) { return pk2(u_lo(a) < u_lo(b) ? u_lo(a) : u_lo(b), u_hi(a) < u_hi(b) ? u_hi(a) : u_hi(b)); }
+inline int pk_subsat(int a, int b) { return pk2(sat16(s_lo(a) - s_lo(b)), sat16(s_hi(a) - s_hi(b))); }
+inline int pk_lshr(int a, int k) { return pk2(u_lo(a) >> k, u_hi(a) >> k); }
+inline int pk_mad(int a, int b, int c) { return pk2(u_lo(a) * u_lo(b) + u_lo(c), u_hi(a) * u_hi(b) + u_hi(c)); }
+inline int perm(int a, int b, int sel)
+{
+	const uint64_t src = (uint64_t)(unsigned)a << 32 | (unsigned)b;
+	unsigned r = 0;
+	for (int k = 0; k < 4; ++k) {
+		const int s = sel >> (8 * k) & 0xff;
+		WM_EMU_ASSERT(s <= 7 || s == 0x0c);
+		const unsigned byte = s == 0x0c ? 0u : (unsigned)(src >> (8 * s) & 0xff);
+		r |= byte << (8 * k);
+	}
+	return (int)r;
+}
+inline int bfi(int mask, int a, int b) { return (a & mask) | (b & ~mask); }
+inline int alignbit(int hi, int lo, int sh) { return (int)(((uint64_t)(unsigned)hi << 32 | (unsigned)lo) >> (sh & 31)); }
+inline int lshr(int a, int k) { return (int)((unsigned)a >> k); }
+#define WM_LIFT2(NAME) \
+	inline V<int> NAME(const V<int> &a, const V<int> &b) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = NAME(a.v[i], b.v[i]); return r; } \
+	inline V<int> NAME(const V<int> &a, int b) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = NAME(a.v[i], b); return r; } \
+	inline V<int> NAME(int a, const V<int> &b) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = NAME(a, b.v[i]); return r; }
+WM_LIFT2(pk_add) WM_LIFT2(pk_sub) WM_LIFT2(pk_max) WM_LIFT2(pk_min) WM_LIFT2(pk_minu) WM_LIFT2(pk_subsat)
+#undef WM_LIFT2
+inline V<int> pk_lshr(const V<int> &a, int k) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = pk_lshr(a.v[i], k); return r; }
+inline V<int> lshr(const V<int> &a, int k) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = lshr(a.v[i], k); return r; }
+inline V<int> pk_mad(const V<int> &a, int b, const V<int> &c) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = pk_mad(a.v[i], b, c.v[i]); return r; }
+inline V<int> pk_mad(const V<int> &a, int b, int c) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = pk_mad(a.v[i], b, c); return r; }
+inline V<int> perm(const V<int> &a, const V<int> &b, int sel) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = perm(a.v[i], b.v[i], sel); return r; }
+inline V<int> bfi(const V<int> &m, const V<int> &a, const V<int> &b) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = bfi(m.v[i], a.v[i], b.v[i]); return r; }
+inline V<int> bfi(int m, const V<int> &a, const V<int> &b) { return bfi(V<int>(m), a, b); }
+inline V<int> bfi(const V<int> &m, int a, const V<int> &b) { return bfi(m, V<int>(a), b); }
+inline V<int> bfi(int m, int a, const V<int> &b) { return bfi(V<int>(m), V<int>(a), b); }
+inline V<int> alignbit(const V<int> &hi, const V<int> &lo, int sh) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = alignbit(hi.v[i], lo.v[i], sh); return r; }
+
 // ---- cross-lane -------------------------------------------------------------------------------------
 // NB (hardware semantics kept): cross-lane reads see the registers of ALL lanes, active or not.
 template <class T> V<T> shr1(const V<T> &x, T fill) { V<T> r; r.v[0] = fill; for (int i = 1; i < WAVE; ++i) r.v[i] = x.v[i - 1]; return r; }

@@ -149,4 +149,5 @@ def test_launcher_starts_n_ranks():
     assert rc == 0
     seen = sorted(open(os.path.join(tmp, f)).read().split() for f in os.listdir(tmp))
     assert seen == [["0", "2", "0"], ["1", "2", "1"]]
-    assert wmdist.host_threads_per_rank(256, 1) == 32 and wmdist.host_threads_per_rank(256, 8) == 24 and wmdist.host_threads_per_rank(4, 8) == 1
+    assert wmdist.host_threads_per_rank(256, 1) == 32 and wmdist.host_threads_per_rank(128, 8) == 16 and wmdist.host_threads_per_rank(16, 1) == 16 and wmdist.host_threads_per_rank(4, 8) == 1
+    assert 1 <= wmdist.available_cores() <= (os.cpu_count() or 1)

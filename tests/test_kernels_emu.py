@@ -33,14 +33,15 @@ def test_ksw_emulated_kernel_matches_oracle(emu, seed):
     for c in kswcases.make_cases(seed, 90, max_len=600):
         o = W.o_ksw_extd2(c["q"], c["t"], mat=W.simple_mat(c["a"], c["b"], 1), q=c["q_"], e=c["e"], q2=c["q2"], e2=c["e2"],
                           w=c["w"], zdrop=c["zdrop"], end_bonus=c["end_bonus"], flag=c["flag"])
-        for force in (-1, 3, 7, 11, 203, 211):   # host's choice, the CLIP+HASN variant of every window size, and the blocked-layout kernel
+        # host's choice; the CLIP+HASN and the plain CLIP variant of every window size; the 2-pair test window (many re-bases / pair boundaries)
+        for force in (-1, 3, 11, 19, 2, 10, 18, 0, 100, 102, 103):
             n, ez, cig, klass = emu_ksw(emu, c, force)
             if n < 0:
                 continue
             seen.add(klass)
             assert [int(x) for x in ez] == [o[k] for k in W.EZ_FIELDS], (klass, c["flag"], c["w"])
             assert np.array_equal(cig, o["cigar"])
-    assert len(seen) >= 6
+    assert len(seen) >= 10, seen
 
 
 def test_block_ksw_kernels_match_oracle(emu):
@@ -58,7 +59,7 @@ def test_block_ksw_kernels_match_oracle(emu):
     for c in cases:
         o = W.o_ksw_extd2(c["q"], c["t"], mat=W.simple_mat(c["a"], c["b"], 1), q=c["q_"], e=c["e"], q2=c["q2"], e2=c["e2"],
                           w=c["w"], zdrop=c["zdrop"], end_bonus=c["end_bonus"], flag=c["flag"])
-        for force in (12, 112, 13, 113, 14, 114, 301, 302, 304):
+        for force in (24, 124, 25, 125, 26, 126, 16, 18, 19):
             n, ez, cig, klass = emu_ksw(emu, c, force)
             if n < 0:
                 continue

@@ -28,6 +28,8 @@ def main():
     a = ap.parse_args()
     cfg = B.CONFIGS[a.config]
     n_cores = os.cpu_count() or 1
+    from winnowmap_amd import dist as wmdist
+    quota = wmdist.available_cores()
     ths = [int(x) for x in a.threads.split(",") if x] or [t for t in (16, 32, 64, 96, 128, 192, 256, 384, 512) if t <= n_cores]
     tmp = tempfile.mkdtemp(prefix="wmsweep_")
     ref, fa, kf = B.make_workload(a.ref_mb, tmp)
@@ -51,7 +53,7 @@ def main():
             B.log(json.dumps(rows[-1]))
     paf = [r for r in rows if r["format"].startswith("paf")]
     best = sorted(paf, key=lambda r: r["map_s"])
-    out = {"config": a.config, "preset": cfg["preset"], "reads": n, "bases": bases, "cpu": B.cpu_model(), "host_threads": n_cores,
+    out = {"config": a.config, "preset": cfg["preset"], "reads": n, "bases": bases, "cpu": B.cpu_model(), "host_threads": n_cores, "usable_cores": quota,
            "best_threads": [r["threads"] for r in best], "rows": rows}
     os.makedirs(a.out, exist_ok=True)
     with open(os.path.join(a.out, "cpu_sweep_c%d.json" % a.config), "w") as f:

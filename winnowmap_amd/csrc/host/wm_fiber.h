@@ -1,45 +1,62 @@
-// wm_fiber.h — cooperative fibers + batching scheduler.
+// wm_fiber.h — cooperative fibers + the batching hub.
 //
 // The reference maps one read per thread with deeply data-dependent control flow (src/map.c:279-974: MCAS windows,
 // MAPQ-gated retries, chain splitting). Rewriting that as explicit state machines is error-prone, so each unit of
 // work (one stage-1 window position, one stage-2 pass) runs as a FIBER whose code reads sequentially; whenever it
-// needs a device operation it enqueues the request and yields. When every fiber is blocked the scheduler flushes the
-// queues as ONE batched device call per operation type and resumes the waiters. Thousands of reads in flight give
-// the kernels their batch sizes; the host code stays a straight restatement of the reference's semantics.
+// needs a device operation it files the request and yields.
+//
+// Execution model (one Hub per mapping call, T worker threads, no barriers):
+//   * every worker owns the fibers of its reads and runs them until all of them wait for a device result;
+//   * requests collect in the worker's local queues and are published to the Hub when the worker runs dry;
+//   * a worker with nothing runnable becomes a DISPATCHER: it takes the whole pending queue of one operation type and
+//     issues it as ONE batched device call (DeviceOps::*_batch — the call itself sleeps while the kernels run); several
+//     dispatchers can be in flight at once (different operations, or the same one: DeviceOps::max_inflight()), so the
+//     device always has queued work while the other workers keep running host glue;
+//   * when a batch returns, the fibers that waited for it are handed back to their owners' inboxes.
+// Queues grow while the device is busy and are taken whole, so batch sizes regulate themselves. Reads are admitted in a
+// sliding window (the worker spawns a new read when one of its reads finishes), which keeps every stage of the path —
+// sketch, seed, chain, align — in demand at the same time instead of in lock-step phases.
+// Results do not depend on how requests are batched (every job is independent), so the output is deterministic.
 #pragma once
 #include <ucontext.h>
 #include <functional>
 #include <deque>
 #include <vector>
 #include <memory>
+#include <mutex>
+#include <condition_variable>
+#include <atomic>
 #include <stdlib.h>
 #include <stdio.h>
 #include <chrono>
-#include <pthread.h>
 #include "wm_ops.h"
 
 namespace wm {
 
 class Scheduler;
+struct Fiber { ucontext_t ctx; char *stack; std::function<void()> fn; bool done; Scheduler *owner; };
+enum { OP_SKETCH = 0, OP_SEED = 1, OP_CHAIN = 2, OP_KSW = 3, OP_N = 4 };
 
-// A TEAM of schedulers, one per host thread, that share their device batches: every member runs its own fibers (the
-// host glue of its reads) in parallel with the others; when all members have nothing runnable they meet at a barrier,
-// member 0 issues ONE batched device call per operation type for the whole team, and everybody resumes its waiters.
-// Host work scales with the threads while the kernels still see the batch of the whole team.
-struct SchedTeam {
-	explicit SchedTeam(int n) : n_(n) { pthread_barrier_init(&bar_, 0, (unsigned)n); }
-	~SchedTeam() { pthread_barrier_destroy(&bar_); }
-	int n_;
-	pthread_barrier_t bar_;
-	std::vector<Scheduler*> members;
-	bool done = false;
-	ParallelExec exec;                                             // members 1.. lend themselves to member 0 during the device phase
-	uint64_t round = 0;
+struct Hub {
+	Hub(DeviceOps *ops_, const wm_ksw_score_t &sc_, int w_, int k_) : ops(ops_), sc(sc_), w(w_), k(k_) { max_inflight = ops->max_inflight(); if (max_inflight < 1) max_inflight = 1; }
+	DeviceOps *ops;
+	wm_ksw_score_t sc;
+	int w, k;
+	int max_inflight;                       // batched device calls that may run concurrently (device contexts of the ops object)
+	std::mutex mu;
+	std::condition_variable cv;
+	// published requests and the fibers waiting for them (taken whole by a dispatcher)
+	std::vector<SketchReq*> q_sketch; std::vector<SeedReq*> q_seed; std::vector<ChainReq*> q_chain; std::vector<KswReq*> q_ksw;
+	std::vector<Fiber*> waiters[OP_N];
+	int inflight = 0, inflight_op[OP_N] = {0, 0, 0, 0};
+	std::atomic<int64_t> live{0};           // fibers alive + reads not yet admitted, over all workers: 0 = the mapping call is finished
+	uint64_t n_batches[OP_N] = {0, 0, 0, 0}, n_reqs[OP_N] = {0, 0, 0, 0};
+	size_t pending(int op) const { return op == OP_SKETCH ? q_sketch.size() : op == OP_SEED ? q_seed.size() : op == OP_CHAIN ? q_chain.size() : q_ksw.size(); }
 };
 
 class Scheduler {
 public:
-	Scheduler(DeviceOps *ops, const wm_ksw_score_t &sc, int w, int k, SchedTeam *team = 0, int rank = 0) : ops_(ops), sc_(sc), w_(w), k_(k), team_(team), rank_(rank) {}
+	explicit Scheduler(Hub *hub, int rank = 0) : hub_(hub), rank_(rank) {}
 	~Scheduler() { for (Fiber *f : pool_) { free(f->stack); delete f; } }
 
 	void spawn(std::function<void()> fn)
@@ -54,41 +71,42 @@ public:
 		makecontext(&f->ctx, (void (*)())&Scheduler::entry, 3, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32), 0);
 		f->owner = this;
 		ready_.push_back(f);
-		++live_;
+		hub_->live.fetch_add(1);
 	}
+	// work that is not a fiber yet (reads waiting for admission) also keeps the mapping call alive
+	void hold(int64_t n) { hub_->live.fetch_add(n); }
+	void release(int64_t n) { hub_->live.fetch_sub(n); }
 
-	// run until every fiber (of the whole team, if there is one) has finished
+	// run until the whole mapping call (all workers) has finished
 	void run()
 	{
-		static const bool trace2 = getenv("WM_TRACE2") != 0;
+		Hub &H = *hub_;
 		for (;;) {
-			const auto tb0 = std::chrono::steady_clock::now();
-			size_t n_run = 0;
 			while (!ready_.empty()) {
 				cur_ = ready_.front(); ready_.pop_front();
 				swapcontext(&main_, &cur_->ctx);
-				if (cur_->done) { cur_->fn = nullptr; pool_.push_back(cur_); --live_; }
+				if (cur_->done) { cur_->fn = nullptr; pool_.push_back(cur_); H.live.fetch_sub(1); }
 				cur_ = 0;
-				++n_run;
 			}
-			if (trace2 && n_run) fprintf(stderr, "[member %d] ran %zu fiber slices in %.2f ms\n", rank_, n_run, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count());
-			if (!team_) {
-				if (live_ == 0) break;
-				flush();
-			} else if (!team_round()) break;
+			std::unique_lock<std::mutex> lk(H.mu);
+			publish_locked();
+			for (;;) {
+				if (!inbox_.empty()) { for (Fiber *f : inbox_) ready_.push_back(f); inbox_.clear(); break; }
+				if (H.live.load() == 0) { H.cv.notify_all(); return; }
+				const int op = pick_locked();
+				if (op >= 0) { dispatch(op, lk); continue; }      // (returns with the lock held again)
+				H.cv.wait(lk);
+			}
 		}
 	}
 
 	// ---- called from inside a fiber ----
-	void sketch(SketchReq &r) { q_sketch_.push_back(&r); wait(w_sketch_); }
-	void seed(SeedReq &r) { q_seed_.push_back(&r); wait(w_seed_); }
-	void chain(ChainReq &r) { q_chain_.push_back(&r); wait(w_chain_); }
-	void ksw(std::vector<KswReq> &rs) { if (rs.empty()) return; for (KswReq &r : rs) q_ksw_.push_back(&r); wait(w_ksw_); }
-
-	uint64_t n_flush = 0, n_ksw_jobs = 0, n_chain_jobs = 0, n_sketch_jobs = 0, n_seed_jobs = 0;
+	void sketch(SketchReq &r) { l_sketch_.push_back(&r); wait(OP_SKETCH); }
+	void seed(SeedReq &r) { l_seed_.push_back(&r); wait(OP_SEED); }
+	void chain(ChainReq &r) { l_chain_.push_back(&r); wait(OP_CHAIN); }
+	void ksw(std::vector<KswReq> &rs) { if (rs.empty()) return; for (KswReq &r : rs) l_ksw_.push_back(&r); wait(OP_KSW); }
 
 private:
-	struct Fiber { ucontext_t ctx; char *stack; std::function<void()> fn; bool done; Scheduler *owner; };
 	static constexpr size_t kStack = 256 * 1024;
 	static void entry(unsigned lo, unsigned hi, unsigned)
 	{
@@ -96,70 +114,69 @@ private:
 		f->fn();
 		f->done = true;                     // uc_link returns to the scheduler
 	}
-	void wait(std::vector<Fiber*> &w) { Fiber *me = cur_; w.push_back(me); swapcontext(&me->ctx, &main_); }
-	void wake(std::vector<Fiber*> &w) { for (Fiber *f : w) ready_.push_back(f); w.clear(); }
-	bool team_round()
+	void wait(int op) { Fiber *me = cur_; l_wait_[op].push_back(me); swapcontext(&me->ctx, &main_); }
+	void publish_locked()
 	{
-		pthread_barrier_wait(&team_->bar_);                            // every member is blocked or finished
-		const uint64_t round = ++my_round_;
-		if (rank_ == 0) {
-			size_t live = 0;
-			for (Scheduler *m : team_->members) live += m->live_;
-			team_->done = live == 0;
-			if (!team_->done) {                                          // gather everybody's requests into this member's queues
-				for (Scheduler *m : team_->members) {
-					if (m == this) continue;
-					q_sketch_.insert(q_sketch_.end(), m->q_sketch_.begin(), m->q_sketch_.end()); m->q_sketch_.clear();
-					q_seed_.insert(q_seed_.end(), m->q_seed_.begin(), m->q_seed_.end()); m->q_seed_.clear();
-					q_chain_.insert(q_chain_.end(), m->q_chain_.begin(), m->q_chain_.end()); m->q_chain_.clear();
-					q_ksw_.insert(q_ksw_.end(), m->q_ksw_.begin(), m->q_ksw_.end()); m->q_ksw_.clear();
-				}
-				team_->exec.wait_servers(team_->n_ - 1);
-				tl_parallel_exec() = &team_->exec;
-				flush();
-				tl_parallel_exec() = 0;
-			}
-			team_->exec.close(round);
-		} else
-			team_->exec.serve(round);                                    // help with the host side of the batched calls until they are done
-		pthread_barrier_wait(&team_->bar_);                            // results are in the requests
-		if (team_->done) return false;
-		if (rank_ != 0) { wake(w_sketch_); wake(w_seed_); wake(w_chain_); wake(w_ksw_); }
-		return true;
+		Hub &H = *hub_;
+		bool any = false;
+		if (!l_sketch_.empty()) { H.q_sketch.insert(H.q_sketch.end(), l_sketch_.begin(), l_sketch_.end()); l_sketch_.clear(); any = true; }
+		if (!l_seed_.empty()) { H.q_seed.insert(H.q_seed.end(), l_seed_.begin(), l_seed_.end()); l_seed_.clear(); any = true; }
+		if (!l_chain_.empty()) { H.q_chain.insert(H.q_chain.end(), l_chain_.begin(), l_chain_.end()); l_chain_.clear(); any = true; }
+		if (!l_ksw_.empty()) { H.q_ksw.insert(H.q_ksw.end(), l_ksw_.begin(), l_ksw_.end()); l_ksw_.clear(); any = true; }
+		for (int op = 0; op < OP_N; ++op)
+			if (!l_wait_[op].empty()) { H.waiters[op].insert(H.waiters[op].end(), l_wait_[op].begin(), l_wait_[op].end()); l_wait_[op].clear(); }
+		if (any) H.cv.notify_all();          // somebody idle may want to dispatch what was just published
 	}
-	void flush()
+	// which operation this idle worker should issue now (-1: none). An operation with nothing in flight goes first (keeps every stage
+	// of the path moving); a second concurrent batch of the same operation is only worth its fixed cost when the queue is large.
+	int pick_locked()
 	{
-		++n_flush;
+		Hub &H = *hub_;
+		if (H.inflight >= H.max_inflight) return -1;
+		static const size_t big[OP_N] = { 4096, 4096, 4096, 65536 };
+		int best = -1;
+		for (int op = OP_N - 1; op >= 0; --op) {              // later stages first: finishing reads frees their memory and admits new ones
+			const size_t n = H.pending(op);
+			if (n == 0) continue;
+			if (H.inflight_op[op] == 0) return op;
+			if (n >= big[op] && best < 0) best = op;
+		}
+		return best;
+	}
+	void dispatch(int op, std::unique_lock<std::mutex> &lk)
+	{
+		Hub &H = *hub_;
+		std::vector<Fiber*> waiters;
+		waiters.swap(H.waiters[op]);
+		std::vector<SketchReq*> a; std::vector<SeedReq*> b; std::vector<ChainReq*> c; std::vector<KswReq*> d;
+		size_t n = 0;
+		if (op == OP_SKETCH) { a.swap(H.q_sketch); n = a.size(); } else if (op == OP_SEED) { b.swap(H.q_seed); n = b.size(); }
+		else if (op == OP_CHAIN) { c.swap(H.q_chain); n = c.size(); } else { d.swap(H.q_ksw); n = d.size(); }
+		++H.inflight; ++H.inflight_op[op]; ++H.n_batches[op]; H.n_reqs[op] += n;
+		lk.unlock();
 		static const bool trace = getenv("WM_TRACE") != 0;
-		auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-		const double t0 = now();
-		const size_t n0 = q_sketch_.size(), n1 = q_seed_.size(), n2 = q_chain_.size(), n3 = q_ksw_.size();
-		if (!q_sketch_.empty()) { n_sketch_jobs += q_sketch_.size(); ops_->sketch_batch(w_, k_, q_sketch_); q_sketch_.clear(); wake(w_sketch_); }
-		const double t1 = now();
-		if (!q_seed_.empty()) { n_seed_jobs += q_seed_.size(); ops_->seed_batch(q_seed_); q_seed_.clear(); wake(w_seed_); }
-		const double t2 = now();
-		if (!q_chain_.empty()) { n_chain_jobs += q_chain_.size(); ops_->chain_batch(q_chain_); q_chain_.clear(); wake(w_chain_); }
-		const double t3 = now();
-		if (!q_ksw_.empty()) { n_ksw_jobs += q_ksw_.size(); ops_->ksw_batch(sc_, q_ksw_); q_ksw_.clear(); wake(w_ksw_); }
-		const double t4 = now();
-		if (trace) fprintf(stderr, "[flush %3llu] host %.1f ms | sketch %zu: %.1f ms | seed %zu: %.1f ms | chain %zu: %.1f ms | ksw %zu: %.1f ms\n",
-		                   (unsigned long long)n_flush, t0 - t_last_, n0, t1 - t0, n1, t2 - t1, n2, t3 - t2, n3, t4 - t3);
-		t_last_ = now();
+		const auto t0 = std::chrono::steady_clock::now();
+		if (op == OP_SKETCH) H.ops->sketch_batch(H.w, H.k, a);
+		else if (op == OP_SEED) H.ops->seed_batch(b);
+		else if (op == OP_CHAIN) H.ops->chain_batch(c);
+		else H.ops->ksw_batch(H.sc, d);
+		if (trace) fprintf(stderr, "[batch] worker %2d %s n=%zu %.1f ms\n", rank_, op == OP_SKETCH ? "sketch" : op == OP_SEED ? "seed" : op == OP_CHAIN ? "chain" : "ksw", n,
+		                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+		lk.lock();
+		--H.inflight; --H.inflight_op[op];
+		for (Fiber *f : waiters) f->owner->inbox_.push_back(f);      // inboxes are protected by the hub mutex
+		H.cv.notify_all();
 	}
-	double t_last_ = 0;
-	DeviceOps *ops_;
-	wm_ksw_score_t sc_;
-	int w_, k_;
-	SchedTeam *team_;
+
+	Hub *hub_;
 	int rank_;
-	uint64_t my_round_ = 0;
 	ucontext_t main_;
 	Fiber *cur_ = 0;
-	size_t live_ = 0;
 	std::deque<Fiber*> ready_;
 	std::vector<Fiber*> pool_;
-	std::vector<SketchReq*> q_sketch_; std::vector<SeedReq*> q_seed_; std::vector<ChainReq*> q_chain_; std::vector<KswReq*> q_ksw_;
-	std::vector<Fiber*> w_sketch_, w_seed_, w_chain_, w_ksw_;
+	std::vector<Fiber*> inbox_;             // fibers whose results arrived (filled by dispatchers under the hub mutex)
+	std::vector<SketchReq*> l_sketch_; std::vector<SeedReq*> l_seed_; std::vector<ChainReq*> l_chain_; std::vector<KswReq*> l_ksw_;
+	std::vector<Fiber*> l_wait_[OP_N];
 };
 
 } // namespace wm

@@ -169,14 +169,16 @@ void stage2(Scheduler &sch, const Index &idx, const MapOpt &opt, ReadTask &T)
 } // namespace
 
 namespace {
-// create the fibers of one read on scheduler `sch` (stage-1 positions, then stage 2; src/map.c:304-341)
-void spawn_read(Scheduler &sch, const Index &idx, const MapOpt &opt, const MapOpt &o2, ReadTask &T)
+struct Worker;
+// create the fibers of one read on scheduler `sch` (stage-1 positions, then stage 2; src/map.c:304-341); returns false if the read needs no work.
+// `on_done` runs (inside the last fiber of the read) when the read is finished.
+bool spawn_read(Scheduler &sch, const Index &idx, const MapOpt &opt, const MapOpt &o2, ReadTask &T, std::function<void()> on_done)
 {
 	{ WM_PROF("map.encode_read");
 	T.codes.resize(T.qlen);
 	for (int j = 0; j < T.qlen; ++j) T.codes[j] = nt4_table[(uint8_t)T.in->seq[j]]; }
-	if (T.qlen == 0) return;
-	if (opt.max_qlen > 0 && T.qlen > opt.max_qlen) return;
+	if (T.qlen == 0) return false;
+	if (opt.max_qlen > 0 && T.qlen > opt.max_qlen) return false;
 	const int off = o2.suffixSampleOffset;
 	const int n_pos = 1 + (int)ceil(T.qlen * 1.0 / off);
 	T.collect.assign(n_pos, std::vector<m128>());
@@ -184,6 +186,12 @@ void spawn_read(Scheduler &sch, const Index &idx, const MapOpt &opt, const MapOp
 	ReadTask *tp = &T;
 	Scheduler *sp = &sch;
 	const Index *ip = &idx; const MapOpt *op = &opt, *o2p = &o2;
+	auto finish = [sp, ip, op, tp, on_done]() {
+		stage2(*sp, *ip, *op, *tp);
+		// the read is done: drop its scratch (the window keeps thousands of reads in flight)
+		std::vector<uint8_t>().swap(tp->codes); std::vector<std::vector<m128>>().swap(tp->collect); std::vector<uint8_t>().swap(tp->mapped);
+		on_done();
+	};
 	if (o2.SVaware && T.qlen >= o2.SVawareMinReadLength) {
 		std::vector<std::pair<int, int>> pos;                           // (sub_begin, suffix_id), src/map.c:334-341
 		for (int sb = 0; sb < T.qlen + off - 1; sb += off) {
@@ -195,11 +203,12 @@ void spawn_read(Scheduler &sch, const Index &idx, const MapOpt &opt, const MapOp
 		}
 		T.pending = (int)pos.size();
 		for (auto p : pos)
-			sch.spawn([sp, ip, op, o2p, tp, p]() {
+			sch.spawn([sp, ip, op, o2p, tp, p, finish]() {
 				stage1_position(*sp, *ip, *op, *o2p, *tp, p.first, p.second);
-				if (--tp->pending == 0) sp->spawn([sp, ip, op, tp]() { stage2(*sp, *ip, *op, *tp); });
+				if (--tp->pending == 0) sp->spawn(finish);
 			});
-	} else sch.spawn([sp, ip, op, tp]() { stage2(*sp, *ip, *op, *tp); });
+	} else sch.spawn(finish);
+	return true;
 }
 } // namespace
 
@@ -213,27 +222,45 @@ void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::v
 	o2.best_n = std::max(5, o2.best_n);
 	std::vector<ReadTask> tasks(reads.size());
 	for (size_t i = 0; i < reads.size(); ++i) { tasks[i].in = &reads[i]; tasks[i].out = &out[i]; tasks[i].qlen = (int)reads[i].seq.size(); }
-	if (n_threads <= 1) {
-		Scheduler sch(ops, sc, idx.w, idx.k);
-		for (ReadTask &T : tasks) spawn_read(sch, idx, opt, o2, T);
-		sch.run();
-		if (stats) { stats->n_flush += sch.n_flush; stats->n_ksw += sch.n_ksw_jobs; stats->n_chain += sch.n_chain_jobs; stats->n_seed += sch.n_seed_jobs; stats->n_sketch += sch.n_sketch_jobs; }
-		return;
-	}
-	// a team of schedulers: read i belongs to member i % T (all fibers of a read stay on one thread); device batches are shared
-	const int T = n_threads;
-	SchedTeam team(T);
+	const int T = n_threads < 1 ? 1 : n_threads;
+	// reads in flight over all workers (WM_INFLIGHT): large enough for full device batches at every stage, small enough that the
+	// stages overlap instead of running in lock-step phases
+	static const long inflight_env = getenv("WM_INFLIGHT") ? atol(getenv("WM_INFLIGHT")) : 0;
+	const size_t window = std::max<size_t>(1, (size_t)(inflight_env > 0 ? inflight_env : 16384) / (size_t)T);
+	Hub hub(ops, sc, idx.w, idx.k);
 	std::vector<std::unique_ptr<Scheduler>> sch(T);
-	for (int t = 0; t < T; ++t) { sch[t].reset(new Scheduler(ops, sc, idx.w, idx.k, &team, t)); team.members.push_back(sch[t].get()); }
+	for (int t = 0; t < T; ++t) sch[t].reset(new Scheduler(&hub, t));
+	// worker t owns reads t, t+T, ...: it admits `window` of them and one more whenever one finishes
+	struct Feed { size_t next; };
+	std::vector<Feed> feed(T);
+	for (int t = 0; t < T; ++t) {
+		feed[t].next = (size_t)t;
+		size_t mine = 0;
+		for (size_t i = t; i < tasks.size(); i += T) ++mine;
+		sch[t]->hold((int64_t)mine);
+	}
+	std::function<void(int)> admit = [&](int t) {
+		for (;;) {                                                       // reads that need no work are skipped
+			const size_t i = feed[t].next;
+			if (i >= tasks.size()) return;
+			feed[t].next += (size_t)T;
+			const bool spawned = spawn_read(*sch[t], idx, opt, o2, tasks[i], [&admit, t]() { admit(t); });
+			sch[t]->release(1);
+			if (spawned) return;
+		}
+	};
 	auto work = [&](int t) {
-		for (size_t i = t; i < tasks.size(); i += T) spawn_read(*sch[t], idx, opt, o2, tasks[i]);
+		for (size_t k = 0; k < window; ++k) admit(t);
 		sch[t]->run();
 	};
 	std::vector<std::thread> th;
 	for (int t = 1; t < T; ++t) th.emplace_back(work, t);
 	work(0);
 	for (auto &x : th) x.join();
-	if (stats) { Scheduler &s0 = *sch[0]; stats->n_flush += s0.n_flush; stats->n_ksw += s0.n_ksw_jobs; stats->n_chain += s0.n_chain_jobs; stats->n_seed += s0.n_seed_jobs; stats->n_sketch += s0.n_sketch_jobs; }
+	if (stats) {
+		stats->n_flush += hub.n_batches[OP_SKETCH] + hub.n_batches[OP_SEED] + hub.n_batches[OP_CHAIN] + hub.n_batches[OP_KSW];
+		stats->n_ksw += hub.n_reqs[OP_KSW]; stats->n_chain += hub.n_reqs[OP_CHAIN]; stats->n_seed += hub.n_reqs[OP_SEED]; stats->n_sketch += hub.n_reqs[OP_SKETCH];
+	}
 }
 
 } // namespace wm

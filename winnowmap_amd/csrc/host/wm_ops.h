@@ -32,8 +32,11 @@ struct KswReq {                    // ksw_extd2_sse (src/ksw2.h:60)
 	std::vector<uint32_t> cigar;   // out
 };
 
+// The batch calls are synchronous (they return when the results are in the requests) and must be callable from several threads at
+// once: the hub (wm_fiber.h) keeps up to max_inflight() of them running concurrently.
 struct DeviceOps {
 	virtual ~DeviceOps() {}
+	virtual int max_inflight() const { return 1; }
 	virtual void sketch_batch(int w, int k, std::vector<SketchReq*> &reqs) = 0;
 	virtual void seed_batch(std::vector<SeedReq*> &reqs) = 0;
 	virtual void chain_batch(std::vector<ChainReq*> &reqs) = 0;

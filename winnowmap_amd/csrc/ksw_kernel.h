@@ -54,264 +54,6 @@ template <int B> WM_DEV int get_lane(const V<int> (&a)[B], int base, int t)
 	return r;
 }
 
-template <int B, bool CLIP, bool HASN>
-WM_DEV void ksw_dp_wave(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const uint8_t *__restrict__ seqs,
-                        uint8_t *__restrict__ tb_arena, wm_ksw_dres_t *__restrict__ res)
-{
-	constexpr int NW = B / 4;       // packed-char words per thread
-	constexpr int D = 16 / B;       // threads per 16-lane block
-	static_assert(B == 4 || B == 8 || B == 16, "B");
-	const int qlen = jb.qlen, tlen = jb.tlen, flag = jb.flag, zdrop = jb.zdrop;
-	const int w = jb.w < 0 ? (tlen > qlen ? tlen : qlen) : jb.w;
-	const bool approx = (flag & KSW_F_APPROX_MAX) != 0, right = (flag & KSW_F_RIGHT) != 0;
-	const uint8_t *query = seqs + jb.q_off, *target = seqs + jb.t_off;
-	uint32_t *tbw = (uint32_t*)(tb_arena + jb.tb_off);
-	const int n_colw = jb.n_col >> 2;
-
-	// gap costs, already ordered so that q+e <= q2+e2 by the host (src/ksw2_extd2_sse.c:70)
-	const int q = sc.q, e = sc.e, q2 = sc.q2, e2 = sc.e2, qe = q + e, qe2 = q2 + e2;
-	const int Q = tb8(q), Q2 = tb8(q2), QE = tb8(qe), QE2 = tb8(qe2);
-	// tie-break tags: left-aligned gaps prefer the EARLIER candidate (s,a,b,a2,b2), right-aligned the later
-	const int tS = right ? 0 : 4, tA = right ? 1 : 3, tB = 2, tA2 = right ? 3 : 1, tB2 = right ? 4 : 0;
-	// "gap continues" test: left a>0, right a>=0 (src/ksw2_extd2_sse.c:255 vs :302)
-	const int hA = right ? tA - 1 : tA, hB = right ? tB - 1 : tB, hA2 = right ? tA2 - 1 : tA2, hB2 = right ? tB2 - 1 : tB2;
-	const int MCH = tb8(sc.match), MCHt = MCH | tS, MISt = tb8(sc.mismatch) | tS;
-	const int NNt = tb8(sc.sc_ambi == 0 ? -e2 : sc.sc_ambi) | tS;
-	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;                    // :94-97
-	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
-	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
-
-	const V<int> ln = lane();
-	int base = 0;
-	V<int> U[B], Vv[B], X[B], Y[B], X2[B], Y2[B], S[B], H[B];
-	V<int> TP[NW], QP[NW];
-#pragma unroll
-	for (int i = 0; i < B; ++i) {
-		U[i] = tb8(-qe); Vv[i] = tb8(-qe); X[i] = tA; Y[i] = tB; X2[i] = tA2; Y2[i] = tB2;   // :103-108
-		S[i] = tS; H[i] = KSW_NEG_INF;
-	}
-#pragma unroll
-	for (int wd = 0; wd < NW; ++wd) {
-		V<int> pk = 0;
-#pragma unroll
-		for (int b = 0; b < 4; ++b) {
-			V<int> t = ln * B + (wd * 4 + b);
-			V<int> c = 0;
-			WM_IF(t < tlen) c = cast<int>(gld(target, t)); WM_END
-			pk = pk | (c << (8 * b));
-		}
-		TP[wd] = pk; QP[wd] = 0;
-	}
-
-	// ez (src/ksw2.h:153-158)
-	int ez_max = 0, ez_zdropped = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1;
-	int ez_mte = KSW_NEG_INF, ez_mte_q = -1, ez_score = KSW_NEG_INF;
-	int H0 = 0, last_H0_t = 0, Hbelow = KSW_NEG_INF;
-	const int n_rows = qlen + tlen - 1;
-
-	for (int r = 0; r < n_rows; ++r) {
-		int st0 = 0, en0 = tlen - 1;
-		if (st0 < r - qlen + 1) st0 = r - qlen + 1;
-		if (en0 > r) en0 = r;
-		if (st0 < (r - w + 1) >> 1) st0 = (r - w + 1) >> 1;
-		if (en0 > (r + w) >> 1) en0 = (r + w) >> 1;
-		if (st0 > en0) { ez_zdropped = 1; break; }                                // :134-137
-		const int st = st0 / 16 * 16, en = (en0 + 16) / 16 * 16 - 1;
-		const int sched = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;   // :150,154
-
-		// ---- neighbour inputs from the previous row (lane t-1), before any state changes -------------
-		V<int> XL = shr1(X[B - 1], tA);
-		V<int> VL = shr1(Vv[B - 1], st == 0 ? tb8(sched) : tb8(-qe));
-		V<int> X2L = shr1(X2[B - 1], tA2);
-		V<int> HL = shr1(H[B - 1], Hbelow);
-		V<int> QL = shr1(cast<int>(cast<unsigned>(QP[NW - 1]) >> 24), 0);
-
-		// ---- re-base the register window when the hull start moves up by one 16-lane block -----------
-		if (st > base) {
-			WM_EMU_ASSERT(st == base + 16);
-			Hbelow = readlane(H[B - 1], D - 1);
-			const V<int> tnew = ln * B + st;           // first lane of each thread after the shift
-#pragma unroll
-			for (int i = 0; i < B; ++i) {
-				U[i] = shift_down(U[i], D, tb8(-qe)); Vv[i] = shift_down(Vv[i], D, tb8(-qe));
-				X[i] = shift_down(X[i], D, tA); Y[i] = shift_down(Y[i], D, tB);
-				X2[i] = shift_down(X2[i], D, tA2); Y2[i] = shift_down(Y2[i], D, tB2);
-				if (CLIP) S[i] = shift_down(S[i], D, tS);
-				if (!approx) H[i] = shift_down(H[i], D, KSW_NEG_INF);
-			}
-			XL = shift_down(XL, D, tA); VL = shift_down(VL, D, tb8(-qe)); X2L = shift_down(X2L, D, tA2);
-			HL = shift_down(HL, D, KSW_NEG_INF); QL = shift_down(QL, D, 0);
-#pragma unroll
-			for (int wd = 0; wd < NW; ++wd) {
-				// new top lanes: target codes from memory, query codes of row r-1 (index r-1-t, zero outside)
-				V<int> tp = 0, qp = 0;
-				WM_IF(ln >= 64 - D)
-#pragma unroll
-					for (int b = 0; b < 4; ++b) {
-						V<int> t = tnew + (wd * 4 + b);
-						V<int> c = 0, d = 0;
-						WM_IF(t < tlen) c = cast<int>(gld(target, t)); WM_END
-						V<int> qi = (r - 1) - t;
-						WM_IF(qi >= 0 && qi < qlen) d = cast<int>(gld(query, qi)); WM_END
-						tp = tp | (c << (8 * b)); qp = qp | (d << (8 * b));
-					}
-				WM_END
-				TP[wd] = shift_down(TP[wd], D, tp);
-				QP[wd] = shift_down(QP[wd], D, qp);
-			}
-			// the top thread's left-neighbour char after the shift belongs to lane tnew-1 at row r-1
-			{
-				V<int> qi = (r - 1) - (tnew - 1);
-				V<int> d = 0;
-				WM_IF(ln >= 64 - D && qi >= 0 && qi < qlen) d = cast<int>(gld(query, qi)); WM_END
-				QL = sel(ln >= 64 - D, d, QL);
-			}
-			base = st;
-		}
-		const V<int> t0 = ln * B + base;
-
-		// ---- advance the query codes to row r: lane t takes the code of lane t-1 (systolic) ----------
-		{
-			const int qi0 = r - base;
-			const int newc = qi0 >= 0 && qi0 < qlen ? (int)gld(query, qi0) : 0;
-			V<int> carry = sel(ln == 0, newc, QL);
-#pragma unroll
-			for (int wd = 0; wd < NW; ++wd) {
-				V<int> nxt = cast<int>(cast<unsigned>(QP[wd]) >> 24);
-				QP[wd] = (QP[wd] << 8) | carry;
-				carry = nxt;
-			}
-		}
-
-		// ---- first-column / first-row boundary of lane r (src/ksw2_extd2_sse.c:152-155) --------------
-		if (en >= r) {
-			const int o = r - base, jr = o / B, ir = o % B;
-			WM_EMU_ASSERT(o >= 0 && o < 64 * B);
-			WM_IF(ln == jr)
-#pragma unroll
-				for (int i = 0; i < B; ++i)
-					if (ir == i) { Y[i] = tB; Y2[i] = tB2; U[i] = tb8(sched); }
-			WM_END
-		}
-
-		// ---- match/mismatch scores; with CLIP the score row is persistent and only the 16-byte chunks
-		//      starting at st0 are rewritten (:158-173) ------------------------------------------------
-		V<int> Sc[B];
-		{
-			const int cend = st0 + (en0 - st0) / 16 * 16 + 15;
-#pragma unroll
-			for (int i = 0; i < B; ++i) {
-				const int wd = i >> 2, sh = 8 * (i & 3);
-				V<int> tc = (TP[wd] >> sh) & 0xff, qc = (QP[wd] >> sh) & 0xff;
-				V<int> s = sel(tc == qc, MCHt, MISt);
-				if (HASN) s = sel((tc == 4) || (qc == 4), NNt, s);
-				if (CLIP) {
-					V<int> t = t0 + i;
-					S[i] = sel(t >= st0 && t <= cend, s, S[i]);
-					Sc[i] = S[i];
-				} else Sc[i] = s;
-			}
-		}
-
-		// ---- the DP cells of this thread (only threads inside the hull) ------------------------------
-		WM_IF(t0 <= en)
-			V<int> pk[NW];
-#pragma unroll
-			for (int wd = 0; wd < NW; ++wd) pk[wd] = 0;
-#pragma unroll
-			for (int i = B - 1; i >= 0; --i) {          // descending: lane i reads the OLD state of lane i-1
-				V<int> x1 = i ? X[i - 1] : XL, v1 = i ? Vv[i - 1] : VL, x21 = i ? X2[i - 1] : X2L;
-				V<int> ut = U[i];
-				V<int> a = add3(x1, v1, -QE), b = add3(Y[i], ut, -QE);
-				V<int> a2 = add3(x21, v1, -QE2), b2 = add3(Y2[i], ut, -QE2);
-				V<int> zz = vmax3(vmax3(Sc[i], a, b), a2, b2);
-				V<int> z = vmin(zz & (int)0xff000000, MCH);
-				V<int> p = zz & 7;
-				U[i] = wsub(z, v1); Vv[i] = wsub(z, ut);
-				V<int> tmp = wsub(z, Q), tmp2 = wsub(z, Q2);
-				a = wsub(a, tmp); b = wsub(b, tmp); a2 = wsub(a2, tmp2); b2 = wsub(b2, tmp2);
-				p = wadd(wadd(p, p), sel(a > hA, 1, 0));
-				p = wadd(wadd(p, p), sel(b > hB, 1, 0));
-				p = wadd(wadd(p, p), sel(a2 > hA2, 1, 0));
-				p = wadd(wadd(p, p), sel(b2 > hB2, 1, 0));
-				X[i] = vmax(a, tA); Y[i] = vmax(b, tB); X2[i] = vmax(a2, tA2); Y2[i] = vmax(b2, tB2);
-				pk[i >> 2] = pk[i >> 2] | (p << (8 * (i & 3)));
-			}
-			uint32_t *trow = tbw + (size_t)r * n_colw;
-#pragma unroll
-			for (int wd = 0; wd < NW; ++wd)
-				gst(trow, ln * NW + wd, cast<uint32_t>(pk[wd]));
-		WM_END
-
-		if (!approx) {   // ---- exact max with the reference's SIMD tie rule (:315-358) -----------------
-			V<long long> key = (long long)(-0x7fffffffffffffffLL - 1);
-			if (r > 0) {
-				const int en1 = st0 + (en0 - st0) / 4 * 4;
-#pragma unroll
-				for (int i = B - 1; i >= 0; --i) {
-					V<int> t = t0 + i, v8 = Vv[i] >> 24, u8 = U[i] >> 24;
-					V<int> hl = i ? H[i - 1] : HL;
-					V<int> hn = H[i] + v8;
-					hn = sel(t == en0, en0 > 0 ? V<int>(hl + u8) : hn, hn);
-					H[i] = sel(t >= st0 && t <= en0, hn, H[i]);
-					// priority on ties: en0, then residue groups 0..3 of [st0,en1) (earliest first), then the tail
-					V<int> grp = sel(t == en0, 5, sel(t < en1, 4 - ((t - st0) & 3), 0));
-					V<int> pri = (grp << 20) | (0xfffff - t);
-					V<long long> k = cast<long long>(H[i]) * 4294967296LL + cast<long long>(pri);
-					key = sel(t >= st0 && t <= en0 && k > key, k, key);
-				}
-			} else {
-				WM_IF(ln == 0) H[0] = (Vv[0] >> 24) - qe; WM_END
-				V<long long> k = cast<long long>(H[0]) * 4294967296LL + (long long)((5 << 20) | 0xfffff);
-				key = sel(ln == 0, k, key);
-			}
-			key = wave_max_i64(key);
-			const long long kk = uniform(key);
-			const int max_H = (int)(kk >> 32), pri = (int)(kk & 0xffffffffLL);
-			const int max_t = 0xfffff - (pri & 0xfffff);
-			if (en0 == tlen - 1) { const int h = get_lane<B>(H, base, en0); if (h > ez_mte) ez_mte = h, ez_mte_q = r - en; }
-			if (r - st0 == qlen - 1) { const int h = get_lane<B>(H, base, st0); if (h > ez_mqe) ez_mqe = h, ez_mqe_t = st0; }
-			// ksw_apply_zdrop (src/ksw2.h:160-176)
-			if (max_H > ez_max) {
-				ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
-			} else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
-				const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
-				if (zdrop >= 0 && ez_max - max_H > zdrop + l * e2) { ez_zdropped = 1; break; }
-			}
-			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = get_lane<B>(H, base, tlen - 1);
-		} else {        // ---- approximate max: follow one diagonal-ish track (:359-375) ---------------
-			if (r > 0) {
-				const bool in0 = last_H0_t >= st0 && last_H0_t <= en0, in1 = last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0;
-				if (in0 && in1) {
-					const int d0 = get_lane<B>(Vv, base, last_H0_t) >> 24, d1 = get_lane<B>(U, base, last_H0_t + 1) >> 24;
-					if (d0 > d1) H0 += d0;
-					else H0 += d1, ++last_H0_t;
-				} else if (in0) {
-					H0 += get_lane<B>(Vv, base, last_H0_t) >> 24;
-				} else {
-					++last_H0_t;
-					H0 += get_lane<B>(U, base, last_H0_t) >> 24;
-				}
-			} else H0 = (readlane(Vv[0], 0) >> 24) - qe, last_H0_t = 0;
-			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = H0;
-		}
-	}
-
-	// ---- results + where the backtrack starts (src/ksw2_extd2_sse.c:381-391) ---------------------------
-	int bt_i = -1, bt_j = -1, reach_end = 0;
-	if (!ez_zdropped && !(flag & KSW_F_EXTZ_ONLY)) bt_i = tlen - 1, bt_j = qlen - 1;
-	else if (!ez_zdropped && (flag & KSW_F_EXTZ_ONLY) && ez_mqe + jb.end_bonus > ez_max) reach_end = 1, bt_i = ez_mqe_t, bt_j = qlen - 1;
-	else if (ez_max_t >= 0 && ez_max_q >= 0) bt_i = ez_max_t, bt_j = ez_max_q;
-	WM_IF(ln == 0)
-		wm_ksw_dres_t o;
-		o.max = ez_max; o.zdropped = ez_zdropped; o.max_q = ez_max_q; o.max_t = ez_max_t;
-		o.mqe = ez_mqe; o.mqe_t = ez_mqe_t; o.mte = ez_mte; o.mte_q = ez_mte_q;
-		o.score = ez_score; o.reach_end = reach_end; o.n_cigar = 0; o.bt_i = bt_i; o.bt_j = bt_j;
-		*res = o;
-	WM_END
-}
-
-
 // ------------------------------------------------------------------------------------------------------
 // Generic kernel for band hulls wider than the register window (> 1008 lanes; long gaps of stage 2, LONG_JOIN
 // segments of asm20): same machine, but the per-lane state lives in memory as int8 arrays indexed by the target
@@ -560,576 +302,6 @@ template <int B> WM_DEV void rebase_striped(V<int> (&a)[B], const V<int> fresh, 
 		cur = nxt;
 	}
 }
-
-template <int B, bool CLIP, bool HASN>
-WM_DEV void ksw_dp_striped(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const uint8_t *__restrict__ seqs,
-                           uint8_t *__restrict__ tb_arena, wm_ksw_dres_t *__restrict__ res)
-{
-	constexpr int NW = B / 4;
-	static_assert(B == 4 || B == 8 || B == 16, "B");
-	const int qlen = jb.qlen, tlen = jb.tlen, flag = jb.flag, zdrop = jb.zdrop;
-	const int w = jb.w < 0 ? (tlen > qlen ? tlen : qlen) : jb.w;
-	const bool approx = (flag & KSW_F_APPROX_MAX) != 0, right = (flag & KSW_F_RIGHT) != 0;
-	const uint8_t *query = seqs + jb.q_off, *target = seqs + jb.t_off;
-	uint8_t *tbp = tb_arena + jb.tb_off;
-	const int q = sc.q, e = sc.e, q2 = sc.q2, e2 = sc.e2, qe = q + e, qe2 = q2 + e2;
-	const int Q = tb8(q), Q2 = tb8(q2), QE = tb8(qe), QE2 = tb8(qe2);
-	const int tS = right ? 0 : 4, tA = right ? 1 : 3, tB = 2, tA2 = right ? 3 : 1, tB2 = right ? 4 : 0;
-	const int hA = right ? tA - 1 : tA, hB = right ? tB - 1 : tB, hA2 = right ? tA2 - 1 : tA2, hB2 = right ? tB2 - 1 : tB2;
-	const int MCH = tb8(sc.match), MCHt = MCH | tS, MISt = tb8(sc.mismatch) | tS;
-	const int NNt = tb8(sc.sc_ambi == 0 ? -e2 : sc.sc_ambi) | tS;
-	const ksw_cell_cst_t cc = { Q, Q2, QE, QE2, MCH, tA, tB, tA2, tB2, hA, hB, hA2, hB2 };
-	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
-	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
-	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
-
-	const V<int> ln = lane();
-	const vbool low48 = ln < 48;
-	int base = 0;
-	V<int> U[B], Vv[B], X[B], Y[B], X2[B], Y2[B], S[B], H[B];
-	V<int> TP[NW], QP[NW];
-#pragma unroll
-	for (int i = 0; i < B; ++i) {
-		U[i] = tb8(-qe); Vv[i] = tb8(-qe); X[i] = tA; Y[i] = tB; X2[i] = tA2; Y2[i] = tB2;
-		S[i] = tS; H[i] = KSW_NEG_INF;
-	}
-#pragma unroll
-	for (int wd = 0; wd < NW; ++wd) {
-		V<int> pk = 0;
-#pragma unroll
-		for (int b = 0; b < 4; ++b) {
-			const V<int> t = ln + 64 * (wd * 4 + b);
-			V<int> c = 0;
-			WM_IF(t < tlen) c = cast<int>(gld(target, t)); WM_END
-			pk = pk | (c << (8 * b));
-		}
-		TP[wd] = pk; QP[wd] = 0;
-	}
-
-	int ez_max = 0, ez_zdropped = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1;
-	int ez_mte = KSW_NEG_INF, ez_mte_q = -1, ez_score = KSW_NEG_INF;
-	int H0 = 0, last_H0_t = 0, Hbelow = KSW_NEG_INF;
-	const int n_rows = qlen + tlen - 1;
-
-	for (int r = 0; r < n_rows; ++r) {
-		int st0 = 0, en0 = tlen - 1;
-		if (st0 < r - qlen + 1) st0 = r - qlen + 1;
-		if (en0 > r) en0 = r;
-		if (st0 < (r - w + 1) >> 1) st0 = (r - w + 1) >> 1;
-		if (en0 > (r + w) >> 1) en0 = (r + w) >> 1;
-		if (st0 > en0) { ez_zdropped = 1; break; }
-		const int st = st0 / 16 * 16, en = (en0 + 16) / 16 * 16 - 1;
-		const int sched = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
-
-		// previous-row values of lane st-1 for the first lane of the hull (src/ksw2_extd2_sse.c:141-151): constants unless the
-		// hull start just moved up, in which case lane st-1 is old chunk 0, thread 15
-		int f_x = tA, f_v = st == 0 ? tb8(sched) : tb8(-qe), f_x2 = tA2;
-		if (st > base) {
-			WM_EMU_ASSERT(st == base + 16);
-			f_x = readlane(X[0], 15); f_v = readlane(Vv[0], 15); f_x2 = readlane(X2[0], 15);
-			Hbelow = readlane(H[0], 15);
-			rebase_striped<B>(U, V<int>(tb8(-qe)), low48); rebase_striped<B>(Vv, V<int>(tb8(-qe)), low48);
-			rebase_striped<B>(X, V<int>(tA), low48); rebase_striped<B>(Y, V<int>(tB), low48);
-			rebase_striped<B>(X2, V<int>(tA2), low48); rebase_striped<B>(Y2, V<int>(tB2), low48);
-			if (CLIP) rebase_striped<B>(S, V<int>(tS), low48);
-			if (!approx) rebase_striped<B>(H, V<int>(KSW_NEG_INF), low48);
-			{   // packed characters: the fresh top 16 lanes take target codes from memory and the query codes of row r-1
-				const V<int> tnew = ln + (st + 64 * (B - 1));
-				V<int> c = 0, d = 0;
-				WM_IF(!low48)
-					WM_IF(tnew < tlen) c = cast<int>(gld(target, tnew)); WM_END
-					const V<int> qi = (r - 1) - tnew;
-					WM_IF(qi >= 0 && qi < qlen) d = cast<int>(gld(query, qi)); WM_END
-				WM_END
-				V<int> rt[NW], rq[NW];
-#pragma unroll
-				for (int wd = 0; wd < NW; ++wd) { rt[wd] = rot_down(TP[wd], 16); rq[wd] = rot_down(QP[wd], 16); }
-#pragma unroll
-				for (int wd = 0; wd < NW; ++wd) {
-					const V<int> nt = wd + 1 < NW ? rt[wd + 1 < NW ? wd + 1 : wd] : c, nq = wd + 1 < NW ? rq[wd + 1 < NW ? wd + 1 : wd] : d;
-					const V<int> ct = cast<int>((cast<unsigned>(rt[wd]) >> 8) | (cast<unsigned>(nt) << 24));
-					const V<int> cq = cast<int>((cast<unsigned>(rq[wd]) >> 8) | (cast<unsigned>(nq) << 24));
-					TP[wd] = sel(low48, rt[wd], ct); QP[wd] = sel(low48, rq[wd], cq);
-				}
-			}
-			base = st;
-		}
-
-		// ---- advance the query codes to row r: every lane takes the code of lane t-1 (one thread down; thread 0 of chunk i
-		//      takes thread 63 of chunk i-1; the first lane of the window takes query[r - base]) --------------------------------
-		{
-			const int qi0 = r - base;
-			const int newc = qi0 >= 0 && qi0 < qlen ? (int)gld(query, qi0) : 0;
-			int q63[NW];
-#pragma unroll
-			for (int wd = 0; wd < NW; ++wd) q63[wd] = readlane(QP[wd], 63);
-#pragma unroll
-			for (int wd = 0; wd < NW; ++wd) {
-				const int fill = (int)(((unsigned)q63[wd] << 8) | (wd ? (unsigned)q63[wd ? wd - 1 : 0] >> 24 : (unsigned)newc));
-				QP[wd] = shr1(QP[wd], fill);
-			}
-		}
-
-		// ---- first-column / first-row boundary of lane r (src/ksw2_extd2_sse.c:152-155) --------------------------------------------
-		if (en >= r) {
-			const int o = r - base, jr = o & 63, ir = o >> 6;
-			WM_EMU_ASSERT(o >= 0 && o < 64 * B);
-			WM_IF(ln == jr)
-#pragma unroll
-				for (int i = 0; i < B; ++i)
-					if (ir == i) { Y[i] = tB; Y2[i] = tB2; U[i] = tb8(sched); }
-			WM_END
-		}
-
-		const int cend = st0 + (en0 - st0) / 16 * 16 + 15;         // last lane of the rewritten score chunks (:158-173)
-		const int NI = ((en - base) >> 6) + 1;                       // chunks that intersect the hull
-		const int NS = CLIP ? ((((cend > en ? cend : en) - base) >> 6) + 1) : NI;
-		WM_EMU_ASSERT(NS <= B);
-		V<int> hmax = KSW_NEG_INF;
-		uint8_t *trow = tbp + (size_t)r * jb.n_col + (base - st);
-
-#pragma unroll
-		for (int i = B - 1; i >= 0; --i) {
-			if (i >= NS) continue;
-			const int c0 = base + 64 * i;
-			const V<int> t = ln + c0;
-			// match/mismatch scores; with CLIP the score row is persistent and only [st0, cend] is rewritten
-			const int wd = i >> 2, sh = 8 * (i & 3);
-			const V<int> tc = (TP[wd] >> sh) & 0xff, qc = (QP[wd] >> sh) & 0xff;
-			V<int> sv = sel(tc == qc, MCHt, MISt);
-			if (HASN) sv = sel((tc == 4) || (qc == 4), NNt, sv);
-			if (CLIP) { S[i] = sel(t >= st0 && t <= cend, sv, S[i]); sv = S[i]; }
-			if (i >= NI) continue;
-			// previous-row values of lane t-1
-			const V<int> x1 = shr1(X[i], i ? readlane(X[i ? i - 1 : 0], 63) : f_x);
-			const V<int> v1 = shr1(Vv[i], i ? readlane(Vv[i ? i - 1 : 0], 63) : f_v);
-			const V<int> x21 = shr1(X2[i], i ? readlane(X2[i ? i - 1 : 0], 63) : f_x2);
-			V<int> hl = KSW_NEG_INF;
-			if (!approx) hl = shr1(H[i], i ? readlane(H[i ? i - 1 : 0], 63) : Hbelow);
-			const V<int> ou = U[i];
-			WM_IF(t <= en)
-				V<int> nu, nv, nx, ny, nx2, ny2, p;
-				ksw_cell(cc, sv, x1, v1, x21, Y[i], ou, Y2[i], nu, nv, nx, ny, nx2, ny2, p);
-				U[i] = nu; Vv[i] = nv; X[i] = nx; Y[i] = ny; X2[i] = nx2; Y2[i] = ny2;
-				gst(trow, t - base, cast<uint8_t>(p));
-			WM_END
-			if (!approx && r > 0) {
-				if (c0 >= st0 && c0 + 63 < en0) {                 // chunk strictly inside the band: every lane is a plain update
-					H[i] = H[i] + (Vv[i] >> 24);
-					hmax = vmax(hmax, H[i]);
-				} else {
-					const V<int> v8 = Vv[i] >> 24, u8 = U[i] >> 24;
-					V<int> hn = H[i] + v8;
-					hn = sel(t == en0, en0 > 0 ? V<int>(hl + u8) : hn, hn);
-					const vbool inb = t >= st0 && t <= en0;
-					H[i] = sel(inb, hn, H[i]);
-					hmax = vmax(hmax, sel(inb, H[i], V<int>(KSW_NEG_INF)));
-				}
-			}
-		}
-
-		if (!approx) {   // ---- exact max: 32-bit wave maximum, then the lanes that reach it ---------------------------------
-			int max_H, max_t;
-			if (r > 0) {
-				max_H = wave_max_i32(hmax);
-				const int en1 = st0 + (en0 - st0) / 4 * 4;
-				int best_pri = -1;
-				max_t = en0;
-#pragma unroll
-				for (int i = 0; i < B; ++i) {
-					if (i >= NI) continue;
-					const int c0 = base + 64 * i;
-					if (c0 > en0 || c0 + 63 < st0) continue;
-					const int lo = st0 > c0 ? st0 - c0 : 0, hi = en0 - c0 < 63 ? en0 - c0 : 63;
-					const uint64_t band = (hi == 63 ? ~(uint64_t)0 : (((uint64_t)1 << (hi + 1)) - 1)) & ~(((uint64_t)1 << lo) - 1);
-					uint64_t m = ballot(H[i] == max_H) & band;
-					while (m) {                                   // priority on ties: en0, then residue groups 0..3 of [st0,en1), then the tail
-						const int tt = c0 + __builtin_ctzll(m);
-						m &= m - 1;
-						const int grp = tt == en0 ? 5 : tt < en1 ? 4 - ((tt - st0) & 3) : 0;
-						const int pri = (grp << 20) | (0xfffff - tt);
-						if (pri > best_pri) best_pri = pri, max_t = tt;
-					}
-				}
-			} else {
-				WM_IF(ln == 0) H[0] = (Vv[0] >> 24) - qe; WM_END
-				max_H = readlane(H[0], 0); max_t = 0;
-			}
-			if (en0 == tlen - 1) { const int h = get_lane_striped<B>(H, base, en0); if (h > ez_mte) ez_mte = h, ez_mte_q = r - en; }
-			if (r - st0 == qlen - 1) { const int h = get_lane_striped<B>(H, base, st0); if (h > ez_mqe) ez_mqe = h, ez_mqe_t = st0; }
-			if (max_H > ez_max) {
-				ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
-			} else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
-				const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
-				if (zdrop >= 0 && ez_max - max_H > zdrop + l * e2) { ez_zdropped = 1; break; }
-			}
-			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = get_lane_striped<B>(H, base, tlen - 1);
-		} else {        // ---- approximate max: follow one diagonal-ish track (:359-375) ----------------------------------
-			if (r > 0) {
-				const bool in0 = last_H0_t >= st0 && last_H0_t <= en0, in1 = last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0;
-				if (in0 && in1) {
-					const int d0 = get_lane_striped<B>(Vv, base, last_H0_t) >> 24, d1 = get_lane_striped<B>(U, base, last_H0_t + 1) >> 24;
-					if (d0 > d1) H0 += d0;
-					else H0 += d1, ++last_H0_t;
-				} else if (in0) {
-					H0 += get_lane_striped<B>(Vv, base, last_H0_t) >> 24;
-				} else {
-					++last_H0_t;
-					H0 += get_lane_striped<B>(U, base, last_H0_t) >> 24;
-				}
-			} else H0 = (readlane(Vv[0], 0) >> 24) - qe, last_H0_t = 0;
-			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = H0;
-		}
-	}
-
-	int bt_i = -1, bt_j = -1, reach_end = 0;
-	if (!ez_zdropped && !(flag & KSW_F_EXTZ_ONLY)) bt_i = tlen - 1, bt_j = qlen - 1;
-	else if (!ez_zdropped && (flag & KSW_F_EXTZ_ONLY) && ez_mqe + jb.end_bonus > ez_max) reach_end = 1, bt_i = ez_mqe_t, bt_j = qlen - 1;
-	else if (ez_max_t >= 0 && ez_max_q >= 0) bt_i = ez_max_t, bt_j = ez_max_q;
-	WM_IF(ln == 0)
-		wm_ksw_dres_t o;
-		o.max = ez_max; o.zdropped = ez_zdropped; o.max_q = ez_max_q; o.max_t = ez_max_t;
-		o.mqe = ez_mqe; o.mqe_t = ez_mqe_t; o.mte = ez_mte; o.mte_q = ez_mte_q;
-		o.score = ez_score; o.reach_end = reach_end; o.n_cigar = 0; o.bt_i = bt_i; o.bt_j = bt_j;
-		*res = o;
-	WM_END
-}
-
-
-// ------------------------------------------------------------------------------------------------------
-// ksw_dp_smulti: the striped machine spread over NWV wavefronts of one workgroup. Chunk c (64 lanes) belongs to wave
-// c % NWV, which keeps its CPW chunks in registers (local index i = c / NWV), so a row costs every wave only the
-// chunks of the hull it owns, the four SIMDs of a CU work on one alignment in parallel, and the register footprint per
-// thread is that of CPW chunks (window = 64*CPW*NWV lanes: <4,4> = 1024, <4,16> = 4096, <8,16> = 8192).
-// What crosses a chunk boundary goes through LDS, since neighbouring chunks live in different waves:
-//   xch[parity][c] : previous-row x, v, x2, H and query code of lane 63 of chunk c (published at the end of a row);
-//   rb[c][10][16]  : on a window re-base, the low 16 threads of every chunk for the chunk below;
-//   pub[parity]    : per-wave row maximum (tie rule applied inside the wave), H at en0 / st0, approximate-max track.
-// One barrier per row (two on re-base rows); every wave replays the same scalar bookkeeping.
-// ------------------------------------------------------------------------------------------------------
-template <int CPW, int NWV> struct ksw_smulti_lds { enum { NC = CPW * NWV, XCH = 2 * NC * 5, PUB = 2 * (2 * NWV + 4), RB = NC * 160, INTS = XCH + PUB + RB }; };
-
-template <int CPW, int NWV, bool CLIP, bool HASN>
-WM_DEV void ksw_dp_smulti(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const uint8_t *query, const uint8_t *target,
-                          uint8_t *__restrict__ tb_arena, int *lds, wm_ksw_dres_t *__restrict__ res)
-{
-	typedef ksw_smulti_lds<CPW, NWV> L;
-	constexpr int NW = (CPW + 3) / 4, NC = CPW * NWV;
-	int *xch = lds, *pub = lds + L::XCH, *rb = pub + L::PUB;
-	const int qlen = jb.qlen, tlen = jb.tlen, flag = jb.flag, zdrop = jb.zdrop;
-	const int w = jb.w < 0 ? (tlen > qlen ? tlen : qlen) : jb.w;
-	const bool approx = (flag & KSW_F_APPROX_MAX) != 0, right = (flag & KSW_F_RIGHT) != 0;
-	uint8_t *tbp = tb_arena + jb.tb_off;
-	const int q = sc.q, e = sc.e, q2 = sc.q2, e2 = sc.e2, qe = q + e, qe2 = q2 + e2;
-	const int Q = tb8(q), Q2 = tb8(q2), QE = tb8(qe), QE2 = tb8(qe2);
-	const int tS = right ? 0 : 4, tA = right ? 1 : 3, tB = 2, tA2 = right ? 3 : 1, tB2 = right ? 4 : 0;
-	const int hA = right ? tA - 1 : tA, hB = right ? tB - 1 : tB, hA2 = right ? tA2 - 1 : tA2, hB2 = right ? tB2 - 1 : tB2;
-	const int MCH = tb8(sc.match), MCHt = MCH | tS, MISt = tb8(sc.mismatch) | tS;
-	const int NNt = tb8(sc.sc_ambi == 0 ? -e2 : sc.sc_ambi) | tS;
-	const ksw_cell_cst_t cc = { Q, Q2, QE, QE2, MCH, tA, tB, tA2, tB2, hA, hB, hA2, hB2 };
-	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
-	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
-	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
-
-	const V<int> ln = lane();
-	const vbool low48 = ln < 48;
-	const int wv = wave_in_block();
-	int base = 0;
-	V<int> U[CPW], Vv[CPW], X[CPW], Y[CPW], X2[CPW], Y2[CPW], S[CPW], H[CPW];
-	V<int> TP[NW], QP[NW];                                    // byte k of word wd: local chunk 4*wd + k
-#pragma unroll
-	for (int i = 0; i < CPW; ++i) {
-		U[i] = tb8(-qe); Vv[i] = tb8(-qe); X[i] = tA; Y[i] = tB; X2[i] = tA2; Y2[i] = tB2;
-		S[i] = tS; H[i] = KSW_NEG_INF;
-	}
-#pragma unroll
-	for (int wd = 0; wd < NW; ++wd) {
-		V<int> pk = 0;
-#pragma unroll
-		for (int b = 0; b < 4; ++b) {
-			if (wd * 4 + b >= CPW) continue;
-			const V<int> t = ln + 64 * ((wd * 4 + b) * NWV + wv);
-			V<int> c = 0;
-			WM_IF(t < tlen) c = cast<int>(gld(target, t)); WM_END
-			pk = pk | (c << (8 * b));
-		}
-		TP[wd] = pk; QP[wd] = 0;
-	}
-	// "previous row" of row 0 = the initial state (parity 1)
-	WM_IF(ln == 0)
-#pragma unroll
-		for (int i = 0; i < CPW; ++i) {
-			int *x = xch + (1 * NC + (i * NWV + wv)) * 5;
-			gst(x, V<int>(0), V<int>(tA)); gst(x, V<int>(1), V<int>(tb8(-qe))); gst(x, V<int>(2), V<int>(tA2)); gst(x, V<int>(3), V<int>(KSW_NEG_INF)); gst(x, V<int>(4), V<int>(0));
-		}
-	WM_END
-	block_sync_lds();
-
-	int ez_max = 0, ez_zdropped = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1;
-	int ez_mte = KSW_NEG_INF, ez_mte_q = -1, ez_score = KSW_NEG_INF;
-	int H0 = 0, last_H0_t = 0, Hbelow = KSW_NEG_INF;
-	const int n_rows = qlen + tlen - 1;
-
-	for (int r = 0; r < n_rows; ++r) {
-		int st0 = 0, en0 = tlen - 1;
-		if (st0 < r - qlen + 1) st0 = r - qlen + 1;
-		if (en0 > r) en0 = r;
-		if (st0 < (r - w + 1) >> 1) st0 = (r - w + 1) >> 1;
-		if (en0 > (r + w) >> 1) en0 = (r + w) >> 1;
-		if (st0 > en0) { ez_zdropped = 1; break; }
-		const int st = st0 / 16 * 16, en = (en0 + 16) / 16 * 16 - 1;
-		const int sched = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
-		const int par = r & 1, ppar = par ^ 1;
-		int *pubr = pub + par * (2 * NWV + 4);
-		const int *xprev = xch + ppar * NC * 5;
-		int *xcur = xch + par * NC * 5;
-
-		// previous-row values of the lane below every chunk's first lane (nb*): normally lane 63 of the chunk below (xch; for
-		// chunk 0 the constants of src/ksw2_extd2_sse.c:141-151). On a re-base row the window moves up by 16 lanes, so the lane
-		// below new thread 0 is OLD thread 15 of the same chunk: read it before the rotation.
-		const int qi0n = r - st;
-		const int newc = qi0n >= 0 && qi0n < qlen ? (int)gld(query, qi0n) : 0;
-		int nbx[CPW], nbv[CPW], nbx2[CPW], nbh[CPW], nbq[CPW];
-		if (st > base) {
-			WM_EMU_ASSERT(st == base + 16);
-#pragma unroll
-			for (int i = 0; i < CPW; ++i) {
-				nbx[i] = readlane(X[i], 15); nbv[i] = readlane(Vv[i], 15); nbx2[i] = readlane(X2[i], 15); nbh[i] = readlane(H[i], 15);
-				nbq[i] = readlane((QP[i >> 2] >> (8 * (i & 3))) & 0xff, 15);
-			}
-			if (wv == 0) { Hbelow = nbh[0]; nbq[0] = newc; }
-			// every chunk hands its low 16 threads to the chunk below (which lives in another wave)
-			WM_IF(ln < 16)
-#pragma unroll
-				for (int i = 0; i < CPW; ++i) {
-					int *o = rb + (i * NWV + wv) * 160;
-					const int wd = i >> 2, sh = 8 * (i & 3);
-					gst(o, ln, U[i]); gst(o, ln + 16, Vv[i]); gst(o, ln + 32, X[i]); gst(o, ln + 48, Y[i]); gst(o, ln + 64, X2[i]); gst(o, ln + 80, Y2[i]);
-					gst(o, ln + 96, S[i]); gst(o, ln + 112, H[i]); gst(o, ln + 128, (TP[wd] >> sh) & 0xff); gst(o, ln + 144, (QP[wd] >> sh) & 0xff);
-				}
-			WM_END
-			block_sync_lds();
-#pragma unroll
-			for (int i = 0; i < CPW; ++i) {
-				const int c = i * NWV + wv, wd = i >> 2, sh = 8 * (i & 3);
-				V<int> fU = tb8(-qe), fV = tb8(-qe), fX = tA, fY = tB, fX2 = tA2, fY2 = tB2, fS = tS, fH = KSW_NEG_INF, fT = 0, fQ = 0;
-				if (c + 1 < NC) {
-					const int *o = rb + (c + 1) * 160;
-					WM_IF(!low48)
-						const V<int> k = ln - 48;
-						fU = gld(o, k); fV = gld(o, k + 16); fX = gld(o, k + 32); fY = gld(o, k + 48); fX2 = gld(o, k + 64); fY2 = gld(o, k + 80);
-						fS = gld(o, k + 96); fH = gld(o, k + 112); fT = gld(o, k + 128); fQ = gld(o, k + 144);
-					WM_END
-				} else {                                           // top of the window: fresh lanes
-					const V<int> tnew = ln + (st + 64 * c);
-					WM_IF(!low48)
-						WM_IF(tnew < tlen) fT = cast<int>(gld(target, tnew)); WM_END
-						const V<int> qi = (r - 1) - tnew;
-						WM_IF(qi >= 0 && qi < qlen) fQ = cast<int>(gld(query, qi)); WM_END
-					WM_END
-				}
-				U[i] = sel(low48, rot_down(U[i], 16), fU); Vv[i] = sel(low48, rot_down(Vv[i], 16), fV);
-				X[i] = sel(low48, rot_down(X[i], 16), fX); Y[i] = sel(low48, rot_down(Y[i], 16), fY);
-				X2[i] = sel(low48, rot_down(X2[i], 16), fX2); Y2[i] = sel(low48, rot_down(Y2[i], 16), fY2);
-				if (CLIP) S[i] = sel(low48, rot_down(S[i], 16), fS);
-				if (!approx) H[i] = sel(low48, rot_down(H[i], 16), fH);
-				const V<int> tcn = sel(low48, rot_down((TP[wd] >> sh) & 0xff, 16), fT), qcn = sel(low48, rot_down((QP[wd] >> sh) & 0xff, 16), fQ);
-				TP[wd] = (TP[wd] & ~(0xff << sh)) | (tcn << sh);
-				QP[wd] = (QP[wd] & ~(0xff << sh)) | (qcn << sh);
-			}
-			base = st;
-		} else {
-#pragma unroll
-			for (int i = 0; i < CPW; ++i) {
-				const int c = i * NWV + wv;
-				if (c) { const int *x = xprev + (c - 1) * 5; nbx[i] = gld(x, 0LL); nbv[i] = gld(x, 1LL); nbx2[i] = gld(x, 2LL); nbh[i] = gld(x, 3LL); nbq[i] = gld(x, 4LL); }
-				else { nbx[i] = tA; nbv[i] = st == 0 ? tb8(sched) : tb8(-qe); nbx2[i] = tA2; nbh[i] = Hbelow; nbq[i] = newc; }
-			}
-		}
-
-		// ---- advance the query codes to row r: every lane takes the code of lane t-1; thread 0 of chunk c takes lane 63 of
-		//      chunk c-1 (previous row: xch), the first lane of the window takes query[r - base] ------------------------------------
-		{
-#pragma unroll
-			for (int wd = 0; wd < NW; ++wd) {
-				unsigned fill = 0;
-#pragma unroll
-				for (int b = 0; b < 4; ++b) {
-					if (wd * 4 + b >= CPW) continue;
-					fill |= (unsigned)(nbq[wd * 4 + b < CPW ? wd * 4 + b : 0] & 0xff) << (8 * b);
-				}
-				QP[wd] = shr1(QP[wd], (int)fill);
-			}
-		}
-
-		// ---- first-column / first-row boundary of lane r ------------------------------------------------------------------------------
-		if (en >= r) {
-			const int o = r - base, jr = o & 63, cr = o >> 6;
-			WM_EMU_ASSERT(o >= 0 && o < 64 * NC);
-			if (cr % NWV == wv) {
-				const int ir = cr / NWV;
-				WM_IF(ln == jr)
-#pragma unroll
-					for (int i = 0; i < CPW; ++i)
-						if (ir == i) { Y[i] = tB; Y2[i] = tB2; U[i] = tb8(sched); }
-				WM_END
-			}
-		}
-
-		const int cend = st0 + (en0 - st0) / 16 * 16 + 15;
-		const int NI = ((en - base) >> 6) + 1;
-		const int NS = CLIP ? ((((cend > en ? cend : en) - base) >> 6) + 1) : NI;
-		WM_EMU_ASSERT(NS <= NC);
-		V<int> hmax = KSW_NEG_INF;
-		uint8_t *trow = tbp + (size_t)r * jb.n_col + (base - st);
-
-#pragma unroll
-		for (int i = 0; i < CPW; ++i) {
-			const int c = i * NWV + wv;
-			if (c >= NS) continue;
-			const int c0 = base + 64 * c;
-			const V<int> t = ln + c0;
-			const int wd = i >> 2, sh = 8 * (i & 3);
-			const V<int> tc = (TP[wd] >> sh) & 0xff, qc = (QP[wd] >> sh) & 0xff;
-			V<int> sv = sel(tc == qc, MCHt, MISt);
-			if (HASN) sv = sel((tc == 4) || (qc == 4), NNt, sv);
-			if (CLIP) { S[i] = sel(t >= st0 && t <= cend, sv, S[i]); sv = S[i]; }
-			if (c >= NI) continue;
-			// previous-row values of lane t-1: one DPP shift inside the chunk, the chunk below (xch) for thread 0
-			const V<int> x1 = shr1(X[i], nbx[i]), v1 = shr1(Vv[i], nbv[i]), x21 = shr1(X2[i], nbx2[i]);
-			V<int> hl = KSW_NEG_INF;
-			if (!approx) hl = shr1(H[i], nbh[i]);
-			const V<int> ou = U[i];
-			WM_IF(t <= en)
-				V<int> nu, nv, nx, ny, nx2, ny2, p;
-				ksw_cell(cc, sv, x1, v1, x21, Y[i], ou, Y2[i], nu, nv, nx, ny, nx2, ny2, p);
-				U[i] = nu; Vv[i] = nv; X[i] = nx; Y[i] = ny; X2[i] = nx2; Y2[i] = ny2;
-				gst(trow, t - base, cast<uint8_t>(p));
-			WM_END
-			if (!approx && r > 0) {
-				if (c0 >= st0 && c0 + 63 < en0) {
-					H[i] = H[i] + (Vv[i] >> 24);
-					hmax = vmax(hmax, H[i]);
-				} else {
-					const V<int> v8 = Vv[i] >> 24, u8 = U[i] >> 24;
-					V<int> hn = H[i] + v8;
-					hn = sel(t == en0, en0 > 0 ? V<int>(hl + u8) : hn, hn);
-					const vbool inb = t >= st0 && t <= en0;
-					H[i] = sel(inb, hn, H[i]);
-					hmax = vmax(hmax, sel(inb, H[i], V<int>(KSW_NEG_INF)));
-				}
-			}
-		}
-
-		if (!approx) {   // ---- exact max: per-wave maximum with the tie rule among the lanes of this wave that reach it -----------
-			long long kk = -0x7fffffffffffffffLL - 1;
-			if (r > 0) {
-				const int hm = wave_max_i32(hmax);
-				if (hm > KSW_NEG_INF) {
-					const int en1 = st0 + (en0 - st0) / 4 * 4;
-					int best_pri = -1;
-#pragma unroll
-					for (int i = 0; i < CPW; ++i) {
-						const int c = i * NWV + wv, c0 = base + 64 * c;
-						if (c >= NI || c0 > en0 || c0 + 63 < st0) continue;
-						const int lo = st0 > c0 ? st0 - c0 : 0, hi = en0 - c0 < 63 ? en0 - c0 : 63;
-						const uint64_t band = (hi == 63 ? ~(uint64_t)0 : (((uint64_t)1 << (hi + 1)) - 1)) & ~(((uint64_t)1 << lo) - 1);
-						uint64_t m = ballot(H[i] == hm) & band;
-						while (m) {
-							const int tt = c0 + __builtin_ctzll(m);
-							m &= m - 1;
-							const int grp = tt == en0 ? 5 : tt < en1 ? 4 - ((tt - st0) & 3) : 0;
-							const int pri = (grp << 20) | (0xfffff - tt);
-							if (pri > best_pri) best_pri = pri;
-						}
-					}
-					if (best_pri >= 0) kk = (long long)hm * 4294967296LL + (long long)best_pri;
-				}
-			} else if (wv == 0) {
-				WM_IF(ln == 0) H[0] = (Vv[0] >> 24) - qe; WM_END
-				kk = (long long)readlane(H[0], 0) * 4294967296LL + (long long)((5 << 20) | 0xfffff);
-			}
-			{   // H of lanes en0 / st0: published by the wave that owns their chunk
-				const int ce = (en0 - base) >> 6, cs = (st0 - base) >> 6;
-				if (ce % NWV == wv) { int h = 0;
-#pragma unroll
-					for (int i = 0; i < CPW; ++i) if (ce / NWV == i) h = readlane(H[i], (en0 - base) & 63);
-					WM_IF(ln == 0) gst(pubr, V<int>(2 * NWV + 0), V<int>(h)); WM_END }
-				if (cs % NWV == wv) { int h = 0;
-#pragma unroll
-					for (int i = 0; i < CPW; ++i) if (cs / NWV == i) h = readlane(H[i], (st0 - base) & 63);
-					WM_IF(ln == 0) gst(pubr, V<int>(2 * NWV + 1), V<int>(h)); WM_END }
-			}
-			WM_IF(ln == 0) gst(pubr, V<int>(2 * wv), V<int>((int)(unsigned)(kk & 0xffffffffLL))); gst(pubr, V<int>(2 * wv + 1), V<int>((int)(kk >> 32))); WM_END
-		} else {
-			const int c0h = (last_H0_t - base) >> 6, c1h = (last_H0_t + 1 - base) >> 6;
-			if (last_H0_t >= base && c0h < NC && c0h % NWV == wv) { int d = 0;
-#pragma unroll
-				for (int i = 0; i < CPW; ++i) if (c0h / NWV == i) d = readlane(Vv[i], (last_H0_t - base) & 63) >> 24;
-				WM_IF(ln == 0) gst(pubr, V<int>(2 * NWV + 2), V<int>(d)); WM_END }
-			if (last_H0_t + 1 >= base && c1h < NC && c1h % NWV == wv) { int d = 0;
-#pragma unroll
-				for (int i = 0; i < CPW; ++i) if (c1h / NWV == i) d = readlane(U[i], (last_H0_t + 1 - base) & 63) >> 24;
-				WM_IF(ln == 0) gst(pubr, V<int>(2 * NWV + 3), V<int>(d)); WM_END }
-		}
-		// the next row's cross-chunk neighbour values (lane 63 of every chunk of this wave)
-		WM_IF(ln == 63)
-#pragma unroll
-			for (int i = 0; i < CPW; ++i) {
-				int *x = xcur + (i * NWV + wv) * 5;
-				gst(x, V<int>(0), X[i]); gst(x, V<int>(1), Vv[i]); gst(x, V<int>(2), X2[i]); gst(x, V<int>(3), H[i]);
-				gst(x, V<int>(4), (QP[i >> 2] >> (8 * (i & 3))) & 0xff);
-			}
-		WM_END
-		block_sync_lds();
-
-		// ---- scalar bookkeeping, identical in every wave ----------------------------------------------------------------------------
-		if (!approx) {
-			long long kk = -0x7fffffffffffffffLL - 1;
-			for (int w2 = 0; w2 < NWV; ++w2) {
-				const long long k2 = (long long)(((unsigned long long)(unsigned)gld(pubr, (long long)(2 * w2 + 1)) << 32) | (unsigned)gld(pubr, (long long)(2 * w2)));
-				if (k2 > kk) kk = k2;
-			}
-			const int max_H = (int)(kk >> 32), pri = (int)(kk & 0xffffffffLL);
-			const int max_t = 0xfffff - (pri & 0xfffff);
-			if (en0 == tlen - 1) { const int h = gld(pubr, (long long)(2 * NWV)); if (h > ez_mte) ez_mte = h, ez_mte_q = r - en; }
-			if (r - st0 == qlen - 1) { const int h = gld(pubr, (long long)(2 * NWV + 1)); if (h > ez_mqe) ez_mqe = h, ez_mqe_t = st0; }
-			if (max_H > ez_max) {
-				ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
-			} else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
-				const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
-				if (zdrop >= 0 && ez_max - max_H > zdrop + l * e2) { ez_zdropped = 1; break; }
-			}
-			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = gld(pubr, (long long)(2 * NWV));
-		} else {
-			if (r > 0) {
-				const bool in0 = last_H0_t >= st0 && last_H0_t <= en0, in1 = last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0;
-				if (in0 && in1) {
-					const int d0 = gld(pubr, (long long)(2 * NWV + 2)), d1 = gld(pubr, (long long)(2 * NWV + 3));
-					if (d0 > d1) H0 += d0;
-					else H0 += d1, ++last_H0_t;
-				} else if (in0) H0 += gld(pubr, (long long)(2 * NWV + 2));
-				else { ++last_H0_t; H0 += gld(pubr, (long long)(2 * NWV + 3)); }
-			} else H0 = gld(pubr, (long long)(2 * NWV + 2)) - qe, last_H0_t = 0;
-			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = H0;
-		}
-	}
-
-	int bt_i = -1, bt_j = -1, reach_end = 0;
-	if (!ez_zdropped && !(flag & KSW_F_EXTZ_ONLY)) bt_i = tlen - 1, bt_j = qlen - 1;
-	else if (!ez_zdropped && (flag & KSW_F_EXTZ_ONLY) && ez_mqe + jb.end_bonus > ez_max) reach_end = 1, bt_i = ez_mqe_t, bt_j = qlen - 1;
-	else if (ez_max_t >= 0 && ez_max_q >= 0) bt_i = ez_max_t, bt_j = ez_max_q;
-	if (wv == 0) {
-		WM_IF(ln == 0)
-			wm_ksw_dres_t o;
-			o.max = ez_max; o.zdropped = ez_zdropped; o.max_q = ez_max_q; o.max_t = ez_max_t;
-			o.mqe = ez_mqe; o.mqe_t = ez_mqe_t; o.mte = ez_mte; o.mte_q = ez_mte_q;
-			o.score = ez_score; o.reach_end = reach_end; o.n_cigar = 0; o.bt_i = bt_i; o.bt_j = bt_j;
-			*res = o;
-		WM_END
-	}
-}
-
 
 // ------------------------------------------------------------------------------------------------------
 // ksw_dp_multi: the SAME register-resident machine as ksw_dp_wave, spread over NWV wavefronts of one workgroup: global

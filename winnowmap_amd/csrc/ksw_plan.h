@@ -4,9 +4,9 @@
 #include <stdint.h>
 #include "wm_internal.h"
 
-enum {            // klass = B-index*4 + CLIP*2 + HASN  for the register kernels; 12, 13 = multi-wave LDS kernels; 14 = multi-wave kernel with its state in global scratch;
-	                  // 15 = single-wave generic kernel (global scratch, any size)
-	WM_KSW_B4 = 0, WM_KSW_B8 = 4, WM_KSW_B16 = 8, WM_KSW_BLOCK = 12, WM_KSW_BLOCK2 = 13, WM_KSW_BLOCK3 = 14, WM_KSW_GENERIC = 15, WM_KSW_NCLASS = 16
+enum {            // register classes (ksw_dp_packed<BP,...>): klass = window*8 + EXACT*4 + CLIP*2 + HASN with window 0/1/2 = 4/8/16 chunk pairs (hull <= 496 /
+	                  // 1008 / 2032 lanes); 24, 25 = multi-wave LDS kernels; 26 = multi-wave kernel with its state in global scratch; 27 = single-wave generic kernel
+	WM_KSW_P4 = 0, WM_KSW_P8 = 8, WM_KSW_P16 = 16, WM_KSW_BLOCK = 24, WM_KSW_BLOCK2 = 25, WM_KSW_BLOCK3 = 26, WM_KSW_GENERIC = 27, WM_KSW_NCLASS = 28
 };
 // geometry of the block kernels (ksw_dp_block<NWV, K>): NWV waves x K tiles x 64 lanes per row, LDS window of WN lanes
 enum { WM_KSW_MULTI_B = 8, WM_KSW_MULTI_NWV = 8,                          // BLOCK: register-resident multi-wave kernel ksw_dp_multi<8, 8>: hulls up to 4080 lanes
@@ -56,22 +56,23 @@ static inline int wm_ksw_has_n(const uint8_t *s, int n)
 	return 0;
 }
 
-// CLIP = 0 only when the band provably never limits a row (then out-of-band lanes never feed band cells)
-static inline int wm_ksw_classify(int qlen, int tlen, int w, int has_n, int *n_col_out)
+// CLIP = 0 only when the band provably never limits a row (then out-of-band lanes never feed band cells);
+// EXACT = the exact row maximum is wanted (no KSW_EZ_APPROX_MAX, src/ksw2.h:11)
+static inline int wm_ksw_classify(int qlen, int tlen, int w, int has_n, int flag, int *n_col_out)
 {
 	const int n_col = wm_ksw_ncol(qlen, tlen, w);
 	if (w < 0) w = tlen > qlen ? tlen : qlen;
-	const int clip = !(w >= qlen && w >= tlen);
-	int k;
-	if (n_col <= 64 * 4 - 16) k = WM_KSW_B4;
-	else if (n_col <= 64 * 8 - 16) k = WM_KSW_B8;
-	else if (n_col <= 64 * 16 - 16) k = WM_KSW_B16;
-	else if (n_col + 16 <= 64 * WM_KSW_MULTI_NWV * WM_KSW_MULTI_B) { *n_col_out = n_col; return WM_KSW_BLOCK; }
-	else if (n_col + 16 <= 64 * 2 * WM_KSW_MULTI_NWV * WM_KSW_MULTI_B) { *n_col_out = n_col; return WM_KSW_BLOCK2; }   // ksw_dp_multi<8,16>: 8192 lanes
-	else if (n_col + 16 <= 64 * WM_KSW_BLK_NWV * WM_KSW_BLK2_K * WM_KSW_BLK_MAXC) { *n_col_out = n_col; return WM_KSW_BLOCK3; }
-	else { *n_col_out = n_col; return WM_KSW_GENERIC; }
+	const int clip = !(w >= qlen && w >= tlen), exact = !(flag & 0x08);
 	*n_col_out = n_col;
-	return k + clip * 2 + (has_n ? 1 : 0);
+	int k;
+	if (n_col <= 128 * 4 - 16) k = WM_KSW_P4;
+	else if (n_col <= 128 * 8 - 16) k = WM_KSW_P8;
+	else if (n_col <= 128 * 16 - 16) k = WM_KSW_P16;
+	else if (n_col + 16 <= 64 * WM_KSW_MULTI_NWV * WM_KSW_MULTI_B) return WM_KSW_BLOCK;
+	else if (n_col + 16 <= 64 * 2 * WM_KSW_MULTI_NWV * WM_KSW_MULTI_B) return WM_KSW_BLOCK2;     // ksw_dp_multi<8,16>: 8192 lanes
+	else if (n_col + 16 <= 64 * WM_KSW_BLK_NWV * WM_KSW_BLK2_K * WM_KSW_BLK_MAXC) return WM_KSW_BLOCK3;
+	else return WM_KSW_GENERIC;
+	return k + exact * 4 + clip * 2 + (has_n ? 1 : 0);
 }
 
 // parameter ranges the kernels support (everything the reference's mm_check_opt admits, src/options.c:166-176)

@@ -36,6 +36,25 @@ WM_DEV int add3(int a, int b, int c) { return (int)((unsigned)a + (unsigned)b + 
 WM_DEV int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }     // wrapping 32-bit add
 WM_DEV int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }     // wrapping 32-bit sub
 
+// ---- packed 2 x 16-bit lanes inside one 32-bit register (VOP3P: one instruction works on both halves) ----------------
+typedef short wm_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short wm_u16x2 __attribute__((ext_vector_type(2)));
+WM_DEV wm_s16x2 as_s16x2(int a) { return __builtin_bit_cast(wm_s16x2, a); }
+WM_DEV wm_u16x2 as_u16x2(int a) { return __builtin_bit_cast(wm_u16x2, a); }
+WM_DEV int pk_add(int a, int b) { return __builtin_bit_cast(int, as_u16x2(a) + as_u16x2(b)); }                          // v_pk_add_u16 (wrapping)
+WM_DEV int pk_sub(int a, int b) { return __builtin_bit_cast(int, as_u16x2(a) - as_u16x2(b)); }                          // v_pk_sub_u16 (wrapping)
+WM_DEV int pk_max(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_max(as_s16x2(a), as_s16x2(b))); } // v_pk_max_i16
+WM_DEV int pk_min(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_min(as_s16x2(a), as_s16x2(b))); } // v_pk_min_i16
+WM_DEV int pk_minu(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_min(as_u16x2(a), as_u16x2(b))); } // v_pk_min_u16
+WM_DEV int pk_subsat(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_sub_sat(as_s16x2(a), as_s16x2(b))); } // v_pk_sub_i16 clamp
+WM_DEV int pk_lshr(int a, int k) { return __builtin_bit_cast(int, as_u16x2(a) >> (unsigned short)k); }                  // v_pk_lshrrev_b16
+WM_DEV int pk_mad(int a, int b, int c) { return __builtin_bit_cast(int, as_u16x2(a) * as_u16x2(b) + as_u16x2(c)); }     // v_pk_mad_u16 (wrapping)
+// byte permute: result byte k = byte sel[k] of the 8 bytes {hi word a : lo word b} (selector 0..3 -> b, 4..7 -> a, 0x0c -> 0x00)
+WM_DEV int perm(int a, int b, int sel) { return (int)__builtin_amdgcn_perm((unsigned)a, (unsigned)b, (unsigned)sel); }
+WM_DEV int bfi(int mask, int a, int b) { return (a & mask) | (b & ~mask); }                                           // v_bfi_b32
+WM_DEV int alignbit(int hi, int lo, int sh) { return (int)__builtin_amdgcn_alignbit((unsigned)hi, (unsigned)lo, (unsigned)sh); }   // ({hi,lo} >> sh)[31:0]
+WM_DEV int lshr(int a, int k) { return (int)((unsigned)a >> k); }
+
 // DPP cross-lane moves (gfx9 encodings): one VALU operation each, no LDS crossbar round trip.
 // Lanes without a source lane (or in a row that row_mask disables) receive `old`.
 template <int CTRL, int ROW_MASK> WM_DEV int dpp_mov(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, ROW_MASK, 0xf, false); }

@@ -39,6 +39,7 @@ template <class T> struct UBuf {
 static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #include "simt.h"
 #include "ksw_kernel.h"
+#include "ksw_packed_kernel.h"
 #include "ksw_plan.h"
 #include "sketch_kernel.h"
 #include "seedchain_kernel.h"
@@ -46,23 +47,14 @@ static inline double now_ms() { return std::chrono::duration<double, std::milli>
 // ======================================================================================================
 // kernels
 // ======================================================================================================
-template <int B, bool CLIP, bool HASN>
-__global__ __launch_bounds__(64) void ksw_dp_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs,
-                                                     const int *__restrict__ order, const uint8_t *__restrict__ seqs,
-                                                     uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res)
+// register classes: one wave per alignment, two DP cells per lane (ksw_dp_packed, ksw_packed_kernel.h)
+template <int BP, bool CLIP, bool HASN, bool EXACT>
+__global__ __launch_bounds__(64) void ksw_dpp_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs,
+                                                      const int *__restrict__ order, const uint8_t *__restrict__ seqs,
+                                                      uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res)
 {
 	const int j = order[blockIdx.x];
-	wmk::ksw_dp_wave<B, CLIP, HASN>(sc, jobs[j], seqs, tb, res + j);
-}
-
-// the same classes with the striped lane layout (work follows the hull width): the default
-template <int B, bool CLIP, bool HASN>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(B == 16 ? 3 : 4))) void ksw_dps_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs,
-                                                     const int *__restrict__ order, const uint8_t *__restrict__ seqs,
-                                                     uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res)
-{
-	const int j = order[blockIdx.x];
-	wmk::ksw_dp_striped<B, CLIP, HASN>(sc, jobs[j], seqs, tb, res + j);
+	wmk::ksw_dp_packed<BP, CLIP, HASN, EXACT>(sc, jobs[j], seqs, tb, res + j);
 }
 
 // generic class: per-lane state in a global scratch slab (7*T int8 + T int32 per job), one wave per alignment
@@ -126,17 +118,6 @@ __global__ __launch_bounds__(64 * NWV) void ksw_multi_kernel(wm_ksw_score_t sc, 
 		wmk::ksw_dp_multi<WM_KSW_MULTI_B, NWV, true, true>(sc, jb, sq, st, tb, lds, res + j);
 	} else
 		wmk::ksw_dp_multi<WM_KSW_MULTI_B, NWV, true, true>(sc, jb, seqs + jb.q_off, seqs + jb.t_off, tb, lds, res + j);
-}
-
-// striped multi-wave kernels (ksw_dp_smulti<CPW,NWV>): <4,4> for hulls up to 1008 lanes (the B=16 classes), <4,16> BLOCK, <8,16> BLOCK2
-template <int CPW, int NWV>
-__global__ __launch_bounds__(64 * NWV) void ksw_smulti_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
-                                                               const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res)
-{
-	__shared__ int lds[wmk::ksw_smulti_lds<CPW, NWV>::INTS];
-	const int j = order[blockIdx.x];
-	const wm_ksw_djob_t jb = jobs[j];
-	wmk::ksw_dp_smulti<CPW, NWV, true, true>(sc, jb, seqs + jb.q_off, seqs + jb.t_off, tb, lds, res + j);
 }
 
 // one thread per alignment: walk the traceback, write run-length ops (backtrack order) into the job's slot
@@ -211,6 +192,7 @@ struct wm_ctx_s {
 	uint8_t *arena;
 	size_t arena_bytes, arena_used;
 	hipEvent_t ev[4];
+	hipEvent_t sync_ev;                         // blocking-sync event: waiting threads sleep instead of spinning (the host cores are the scarce resource)
 	float last_ms, aux_ms;
 	uint64_t acc_cells; double t_prep, t_run, t_fetch;
 	// flat index in HBM (wm_index_upload)
@@ -258,6 +240,17 @@ struct wm_ksw_dev_batch_s {
 
 extern "C" const char *wm_last_error(void) { return g_err; }
 
+// wait for everything queued on the context's stream. hipStreamSynchronize spin-waits (it burns a host core — and the container's CPU quota —
+// for as long as the kernels run); a blocking-sync event puts the thread to sleep instead. WM_SPIN_SYNC=1 restores the spinning wait (A/B).
+static hipError_t ctx_sync(wm_ctx_s *c)
+{
+	static const bool spin = getenv("WM_SPIN_SYNC") != 0;
+	if (spin) return hipStreamSynchronize(c->stream);
+	hipError_t e = hipEventRecord(c->sync_ev, c->stream);
+	if (e != hipSuccess) return e;
+	return hipEventSynchronize(c->sync_ev);
+}
+
 extern "C" int wm_device_count(void)
 {
 	int n = 0;
@@ -286,6 +279,7 @@ extern "C" int wm_ctx_create(int device, size_t arena_bytes, wm_ctx_t **out)
 	for (int i = 0; i < 5; ++i) HIPCHK(hipEventCreateWithFlags(&c->kev[i], hipEventDisableTiming));
 	for (int k = 0; k < WM_KSW_NCLASS; ++k) { HIPCHK(hipEventCreate(&c->cev[k][0])); HIPCHK(hipEventCreate(&c->cev[k][1])); c->k_ms[k] = 0; c->k_cells[k] = c->k_launches[k] = 0; }
 	for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
+	HIPCHK(hipEventCreateWithFlags(&c->sync_ev, hipEventBlockingSync | hipEventDisableTiming));
 	c->arena_used = 0; c->last_ms = 0; c->aux_ms = 0; c->host_threads = 1; c->pin = 0; c->pin_bytes = c->pin_used = 0; c->have_index = false; c->owns_index = false; c->d_hkey = c->d_hval = c->d_P = 0; c->d_bloom = 0;
 	*out = c;
 	return WM_OK;
@@ -297,6 +291,7 @@ extern "C" void wm_ctx_destroy(wm_ctx_t *c)
 	hipSetDevice(c->device);
 	hipStreamSynchronize(c->stream);
 	for (int i = 0; i < 4; ++i) hipEventDestroy(c->ev[i]);
+	hipEventDestroy(c->sync_ev);
 	hipStreamDestroy(c->stream);
 	if (c->pin) hipHostFree(c->pin);
 	for (int i = 0; i < 4; ++i) hipStreamDestroy(c->kstream[i]);
@@ -318,22 +313,21 @@ static void *arena_take(wm_ctx_t *c, size_t bytes)
 	return c->arena + a;
 }
 
-template <int B> static void launch_dp(int clip, int hasn, int n, hipStream_t s, const wm_ksw_score_t &sc, const wm_ksw_djob_t *jobs, const int *order,
-                                       const uint8_t *seqs, uint8_t *tb, wm_ksw_dres_t *res)
+// variant = EXACT*4 + CLIP*2 + HASN; jobs with an N run on the CLIP instantiation (a superset: exact emulation of stale lanes)
+template <int BP> static void launch_dpp(int variant, int n, hipStream_t s, const wm_ksw_score_t &sc, const wm_ksw_djob_t *jobs, const int *order,
+                                         const uint8_t *seqs, uint8_t *tb, wm_ksw_dres_t *res)
 {
 	dim3 g(n), b(64);
-	static const bool blocked = getenv("WM_KSW_BLOCKED") != 0;        // A/B switch: the older blocked-layout kernel
-	if (blocked) {
-		if (clip && hasn) hipLaunchKernelGGL((ksw_dp_kernel<B, true, true>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
-		else if (clip) hipLaunchKernelGGL((ksw_dp_kernel<B, true, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
-		else if (hasn) hipLaunchKernelGGL((ksw_dp_kernel<B, false, true>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
-		else hipLaunchKernelGGL((ksw_dp_kernel<B, false, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
-		return;
+	const bool exact = variant & 4, clip = (variant & 2) || (variant & 1), hasn = variant & 1;
+	if (exact) {
+		if (hasn) hipLaunchKernelGGL((ksw_dpp_kernel<BP, true, true, true>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
+		else if (clip) hipLaunchKernelGGL((ksw_dpp_kernel<BP, true, false, true>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
+		else hipLaunchKernelGGL((ksw_dpp_kernel<BP, false, false, true>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
+	} else {
+		if (hasn) hipLaunchKernelGGL((ksw_dpp_kernel<BP, true, true, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
+		else if (clip) hipLaunchKernelGGL((ksw_dpp_kernel<BP, true, false, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
+		else hipLaunchKernelGGL((ksw_dpp_kernel<BP, false, false, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
 	}
-	if (clip && hasn) hipLaunchKernelGGL((ksw_dps_kernel<B, true, true>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
-	else if (clip) hipLaunchKernelGGL((ksw_dps_kernel<B, true, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
-	else if (hasn) hipLaunchKernelGGL((ksw_dps_kernel<B, false, true>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
-	else hipLaunchKernelGGL((ksw_dps_kernel<B, false, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
 }
 
 extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs, const wm_ksw_job_t *jobs,
@@ -369,7 +363,7 @@ extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int 
 		if (s.qlen <= 0 || s.tlen <= 0 || never) { d.klass = -1; return; }                                                 // :68,:92
 		if ((size_t)s.q_off + s.qlen > seqs_bytes || (size_t)s.t_off + s.tlen > seqs_bytes) { bad = (int)i; bad_kind = 2; d.klass = -1; return; }
 		int n_col;
-		d.klass = wm_ksw_classify(s.qlen, s.tlen, s.w, wm_ksw_has_n(seqs + s.q_off, s.qlen) | wm_ksw_has_n(seqs + s.t_off, s.tlen), &n_col);
+		d.klass = wm_ksw_classify(s.qlen, s.tlen, s.w, wm_ksw_has_n(seqs + s.q_off, s.qlen) | wm_ksw_has_n(seqs + s.t_off, s.tlen), s.flag, &n_col);
 		d.n_col = n_col;
 		cells[i] = wm_ksw_cells(s.qlen, s.tlen, s.w, &bands[i]);
 	});
@@ -448,7 +442,7 @@ extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int 
 	HIPCHK(hipMemcpyAsync(b->d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream));
 	if (!b->goff.empty()) HIPCHK(hipMemcpyAsync(b->d_goff, b->goff.data(), b->goff.size() * 8, hipMemcpyHostToDevice, c->stream));
 	if (!b->b3off.empty()) HIPCHK(hipMemcpyAsync(b->d_b3off, b->b3off.data(), b->b3off.size() * 8, hipMemcpyHostToDevice, c->stream));
-	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(ctx_sync(c));
 	*out = b;
 	return WM_OK;
 }
@@ -504,24 +498,6 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		const double tk0 = trace_k ? now_ms() : 0;
 		hipEventRecord(c->cev[k][0], ks);
 		struct Done { decltype(class_done) &f; int k; double t; hipEvent_t e; hipStream_t s; ~Done() { hipEventRecord(e, s); f(k, t); } } done_guard{ class_done, k, tk0, c->cev[k][1], ks };
-		static const int smulti = getenv("WM_KSW_SMULTI") ? atoi(getenv("WM_KSW_SMULTI")) : 0;     // experiment switch (bit 0: B=16 classes, 1: BLOCK, 2: BLOCK2):
-		// the striped multi-wave kernels cut per-job latency but cost more VALU work in total, and the mapper is VALU-throughput bound -> off by default
-		if ((smulti & 8) && k >= WM_KSW_B16 && k < WM_KSW_BLOCK) {                 // two waves x 8 chunks
-			hipLaunchKernelGGL((ksw_smulti_kernel<8, 2>), dim3(nk), dim3(128), 0, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res);
-			continue;
-		}
-		if ((smulti & 1) && k >= WM_KSW_B16 && k < WM_KSW_BLOCK) {
-			hipLaunchKernelGGL((ksw_smulti_kernel<4, 4>), dim3(nk), dim3(256), 0, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res);
-			continue;
-		}
-		if ((smulti & 2) && k == WM_KSW_BLOCK) {
-			hipLaunchKernelGGL((ksw_smulti_kernel<4, 16>), dim3(nk), dim3(1024), 0, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res);
-			continue;
-		}
-		if ((smulti & 4) && k == WM_KSW_BLOCK2) {
-			hipLaunchKernelGGL((ksw_smulti_kernel<8, 16>), dim3(nk), dim3(1024), 0, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res);
-			continue;
-		}
 		if (k == WM_KSW_BLOCK || k == WM_KSW_BLOCK2 || k == WM_KSW_BLOCK3) {
 			const size_t fixed = (size_t)WM_KSW_BLK_PUB * 4;
 			if (k == WM_KSW_BLOCK) {
@@ -545,11 +521,10 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 			hipLaunchKernelGGL(ksw_generic_kernel, dim3(nk), dim3(64), 0, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_gscratch, b->d_goff, b->d_res);
 			continue;
 		}
-		const int clip = k >> 1 & 1, hasn = k & 1;
-		switch (k & ~3) {
-		case WM_KSW_B4: launch_dp<4>(clip, hasn, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
-		case WM_KSW_B8: launch_dp<8>(clip, hasn, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
-		default: launch_dp<16>(clip, hasn, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
+		switch (k & ~7) {
+		case WM_KSW_P4: launch_dpp<4>(k & 7, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
+		case WM_KSW_P8: launch_dpp<8>(k & 7, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
+		default: launch_dpp<16>(k & 7, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
 		}
 	}
 	for (int si = 0; si < 4; ++si)
@@ -560,7 +535,7 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	hipLaunchKernelGGL(ksw_gather_kernel, dim3(n), dim3(64), 0, c->stream, b->d_jobs, b->d_res, b->d_off, b->d_cig, b->d_pool, (uint32_t)b->pool_cap);
 	HIPCHK(hipEventRecord(c->ev[2], c->stream));
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(ctx_sync(c));
 	HIPCHK(hipEventElapsedTime(&b->dp_ms, c->ev[0], c->ev[1]));
 	HIPCHK(hipEventElapsedTime(&b->bt_ms, c->ev[1], c->ev[2]));
 	c->last_ms = b->dp_ms + b->bt_ms;
@@ -877,7 +852,7 @@ extern "C" int wm_sketch_batch(wm_ctx_t *c, int n, const uint8_t *seqs, size_t s
 		UBuf<wm128_t> tmp(tot + 1, c);
 		HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt, jb.size() * 4, hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(hipMemcpyAsync(tmp.data(), d_out, tot * sizeof(wm128_t), hipMemcpyDeviceToHost, c->stream));
-		HIPCHK(hipStreamSynchronize(c->stream));
+		HIPCHK(ctx_sync(c));
 		HIPCHK(hipGetLastError());
 		float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); ms_total += ms;
 		std::vector<int> again;
@@ -941,7 +916,7 @@ extern "C" int wm_seed_batch(wm_ctx_t *c, int n, const wm128_t *mini, const uint
 		UBuf<wm128_t> tmp(tot + 1, c);
 		HIPCHK(hipMemcpyAsync(res.data(), d_res, jb.size() * sizeof(wm_seed_res_t), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(hipMemcpyAsync(tmp.data(), d_out, tot * sizeof(wm128_t), hipMemcpyDeviceToHost, c->stream));
-		HIPCHK(hipStreamSynchronize(c->stream));
+		HIPCHK(ctx_sync(c));
 		HIPCHK(hipGetLastError());
 		float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); ms_total += ms;
 		std::vector<int> again;
@@ -1036,7 +1011,7 @@ extern "C" int wm_chain_batch(wm_ctx_t *c, int n, wm128_t *a, const uint64_t *a_
 	const double tt2 = trace ? now_ms() : 0;
 	UBuf<int> fpvt((tot + 1) * 4, c);
 	HIPCHK(hipMemcpyAsync(fpvt.data(), d_fpvt, tot * 16, hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(ctx_sync(c));
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventElapsedTime(&c->aux_ms, c->ev[0], c->ev[1]));
 	const double tt3 = trace ? now_ms() : 0;
@@ -1065,14 +1040,15 @@ extern "C" int wm_chain_batch(wm_ctx_t *c, int n, wm128_t *a, const uint64_t *a_
 // ======================================================================================================
 // GpuOps: the product implementation of the mapper's device operations
 // ======================================================================================================
-struct GpuOps : wm::DeviceOps {
+// one device context (stream + arena + staging slab) worth of batched operations; GpuOps below hands the contexts out
+struct GpuOpsCtx {
 	wm_ctx_t *c;
 	uint64_t cells = 0;
 	double ksw_us = 0, aux_us = 0;
 	double t_pack = 0, t_prep = 0, t_run = 0, t_fetch = 0, t_unpack = 0, t_sketch = 0, t_seed = 0, t_chain = 0;
 	std::string error;
 	void fail(const char *what) { if (error.empty()) error = std::string(what) + ": " + g_err; }
-	void sketch_batch(int, int, std::vector<wm::SketchReq*> &reqs) override
+	void sketch_batch(int, int, std::vector<wm::SketchReq*> &reqs)
 	{
 		const int n = (int)reqs.size();
 		std::vector<uint64_t> off(n), ooff(n);
@@ -1098,7 +1074,7 @@ struct GpuOps : wm::DeviceOps {
 		aux_us += c->aux_ms * 1e3;
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { reqs[i]->mini.assign(out.begin() + ooff[i], out.begin() + ooff[i] + cnt[i]); });
 	}
-	void seed_batch(std::vector<wm::SeedReq*> &reqs) override
+	void seed_batch(std::vector<wm::SeedReq*> &reqs)
 	{
 		const int n = (int)reqs.size();
 		// one launch per (max_occ, flag) class; in practice a single class
@@ -1122,7 +1098,7 @@ struct GpuOps : wm::DeviceOps {
 		}
 		fail("seed (anchor pool)");
 	}
-	void chain_batch(std::vector<wm::ChainReq*> &reqs) override
+	void chain_batch(std::vector<wm::ChainReq*> &reqs)
 	{
 		const int n = (int)reqs.size();
 		std::vector<uint64_t> aoff(n), uoff(n);
@@ -1146,7 +1122,7 @@ struct GpuOps : wm::DeviceOps {
 			reqs[i]->a.assign(a.begin() + aoff[i], a.begin() + aoff[i] + nv[i]);
 		});
 	}
-	void ksw_batch(const wm_ksw_score_t &sc, std::vector<wm::KswReq*> &reqs) override
+	void ksw_batch(const wm_ksw_score_t &sc, std::vector<wm::KswReq*> &reqs)
 	{
 		const double t0 = now_ms();
 		const int n = (int)reqs.size();
@@ -1183,6 +1159,30 @@ struct GpuOps : wm::DeviceOps {
 	}
 };
 
+// The product's DeviceOps: a pool of device contexts. Every batched call borrows a free context (its own HIP stream, arena and pinned
+// slab), so up to max_inflight() batches — of the same or of different operations — are on the device at once, issued by different
+// host threads (wm_fiber.h).
+struct GpuOps : wm::DeviceOps {
+	std::vector<GpuOpsCtx> ctxs;
+	std::vector<int> free_;
+	std::mutex mu;
+	std::condition_variable cv;
+	void init(const std::vector<wm_ctx_t*> &cs) { ctxs.resize(cs.size()); for (size_t i = 0; i < cs.size(); ++i) { ctxs[i].c = cs[i]; free_.push_back((int)i); } }
+	int max_inflight() const override { return (int)ctxs.size(); }
+	template <class F> void with(F f)
+	{
+		int i;
+		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !free_.empty(); }); i = free_.back(); free_.pop_back(); }
+		f(ctxs[i]);
+		{ std::lock_guard<std::mutex> lk(mu); free_.push_back(i); }
+		cv.notify_one();
+	}
+	void sketch_batch(int w, int k, std::vector<wm::SketchReq*> &reqs) override { with([&](GpuOpsCtx &x) { x.sketch_batch(w, k, reqs); }); }
+	void seed_batch(std::vector<wm::SeedReq*> &reqs) override { with([&](GpuOpsCtx &x) { x.seed_batch(reqs); }); }
+	void chain_batch(std::vector<wm::ChainReq*> &reqs) override { with([&](GpuOpsCtx &x) { x.chain_batch(reqs); }); }
+	void ksw_batch(const wm_ksw_score_t &sc, std::vector<wm::KswReq*> &reqs) override { with([&](GpuOpsCtx &x) { x.ksw_batch(sc, reqs); }); }
+};
+
 struct wm_mapper_s {
 	wm_ctx_t *c; const wm_index_t *idx;
 	std::vector<wm_ctx_t*> workers;        // extra contexts (own stream + arena slice) for groups 1..G-1
@@ -1213,22 +1213,21 @@ extern "C" int wm_mapper_create(wm_ctx_t *c, const wm_index_t *idx, const char *
 }
 extern "C" void wm_mapper_destroy(wm_mapper_t *m) { if (m) { for (wm_ctx_t *w : m->workers) wm_ctx_destroy(w); delete m; } }
 
-// Host parallelism: n_threads host threads in G groups. A group is a SchedTeam (wm_fiber.h): its threads run the host
-// glue of the group's reads in parallel and share ONE device batch per operation and round, issued on the group's own
-// HIP stream + arena slice. Two or more groups keep the GPU busy while another group is in its host phase.
-extern "C" int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena_bytes_per_group)
+// Host parallelism: n_threads worker threads run the host glue of the reads (fibers, wm_fiber.h) and take turns issuing the batched
+// device calls; C device contexts (own HIP stream + arena + pinned slab each; WM_CONTEXTS, default 4) let C batches be in flight at once.
+extern "C" int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena_bytes_per_context)
 {
 	if (n_threads < 1) return set_err(WM_EINVAL, "n_threads < 1");
 	for (wm_ctx_t *w : m->workers) wm_ctx_destroy(w);
 	m->workers.clear();
-	int G = getenv("WM_GROUPS") ? atoi(getenv("WM_GROUPS")) : (n_threads >= 16 ? 4 : n_threads >= 8 ? 2 : 1);
-	if (G < 1) G = 1;
-	if (G > n_threads) G = n_threads;
+	int C = getenv("WM_CONTEXTS") ? atoi(getenv("WM_CONTEXTS")) : (getenv("WM_GROUPS") ? atoi(getenv("WM_GROUPS")) : (n_threads >= 8 ? 4 : n_threads >= 2 ? 2 : 1));
+	if (C < 1) C = 1;
 	m->n_threads = n_threads;
-	m->c->host_threads = std::max(1, n_threads / G);
-	for (int g = 1; g < G; ++g) {
+	const int bt = getenv("WM_BATCH_THREADS") ? atoi(getenv("WM_BATCH_THREADS")) : 1;     // extra threads a batched call may spawn for its own packing
+	m->c->host_threads = std::max(1, bt);
+	for (int g = 1; g < C; ++g) {
 		wm_ctx_t *w = 0;
-		const int rc = wm_ctx_create(m->c->device, arena_bytes_per_group ? arena_bytes_per_group : m->c->arena_bytes, &w);
+		const int rc = wm_ctx_create(m->c->device, arena_bytes_per_context ? arena_bytes_per_context : m->c->arena_bytes, &w);
 		if (rc) return rc;
 		w->d_hkey = m->c->d_hkey; w->d_hval = m->c->d_hval; w->d_P = m->c->d_P; w->d_bloom = m->c->d_bloom; w->hbits = m->c->hbits; w->skp = m->c->skp;
 		w->have_index = true; w->owns_index = false;
@@ -1265,39 +1264,21 @@ static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double
 	for (int i = 0; i < n; ++i) bases += reads[i].seq.size();
 	std::vector<wm::ReadOut> out(n);
 	const double tm1 = now_ms();
-	const int T = (int)m->workers.size() + 1;
-	std::vector<GpuOps> ops(T);
-	std::vector<wm::MapStats> sts(T);
-	std::vector<std::vector<wm::ReadIn>> part(T);
-	std::vector<std::vector<wm::ReadOut>> pout(T);
-	std::vector<std::vector<int>> which(T);
-	for (int i = 0; i < n; ++i) { which[i % T].push_back(i); part[i % T].push_back(std::move(reads[i])); }
-	const int team = std::max(1, m->n_threads / T);
-	auto work = [&](int t) {
-		ops[t].c = t == 0 ? m->c : m->workers[t - 1];
-		hipSetDevice(ops[t].c->device);
-		wm::map_batch(m->idx->ix, m->mo, &ops[t], part[t], pout[t], &sts[t], team);
-	};
-	{
-		std::vector<std::thread> th;
-		for (int t = 1; t < T; ++t) th.emplace_back(work, t);
-		work(0);
-		for (auto &x : th) x.join();
-	}
-	{ std::string ie; if (wm::take_internal_error(ie)) return set_err(WM_EINTERNAL, "%s", ie.c_str()); }
+	GpuOps ops;
+	{ std::vector<wm_ctx_t*> cs; cs.push_back(m->c); cs.insert(cs.end(), m->workers.begin(), m->workers.end()); ops.init(cs); }
 	wm::MapStats st;
-	GpuOps tot; tot.c = m->c;
-	for (int t = 0; t < T; ++t) {
-		if (!ops[t].error.empty()) return set_err(WM_ENODEV, "%s", ops[t].error.c_str());
-		for (size_t k = 0; k < which[t].size(); ++k) { out[which[t][k]] = std::move(pout[t][k]); reads[which[t][k]] = std::move(part[t][k]); }
-		st.n_flush = std::max(st.n_flush, sts[t].n_flush); st.n_ksw += sts[t].n_ksw; st.n_chain += sts[t].n_chain; st.n_seed += sts[t].n_seed; st.n_sketch += sts[t].n_sketch;
-		tot.cells += ops[t].cells; tot.ksw_us += ops[t].ksw_us; tot.aux_us += ops[t].aux_us;
-	}
-	GpuOps &opsr = tot;
+	hipSetDevice(m->c->device);
+	wm::map_batch(m->idx->ix, m->mo, &ops, reads, out, &st, m->n_threads);
+	for (GpuOpsCtx &x : ops.ctxs)
+		if (!x.error.empty()) return set_err(WM_ENODEV, "%s", x.error.c_str());
+	{ std::string ie; if (wm::take_internal_error(ie)) return set_err(WM_EINTERNAL, "%s", ie.c_str()); }
+	GpuOpsCtx tot; tot.c = m->c;
+	for (GpuOpsCtx &x : ops.ctxs) { tot.cells += x.cells; tot.ksw_us += x.ksw_us; tot.aux_us += x.aux_us; }
+	GpuOpsCtx &opsr = tot;
 	if (getenv("WM_TRACE")) {
 		double a[8] = {0};
-		for (int t = 0; t < T; ++t) { a[0] += ops[t].t_pack; a[1] += ops[t].t_prep; a[2] += ops[t].t_run; a[3] += ops[t].t_fetch; a[4] += ops[t].t_unpack; a[5] += ops[t].t_sketch; a[6] += ops[t].t_seed; a[7] += ops[t].t_chain; }
-		fprintf(stderr, "[ops, sum over %d groups, ms] ksw: pack %.0f prepare %.0f run %.0f fetch %.0f unpack %.0f | sketch %.0f seed %.0f chain %.0f\n", T, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
+		for (GpuOpsCtx &x : ops.ctxs) { a[0] += x.t_pack; a[1] += x.t_prep; a[2] += x.t_run; a[3] += x.t_fetch; a[4] += x.t_unpack; a[5] += x.t_sketch; a[6] += x.t_seed; a[7] += x.t_chain; }
+		fprintf(stderr, "[ops, sum over %zu contexts, ms] ksw: pack %.0f prepare %.0f run %.0f fetch %.0f unpack %.0f | sketch %.0f seed %.0f chain %.0f | batches %llu\n", ops.ctxs.size(), a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], (unsigned long long)st.n_flush);
 	}
 	const double tm2 = now_ms();
 	// output records: formatted per read in parallel, then laid out in input order

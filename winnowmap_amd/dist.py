@@ -56,10 +56,38 @@ def sum_over_ranks(values, dist, device):
     return [float(x) for x in t.tolist()]
 
 
+def available_cores():
+    """Host cores this process can really use: the smallest of the hardware threads, the affinity mask and the container's
+    CPU quota (cgroup v2 cpu.max / v1 cfs_quota). The GPU boxes report 256 hardware threads under a 16-CPU quota: threads
+    beyond the quota only add throttling (profiles/r02_cpu_scaling.txt)."""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = int(f.read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def host_threads_per_rank(n_cores, world):
-    """Host threads one rank's mapper uses: the ranks of a node share its cores, so they are divided explicitly
-    (0.75 of the hardware threads over the ranks, at most 32 per rank — more per process does not pay)."""
-    return max(1, min(32, int(0.75 * n_cores / max(1, world))))
+    """Host threads one rank's mapper uses: the ranks of a node share its (usable) cores, so they are divided explicitly;
+    at most 32 per rank."""
+    return max(1, min(32, n_cores // max(1, world)))
 
 
 def free_port():
