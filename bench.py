@@ -27,6 +27,7 @@ import argparse
 import json
 import os
 import re
+import resource
 import subprocess
 import sys
 import tempfile
@@ -141,14 +142,30 @@ def cpu_reference_baseline(fa, kf, names, seqs, preset, tmp, n_cores):
                       "mapping phase %.2f s = best of the -t sweep (index build %.1f s excluded)" % (len(seqs), bases / 1e9, t_best, preset, t_map, t_idx)}, outp
 
 
-KSW_CLASS_NAMES = {0: "ksw_dps_kernel<4,...>", 4: "ksw_dps_kernel<8,...>", 8: "ksw_dps_kernel<16,...>", 12: "ksw_multi_kernel<8>", 13: "ksw_multi_kernel<16>",
-                   14: "ksw_block_kernel<7,0>", 15: "ksw_generic_kernel"}
+KSW_WIDE_CLASSES = {24: "ksw_multi_kernel<8>", 25: "ksw_multi_kernel<16>", 26: "ksw_block_kernel<7, 0>", 27: "ksw_generic_kernel"}
 
 
 def ksw_class_name(k):
-    if k >= 12:
-        return KSW_CLASS_NAMES[k]
-    return KSW_CLASS_NAMES[k & ~3].replace("...", "%s,%s" % ("true" if k >> 1 & 1 else "false", "true" if k & 1 else "false"))
+    """kernel name of a ksw class id (winnowmap_amd/csrc/ksw_plan.h: window*8 + EXACT*4 + CLIP*2 + HASN; 24.. = the wide-hull kernels);
+    spelled as rocprofv3 prints the instantiation ksw_dpp_kernel<BP, CLIP, HASN, EXACT> (jobs with an N run on the CLIP instantiation)"""
+    if k >= 24:
+        return KSW_WIDE_CLASSES[k]
+    bp = (4, 8, 16)[k >> 3]
+    exact, clip, hasn = bool(k & 4), bool(k & 2) or bool(k & 1), bool(k & 1)
+    return "ksw_dpp_kernel<%d, %s, %s, %s>" % (bp, str(clip).lower(), str(hasn).lower(), str(exact).lower())
+
+
+def host_report(hs0, hs1, ru0, ru1, elapsed, n_cores):
+    """Where the host time of the timed region went (rank 0): the per-read glue and the batched calls, against the usable cores."""
+    d = lambda a, b: b - a  # noqa: E731
+    cpu = d(ru0.ru_utime, ru1.ru_utime) + d(ru0.ru_stime, ru1.ru_stime)
+    ops = ("sketch", "seed", "chain", "ksw")
+    return {"usable_cores": n_cores, "process_cpu_s": round(cpu, 2), "cpu_utilisation": round(cpu / max(elapsed, 1e-9) / max(1, n_cores), 3),
+            "glue_cpu_s": round(d(hs0["cpu_glue_s"], hs1["cpu_glue_s"]), 2), "idle_wall_s": round(d(hs0["idle_wall_s"], hs1["idle_wall_s"]), 2),
+            "batched_cpu_s": {o: round(d(hs0["cpu_batched_s"][o], hs1["cpu_batched_s"][o]), 2) for o in ops},
+            "batched_wall_s": {o: round(d(hs0["wall_batched_s"][o], hs1["wall_batched_s"][o]), 2) for o in ops},
+            "batched_calls": {o: hs1["batched_calls"][o] - hs0["batched_calls"][o] for o in ops},
+            "map_wall_s": round(d(hs0["map_wall_s"], hs1["map_wall_s"]), 2), "format_wall_s": round(d(hs0["format_wall_s"], hs1["format_wall_s"]), 2)}
 
 
 def make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1):
@@ -275,6 +292,8 @@ def main():
         mapper.map(*b, copy_text=False)
     sync()
     ks0 = mapper.kernel_stats()
+    hs0 = mapper.host_stats()
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t_start = time.time()
     cells = ksw_us = aux_us = bases = hits = 0
     for b in batches[args.warmup:]:
@@ -283,7 +302,9 @@ def main():
         cells += st["dp_cells"]; ksw_us += st["ksw_kernel_us"]; aux_us += st["aux_kernel_us"]; bases += st["read_bases"]; hits += len(h)
     sync()
     elapsed = time.time() - t_start
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
     ks1 = mapper.kernel_stats()
+    hs1 = mapper.host_stats()
     if dist is not None:
         dev = torch.device("cuda", local)
         elapsed = wmdist.max_over_ranks(elapsed, dist, dev)
@@ -295,6 +316,7 @@ def main():
         out = make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1)
         if dist is not None:
             out["config"]["rccl_world_size"] = dist.get_world_size()
+        out["host"] = host_report(hs0, hs1, ru0, ru1, elapsed, n_cores)
         if world == 1 and args.cpu_sample != 0:
             # one full step (the first timed batch) through the REAL reference on this host's cores: CPU baseline + parity
             bn, bs = batches[args.warmup]

@@ -10,8 +10,9 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 python bench.py "$@" > $OUT/bench.json 2> $OUT/bench.log
 tail -3 $OUT/bench.log; cat $OUT/bench.json
-( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python $ROOT/bench.py "$@" > $OUT/bench_prof.json 2> $OUT/bench_prof.log )
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python $ROOT/bench.py "$@" ${PROF_ARGS:---cpu-sample 0} > $OUT/bench_prof.json 2> $OUT/bench_prof.log )
 cat $OUT/bench_prof.json
+for f in $OUT/stats/*.db; do python $ROOT/tools/gpu_timeline.py $f 0.35 > $OUT/timeline.txt 2>&1; done; cat $OUT/timeline.txt
 if [ "${PMC:-0}" = "1" ]; then
   # HBM traffic (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE, in their own passes, no trace domains)
   # (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950; a reduced batch keeps the serialised counter runs short)

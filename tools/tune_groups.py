@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""One-process sweep of (host threads, scheduler groups) on the bench workload: reads/s per configuration.
-  python tools/tune_groups.py "32:4,64:8,64:16" [--config 2] [--reads 65536]"""
+"""One-process sweep of (host threads, device contexts[, reads in flight]) on the bench workload: reads/s per configuration.
+  python tools/tune_groups.py "16:4,16:8:32768,16:8:65536" [--config 2] [--reads 65536]"""
 import argparse
 import importlib.util
 import json
@@ -37,18 +37,27 @@ def main():
     batches = [(names[:n], seqs[:n]), (names[n:], seqs[n:])]
     rows = []
     for spec_ in a.configs.split(","):
-        t, g = (int(x) for x in spec_.split(":"))
+        f = [int(x) for x in spec_.split(":")]
+        t, g, infl = f[0], f[1], (f[2] if len(f) > 2 else 0)
         os.environ["WM_GROUPS"] = str(g)
+        os.environ["WM_INFLIGHT"] = str(infl) if infl else ""
+        if not infl:
+            os.environ.pop("WM_INFLIGHT")
         arena = int(min(48.0, a.hbm_gb / g) * (1 << 30))
         ctx = gpu.Context(0, arena)
         idx.upload(ctx)
         m = gpu.Mapper(ctx, idx, cfg["preset"], gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
         m.set_threads(t, arena)
-        m.map(*batches[0], copy_text=False)
+        m.map(batches[0][0][:n // 4], batches[0][1][:n // 4], copy_text=False)     # warm-up (pinned slabs, code objects)
+        hs0 = m.host_stats()
         t0 = time.time()
         _, h, _, _ = m.map(*batches[1], copy_text=False)
         dt = time.time() - t0
-        rows.append({"threads": t, "groups": g, "arena_gb": arena / (1 << 30), "s_per_step": dt, "reads_per_s": n / dt, "gbps": n * cfg["read_len"] / dt / 1e9, "hits": len(h)})
+        hs1 = m.host_stats()
+        rows.append({"threads": t, "contexts": g, "inflight": infl or 16384, "arena_gb": arena / (1 << 30), "s_per_step": round(dt, 3), "reads_per_s": round(n / dt, 1), "gbps": round(n * cfg["read_len"] / dt / 1e9, 4), "hits": len(h),
+                     "glue_cpu_s": round(hs1["cpu_glue_s"] - hs0["cpu_glue_s"], 1), "idle_wall_s": round(hs1["idle_wall_s"] - hs0["idle_wall_s"], 1),
+                     "batched_wall_s": {o: round(hs1["wall_batched_s"][o] - hs0["wall_batched_s"][o], 1) for o in hs1["wall_batched_s"]},
+                     "batched_calls": {o: hs1["batched_calls"][o] - hs0["batched_calls"][o] for o in hs1["batched_calls"]}})
         B.log(json.dumps(rows[-1]))
         m.close(); ctx.close()
     print(json.dumps(rows))

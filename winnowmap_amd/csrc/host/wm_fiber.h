@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <chrono>
+#include <time.h>
 #include "wm_ops.h"
 
 namespace wm {
@@ -36,6 +37,8 @@ namespace wm {
 class Scheduler;
 struct Fiber { ucontext_t ctx; char *stack; std::function<void()> fn; bool done; Scheduler *owner; };
 enum { OP_SKETCH = 0, OP_SEED = 1, OP_CHAIN = 2, OP_KSW = 3, OP_N = 4 };
+inline double thread_cpu_s() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+inline double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct Hub {
 	Hub(DeviceOps *ops_, const wm_ksw_score_t &sc_, int w_, int k_) : ops(ops_), sc(sc_), w(w_), k(k_) { max_inflight = ops->max_inflight(); if (max_inflight < 1) max_inflight = 1; }
@@ -51,19 +54,25 @@ struct Hub {
 	int inflight = 0, inflight_op[OP_N] = {0, 0, 0, 0};
 	std::atomic<int64_t> live{0};           // fibers alive + reads not yet admitted, over all workers: 0 = the mapping call is finished
 	uint64_t n_batches[OP_N] = {0, 0, 0, 0}, n_reqs[OP_N] = {0, 0, 0, 0};
+	// where the host time goes (seconds, summed over the workers): CPU time running fibers, CPU and wall time inside the batched
+	// calls per operation, wall time asleep waiting for results
+	double cpu_fiber = 0, cpu_op[OP_N] = {0, 0, 0, 0}, wall_op[OP_N] = {0, 0, 0, 0}, wall_idle = 0;
 	size_t pending(int op) const { return op == OP_SKETCH ? q_sketch.size() : op == OP_SEED ? q_seed.size() : op == OP_CHAIN ? q_chain.size() : q_ksw.size(); }
 };
 
 class Scheduler {
 public:
 	explicit Scheduler(Hub *hub, int rank = 0) : hub_(hub), rank_(rank) {}
-	~Scheduler() { for (Fiber *f : pool_) { free(f->stack); delete f; } }
+	~Scheduler() { for (Fiber *f : pool_) delete f; for (char *sl : slabs_) free(sl); }
 
 	void spawn(std::function<void()> fn)
 	{
 		Fiber *f;
 		if (!pool_.empty()) { f = pool_.back(); pool_.pop_back(); }
-		else { f = new Fiber(); f->stack = (char*)malloc(kStack); }
+		else {           // stacks come from slabs of 64 (one mapping per slab: a window of 10^4..10^5 reads x ~10 fibers would otherwise need that many mappings)
+			if (slab_left_ == 0) { slabs_.push_back((char*)malloc(kStack * kSlab)); slab_left_ = kSlab; }
+			f = new Fiber(); f->stack = slabs_.back() + kStack * (size_t)(kSlab - slab_left_--);
+		}
 		f->fn = std::move(fn); f->done = false;
 		getcontext(&f->ctx);
 		f->ctx.uc_stack.ss_sp = f->stack; f->ctx.uc_stack.ss_size = kStack; f->ctx.uc_link = &main_;
@@ -81,21 +90,26 @@ public:
 	void run()
 	{
 		Hub &H = *hub_;
+		double cpu_fiber = 0, wall_idle = 0;
 		for (;;) {
+			const double c0 = thread_cpu_s();
 			while (!ready_.empty()) {
 				cur_ = ready_.front(); ready_.pop_front();
 				swapcontext(&main_, &cur_->ctx);
 				if (cur_->done) { cur_->fn = nullptr; pool_.push_back(cur_); H.live.fetch_sub(1); }
 				cur_ = 0;
 			}
+			cpu_fiber += thread_cpu_s() - c0;
 			std::unique_lock<std::mutex> lk(H.mu);
 			publish_locked();
 			for (;;) {
 				if (!inbox_.empty()) { for (Fiber *f : inbox_) ready_.push_back(f); inbox_.clear(); break; }
-				if (H.live.load() == 0) { H.cv.notify_all(); return; }
+				if (H.live.load() == 0) { H.cpu_fiber += cpu_fiber; H.wall_idle += wall_idle; H.cv.notify_all(); return; }
 				const int op = pick_locked();
 				if (op >= 0) { dispatch(op, lk); continue; }      // (returns with the lock held again)
+				const double w0 = wall_s();
 				H.cv.wait(lk);
+				wall_idle += wall_s() - w0;
 			}
 		}
 	}
@@ -108,6 +122,7 @@ public:
 
 private:
 	static constexpr size_t kStack = 256 * 1024;
+	static constexpr int kSlab = 64;
 	static void entry(unsigned lo, unsigned hi, unsigned)
 	{
 		Fiber *f = (Fiber*)((uintptr_t)lo | (uintptr_t)hi << 32);
@@ -156,13 +171,16 @@ private:
 		lk.unlock();
 		static const bool trace = getenv("WM_TRACE") != 0;
 		const auto t0 = std::chrono::steady_clock::now();
+		const double c0 = thread_cpu_s(), w0 = wall_s();
 		if (op == OP_SKETCH) H.ops->sketch_batch(H.w, H.k, a);
 		else if (op == OP_SEED) H.ops->seed_batch(b);
 		else if (op == OP_CHAIN) H.ops->chain_batch(c);
 		else H.ops->ksw_batch(H.sc, d);
 		if (trace) fprintf(stderr, "[batch] worker %2d %s n=%zu %.1f ms\n", rank_, op == OP_SKETCH ? "sketch" : op == OP_SEED ? "seed" : op == OP_CHAIN ? "chain" : "ksw", n,
 		                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+		const double dc = thread_cpu_s() - c0, dw = wall_s() - w0;
 		lk.lock();
+		H.cpu_op[op] += dc; H.wall_op[op] += dw;
 		--H.inflight; --H.inflight_op[op];
 		for (Fiber *f : waiters) f->owner->inbox_.push_back(f);      // inboxes are protected by the hub mutex
 		H.cv.notify_all();
@@ -174,6 +192,7 @@ private:
 	Fiber *cur_ = 0;
 	std::deque<Fiber*> ready_;
 	std::vector<Fiber*> pool_;
+	std::vector<char*> slabs_; int slab_left_ = 0;
 	std::vector<Fiber*> inbox_;             // fibers whose results arrived (filled by dispatchers under the hub mutex)
 	std::vector<SketchReq*> l_sketch_; std::vector<SeedReq*> l_seed_; std::vector<ChainReq*> l_chain_; std::vector<KswReq*> l_ksw_;
 	std::vector<Fiber*> l_wait_[OP_N];

@@ -225,7 +225,7 @@ void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::v
 	const int T = n_threads < 1 ? 1 : n_threads;
 	// reads in flight over all workers (WM_INFLIGHT): large enough for full device batches at every stage, small enough that the
 	// stages overlap instead of running in lock-step phases
-	static const long inflight_env = getenv("WM_INFLIGHT") ? atol(getenv("WM_INFLIGHT")) : 0;
+	const long inflight_env = getenv("WM_INFLIGHT") ? atol(getenv("WM_INFLIGHT")) : 0;
 	const size_t window = std::max<size_t>(1, (size_t)(inflight_env > 0 ? inflight_env : 16384) / (size_t)T);
 	Hub hub(ops, sc, idx.w, idx.k);
 	std::vector<std::unique_ptr<Scheduler>> sch(T);
@@ -260,6 +260,8 @@ void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::v
 	if (stats) {
 		stats->n_flush += hub.n_batches[OP_SKETCH] + hub.n_batches[OP_SEED] + hub.n_batches[OP_CHAIN] + hub.n_batches[OP_KSW];
 		stats->n_ksw += hub.n_reqs[OP_KSW]; stats->n_chain += hub.n_reqs[OP_CHAIN]; stats->n_seed += hub.n_reqs[OP_SEED]; stats->n_sketch += hub.n_reqs[OP_SKETCH];
+		stats->cpu_fiber += hub.cpu_fiber; stats->wall_idle += hub.wall_idle;
+		for (int op = 0; op < OP_N; ++op) { stats->n_batches[op] += hub.n_batches[op]; stats->cpu_op[op] += hub.cpu_op[op]; stats->wall_op[op] += hub.wall_op[op]; }
 	}
 }
 

@@ -1191,6 +1191,7 @@ struct wm_mapper_s {
 	std::string text;
 	std::vector<int32_t> hits; std::vector<uint32_t> cigars; std::vector<int64_t> first;
 	uint64_t stats[9];
+	double host_stats[17] = {0};
 	std::vector<std::string> cmdline;      // argv of the front end, for the @PG line of SAM files (wm_mapper_set_cmdline)
 };
 
@@ -1307,6 +1308,12 @@ static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double
 	});
 	if (trace_m) fprintf(stderr, "[map_reads] n=%d ingest %.1f ms, map %.1f ms, format %.1f ms\n", n, tm1 - tm0, tm2 - tm1, now_ms() - tm2);
 	m->stats[0] = st.n_flush; m->stats[1] = st.n_ksw; m->stats[2] = st.n_chain; m->stats[3] = st.n_seed; m->stats[4] = st.n_sketch;
+	m->host_stats[0] += st.cpu_fiber; m->host_stats[1] += st.wall_idle;
+	for (int op = 0; op < 4; ++op) { m->host_stats[2 + op] += st.cpu_op[op]; m->host_stats[6 + op] += st.wall_op[op]; m->host_stats[10 + op] += (double)st.n_batches[op]; }
+	m->host_stats[14] += (tm2 - tm1) * 1e-3; m->host_stats[15] += (now_ms() - tm2) * 1e-3; m->host_stats[16] = m->n_threads;
+	if (trace_m) fprintf(stderr, "[host] fibers cpu %.2f s | idle wall %.2f s | batched calls cpu/wall/n: sketch %.2f/%.2f/%llu seed %.2f/%.2f/%llu chain %.2f/%.2f/%llu ksw %.2f/%.2f/%llu\n", st.cpu_fiber, st.wall_idle,
+	                     st.cpu_op[0], st.wall_op[0], (unsigned long long)st.n_batches[0], st.cpu_op[1], st.wall_op[1], (unsigned long long)st.n_batches[1],
+	                     st.cpu_op[2], st.wall_op[2], (unsigned long long)st.n_batches[2], st.cpu_op[3], st.wall_op[3], (unsigned long long)st.n_batches[3]);
 	m->stats[5] = opsr.cells; m->stats[6] = (uint64_t)opsr.ksw_us; m->stats[7] = (uint64_t)opsr.aux_us; m->stats[8] = bases;
 	return WM_OK;
 }
@@ -1360,6 +1367,13 @@ extern "C" int wm_mapper_kernel_stats(const wm_mapper_t *m, double *out, int cap
 		for (const wm_ctx_t *w : m->workers) { ms += w->k_ms[k]; cells += (double)w->k_cells[k]; ln += (double)w->k_launches[k]; }
 		out[3 * k] = ms; out[3 * k + 1] = cells; out[3 * k + 2] = ln;
 	}
+	return WM_OK;
+}
+
+extern "C" int wm_mapper_host_stats(const wm_mapper_t *m, double *out, int cap)
+{
+	if (cap < 17) return set_err(WM_EINVAL, "need room for 17 doubles");
+	memcpy(out, m->host_stats, sizeof(m->host_stats));
 	return WM_OK;
 }
 

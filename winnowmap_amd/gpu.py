@@ -296,6 +296,16 @@ class Mapper:
         _chk(lib().wm_mapper_kernel_stats(self._h, out.ctypes.data, len(out), C.byref(n)))
         return {k: (float(out[3 * k]), float(out[3 * k + 1]), int(out[3 * k + 2])) for k in range(n.value)}
 
+    def host_stats(self):
+        """host time accounting since the mapper was created (wm_mapper_host_stats), seconds summed over the worker threads"""
+        a = np.zeros(17, np.float64)
+        lib().wm_mapper_host_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _chk(lib().wm_mapper_host_stats(self._h, a.ctypes.data, len(a)))
+        ops = ("sketch", "seed", "chain", "ksw")
+        return {"cpu_glue_s": float(a[0]), "idle_wall_s": float(a[1]), "cpu_batched_s": {o: float(a[2 + i]) for i, o in enumerate(ops)},
+                "wall_batched_s": {o: float(a[6 + i]) for i, o in enumerate(ops)}, "batched_calls": {o: int(a[10 + i]) for i, o in enumerate(ops)},
+                "map_wall_s": float(a[14]), "format_wall_s": float(a[15]), "threads": int(a[16])}
+
     def close(self):
         if self._h:
             lib().wm_mapper_destroy(self._h)
