@@ -79,6 +79,25 @@ int wm_ksw_batch(wm_ctx_t *ctx, const wm_ksw_score_t *sc, int n_jobs, const wm_k
                  const uint8_t *seqs, size_t seqs_bytes,
                  wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used);
 
+/* The same batch with the operands given as POSITIONS in data the device already holds — the packed reference (wm_index_upload:
+ * the S array of mm_idx_t, 4 bits per base, src/index.c:329-335, read like mm_idx_getseq, src/index.c:161-171) and the 0..4 codes of the
+ * reads of the current mini-batch (wm_reads_upload) — instead of bytes: nothing is unpacked, copied or shipped per alignment; a
+ * kernel expands the operands inside HBM. Query element i = index q_pos + i*step of the TWO-STRAND SPACE of the (sub)read that starts
+ * at code qwin_off and is qwin_len long: [0, L) forward strand, [L, 2L) reverse complement, outside = N — the layout of the reference's
+ * qseq0 buffer (src/align.c:871-877). Target element i = base t_pos + i*step of contig rid. step = -1 aligns both operands back to
+ * front (the left extension, src/align.c:690-705). has_n: 0 promises that neither operand holds an ambiguous base. */
+typedef struct {
+	int64_t qwin_off;
+	int32_t qwin_len, q_pos;
+	int32_t rid, t_pos;
+	int32_t qlen, tlen;
+	int32_t w, zdrop, end_bonus, flag;
+	int8_t step, has_n, pad[6];
+} wm_ksw_pos_t;
+int wm_reads_upload(wm_ctx_t *ctx, const uint8_t *codes, size_t n);
+int wm_ksw_batch_pos(wm_ctx_t *ctx, const wm_ksw_score_t *sc, int n_jobs, const wm_ksw_pos_t *jobs,
+                     wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used);
+
 /* Same computation with the inputs already resident in HBM (device pointers from wm_dev_alloc /
  * wm_dev_upload); results stay on the device until wm_ksw_fetch. Used by bench.py so that the timed
  * region contains kernels only, and by the batched mapper which keeps reads and reference resident. */

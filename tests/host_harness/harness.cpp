@@ -19,9 +19,36 @@ using namespace wm;
 struct OracleOps : DeviceOps {
 	const Index *idx; wmo_bloom_t *bloom; const MapOpt *opt;
 	int max_inflight() const override { return 64; }             // stateless CPU calls: any number may run at once
+	// "resident" data like the device implementation keeps it: the batch's read codes (and the index's packed reference). Requests are
+	// served from their host views; the resident positions they carry are decoded as well and must give the same bytes.
+	const uint8_t *rd = 0; size_t rd_n = 0;
+	std::atomic<long> n_pos_checked{0}, n_pos_bad{0};
+	bool load_reads(const uint8_t *codes, size_t n) override { rd = codes; rd_n = n; return true; }
+	uint8_t two_strand(const KswReq &r, int64_t p) const
+	{   // KswReq: [0,L) forward strand, [L,2L) reverse complement, negative = N padding
+		const int64_t L = r.qwin_len;
+		if (p < 0 || p >= 2 * L) return 4;
+		const uint8_t c = p < L ? rd[r.qwin_off + p] : rd[r.qwin_off + (2 * L - 1 - p)];
+		return p < L ? c : (c < 4 ? 3 - c : 4);
+	}
+	void check_positions(const KswReq &r, const std::vector<uint8_t> &q, const std::vector<uint8_t> &t)
+	{
+		if (!r.resident()) return;
+		bool bad = false, any_n = false;
+		for (int i = 0; i < r.ql; ++i) { bad |= two_strand(r, (int64_t)r.q_pos + (int64_t)i * r.step) != q[i]; any_n |= q[i] >= 4; }
+		std::vector<uint8_t> tt(r.tl > 0 ? r.tl : 0);
+		if (r.tl > 0) {
+			const int lo = r.step > 0 ? r.t_pos : r.t_pos - (r.tl - 1);
+			idx->getseq(r.rid, lo, lo + r.tl, tt.data());
+			for (int i = 0; i < r.tl; ++i) { bad |= tt[r.step > 0 ? i : r.tl - 1 - i] != t[i]; any_n |= t[i] >= 4; }
+		}
+		if (any_n && !r.has_n) bad = true;                        // has_n may be conservative, never optimistic
+		++n_pos_checked; if (bad) ++n_pos_bad;
+	}
 	void sketch_batch(int w, int k, std::vector<SketchReq*> &reqs) override
 	{
 		for (SketchReq *r : reqs) {
+			if (r->dev_off >= 0) { ++n_pos_checked; if ((size_t)r->dev_off + r->len > rd_n || memcmp(rd + r->dev_off, r->seq, r->len) != 0) ++n_pos_bad; }
 			std::vector<uint64_t> x(r->len + 8), y(r->len + 8);
 			int64_t n = wmo_sketch((const char*)r->seq, r->len, w, k, 0, bloom, x.data(), y.data(), r->len + 8);
 			r->mini.resize(n);
@@ -97,9 +124,12 @@ struct OracleOps : DeviceOps {
 		wm::parallel_for(4, reqs.size(), [&](size_t ri) {
 			KswReq *r = reqs[ri];
 			wmo_ez_t ez;
-			if (getenv("WM_KSW_STATS")) fprintf(stderr, "KSWJOB %d %d %d %d %d\n", (int)r->q.size(), (int)r->t.size(), r->w, r->zdrop, r->flag);
-			std::vector<uint32_t> cig(r->q.size() + r->t.size() + 4);
-			wmo_ksw_extd2((int)r->q.size(), r->q.data(), (int)r->t.size(), r->t.data(), 5, mat, sc.q, sc.e, sc.q2, sc.e2, r->w, r->zdrop, r->end_bonus, r->flag, &ez, cig.data(), 0);
+			if (getenv("WM_KSW_STATS")) fprintf(stderr, "KSWJOB %d %d %d %d %d\n", r->ql, r->tl, r->w, r->zdrop, r->flag);
+			std::vector<uint8_t> q(r->ql > 0 ? r->ql : 0), t(r->tl > 0 ? r->tl : 0);
+			r->copy_query(q.data()); r->copy_target(t.data());
+			check_positions(*r, q, t);
+			std::vector<uint32_t> cig(q.size() + t.size() + 4);
+			wmo_ksw_extd2((int)q.size(), q.data(), (int)t.size(), t.data(), 5, mat, sc.q, sc.e, sc.q2, sc.e2, r->w, r->zdrop, r->end_bonus, r->flag, &ez, cig.data(), 0);
 			r->ez.max = ez.max; r->ez.zdropped = ez.zdropped; r->ez.max_q = ez.max_q; r->ez.max_t = ez.max_t; r->ez.mqe = ez.mqe; r->ez.mqe_t = ez.mqe_t;
 			r->ez.mte = ez.mte; r->ez.mte_q = ez.mte_q; r->ez.score = ez.score; r->ez.reach_end = ez.reach_end; r->ez.n_cigar = ez.n_cigar; r->ez.cig_off = 0;
 			r->cigar.assign(cig.begin(), cig.begin() + ez.n_cigar);
@@ -108,6 +138,8 @@ struct OracleOps : DeviceOps {
 };
 
 struct Harness { Index idx; wmo_bloom_t *bloom; };
+static std::atomic<long> g_pos_checked{0}, g_pos_bad{0};       // resident-position checks of all OracleOps so far (h_pos_check)
+static void note_pos(const OracleOps &o) { g_pos_checked += o.n_pos_checked.load(); g_pos_bad += o.n_pos_bad.load(); }
 
 extern "C" {
 
@@ -200,6 +232,8 @@ int h_map(void *hv, const char *preset, int64_t flag_extra, const char *seq, int
 	std::vector<ReadOut> out;
 	MapStats st;
 	map_batch(h->idx, mo, &ops, reads, out, &st);
+	note_pos(ops);
+	if (ops.n_pos_bad.load()) return -3;
 	if (stats_out) { stats_out[0] = st.n_flush; stats_out[1] = st.n_ksw; stats_out[2] = st.n_chain; stats_out[3] = st.n_sketch; }
 	int64_t nc = 0;
 	const std::vector<Reg> &regs = out[0].regs;
@@ -215,6 +249,9 @@ int h_map(void *hv, const char *preset, int64_t flag_extra, const char *seq, int
 	return (int)regs.size();
 }
 
+// how many requests carried resident positions (checked against their host views) and how many of them disagreed
+void h_pos_check(long *checked, long *bad) { *checked = g_pos_checked.load(); *bad = g_pos_bad.load(); }
+
 // several reads at once on a team of `n_threads` schedulers; hits of read i start at hit_first[i] (16 ints each)
 int h_map_many(void *hv, const char *preset, int64_t flag_extra, int n, const char *const *seqs, const int *lens, int n_threads,
                int32_t *hit_out, int hit_cap, int64_t *hit_first, uint32_t *cig_out, int64_t cig_cap, int64_t *n_cig_total)
@@ -229,6 +266,8 @@ int h_map_many(void *hv, const char *preset, int64_t flag_extra, int n, const ch
 	for (int i = 0; i < n; ++i) { reads[i].name = "read" + std::to_string(i); reads[i].seq.assign(seqs[i], lens[i]); }
 	std::vector<ReadOut> out;
 	map_batch(h->idx, mo, &ops, reads, out, 0, n_threads);
+	note_pos(ops);
+	if (ops.n_pos_bad.load()) return -3;
 	if (prof_on()) prof_report(stderr);
 	int64_t nc = 0; int nh = 0;
 	for (int k = 0; k < n; ++k) {
@@ -261,6 +300,8 @@ int64_t h_map_text(void *hv, const char *preset, int64_t flag_extra, int n, cons
 	for (int i = 0; i < n; ++i) { reads[i].name = names[i]; reads[i].seq.assign(seqs[i], lens[i]); }
 	std::vector<ReadOut> outv;
 	map_batch(h->idx, mo, &ops, reads, outv, 0, n_threads);
+	note_pos(ops);
+	if (ops.n_pos_bad.load()) return -3;
 	std::string text;
 	for (int i = 0; i < n; ++i) write_read(text, h->idx, reads[i], outv[i], mo.flag);
 	if ((int64_t)text.size() > cap) return -(int64_t)text.size();

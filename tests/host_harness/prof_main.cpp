@@ -36,7 +36,7 @@ struct ReplayOps : DeviceOps {
 	{
 		++n_calls[3]; n_reqs[3] += reqs.size();
 		if (!replay) { inner->ksw_batch(sc, reqs); for (KswReq *r : reqs) { kr.push_back(KR{ r->ez, r->cigar }); } return; }
-		for (KswReq *r : reqs) { r->ez = kr[i_kr].ez; r->cigar = kr[i_kr++].cigar; bytes_q += r->q.size() + r->t.size(); }
+		for (KswReq *r : reqs) { r->ez = kr[i_kr].ez; r->cigar = kr[i_kr++].cigar; bytes_q += r->ql + r->tl; }
 	}
 };
 

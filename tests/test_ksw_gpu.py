@@ -117,3 +117,63 @@ def test_wide_band_jobs_block_and_generic_kernels(ctx):
         cases.append(dict(q=synth.mutate_codes(t, rng, 0.03, 0.03, 0.03), t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=-1, zdrop=400, end_bonus=-1, flag=fl))
     bad = _run_group(ctx, cases)
     assert not bad, bad[:3]
+
+
+def test_position_jobs_equal_byte_jobs(tmp_path):
+    """wm_ksw_batch_pos expands its operands inside HBM from the resident read codes (two-strand space, src/align.c:871-877) and the
+    packed reference (mm_idx_getseq, src/index.c:161-171): results must equal wm_ksw_batch on the same operands as bytes, which the
+    other tests pin to the oracle. Covers both strands, reversed operands (left extension), N padding in front of a strand, N bases."""
+    from winnowmap_amd import synth
+    rng = np.random.default_rng(11)
+    ref = synth.make_reference(3, 60000, 21, repeat_frac=0.0)
+    ref[1][1000:1040] = 4                                        # a run of N in the second contig
+    fa = str(tmp_path / "ref.fa")
+    synth.write_fasta(fa, ref)
+    c = gpu.Context(0, 2 << 30)
+    idx = gpu.Index(fa, None, k=15, w=50, n_threads=2)
+    idx.upload(c)
+    lens = [3000, 5000, 2500, 4000]
+    reads = [rng.integers(0, 4, n).astype(np.uint8) for n in lens]
+    reads[2][100:110] = 4
+    codes = np.concatenate(reads)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    c.reads_upload(codes)
+    sc = gpu.KswScore(2, -4, -1, 4, 2, 24, 1)
+    n = 300
+    pos = np.zeros(n, gpu.KSW_POS_DTYPE)
+    pairs = []
+    for i in range(n):
+        ri = int(rng.integers(0, len(reads)))
+        sub0 = int(rng.integers(0, lens[ri] // 2))                # a window of the read, like a stage-1 prefix
+        L = int(rng.integers(600, lens[ri] - sub0 + 1))
+        win = reads[ri][sub0:sub0 + L]
+        both = np.concatenate([np.full(8, 4, np.uint8), win, np.where(win[::-1] < 4, 3 - win[::-1], 4).astype(np.uint8)])   # qseq0 with its padding
+        ql, tl = int(rng.integers(1, 500)), int(rng.integers(1, 500))
+        step = -1 if i % 3 == 0 else 1
+        strand = int(rng.integers(0, 2))
+        q_lo = int(rng.integers(0, L - ql + 1)) + strand * L
+        if i % 17 == 0 and q_lo >= 4:                             # a few bases in front of a strand (mm_align1_inv, src/align.c:826-828)
+            q_lo = strand * L - 3
+        rid = int(rng.integers(0, 3))
+        t_lo = int(rng.integers(900, 1100 - 0)) if (rid == 1 and i % 5 == 0) else int(rng.integers(0, 60000 - tl + 1))
+        q = both[8 + q_lo:8 + q_lo + ql]
+        t = ref[rid][t_lo:t_lo + tl]
+        if step < 0:
+            q, t = q[::-1], t[::-1]
+        flag = [0, 0x08, 0x40, 0x40 | 0x02 | 0x80][i % 4]
+        w = [751, 100, 30, 751][i % 4]
+        pairs.append((q.copy(), t.copy(), dict(w=w, zdrop=400, end_bonus=-1 if i % 2 else 5, flag=flag)))
+        has_n = bool((q >= 4).any() or (t >= 4).any())
+        pos[i] = (offs[ri] + sub0, L, q_lo if step > 0 else q_lo + ql - 1, rid, t_lo if step > 0 else t_lo + tl - 1, ql, tl, w, 400, -1 if i % 2 else 5, flag, step, has_n, 0)
+    jobs, seqs = gpu.pack_jobs(pairs)
+    r0, p0 = c.ksw_batch(sc, jobs, seqs)
+    r1, p1 = c.ksw_batch_pos(sc, pos)
+    for k in r0.dtype.names:
+        assert np.array_equal(r0[k], r1[k]), k
+    assert np.array_equal(p0, p1)
+    # positions outside the resident data are refused, not read
+    bad = pos[:1].copy()
+    bad["t_pos"] = 59990; bad["tlen"] = 100; bad["step"] = 1
+    with pytest.raises(gpu.WmError):
+        c.ksw_batch_pos(sc, bad)
+    idx.close(); c.close()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """One-process sweep of (host threads, device contexts[, reads in flight]) on the bench workload: reads/s per configuration.
-  python tools/tune_groups.py "16:4,16:8:32768,16:8:65536" [--config 2] [--reads 65536]"""
+  python tools/tune_groups.py "16:4,16:8:32768,16:6:16384:WM_NO_RESIDENT=1;WM_KSW_HEAVY_UNITS=0" [--config 2] [--reads 65536]"""
 import argparse
 import importlib.util
 import json
@@ -37,8 +37,12 @@ def main():
     batches = [(names[:n], seqs[:n]), (names[n:], seqs[n:])]
     rows = []
     for spec_ in a.configs.split(","):
-        f = [int(x) for x in spec_.split(":")]
+        parts = spec_.split(":")
+        envs = dict(kv.split("=", 1) for kv in parts[3].split(";")) if len(parts) > 3 and parts[3] else {}
+        f = [int(x) for x in parts[:3]]
         t, g, infl = f[0], f[1], (f[2] if len(f) > 2 else 0)
+        for k_, v_ in envs.items():
+            os.environ[k_] = v_
         os.environ["WM_GROUPS"] = str(g)
         os.environ["WM_INFLIGHT"] = str(infl) if infl else ""
         if not infl:
@@ -54,7 +58,9 @@ def main():
         _, h, _, _ = m.map(*batches[1], copy_text=False)
         dt = time.time() - t0
         hs1 = m.host_stats()
-        rows.append({"threads": t, "contexts": g, "inflight": infl or 16384, "arena_gb": arena / (1 << 30), "s_per_step": round(dt, 3), "reads_per_s": round(n / dt, 1), "gbps": round(n * cfg["read_len"] / dt / 1e9, 4), "hits": len(h),
+        for k_ in envs:
+            os.environ.pop(k_)
+        rows.append({"env": envs, "threads": t, "contexts": g, "inflight": infl or 16384, "arena_gb": arena / (1 << 30), "s_per_step": round(dt, 3), "reads_per_s": round(n / dt, 1), "gbps": round(n * cfg["read_len"] / dt / 1e9, 4), "hits": len(h),
                      "glue_cpu_s": round(hs1["cpu_glue_s"] - hs0["cpu_glue_s"], 1), "idle_wall_s": round(hs1["idle_wall_s"] - hs0["idle_wall_s"], 1),
                      "batched_wall_s": {o: round(hs1["wall_batched_s"][o] - hs0["wall_batched_s"][o], 1) for o in hs1["wall_batched_s"]},
                      "batched_calls": {o: hs1["batched_calls"][o] - hs0["batched_calls"][o] for o in hs1["batched_calls"]}})

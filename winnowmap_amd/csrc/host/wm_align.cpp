@@ -88,7 +88,25 @@ int ll_i16(int qlen, const uint8_t *query, int tlen, const uint8_t *target, cons
 // ------------------------------------------------------------------------------------------------------------
 struct AlnEnv {
 	const MapOpt *opt; const Index *idx; int qlen; const uint8_t *qseq0[2]; int8_t mat[25];
+	int64_t q_dev_off;      // where qcodes[0] lives in the resident read codes (-1: not resident), see KswReq
+	bool q_has_n;
 };
+
+// one ksw request on query strand `rev`, strand coordinates [qs, qe), and reference [rs, re) of contig rid; `tb` = codes of the
+// reference from base tb0 on. reversed: both operands back to front (left extension)
+static KswReq make_job(const AlnEnv &E, int rev, int32_t qs, int32_t qe, int32_t rid, int32_t rs, int32_t re, const uint8_t *tb, int32_t tb0, bool t_has_n, bool reversed)
+{
+	KswReq j;
+	const uint8_t *qstr = E.qseq0[rev];
+	j.ql = qe - qs; j.tl = re - rs; j.step = reversed ? -1 : 1;
+	j.qp = reversed ? qstr + qe - 1 : qstr + qs;
+	j.tp = reversed ? tb + (re - 1 - tb0) : tb + (rs - tb0);
+	j.qwin_off = E.q_dev_off; j.qwin_len = E.qlen;
+	j.q_pos = (rev ? E.qlen : 0) + (reversed ? qe - 1 : qs);
+	j.rid = rid; j.t_pos = reversed ? re - 1 : rs;
+	j.has_n = E.q_has_n || t_has_n;
+	return j;
+}
 
 static inline void adjust_minier(const Index &idx, const m128 &a, int32_t *r, int32_t *q)
 {   // mm_adjust_minier, non-HPC branch (src/align.c:362-363)
@@ -352,6 +370,8 @@ struct RegAln {
 	std::vector<Fill> fills;
 	std::vector<int> redo_code;
 	bool empty = false;
+	std::vector<uint8_t> tbuf;       // reference codes of [rs0, re0): every DP of the region and the final statistics read from here
+	bool t_has_n = false;
 };
 
 static inline std::vector<uint8_t> ref_codes(const Index &idx, int rid, int st, int en)
@@ -442,12 +462,12 @@ static void plan_reg(const AlnEnv &E, RegAln &A, m128 *a, std::vector<KswReq> &j
 	}
 	WM_INVARIANT(re0 > rs0);
 	A.rs0 = rs0, A.qs0 = qs0, A.re0 = re0, A.qe0 = qe0;
-	const uint8_t *qs_strand = E.qseq0[A.rev];
+	A.tbuf = ref_codes(mi, rid, rs0, re0);                             // (mm_idx_getseq per DP in the reference, src/align.c:699,724,773)
+	A.t_has_n = mi.has_n(rid, rs0, re0);
+	const uint8_t *tb = A.tbuf.data();
 
 	if (qs > 0 && rs > 0) {                                            // left extension on reversed sequences (:690-705)
-		KswReq j;
-		j.q.assign(qs_strand + qs0, qs_strand + qs); std::reverse(j.q.begin(), j.q.end());
-		j.t = ref_codes(mi, rid, rs0, rs); std::reverse(j.t.begin(), j.t.end());
+		KswReq j = make_job(E, A.rev, qs0, qs, rid, rs0, rs, tb, rs0, A.t_has_n, true);
 		j.w = A.bw; j.end_bonus = opt.end_bonus; j.zdrop = r.split_inv ? opt.zdrop_inv : opt.zdrop;
 		j.flag = EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR;
 		A.left_job = (int)jobs.size(); jobs.push_back(std::move(j));
@@ -458,9 +478,7 @@ static void plan_reg(const AlnEnv &E, RegAln &A, m128 *a, std::vector<KswReq> &j
 		if (i == cnt1 - 1 || (a[as1 + i].y & SEED_LONG_JOIN) || (qe - qs >= opt.min_ksw_len && re - rs >= opt.min_ksw_len)) {
 			Fill f; f.idx = i; f.qs = qs; f.qe = qe; f.rs = rs; f.re = re; f.bw1 = A.bw; f.redo_job = -1;
 			if (a[as1 + i].y & SEED_LONG_JOIN) f.bw1 = qe - qs > re - rs ? qe - qs : re - rs;
-			KswReq j;
-			j.q.assign(qs_strand + qs, qs_strand + qe);
-			j.t = ref_codes(mi, rid, rs, re);
+			KswReq j = make_job(E, A.rev, qs, qe, rid, rs, re, tb, rs0, A.t_has_n, false);
 			j.w = f.bw1; j.end_bonus = -1; j.zdrop = opt.zdrop; j.flag = EZ_APPROX_MAX;
 			f.job = (int)jobs.size(); jobs.push_back(std::move(j));
 			A.fills.push_back(f);
@@ -469,9 +487,7 @@ static void plan_reg(const AlnEnv &E, RegAln &A, m128 *a, std::vector<KswReq> &j
 	}
 	A.re = re, A.qe = qe;                                              // coordinates of the last anchor
 	if (qe < qe0 && re < re0) {                                        // right extension (:767-778), used unless a fill z-drops
-		KswReq j;
-		j.q.assign(qs_strand + qe, qs_strand + qe0);
-		j.t = ref_codes(mi, rid, re, re0);
+		KswReq j = make_job(E, A.rev, qe, qe0, rid, re, re0, tb, rs0, A.t_has_n, false);
 		j.w = A.bw; j.end_bonus = opt.end_bonus; j.zdrop = opt.zdrop; j.flag = EZ_EXTZ_ONLY;
 		A.right_job = (int)jobs.size(); jobs.push_back(std::move(j));
 	}
@@ -486,11 +502,11 @@ static void judge_reg(const AlnEnv &E, RegAln &A, const std::vector<KswReq> &job
 	for (size_t k = 0; k < A.fills.size(); ++k) {
 		Fill &f = A.fills[k];
 		const KswReq &j = jobs[f.job];
-		const int code = test_zdrop(*E.opt, j.q.data(), j.t.data(), j.cigar, E.mat);
+		const int code = test_zdrop(*E.opt, j.qp, j.tp, j.cigar, E.mat);      // (fills are never reversed)
 		A.redo_code[k] = code;
 		if (code != 0) {
-			KswReq d;
-			d.q = j.q; d.t = j.t; d.w = f.bw1; d.end_bonus = -1; d.zdrop = code == 2 ? E.opt->zdrop_inv : E.opt->zdrop; d.flag = 0;
+			KswReq d = j;                                                      // same operands, exact maximum this time
+			d.cigar.clear(); d.w = f.bw1; d.end_bonus = -1; d.zdrop = code == 2 ? E.opt->zdrop_inv : E.opt->zdrop; d.flag = 0;
 			f.redo_job = (int)redo.size(); redo.push_back(std::move(d));
 		}
 	}
@@ -556,8 +572,8 @@ static void finish_reg(const AlnEnv &E, RegAln &A, m128 *a, const std::vector<Ks
 	if (A.rev) r.qs = qlen - qe1, r.qe = qlen - qs1;
 	else r.qs = qs1, r.qe = qe1;
 	if (r.has_p) {
-		std::vector<uint8_t> t = ref_codes(*E.idx, A.rid, rs1, re1);
-		update_extra(r, E.qseq0[r.rev] + qs1, t.data(), E.mat, opt.q, opt.e);
+		WM_INVARIANT(rs1 >= A.rs0 && re1 <= A.re0);
+		update_extra(r, E.qseq0[r.rev] + qs1, A.tbuf.data() + (rs1 - A.rs0), E.mat, opt.q, opt.e);
 	}
 }
 
@@ -586,8 +602,9 @@ static bool align_inv(Scheduler &sch, const AlnEnv &E, const Reg &r1, const Reg 
 	q_off = ql - (q_off + 1), t_off = tl - (t_off + 1);
 	const uint8_t *qstart = qsrc + q_off;
 	std::vector<KswReq> jobs(1);
-	jobs[0].q.assign(qstart, qsrc + ql);
-	jobs[0].t.assign(tseq.begin() + t_off, tseq.end());
+	jobs[0].qp = qstart; jobs[0].ql = ql - q_off; jobs[0].tp = tseq.data() + t_off; jobs[0].tl = tl - t_off; jobs[0].step = 1;
+	jobs[0].qwin_off = E.q_dev_off; jobs[0].qwin_len = E.qlen; jobs[0].q_pos = (int32_t)(qstart - E.qseq0[0]);   // (two-strand space: the strands are contiguous)
+	jobs[0].rid = r1.rid; jobs[0].t_pos = r1.re + t_off; jobs[0].has_n = E.q_has_n || q_off < 0 || E.idx->has_n(r1.rid, r1.re, r2.rs);
 	jobs[0].w = (int)(opt.bw * 1.5); jobs[0].end_bonus = -1; jobs[0].zdrop = opt.zdrop; jobs[0].flag = EZ_EXTZ_ONLY;
 	sch.ksw(jobs);
 	const KswReq &j = jobs[0];
@@ -603,15 +620,15 @@ static bool align_inv(Scheduler &sch, const AlnEnv &E, const Reg &r1, const Reg 
 	return true;
 }
 
-void align_skeleton(Scheduler &sch, const MapOpt &opt, const Index &idx, int qlen, const uint8_t *qcodes, std::vector<Reg> &regs, m128 *a)
+void align_skeleton(Scheduler &sch, const MapOpt &opt, const Index &idx, int qlen, const uint8_t *qcodes, int64_t q_dev_off, std::vector<Reg> &regs, m128 *a)
 {
 	AlnEnv E;
-	E.opt = &opt; E.idx = &idx; E.qlen = qlen;
+	E.opt = &opt; E.idx = &idx; E.qlen = qlen; E.q_dev_off = q_dev_off; E.q_has_n = false;
 	// both strands in ONE buffer, reverse complement right behind the forward strand, exactly like the reference's
 	// qseq0 (src/align.c:871-877): mm_align1_inv may step a few bases in front of a strand (see align_inv)
 	std::vector<uint8_t> both((size_t)2 * qlen + 8, 4);
 	uint8_t *fw = both.data() + 8, *rc = fw + qlen;
-	for (int i = 0; i < qlen; ++i) { fw[i] = qcodes[i]; rc[qlen - 1 - i] = qcodes[i] < 4 ? 3 - qcodes[i] : 4; }
+	for (int i = 0; i < qlen; ++i) { fw[i] = qcodes[i]; rc[qlen - 1 - i] = qcodes[i] < 4 ? 3 - qcodes[i] : 4; E.q_has_n |= qcodes[i] >= 4; }
 	E.qseq0[0] = fw; E.qseq0[1] = rc;
 	gen_simple_mat(E.mat, opt.a, opt.b, opt.sc_ambi);
 	const int n_a = squeeze_a(regs, a);

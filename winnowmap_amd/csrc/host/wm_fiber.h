@@ -35,13 +35,15 @@
 namespace wm {
 
 class Scheduler;
-struct Fiber { ucontext_t ctx; char *stack; std::function<void()> fn; bool done; Scheduler *owner; };
-enum { OP_SKETCH = 0, OP_SEED = 1, OP_CHAIN = 2, OP_KSW = 3, OP_N = 4 };
+struct Fiber { ucontext_t ctx; char *stack; std::function<void()> fn; bool done; Scheduler *owner; int pending; };   // pending: batches this fiber still waits for
+// OP_KSW_HEAVY: alignments whose single-wave run time is long (many rows x many lanes). They get their own queue so that the tail of a
+// batch of heavy jobs (tens of milliseconds for ONE alignment) never delays the bulk of short gap fills.
+enum { OP_SKETCH = 0, OP_SEED = 1, OP_CHAIN = 2, OP_KSW = 3, OP_KSW_HEAVY = 4, OP_N = 5 };
 inline double thread_cpu_s() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 inline double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct Hub {
-	Hub(DeviceOps *ops_, const wm_ksw_score_t &sc_, int w_, int k_) : ops(ops_), sc(sc_), w(w_), k(k_) { max_inflight = ops->max_inflight(); if (max_inflight < 1) max_inflight = 1; }
+	Hub(DeviceOps *ops_, const wm_ksw_score_t &sc_, int w_, int k_) : ops(ops_), sc(sc_), w(w_), k(k_) { max_inflight = ops->max_inflight(); if (max_inflight < 1) max_inflight = 1; read_env(); }
 	DeviceOps *ops;
 	wm_ksw_score_t sc;
 	int w, k;
@@ -49,15 +51,30 @@ struct Hub {
 	std::mutex mu;
 	std::condition_variable cv;
 	// published requests and the fibers waiting for them (taken whole by a dispatcher)
-	std::vector<SketchReq*> q_sketch; std::vector<SeedReq*> q_seed; std::vector<ChainReq*> q_chain; std::vector<KswReq*> q_ksw;
+	std::vector<SketchReq*> q_sketch; std::vector<SeedReq*> q_seed; std::vector<ChainReq*> q_chain; std::vector<KswReq*> q_ksw, q_kswh;
 	std::vector<Fiber*> waiters[OP_N];
-	int inflight = 0, inflight_op[OP_N] = {0, 0, 0, 0};
+	int inflight = 0, inflight_op[OP_N] = {0, 0, 0, 0, 0};
 	std::atomic<int64_t> live{0};           // fibers alive + reads not yet admitted, over all workers: 0 = the mapping call is finished
-	uint64_t n_batches[OP_N] = {0, 0, 0, 0}, n_reqs[OP_N] = {0, 0, 0, 0};
+	uint64_t n_batches[OP_N] = {0, 0, 0, 0, 0}, n_reqs[OP_N] = {0, 0, 0, 0, 0};
 	// where the host time goes (seconds, summed over the workers): CPU time running fibers, CPU and wall time inside the batched
 	// calls per operation, wall time asleep waiting for results
-	double cpu_fiber = 0, cpu_op[OP_N] = {0, 0, 0, 0}, wall_op[OP_N] = {0, 0, 0, 0}, wall_idle = 0;
-	size_t pending(int op) const { return op == OP_SKETCH ? q_sketch.size() : op == OP_SEED ? q_seed.size() : op == OP_CHAIN ? q_chain.size() : q_ksw.size(); }
+	double cpu_fiber = 0, cpu_op[OP_N] = {0, 0, 0, 0, 0}, wall_op[OP_N] = {0, 0, 0, 0, 0}, wall_idle = 0;
+	size_t pending(int op) const { return op == OP_SKETCH ? q_sketch.size() : op == OP_SEED ? q_seed.size() : op == OP_CHAIN ? q_chain.size() : op == OP_KSW ? q_ksw.size() : q_kswh.size(); }
+	// scheduling knobs (environment, read once per mapping call): a further concurrent batch of an operation that is already in flight is
+	// issued when at least min_more[op] requests are pending and fewer than max_op[op] batches of it are running
+	size_t min_more[OP_N] = { 4096, 4096, 4096, 24576, 2048 };
+	int max_op[OP_N] = { 2, 2, 2, 3, 2 };
+	long heavy_units = 8192;                // rows x 128-lane register pairs above which an alignment goes to the heavy queue (0 = no heavy queue)
+	void read_env()
+	{
+		static const char *nm[OP_N] = { "SKETCH", "SEED", "CHAIN", "KSW", "KSWH" };
+		for (int op = 0; op < OP_N; ++op) {
+			char key[64];
+			snprintf(key, sizeof(key), "WM_%s_MIN_MORE", nm[op]); if (getenv(key)) min_more[op] = (size_t)atol(getenv(key));
+			snprintf(key, sizeof(key), "WM_%s_MAX", nm[op]); if (getenv(key)) max_op[op] = atoi(getenv(key));
+		}
+		if (getenv("WM_KSW_HEAVY_UNITS")) heavy_units = atol(getenv("WM_KSW_HEAVY_UNITS"));
+	}
 };
 
 class Scheduler {
@@ -115,10 +132,29 @@ public:
 	}
 
 	// ---- called from inside a fiber ----
-	void sketch(SketchReq &r) { l_sketch_.push_back(&r); wait(OP_SKETCH); }
-	void seed(SeedReq &r) { l_seed_.push_back(&r); wait(OP_SEED); }
-	void chain(ChainReq &r) { l_chain_.push_back(&r); wait(OP_CHAIN); }
-	void ksw(std::vector<KswReq> &rs) { if (rs.empty()) return; for (KswReq &r : rs) l_ksw_.push_back(&r); wait(OP_KSW); }
+	void sketch(SketchReq &r) { l_sketch_.push_back(&r); wait(1 << OP_SKETCH); }
+	void seed(SeedReq &r) { l_seed_.push_back(&r); wait(1 << OP_SEED); }
+	void chain(ChainReq &r) { l_chain_.push_back(&r); wait(1 << OP_CHAIN); }
+	void ksw(std::vector<KswReq> &rs)
+	{
+		if (rs.empty()) return;
+		int ops = 0;
+		const long hu = hub_->heavy_units;
+		for (KswReq &r : rs) {
+			const bool heavy = hu > 0 && ksw_units(r) > hu;
+			(heavy ? l_kswh_ : l_ksw_).push_back(&r);
+			ops |= 1 << (heavy ? OP_KSW_HEAVY : OP_KSW);
+		}
+		wait(ops);
+	}
+	// serial work of one alignment on its wavefront: anti-diagonals x 128-lane register pairs of the band hull
+	static long ksw_units(const KswReq &r)
+	{
+		const long ql = (long)r.qlen(), tl = (long)r.tlen();
+		long w = r.w < 0 ? (ql > tl ? ql : tl) : r.w, n = ql < tl ? ql : tl;
+		if (n > w + 1) n = w + 1;
+		return (ql + tl) * ((n + 127) / 128 + 1);
+	}
 
 private:
 	static constexpr size_t kStack = 256 * 1024;
@@ -129,7 +165,13 @@ private:
 		f->fn();
 		f->done = true;                     // uc_link returns to the scheduler
 	}
-	void wait(int op) { Fiber *me = cur_; l_wait_[op].push_back(me); swapcontext(&me->ctx, &main_); }
+	void wait(int ops)                      // ops: bit set of the operations this fiber filed requests for
+	{
+		Fiber *me = cur_;
+		me->pending = 0;
+		for (int op = 0; op < OP_N; ++op) if (ops >> op & 1) { l_wait_[op].push_back(me); ++me->pending; }
+		swapcontext(&me->ctx, &main_);
+	}
 	void publish_locked()
 	{
 		Hub &H = *hub_;
@@ -138,23 +180,23 @@ private:
 		if (!l_seed_.empty()) { H.q_seed.insert(H.q_seed.end(), l_seed_.begin(), l_seed_.end()); l_seed_.clear(); any = true; }
 		if (!l_chain_.empty()) { H.q_chain.insert(H.q_chain.end(), l_chain_.begin(), l_chain_.end()); l_chain_.clear(); any = true; }
 		if (!l_ksw_.empty()) { H.q_ksw.insert(H.q_ksw.end(), l_ksw_.begin(), l_ksw_.end()); l_ksw_.clear(); any = true; }
+		if (!l_kswh_.empty()) { H.q_kswh.insert(H.q_kswh.end(), l_kswh_.begin(), l_kswh_.end()); l_kswh_.clear(); any = true; }
 		for (int op = 0; op < OP_N; ++op)
 			if (!l_wait_[op].empty()) { H.waiters[op].insert(H.waiters[op].end(), l_wait_[op].begin(), l_wait_[op].end()); l_wait_[op].clear(); }
 		if (any) H.cv.notify_all();          // somebody idle may want to dispatch what was just published
 	}
 	// which operation this idle worker should issue now (-1: none). An operation with nothing in flight goes first (keeps every stage
-	// of the path moving); a second concurrent batch of the same operation is only worth its fixed cost when the queue is large.
+	// of the path moving); a further concurrent batch of the same operation is only worth its fixed cost when the queue is large.
 	int pick_locked()
 	{
 		Hub &H = *hub_;
 		if (H.inflight >= H.max_inflight) return -1;
-		static const size_t big[OP_N] = { 4096, 4096, 4096, 65536 };
 		int best = -1;
 		for (int op = OP_N - 1; op >= 0; --op) {              // later stages first: finishing reads frees their memory and admits new ones
 			const size_t n = H.pending(op);
 			if (n == 0) continue;
 			if (H.inflight_op[op] == 0) return op;
-			if (n >= big[op] && best < 0) best = op;
+			if (n >= H.min_more[op] && H.inflight_op[op] < H.max_op[op] && best < 0) best = op;
 		}
 		return best;
 	}
@@ -166,7 +208,7 @@ private:
 		std::vector<SketchReq*> a; std::vector<SeedReq*> b; std::vector<ChainReq*> c; std::vector<KswReq*> d;
 		size_t n = 0;
 		if (op == OP_SKETCH) { a.swap(H.q_sketch); n = a.size(); } else if (op == OP_SEED) { b.swap(H.q_seed); n = b.size(); }
-		else if (op == OP_CHAIN) { c.swap(H.q_chain); n = c.size(); } else { d.swap(H.q_ksw); n = d.size(); }
+		else if (op == OP_CHAIN) { c.swap(H.q_chain); n = c.size(); } else if (op == OP_KSW) { d.swap(H.q_ksw); n = d.size(); } else { d.swap(H.q_kswh); n = d.size(); }
 		++H.inflight; ++H.inflight_op[op]; ++H.n_batches[op]; H.n_reqs[op] += n;
 		lk.unlock();
 		static const bool trace = getenv("WM_TRACE") != 0;
@@ -176,13 +218,14 @@ private:
 		else if (op == OP_SEED) H.ops->seed_batch(b);
 		else if (op == OP_CHAIN) H.ops->chain_batch(c);
 		else H.ops->ksw_batch(H.sc, d);
-		if (trace) fprintf(stderr, "[batch] worker %2d %s n=%zu %.1f ms\n", rank_, op == OP_SKETCH ? "sketch" : op == OP_SEED ? "seed" : op == OP_CHAIN ? "chain" : "ksw", n,
+		if (trace) fprintf(stderr, "[batch] worker %2d %s n=%zu %.1f ms\n", rank_, op == OP_SKETCH ? "sketch" : op == OP_SEED ? "seed" : op == OP_CHAIN ? "chain" : op == OP_KSW ? "ksw" : "ksw-heavy", n,
 		                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 		const double dc = thread_cpu_s() - c0, dw = wall_s() - w0;
 		lk.lock();
 		H.cpu_op[op] += dc; H.wall_op[op] += dw;
 		--H.inflight; --H.inflight_op[op];
-		for (Fiber *f : waiters) f->owner->inbox_.push_back(f);      // inboxes are protected by the hub mutex
+		for (Fiber *f : waiters)
+			if (--f->pending == 0) f->owner->inbox_.push_back(f);      // (counters and inboxes are protected by the hub mutex)
 		H.cv.notify_all();
 	}
 
@@ -194,7 +237,7 @@ private:
 	std::vector<Fiber*> pool_;
 	std::vector<char*> slabs_; int slab_left_ = 0;
 	std::vector<Fiber*> inbox_;             // fibers whose results arrived (filled by dispatchers under the hub mutex)
-	std::vector<SketchReq*> l_sketch_; std::vector<SeedReq*> l_seed_; std::vector<ChainReq*> l_chain_; std::vector<KswReq*> l_ksw_;
+	std::vector<SketchReq*> l_sketch_; std::vector<SeedReq*> l_seed_; std::vector<ChainReq*> l_chain_; std::vector<KswReq*> l_ksw_, l_kswh_;
 	std::vector<Fiber*> l_wait_[OP_N];
 };
 

@@ -167,6 +167,38 @@ int Index::getseq(uint32_t rid, uint32_t st, uint32_t en, uint8_t *out) const
 	return (int)(en - st);
 }
 
+void Index::scan_n_runs()
+{
+	n_runs.clear();
+	uint64_t run_b = 0; bool in_run = false;
+	const uint64_t n_words = (total_len + 7) / 8;
+	for (uint64_t wi = 0; wi < n_words && wi < S.size(); ++wi) {
+		const uint32_t wv = S[wi];
+		if (!(wv & 0xccccccccu)) {                         // eight codes < 4
+			if (in_run) { n_runs.emplace_back(run_b, wi * 8); in_run = false; }
+			continue;
+		}
+		for (int b = 0; b < 8; ++b) {
+			const uint64_t pos = wi * 8 + b;
+			if (pos >= total_len) break;
+			const bool isn = (wv >> (4 * b) & 0xf) >= 4;
+			if (isn && !in_run) { run_b = pos; in_run = true; }
+			else if (!isn && in_run) { n_runs.emplace_back(run_b, pos); in_run = false; }
+		}
+	}
+	if (in_run) n_runs.emplace_back(run_b, total_len);
+}
+
+bool Index::has_n(uint32_t rid, uint32_t st, uint32_t en) const
+{
+	if (n_runs.empty() || rid >= seq.size() || en <= st) return false;
+	const uint64_t b = seq[rid].offset + st, e = seq[rid].offset + en;
+	// first run that ends after b
+	size_t lo = 0, hi = n_runs.size();
+	while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (n_runs[mid].second <= b) lo = mid + 1; else hi = mid; }
+	return lo < n_runs.size() && n_runs[lo].first < e;
+}
+
 int index_build(const IdxOpt &io, const std::vector<std::string> &names, const std::vector<std::string> &seqs,
                 const std::string &kmer_file, int n_threads, Index &ix, std::string &err)
 {
@@ -229,6 +261,7 @@ int index_build(const IdxOpt &io, const std::vector<std::string> &names, const s
 // (key, position) records -> the flat table: grouped by minimizer key, positions ascending (src/index.c:200-252)
 void index_table_from_minimizers(Index &ix, std::vector<m128> &all)
 {
+	ix.scan_n_runs();                                      // (S is complete on every path that gets here)
 	ix.n_minimizers = all.size();
 	std::sort(all.begin(), all.end(), [](const m128 &a, const m128 &b) { return (a.x >> 8) != (b.x >> 8) ? (a.x >> 8) < (b.x >> 8) : a.y < b.y; });
 	size_t nk = 0;

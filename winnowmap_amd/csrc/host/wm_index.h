@@ -39,6 +39,11 @@ struct Index {
 
 	const uint64_t *get(uint64_t minier, int *n) const;            // mm_idx_get, src/index.c:88
 	int getseq(uint32_t rid, uint32_t st, uint32_t en, uint8_t *out) const;   // mm_idx_getseq, src/index.c:161
+	// runs of ambiguous bases (codes >= 4) in S as [begin, end) global base offsets, ascending: lets the aligner pick the kernel
+	// variant without scanning the operands (a contig of plain ACGT answers in O(1))
+	std::vector<std::pair<uint64_t, uint64_t>> n_runs;
+	void scan_n_runs();
+	bool has_n(uint32_t rid, uint32_t st, uint32_t en) const;
 	static uint64_t slot_of(uint64_t key, int hbits) { return (key * 0x9E3779B97F4A7C15ULL) >> (64 - hbits); }
 };
 

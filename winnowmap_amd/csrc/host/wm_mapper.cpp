@@ -27,7 +27,7 @@ inline uint32_t read_hash(const char *qname, int qlen, int seed)
 }
 
 // chaining + region generation + alignment + MAPQ on a given sorted anchor set (src/map.c:375-430 and :880-933)
-void chain_and_align(Scheduler &sch, const Index &idx, const MapOpt &o, float gap_scale, const uint8_t *codes, int qlen, uint32_t hash,
+void chain_and_align(Scheduler &sch, const Index &idx, const MapOpt &o, float gap_scale, const uint8_t *codes, int64_t dev_off, int qlen, uint32_t hash,
                      std::vector<m128> &&anchors, int rep_len, Segment &out, int *frag_gap)
 {
 	const int max_gap_qry = o.max_gap;
@@ -55,7 +55,7 @@ void chain_and_align(Scheduler &sch, const Index &idx, const MapOpt &o, float ga
 	}
 	// align_regs (src/map.c:267-277)
 	if (o.flag & F_CIGAR) {
-		align_skeleton(sch, o, idx, qlen, codes, out.regs, out.a.data());
+		align_skeleton(sch, o, idx, qlen, codes, dev_off, out.regs, out.a.data());
 		if (!(o.flag & F_ALL_CHAINS)) {
 			set_parent(o.mask_level, o.mask_len, out.regs, o.a * 2 + o.b, (o.flag & F_HARD_MLEVEL) != 0);
 			select_sub(o.pri_ratio, idx.k * 2, o.best_n, out.regs);
@@ -66,9 +66,9 @@ void chain_and_align(Scheduler &sch, const Index &idx, const MapOpt &o, float ga
 }
 
 // sketch → seed: collect_minimizers + collect_seed_hits (src/map.c:69-84, 222-254)
-void sketch_and_seed(Scheduler &sch, const MapOpt &o, const uint8_t *codes, int len, std::vector<m128> &anchors, int *rep_len)
+void sketch_and_seed(Scheduler &sch, const MapOpt &o, const uint8_t *codes, int64_t dev_off, int len, std::vector<m128> &anchors, int *rep_len)
 {
-	SketchReq sk; sk.seq = codes; sk.len = len;
+	SketchReq sk; sk.seq = codes; sk.len = len; sk.dev_off = dev_off;
 	sch.sketch(sk);
 	SeedReq sd; sd.mini = sk.mini.data(); sd.n_mini = (int)sk.mini.size(); sd.qlen = len; sd.max_occ = o.mid_occ; sd.flag = o.flag;
 	if (sd.n_mini > 0) sch.seed(sd);
@@ -79,7 +79,8 @@ void sketch_and_seed(Scheduler &sch, const MapOpt &o, const uint8_t *codes, int 
 struct ReadTask {
 	const ReadIn *in = 0;
 	ReadOut *out = 0;
-	std::vector<uint8_t> codes;
+	const uint8_t *codes = 0;                    // 0..4 codes of the read (inside the mini-batch's code buffer)
+	int64_t dev_off = -1;                        // where they live on the device (DeviceOps::load_reads), -1 = not resident
 	int qlen = 0;
 	std::vector<std::vector<m128>> collect;     // MCAS anchors per suffix position (collect_a, src/map.c:296)
 	std::vector<uint8_t> mapped;                 // seqMapped, src/map.c:310
@@ -99,8 +100,9 @@ void stage1_position(Scheduler &sch, const Index &idx, const MapOpt &opt, const 
 			Segment S;
 			std::vector<m128> anchors;
 			int rep_len = 0;
-			sketch_and_seed(sch, o2, T.codes.data() + start, sub_len, anchors, &rep_len);
-			chain_and_align(sch, idx, o2, opt.chain_gap_scale, T.codes.data() + start, sub_len, read_hash(qname, sub_len, o2.seed), std::move(anchors), rep_len, S, 0);
+			const int64_t dev = T.dev_off >= 0 ? T.dev_off + start : -1;
+			sketch_and_seed(sch, o2, T.codes + start, dev, sub_len, anchors, &rep_len);
+			chain_and_align(sch, idx, o2, opt.chain_gap_scale, T.codes + start, dev, sub_len, read_hash(qname, sub_len, o2.seed), std::move(anchors), rep_len, S, 0);
 			for (const Reg &r : S.regs) {
 				if ((int)r.mapq >= o2.min_mapq && r.blen >= o2.min_qcov * sub_len && r.cnt > 0) {
 					found = true;
@@ -147,20 +149,20 @@ void stage2(Scheduler &sch, const Index &idx, const MapOpt &opt, ReadTask &T)
 	size_t unmapped = 0;
 	for (int i = 0; i < L; ++i) unmapped += T.mapped[i] == 0;
 	if (!a.empty() && unmapped > 0) {                                  // seeds from the stretches stage 1 left unmapped (:786-846)
-		std::vector<uint8_t> masked(T.codes);
+		std::vector<uint8_t> masked(T.codes, T.codes + L);
 		for (int i = 0; i < L; ++i) if (T.mapped[i]) masked[i] = 4;
 		std::vector<m128> rest;
-		sketch_and_seed(sch, o3, masked.data(), L, rest, &rep_len);
+		sketch_and_seed(sch, o3, masked.data(), -1, L, rest, &rep_len);             // (a masked copy: not resident)
 		a.insert(a.end(), rest.begin(), rest.end());
 		radix_sort_128x(a.data(), a.data() + a.size());
 	}
 	if (a.empty()) {                                                   // plain minimap2-style mapping with the user's options (:849-865)
 		o3 = opt;
-		sketch_and_seed(sch, o3, T.codes.data(), L, a, &rep_len);
+		sketch_and_seed(sch, o3, T.codes, T.dev_off, L, a, &rep_len);
 	}
 	Segment S;
 	int frag_gap = 0;
-	chain_and_align(sch, idx, o3, opt.chain_gap_scale, T.codes.data(), L, hash, std::move(a), rep_len, S, &frag_gap);
+	chain_and_align(sch, idx, o3, opt.chain_gap_scale, T.codes, T.dev_off, L, hash, std::move(a), rep_len, S, &frag_gap);
 	T.out->regs = std::move(S.regs);
 	T.out->rep_len = rep_len;
 	T.out->frag_gap = frag_gap;
@@ -174,9 +176,6 @@ struct Worker;
 // `on_done` runs (inside the last fiber of the read) when the read is finished.
 bool spawn_read(Scheduler &sch, const Index &idx, const MapOpt &opt, const MapOpt &o2, ReadTask &T, std::function<void()> on_done)
 {
-	{ WM_PROF("map.encode_read");
-	T.codes.resize(T.qlen);
-	for (int j = 0; j < T.qlen; ++j) T.codes[j] = nt4_table[(uint8_t)T.in->seq[j]]; }
 	if (T.qlen == 0) return false;
 	if (opt.max_qlen > 0 && T.qlen > opt.max_qlen) return false;
 	const int off = o2.suffixSampleOffset;
@@ -189,7 +188,7 @@ bool spawn_read(Scheduler &sch, const Index &idx, const MapOpt &opt, const MapOp
 	auto finish = [sp, ip, op, tp, on_done]() {
 		stage2(*sp, *ip, *op, *tp);
 		// the read is done: drop its scratch (the window keeps thousands of reads in flight)
-		std::vector<uint8_t>().swap(tp->codes); std::vector<std::vector<m128>>().swap(tp->collect); std::vector<uint8_t>().swap(tp->mapped);
+		std::vector<std::vector<m128>>().swap(tp->collect); std::vector<uint8_t>().swap(tp->mapped);
 		on_done();
 	};
 	if (o2.SVaware && T.qlen >= o2.SVawareMinReadLength) {
@@ -221,8 +220,23 @@ void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::v
 	MapOpt o2 = opt;                                                   // stage-1 options (src/map.c:300-302)
 	o2.best_n = std::max(5, o2.best_n);
 	std::vector<ReadTask> tasks(reads.size());
-	for (size_t i = 0; i < reads.size(); ++i) { tasks[i].in = &reads[i]; tasks[i].out = &out[i]; tasks[i].qlen = (int)reads[i].seq.size(); }
-	const int T = n_threads < 1 ? 1 : n_threads;
+	// n_threads = host cores to use. Workers inside a batched device call sleep, so up to max_inflight() more workers keep the cores busy
+	const int extra = getenv("WM_EXTRA_WORKERS") ? atoi(getenv("WM_EXTRA_WORKERS")) : (ops->waits_asleep() && n_threads > 1 ? ops->max_inflight() : 0);
+	const int T = (n_threads < 1 ? 1 : n_threads) + (extra > 0 ? extra : 0);
+	// the 0..4 codes of the whole mini-batch, back to back (seq_nt4_table, src/sketch.c:19-36): encoded once, handed to the device once
+	std::vector<uint64_t> code_off(reads.size() + 1, 0);
+	for (size_t i = 0; i < reads.size(); ++i) code_off[i + 1] = code_off[i] + reads[i].seq.size();
+	std::unique_ptr<uint8_t[]> codes_all(new uint8_t[code_off[reads.size()] + 1]);
+	parallel_for(T, reads.size(), [&](size_t i) {
+		uint8_t *d = codes_all.get() + code_off[i];
+		const std::string &s = reads[i].seq;
+		for (size_t j = 0; j < s.size(); ++j) d[j] = nt4_table[(uint8_t)s[j]];
+	});
+	const bool resident = ops->load_reads(codes_all.get(), (size_t)code_off[reads.size()]);
+	for (size_t i = 0; i < reads.size(); ++i) {
+		tasks[i].in = &reads[i]; tasks[i].out = &out[i]; tasks[i].qlen = (int)reads[i].seq.size();
+		tasks[i].codes = codes_all.get() + code_off[i]; tasks[i].dev_off = resident ? (int64_t)code_off[i] : -1;
+	}
 	// reads in flight over all workers (WM_INFLIGHT): large enough for full device batches at every stage, small enough that the
 	// stages overlap instead of running in lock-step phases
 	const long inflight_env = getenv("WM_INFLIGHT") ? atol(getenv("WM_INFLIGHT")) : 0;
@@ -258,10 +272,13 @@ void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::v
 	work(0);
 	for (auto &x : th) x.join();
 	if (stats) {
-		stats->n_flush += hub.n_batches[OP_SKETCH] + hub.n_batches[OP_SEED] + hub.n_batches[OP_CHAIN] + hub.n_batches[OP_KSW];
-		stats->n_ksw += hub.n_reqs[OP_KSW]; stats->n_chain += hub.n_reqs[OP_CHAIN]; stats->n_seed += hub.n_reqs[OP_SEED]; stats->n_sketch += hub.n_reqs[OP_SKETCH];
+		stats->n_flush += hub.n_batches[OP_SKETCH] + hub.n_batches[OP_SEED] + hub.n_batches[OP_CHAIN] + hub.n_batches[OP_KSW] + hub.n_batches[OP_KSW_HEAVY];
+		stats->n_ksw += hub.n_reqs[OP_KSW] + hub.n_reqs[OP_KSW_HEAVY]; stats->n_chain += hub.n_reqs[OP_CHAIN]; stats->n_seed += hub.n_reqs[OP_SEED]; stats->n_sketch += hub.n_reqs[OP_SKETCH];
 		stats->cpu_fiber += hub.cpu_fiber; stats->wall_idle += hub.wall_idle;
-		for (int op = 0; op < OP_N; ++op) { stats->n_batches[op] += hub.n_batches[op]; stats->cpu_op[op] += hub.cpu_op[op]; stats->wall_op[op] += hub.wall_op[op]; }
+		for (int op = 0; op < OP_N; ++op) {           // (the heavy alignment queue is reported with the ksw operation)
+			const int o = op == OP_KSW_HEAVY ? OP_KSW : op;
+			stats->n_batches[o] += hub.n_batches[op]; stats->cpu_op[o] += hub.cpu_op[op]; stats->wall_op[o] += hub.wall_op[op];
+		}
 	}
 }
 

@@ -7,8 +7,13 @@
 
 namespace wm {
 
+// Sequences the mapper hands to the device exist twice: as host views (plain pointers to 0..4 codes, used by the host-side judge /
+// finish code and by checker-backed implementations) and as POSITIONS in data the device already holds — the codes of the whole
+// mini-batch, uploaded once by DeviceOps::load_reads, and the packed reference uploaded with the index — so that a device
+// implementation never has to copy, pack or ship a sequence per request. dev_off < 0: the sequence is not resident (use the view).
 struct SketchReq {                 // mm_sketch of one (sub)sequence of 0..4 codes, rid = 0
 	const uint8_t *seq = 0; int len = 0;
+	int64_t dev_off = -1;          // offset of seq[0] in the resident read codes
 	std::vector<m128> mini;        // out
 };
 
@@ -26,10 +31,24 @@ struct ChainReq {                  // mm_chain_dp (src/chain.c:22); consumes `a`
 };
 
 struct KswReq {                    // ksw_extd2_sse (src/ksw2.h:60)
-	std::vector<uint8_t> q, t;
+	// host views: element i of the query is qp[i * step], of the target tp[i * step]; step = -1 for the left extension, which aligns
+	// both sequences reversed (src/align.c:690-705). Valid while the request is pending.
+	const uint8_t *qp = 0, *tp = 0;
+	int32_t ql = 0, tl = 0, step = 1;
+	// the same operands as positions in resident data. Query: index q_pos of the TWO-STRAND SPACE of the (sub)read that starts at
+	// qwin_off and is qwin_len long — [0, L) forward strand, [L, 2L) reverse complement, negative = N padding; this is the layout of the
+	// reference's qseq0 buffer (src/align.c:871-877), including the few bases in front of a strand that mm_align1_inv may touch.
+	// Target: base t_pos of contig rid. has_n: an operand may contain an ambiguous base (conservative).
+	int64_t qwin_off = -1; int32_t qwin_len = 0, q_pos = 0, rid = -1, t_pos = 0;
+	bool has_n = true;
 	int w = 0, zdrop = 0, end_bonus = 0, flag = 0;
 	wm_ksw_result_t ez;            // out
 	std::vector<uint32_t> cigar;   // out
+	int qlen() const { return ql; }
+	int tlen() const { return tl; }
+	bool resident() const { return qwin_off >= 0 && rid >= 0; }
+	void copy_query(uint8_t *dst) const { for (int i = 0; i < ql; ++i) dst[i] = qp[(ptrdiff_t)i * step]; }
+	void copy_target(uint8_t *dst) const { for (int i = 0; i < tl; ++i) dst[i] = tp[(ptrdiff_t)i * step]; }
 };
 
 // The batch calls are synchronous (they return when the results are in the requests) and must be callable from several threads at
@@ -37,6 +56,11 @@ struct KswReq {                    // ksw_extd2_sse (src/ksw2.h:60)
 struct DeviceOps {
 	virtual ~DeviceOps() {}
 	virtual int max_inflight() const { return 1; }
+	// true if a thread inside a batched call mostly sleeps (waiting for the device): the mapper then runs that many workers more than cores
+	virtual bool waits_asleep() const { return false; }
+	// the 0..4 codes of every read of the mini-batch, back to back (SketchReq::dev_off / KswReq::qwin_off index this buffer). Returns
+	// true if the implementation keeps them resident; false = requests must be served from their host views.
+	virtual bool load_reads(const uint8_t *codes, size_t n) { (void)codes; (void)n; return false; }
 	virtual void sketch_batch(int w, int k, std::vector<SketchReq*> &reqs) = 0;
 	virtual void seed_batch(std::vector<SeedReq*> &reqs) = 0;
 	virtual void chain_batch(std::vector<ChainReq*> &reqs) = 0;

@@ -120,6 +120,29 @@ __global__ __launch_bounds__(64 * NWV) void ksw_multi_kernel(wm_ksw_score_t sc, 
 		wmk::ksw_dp_multi<WM_KSW_MULTI_B, NWV, true, true>(sc, jb, seqs + jb.q_off, seqs + jb.t_off, tb, lds, res + j);
 }
 
+// operands of position jobs (wm_ksw_batch_pos): expand query and target of job blockIdx.x into the batch's sequence slab. Query = two-strand
+// space of a (sub)read of the resident read codes (src/align.c:871-877), target = 4-bit packed reference (mm_idx_getseq, src/index.c:161-171).
+__global__ __launch_bounds__(64) void ksw_expand_kernel(const wm_ksw_djob_t *__restrict__ jobs, const wm_ksw_dsrc_t *__restrict__ src,
+                                                         const uint8_t *__restrict__ reads, const uint32_t *__restrict__ S, uint8_t *__restrict__ seqs)
+{
+	const int j = blockIdx.x;
+	const wm_ksw_djob_t jb = jobs[j];
+	const wm_ksw_dsrc_t sr = src[j];
+	const int64_t L = sr.qwin_len;
+	uint8_t *q = seqs + jb.q_off, *t = seqs + jb.t_off;
+	for (int i = threadIdx.x; i < jb.qlen; i += 64) {
+		const int64_t p = (int64_t)sr.q_pos + (int64_t)i * sr.step;
+		uint8_t c = 4;
+		if (p >= 0 && p < L) c = reads[sr.qwin_off + p];
+		else if (p >= L && p < 2 * L) { c = reads[sr.qwin_off + (2 * L - 1 - p)]; c = c < 4 ? 3 - c : 4; }
+		q[i] = c;
+	}
+	for (int i = threadIdx.x; i < jb.tlen; i += 64) {
+		const int64_t p = sr.t_base + (int64_t)i * sr.step;
+		t[i] = (uint8_t)(S[p >> 3] >> ((p & 7) << 2) & 0xf);
+	}
+}
+
 // one thread per alignment: walk the traceback, write run-length ops (backtrack order) into the job's slot
 __global__ __launch_bounds__(64) void ksw_backtrack_kernel(int n, const wm_ksw_djob_t *__restrict__ jobs, const uint8_t *__restrict__ tb,
                                                             wm_ksw_dres_t *__restrict__ res, uint32_t *__restrict__ cig_scratch, int *__restrict__ err)
@@ -198,6 +221,9 @@ struct wm_ctx_s {
 	// flat index in HBM (wm_index_upload)
 	uint64_t *d_hkey, *d_hval, *d_P;
 	uint8_t *d_bloom;
+	uint32_t *d_S;                              // packed reference (4 bits per base), for position jobs
+	std::vector<uint64_t> seq_off; std::vector<uint32_t> seq_len;       // contig table of the uploaded index (bounds of position jobs)
+	uint8_t *d_reads; size_t reads_bytes, reads_cap; bool owns_reads;   // 0..4 codes of the current mini-batch (wm_reads_upload)
 	int hbits;
 	wm_sketch_params_t skp;
 	bool have_index, owns_index;
@@ -226,6 +252,7 @@ struct wm_ksw_dev_batch_s {
 	wm_ksw_score_t sc;
 	std::vector<wm_ksw_djob_t> jobs;            // host copy
 	std::vector<int> order[WM_KSW_NCLASS];      // job indices per class, largest first
+	std::vector<int> ord;                       // the classes' orders back to back (what the device sees)
 	std::vector<int> degenerate;                // jobs the reference returns from early (src/ksw2_extd2_sse.c:68,92)
 	// device pointers (inside the arena)
 	uint8_t *d_gscratch; uint64_t *d_goff; std::vector<uint64_t> goff;
@@ -236,19 +263,28 @@ struct wm_ksw_dev_batch_s {
 	uint64_t class_cells[WM_KSW_NCLASS];
 	float dp_ms, bt_ms;
 	uint32_t total_ops;
+	int h_err;
 };
 
 extern "C" const char *wm_last_error(void) { return g_err; }
 
-// wait for everything queued on the context's stream. hipStreamSynchronize spin-waits (it burns a host core — and the container's CPU quota —
-// for as long as the kernels run); a blocking-sync event puts the thread to sleep instead. WM_SPIN_SYNC=1 restores the spinning wait (A/B).
+// wait for everything queued on the context's stream WITHOUT burning a host core: hipStreamSynchronize — and, on the GPU boxes, also
+// hipEventSynchronize on a blocking-sync event (thread CPU time == wall time inside the batched calls, profiles/r02c_bench_hub.json) —
+// spin for as long as the kernels run, and the container's CPU quota is the scarce resource. So: record an event, poll it, sleep in
+// between (50 us doubling to 1 ms; the batches take tens of milliseconds). WM_SPIN_SYNC=1 restores hipStreamSynchronize (A/B).
 static hipError_t ctx_sync(wm_ctx_s *c)
 {
 	static const bool spin = getenv("WM_SPIN_SYNC") != 0;
 	if (spin) return hipStreamSynchronize(c->stream);
 	hipError_t e = hipEventRecord(c->sync_ev, c->stream);
 	if (e != hipSuccess) return e;
-	return hipEventSynchronize(c->sync_ev);
+	int us = 50;
+	for (;;) {
+		e = hipEventQuery(c->sync_ev);
+		if (e != hipErrorNotReady) return e;
+		std::this_thread::sleep_for(std::chrono::microseconds(us));
+		if (us < 1000) us *= 2;
+	}
 }
 
 extern "C" int wm_device_count(void)
@@ -281,6 +317,7 @@ extern "C" int wm_ctx_create(int device, size_t arena_bytes, wm_ctx_t **out)
 	for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
 	HIPCHK(hipEventCreateWithFlags(&c->sync_ev, hipEventBlockingSync | hipEventDisableTiming));
 	c->arena_used = 0; c->last_ms = 0; c->aux_ms = 0; c->host_threads = 1; c->pin = 0; c->pin_bytes = c->pin_used = 0; c->have_index = false; c->owns_index = false; c->d_hkey = c->d_hval = c->d_P = 0; c->d_bloom = 0;
+	c->d_S = 0; c->d_reads = 0; c->reads_bytes = c->reads_cap = 0; c->owns_reads = false;
 	*out = c;
 	return WM_OK;
 }
@@ -298,7 +335,8 @@ extern "C" void wm_ctx_destroy(wm_ctx_t *c)
 	for (int i = 0; i < 5; ++i) hipEventDestroy(c->kev[i]);
 	for (int k = 0; k < WM_KSW_NCLASS; ++k) { hipEventDestroy(c->cev[k][0]); hipEventDestroy(c->cev[k][1]); }
 	hipFree(c->arena);
-	if (c->have_index && c->owns_index) { hipFree(c->d_hkey); hipFree(c->d_hval); hipFree(c->d_P); hipFree(c->d_bloom); }
+	if (c->have_index && c->owns_index) { hipFree(c->d_hkey); hipFree(c->d_hval); hipFree(c->d_P); hipFree(c->d_bloom); hipFree(c->d_S); }
+	if (c->d_reads && c->owns_reads) hipFree(c->d_reads);
 	delete c;
 }
 
@@ -330,8 +368,10 @@ template <int BP> static void launch_dpp(int variant, int n, hipStream_t s, cons
 	}
 }
 
-extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs, const wm_ksw_job_t *jobs,
-                                  const uint8_t *seqs, size_t seqs_bytes, wm_ksw_dev_batch_t **out)
+// Plans one batch: kernel class, traceback pitch and arena offsets per job; uploads the job table and the operands. Operands are either
+// bytes (`jobs` + `seqs`: only the part of `seqs` the jobs refer to is uploaded) or positions in resident data (`pos`: expanded in HBM).
+static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs, const wm_ksw_job_t *jobs, const uint8_t *seqs, size_t seqs_bytes,
+                            const wm_ksw_pos_t *pos, wm_ksw_dev_batch_t **out)
 {
 	*out = 0;
 	if (!c) return set_err(WM_EINVAL, "null context");
@@ -339,12 +379,49 @@ extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int 
 	wm_ksw_score_t sc = *sc_in;
 	if (!wm_ksw_score_ok(&sc)) return set_err(WM_EINVAL, "unsupported scoring parameters (need match>0, mismatch<0, sc_ambi<=0, q,e,q2>0, e2>=0, (q+e)+(q2+e2)<=127 as src/options.c:166-176)");
 	if (sc.q2 + sc.e2 < sc.q + sc.e) { int8_t t = sc.q; sc.q = sc.q2; sc.q2 = t; t = sc.e; sc.e = sc.e2; sc.e2 = t; }   // src/ksw2_extd2_sse.c:70
+	if (pos && (!c->d_S || c->seq_len.empty())) return set_err(WM_EINVAL, "position jobs need wm_index_upload on this context");
+	if (pos && !c->d_reads) return set_err(WM_EINVAL, "position jobs need wm_reads_upload on this context");
 	HIPCHK(hipSetDevice(c->device));
 	wm_ksw_dev_batch_t *b = new wm_ksw_dev_batch_t();
-	b->n_jobs = n_jobs; b->sc = sc; b->cells = b->tb_bytes = 0; b->dp_ms = b->bt_ms = 0; b->total_ops = 0;
+	b->n_jobs = n_jobs; b->sc = sc; b->cells = b->tb_bytes = 0; b->dp_ms = b->bt_ms = 0; b->total_ops = 0; b->h_err = 0;
 	memset(b->class_cells, 0, sizeof(b->class_cells));
 	b->arena_mark = c->arena_used;
 	b->jobs.resize(n_jobs);
+	// where the operands go in the device slab: position jobs are laid out back to back; byte jobs keep their offsets, rebased to the
+	// lowest one so that only [lo, hi) of the caller's buffer travels
+	std::vector<wm_ksw_dsrc_t> dsrc(pos ? n_jobs : 0);
+	size_t slab_lo = 0, slab_bytes = 0;
+	int bad0 = -1;
+	if (pos) {
+		uint64_t tot = 0;
+		for (int i = 0; i < n_jobs; ++i) {
+			const wm_ksw_pos_t &s = pos[i];
+			wm_ksw_djob_t &d = b->jobs[i];
+			const uint64_t ql = s.qlen > 0 ? s.qlen : 0, tl = s.tlen > 0 ? s.tlen : 0;
+			d.q_off = (uint32_t)tot; d.t_off = (uint32_t)(tot + ql);
+			tot += ql + tl;
+			if (ql == 0 || tl == 0) continue;                                  // degenerate: never read
+			const int64_t t_last = (int64_t)s.t_pos + (int64_t)(s.tlen - 1) * s.step;
+			if ((s.step != 1 && s.step != -1) || s.rid < 0 || (size_t)s.rid >= c->seq_len.size() || s.t_pos < 0 || t_last < 0 ||
+			    (uint32_t)s.t_pos >= c->seq_len[s.rid] || (uint64_t)t_last >= c->seq_len[s.rid] ||
+			    s.qwin_off < 0 || s.qwin_len < 0 || (uint64_t)s.qwin_off + (uint64_t)s.qwin_len > c->reads_bytes) { if (bad0 < 0) bad0 = i; continue; }
+			dsrc[i].qwin_off = s.qwin_off; dsrc[i].qwin_len = s.qwin_len; dsrc[i].q_pos = s.q_pos; dsrc[i].step = s.step; dsrc[i].pad = 0;
+			dsrc[i].t_base = (int64_t)c->seq_off[s.rid] + s.t_pos;
+		}
+		if (tot >= ((uint64_t)1 << 32)) { delete b; return set_err(WM_ENOMEM, "batch holds %.1f GB of sequence (limit 4 GB per batch)", tot / 1073741824.0); }
+		slab_bytes = (size_t)tot;
+	} else {
+		size_t lo = seqs_bytes, hi = 0;
+		for (int i = 0; i < n_jobs; ++i) {
+			const wm_ksw_job_t &s = jobs[i];
+			if (s.qlen <= 0 || s.tlen <= 0) continue;
+			if ((size_t)s.q_off + s.qlen > seqs_bytes || (size_t)s.t_off + s.tlen > seqs_bytes) { if (bad0 < 0) bad0 = i; continue; }
+			lo = std::min(lo, (size_t)std::min(s.q_off, s.t_off));
+			hi = std::max(hi, std::max((size_t)s.q_off + s.qlen, (size_t)s.t_off + s.tlen));
+		}
+		if (hi > lo) { slab_lo = lo; slab_bytes = hi - lo; }
+	}
+	if (bad0 >= 0) { delete b; return set_err(WM_EINVAL, pos ? "job %d: operand positions outside the resident reads / reference" : "job %d: sequence offsets outside seqs", bad0); }
 	// the reference returns before doing anything when a mismatch can never be seen (:92)
 	const int n_sc = sc.sc_ambi == 0 ? -sc.e2 : sc.sc_ambi;
 	int min_sc = sc.mismatch < n_sc ? sc.mismatch : n_sc;
@@ -352,35 +429,36 @@ extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int 
 	const bool never = -min_sc > 2 * (sc.q + sc.e);
 	uint64_t tb_off = 0, cig_off = 0;
 	std::vector<uint64_t> cells(n_jobs, 0), bands(n_jobs, 0);
-	std::atomic<int> bad(-1), bad_kind(0);
-	wm::parallel_for(c->host_threads, (size_t)n_jobs, [&](size_t i) {          // per-job classification (scans both sequences for N)
-		const wm_ksw_job_t &s = jobs[i];
+	std::atomic<int> bad(-1);
+	wm::parallel_for(c->host_threads, (size_t)n_jobs, [&](size_t i) {          // per-job classification (byte jobs: scans both sequences for N)
 		wm_ksw_djob_t &d = b->jobs[i];
+		int32_t qlen, tlen, w, zdrop, end_bonus, flag;
+		uint32_t q_off = d.q_off, t_off = d.t_off;
+		if (pos) { const wm_ksw_pos_t &s = pos[i]; qlen = s.qlen; tlen = s.tlen; w = s.w; zdrop = s.zdrop; end_bonus = s.end_bonus; flag = s.flag; }
+		else { const wm_ksw_job_t &s = jobs[i]; qlen = s.qlen; tlen = s.tlen; w = s.w; zdrop = s.zdrop; end_bonus = s.end_bonus; flag = s.flag; q_off = s.q_off; t_off = s.t_off; }
 		memset(&d, 0, sizeof(d));
-		d.q_off = s.q_off; d.t_off = s.t_off; d.qlen = s.qlen; d.tlen = s.tlen;
-		d.w = s.w; d.zdrop = s.zdrop; d.end_bonus = s.end_bonus; d.flag = s.flag;
-		if (s.flag & (0x01 | 0x04 | 0x10 | 0x100 | 0x200 | 0x400)) { bad = (int)i; bad_kind = 1; d.klass = -1; return; }
-		if (s.qlen <= 0 || s.tlen <= 0 || never) { d.klass = -1; return; }                                                 // :68,:92
-		if ((size_t)s.q_off + s.qlen > seqs_bytes || (size_t)s.t_off + s.tlen > seqs_bytes) { bad = (int)i; bad_kind = 2; d.klass = -1; return; }
+		d.qlen = qlen; d.tlen = tlen; d.w = w; d.zdrop = zdrop; d.end_bonus = end_bonus; d.flag = flag;
+		if (flag & (0x01 | 0x04 | 0x10 | 0x100 | 0x200 | 0x400)) { bad = (int)i; d.klass = -1; return; }
+		if (qlen <= 0 || tlen <= 0 || never) { d.klass = -1; return; }                                                 // :68,:92
+		const int has_n = pos ? (pos[i].has_n != 0) : (wm_ksw_has_n(seqs + q_off, qlen) | wm_ksw_has_n(seqs + t_off, tlen));
+		d.q_off = pos ? q_off : (uint32_t)(q_off - slab_lo); d.t_off = pos ? t_off : (uint32_t)(t_off - slab_lo);
 		int n_col;
-		d.klass = wm_ksw_classify(s.qlen, s.tlen, s.w, wm_ksw_has_n(seqs + s.q_off, s.qlen) | wm_ksw_has_n(seqs + s.t_off, s.tlen), s.flag, &n_col);
+		d.klass = wm_ksw_classify(qlen, tlen, w, has_n, flag, &n_col);
 		d.n_col = n_col;
-		cells[i] = wm_ksw_cells(s.qlen, s.tlen, s.w, &bands[i]);
+		cells[i] = wm_ksw_cells(qlen, tlen, w, &bands[i]);
 	});
 	if (bad >= 0) {
-		const int i = bad, kind = bad_kind;
+		const int i = bad;
 		delete b;
-		return kind == 1 ? set_err(WM_EINVAL, "job %d: KSW_EZ_SCORE_ONLY/GENERIC_SC/APPROX_DROP/SPLICE flags are not used by the mapper (src/align.c) and not supported", i)
-		                 : set_err(WM_EINVAL, "job %d: sequence offsets outside seqs", i);
+		return set_err(WM_EINVAL, "job %d: KSW_EZ_SCORE_ONLY/GENERIC_SC/APPROX_DROP/SPLICE flags are not used by the mapper (src/align.c) and not supported", i);
 	}
 	for (int i = 0; i < n_jobs; ++i) {
-		const wm_ksw_job_t &s = jobs[i];
 		wm_ksw_djob_t &d = b->jobs[i];
 		if (d.klass < 0) { b->degenerate.push_back(i); continue; }
 		d.tb_off = tb_off;
-		const uint64_t rows = (uint64_t)s.qlen + s.tlen - 1;
+		const uint64_t rows = (uint64_t)d.qlen + d.tlen - 1;
 		tb_off += (rows * d.n_col + 15) & ~(uint64_t)15;
-		d.cig_off = (uint32_t)cig_off; d.cig_cap = s.qlen + s.tlen + 2;
+		d.cig_off = (uint32_t)cig_off; d.cig_cap = d.qlen + d.tlen + 2;
 		cig_off += d.cig_cap;
 		b->cells += bands[i]; b->tb_bytes += cells[i];
 		b->class_cells[d.klass] += bands[i];
@@ -397,10 +475,10 @@ extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int 
 			int cnt[130];
 			memset(cnt, 0, sizeof(cnt));
 			for (int j : o) ++cnt[size_key(j)];
-			int pos[130], acc = 0;
-			for (int kk = 129; kk >= 0; --kk) { pos[kk] = acc; acc += cnt[kk]; }      // descending keys
+			int pos_[130], acc = 0;
+			for (int kk = 129; kk >= 0; --kk) { pos_[kk] = acc; acc += cnt[kk]; }      // descending keys
 			tmp.resize(o.size());
-			for (int j : o) tmp[pos[size_key(j)]++] = j;
+			for (int j : o) tmp[pos_[size_key(j)]++] = j;
 			o.swap(tmp);
 		}
 	}
@@ -412,7 +490,8 @@ extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int 
 	b->d_off = (uint32_t*)arena_take(c, nj * 4 + 64);
 	b->d_total = (uint32_t*)arena_take(c, 64);
 	b->d_err = (int*)arena_take(c, 64);
-	b->d_seqs = (uint8_t*)arena_take(c, seqs_bytes + 64);
+	b->d_seqs = (uint8_t*)arena_take(c, slab_bytes + 64);
+	wm_ksw_dsrc_t *d_src = pos ? (wm_ksw_dsrc_t*)arena_take(c, nj * sizeof(wm_ksw_dsrc_t)) : 0;
 	b->d_cig = (uint32_t*)arena_take(c, (cig_off + 16) * 4);
 	b->pool_cap = cig_off + 16;
 	b->d_pool = (uint32_t*)arena_take(c, b->pool_cap * 4);
@@ -429,21 +508,50 @@ extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int 
 		b->d_b3off = (uint64_t*)arena_take(c, b->b3off.size() * 8 + 64);
 		if (!b->d_b3state || !b->d_b3off) b->d_tb = 0;
 	}
-	if (!b->d_jobs || !b->d_order || !b->d_res || !b->d_off || !b->d_total || !b->d_err || !b->d_seqs || !b->d_cig || !b->d_pool || !b->d_tb) {
+	if (!b->d_jobs || !b->d_order || !b->d_res || !b->d_off || !b->d_total || !b->d_err || !b->d_seqs || (pos && !d_src) || !b->d_cig || !b->d_pool || !b->d_tb) {
 		c->arena_used = b->arena_mark;
 		delete b;
-		return set_err(WM_ENOMEM, "batch needs %.1f MB of traceback + buffers; arena is %.1f MB", (tb_off + cig_off * 8 + seqs_bytes) / 1048576.0, c->arena_bytes / 1048576.0);
+		return set_err(WM_ENOMEM, "batch needs %.1f MB of traceback + buffers; arena is %.1f MB", (tb_off + cig_off * 8 + slab_bytes) / 1048576.0, c->arena_bytes / 1048576.0);
 	}
-	std::vector<int> ord;
-	ord.reserve(nj);
-	for (int k = 0; k < WM_KSW_NCLASS; ++k) ord.insert(ord.end(), b->order[k].begin(), b->order[k].end());
+	b->ord.clear();
+	b->ord.reserve(nj);
+	for (int k = 0; k < WM_KSW_NCLASS; ++k) b->ord.insert(b->ord.end(), b->order[k].begin(), b->order[k].end());
 	HIPCHK(hipMemcpyAsync(b->d_jobs, b->jobs.data(), n_jobs * sizeof(wm_ksw_djob_t), hipMemcpyHostToDevice, c->stream));
-	if (!ord.empty()) HIPCHK(hipMemcpyAsync(b->d_order, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-	HIPCHK(hipMemcpyAsync(b->d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream));
+	if (!b->ord.empty()) HIPCHK(hipMemcpyAsync(b->d_order, b->ord.data(), b->ord.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+	if (pos) {
+		if (n_jobs > 0) {
+			HIPCHK(hipMemcpyAsync(d_src, dsrc.data(), (size_t)n_jobs * sizeof(wm_ksw_dsrc_t), hipMemcpyHostToDevice, c->stream));
+			hipLaunchKernelGGL(ksw_expand_kernel, dim3(n_jobs), dim3(64), 0, c->stream, b->d_jobs, d_src, c->d_reads, c->d_S, b->d_seqs);
+		}
+	} else if (slab_bytes) HIPCHK(hipMemcpyAsync(b->d_seqs, seqs + slab_lo, slab_bytes, hipMemcpyHostToDevice, c->stream));
 	if (!b->goff.empty()) HIPCHK(hipMemcpyAsync(b->d_goff, b->goff.data(), b->goff.size() * 8, hipMemcpyHostToDevice, c->stream));
 	if (!b->b3off.empty()) HIPCHK(hipMemcpyAsync(b->d_b3off, b->b3off.data(), b->b3off.size() * 8, hipMemcpyHostToDevice, c->stream));
-	HIPCHK(ctx_sync(c));
+	HIPCHK(ctx_sync(c));             // (the host tables above are read by the copies until here)
 	*out = b;
+	return WM_OK;
+}
+
+extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs, const wm_ksw_job_t *jobs,
+                                  const uint8_t *seqs, size_t seqs_bytes, wm_ksw_dev_batch_t **out)
+{
+	return ksw_prepare_impl(c, sc_in, n_jobs, jobs, seqs, seqs_bytes, 0, out);
+}
+
+extern "C" int wm_reads_upload(wm_ctx_t *c, const uint8_t *codes, size_t n)
+{
+	if (!c || (n && !codes)) return set_err(WM_EINVAL, "null argument");
+	HIPCHK(hipSetDevice(c->device));
+	if (!c->owns_reads) { c->d_reads = 0; c->reads_cap = 0; }
+	if (n + 64 > c->reads_cap) {
+		if (c->d_reads) HIPCHK(hipFree(c->d_reads));
+		c->d_reads = 0; c->reads_cap = 0;
+		const size_t cap = n + n / 8 + (1 << 20);
+		HIPCHK(hipMalloc((void**)&c->d_reads, cap));
+		c->reads_cap = cap;
+	}
+	c->owns_reads = true;
+	if (n) HIPCHK(hipMemcpy(c->d_reads, codes, n, hipMemcpyHostToDevice));
+	c->reads_bytes = n;
 	return WM_OK;
 }
 
@@ -473,12 +581,13 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	// the size classes are independent: spread them over the side streams so that one class's long jobs overlap the others
 	int n_nonempty = 0, used_mask = 0, rr = 0;
 	for (int k = 0; k < WM_KSW_NCLASS; ++k) n_nonempty += !b->order[k].empty();
-	const bool fan = n_nonempty > 1 && !trace_k;
+	static const int n_side = std::max(0, std::min(4, getenv("WM_SIDE_STREAMS") ? atoi(getenv("WM_SIDE_STREAMS")) : 3));   // contexts x (1 + side streams) should not exceed the hardware queues
+	const bool fan = n_nonempty > 1 && !trace_k && n_side > 0;
 	if (fan) HIPCHK(hipEventRecord(c->kev[4], c->stream));
 	hipStream_t ks = c->stream;
 	auto next_stream = [&]() {
 		if (!fan) return;
-		const int si = rr++ & 3;
+		const int si = rr++ % n_side;
 		ks = c->kstream[si];
 		if (!(used_mask >> si & 1)) { hipStreamWaitEvent(ks, c->kev[4], 0); used_mask |= 1 << si; }
 	};
@@ -535,6 +644,8 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	hipLaunchKernelGGL(ksw_gather_kernel, dim3(n), dim3(64), 0, c->stream, b->d_jobs, b->d_res, b->d_off, b->d_cig, b->d_pool, (uint32_t)b->pool_cap);
 	HIPCHK(hipEventRecord(c->ev[2], c->stream));
 	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(&b->h_err, b->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(&b->total_ops, b->d_total, 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(ctx_sync(c));
 	HIPCHK(hipEventElapsedTime(&b->dp_ms, c->ev[0], c->ev[1]));
 	HIPCHK(hipEventElapsedTime(&b->bt_ms, c->ev[1], c->ev[2]));
@@ -544,10 +655,7 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 			float ms = 0;
 			if (hipEventElapsedTime(&ms, c->cev[k][0], c->cev[k][1]) == hipSuccess) { c->k_ms[k] += ms; c->k_cells[k] += b->class_cells[k]; c->k_launches[k] += 1; }
 		}
-	int err = 0;
-	HIPCHK(hipMemcpy(&err, b->d_err, 4, hipMemcpyDeviceToHost));
-	HIPCHK(hipMemcpy(&b->total_ops, b->d_total, 4, hipMemcpyDeviceToHost));
-	if (err) return set_err(WM_EINTERNAL, "cigar slot overflow in backtrack");
+	if (b->h_err) return set_err(WM_EINTERNAL, "cigar slot overflow in backtrack");
 	return WM_OK;
 }
 
@@ -557,18 +665,19 @@ extern "C" int wm_ksw_dev_fetch(wm_ctx_t *c, wm_ksw_dev_batch_t *b, wm_ksw_resul
 	const int n = b->n_jobs;
 	if (cigar_used) *cigar_used = b->total_ops;
 	if (n == 0) return WM_OK;
-	std::vector<wm_ksw_dres_t> res(n);
-	std::vector<uint32_t> off(n);
-	HIPCHK(hipMemcpy(res.data(), b->d_res, n * sizeof(wm_ksw_dres_t), hipMemcpyDeviceToHost));
-	HIPCHK(hipMemcpy(off.data(), b->d_off, n * 4, hipMemcpyDeviceToHost));
+	UBuf<wm_ksw_dres_t> res(n, c);
+	UBuf<uint32_t> off(n, c);
+	if (b->total_ops > cigar_cap) return set_err(WM_ENOMEM, "cigar_pool too small: need %u ops", b->total_ops);
+	HIPCHK(hipMemcpyAsync(res.data(), b->d_res, n * sizeof(wm_ksw_dres_t), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(off.data(), b->d_off, n * 4, hipMemcpyDeviceToHost, c->stream));
+	if (b->total_ops) HIPCHK(hipMemcpyAsync(cigar_pool, b->d_pool, (size_t)b->total_ops * 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(ctx_sync(c));
 	for (int i = 0; i < n; ++i) {
 		wm_ksw_result_t &o = results[i];
 		const wm_ksw_dres_t &r = res[i];
 		o.max = r.max; o.zdropped = r.zdropped; o.max_q = r.max_q; o.max_t = r.max_t; o.mqe = r.mqe; o.mqe_t = r.mqe_t;
 		o.mte = r.mte; o.mte_q = r.mte_q; o.score = r.score; o.reach_end = r.reach_end; o.n_cigar = r.n_cigar; o.cig_off = off[i];
 	}
-	if (b->total_ops > cigar_cap) return set_err(WM_ENOMEM, "cigar_pool too small: need %u ops", b->total_ops);
-	if (b->total_ops) HIPCHK(hipMemcpy(cigar_pool, b->d_pool, (size_t)b->total_ops * 4, hipMemcpyDeviceToHost));
 	return WM_OK;
 }
 
@@ -588,10 +697,10 @@ extern "C" void wm_ksw_dev_free(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	delete b;
 }
 
-extern "C" int wm_ksw_batch(wm_ctx_t *c, const wm_ksw_score_t *sc, int n_jobs, const wm_ksw_job_t *jobs, const uint8_t *seqs, size_t seqs_bytes,
-                            wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used)
+static int ksw_batch_impl(wm_ctx_t *c, const wm_ksw_score_t *sc, int n_jobs, const wm_ksw_job_t *jobs, const uint8_t *seqs, size_t seqs_bytes, const wm_ksw_pos_t *pos,
+                          wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used)
 {
-	// process in chunks whose traceback fits the arena
+	// process in chunks whose traceback (and operands) fit the arena
 	if (!c) return set_err(WM_EINVAL, "null context");
 	size_t used = 0;
 	int i0 = 0;
@@ -599,17 +708,17 @@ extern "C" int wm_ksw_batch(wm_ctx_t *c, const wm_ksw_score_t *sc, int n_jobs, c
 	const size_t budget = (size_t)(c->arena_bytes * 0.8);
 	while (i0 < n_jobs || (n_jobs == 0 && i0 == 0)) {
 		int i1 = i0;
-		size_t need = seqs_bytes;
+		size_t need = 0;
 		while (i1 < n_jobs) {
-			const wm_ksw_job_t &s = jobs[i1];
-			size_t t = 0;
-			if (s.qlen > 0 && s.tlen > 0) t = ((size_t)s.qlen + s.tlen) * ((size_t)wm_ksw_ncol(s.qlen, s.tlen, s.w) + 8) + 256;
+			const int ql = pos ? pos[i1].qlen : jobs[i1].qlen, tl = pos ? pos[i1].tlen : jobs[i1].tlen, w = pos ? pos[i1].w : jobs[i1].w;
+			size_t t = 128;
+			if (ql > 0 && tl > 0) t = ((size_t)ql + tl) * ((size_t)wm_ksw_ncol(ql, tl, w) + 10) + 512;
 			if (i1 > i0 && need + t > budget) break;
 			need += t; ++i1;
 		}
 		wm_ksw_dev_batch_t *b = 0;
 		const double ta = now_ms();
-		int rc = wm_ksw_dev_prepare(c, sc, i1 - i0, jobs + i0, seqs, seqs_bytes, &b);
+		int rc = ksw_prepare_impl(c, sc, i1 - i0, pos ? 0 : jobs + i0, seqs, seqs_bytes, pos ? pos + i0 : 0, &b);
 		if (rc) return rc;
 		const double tb_ = now_ms();
 		rc = wm_ksw_dev_run(c, b);
@@ -627,6 +736,19 @@ extern "C" int wm_ksw_batch(wm_ctx_t *c, const wm_ksw_score_t *sc, int n_jobs, c
 	if (cigar_used) *cigar_used = used;
 	c->last_ms = kms;
 	return WM_OK;
+}
+
+extern "C" int wm_ksw_batch(wm_ctx_t *c, const wm_ksw_score_t *sc, int n_jobs, const wm_ksw_job_t *jobs, const uint8_t *seqs, size_t seqs_bytes,
+                            wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used)
+{
+	return ksw_batch_impl(c, sc, n_jobs, jobs, seqs, seqs_bytes, 0, results, cigar_pool, cigar_cap, cigar_used);
+}
+
+extern "C" int wm_ksw_batch_pos(wm_ctx_t *c, const wm_ksw_score_t *sc, int n_jobs, const wm_ksw_pos_t *jobs,
+                                wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used)
+{
+	if (n_jobs > 0 && !jobs) return set_err(WM_EINVAL, "null jobs");
+	return ksw_batch_impl(c, sc, n_jobs, 0, 0, 0, jobs, results, cigar_pool, cigar_cap, cigar_used);
 }
 
 extern "C" int wm_ksw_extd2(wm_ctx_t *c, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
@@ -779,6 +901,7 @@ extern "C" int wm_index_import(const uint64_t *sizes9, const uint32_t *S, const 
 	ix.n_minimizers = ix.P.size();
 	ix.n_keys = 0;
 	for (uint64_t kk : ix.hkey) ix.n_keys += kk != ~0ULL;
+	ix.scan_n_runs();
 	*out = h;
 	return WM_OK;
 }
@@ -794,12 +917,16 @@ extern "C" int wm_index_upload(wm_ctx_t *c, const wm_index_t *h)
 	HIPCHK(hipSetDevice(c->device));
 	const wm::Index &ix = h->ix;
 	if (ix.bloom.table_bits >= ((uint64_t)1 << 32)) return set_err(WM_EINVAL, "bloom table of %llu bits not supported on device", (unsigned long long)ix.bloom.table_bits);
-	if (c->have_index && c->owns_index) { hipFree(c->d_hkey); hipFree(c->d_hval); hipFree(c->d_P); hipFree(c->d_bloom); }
-	c->have_index = false;
+	if (c->have_index && c->owns_index) { hipFree(c->d_hkey); hipFree(c->d_hval); hipFree(c->d_P); hipFree(c->d_bloom); hipFree(c->d_S); }
+	c->have_index = false; c->d_S = 0; c->seq_off.clear(); c->seq_len.clear();
 	HIPCHK(hipMalloc((void**)&c->d_hkey, ix.hkey.size() * 8 + 8));
 	HIPCHK(hipMalloc((void**)&c->d_hval, ix.hval.size() * 8 + 8));
 	HIPCHK(hipMalloc((void**)&c->d_P, ix.P.size() * 8 + 8));
 	HIPCHK(hipMalloc((void**)&c->d_bloom, ix.bloom.bits.size() + 8));
+	HIPCHK(hipMalloc((void**)&c->d_S, ix.S.size() * 4 + 8));
+	HIPCHK(hipMemcpy(c->d_S, ix.S.data(), ix.S.size() * 4, hipMemcpyHostToDevice));
+	c->seq_off.clear(); c->seq_len.clear();
+	for (const wm::RefSeq &r : ix.seq) { c->seq_off.push_back(r.offset); c->seq_len.push_back(r.len); }
 	HIPCHK(hipMemcpy(c->d_hkey, ix.hkey.data(), ix.hkey.size() * 8, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(c->d_hval, ix.hval.data(), ix.hval.size() * 8, hipMemcpyHostToDevice));
 	if (!ix.P.empty()) HIPCHK(hipMemcpy(c->d_P, ix.P.data(), ix.P.size() * 8, hipMemcpyHostToDevice));
@@ -812,8 +939,16 @@ extern "C" int wm_index_upload(wm_ctx_t *c, const wm_index_t *h)
 
 struct ArenaMark { wm_ctx_t *c; size_t m; ArenaMark(wm_ctx_t *c_) : c(c_), m(c_->arena_used) {} ~ArenaMark() { c->arena_used = m; } };
 
+// resident (optional, n flags): sequence i starts at code seq_off[i] of the resident read codes (wm_reads_upload) instead of `seqs`
+static int sketch_batch_impl(wm_ctx_t *c, int n, const uint8_t *seqs, size_t seqs_bytes, const uint64_t *seq_off, const int32_t *len, const uint8_t *resident,
+                             wm128_t *out, size_t out_cap, uint64_t *out_off, int32_t *counts);
 extern "C" int wm_sketch_batch(wm_ctx_t *c, int n, const uint8_t *seqs, size_t seqs_bytes, const uint64_t *seq_off, const int32_t *len,
                                wm128_t *out, size_t out_cap, uint64_t *out_off, int32_t *counts)
+{
+	return sketch_batch_impl(c, n, seqs, seqs_bytes, seq_off, len, 0, out, out_cap, out_off, counts);
+}
+static int sketch_batch_impl(wm_ctx_t *c, int n, const uint8_t *seqs, size_t seqs_bytes, const uint64_t *seq_off, const int32_t *len, const uint8_t *resident,
+                             wm128_t *out, size_t out_cap, uint64_t *out_off, int32_t *counts)
 {
 	if (!c || !c->have_index) return set_err(WM_EINVAL, "wm_index_upload has not been called on this context");
 	if (n <= 0) return WM_OK;
@@ -832,19 +967,23 @@ extern "C" int wm_sketch_batch(wm_ctx_t *c, int n, const uint8_t *seqs, size_t s
 		ArenaMark mark(c);
 		std::vector<wm_sketch_job_t> jb(todo.size());
 		uint64_t tot = 0;
+		wm_sketch_job_t *d_jobs = (wm_sketch_job_t*)arena_take(c, jb.size() * sizeof(wm_sketch_job_t));
+		uint8_t *d_seqs = (uint8_t*)arena_take(c, seqs_bytes + 64);
+		// one base pointer for the kernel (the staged slab); resident sequences are addressed relative to it
+		const uint64_t res_delta = resident && d_seqs ? (uint64_t)((uintptr_t)c->d_reads - (uintptr_t)d_seqs) : 0;
 		for (size_t t = 0; t < todo.size(); ++t) {
 			const int i = todo[t];
-			jb[t].seq_off = seq_off[i]; jb[t].len = len[i];
+			const bool res = resident && resident[i];
+			if (res ? (seq_off[i] + (uint64_t)len[i] > c->reads_bytes || !c->d_reads) : (seq_off[i] + (uint64_t)len[i] > seqs_bytes)) return set_err(WM_EINVAL, "sequence %d outside its buffer", i);
+			jb[t].seq_off = res ? res_delta + seq_off[i] : seq_off[i]; jb[t].len = len[i];
 			jb[t].cap = round == 0 ? len[i] / 8 + 16 : len[i] + 1;
 			jb[t].out_off = tot; tot += jb[t].cap;
 		}
-		wm_sketch_job_t *d_jobs = (wm_sketch_job_t*)arena_take(c, jb.size() * sizeof(wm_sketch_job_t));
-		uint8_t *d_seqs = (uint8_t*)arena_take(c, seqs_bytes + 64);
 		wm128_t *d_out = (wm128_t*)arena_take(c, (tot + 1) * sizeof(wm128_t));
 		int *d_cnt = (int*)arena_take(c, jb.size() * 4 + 64);
 		if (!d_jobs || !d_seqs || !d_out || !d_cnt) return set_err(WM_ENOMEM, "sketch batch does not fit the arena");
 		HIPCHK(hipMemcpyAsync(d_jobs, jb.data(), jb.size() * sizeof(wm_sketch_job_t), hipMemcpyHostToDevice, c->stream));
-		HIPCHK(hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream));
+		if (seqs_bytes) HIPCHK(hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream));
 		HIPCHK(hipEventRecord(c->ev[0], c->stream));
 		hipLaunchKernelGGL(sketch_kernel, dim3(((int)jb.size() + 63) / 64), dim3(64), lds, c->stream, c->skp, d_jobs, (int)jb.size(), d_seqs, c->d_bloom, d_out, d_cnt);
 		HIPCHK(hipEventRecord(c->ev[1], c->stream));
@@ -1048,31 +1187,37 @@ struct GpuOpsCtx {
 	double t_pack = 0, t_prep = 0, t_run = 0, t_fetch = 0, t_unpack = 0, t_sketch = 0, t_seed = 0, t_chain = 0;
 	std::string error;
 	void fail(const char *what) { if (error.empty()) error = std::string(what) + ": " + g_err; }
+	bool resident = false;                      // the mini-batch's read codes are on the device (load_reads)
 	void sketch_batch(int, int, std::vector<wm::SketchReq*> &reqs)
 	{
 		const int n = (int)reqs.size();
 		std::vector<uint64_t> off(n), ooff(n);
 		std::vector<int32_t> len(n), cnt(n);
-		size_t tot = 0;
-		for (int i = 0; i < n; ++i) { off[i] = tot; len[i] = reqs[i]->len; tot += reqs[i]->len; }
+		std::vector<uint8_t> res(n, 0);
+		size_t tot = 0, tot_all = 0;                // bytes to stage (sequences that are not resident); all bases
+		for (int i = 0; i < n; ++i) {
+			len[i] = reqs[i]->len; tot_all += reqs[i]->len;
+			if (resident && reqs[i]->dev_off >= 0) { res[i] = 1; off[i] = (uint64_t)reqs[i]->dev_off; }
+			else { off[i] = tot; tot += reqs[i]->len; }
+		}
 		UBuf<uint8_t> seqs(tot + 1, c);
-		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { memcpy(seqs.data() + off[i], reqs[i]->seq, reqs[i]->len); });
-		UBuf<wm128_t> out(tot / 8 + (size_t)17 * n + 64, c);          // wm_sketch_batch tries len/8 + 16 slots per sequence first
+		for (int i = 0; i < n; ++i) if (!res[i]) memcpy(seqs.data() + off[i], reqs[i]->seq, reqs[i]->len);
+		UBuf<wm128_t> out(tot_all / 8 + (size_t)17 * n + 64, c);          // the batch tries len/8 + 16 slots per sequence first
 		const double ts = now_ms();
-		int rc = wm_sketch_batch(c, n, seqs.data(), tot, off.data(), len.data(), out.data(), out.size(), ooff.data(), cnt.data());
+		int rc = sketch_batch_impl(c, n, seqs.data(), tot, off.data(), len.data(), res.data(), out.data(), out.size(), ooff.data(), cnt.data());
 		if (rc == WM_ENOMEM && strstr(g_err, "minimizer output pool")) {   // pathological density: redo with one slot per base
-			UBuf<wm128_t> big(tot + n + 1);
-			rc = wm_sketch_batch(c, n, seqs.data(), tot, off.data(), len.data(), big.data(), big.size(), ooff.data(), cnt.data());
+			UBuf<wm128_t> big(tot_all + n + 1);
+			rc = sketch_batch_impl(c, n, seqs.data(), tot, off.data(), len.data(), res.data(), big.data(), big.size(), ooff.data(), cnt.data());
 			if (rc) { fail("sketch"); return; }
 			t_sketch += now_ms() - ts;
 			aux_us += c->aux_ms * 1e3;
-			wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { reqs[i]->mini.assign(big.begin() + ooff[i], big.begin() + ooff[i] + cnt[i]); });
+			for (int i = 0; i < n; ++i) reqs[i]->mini.assign(big.begin() + ooff[i], big.begin() + ooff[i] + cnt[i]);
 			return;
 		}
 		if (rc) { fail("sketch"); return; }
 		t_sketch += now_ms() - ts;
 		aux_us += c->aux_ms * 1e3;
-		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { reqs[i]->mini.assign(out.begin() + ooff[i], out.begin() + ooff[i] + cnt[i]); });
+		for (int i = 0; i < n; ++i) reqs[i]->mini.assign(out.begin() + ooff[i], out.begin() + ooff[i] + cnt[i]);
 	}
 	void seed_batch(std::vector<wm::SeedReq*> &reqs)
 	{
@@ -1126,35 +1271,48 @@ struct GpuOpsCtx {
 	{
 		const double t0 = now_ms();
 		const int n = (int)reqs.size();
-		std::vector<wm_ksw_job_t> jobs(n);
-		size_t tot = 0, cap = 16;
-		for (int i = 0; i < n; ++i) {
-			wm::KswReq &r = *reqs[i];
-			jobs[i].q_off = (uint32_t)tot; tot += r.q.size();
-			jobs[i].t_off = (uint32_t)tot; tot += r.t.size();
-			jobs[i].qlen = (int)r.q.size(); jobs[i].tlen = (int)r.t.size();
-			jobs[i].w = r.w; jobs[i].zdrop = r.zdrop; jobs[i].end_bonus = r.end_bonus; jobs[i].flag = r.flag;
-			cap += r.q.size() + r.t.size() + 2;
-		}
-		if (tot >= ((size_t)1 << 32)) { error = "ksw batch exceeds 4 GB of sequence"; return; }
-		UBuf<uint8_t> seqs(tot + 1, c);
-		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
-			memcpy(seqs.data() + jobs[i].q_off, reqs[i]->q.data(), reqs[i]->q.size());
-			memcpy(seqs.data() + jobs[i].t_off, reqs[i]->t.data(), reqs[i]->t.size());
-		});
+		size_t cap = 16;
+		bool all_res = resident;
+		for (int i = 0; i < n && all_res; ++i) all_res = reqs[i]->resident();
+		for (int i = 0; i < n; ++i) cap += (size_t)reqs[i]->ql + reqs[i]->tl + 2;
 		std::vector<wm_ksw_result_t> res(n);
 		UBuf<uint32_t> pool(cap, c);
 		size_t used = 0;
-		const double t1 = now_ms();
 		c->acc_cells = 0; c->t_prep = c->t_run = c->t_fetch = 0;
-		if (wm_ksw_batch(c, &sc, n, jobs.data(), seqs.data(), tot, res.data(), pool.data(), cap, &used)) { fail("ksw"); return; }
+		double t1;
+		if (all_res) {          // operands as positions in the resident reads / packed reference: nothing is copied or shipped per alignment
+			UBuf<wm_ksw_pos_t> jobs(n + 1, c);
+			for (int i = 0; i < n; ++i) {
+				const wm::KswReq &r = *reqs[i];
+				wm_ksw_pos_t &j = jobs[i];
+				j.qwin_off = r.qwin_off; j.qwin_len = r.qwin_len; j.q_pos = r.q_pos; j.rid = r.rid; j.t_pos = r.t_pos; j.qlen = r.ql; j.tlen = r.tl;
+				j.w = r.w; j.zdrop = r.zdrop; j.end_bonus = r.end_bonus; j.flag = r.flag; j.step = (int8_t)r.step; j.has_n = r.has_n; memset(j.pad, 0, sizeof(j.pad));
+			}
+			t1 = now_ms();
+			if (wm_ksw_batch_pos(c, &sc, n, jobs.data(), res.data(), pool.data(), cap, &used)) { fail("ksw"); return; }
+		} else {                // host views -> one byte slab
+			std::vector<wm_ksw_job_t> jobs(n);
+			size_t tot = 0;
+			for (int i = 0; i < n; ++i) {
+				wm::KswReq &r = *reqs[i];
+				jobs[i].q_off = (uint32_t)tot; tot += (size_t)r.ql;
+				jobs[i].t_off = (uint32_t)tot; tot += (size_t)r.tl;
+				jobs[i].qlen = r.ql; jobs[i].tlen = r.tl;
+				jobs[i].w = r.w; jobs[i].zdrop = r.zdrop; jobs[i].end_bonus = r.end_bonus; jobs[i].flag = r.flag;
+			}
+			if (tot >= ((size_t)1 << 32)) { error = "ksw batch exceeds 4 GB of sequence"; return; }
+			UBuf<uint8_t> seqs(tot + 1, c);
+			wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { reqs[i]->copy_query(seqs.data() + jobs[i].q_off); reqs[i]->copy_target(seqs.data() + jobs[i].t_off); });
+			t1 = now_ms();
+			if (wm_ksw_batch(c, &sc, n, jobs.data(), seqs.data(), tot, res.data(), pool.data(), cap, &used)) { fail("ksw"); return; }
+		}
 		const double t2 = now_ms();
 		ksw_us += c->last_ms * 1e3;
 		cells += c->acc_cells;
-		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
+		for (int i = 0; i < n; ++i) {
 			reqs[i]->ez = res[i];
 			reqs[i]->cigar.assign(pool.begin() + res[i].cig_off, pool.begin() + res[i].cig_off + res[i].n_cigar);
-		});
+		}
 		t_pack += t1 - t0; t_unpack += now_ms() - t2; t_prep += c->t_prep; t_run += c->t_run; t_fetch += c->t_fetch;
 	}
 };
@@ -1169,6 +1327,21 @@ struct GpuOps : wm::DeviceOps {
 	std::condition_variable cv;
 	void init(const std::vector<wm_ctx_t*> &cs) { ctxs.resize(cs.size()); for (size_t i = 0; i < cs.size(); ++i) { ctxs[i].c = cs[i]; free_.push_back((int)i); } }
 	int max_inflight() const override { return (int)ctxs.size(); }
+	bool waits_asleep() const override { return getenv("WM_SPIN_SYNC") == 0; }
+	// the mini-batch's read codes go to the device once (the first context owns the buffer, the others alias it: one device)
+	bool load_reads(const uint8_t *codes, size_t n) override
+	{
+		const bool off = getenv("WM_NO_RESIDENT") != 0;            // A/B switch: per-request staging as before
+		if (off || ctxs.empty()) return false;
+		wm_ctx_t *c0 = ctxs[0].c;
+		if (wm_reads_upload(c0, codes, n)) { ctxs[0].fail("reads upload"); return false; }
+		for (size_t i = 0; i < ctxs.size(); ++i) {
+			wm_ctx_t *c = ctxs[i].c;
+			if (i) { if (c->owns_reads && c->d_reads) hipFree(c->d_reads); c->d_reads = c0->d_reads; c->reads_bytes = c0->reads_bytes; c->reads_cap = 0; c->owns_reads = false; }
+			ctxs[i].resident = true;
+		}
+		return true;
+	}
 	template <class F> void with(F f)
 	{
 		int i;
@@ -1221,7 +1394,7 @@ extern "C" int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena
 	if (n_threads < 1) return set_err(WM_EINVAL, "n_threads < 1");
 	for (wm_ctx_t *w : m->workers) wm_ctx_destroy(w);
 	m->workers.clear();
-	int C = getenv("WM_CONTEXTS") ? atoi(getenv("WM_CONTEXTS")) : (getenv("WM_GROUPS") ? atoi(getenv("WM_GROUPS")) : (n_threads >= 8 ? 4 : n_threads >= 2 ? 2 : 1));
+	int C = getenv("WM_CONTEXTS") ? atoi(getenv("WM_CONTEXTS")) : (getenv("WM_GROUPS") ? atoi(getenv("WM_GROUPS")) : (n_threads >= 8 ? 6 : n_threads >= 2 ? 2 : 1));
 	if (C < 1) C = 1;
 	m->n_threads = n_threads;
 	const int bt = getenv("WM_BATCH_THREADS") ? atoi(getenv("WM_BATCH_THREADS")) : 1;     // extra threads a batched call may spawn for its own packing
@@ -1231,6 +1404,7 @@ extern "C" int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena
 		const int rc = wm_ctx_create(m->c->device, arena_bytes_per_context ? arena_bytes_per_context : m->c->arena_bytes, &w);
 		if (rc) return rc;
 		w->d_hkey = m->c->d_hkey; w->d_hval = m->c->d_hval; w->d_P = m->c->d_P; w->d_bloom = m->c->d_bloom; w->hbits = m->c->hbits; w->skp = m->c->skp;
+		w->d_S = m->c->d_S; w->seq_off = m->c->seq_off; w->seq_len = m->c->seq_len;
 		w->have_index = true; w->owns_index = false;
 		w->host_threads = m->c->host_threads;
 		m->workers.push_back(w);

@@ -15,6 +15,14 @@ typedef struct {
 	int32_t cig_cap;
 } wm_ksw_djob_t;
 
+// where the operands of a device job come from when they are expanded inside HBM (wm_ksw_batch_pos): parallel to the job table
+typedef struct {
+	int64_t qwin_off;     // first code of the (sub)read in the resident read codes
+	int64_t t_base;       // global base index into the packed reference S of target element 0
+	int32_t qwin_len, q_pos;
+	int32_t step, pad;
+} wm_ksw_dsrc_t;
+
 typedef struct {
 	int32_t max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, reach_end;
 	int32_t n_cigar;

@@ -23,6 +23,10 @@ KSW_RES_DTYPE = np.dtype([("max", np.int32), ("zdropped", np.int32), ("max_q", n
                           ("mqe", np.int32), ("mqe_t", np.int32), ("mte", np.int32), ("mte_q", np.int32),
                           ("score", np.int32), ("reach_end", np.int32), ("n_cigar", np.int32), ("cig_off", np.uint32)])
 
+KSW_POS_DTYPE = np.dtype([("qwin_off", np.int64), ("qwin_len", np.int32), ("q_pos", np.int32), ("rid", np.int32), ("t_pos", np.int32),
+                          ("qlen", np.int32), ("tlen", np.int32), ("w", np.int32), ("zdrop", np.int32), ("end_bonus", np.int32), ("flag", np.int32),
+                          ("step", np.int8), ("has_n", np.int8), ("pad", np.int8, (6,))])      # wm_ksw_pos_t
+
 _lib = None
 
 
@@ -82,6 +86,24 @@ class Context:
         used = C.c_size_t(0)
         _chk(lib().wm_ksw_batch(self._h, C.byref(score), len(jobs), jobs.ctypes.data, seqs.ctypes.data, seqs.nbytes,
                                 res.ctypes.data, pool.ctypes.data, cap, C.byref(used)))
+        return res, pool[:used.value]
+
+    def reads_upload(self, codes):
+        """0..4 codes of the current mini-batch, kept resident for position jobs (wm_reads_upload)"""
+        codes = np.ascontiguousarray(codes, np.uint8)
+        lib().wm_reads_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        _chk(lib().wm_reads_upload(self._h, codes.ctypes.data, codes.nbytes))
+
+    def ksw_batch_pos(self, score, jobs):
+        """jobs: structured array KSW_POS_DTYPE (operands as positions in the resident reads / packed reference, wm_ksw_batch_pos)"""
+        jobs = np.ascontiguousarray(jobs, KSW_POS_DTYPE)
+        assert KSW_POS_DTYPE.itemsize == 56
+        res = np.zeros(len(jobs), KSW_RES_DTYPE)
+        cap = int((np.maximum(jobs["qlen"], 0).astype(np.int64) + np.maximum(jobs["tlen"], 0) + 2).sum()) + 16
+        pool = np.zeros(cap, np.uint32)
+        used = C.c_size_t(0)
+        lib().wm_ksw_batch_pos.argtypes = [C.c_void_p, C.POINTER(KswScore), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        _chk(lib().wm_ksw_batch_pos(self._h, C.byref(score), len(jobs), jobs.ctypes.data, res.ctypes.data, pool.ctypes.data, cap, C.byref(used)))
         return res, pool[:used.value]
 
     def ksw_prepare(self, score, jobs, seqs):

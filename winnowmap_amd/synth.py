@@ -6,8 +6,8 @@ threshold, README.md:29-30 / ext/meryl/src/meryl/merylOp-nextMer.C:103-115) that
 Pure numpy; no reference code involved."""
 import numpy as np
 
-_ACGT = np.frombuffer(b"ACGT", np.uint8)
-_COMP = np.array([3, 2, 1, 0], np.uint8)
+_ACGT = np.frombuffer(b"ACGTN", np.uint8)          # code 4 = ambiguous base
+_COMP = np.array([3, 2, 1, 0, 4], np.uint8)
 
 
 def random_codes(n, rng):
@@ -109,7 +109,7 @@ def write_fasta(path, seqs, prefix="s"):
     with open(path, "wb") as f:
         for i, s in enumerate(seqs):
             f.write(b">%s%d\n" % (prefix.encode(), i))
-            f.write(codes_to_ascii(s) if s.dtype == np.uint8 and s.max(initial=0) < 4 else bytes(s))
+            f.write(codes_to_ascii(s) if s.dtype == np.uint8 and s.max(initial=0) < 5 else bytes(s))
             f.write(b"\n")
 
 
