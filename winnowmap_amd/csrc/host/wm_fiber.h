@@ -54,6 +54,7 @@ struct Hub {
 	std::vector<SketchReq*> q_sketch; std::vector<SeedReq*> q_seed; std::vector<ChainReq*> q_chain; std::vector<KswReq*> q_ksw, q_kswh;
 	std::vector<Fiber*> waiters[OP_N];
 	int inflight = 0, inflight_op[OP_N] = {0, 0, 0, 0, 0};
+	int n_workers = 1, n_idle = 0;          // workers of the mapping call; workers asleep with nothing runnable
 	std::atomic<int64_t> live{0};           // fibers alive + reads not yet admitted, over all workers: 0 = the mapping call is finished
 	uint64_t n_batches[OP_N] = {0, 0, 0, 0, 0}, n_reqs[OP_N] = {0, 0, 0, 0, 0};
 	// where the host time goes (seconds, summed over the workers): CPU time running fibers, CPU and wall time inside the batched
@@ -64,6 +65,12 @@ struct Hub {
 	// issued when at least min_more[op] requests are pending and fewer than max_op[op] batches of it are running
 	size_t min_more[OP_N] = { 4096, 4096, 4096, 24576, 2048 };
 	int max_op[OP_N] = { 2, 2, 2, 3, 2 };
+	// a batch is worth its fixed cost — a kernel launch lasts at least as long as its longest job, and the device runs only so many
+	// kernels at once — when it is large: an operation is issued when min_batch[op] requests are pending or the oldest has waited
+	// max_wait_ms[op], whichever comes first (0 / 0 = at once)
+	size_t min_batch[OP_N] = { 8192, 8192, 8192, 98304, 12288 };
+	double max_wait_ms[OP_N] = { 15, 15, 15, 30, 60 };
+	double first_pending[OP_N] = { 0, 0, 0, 0, 0 };          // wall_s() when the queue of the operation last became non-empty
 	long heavy_units = 8192;                // rows x 128-lane register pairs above which an alignment goes to the heavy queue (0 = no heavy queue)
 	void read_env()
 	{
@@ -72,6 +79,8 @@ struct Hub {
 			char key[64];
 			snprintf(key, sizeof(key), "WM_%s_MIN_MORE", nm[op]); if (getenv(key)) min_more[op] = (size_t)atol(getenv(key));
 			snprintf(key, sizeof(key), "WM_%s_MAX", nm[op]); if (getenv(key)) max_op[op] = atoi(getenv(key));
+			snprintf(key, sizeof(key), "WM_%s_MIN_BATCH", nm[op]); if (getenv(key)) min_batch[op] = (size_t)atol(getenv(key));
+			snprintf(key, sizeof(key), "WM_%s_MAX_WAIT_MS", nm[op]); if (getenv(key)) max_wait_ms[op] = atof(getenv(key));
 		}
 		if (getenv("WM_KSW_HEAVY_UNITS")) heavy_units = atol(getenv("WM_KSW_HEAVY_UNITS"));
 	}
@@ -122,10 +131,14 @@ public:
 			for (;;) {
 				if (!inbox_.empty()) { for (Fiber *f : inbox_) ready_.push_back(f); inbox_.clear(); break; }
 				if (H.live.load() == 0) { H.cpu_fiber += cpu_fiber; H.wall_idle += wall_idle; H.cv.notify_all(); return; }
-				const int op = pick_locked();
+				double wake_in = 1e9;
+				const int op = pick_locked(&wake_in);
 				if (op >= 0) { dispatch(op, lk); continue; }      // (returns with the lock held again)
 				const double w0 = wall_s();
-				H.cv.wait(lk);
+				++H.n_idle;
+				if (wake_in > 0.5) wake_in = 0.5;                  // (also re-checks the drain condition)
+				H.cv.wait_for(lk, std::chrono::duration<double>(wake_in < 2e-4 ? 2e-4 : wake_in));
+				--H.n_idle;
 				wall_idle += wall_s() - w0;
 			}
 		}
@@ -176,6 +189,8 @@ private:
 	{
 		Hub &H = *hub_;
 		bool any = false;
+		const double now = wall_s();
+		for (int op = 0; op < OP_N; ++op) if (H.pending(op) == 0) H.first_pending[op] = now;     // (stamps queues that are about to become non-empty)
 		if (!l_sketch_.empty()) { H.q_sketch.insert(H.q_sketch.end(), l_sketch_.begin(), l_sketch_.end()); l_sketch_.clear(); any = true; }
 		if (!l_seed_.empty()) { H.q_seed.insert(H.q_seed.end(), l_seed_.begin(), l_seed_.end()); l_seed_.clear(); any = true; }
 		if (!l_chain_.empty()) { H.q_chain.insert(H.q_chain.end(), l_chain_.begin(), l_chain_.end()); l_chain_.clear(); any = true; }
@@ -187,14 +202,21 @@ private:
 	}
 	// which operation this idle worker should issue now (-1: none). An operation with nothing in flight goes first (keeps every stage
 	// of the path moving); a further concurrent batch of the same operation is only worth its fixed cost when the queue is large.
-	int pick_locked()
+	int pick_locked(double *wake_in_s)
 	{
 		Hub &H = *hub_;
+		*wake_in_s = 1e9;
 		if (H.inflight >= H.max_inflight) return -1;
+		const double now = wall_s();
+		// nothing running anywhere and nobody able to produce more requests: whatever is pending must go now
+		const bool drain = H.inflight == 0 && H.n_idle + 1 >= H.n_workers;
 		int best = -1;
 		for (int op = OP_N - 1; op >= 0; --op) {              // later stages first: finishing reads frees their memory and admits new ones
 			const size_t n = H.pending(op);
 			if (n == 0) continue;
+			const double waited_ms = (now - H.first_pending[op]) * 1e3;
+			const bool ripe = drain || n >= H.min_batch[op] || waited_ms >= H.max_wait_ms[op];
+			if (!ripe) { const double left = (H.max_wait_ms[op] - waited_ms) * 1e-3; if (left < *wake_in_s) *wake_in_s = left; continue; }
 			if (H.inflight_op[op] == 0) return op;
 			if (n >= H.min_more[op] && H.inflight_op[op] < H.max_op[op] && best < 0) best = op;
 		}
