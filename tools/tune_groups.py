@@ -61,7 +61,7 @@ def main():
         for k_ in envs:
             os.environ.pop(k_)
         rows.append({"env": envs, "threads": t, "contexts": g, "inflight": infl or 16384, "arena_gb": arena / (1 << 30), "s_per_step": round(dt, 3), "reads_per_s": round(n / dt, 1), "gbps": round(n * cfg["read_len"] / dt / 1e9, 4), "hits": len(h),
-                     "glue_cpu_s": round(hs1["cpu_glue_s"] - hs0["cpu_glue_s"], 1), "idle_wall_s": round(hs1["idle_wall_s"] - hs0["idle_wall_s"], 1),
+                     "glue_cpu_s": round(hs1["cpu_glue_s"] - hs0["cpu_glue_s"], 1), "help_cpu_s": round(hs1["cpu_help_s"] - hs0["cpu_help_s"], 1), "idle_wall_s": round(hs1["idle_wall_s"] - hs0["idle_wall_s"], 1),
                      "batched_wall_s": {o: round(hs1["wall_batched_s"][o] - hs0["wall_batched_s"][o], 1) for o in hs1["wall_batched_s"]},
                      "batched_calls": {o: hs1["batched_calls"][o] - hs0["batched_calls"][o] for o in hs1["batched_calls"]}})
         B.log(json.dumps(rows[-1]))

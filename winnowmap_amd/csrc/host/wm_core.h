@@ -96,9 +96,6 @@ uint32_t x31_hash_string(const char *s);                              // __ac_X3
 
 extern const uint8_t *const nt4_table;                                  // seq_nt4_table, src/sketch.c:19-36
 
-// A pool of already-running threads that a batched operation may borrow (the scheduler team's members, idle while
-// member 0 issues the device calls): run(n, fn) executes fn(i) for i in [0, n) on the caller plus every thread
-// currently inside serve().
 // Library code never aborts (include/wm_gpu.h: "integer return codes"): a violated internal invariant — the places where the
 // reference has assert() (src/align.c:166, :282, :645, :782) — is recorded here (first one wins) and surfaced by the C-ABI entry
 // point as WM_EINTERNAL after the batch.
@@ -106,65 +103,16 @@ void note_internal_error(const char *expr, const char *file, int line);
 bool take_internal_error(std::string &msg);          // true + message if one was recorded since the last call; clears it
 #define WM_INVARIANT(x) do { if (!(x)) ::wm::note_internal_error(#x, __FILE__, __LINE__); } while (0)
 
-class ParallelExec {
-public:
-	void run(size_t n, const std::function<void(size_t)> &fn)
-	{
-		if (n == 0) return;
-		{
-			std::unique_lock<std::mutex> lk(mu_);
-			fn_ = &fn; n_ = n; next_.store(0);
-			chunk_ = n / (size_t)(8 * (servers_ + 1)) > 0 ? n / (size_t)(8 * (servers_ + 1)) : 1;
-			pending_ = servers_;
-			++gen_;
-		}
-		cv_job_.notify_all();
-		work();
-		std::unique_lock<std::mutex> lk(mu_);
-		cv_done_.wait(lk, [&] { return pending_ == 0; });
-		fn_ = 0;
-	}
-	// called by a pool thread; returns when close(round) has been called for this round
-	void serve(uint64_t round)
-	{
-		std::unique_lock<std::mutex> lk(mu_);
-		++servers_;
-		uint64_t seen = gen_;
-		for (;;) {
-			cv_job_.wait(lk, [&] { return gen_ != seen || closed_round_ == round; });
-			if (gen_ != seen) {
-				seen = gen_;
-				lk.unlock();
-				work();
-				lk.lock();
-				if (--pending_ == 0) cv_done_.notify_all();
-				continue;
-			}
-			break;                                       // closed
-		}
-		--servers_;
-	}
-	void close(uint64_t round) { { std::unique_lock<std::mutex> lk(mu_); closed_round_ = round; } cv_job_.notify_all(); }
-	// all expected servers have entered serve() (so that run() never starts with a partial pool and a wrong pending count)
-	void wait_servers(int n) { std::unique_lock<std::mutex> lk(mu_); while (servers_ < n) { lk.unlock(); std::this_thread::yield(); lk.lock(); } }
-private:
-	void work() { for (;;) { const size_t b = next_.fetch_add(chunk_); if (b >= n_) break; const size_t e = b + chunk_ < n_ ? b + chunk_ : n_; for (size_t i = b; i < e; ++i) (*fn_)(i); } }
-	std::mutex mu_;
-	std::condition_variable cv_job_, cv_done_;
-	const std::function<void(size_t)> *fn_ = 0;
-	size_t n_ = 0, chunk_ = 1;
-	std::atomic<size_t> next_{0};
-	int servers_ = 0, pending_ = 0;
-	uint64_t gen_ = 0, closed_round_ = ~(uint64_t)0;
-};
-// the pool the calling thread may use (set by the scheduler team around its device phase); otherwise threads are spawned
-inline ParallelExec *&tl_parallel_exec() { static thread_local ParallelExec *p = 0; return p; }
+// A thread that issues a batched device call may borrow the mapper's idle workers for the call's host-side loops (packing, sorting,
+// unpacking): the hub (wm_fiber.h) installs a hook for the duration of the call; parallel_for uses it when present.
+struct ParHook { virtual ~ParHook() {} virtual void run(size_t n, const std::function<void(size_t)> &fn) = 0; };
+inline ParHook *&tl_par_hook() { static thread_local ParHook *p = 0; return p; }
 
 // host-side helper: fn(i) for i in [0, n) on up to n_threads threads (dynamic chunks); used for packing / unpacking batches
 template <class F> inline void parallel_for(int n_threads, size_t n, F fn)
 {
+	if (n >= 256) if (ParHook *h = tl_par_hook()) { const std::function<void(size_t)> f = fn; h->run(n, f); return; }
 	if (n_threads <= 1 || n < 2) { for (size_t i = 0; i < n; ++i) fn(i); return; }
-	if (ParallelExec *ex = tl_parallel_exec()) { const std::function<void(size_t)> f = fn; ex->run(n, f); return; }
 	const size_t T = (size_t)n_threads < n ? (size_t)n_threads : n;
 	const size_t chunk = n / (T * 8) > 0 ? n / (T * 8) : 1;
 	std::atomic<size_t> next(0);

@@ -42,8 +42,11 @@ enum { OP_SKETCH = 0, OP_SEED = 1, OP_CHAIN = 2, OP_KSW = 3, OP_KSW_HEAVY = 4, O
 inline double thread_cpu_s() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 inline double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// a host-side loop of a batched call that idle workers help with (ParHook, wm_core.h)
+struct HelpTask { const std::function<void(size_t)> *fn; size_t n, chunk; std::atomic<size_t> next; int helpers; };
+
 struct Hub {
-	Hub(DeviceOps *ops_, const wm_ksw_score_t &sc_, int w_, int k_) : ops(ops_), sc(sc_), w(w_), k(k_) { max_inflight = ops->max_inflight(); if (max_inflight < 1) max_inflight = 1; read_env(); }
+	Hub(DeviceOps *ops_, const wm_ksw_score_t &sc_, int w_, int k_) : ops(ops_), sc(sc_), w(w_), k(k_) { max_inflight = ops->max_inflight(); if (max_inflight < 1) max_inflight = 1; read_env(); par.H = this; }
 	DeviceOps *ops;
 	wm_ksw_score_t sc;
 	int w, k;
@@ -55,6 +58,29 @@ struct Hub {
 	std::vector<Fiber*> waiters[OP_N];
 	int inflight = 0, inflight_op[OP_N] = {0, 0, 0, 0, 0};
 	int n_workers = 1, n_idle = 0;          // workers of the mapping call; workers asleep with nothing runnable
+	std::vector<HelpTask*> help;            // loops of running batched calls that still have chunks to hand out
+	double cpu_help = 0;                    // CPU seconds idle workers spent inside such loops
+	static void help_work(HelpTask &t)
+	{
+		for (;;) { const size_t b = t.next.fetch_add(t.chunk); if (b >= t.n) break; const size_t e = b + t.chunk < t.n ? b + t.chunk : t.n; for (size_t i = b; i < e; ++i) (*t.fn)(i); }
+	}
+	// the hook a dispatching worker installs around its batched call: the loop is shared with whoever is idle
+	struct Par : ParHook {
+		Hub *H;
+		void run(size_t n, const std::function<void(size_t)> &fn) override
+		{
+			HelpTask t;
+			t.fn = &fn; t.n = n; t.next.store(0); t.helpers = 0;
+			t.chunk = n / (size_t)(4 * (H->n_workers > 0 ? H->n_workers : 1));
+			if (t.chunk < 16) t.chunk = 16;
+			{ std::lock_guard<std::mutex> lk(H->mu); H->help.push_back(&t); }
+			H->cv.notify_all();
+			help_work(t);
+			std::unique_lock<std::mutex> lk(H->mu);
+			for (size_t i = 0; i < H->help.size(); ++i) if (H->help[i] == &t) { H->help.erase(H->help.begin() + i); break; }
+			while (t.helpers > 0) H->cv.wait(lk);          // (helpers announce themselves and leave under the hub mutex)
+		}
+	} par;
 	std::atomic<int64_t> live{0};           // fibers alive + reads not yet admitted, over all workers: 0 = the mapping call is finished
 	uint64_t n_batches[OP_N] = {0, 0, 0, 0, 0}, n_reqs[OP_N] = {0, 0, 0, 0, 0};
 	// where the host time goes (seconds, summed over the workers): CPU time running fibers, CPU and wall time inside the batched
@@ -134,6 +160,21 @@ public:
 				double wake_in = 1e9;
 				const int op = pick_locked(&wake_in);
 				if (op >= 0) { dispatch(op, lk); continue; }      // (returns with the lock held again)
+				{   // nothing to issue: lend a hand to a running batched call's host-side loop
+					HelpTask *ht = 0;
+					for (HelpTask *t : H.help) if (t->next.load() < t->n) { ht = t; break; }
+					if (ht) {
+						++ht->helpers;
+						lk.unlock();
+						const double hc0 = thread_cpu_s();
+						Hub::help_work(*ht);
+						const double hc = thread_cpu_s() - hc0;
+						lk.lock();
+						H.cpu_help += hc;
+						if (--ht->helpers == 0) H.cv.notify_all();
+						continue;
+					}
+				}
 				const double w0 = wall_s();
 				++H.n_idle;
 				if (wake_in > 0.5) wake_in = 0.5;                  // (also re-checks the drain condition)
@@ -236,12 +277,15 @@ private:
 		static const bool trace = getenv("WM_TRACE") != 0;
 		const auto t0 = std::chrono::steady_clock::now();
 		const double c0 = thread_cpu_s(), w0 = wall_s();
+		ParHook *const prev_hook = tl_par_hook();
+		tl_par_hook() = &H.par;
 		if (op == OP_SKETCH) H.ops->sketch_batch(H.w, H.k, a);
 		else if (op == OP_SEED) H.ops->seed_batch(b);
 		else if (op == OP_CHAIN) H.ops->chain_batch(c);
 		else H.ops->ksw_batch(H.sc, d);
 		if (trace) fprintf(stderr, "[batch] worker %2d %s n=%zu %.1f ms\n", rank_, op == OP_SKETCH ? "sketch" : op == OP_SEED ? "seed" : op == OP_CHAIN ? "chain" : op == OP_KSW ? "ksw" : "ksw-heavy", n,
 		                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+		tl_par_hook() = prev_hook;
 		const double dc = thread_cpu_s() - c0, dw = wall_s() - w0;
 		lk.lock();
 		H.cpu_op[op] += dc; H.wall_op[op] += dw;

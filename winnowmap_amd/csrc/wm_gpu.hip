@@ -394,20 +394,26 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 	int bad0 = -1;
 	if (pos) {
 		uint64_t tot = 0;
-		for (int i = 0; i < n_jobs; ++i) {
+		for (int i = 0; i < n_jobs; ++i) {                                        // slab offsets: a running sum
 			const wm_ksw_pos_t &s = pos[i];
 			wm_ksw_djob_t &d = b->jobs[i];
 			const uint64_t ql = s.qlen > 0 ? s.qlen : 0, tl = s.tlen > 0 ? s.tlen : 0;
 			d.q_off = (uint32_t)tot; d.t_off = (uint32_t)(tot + ql);
 			tot += ql + tl;
-			if (ql == 0 || tl == 0) continue;                                  // degenerate: never read
+		}
+		std::atomic<int> badp(-1);
+		wm::parallel_for(c->host_threads, (size_t)n_jobs, [&](size_t i) {
+			const wm_ksw_pos_t &s = pos[i];
+			memset(&dsrc[i], 0, sizeof(dsrc[i]));
+			if (s.qlen <= 0 || s.tlen <= 0) return;                                // degenerate: never read
 			const int64_t t_last = (int64_t)s.t_pos + (int64_t)(s.tlen - 1) * s.step;
 			if ((s.step != 1 && s.step != -1) || s.rid < 0 || (size_t)s.rid >= c->seq_len.size() || s.t_pos < 0 || t_last < 0 ||
 			    (uint32_t)s.t_pos >= c->seq_len[s.rid] || (uint64_t)t_last >= c->seq_len[s.rid] ||
-			    s.qwin_off < 0 || s.qwin_len < 0 || (uint64_t)s.qwin_off + (uint64_t)s.qwin_len > c->reads_bytes) { if (bad0 < 0) bad0 = i; continue; }
+			    s.qwin_off < 0 || s.qwin_len < 0 || (uint64_t)s.qwin_off + (uint64_t)s.qwin_len > c->reads_bytes) { badp = (int)i; return; }
 			dsrc[i].qwin_off = s.qwin_off; dsrc[i].qwin_len = s.qwin_len; dsrc[i].q_pos = s.q_pos; dsrc[i].step = s.step; dsrc[i].pad = 0;
 			dsrc[i].t_base = (int64_t)c->seq_off[s.rid] + s.t_pos;
-		}
+		});
+		if (badp >= 0) bad0 = badp;
 		if (tot >= ((uint64_t)1 << 32)) { delete b; return set_err(WM_ENOMEM, "batch holds %.1f GB of sequence (limit 4 GB per batch)", tot / 1073741824.0); }
 		slab_bytes = (size_t)tot;
 	} else {
@@ -672,12 +678,12 @@ extern "C" int wm_ksw_dev_fetch(wm_ctx_t *c, wm_ksw_dev_batch_t *b, wm_ksw_resul
 	HIPCHK(hipMemcpyAsync(off.data(), b->d_off, n * 4, hipMemcpyDeviceToHost, c->stream));
 	if (b->total_ops) HIPCHK(hipMemcpyAsync(cigar_pool, b->d_pool, (size_t)b->total_ops * 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(ctx_sync(c));
-	for (int i = 0; i < n; ++i) {
+	wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 		wm_ksw_result_t &o = results[i];
 		const wm_ksw_dres_t &r = res[i];
 		o.max = r.max; o.zdropped = r.zdropped; o.max_q = r.max_q; o.max_t = r.max_t; o.mqe = r.mqe; o.mqe_t = r.mqe_t;
 		o.mte = r.mte; o.mte_q = r.mte_q; o.score = r.score; o.reach_end = r.reach_end; o.n_cigar = r.n_cigar; o.cig_off = off[i];
-	}
+	});
 	return WM_OK;
 }
 
@@ -1201,7 +1207,7 @@ struct GpuOpsCtx {
 			else { off[i] = tot; tot += reqs[i]->len; }
 		}
 		UBuf<uint8_t> seqs(tot + 1, c);
-		for (int i = 0; i < n; ++i) if (!res[i]) memcpy(seqs.data() + off[i], reqs[i]->seq, reqs[i]->len);
+		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { if (!res[i]) memcpy(seqs.data() + off[i], reqs[i]->seq, reqs[i]->len); });
 		UBuf<wm128_t> out(tot_all / 8 + (size_t)17 * n + 64, c);          // the batch tries len/8 + 16 slots per sequence first
 		const double ts = now_ms();
 		int rc = sketch_batch_impl(c, n, seqs.data(), tot, off.data(), len.data(), res.data(), out.data(), out.size(), ooff.data(), cnt.data());
@@ -1211,13 +1217,13 @@ struct GpuOpsCtx {
 			if (rc) { fail("sketch"); return; }
 			t_sketch += now_ms() - ts;
 			aux_us += c->aux_ms * 1e3;
-			for (int i = 0; i < n; ++i) reqs[i]->mini.assign(big.begin() + ooff[i], big.begin() + ooff[i] + cnt[i]);
+			wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { reqs[i]->mini.assign(big.begin() + ooff[i], big.begin() + ooff[i] + cnt[i]); });
 			return;
 		}
 		if (rc) { fail("sketch"); return; }
 		t_sketch += now_ms() - ts;
 		aux_us += c->aux_ms * 1e3;
-		for (int i = 0; i < n; ++i) reqs[i]->mini.assign(out.begin() + ooff[i], out.begin() + ooff[i] + cnt[i]);
+		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { reqs[i]->mini.assign(out.begin() + ooff[i], out.begin() + ooff[i] + cnt[i]); });
 	}
 	void seed_batch(std::vector<wm::SeedReq*> &reqs)
 	{
@@ -1282,12 +1288,12 @@ struct GpuOpsCtx {
 		double t1;
 		if (all_res) {          // operands as positions in the resident reads / packed reference: nothing is copied or shipped per alignment
 			UBuf<wm_ksw_pos_t> jobs(n + 1, c);
-			for (int i = 0; i < n; ++i) {
+			wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 				const wm::KswReq &r = *reqs[i];
 				wm_ksw_pos_t &j = jobs[i];
 				j.qwin_off = r.qwin_off; j.qwin_len = r.qwin_len; j.q_pos = r.q_pos; j.rid = r.rid; j.t_pos = r.t_pos; j.qlen = r.ql; j.tlen = r.tl;
 				j.w = r.w; j.zdrop = r.zdrop; j.end_bonus = r.end_bonus; j.flag = r.flag; j.step = (int8_t)r.step; j.has_n = r.has_n; memset(j.pad, 0, sizeof(j.pad));
-			}
+			});
 			t1 = now_ms();
 			if (wm_ksw_batch_pos(c, &sc, n, jobs.data(), res.data(), pool.data(), cap, &used)) { fail("ksw"); return; }
 		} else {                // host views -> one byte slab
@@ -1309,10 +1315,10 @@ struct GpuOpsCtx {
 		const double t2 = now_ms();
 		ksw_us += c->last_ms * 1e3;
 		cells += c->acc_cells;
-		for (int i = 0; i < n; ++i) {
+		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 			reqs[i]->ez = res[i];
 			reqs[i]->cigar.assign(pool.begin() + res[i].cig_off, pool.begin() + res[i].cig_off + res[i].n_cigar);
-		}
+		});
 		t_pack += t1 - t0; t_unpack += now_ms() - t2; t_prep += c->t_prep; t_run += c->t_run; t_fetch += c->t_fetch;
 	}
 };
@@ -1364,7 +1370,7 @@ struct wm_mapper_s {
 	std::string text;
 	std::vector<int32_t> hits; std::vector<uint32_t> cigars; std::vector<int64_t> first;
 	uint64_t stats[9];
-	double host_stats[17] = {0};
+	double host_stats[18] = {0};
 	std::vector<std::string> cmdline;      // argv of the front end, for the @PG line of SAM files (wm_mapper_set_cmdline)
 };
 
@@ -1484,7 +1490,7 @@ static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double
 	m->stats[0] = st.n_flush; m->stats[1] = st.n_ksw; m->stats[2] = st.n_chain; m->stats[3] = st.n_seed; m->stats[4] = st.n_sketch;
 	m->host_stats[0] += st.cpu_fiber; m->host_stats[1] += st.wall_idle;
 	for (int op = 0; op < 4; ++op) { m->host_stats[2 + op] += st.cpu_op[op]; m->host_stats[6 + op] += st.wall_op[op]; m->host_stats[10 + op] += (double)st.n_batches[op]; }
-	m->host_stats[14] += (tm2 - tm1) * 1e-3; m->host_stats[15] += (now_ms() - tm2) * 1e-3; m->host_stats[16] = m->n_threads;
+	m->host_stats[14] += (tm2 - tm1) * 1e-3; m->host_stats[15] += (now_ms() - tm2) * 1e-3; m->host_stats[16] = m->n_threads; m->host_stats[17] += st.cpu_help;
 	if (trace_m) fprintf(stderr, "[host] fibers cpu %.2f s | idle wall %.2f s | batched calls cpu/wall/n: sketch %.2f/%.2f/%llu seed %.2f/%.2f/%llu chain %.2f/%.2f/%llu ksw %.2f/%.2f/%llu\n", st.cpu_fiber, st.wall_idle,
 	                     st.cpu_op[0], st.wall_op[0], (unsigned long long)st.n_batches[0], st.cpu_op[1], st.wall_op[1], (unsigned long long)st.n_batches[1],
 	                     st.cpu_op[2], st.wall_op[2], (unsigned long long)st.n_batches[2], st.cpu_op[3], st.wall_op[3], (unsigned long long)st.n_batches[3]);
@@ -1546,7 +1552,7 @@ extern "C" int wm_mapper_kernel_stats(const wm_mapper_t *m, double *out, int cap
 
 extern "C" int wm_mapper_host_stats(const wm_mapper_t *m, double *out, int cap)
 {
-	if (cap < 17) return set_err(WM_EINVAL, "need room for 17 doubles");
+	if (cap < 18) return set_err(WM_EINVAL, "need room for 18 doubles");
 	memcpy(out, m->host_stats, sizeof(m->host_stats));
 	return WM_OK;
 }
