@@ -264,7 +264,9 @@ def main():
         if rank != 0:
             n_contigs = max(1, int(round(args.ref_mb / 10.0)))
             ref = synth.make_reference(n_contigs, int(args.ref_mb * 1e6 / n_contigs), 3, repeat_frac=0.10)
-    arena = int(os.environ.get("WM_BENCH_ARENA_GB", 48)) << 30   # per group; 288 GB of HBM per GPU
+    # device contexts (own streams + arena each: that many batched calls are on the device at once) share the 288 GB of HBM
+    n_ctx = int(os.environ.setdefault("WM_CONTEXTS", "6"))
+    arena = int(float(os.environ.get("WM_BENCH_ARENA_GB", min(48.0, 216.0 / n_ctx))) * (1 << 30))
     ctx = gpu.Context(local, arena)
     idx.upload(ctx)
     mapper = gpu.Mapper(ctx, idx, cfg["preset"], gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)

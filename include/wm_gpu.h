@@ -189,6 +189,40 @@ int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *out_path, in
 /* argv of the calling front end: with MM_F_OUT_SAM, wm_map_file starts the file with the @SQ lines and the @PG line carrying this
  * command line, as mm_write_sam_hdr does before mapping (src/format.c:118-139, src/main.c:393). Optional (no CL: field without it). */
 int wm_mapper_set_cmdline(wm_mapper_t *m, int argc, const char *const *argv);
+/* All mapping options as plain data: the fields of mm_mapopt_t (src/minimap.h:112-175) this library honours, same names, same meaning, same
+ * defaults (mm_mapopt_init / mm_set_opt, src/options.c:14-131). A front end that has parsed the reference's command line into an
+ * mm_mapopt_t copies it field by field (oracle/wm_binding.cpp does exactly that inside the reference's own CLI).
+ * wm_mapopt_preset = mm_set_opt (preset NULL or "" = defaults; also returns the preset's k and w); wm_mapper_create_opt = wm_mapper_create
+ * with explicit options (checked like mm_check_opt, src/options.c:133-188). */
+typedef struct {
+	int64_t flag;
+	int32_t seed, sdust_thres, max_qlen;
+	int32_t bw, max_gap, max_gap_ref, min_gap_ref, max_frag_len;
+	int32_t max_chain_skip, max_chain_iter, min_cnt, min_chain_score;
+	float chain_gap_scale;
+	int32_t SVaware, SVawareMinReadLength, suffixSampleOffset, min_mapq;
+	float min_qcov;
+	int32_t minPrefixLength, maxPrefixLength;
+	float prefixIncrementFactor;
+	int32_t stage2_bw, stage2_zdrop_inv, stage2_max_gap;
+	float mask_level;
+	int32_t mask_len;
+	float pri_ratio;
+	int32_t best_n;
+	int32_t max_join_long, max_join_short, min_join_flank_sc;
+	float min_join_flank_ratio, alt_drop;
+	int32_t a, b, q, e, q2, e2, sc_ambi;
+	int32_t zdrop, zdrop_inv, end_bonus, min_dp_max, min_ksw_len;
+	float max_clip_ratio;
+	float mid_occ_frac;
+	int32_t min_mid_occ, mid_occ, max_occ;
+	int64_t mini_batch_size, max_sw_mat;
+} wm_mapopt_t;
+int wm_mapopt_preset(const char *preset, wm_mapopt_t *out, int *k, int *w);
+int wm_mapper_create_opt(wm_ctx_t *ctx, const wm_index_t *idx, const wm_mapopt_t *opt, wm_mapper_t **out);
+/* wm_map_file prints the SAM header itself when MM_F_OUT_SAM is set; a front end that has already printed it (the reference's main does,
+ * src/main.c:393) turns that off */
+int wm_mapper_set_sam_header(wm_mapper_t *m, int on);
 int wm_mapper_stats(const wm_mapper_t *m, uint64_t *out9);
 /* per ksw kernel class (B4/B8/B16 x CLIP x HASN register kernels, the two multi-wave LDS kernels, the generic kernel) since
  * wm_mapper_create: out[3k] = summed launch durations (ms, HIP events on the launching stream), out[3k+1] = DP cells,

@@ -1,0 +1,94 @@
+// oracle/wm_binding.cpp — TEST INFRASTRUCTURE: the reference-side binding of INTEGRATION.md (Level 0 / 1), made real.
+//
+// This file is compiled TOGETHER WITH THE REFERENCE'S OWN SOURCES (oracle/Makefile target `wm`, against /root/reference/src/minimap.h)
+// into oracle/_ref/winnowmap_wm: the reference's CLI, option parser, index builder and main() unchanged, with its per-file mapping entry
+// point mm_map_file (src/map.c:1273, called from src/main.c:419) redirected to libwmgpu.so by the linker (-Wl,--wrap=mm_map_file) — no
+// reference source is modified or copied. It is what a Winnowmap maintainer would write to adopt the library:
+//   * the index the reference has just built (mm_idx_t) is handed over through the reference's own index file format (mm_idx_dump,
+//     src/index.c:515 → wm_index_load), the -W list through opt->kmer_freq_filename (the reference does not persist its bloom filter);
+//   * every field of mm_mapopt_t goes into wm_mapopt_t (same names), so presets AND individual command-line options carry over;
+//   * records are written by wm_map_file to stdout exactly where the reference writes them (the SAM header was printed by main already).
+// WM_BACKEND=cpu in the environment runs the reference's own mm_map_file instead (A/B inside one binary).
+// tests/test_binding_gpu.py diffs `winnowmap_wm ...` against `winnowmap_ref ...`.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include "minimap.h"
+#include "../include/wm_gpu.h"
+
+extern "C" int __real_mm_map_file(const mm_idx_t *idx, const char *fn, const mm_mapopt_t *opt, int n_threads);
+
+namespace {
+struct Backend {
+	const mm_idx_t *for_idx = 0;
+	wm_ctx_t *ctx = 0; wm_index_t *idx = 0; wm_mapper_t *mapper = 0;
+	void close()
+	{
+		if (mapper) wm_mapper_destroy(mapper);
+		if (idx) wm_index_destroy(idx);
+		if (ctx) wm_ctx_destroy(ctx);
+		mapper = 0; idx = 0; ctx = 0; for_idx = 0;
+	}
+} g_be;
+
+void copy_opt(const mm_mapopt_t *o, wm_mapopt_t *w)
+{
+	memset(w, 0, sizeof(*w));
+#define CP(f) w->f = o->f
+	CP(flag); CP(seed); CP(sdust_thres); CP(max_qlen); CP(bw); CP(max_gap); CP(max_gap_ref); CP(min_gap_ref); CP(max_frag_len);
+	CP(max_chain_skip); CP(max_chain_iter); CP(min_cnt); CP(min_chain_score); CP(chain_gap_scale);
+	w->SVaware = o->SVaware ? 1 : 0;
+	CP(SVawareMinReadLength); CP(suffixSampleOffset); CP(min_mapq); CP(min_qcov); CP(minPrefixLength); CP(maxPrefixLength); CP(prefixIncrementFactor);
+	CP(stage2_bw); CP(stage2_zdrop_inv); CP(stage2_max_gap); CP(mask_level); CP(mask_len); CP(pri_ratio); CP(best_n);
+	CP(max_join_long); CP(max_join_short); CP(min_join_flank_sc); CP(min_join_flank_ratio); CP(alt_drop);
+	CP(a); CP(b); CP(q); CP(e); CP(q2); CP(e2); CP(sc_ambi); CP(zdrop); CP(zdrop_inv); CP(end_bonus); CP(min_dp_max); CP(min_ksw_len);
+	CP(max_clip_ratio); CP(mid_occ_frac); CP(min_mid_occ); CP(mid_occ); CP(max_occ); CP(mini_batch_size); CP(max_sw_mat);
+#undef CP
+}
+
+int open_backend(const mm_idx_t *mi, const mm_mapopt_t *opt, int n_threads)
+{
+	g_be.close();
+	if (wm_ctx_create(0, 0, &g_be.ctx)) return -1;                       // fails without a GPU: the library has no CPU path
+	char tmpl[] = "/tmp/wm_binding_XXXXXX";
+	const int fd = mkstemp(tmpl);
+	if (fd < 0) return -1;
+	FILE *fp = fdopen(fd, "wb");
+	mm_idx_dump(fp, mi);                                                 // src/index.c:515
+	fclose(fp);
+	const int rc = wm_index_load(tmpl, opt->kmer_freq_filename, &g_be.idx);
+	unlink(tmpl);
+	if (rc) return -1;
+	if (wm_index_upload(g_be.ctx, g_be.idx)) return -1;
+	wm_mapopt_t wo;
+	copy_opt(opt, &wo);
+	if (wm_mapper_create_opt(g_be.ctx, g_be.idx, &wo, &g_be.mapper)) return -1;
+	if (wm_mapper_set_threads(g_be.mapper, n_threads > 1 ? n_threads : 1, 0)) return -1;
+	wm_mapper_set_sam_header(g_be.mapper, 0);                            // main() has printed it (src/main.c:393)
+	g_be.for_idx = mi;
+	return 0;
+}
+} // namespace
+
+extern "C" int __wrap_mm_map_file(const mm_idx_t *idx, const char *fn, const mm_mapopt_t *opt, int n_threads)
+{
+	const char *be = getenv("WM_BACKEND");
+	if (be && strcmp(be, "cpu") == 0) return __real_mm_map_file(idx, fn, opt, n_threads);
+	if (opt->flag & (MM_F_SPLICE | MM_F_SR | MM_F_FRAG_MODE) || opt->split_prefix) {
+		fprintf(stderr, "[wm_gpu] splice / short-read / multi-part modes are not covered by libwmgpu: using the CPU path\n");
+		return __real_mm_map_file(idx, fn, opt, n_threads);
+	}
+	if (g_be.for_idx != idx && open_backend(idx, opt, n_threads)) {
+		fprintf(stderr, "[wm_gpu] %s\n", wm_last_error());
+		return -1;
+	}
+	fflush(stdout);
+	double st[6];
+	const int rc = wm_map_file(g_be.mapper, fn, "-", opt->mini_batch_size, st);
+	if (rc) { fprintf(stderr, "[wm_gpu] %s\n", wm_last_error()); return -1; }
+	if (mm_verbose >= 3) fprintf(stderr, "[M::wm_gpu] mapped %.0f sequences (%.0f bases) in %.0f mini-batch(es) on the GPU\n", st[0], st[1], st[2]);
+	return 0;
+}
+
+__attribute__((destructor)) static void wm_binding_fini() { g_be.close(); }

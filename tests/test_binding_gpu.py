@@ -1,0 +1,123 @@
+"""GPU: (1) the reference's own CLI with its mapping entry point bound to libwmgpu.so (oracle/_ref/winnowmap_wm = the reference's
+main + all its objects + oracle/wm_binding.cpp, linked with -Wl,--wrap=mm_map_file; INTEGRATION.md Level 0/1) must print what the
+untouched reference prints; (2) bit-exact parity AT SCALE — >= 10^3 reads per BASELINE-shaped configuration — against the reference
+binary on the same box (parity had only been shown on a few dozen reads)."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from winnowmap_amd import gpu, parity, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "winnowmap_ref")
+WM_BIN = os.path.join(ROOT, "oracle", "_ref", "winnowmap_wm")
+need_ref = pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/winnowmap_ref not built")
+
+
+def _write_reads(path, reads, prefix="r"):
+    with open(path, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b">%s%d\n" % (prefix.encode(), i))
+            f.write(synth.codes_to_ascii(r))
+            f.write(b"\n")
+
+
+def _run(binary, args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([binary] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=1200)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    return p.stdout
+
+
+@need_ref
+@pytest.mark.skipif(not os.path.exists(WM_BIN), reason="oracle/_ref/winnowmap_wm not built")
+def test_reference_cli_bound_to_the_library_prints_the_references_output():
+    tmp = tempfile.mkdtemp()
+    ref = synth.make_reference(2, 400000, 31, repeat_frac=0.08)
+    fa = os.path.join(tmp, "ref.fa")
+    synth.write_fasta(fa, ref, prefix="chr")
+    km, cnt = synth.repetitive_kmers(ref, 15)
+    kf = os.path.join(tmp, "rep.txt")
+    synth.write_kmer_list(kf, km, cnt, 15)
+    reads, _ = synth.make_reads(ref, 40, 12000, 32, profile="ont", sv_frac=0.2)
+    reads += synth.make_reads(ref, 12, 3000, 33, profile="ont")[0]            # below the 10 kb MCAS gate
+    rq = os.path.join(tmp, "reads.fa")
+    _write_reads(rq, reads)
+    for fmt, extra in (("-cx", []), ("-ax", []), ("-cx", ["-N", "3", "-p", "0.5", "--cs"])):   # PAF+CIGAR, SAM, individual options on top of the preset
+        args = ["-t", "4", "-W", kf] + extra + [fmt, "map-ont", fa, rq]
+        sam = fmt == "-ax"
+        want = _run(REF_BIN, args)
+        got = _run(WM_BIN, args)
+        d = parity.diff_texts(want, got, sam=sam)
+        assert d["reads"] >= 40 and d["hits"] >= 40 and d["mismatches"] == 0, (fmt, extra, d)
+        if sam:            # header: same @SQ lines (the @PG line carries the program path)
+            hw = [l for l in want.split(b"\n") if l.startswith(b"@SQ")]
+            hg = [l for l in got.split(b"\n") if l.startswith(b"@SQ")]
+            assert hw == hg and len(hw) == 2
+        # the same binary on its CPU path (WM_BACKEND=cpu) is the reference
+        if fmt == "-cx" and not extra:
+            assert _run(WM_BIN, args, env={"WM_BACKEND": "cpu"}) == want
+
+
+def _at_scale(preset, k, w, ref, reads, kmer_list, threads=16):
+    tmp = tempfile.mkdtemp()
+    fa = os.path.join(tmp, "ref.fa")
+    synth.write_fasta(fa, ref, prefix="ctg")
+    kf = None
+    if kmer_list:
+        km, cnt = synth.repetitive_kmers(ref, k)
+        kf = os.path.join(tmp, "rep.txt")
+        synth.write_kmer_list(kf, km, cnt, k)
+    rq = os.path.join(tmp, "reads.fa")
+    _write_reads(rq, reads)
+    want = _run(REF_BIN, ["-t", str(threads)] + (["-W", kf] if kf else []) + ["-cx", preset, fa, rq])
+    ctx = gpu.Context(0, 24 << 30)
+    idx = gpu.Index(fa, kf, k=k, w=w, n_threads=threads)
+    idx.upload(ctx)
+    m = gpu.Mapper(ctx, idx, preset, gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
+    m.set_threads(threads, 24 << 30)
+    text, hits, _, _ = m.map([b"r%d" % i for i in range(len(reads))], [synth.codes_to_ascii(r) for r in reads])
+    d = parity.diff_texts(want, text, sam=False)
+    m.close(); idx.close(); ctx.close()
+    return d, len(hits)
+
+
+@need_ref
+def test_parity_at_scale_config2_shape_ont():
+    """BASELINE config 2 shape: 2 048 x 15 kb ONT reads (1 % with an SV) vs a 20 Mb repeat-rich reference, -W, map-ont."""
+    ref = synth.make_reference(2, 10_000_000, 3, repeat_frac=0.10)
+    reads, _ = synth.make_reads(ref, 2048, 15000, 4, profile="ont", sv_frac=0.01)
+    d, nh = _at_scale("map-ont", 15, 50, ref, reads, True)
+    assert d["reads"] == 2048 and d["hits"] >= 2048 and d["mismatches"] == 0, d
+
+
+@need_ref
+def test_parity_at_scale_config3_shape_hifi():
+    """BASELINE config 3 shape: 1 024 x 20 kb HiFi reads vs the same kind of reference, map-pb."""
+    ref = synth.make_reference(2, 10_000_000, 3, repeat_frac=0.10)
+    reads, _ = synth.make_reads(ref, 1024, 20000, 5, profile="hifi")
+    d, nh = _at_scale("map-pb", 15, 50, ref, reads, True)
+    assert d["reads"] == 1024 and d["hits"] >= 1024 and d["mismatches"] == 0, d
+
+
+@need_ref
+def test_parity_at_scale_config5_shape_asm20():
+    """BASELINE config 5 shape: 50 x 1 Mb contigs at 5 % divergence with SVs vs the reference they were drawn from, asm20 (k = 19; w stays 50, src/options.c:112-115)."""
+    ref = synth.make_reference(3, 20_000_000, 6, repeat_frac=0.10)
+    rng = np.random.default_rng(8)
+    contigs = []
+    for i in range(50):
+        c = ref[int(rng.integers(0, 3))]
+        st = int(rng.integers(0, len(c) - 1_000_000))
+        q = synth.mutate_codes(c[st:st + 1_000_000].copy(), rng, 0.03, 0.01, 0.01)
+        for _ in range(10):                                                   # 1 SV / 100 kb: a 2 kb deletion or a 1 kb insertion
+            p = int(rng.integers(10000, len(q) - 10000))
+            q = np.concatenate([q[:p], q[p + 2000:]]) if rng.integers(0, 2) else np.concatenate([q[:p], synth.random_codes(1000, rng), q[p:]])
+        contigs.append(q if i % 2 else synth.revcomp_codes(q))
+    d, nh = _at_scale("asm20", 19, 50, ref, contigs, False)
+    assert d["reads"] == 50 and d["hits"] >= 50 and d["mismatches"] == 0, d

@@ -229,6 +229,7 @@ struct wm_ctx_s {
 	bool have_index, owns_index;
 	int host_threads;                           // threads the batched entry points may use for their host-side packing / sorting
 	uint8_t *pin; size_t pin_bytes, pin_used;   // pinned host slab for staging (allocated on first use)
+	int *pin_small;                             // a few pinned words for scalar read-backs (an async copy into pageable memory makes the caller spin until the stream gets there)
 };
 
 static void *pin_take(wm_ctx_s *c, size_t bytes, size_t *mark)
@@ -317,6 +318,8 @@ extern "C" int wm_ctx_create(int device, size_t arena_bytes, wm_ctx_t **out)
 	for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
 	HIPCHK(hipEventCreateWithFlags(&c->sync_ev, hipEventBlockingSync | hipEventDisableTiming));
 	c->arena_used = 0; c->last_ms = 0; c->aux_ms = 0; c->host_threads = 1; c->pin = 0; c->pin_bytes = c->pin_used = 0; c->have_index = false; c->owns_index = false; c->d_hkey = c->d_hval = c->d_P = 0; c->d_bloom = 0;
+	c->pin_small = 0;
+	if (hipHostMalloc((void**)&c->pin_small, 256, hipHostMallocDefault) != hipSuccess) { c->pin_small = 0; (void)hipGetLastError(); }
 	c->d_S = 0; c->d_reads = 0; c->reads_bytes = c->reads_cap = 0; c->owns_reads = false;
 	*out = c;
 	return WM_OK;
@@ -331,6 +334,7 @@ extern "C" void wm_ctx_destroy(wm_ctx_t *c)
 	hipEventDestroy(c->sync_ev);
 	hipStreamDestroy(c->stream);
 	if (c->pin) hipHostFree(c->pin);
+	if (c->pin_small) hipHostFree(c->pin_small);
 	for (int i = 0; i < 4; ++i) hipStreamDestroy(c->kstream[i]);
 	for (int i = 0; i < 5; ++i) hipEventDestroy(c->kev[i]);
 	for (int k = 0; k < WM_KSW_NCLASS; ++k) { hipEventDestroy(c->cev[k][0]); hipEventDestroy(c->cev[k][1]); }
@@ -650,9 +654,12 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	hipLaunchKernelGGL(ksw_gather_kernel, dim3(n), dim3(64), 0, c->stream, b->d_jobs, b->d_res, b->d_off, b->d_cig, b->d_pool, (uint32_t)b->pool_cap);
 	HIPCHK(hipEventRecord(c->ev[2], c->stream));
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipMemcpyAsync(&b->h_err, b->d_err, 4, hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipMemcpyAsync(&b->total_ops, b->d_total, 4, hipMemcpyDeviceToHost, c->stream));
+	int *h_small = c->pin_small ? c->pin_small : &b->h_err;            // [0] error flag, [1] total ops
+	uint32_t *h_total = c->pin_small ? (uint32_t*)(c->pin_small + 1) : &b->total_ops;
+	HIPCHK(hipMemcpyAsync(h_small, b->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(h_total, b->d_total, 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(ctx_sync(c));
+	b->h_err = *h_small; b->total_ops = *h_total;
 	HIPCHK(hipEventElapsedTime(&b->dp_ms, c->ev[0], c->ev[1]));
 	HIPCHK(hipEventElapsedTime(&b->bt_ms, c->ev[1], c->ev[2]));
 	c->last_ms = b->dp_ms + b->bt_ms;
@@ -993,7 +1000,7 @@ static int sketch_batch_impl(wm_ctx_t *c, int n, const uint8_t *seqs, size_t seq
 		HIPCHK(hipEventRecord(c->ev[0], c->stream));
 		hipLaunchKernelGGL(sketch_kernel, dim3(((int)jb.size() + 63) / 64), dim3(64), lds, c->stream, c->skp, d_jobs, (int)jb.size(), d_seqs, c->d_bloom, d_out, d_cnt);
 		HIPCHK(hipEventRecord(c->ev[1], c->stream));
-		std::vector<int> cnt(jb.size());
+		UBuf<int> cnt(jb.size() + 1, c);
 		UBuf<wm128_t> tmp(tot + 1, c);
 		HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt, jb.size() * 4, hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(hipMemcpyAsync(tmp.data(), d_out, tot * sizeof(wm128_t), hipMemcpyDeviceToHost, c->stream));
@@ -1057,7 +1064,7 @@ extern "C" int wm_seed_batch(wm_ctx_t *c, int n, const wm128_t *mini, const uint
 		HIPCHK(hipEventRecord(c->ev[0], c->stream));
 		hipLaunchKernelGGL(seed_kernel, dim3((int)jb.size()), dim3(64), 0, c->stream, ix, d_jobs, d_mini, d_out, d_occ, d_occ_off, d_res);
 		HIPCHK(hipEventRecord(c->ev[1], c->stream));
-		std::vector<wm_seed_res_t> res(jb.size());
+		UBuf<wm_seed_res_t> res(jb.size() + 1, c);
 		UBuf<wm128_t> tmp(tot + 1, c);
 		HIPCHK(hipMemcpyAsync(res.data(), d_res, jb.size() * sizeof(wm_seed_res_t), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(hipMemcpyAsync(tmp.data(), d_out, tot * sizeof(wm128_t), hipMemcpyDeviceToHost, c->stream));
@@ -1235,9 +1242,9 @@ struct GpuOpsCtx {
 		for (int i = 0; i < n; ++i) { moff[i] = tot; nm[i] = reqs[i]->n_mini; ql[i] = reqs[i]->qlen; tot += reqs[i]->n_mini; }
 		UBuf<wm128_t> mini(tot + 1, c);
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { memcpy(mini.data() + moff[i], reqs[i]->mini, (size_t)reqs[i]->n_mini * sizeof(wm128_t)); });
-		size_t cap = tot * 8 + 1024;
+		size_t cap = tot * 3 + 4096;               // anchors per minimizer: ~1.15 on the bench reference; repeats are retried at 8x
 		for (int attempt = 0; attempt < 6; ++attempt) {
-			UBuf<wm128_t> out(cap);
+			UBuf<wm128_t> out(cap, c);
 			const double ts = now_ms();
 			const int rc = wm_seed_batch(c, n, mini.data(), moff.data(), nm.data(), ql.data(), reqs[0]->max_occ, reqs[0]->flag, out.data(), out.size(), ooff.data(), na.data(), rl.data());
 			if (rc == WM_ENOMEM && strstr(g_err, "anchor output pool")) { cap *= 8; continue; }
@@ -1262,7 +1269,7 @@ struct GpuOpsCtx {
 			par[i] = { r.max_dist_x, r.min_dist_x, r.max_dist_y, r.bw, r.max_skip, r.max_iter, r.min_cnt, r.min_sc, r.gap_scale };
 		}
 		UBuf<wm128_t> a(tot + 1, c);
-		UBuf<uint64_t> u(tot + 1);
+		UBuf<uint64_t> u(tot + 1, c);
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { memcpy(a.data() + aoff[i], reqs[i]->a.data(), reqs[i]->a.size() * sizeof(wm128_t)); });
 		const double ts = now_ms();
 		if (wm_chain_batch(c, n, a.data(), aoff.data(), na.data(), par.data(), u.data(), uoff.data(), nu.data(), nv.data())) { fail("chain"); return; }
@@ -1371,6 +1378,7 @@ struct wm_mapper_s {
 	std::vector<int32_t> hits; std::vector<uint32_t> cigars; std::vector<int64_t> first;
 	uint64_t stats[9];
 	double host_stats[18] = {0};
+	bool sam_header = true;                // wm_map_file writes the @SQ / @PG lines (wm_mapper_set_sam_header)
 	std::vector<std::string> cmdline;      // argv of the front end, for the @PG line of SAM files (wm_mapper_set_cmdline)
 };
 
@@ -1391,6 +1399,55 @@ extern "C" int wm_mapper_create(wm_ctx_t *c, const wm_index_t *idx, const char *
 	*out = m;
 	return WM_OK;
 }
+#define WM_MAPOPT_FIELDS(X) X(flag) X(seed) X(sdust_thres) X(max_qlen) X(bw) X(max_gap) X(max_gap_ref) X(min_gap_ref) X(max_frag_len) \
+	X(max_chain_skip) X(max_chain_iter) X(min_cnt) X(min_chain_score) X(chain_gap_scale) X(SVawareMinReadLength) X(suffixSampleOffset) X(min_mapq) \
+	X(min_qcov) X(minPrefixLength) X(maxPrefixLength) X(prefixIncrementFactor) X(stage2_bw) X(stage2_zdrop_inv) X(stage2_max_gap) X(mask_level) \
+	X(mask_len) X(pri_ratio) X(best_n) X(max_join_long) X(max_join_short) X(min_join_flank_sc) X(min_join_flank_ratio) X(alt_drop) X(a) X(b) X(q) X(e) \
+	X(q2) X(e2) X(sc_ambi) X(zdrop) X(zdrop_inv) X(end_bonus) X(min_dp_max) X(min_ksw_len) X(max_clip_ratio) X(mid_occ_frac) X(min_mid_occ) X(mid_occ) \
+	X(max_occ) X(mini_batch_size) X(max_sw_mat)
+static void mapopt_to_c(const wm::MapOpt &o, wm_mapopt_t *c)
+{
+	memset(c, 0, sizeof(*c));
+#define X(f) c->f = (decltype(c->f))o.f;
+	WM_MAPOPT_FIELDS(X)
+#undef X
+	c->SVaware = o.SVaware ? 1 : 0;
+}
+static void mapopt_from_c(const wm_mapopt_t *c, wm::MapOpt &o)
+{
+#define X(f) o.f = (decltype(o.f))c->f;
+	WM_MAPOPT_FIELDS(X)
+#undef X
+	o.SVaware = c->SVaware != 0;
+}
+extern "C" int wm_mapopt_preset(const char *preset, wm_mapopt_t *out, int *k, int *w)
+{
+	wm::IdxOpt io; wm::MapOpt mo;
+	wm::set_preset(0, io, mo);
+	if (preset && preset[0] && wm::set_preset(preset, io, mo) < 0) return set_err(WM_EINVAL, "unknown preset '%s'", preset);
+	mapopt_to_c(mo, out);
+	if (k) *k = io.k;
+	if (w) *w = io.w;
+	return WM_OK;
+}
+extern "C" int wm_mapper_create_opt(wm_ctx_t *c, const wm_index_t *idx, const wm_mapopt_t *opt, wm_mapper_t **out)
+{
+	*out = 0;
+	if (!c || !idx || !opt) return set_err(WM_EINVAL, "null argument");
+	if (!c->have_index) return set_err(WM_EINVAL, "wm_index_upload has not been called on this context");
+	wm_mapper_t *m = new wm_mapper_t();
+	m->c = c; m->idx = idx;
+	wm::set_preset(0, m->io, m->mo);
+	mapopt_from_c(opt, m->mo);
+	m->io.k = idx->ix.k; m->io.w = idx->ix.w;
+	std::string err;
+	if (wm::check_opt(m->io, m->mo, err) < 0) { delete m; return set_err(WM_EINVAL, "%s", err.c_str()); }
+	memset(m->stats, 0, sizeof(m->stats));
+	*out = m;
+	return WM_OK;
+}
+extern "C" int wm_mapper_set_sam_header(wm_mapper_t *m, int on) { if (!m) return set_err(WM_EINVAL, "null mapper"); m->sam_header = on != 0; return WM_OK; }
+
 extern "C" void wm_mapper_destroy(wm_mapper_t *m) { if (m) { for (wm_ctx_t *w : m->workers) wm_ctx_destroy(w); delete m; } }
 
 // Host parallelism: n_threads worker threads run the host glue of the reads (fibers, wm_fiber.h) and take turns issuing the batched
@@ -1415,6 +1472,9 @@ extern "C" int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena
 		w->host_threads = m->c->host_threads;
 		m->workers.push_back(w);
 	}
+	// the pinned staging slabs are allocated now, not inside the first mapping call (page-locking a few GB takes a noticeable fraction of a second)
+	{ size_t mark = 0; if (pin_take(m->c, 1, &mark)) pin_release(m->c, mark); }
+	for (wm_ctx_t *w : m->workers) { size_t mark = 0; if (pin_take(w, 1, &mark)) pin_release(w, mark); }
 	return WM_OK;
 }
 
@@ -1515,7 +1575,7 @@ extern "C" int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *o
 	FILE *out = strcmp(out_path, "-") == 0 ? stdout : fopen(out_path, "wb");
 	if (!out) return set_err(WM_EINVAL, "cannot open '%s' for writing", out_path);
 	std::string err;
-	if (m->mo.flag & 0x8) {                                            // MM_F_OUT_SAM: @SQ / @PG lines first (mm_write_sam_hdr, src/main.c:393)
+	if ((m->mo.flag & 0x8) && m->sam_header) {                         // MM_F_OUT_SAM: @SQ / @PG lines first (mm_write_sam_hdr, src/main.c:393)
 		std::string hdr;
 		std::vector<const char*> av;
 		for (const std::string &a : m->cmdline) av.push_back(a.c_str());
