@@ -59,9 +59,9 @@ def test_reference_cli_bound_to_the_library_prints_the_references_output():
             hw = [l for l in want.split(b"\n") if l.startswith(b"@SQ")]
             hg = [l for l in got.split(b"\n") if l.startswith(b"@SQ")]
             assert hw == hg and len(hw) == 2
-        # the same binary on its CPU path (WM_BACKEND=cpu) is the reference
+        # the same binary on its CPU path (WM_BACKEND=cpu) is the reference (MAPQ / rl:i differ from run to run in the reference itself)
         if fmt == "-cx" and not extra:
-            assert _run(WM_BIN, args, env={"WM_BACKEND": "cpu"}) == want
+            assert parity.diff_texts(want, _run(WM_BIN, args, env={"WM_BACKEND": "cpu"}), sam=False)["mismatches"] == 0
 
 
 def _at_scale(preset, k, w, ref, reads, kmer_list, threads=16):

@@ -93,6 +93,12 @@ WM_DEV int wave_max_i32(int x) { return __builtin_amdgcn_readlane(wave_scan_max(
 // value of lane-o for a uniform o (lanes < o receive their own value; callers mask them)
 WM_DEV int shr_n(int x, int o) { return __shfl_up(x, (unsigned)o, 64); }
 WM_DEV int readlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+WM_DEV double readlane(double x, int l)
+{
+	const long long b = __builtin_bit_cast(long long, x);
+	const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), l);
+	return __builtin_bit_cast(double, (long long)((unsigned long long)hi << 32 | lo));
+}
 WM_DEV int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 WM_DEV long long uniform(long long x)
 {
@@ -126,6 +132,8 @@ template <class T> WM_DEV void gst(T *p, long long i, T v) { p[i] = v; }
 // "coherent" scratch accessors: data written by one lane and read by another lane of the SAME wave through global
 // memory must not be served from a stale L1 line, so these go to L2 (relaxed agent-scope atomics = sc1 accesses).
 WM_DEV void mem_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+// agent-scope release + acquire: one lane's plain global stores become visible to the plain loads of every other lane of the wave (no stale L1 line)
+WM_DEV void mem_sync_agent() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 WM_DEV int cld8(signed char *p, long long i) { return (int)__hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 WM_DEV void cst8(signed char *p, long long i, int v) { __hip_atomic_store(p + i, (signed char)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 WM_DEV int cld(int *p, long long i) { return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -160,4 +160,132 @@ WM_DEV void sketch_wave(const wm_sketch_params_t P, const wm_sketch_job_t *jobs,
 	WM_IF(have) gst(counts, job, n_out); WM_END
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// sketch_coop: ONE WAVEFRONT per sequence, for odd k (every preset: k = 15 / 19). With k odd a k-mer never equals its reverse
+// complement, so the reference's "skip the palindrome" step (src/sketch.c:166) never fires, slot t of the winnowing ring is simply
+// position t, and a k-mer is valid iff the last k bases are all unambiguous (l >= k; an N only resets l, src/sketch.c:175).
+//
+// Phase 1 (data parallel, 64 positions per step, coalesced byte loads): lane j builds the forward / reverse k-mers that end at its
+// position from the k codes before it, picks the strand, probes the bloom filter, evaluates the fp64 order (applyWeight, :70-89) and
+// stores (order, hash << 8 | k, pos << 1 | strand, l) of the slot — 24 B per position in a scratch slab in HBM (L2 resident).
+// Phase 2 walks the CHAIN OF WINDOW MINIMA instead of every position. If slot m holds the current minimum after step m, the
+// reference's automaton (:180-205) changes it next either at the first t in (m, m + w] whose order is STRICTLY smaller (a new minimum:
+// emit m if l_t >= w + k) or, if there is none, at t = m + w when m is overwritten (emit m if l_t >= w + k - 1; the new minimum is the
+// RIGHTMOST smallest slot of (m, m + w], the ">=" rescan of :199-204). Both questions are one ballot over the w orders that follow m,
+// so a hop costs a few dozen instructions and advances ~(w + 1) / 2 positions; ties between identical k-mers (tandem repeats) and
+// empty windows (N runs, masked reads) follow the same two rules, so the result is the reference's bit for bit. After the last
+// position the current minimum is flushed (:208-214).
+// Slot 0 is always empty for k >= 2 (l = 1 < k), which makes "m = 0, empty" the state after step 0.
+// ------------------------------------------------------------------------------------------------------------------------------
+WM_DEV void sketch_coop(const wm_sketch_params_t P, const wm_sketch_job_t jb, const uint8_t *seqs, const uint8_t *bloom_bits,
+                        double *so, uint64_t *sx, uint32_t *sy, uint32_t *sl, wm128_t *out, int *count_out)
+{
+	const int w = P.w, k = P.k, n = jb.len;
+	const uint64_t mask = (1ULL << 2 * k) - 1;
+	const V<int> ln = lane();
+	const long long soff = (long long)jb.seq_off;
+	// ---- phase 1 ----
+	int last_n = -1;                                 // position of the last ambiguous base seen so far
+	for (int t0 = 0; t0 < n; t0 += 64) {
+		const V<int> i = ln + t0;
+		const vbool in = i < n;
+		V<int> c = 4;
+		WM_IF(in) c = cast<int>(gld(seqs, cast<long long>(i) + soff)); WM_END
+		const V<int> lastN = vmax(wave_scan_max(sel(in && c >= 4, i, V<int>(-1))), last_n);
+		const V<int> l = i - lastN;                  // unambiguous bases ending here (0 on an N)
+		last_n = readlane(lastN, 63);
+		const vbool valid = in && l >= k;
+		V<double> co = 2.0;
+		V<uint64_t> cx = ~(uint64_t)0;
+		V<uint32_t> cy = 0xffffffffu;
+		WM_IF(valid)
+			V<uint64_t> f = (uint64_t)0, g = (uint64_t)0;
+			for (int j = 0; j < k; ++j) {            // base j steps back: digit j of the forward k-mer, digit k-1-j of the reverse complement
+				const V<uint64_t> cj = cast<uint64_t>(gld(seqs, cast<long long>(i - j) + soff));
+				f = f | (cj << (2 * j));
+				g = g | ((cj ^ (uint64_t)3) << (2 * (k - 1 - j)));
+			}
+			const V<int> strand = sel(f < g, 0, 1);
+			const V<uint64_t> km = sel(strand == 1, g, f);
+			const V<uint32_t> h0 = sk_bloom_hash(km, P.salt0) % P.table_bits, h1 = sk_bloom_hash(km, P.salt1) % P.table_bits;
+			const V<int> b0 = cast<int>(gld(bloom_bits, h0 >> 3)) >> cast<int>(h0 & 7u), b1 = cast<int>(gld(bloom_bits, h1 >> 3)) >> cast<int>(h1 & 7u);
+			const vbool down = ((b0 & b1) & 1) == 1;
+			const V<double> x = cast<double>(sk_fmix64(km)) * 1.0 / 18446744073709551616.0;
+			const V<double> x2 = x * x, x4 = x2 * x2;
+			co = sel(down, -1.0 * (x4 * x4), -1.0 * x);
+			cx = (sk_hash64(km, mask) << 8) | (uint64_t)k;
+			cy = cast<uint32_t>((i << 1) | strand);
+		WM_END
+		WM_IF(in)
+			gst(so, i, co); gst(sx, i, cx); gst(sy, i, cy); gst(sl, i, cast<uint32_t>(l));
+		WM_END
+	}
+	mem_sync_agent();                                // phase 2 reads what other lanes of this wave wrote
+	// ---- phase 2 ----
+	int m = 0, n_out = 0;
+	double om = 2.0;
+	bool m_set = false;                              // the current minimum is a real k-mer
+	const long long ooff = (long long)jb.out_off;
+	for (;;) {
+		int found = -1;
+		for (int b = m + 1; b <= m + w && b < n && found < 0; b += 64) {
+			const V<int> t = ln + b;
+			const vbool inr = t <= m + w && t < n;
+			V<double> o = 2.0;
+			WM_IF(inr) o = gld(so, t); WM_END
+			const uint64_t bm = ballot(inr && o < om);
+			if (bm) found = b + __builtin_ctzll(bm);
+		}
+		if (found >= 0) {                            // a strictly smaller order arrives at step `found` (:180-190)
+			if (m_set && (int)gld(sl, (long long)found) >= w + k) {
+				WM_IF(ln == 0 && n_out < jb.cap)
+					gst((uint64_t*)out, V<long long>((ooff + n_out) * 2), V<uint64_t>(gld(sx, (long long)m)));
+					gst((uint64_t*)out, V<long long>((ooff + n_out) * 2 + 1), V<uint64_t>((uint64_t)gld(sy, (long long)m)));
+				WM_END
+				++n_out;
+			}
+			m = found; om = gld(so, (long long)m); m_set = true;
+			continue;
+		}
+		if (m + w > n - 1) break;                    // the minimum is never overwritten: flushed below
+		{
+			const int t = m + w;                     // slot m is overwritten at step m + w (:191-205)
+			if (m_set && (int)gld(sl, (long long)t) >= w + k - 1) {
+				WM_IF(ln == 0 && n_out < jb.cap)
+					gst((uint64_t*)out, V<long long>((ooff + n_out) * 2), V<uint64_t>(gld(sx, (long long)m)));
+					gst((uint64_t*)out, V<long long>((ooff + n_out) * 2 + 1), V<uint64_t>((uint64_t)gld(sy, (long long)m)));
+				WM_END
+				++n_out;
+			}
+			// the rightmost smallest order of (m, m + w]: per 64 slots, descend from the rightmost slot to ever smaller orders
+			double best = 3.0; int best_t = m + 1;
+			for (int b = m + 1; b <= t; b += 64) {
+				const V<int> tt = ln + b;
+				const vbool inr = tt <= t;
+				V<double> o = 2.0;
+				WM_IF(inr) o = gld(so, tt); WM_END
+				uint64_t cand = ballot(inr);
+				int p = 63 - __builtin_clzll(cand);
+				double v = readlane(o, p);
+				for (;;) {
+					const uint64_t lower = ballot(inr && o < v);
+					if (!lower) break;
+					p = 63 - __builtin_clzll(lower);
+					v = readlane(o, p);
+				}
+				if (v <= best) { best = v; best_t = b + p; }   // (a later block wins ties)
+			}
+			m = best_t; om = best; m_set = om < 2.0;
+		}
+	}
+	if (m_set) {                                     // flush (:208-214)
+		WM_IF(ln == 0 && n_out < jb.cap)
+			gst((uint64_t*)out, V<long long>((ooff + n_out) * 2), V<uint64_t>(gld(sx, (long long)m)));
+			gst((uint64_t*)out, V<long long>((ooff + n_out) * 2 + 1), V<uint64_t>((uint64_t)gld(sy, (long long)m)));
+		WM_END
+		++n_out;
+	}
+	WM_IF(ln == 0) gst(count_out, V<long long>(0), V<int>(n_out)); WM_END
+}
+
 } // namespace wmk

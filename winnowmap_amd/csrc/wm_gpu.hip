@@ -807,6 +807,15 @@ __global__ __launch_bounds__(64) void sketch_kernel(wm_sketch_params_t P, const 
 	wmk::sketch_wave(P, jobs, n_jobs, blockIdx.x, seqs, bloom, ring_o, ring_y, out, counts);
 }
 
+// one wavefront per sequence (sketch_coop, odd k): order[] lists the jobs longest first; so / sx / sy / sl = per-position scratch
+__global__ __launch_bounds__(64) void sketch_coop_kernel(wm_sketch_params_t P, const wm_sketch_job_t *jobs, const int *order, const uint8_t *seqs, const uint8_t *bloom,
+                                                          double *so, uint64_t *sx, uint32_t *sy, uint32_t *sl, wm128_t *out, int *counts)
+{
+	const int j = order[blockIdx.x];
+	const wm_sketch_job_t jb = jobs[j];
+	wmk::sketch_coop(P, jb, seqs, bloom, so + jb.scratch_off, sx + jb.scratch_off, sy + jb.scratch_off, sl + jb.scratch_off, out, counts + j);
+}
+
 __global__ __launch_bounds__(64) void seed_kernel(wm_index_view_t ix, const wm_seed_job_t *jobs, const wm128_t *mini, wm128_t *anchors,
                                                    int *occ_scratch, const uint64_t *occ_off, wm_seed_res_t *res)
 {
@@ -984,6 +993,11 @@ static int sketch_batch_impl(wm_ctx_t *c, int n, const uint8_t *seqs, size_t seq
 		uint8_t *d_seqs = (uint8_t*)arena_take(c, seqs_bytes + 64);
 		// one base pointer for the kernel (the staged slab); resident sequences are addressed relative to it
 		const uint64_t res_delta = resident && d_seqs ? (uint64_t)((uintptr_t)c->d_reads - (uintptr_t)d_seqs) : 0;
+		// odd k (every preset): one wavefront per sequence walking the chain of window minima (sketch_coop); even k: the palindrome rule
+		// of src/sketch.c:166 makes the slot stream data dependent -> the one-lane-per-sequence automaton (sketch_wave). WM_SKETCH_LANE=1 forces the latter.
+		static const bool force_lane = getenv("WM_SKETCH_LANE") != 0;
+		const bool coop = (c->skp.k & 1) && c->skp.k >= 2 && !force_lane;
+		uint64_t slots = 0;
 		for (size_t t = 0; t < todo.size(); ++t) {
 			const int i = todo[t];
 			const bool res = resident && resident[i];
@@ -991,14 +1005,30 @@ static int sketch_batch_impl(wm_ctx_t *c, int n, const uint8_t *seqs, size_t seq
 			jb[t].seq_off = res ? res_delta + seq_off[i] : seq_off[i]; jb[t].len = len[i];
 			jb[t].cap = round == 0 ? len[i] / 8 + 16 : len[i] + 1;
 			jb[t].out_off = tot; tot += jb[t].cap;
+			jb[t].scratch_off = slots; slots += (uint64_t)(len[i] > 0 ? len[i] : 0);
 		}
 		wm128_t *d_out = (wm128_t*)arena_take(c, (tot + 1) * sizeof(wm128_t));
 		int *d_cnt = (int*)arena_take(c, jb.size() * 4 + 64);
 		if (!d_jobs || !d_seqs || !d_out || !d_cnt) return set_err(WM_ENOMEM, "sketch batch does not fit the arena");
 		HIPCHK(hipMemcpyAsync(d_jobs, jb.data(), jb.size() * sizeof(wm_sketch_job_t), hipMemcpyHostToDevice, c->stream));
 		if (seqs_bytes) HIPCHK(hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream));
-		HIPCHK(hipEventRecord(c->ev[0], c->stream));
-		hipLaunchKernelGGL(sketch_kernel, dim3(((int)jb.size() + 63) / 64), dim3(64), lds, c->stream, c->skp, d_jobs, (int)jb.size(), d_seqs, c->d_bloom, d_out, d_cnt);
+		std::vector<int> ord;
+		if (coop) {
+			double *d_so = (double*)arena_take(c, (slots + 1) * 8);
+			uint64_t *d_sx = (uint64_t*)arena_take(c, (slots + 1) * 8);
+			uint32_t *d_sy = (uint32_t*)arena_take(c, (slots + 1) * 4), *d_sl = (uint32_t*)arena_take(c, (slots + 1) * 4);
+			int *d_ord = (int*)arena_take(c, jb.size() * 4 + 64);
+			if (!d_so || !d_sx || !d_sy || !d_sl || !d_ord) return set_err(WM_ENOMEM, "sketch batch does not fit the arena");
+			ord.resize(jb.size());
+			for (size_t t = 0; t < jb.size(); ++t) ord[t] = (int)t;
+			std::sort(ord.begin(), ord.end(), [&](int a, int b) { return jb[a].len != jb[b].len ? jb[a].len > jb[b].len : a < b; });     // longest first
+			HIPCHK(hipMemcpyAsync(d_ord, ord.data(), ord.size() * 4, hipMemcpyHostToDevice, c->stream));
+			HIPCHK(hipEventRecord(c->ev[0], c->stream));
+			hipLaunchKernelGGL(sketch_coop_kernel, dim3((int)jb.size()), dim3(64), 0, c->stream, c->skp, d_jobs, d_ord, d_seqs, c->d_bloom, d_so, d_sx, d_sy, d_sl, d_out, d_cnt);
+		} else {
+			HIPCHK(hipEventRecord(c->ev[0], c->stream));
+			hipLaunchKernelGGL(sketch_kernel, dim3(((int)jb.size() + 63) / 64), dim3(64), lds, c->stream, c->skp, d_jobs, (int)jb.size(), d_seqs, c->d_bloom, d_out, d_cnt);
+		}
 		HIPCHK(hipEventRecord(c->ev[1], c->stream));
 		UBuf<int> cnt(jb.size() + 1, c);
 		UBuf<wm128_t> tmp(tot + 1, c);

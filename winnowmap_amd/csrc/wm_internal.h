@@ -34,6 +34,7 @@ typedef struct {
 	uint64_t seq_off;     // offset of the 0..4 codes inside the batch sequence arena
 	uint64_t out_off;     // first minimizer slot of this job in the output pool
 	int32_t len, cap;     // sequence length; capacity of the output slot
+	uint64_t scratch_off; // first slot of this job in the per-position scratch arrays (sketch_coop)
 } wm_sketch_job_t;
 
 typedef struct {
