@@ -124,7 +124,7 @@ int emu_sketch(int n, const uint8_t *seqs, const uint64_t *offs, const int32_t *
 {
 	std::vector<wm_sketch_job_t> jobs(n);
 	uint64_t tot = 0;
-	for (int i = 0; i < n; ++i) { jobs[i].seq_off = offs[i]; jobs[i].len = lens[i]; jobs[i].out_off = out_offs[i]; jobs[i].cap = caps[i]; tot = std::max<uint64_t>(tot, out_offs[i] + caps[i]); }
+	for (int i = 0; i < n; ++i) { jobs[i].seq_off = offs[i]; jobs[i].len = lens[i]; jobs[i].out_off = out_offs[i]; jobs[i].cap = caps[i]; jobs[i].scratch_off = 0; tot = std::max<uint64_t>(tot, out_offs[i] + caps[i]); }
 	std::vector<wm128_t> out(tot + 1);
 	wm_sketch_params_t P = { w, k, table_bits, salt0, salt1 };
 	std::vector<double> ro((size_t)w * 64);
@@ -132,6 +132,26 @@ int emu_sketch(int n, const uint8_t *seqs, const uint64_t *offs, const int32_t *
 	for (int wv = 0; wv * 64 < n; ++wv) {
 		simt::exec_mask() = ~0ull;
 		wmk::sketch_wave(P, jobs.data(), n, wv, seqs, bloom_bits, ro.data(), ry.data(), out.data(), counts);
+	}
+	for (uint64_t i = 0; i < tot; ++i) ox[i] = out[i].x, oy[i] = out[i].y;
+	return 0;
+}
+
+// the same through the one-wavefront-per-sequence kernel (sketch_coop, odd k)
+int emu_sketch_coop(int n, const uint8_t *seqs, const uint64_t *offs, const int32_t *lens, int w, int k, uint32_t table_bits, uint32_t salt0, uint32_t salt1,
+                    const uint8_t *bloom_bits, uint64_t *ox, uint64_t *oy, const uint64_t *out_offs, const int32_t *caps, int32_t *counts)
+{
+	uint64_t tot = 0;
+	wm_sketch_params_t P = { w, k, table_bits, salt0, salt1 };
+	for (int i = 0; i < n; ++i) tot = std::max<uint64_t>(tot, out_offs[i] + caps[i]);
+	std::vector<wm128_t> out(tot + 1);
+	for (int i = 0; i < n; ++i) {
+		wm_sketch_job_t jb;
+		jb.seq_off = offs[i]; jb.len = lens[i]; jb.out_off = out_offs[i]; jb.cap = caps[i]; jb.scratch_off = 0;
+		const size_t L = (size_t)(lens[i] > 0 ? lens[i] : 0) + 1;
+		std::vector<double> so(L); std::vector<uint64_t> sx(L); std::vector<uint32_t> sy(L), sl(L);
+		simt::exec_mask() = ~0ull;
+		wmk::sketch_coop(P, jb, seqs, bloom_bits, so.data(), sx.data(), sy.data(), sl.data(), out.data(), counts + i);
 	}
 	for (uint64_t i = 0; i < tot; ++i) ox[i] = out[i].x, oy[i] = out[i].y;
 	return 0;

@@ -169,3 +169,37 @@ def test_chain_large_sparse_and_dense_anchor_sets(env):
             ou, obx, oby = W.o_chain_dp(a["x"], a["y"], max_dist_x=prm[0], min_dist_x=prm[1], max_dist_y=prm[2], bw=prm[3])
             g = alla[int(aoff2[i]):int(aoff2[i]) + nv[i]]
             assert np.array_equal(u[int(uoff[i]):int(uoff[i]) + nu[i]], ou) and np.array_equal(g["x"], obx) and np.array_equal(g["y"], oby), (i, prm)
+
+
+def test_index_build_on_device_equals_host_build(tmp_path):
+    """the reference index with mm_sketch of the whole reference on the device (sketch_coop, one wavefront per contig) must be
+    bit-identical to the host build — packed bases, key table, position runs, bloom bits — for ragged contigs, N runs, satellite
+    arrays (ties between identical k-mers inside one window) and a -W list; also with an arena that forces several contig groups."""
+    import time
+    from winnowmap_amd import synth
+    ref = synth.make_reference(5, 1_500_000, 17, repeat_frac=0.15)
+    ref[1] = ref[1][:1_234_567]
+    ref[2][400000:400100] = 4
+    ref[3][:20] = 4
+    ref.append(np.tile(np.array([0, 3], np.uint8), 5000))          # (AT)n: every window is full of ties
+    ref.append(ref[0][:37].copy())
+    fa = str(tmp_path / "ref.fa")
+    synth.write_fasta(fa, ref)
+    km, cnt = synth.repetitive_kmers(ref, 15)
+    kf = str(tmp_path / "rep.txt")
+    synth.write_kmer_list(kf, km, cnt, 15)
+    host = gpu.Index(fa, kf, k=15, w=50, n_threads=8)
+    hs, ha = host.export_arrays()
+    for arena in (2 << 30, 96 << 20):                                # one group of contigs; several groups (28 B per base)
+        c = gpu.Context(0, arena)
+        t0 = time.time()
+        dev, st = gpu.Index.build_on_device(c, fa, kf, k=15, w=50, n_threads=8)
+        ds, da = dev.export_arrays()
+        assert np.array_equal(hs, ds), (hs, ds)
+        for a, b in zip(ha, da):
+            assert np.array_equal(a, b)
+        assert st["minimizers"] == host.n_minimizers
+        print("device index build: %.2fs total, device sketch %.3fs, %d minimizers (arena %d MB)" % (time.time() - t0, st["device_sketch_s"], st["minimizers"], arena >> 20))
+        dev.upload(c)                                                 # and the context is usable afterwards
+        dev.close(); c.close()
+    host.close()

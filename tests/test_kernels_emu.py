@@ -13,6 +13,7 @@ def emu():
     E = C.CDLL(build.build_emu())
     E.emu_ksw_extd2.argtypes = [C.c_int, W.u8p, C.c_int, W.u8p, W.i8p] + [C.c_int] * 9 + [W.i32p, W.u32p, C.c_int, C.POINTER(C.c_int)]
     E.emu_sketch.argtypes = [C.c_int, W.u8p, W.u64p, W.i32p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, W.u64p, W.u64p, W.u64p, W.i32p, W.i32p]
+    E.emu_sketch_coop.argtypes = E.emu_sketch.argtypes
     E.emu_seed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, W.u64p, W.u64p, C.c_int, C.c_int, C.c_int, C.c_int, W.u64p, W.u64p, C.c_int, W.i32p]
     E.emu_chain_fill.argtypes = [C.c_int64, W.u64p, W.u64p] + [C.c_int] * 6 + [C.c_float, C.c_float, W.i32p, W.i32p, W.i32p]
     return E
@@ -100,10 +101,17 @@ def small_index():
     return dict(H=H, h=h, hk=hk, hv=hv, P=P, hbits=hb.value, tb=tb.value, salts=(salts[0], salts[1]), bloom_bits=bb, bloom=W.o_bloom(km), reads=reads, synth=synth)
 
 
-def test_sketch_kernel_emulated_matches_oracle(emu, small_index):
+@pytest.mark.parametrize("kernel,w,k", [("lane", 50, 15), ("coop", 50, 15), ("coop", 50, 19), ("coop", 100, 21), ("coop", 10, 15), ("coop", 5, 11), ("coop", 200, 27), ("lane", 20, 14)])
+def test_sketch_kernel_emulated_matches_oracle(emu, small_index, kernel, w, k):
+    """both sketch kernels: one lane per sequence (sketch_wave, any k) and one wavefront per sequence (sketch_coop, odd k)"""
     S = small_index
     rng = np.random.default_rng(4)
     seqs = [r[st:st + 2000].copy() for r in S["reads"][:3] for st in range(0, 14000, 4000)]
+    # masked reads as stage 2 sketches them (mapped stretches replaced by N, src/map.c:786-846), N runs of every length around w and k
+    m = S["reads"][1].copy(); m[1000:6000] = 4; m[9000:9049] = 4; m[9100:9151] = 4; m[12000:12014] = 4; m[12100:12115] = 4
+    seqs += [m, np.full(300, 4, np.uint8), np.concatenate([np.full(70, 4, np.uint8), S["reads"][2][:500], np.full(3, 4, np.uint8), S["reads"][2][500:520]])]
+    for ln_ in (1, 14, 15, 16, 63, 64, 65, 66, 79, 113, 128, 129):       # lengths around k, w + k and the 64-position tile
+        seqs.append(S["reads"][3][100:100 + ln_].copy())
     for it in range(12):                      # low-complexity / periodic sequences, some with N
         L, unit = int(rng.integers(100, 2500)), int(rng.integers(1, 13))
         s = np.tile(rng.integers(0, 4, unit), L // unit + 1)[:L].astype(np.uint8)
@@ -114,12 +122,13 @@ def test_sketch_kernel_emulated_matches_oracle(emu, small_index):
     seqs += [S["reads"][0], np.array([0, 1, 2], np.uint8)]
     lens = np.array([len(s) for s in seqs], np.int32)
     offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
-    caps = (lens // 4 + 16).astype(np.int32)
+    caps = (lens + 1).astype(np.int32)
     ooffs = np.concatenate([[0], np.cumsum(caps)[:-1]]).astype(np.uint64)
     ox = np.zeros(int(caps.sum()), np.uint64); oy = np.zeros(int(caps.sum()), np.uint64); counts = np.zeros(len(seqs), np.int32)
-    emu.emu_sketch(len(seqs), np.concatenate(seqs), offs, lens, 50, 15, S["tb"], S["salts"][0], S["salts"][1], C.cast(S["bloom_bits"], C.c_void_p), ox, oy, ooffs, caps, counts)
+    fn = emu.emu_sketch if kernel == "lane" else emu.emu_sketch_coop
+    fn(len(seqs), np.concatenate(seqs), offs, lens, w, k, S["tb"], S["salts"][0], S["salts"][1], C.cast(S["bloom_bits"], C.c_void_p), ox, oy, ooffs, caps, counts)
     for i, s in enumerate(seqs):
-        ex, ey = W.o_sketch(bytes(s), 50, 15, rid=0, bloom=S["bloom"])
+        ex, ey = W.o_sketch(bytes(s), w, k, rid=0, bloom=S["bloom"])
         n = counts[i]
         assert n == len(ex), (i, n, len(ex))
         assert np.array_equal(ox[int(ooffs[i]):int(ooffs[i]) + n], ex) and np.array_equal(oy[int(ooffs[i]):int(ooffs[i]) + n], ey)

@@ -199,8 +199,7 @@ bool Index::has_n(uint32_t rid, uint32_t st, uint32_t en) const
 	return lo < n_runs.size() && n_runs[lo].first < e;
 }
 
-int index_build(const IdxOpt &io, const std::vector<std::string> &names, const std::vector<std::string> &seqs,
-                const std::string &kmer_file, int n_threads, Index &ix, std::string &err)
+int index_begin(const IdxOpt &io, const std::vector<std::string> &names, const std::vector<std::string> &seqs, const std::string &kmer_file, int n_threads, Index &ix, std::string &err)
 {
 	ix = Index();
 	ix.k = io.k; ix.w = io.w; ix.flag = io.flag;
@@ -226,7 +225,33 @@ int index_build(const IdxOpt &io, const std::vector<std::string> &names, const s
 	}
 	ix.total_len = sum;
 	ix.S.assign((sum + 7) / 8 + 1, 0);
-	// sketch every contig (independent → one task per contig) and pack it
+	// (contigs share a packed word only at their first / last word: pack word-aligned interiors in parallel, the edges serially)
+	parallel_for(n_threads, seqs.size(), [&](size_t i) {
+		const uint64_t o = ix.seq[i].offset, n = seqs[i].size();
+		uint64_t j = 0;
+		const uint64_t head = (8 - (o & 7)) & 7;                // bases before the first word this contig owns alone
+		for (j = head < n ? head : n; j + 8 <= n && ((o + j) >> 3) < ((o + n) >> 3); j += 8) {
+			uint32_t wv = 0;
+			for (int b = 0; b < 8; ++b) wv |= (uint32_t)nt4_table[(uint8_t)seqs[i][j + b]] << (4 * b);
+			ix.S[(o + j) >> 3] = wv;
+		}
+	});
+	for (size_t i = 0; i < seqs.size(); ++i) {
+		const uint64_t o = ix.seq[i].offset, n = seqs[i].size();
+		const uint64_t head = (8 - (o & 7)) & 7;
+		for (uint64_t j = 0; j < (head < n ? head : n); ++j) { const uint64_t p = o + j; ix.S[p >> 3] |= (uint32_t)nt4_table[(uint8_t)seqs[i][j]] << ((p & 7) << 2); }
+		uint64_t j = head < n ? head : n;
+		while (j + 8 <= n && ((o + j) >> 3) < ((o + n) >> 3)) j += 8;      // (what the parallel pass covered)
+		for (; j < n; ++j) { const uint64_t p = o + j; ix.S[p >> 3] |= (uint32_t)nt4_table[(uint8_t)seqs[i][j]] << ((p & 7) << 2); }
+	}
+	return 0;
+}
+
+int index_build(const IdxOpt &io, const std::vector<std::string> &names, const std::vector<std::string> &seqs,
+                const std::string &kmer_file, int n_threads, Index &ix, std::string &err)
+{
+	if (index_begin(io, names, seqs, kmer_file, n_threads, ix, err) < 0) return -1;
+	// sketch every contig (independent → one task per contig)
 	std::vector<std::vector<m128>> per(seqs.size());
 	std::atomic<size_t> next(0);
 	auto work = [&]() {
@@ -241,13 +266,6 @@ int index_build(const IdxOpt &io, const std::vector<std::string> &names, const s
 		for (int t = 1; t < nt; ++t) th.emplace_back(work);
 		work();
 		for (auto &t : th) t.join();
-	}
-	for (size_t i = 0; i < seqs.size(); ++i) {
-		const uint64_t o = ix.seq[i].offset;
-		for (uint64_t j = 0; j < seqs[i].size(); ++j) {
-			const uint64_t p = o + j;
-			ix.S[p >> 3] |= (uint32_t)nt4_table[(uint8_t)seqs[i][j]] << ((p & 7) << 2);
-		}
 	}
 	std::vector<m128> all;
 	size_t tot = 0;

@@ -54,6 +54,9 @@ int index_build(const IdxOpt &io, const std::vector<std::string> &names, const s
 int index_build_from_fasta(const IdxOpt &io, const std::string &fasta, const std::string &kmer_file, int n_threads, Index &out, std::string &err);
 
 void index_table_from_minimizers(Index &ix, std::vector<m128> &all);
+// the two halves of index_build around the sketching of the contigs (so that a device can do that part): bloom filter from the -W list +
+// sequence table + 4-bit packing, then (key, position) records -> table
+int index_begin(const IdxOpt &io, const std::vector<std::string> &names, const std::vector<std::string> &seqs, const std::string &kmer_file, int n_threads, Index &ix, std::string &err);
 // the reference's index file format (winnowmap -d): written by either program, read by either program
 int index_save_mmi(const Index &ix, const std::string &path, std::string &err);
 int index_load_mmi(const std::string &path, const std::string &kmer_file, Index &ix, std::string &err);

@@ -959,6 +959,68 @@ extern "C" int wm_index_upload(wm_ctx_t *c, const wm_index_t *h)
 	return WM_OK;
 }
 
+static int sketch_batch_impl(wm_ctx_t *c, int n, const uint8_t *seqs, size_t seqs_bytes, const uint64_t *seq_off, const int32_t *len, const uint8_t *resident,
+                             wm128_t *out, size_t out_cap, uint64_t *out_off, int32_t *counts);
+
+extern "C" int wm_index_build_gpu(wm_ctx_t *c, const char *fasta, const char *kmer_file, int k, int w, int n_threads, wm_index_t **out, double *stats)
+{
+	*out = 0;
+	if (!c) return set_err(WM_EINVAL, "null context");
+	wm::IdxOpt io; io.k = k; io.w = w;
+	wm::MapOpt mo; std::string err;
+	if (wm::check_opt(io, mo, err) < 0) return set_err(WM_EINVAL, "%s", err.c_str());
+	if (!(k & 1) || k < 2) return set_err(WM_EINVAL, "the device index build needs an odd k (got %d): use wm_index_build", k);
+	if (c->have_index) return set_err(WM_EINVAL, "the context already holds an index: build on a fresh context, then wm_index_upload");
+	HIPCHK(hipSetDevice(c->device));
+	const double t0 = now_ms();
+	std::vector<std::string> names, seqs;
+	if (wm::read_fastx(fasta, names, seqs, 0, 0, err) < 0) return set_err(WM_EINVAL, "%s", err.c_str());
+	if (seqs.empty()) return set_err(WM_EINVAL, "no sequences in %s", fasta);
+	wm_index_t *h = new wm_index_t();
+	wm::Index &ix = h->ix;
+	if (wm::index_begin(io, names, seqs, kmer_file ? kmer_file : "", n_threads, ix, err) < 0) { delete h; return set_err(WM_EINVAL, "%s", err.c_str()); }
+	if (ix.bloom.table_bits >= ((uint64_t)1 << 32)) { delete h; return set_err(WM_EINVAL, "bloom table of %llu bits not supported on device", (unsigned long long)ix.bloom.table_bits); }
+	const double t1 = now_ms();
+	// the bloom bit table goes first (the sketch kernel probes it); it is replaced by wm_index_upload later
+	uint8_t *d_bloom = 0;
+	if (hipMalloc((void**)&d_bloom, ix.bloom.bits.size() + 8) != hipSuccess || hipMemcpy(d_bloom, ix.bloom.bits.data(), ix.bloom.bits.size(), hipMemcpyHostToDevice) != hipSuccess) {
+		delete h; if (d_bloom) hipFree(d_bloom); return set_err(WM_ENOMEM, "cannot place the bloom filter on the device");
+	}
+	c->d_bloom = d_bloom;
+	c->skp.w = w; c->skp.k = k; c->skp.table_bits = (uint32_t)ix.bloom.table_bits; c->skp.salt0 = ix.bloom.salt[0]; c->skp.salt1 = ix.bloom.salt[1];
+	std::vector<wm::m128> all;
+	int rc = WM_OK;
+	const size_t budget = (size_t)(c->arena_bytes * 0.85);
+	for (size_t g0 = 0; g0 < seqs.size() && rc == WM_OK;) {             // groups of contigs that fit the arena: 1 B codes + 24 B scratch + 2 B output per base
+		size_t g1 = g0, bases = 0;
+		while (g1 < seqs.size() && (g1 == g0 || (bases + seqs[g1].size()) * 28 + 4096 * (g1 - g0 + 1) <= budget)) { bases += seqs[g1].size(); ++g1; }
+		if (bases * 28 > budget) { rc = set_err(WM_ENOMEM, "contig %zu (%zu bases) needs %.1f GB of arena for the device sketch", g0, seqs[g0].size(), seqs[g0].size() * 28 / 1073741824.0); break; }
+		const int n = (int)(g1 - g0);
+		std::vector<uint64_t> off(n), ooff(n);
+		std::vector<int32_t> len(n), cnt(n);
+		std::unique_ptr<uint8_t[]> codes(new uint8_t[bases + 1]);
+		size_t tot = 0;
+		for (int i = 0; i < n; ++i) { off[i] = tot; len[i] = (int32_t)seqs[g0 + i].size(); tot += seqs[g0 + i].size(); }
+		wm::parallel_for(n_threads, (size_t)n, [&](size_t i) { const std::string &sq = seqs[g0 + i]; uint8_t *d = codes.get() + off[i]; for (size_t j = 0; j < sq.size(); ++j) d[j] = wm::nt4_table[(uint8_t)sq[j]]; });
+		std::vector<wm128_t> mv(bases / 8 + (size_t)17 * n + 64);
+		rc = sketch_batch_impl(c, n, codes.get(), tot, off.data(), len.data(), 0, mv.data(), mv.size(), ooff.data(), cnt.data());
+		if (rc == WM_ENOMEM && strstr(g_err, "minimizer output pool")) { mv.resize(bases + n + 1); rc = sketch_batch_impl(c, n, codes.get(), tot, off.data(), len.data(), 0, mv.data(), mv.size(), ooff.data(), cnt.data()); }
+		if (rc) break;
+		for (int i = 0; i < n; ++i)
+			for (int t = 0; t < cnt[i]; ++t) { wm::m128 e; e.x = mv[ooff[i] + t].x; e.y = mv[ooff[i] + t].y | (uint64_t)(g0 + i) << 32; all.push_back(e); }     // rid (src/sketch.c:172)
+		g0 = g1;
+	}
+	c->d_bloom = 0;
+	hipFree(d_bloom);
+	if (rc) { delete h; return rc; }
+	const double t2 = now_ms();
+	const double n_mini = (double)all.size();
+	wm::index_table_from_minimizers(ix, all);
+	if (stats) { stats[0] = (t1 - t0) * 1e-3; stats[1] = (t2 - t1) * 1e-3; stats[2] = (now_ms() - t2) * 1e-3; stats[3] = n_mini; }
+	*out = h;
+	return WM_OK;
+}
+
 struct ArenaMark { wm_ctx_t *c; size_t m; ArenaMark(wm_ctx_t *c_) : c(c_), m(c_->arena_used) {} ~ArenaMark() { c->arena_used = m; } };
 
 // resident (optional, n flags): sequence i starts at code seq_off[i] of the resident read codes (wm_reads_upload) instead of `seqs`
@@ -972,7 +1034,7 @@ extern "C" int wm_sketch_batch(wm_ctx_t *c, int n, const uint8_t *seqs, size_t s
 static int sketch_batch_impl(wm_ctx_t *c, int n, const uint8_t *seqs, size_t seqs_bytes, const uint64_t *seq_off, const int32_t *len, const uint8_t *resident,
                              wm128_t *out, size_t out_cap, uint64_t *out_off, int32_t *counts)
 {
-	if (!c || !c->have_index) return set_err(WM_EINVAL, "wm_index_upload has not been called on this context");
+	if (!c || !c->d_bloom) return set_err(WM_EINVAL, "wm_index_upload has not been called on this context");
 	if (n <= 0) return WM_OK;
 	HIPCHK(hipSetDevice(c->device));
 	const int w = c->skp.w;

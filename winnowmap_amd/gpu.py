@@ -208,6 +208,17 @@ class Index:
             return
         _chk(L.wm_index_build(os.fsencode(fasta), os.fsencode(kmer_file) if kmer_file else None, k, w, n_threads, C.byref(self._h)))
 
+    @staticmethod
+    def build_on_device(ctx, fasta, kmer_file=None, k=15, w=50, n_threads=8):
+        """wm_index_build_gpu: the reference is sketched on the device (one wavefront per contig). Returns (Index, stats dict)."""
+        L = lib()
+        _bind_map(L)
+        L.wm_index_build_gpu.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]
+        h = C.c_void_p()
+        st = np.zeros(4, np.float64)
+        _chk(L.wm_index_build_gpu(ctx._h, os.fsencode(fasta), os.fsencode(kmer_file) if kmer_file else None, k, w, n_threads, C.byref(h), st.ctypes.data))
+        return Index(_handle=h), {"read_pack_s": float(st[0]), "device_sketch_s": float(st[1]), "table_s": float(st[2]), "minimizers": int(st[3])}
+
     def export_arrays(self):
         """(sizes9, [S, hkey, hval, P, bloom, seq_meta, names]) as numpy arrays — the payload of the RCCL broadcast."""
         L = lib()
