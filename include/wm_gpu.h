@@ -145,6 +145,10 @@ const uint64_t *wm_index_get(const wm_index_t *idx, uint64_t minier, int *n);
 /* The `-W` list of a FASTA (canonical k-mers above the 0.9998-distinct count threshold, README.md:29-30): what
  * `meryl count k=15` + `meryl print greater-than distinct=0.9998` produce; meryl cannot be built offline. */
 int wm_write_repetitive_kmers(const char *fasta, int k, double distinct, const char *out_path, uint64_t *n_out);
+/* The same list counted on the device: canonical k-mer of every reference position -> radix sort -> run lengths -> count histogram -> meryl's
+ * threshold -> the k-mers above it (references below 4 Gbase; byte-identical output). stats (optional, 4 doubles): seconds reading +
+ * encoding, on the device (incl. transfers), writing; distinct k-mers. */
+int wm_write_repetitive_kmers_gpu(wm_ctx_t *ctx, const char *fasta, int k, double distinct, const char *out_path, uint64_t *n_out, double *stats);
 /* Flat-array export / import (multi-GPU: one rank builds, RCCL broadcasts the arrays, the others import).
  * Call wm_index_export with S == NULL to obtain sizes9 = {|S| u32, |hkey|=|hval| u64, |P| u64, |bloom| bytes,
  * n_seq, name bytes, packed k/w/hbits/flag, bloom bits, bloom salts}; seq_meta holds (offset, len) per sequence. */

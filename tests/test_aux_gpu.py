@@ -203,3 +203,26 @@ def test_index_build_on_device_equals_host_build(tmp_path):
         dev.upload(c)                                                 # and the context is usable afterwards
         dev.close(); c.close()
     host.close()
+
+
+@pytest.mark.parametrize("k,distinct", [(15, 0.9998), (19, 0.99), (11, 0.5)])
+def test_repetitive_kmer_list_on_device_equals_host_list(tmp_path, k, distinct):
+    """the -W list (meryl `count` + `print greater-than distinct=`) counted on the device — k-mer keys, radix sort, run lengths,
+    histogram, threshold, selection — must be the file the host counter writes (which tests/test_kmers.py pins to the numpy restatement of
+    meryl's rule), for contigs with N and several contigs (no k-mer may span two contigs)."""
+    from winnowmap_amd import synth
+    ref = synth.make_reference(3, 400000, 40 + k, repeat_frac=0.2)
+    ref[1][1000:1010] = 4
+    ref.append(ref[0][:k - 1].copy())              # shorter than k: contributes nothing
+    ref.append(ref[0][:k].copy())                  # exactly one k-mer
+    fa = str(tmp_path / "ref.fa")
+    synth.write_fasta(fa, ref)
+    a, b = str(tmp_path / "host.txt"), str(tmp_path / "dev.txt")
+    n_host = gpu.write_repetitive_kmers(fa, k, a, distinct)
+    c = gpu.Context(0, 1 << 30)
+    n_dev, st = gpu.write_repetitive_kmers_gpu(c, fa, k, b, distinct)
+    c.close()
+    assert n_dev == n_host and n_host > 0
+    assert open(a, "rb").read() == open(b, "rb").read()
+    km, cnt = synth.repetitive_kmers(ref, k, distinct)
+    assert len(km) == n_dev

@@ -16,3 +16,7 @@ hs, ha = host.export_arrays(); ds, da = dev.export_arrays()
 same = bool(np.array_equal(hs, ds) and all(np.array_equal(a, b) for a, b in zip(ha, da)))
 print("reference %.0f Mb: host build %.2f s | device build %.2f s (read+pack %.2f, device sketch %.2f, table %.2f) | %d minimizers | identical arrays: %s" %
       (mb, t_host, t_dev, st["read_pack_s"], st["device_sketch_s"], st["table_s"], st["minimizers"], same))
+t0 = time.time(); n_dev, kst = gpu.write_repetitive_kmers_gpu(c, fa, 15, tmp + "/rep_dev.txt"); t_k = time.time() - t0
+t0 = time.time(); n_host = gpu.write_repetitive_kmers(fa, 15, tmp + "/rep_host.txt"); t_kh = time.time() - t0
+print("-W list: host %.2f s | device %.2f s (read+encode %.2f, device %.2f, write %.2f) | %d k-mers of %d distinct | identical files: %s" %
+      (t_kh, t_k, kst["read_encode_s"], kst["device_s"], kst["write_s"], n_dev, kst["distinct_kmers"], open(tmp + "/rep_dev.txt", "rb").read() == open(tmp + "/rep_host.txt", "rb").read() and n_dev == n_host))

@@ -3,6 +3,9 @@
 // context's stream, measures kernel time with HIP events on that stream, and gathers results.
 // There is no CPU compute path in this file: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <string.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>          // device radix sort + run-length encode for the k-mer counter (wm_write_repetitive_kmers_gpu)
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -888,6 +891,130 @@ extern "C" int wm_write_repetitive_kmers(const char *fasta, int k, double distin
 	std::vector<std::string> names, seqs; std::string err;
 	if (wm::read_fastx(fasta, names, seqs, 0, 0, err) < 0) return set_err(WM_EINVAL, "%s", err.c_str());
 	if (wm::write_repetitive_kmers(seqs, k, distinct, out_path, n_out, err) < 0) return set_err(WM_EINVAL, "%s", err.c_str());
+	return WM_OK;
+}
+
+// ---- the -W list on the device: canonical k-mers of the whole reference -> radix sort -> run lengths -> count histogram ->
+//      meryl's threshold (ext/meryl/src/meryl/merylOp-nextMer.C:103-115) -> the k-mers above it. Same output as wm_write_repetitive_kmers.
+// codes: all contigs back to back, one code-4 byte between them; key of position i = canonical k-mer ending there, or `inv` (= 4^k, sorts last)
+__global__ __launch_bounds__(256) void kmer_key_kernel(const uint8_t *__restrict__ codes, uint64_t n, int k, uint64_t inv, uint64_t *__restrict__ keys)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	uint64_t fw = 0, rc = 0;
+	bool ok = i + 1 >= (uint64_t)k;
+	if (ok)
+		for (int j = 0; j < k; ++j) {              // base j steps back: digit j of the forward k-mer, digit k-1-j of the reverse complement
+			const uint64_t c = codes[i - j];
+			ok &= c < 4;
+			fw |= (c & 3) << (2 * j);
+			rc |= ((c & 3) ^ 3) << (2 * (k - 1 - j));
+		}
+	keys[i] = ok ? (fw < rc ? fw : rc) : inv;
+}
+__global__ __launch_bounds__(256) void kmer_hist_kernel(const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ n_runs, uint64_t inv,
+                                                        unsigned long long *__restrict__ hist, uint32_t hcap)
+{
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= *n_runs || uniq[i] == inv) return;
+	const uint32_t c = cnt[i] < hcap - 1 ? cnt[i] : hcap - 1;
+	atomicAdd(&hist[c], 1ULL);
+}
+__global__ __launch_bounds__(256) void kmer_select_kernel(const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ n_runs, uint64_t inv,
+                                                          uint32_t thr, uint64_t *__restrict__ out_key, uint32_t *__restrict__ out_cnt, unsigned long long *__restrict__ n_sel, uint64_t cap)
+{
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= *n_runs || uniq[i] == inv || cnt[i] <= thr) return;
+	const unsigned long long o = atomicAdd(n_sel, 1ULL);
+	if (o < cap) { out_key[o] = uniq[i]; out_cnt[o] = cnt[i]; }
+}
+
+extern "C" int wm_write_repetitive_kmers_gpu(wm_ctx_t *c, const char *fasta, int k, double distinct, const char *out_path, uint64_t *n_out, double *stats)
+{
+	if (!c) return set_err(WM_EINVAL, "null context");
+	if (k < 1 || k > 28) return set_err(WM_EINVAL, "k out of range");
+	HIPCHK(hipSetDevice(c->device));
+	const double t0 = now_ms();
+	std::vector<std::string> names, seqs; std::string err;
+	if (wm::read_fastx(fasta, names, seqs, 0, 0, err) < 0) return set_err(WM_EINVAL, "%s", err.c_str());
+	uint64_t n = 0;
+	for (const std::string &sq : seqs) n += sq.size() + 1;
+	if (n >= ((uint64_t)1 << 32)) return set_err(WM_EINVAL, "references of 4 Gbase and more must be counted in parts");   // (run counts and indices are 32 bits)
+	std::unique_ptr<uint8_t[]> codes(new uint8_t[n + 1]);
+	{
+		std::vector<uint64_t> off(seqs.size());
+		uint64_t o = 0;
+		for (size_t i = 0; i < seqs.size(); ++i) { off[i] = o; o += seqs[i].size() + 1; }
+		wm::parallel_for(16, seqs.size(), [&](size_t i) { uint8_t *d = codes.get() + off[i]; const std::string &sq = seqs[i]; for (size_t j = 0; j < sq.size(); ++j) d[j] = wm::nt4_table[(uint8_t)sq[j]]; d[sq.size()] = 4; });
+	}
+	const double t1 = now_ms();
+	const uint64_t inv = 1ULL << 2 * k;
+	const uint32_t hcap = 1u << 20;
+	uint8_t *d_codes = 0; uint64_t *d_keys = 0, *d_sorted = 0, *d_uniq = 0, *d_okey = 0; uint32_t *d_cnt = 0, *d_nruns = 0, *d_ocnt = 0; unsigned long long *d_hist = 0, *d_nsel = 0; void *d_tmp = 0;
+	auto cleanup = [&]() { hipFree(d_codes); hipFree(d_keys); hipFree(d_sorted); hipFree(d_uniq); hipFree(d_cnt); hipFree(d_nruns); hipFree(d_hist); hipFree(d_nsel); hipFree(d_tmp); hipFree(d_okey); hipFree(d_ocnt); };
+#define KM_CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return set_err(WM_ENOMEM, "%s failed: %s", #x, hipGetErrorString(e_)); } } while (0)
+	KM_CHK(hipMalloc((void**)&d_codes, n + 8));
+	KM_CHK(hipMalloc((void**)&d_keys, n * 8 + 8)); KM_CHK(hipMalloc((void**)&d_sorted, n * 8 + 8));
+	KM_CHK(hipMalloc((void**)&d_nruns, 8)); KM_CHK(hipMalloc((void**)&d_hist, (size_t)hcap * 8)); KM_CHK(hipMalloc((void**)&d_nsel, 8));
+	KM_CHK(hipMemcpy(d_codes, codes.get(), n, hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(kmer_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_codes, n, k, inv, d_keys);
+	size_t tmp_bytes = 0;
+	KM_CHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, d_keys, d_sorted, (size_t)n, 0, 2 * k + 1, c->stream));
+	KM_CHK(hipMalloc(&d_tmp, tmp_bytes + 8));
+	KM_CHK(rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_keys, d_sorted, (size_t)n, 0, 2 * k + 1, c->stream));
+	KM_CHK(hipStreamSynchronize(c->stream));
+	hipFree(d_tmp); d_tmp = 0; hipFree(d_keys); d_keys = 0;
+	KM_CHK(hipMalloc((void**)&d_uniq, n * 8 + 8)); KM_CHK(hipMalloc((void**)&d_cnt, n * 4 + 8));
+	tmp_bytes = 0;
+	KM_CHK(rocprim::run_length_encode(nullptr, tmp_bytes, d_sorted, (unsigned int)n, d_uniq, d_cnt, d_nruns, c->stream));
+	KM_CHK(hipMalloc(&d_tmp, tmp_bytes + 8));
+	KM_CHK(rocprim::run_length_encode(d_tmp, tmp_bytes, d_sorted, (unsigned int)n, d_uniq, d_cnt, d_nruns, c->stream));
+	KM_CHK(hipMemsetAsync(d_hist, 0, (size_t)hcap * 8, c->stream));
+	uint32_t n_runs = 0;
+	KM_CHK(hipMemcpyAsync(&n_runs, d_nruns, 4, hipMemcpyDeviceToHost, c->stream));
+	KM_CHK(hipStreamSynchronize(c->stream));
+	hipLaunchKernelGGL(kmer_hist_kernel, dim3((n_runs + 255) / 256 + 1), dim3(256), 0, c->stream, d_uniq, d_cnt, d_nruns, inv, d_hist, hcap);
+	std::vector<unsigned long long> hist(hcap);
+	KM_CHK(hipMemcpyAsync(hist.data(), d_hist, (size_t)hcap * 8, hipMemcpyDeviceToHost, c->stream));
+	KM_CHK(hipStreamSynchronize(c->stream));
+	// threshold exactly as merylOp-nextMer.C:103-115 (and host/wm_kmers.cpp): truncated target, only count values that occur
+	uint64_t n_distinct = 0, cum = 0, thr = 0, n_sel = 0;
+	for (uint32_t cc = 1; cc < hcap; ++cc) n_distinct += hist[cc];
+	const uint64_t target = (uint64_t)(distinct * (double)n_distinct);
+	bool found = false;
+	for (uint32_t cc = 1; cc < hcap; ++cc) {
+		if (hist[cc] == 0) continue;
+		cum += hist[cc];
+		if (cum >= target) { thr = cc; found = true; break; }
+	}
+	if (found && thr == hcap - 1) { cleanup(); return set_err(WM_EINTERNAL, "count threshold beyond the device histogram (%u): use wm_write_repetitive_kmers", hcap); }
+	if (!found) thr = 0;
+	for (uint32_t cc = (uint32_t)thr + 1; cc < hcap; ++cc) n_sel += hist[cc];
+	KM_CHK(hipMalloc((void**)&d_okey, n_sel * 8 + 8)); KM_CHK(hipMalloc((void**)&d_ocnt, n_sel * 4 + 8));
+	KM_CHK(hipMemsetAsync(d_nsel, 0, 8, c->stream));
+	hipLaunchKernelGGL(kmer_select_kernel, dim3((n_runs + 255) / 256 + 1), dim3(256), 0, c->stream, d_uniq, d_cnt, d_nruns, inv, (uint32_t)thr, d_okey, d_ocnt, d_nsel, n_sel);
+	std::vector<uint64_t> okey(n_sel); std::vector<uint32_t> ocnt(n_sel);
+	if (n_sel) { KM_CHK(hipMemcpyAsync(okey.data(), d_okey, n_sel * 8, hipMemcpyDeviceToHost, c->stream)); KM_CHK(hipMemcpyAsync(ocnt.data(), d_ocnt, n_sel * 4, hipMemcpyDeviceToHost, c->stream)); }
+	KM_CHK(hipStreamSynchronize(c->stream));
+	KM_CHK(hipGetLastError());
+#undef KM_CHK
+	cleanup();
+	const double t2 = now_ms();
+	std::vector<uint32_t> ord(n_sel);
+	for (uint32_t i = 0; i < n_sel; ++i) ord[i] = i;
+	std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return okey[a] < okey[b]; });      // (the appends arrive in any order)
+	FILE *fp = fopen(out_path, "w");
+	if (!fp) return set_err(WM_EINVAL, "cannot write %s", out_path);
+	char buf[40];
+	for (uint32_t oi : ord) {
+		const uint64_t km = okey[oi];
+		for (int i = 0; i < k; ++i) buf[i] = "ACGT"[km >> (2 * (k - 1 - i)) & 3];
+		buf[k] = 0;
+		fprintf(fp, "%s\t%u\n", buf, ocnt[oi]);
+	}
+	if (fclose(fp) != 0) return set_err(WM_EINVAL, "write error on %s", out_path);
+	if (n_out) *n_out = n_sel;
+	if (stats) { stats[0] = (t1 - t0) * 1e-3; stats[1] = (t2 - t1) * 1e-3; stats[2] = (now_ms() - t2) * 1e-3; stats[3] = (double)n_distinct; }
 	return WM_OK;
 }
 

@@ -193,6 +193,16 @@ def write_repetitive_kmers(fasta, k, out_path, distinct=0.9998):
     return int(n.value)
 
 
+def write_repetitive_kmers_gpu(ctx, fasta, k, out_path, distinct=0.9998):
+    """The -W list counted on the device (wm_write_repetitive_kmers_gpu). Returns (number of k-mers written, stats dict)."""
+    L = lib()
+    L.wm_write_repetitive_kmers_gpu.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_double, C.c_char_p, C.POINTER(C.c_uint64), C.c_void_p]
+    n = C.c_uint64()
+    st = np.zeros(4, np.float64)
+    _chk(L.wm_write_repetitive_kmers_gpu(ctx._h, os.fsencode(fasta), k, distinct, os.fsencode(out_path), C.byref(n), st.ctypes.data))
+    return int(n.value), {"read_encode_s": float(st[0]), "device_s": float(st[1]), "write_s": float(st[2]), "distinct_kmers": int(st[3])}
+
+
 _EXPORT_DTYPES = (np.uint32, np.uint64, np.uint64, np.uint64, np.uint8, np.uint64, np.uint8)
 
 
