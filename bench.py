@@ -47,7 +47,8 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def make_workload(ref_mb, tmp):
+def make_workload(ref_mb, tmp, ctx=None):
+    """the synthetic reference and its -W list (counted on the device when a context is given, on the host otherwise: same file)"""
     n_contigs = max(1, int(round(ref_mb / 10.0)))
     clen = int(ref_mb * 1e6 / n_contigs)
     t0 = time.time()
@@ -55,8 +56,12 @@ def make_workload(ref_mb, tmp):
     fa = os.path.join(tmp, "ref.fa")
     synth.write_fasta(fa, ref, prefix="ctg")
     kf = os.path.join(tmp, "repetitive_k15.txt")
-    n_k = gpu.write_repetitive_kmers(fa, 15, kf)
-    log("reference %d x %d bp, -W list %d k-mers (%.1fs)" % (n_contigs, clen, n_k, time.time() - t0))
+    t1 = time.time()
+    if ctx is not None:
+        n_k, st = gpu.write_repetitive_kmers_gpu(ctx, fa, 15, kf)
+    else:
+        n_k = gpu.write_repetitive_kmers(fa, 15, kf)
+    log("reference %d x %d bp (%.1fs), -W list %d k-mers (%.1fs on the %s)" % (n_contigs, clen, t1 - t0, n_k, time.time() - t1, "device" if ctx is not None else "host"))
     return ref, fa, kf
 
 
@@ -253,10 +258,15 @@ def main():
 
     # ---- reference + index: rank 0 builds, RCCL broadcasts the flat arrays ----
     t0 = time.time()
+    # device contexts (own streams + arena each: that many batched calls are on the device at once) share the 288 GB of HBM
+    n_ctx = int(os.environ.setdefault("WM_CONTEXTS", "6"))
+    arena = int(float(os.environ.get("WM_BENCH_ARENA_GB", min(48.0, 216.0 / n_ctx))) * (1 << 30))
+    ctx = gpu.Context(local, arena)
     if rank == 0:
-        ref, fa, kf = make_workload(args.ref_mb, tmp)
-        idx = gpu.Index(fa, kf, k=15, w=50, n_threads=min(64, n_cores))      # map-ont and map-pb: k=15, w=50 (src/options.c:94-103)
-        log("index: %d minimizers (%.1fs)" % (idx.n_minimizers, time.time() - t0))
+        ref, fa, kf = make_workload(args.ref_mb, tmp, ctx)
+        t_i = time.time()
+        idx, ist = gpu.Index.build_on_device(ctx, fa, kf, k=15, w=50, n_threads=min(64, n_cores))      # map-ont and map-pb: k=15, w=50 (src/options.c:94-103)
+        log("index: %d minimizers, built in %.1fs (reference sketched on the device in %.2fs)" % (idx.n_minimizers, time.time() - t_i, ist["device_sketch_s"]))
     if dist is not None:
         dev = torch.device("cuda", local)
         idx = wmdist.broadcast_index(idx if rank == 0 else None, rank, dist, dev)      # RCCL over xGMI, one broadcast per flat array
@@ -264,10 +274,6 @@ def main():
         if rank != 0:
             n_contigs = max(1, int(round(args.ref_mb / 10.0)))
             ref = synth.make_reference(n_contigs, int(args.ref_mb * 1e6 / n_contigs), 3, repeat_frac=0.10)
-    # device contexts (own streams + arena each: that many batched calls are on the device at once) share the 288 GB of HBM
-    n_ctx = int(os.environ.setdefault("WM_CONTEXTS", "6"))
-    arena = int(float(os.environ.get("WM_BENCH_ARENA_GB", min(48.0, 216.0 / n_ctx))) * (1 << 30))
-    ctx = gpu.Context(local, arena)
     idx.upload(ctx)
     mapper = gpu.Mapper(ctx, idx, cfg["preset"], gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
     if n_threads > 1:

@@ -161,6 +161,10 @@ int wm_index_import(const uint64_t *sizes9, const uint32_t *S, const uint64_t *h
 /* mm_sketch of n sequences of 0..4 codes (rid = 0). Minimizers of sequence i: out[out_off[i] .. +counts[i]). */
 int wm_sketch_batch(wm_ctx_t *ctx, int n, const uint8_t *seqs, size_t seqs_bytes, const uint64_t *seq_off, const int32_t *len,
                     wm128_t *out, size_t out_cap, uint64_t *out_off, int32_t *counts);
+/* wm_sketch_batch without an index on the context: the caller supplies the -W bloom filter (the bit table and hash salts of the reference's
+ * bloom_filter object, ext/bloom/bloom_filter.hpp; table_bits = 0 / bits = NULL for none) and the sketch parameters. This is what a
+ * link-level substitute of mm_sketch (src/mmpriv.h:61) needs: see oracle/wm_subst.cpp. */
+int wm_sketch_set_filter(wm_ctx_t *ctx, const uint8_t *bits, size_t n_bytes, uint64_t table_bits, uint32_t salt0, uint32_t salt1, int k, int w);
 /* collect_seed_hits: minimizers of job i are mini[mini_off[i] .. +n_mini[i]); anchors (sorted by x with the
  * reference's radix_sort_128x permutation) go to out[out_off[i] .. +n_anchors[i]); rep_len as src/map.c:126. */
 int wm_seed_batch(wm_ctx_t *ctx, int n, const wm128_t *mini, const uint64_t *mini_off, const int32_t *n_mini, const int32_t *qlen,

@@ -230,6 +230,7 @@ struct wm_ctx_s {
 	int hbits;
 	wm_sketch_params_t skp;
 	bool have_index, owns_index;
+	bool owns_filter;                           // d_bloom came from wm_sketch_set_filter (no index on this context)
 	int host_threads;                           // threads the batched entry points may use for their host-side packing / sorting
 	uint8_t *pin; size_t pin_bytes, pin_used;   // pinned host slab for staging (allocated on first use)
 	int *pin_small;                             // a few pinned words for scalar read-backs (an async copy into pageable memory makes the caller spin until the stream gets there)
@@ -321,6 +322,7 @@ extern "C" int wm_ctx_create(int device, size_t arena_bytes, wm_ctx_t **out)
 	for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
 	HIPCHK(hipEventCreateWithFlags(&c->sync_ev, hipEventBlockingSync | hipEventDisableTiming));
 	c->arena_used = 0; c->last_ms = 0; c->aux_ms = 0; c->host_threads = 1; c->pin = 0; c->pin_bytes = c->pin_used = 0; c->have_index = false; c->owns_index = false; c->d_hkey = c->d_hval = c->d_P = 0; c->d_bloom = 0;
+	c->owns_filter = false;
 	c->pin_small = 0;
 	if (hipHostMalloc((void**)&c->pin_small, 256, hipHostMallocDefault) != hipSuccess) { c->pin_small = 0; (void)hipGetLastError(); }
 	c->d_S = 0; c->d_reads = 0; c->reads_bytes = c->reads_cap = 0; c->owns_reads = false;
@@ -344,6 +346,7 @@ extern "C" void wm_ctx_destroy(wm_ctx_t *c)
 	hipFree(c->arena);
 	if (c->have_index && c->owns_index) { hipFree(c->d_hkey); hipFree(c->d_hval); hipFree(c->d_P); hipFree(c->d_bloom); hipFree(c->d_S); }
 	if (c->d_reads && c->owns_reads) hipFree(c->d_reads);
+	if (!c->have_index && c->owns_filter && c->d_bloom) hipFree(c->d_bloom);
 	delete c;
 }
 
@@ -1067,6 +1070,8 @@ extern "C" int wm_index_upload(wm_ctx_t *c, const wm_index_t *h)
 	const wm::Index &ix = h->ix;
 	if (ix.bloom.table_bits >= ((uint64_t)1 << 32)) return set_err(WM_EINVAL, "bloom table of %llu bits not supported on device", (unsigned long long)ix.bloom.table_bits);
 	if (c->have_index && c->owns_index) { hipFree(c->d_hkey); hipFree(c->d_hval); hipFree(c->d_P); hipFree(c->d_bloom); hipFree(c->d_S); }
+	if (!c->have_index && c->owns_filter && c->d_bloom) { hipFree(c->d_bloom); c->d_bloom = 0; }
+	c->owns_filter = false;
 	c->have_index = false; c->d_S = 0; c->seq_off.clear(); c->seq_len.clear();
 	HIPCHK(hipMalloc((void**)&c->d_hkey, ix.hkey.size() * 8 + 8));
 	HIPCHK(hipMalloc((void**)&c->d_hval, ix.hval.size() * 8 + 8));
@@ -1113,6 +1118,8 @@ extern "C" int wm_index_build_gpu(wm_ctx_t *c, const char *fasta, const char *km
 	if (hipMalloc((void**)&d_bloom, ix.bloom.bits.size() + 8) != hipSuccess || hipMemcpy(d_bloom, ix.bloom.bits.data(), ix.bloom.bits.size(), hipMemcpyHostToDevice) != hipSuccess) {
 		delete h; if (d_bloom) hipFree(d_bloom); return set_err(WM_ENOMEM, "cannot place the bloom filter on the device");
 	}
+	if (c->owns_filter && c->d_bloom) hipFree(c->d_bloom);
+	c->owns_filter = false;
 	c->d_bloom = d_bloom;
 	c->skp.w = w; c->skp.k = k; c->skp.table_bits = (uint32_t)ix.bloom.table_bits; c->skp.salt0 = ix.bloom.salt[0]; c->skp.salt1 = ix.bloom.salt[1];
 	std::vector<wm::m128> all;
@@ -1153,6 +1160,23 @@ struct ArenaMark { wm_ctx_t *c; size_t m; ArenaMark(wm_ctx_t *c_) : c(c_), m(c_-
 // resident (optional, n flags): sequence i starts at code seq_off[i] of the resident read codes (wm_reads_upload) instead of `seqs`
 static int sketch_batch_impl(wm_ctx_t *c, int n, const uint8_t *seqs, size_t seqs_bytes, const uint64_t *seq_off, const int32_t *len, const uint8_t *resident,
                              wm128_t *out, size_t out_cap, uint64_t *out_off, int32_t *counts);
+extern "C" int wm_sketch_set_filter(wm_ctx_t *c, const uint8_t *bits, size_t n_bytes, uint64_t table_bits, uint32_t salt0, uint32_t salt1, int k, int w)
+{
+	if (!c) return set_err(WM_EINVAL, "null context");
+	if (c->have_index) return set_err(WM_EINVAL, "the context holds an index (its filter is in use)");
+	if (k < 1 || k > 28 || w < 1 || w > 255) return set_err(WM_EINVAL, "need 0 < k <= 28 and 0 < w < 256 (src/sketch.c:140)");
+	if (table_bits >= ((uint64_t)1 << 32)) return set_err(WM_EINVAL, "bloom table of %llu bits not supported on device", (unsigned long long)table_bits);
+	HIPCHK(hipSetDevice(c->device));
+	static const uint8_t none[8] = {0, 0, 0, 0, 0, 0, 0, 0};           // no filter: a table of 8 zero bits never matches
+	if (!bits || table_bits == 0) { bits = none; n_bytes = 1; table_bits = 8; }
+	if (c->d_bloom) { hipFree(c->d_bloom); c->d_bloom = 0; }
+	HIPCHK(hipMalloc((void**)&c->d_bloom, n_bytes + 8));
+	HIPCHK(hipMemcpy(c->d_bloom, bits, n_bytes, hipMemcpyHostToDevice));
+	c->skp.w = w; c->skp.k = k; c->skp.table_bits = (uint32_t)table_bits; c->skp.salt0 = salt0; c->skp.salt1 = salt1;
+	c->owns_filter = true;
+	return WM_OK;
+}
+
 extern "C" int wm_sketch_batch(wm_ctx_t *c, int n, const uint8_t *seqs, size_t seqs_bytes, const uint64_t *seq_off, const int32_t *len,
                                wm128_t *out, size_t out_cap, uint64_t *out_off, int32_t *counts)
 {
