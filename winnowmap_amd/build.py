@@ -34,6 +34,8 @@ def build_oracle():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], stdout=subprocess.DEVNULL)
     if os.path.exists("/root/reference/src/map.c"):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref", "-j8"], stdout=subprocess.DEVNULL)
+        if os.path.exists(LIB):      # the reference's CLI bound to / substituted by libwmgpu.so (oracle/wm_binding.cpp, oracle/wm_subst.cpp)
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "wm", "subst", "-j8"], stdout=subprocess.DEVNULL)
 
 
 def build_emu():

@@ -11,6 +11,7 @@
 #include <string.h>
 #include <stdarg.h>
 #include <vector>
+#include <new>
 #include <algorithm>
 #include <numeric>
 #include <thread>
@@ -30,7 +31,7 @@ template <class T> struct UBuf {
 		const size_t bytes = (n_ ? n_ : 1) * sizeof(T);
 		if (c) { p = (T*)pin_take(c, bytes, &mark); pinned = p != 0; }
 		if (!p) p = (T*)malloc(bytes);
-		if (!p) abort();
+		if (!p) throw std::bad_alloc();         // (caught where the batched calls are issued: reported as an error, never abort())
 	}
 	~UBuf() { if (pinned) pin_release(c, mark); else free(p); }
 	UBuf(const UBuf&) = delete; UBuf &operator=(const UBuf&) = delete;
@@ -679,7 +680,7 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 }
 
 extern "C" int wm_ksw_dev_fetch(wm_ctx_t *c, wm_ksw_dev_batch_t *b, wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used)
-{
+try {
 	HIPCHK(hipSetDevice(c->device));
 	const int n = b->n_jobs;
 	if (cigar_used) *cigar_used = b->total_ops;
@@ -699,6 +700,7 @@ extern "C" int wm_ksw_dev_fetch(wm_ctx_t *c, wm_ksw_dev_batch_t *b, wm_ksw_resul
 	});
 	return WM_OK;
 }
+catch (const std::bad_alloc &) { return set_err(WM_ENOMEM, "out of host memory"); }
 
 extern "C" int wm_ksw_dev_stats(const wm_ksw_dev_batch_t *b, uint64_t *cells, uint64_t *tb_bytes, float *dp_ms, float *bt_ms)
 {
@@ -1184,7 +1186,7 @@ extern "C" int wm_sketch_batch(wm_ctx_t *c, int n, const uint8_t *seqs, size_t s
 }
 static int sketch_batch_impl(wm_ctx_t *c, int n, const uint8_t *seqs, size_t seqs_bytes, const uint64_t *seq_off, const int32_t *len, const uint8_t *resident,
                              wm128_t *out, size_t out_cap, uint64_t *out_off, int32_t *counts)
-{
+try {
 	if (!c || !c->d_bloom) return set_err(WM_EINVAL, "wm_index_upload has not been called on this context");
 	if (n <= 0) return WM_OK;
 	HIPCHK(hipSetDevice(c->device));
@@ -1264,10 +1266,11 @@ static int sketch_batch_impl(wm_ctx_t *c, int n, const uint8_t *seqs, size_t seq
 	c->aux_ms = ms_total;
 	return WM_OK;
 }
+catch (const std::bad_alloc &) { return set_err(WM_ENOMEM, "out of host memory"); }
 
 extern "C" int wm_seed_batch(wm_ctx_t *c, int n, const wm128_t *mini, const uint64_t *mini_off, const int32_t *n_mini, const int32_t *qlen,
                              int max_occ, int64_t flag, wm128_t *out, size_t out_cap, uint64_t *out_off, int32_t *n_anchors, int32_t *rep_len)
-{
+try {
 	if (!c || !c->have_index) return set_err(WM_EINVAL, "wm_index_upload has not been called on this context");
 	if (n <= 0) return WM_OK;
 	HIPCHK(hipSetDevice(c->device));
@@ -1337,10 +1340,11 @@ extern "C" int wm_seed_batch(wm_ctx_t *c, int n, const wm128_t *mini, const uint
 	c->aux_ms = ms_total;
 	return WM_OK;
 }
+catch (const std::bad_alloc &) { return set_err(WM_ENOMEM, "out of host memory"); }
 
 extern "C" int wm_chain_batch(wm_ctx_t *c, int n, wm128_t *a, const uint64_t *a_off, const int32_t *n_a, const wm_chain_par_t *par,
                               uint64_t *u, uint64_t *u_off, int32_t *n_u, int32_t *n_v)
-{
+try {
 	if (!c) return set_err(WM_EINVAL, "null context");
 	if (n <= 0) return WM_OK;
 	HIPCHK(hipSetDevice(c->device));
@@ -1431,6 +1435,7 @@ extern "C" int wm_chain_batch(wm_ctx_t *c, int n, wm128_t *a, const uint64_t *a_
 	                   tt1 - tt0, tt2 - tt1, tt3 - tt2, c->aux_ms, now_ms() - tt3);
 	return WM_OK;
 }
+catch (const std::bad_alloc &) { return set_err(WM_ENOMEM, "out of host memory"); }
 
 // ======================================================================================================
 // GpuOps: the product implementation of the mapper's device operations
@@ -1602,7 +1607,8 @@ struct GpuOps : wm::DeviceOps {
 	{
 		int i;
 		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !free_.empty(); }); i = free_.back(); free_.pop_back(); }
-		f(ctxs[i]);
+		try { f(ctxs[i]); }
+		catch (const std::exception &e) { if (ctxs[i].error.empty()) ctxs[i].error = std::string("batched device call: ") + e.what(); }
 		{ std::lock_guard<std::mutex> lk(mu); free_.push_back(i); }
 		cv.notify_one();
 	}
