@@ -211,7 +211,8 @@ bool spawn_read(Scheduler &sch, const Index &idx, const MapOpt &opt, const MapOp
 }
 } // namespace
 
-void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::vector<ReadIn> &reads, std::vector<ReadOut> &out, MapStats *stats, int n_threads)
+void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::vector<ReadIn> &reads, std::vector<ReadOut> &out, MapStats *stats, int n_threads,
+               const std::function<void(size_t)> *on_read_done)
 {
 	out.assign(reads.size(), ReadOut());
 	wm_ksw_score_t sc;
@@ -259,9 +260,10 @@ void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::v
 			const size_t i = feed[t].next;
 			if (i >= tasks.size()) return;
 			feed[t].next += (size_t)T;
-			const bool spawned = spawn_read(*sch[t], idx, opt, o2, tasks[i], [&admit, t]() { admit(t); });
+			const bool spawned = spawn_read(*sch[t], idx, opt, o2, tasks[i], [&admit, t, i, on_read_done]() { if (on_read_done) (*on_read_done)(i); admit(t); });
 			sch[t]->release(1);
 			if (spawned) return;
+			if (on_read_done) (*on_read_done)(i);
 		}
 	};
 	auto work = [&](int t) {
@@ -273,11 +275,11 @@ void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::v
 	work(0);
 	for (auto &x : th) x.join();
 	if (stats) {
-		stats->n_flush += hub.n_batches[OP_SKETCH] + hub.n_batches[OP_SEED] + hub.n_batches[OP_CHAIN] + hub.n_batches[OP_KSW] + hub.n_batches[OP_KSW_HEAVY];
-		stats->n_ksw += hub.n_reqs[OP_KSW] + hub.n_reqs[OP_KSW_HEAVY]; stats->n_chain += hub.n_reqs[OP_CHAIN]; stats->n_seed += hub.n_reqs[OP_SEED]; stats->n_sketch += hub.n_reqs[OP_SKETCH];
+		stats->n_flush += hub.n_batches[OP_SKETCH] + hub.n_batches[OP_SEED] + hub.n_batches[OP_CHAIN] + hub.n_batches[OP_KSW] + hub.n_batches[OP_KSW_HEAVY] + hub.n_batches[OP_KSW_HUGE];
+		stats->n_ksw += hub.n_reqs[OP_KSW] + hub.n_reqs[OP_KSW_HEAVY] + hub.n_reqs[OP_KSW_HUGE]; stats->n_chain += hub.n_reqs[OP_CHAIN]; stats->n_seed += hub.n_reqs[OP_SEED]; stats->n_sketch += hub.n_reqs[OP_SKETCH];
 		stats->cpu_fiber += hub.cpu_fiber; stats->wall_idle += hub.wall_idle; stats->cpu_help += hub.cpu_help;
 		for (int op = 0; op < OP_N; ++op) {           // (the heavy alignment queue is reported with the ksw operation)
-			const int o = op == OP_KSW_HEAVY ? OP_KSW : op;
+			const int o = op >= OP_KSW_HEAVY ? OP_KSW : op;
 			stats->n_batches[o] += hub.n_batches[op]; stats->cpu_op[o] += hub.cpu_op[op]; stats->wall_op[o] += hub.wall_op[op];
 		}
 	}

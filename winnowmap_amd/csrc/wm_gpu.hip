@@ -1758,7 +1758,10 @@ static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double
 	{ std::vector<wm_ctx_t*> cs; cs.push_back(m->c); cs.insert(cs.end(), m->workers.begin(), m->workers.end()); ops.init(cs); }
 	wm::MapStats st;
 	hipSetDevice(m->c->device);
-	wm::map_batch(m->idx->ix, m->mo, &ops, reads, out, &st, m->n_threads);
+	// records are formatted by the worker that finishes a read, while the other reads are still being mapped
+	std::vector<std::string> texts(n);
+	const std::function<void(size_t)> fmt = [&](size_t i) { wm::write_read(texts[i], m->idx->ix, reads[i], out[i], m->mo.flag); };
+	wm::map_batch(m->idx->ix, m->mo, &ops, reads, out, &st, m->n_threads, &fmt);
 	for (GpuOpsCtx &x : ops.ctxs)
 		if (!x.error.empty()) return set_err(WM_ENODEV, "%s", x.error.c_str());
 	{ std::string ie; if (wm::take_internal_error(ie)) return set_err(WM_EINTERNAL, "%s", ie.c_str()); }
@@ -1771,11 +1774,9 @@ static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double
 		fprintf(stderr, "[ops, sum over %zu contexts, ms] ksw: pack %.0f prepare %.0f run %.0f fetch %.0f unpack %.0f | sketch %.0f seed %.0f chain %.0f | batches %llu\n", ops.ctxs.size(), a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], (unsigned long long)st.n_flush);
 	}
 	const double tm2 = now_ms();
-	// output records: formatted per read in parallel, then laid out in input order
-	std::vector<std::string> texts(n);
+	// output records (formatted above, per read), laid out in input order
 	std::vector<size_t> toff(n + 1, 0), coff(n + 1, 0);
 	m->first.assign(n + 1, 0);
-	wm::parallel_for(m->n_threads, (size_t)n, [&](size_t i) { wm::write_read(texts[i], m->idx->ix, reads[i], out[i], m->mo.flag); });
 	for (int i = 0; i < n; ++i) {
 		toff[i + 1] = toff[i] + texts[i].size();
 		m->first[i + 1] = m->first[i] + (int64_t)out[i].regs.size();
