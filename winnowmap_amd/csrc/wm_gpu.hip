@@ -212,7 +212,11 @@ static int set_err(int code, const char *fmt, ...)
 struct wm_ctx_s {
 	int device;
 	hipStream_t stream;
-	hipStream_t kstream[4];                     // side streams: kernel classes of one batch run concurrently
+	hipStream_t kstream[4];                     // own side streams (created on first use): kernel classes of one batch run concurrently
+	// the mapper's contexts draw their side streams from ONE pool instead, sized so that all streams of the mapper fit the hardware queues
+	// (GPU_MAX_HW_QUEUES = 16: more streams than queues share queues and serialise, profiles/r02f_stream_conc.txt)
+	hipStream_t *side_pool; int n_side_pool; std::atomic<unsigned> *side_next;
+	std::vector<hipStream_t> owned_pool; std::atomic<unsigned> owned_next{0};   // (the pool lives in the mapper's first context; the others point at it)
 	hipEvent_t kev[5];
 	hipEvent_t cev[WM_KSW_NCLASS][2];           // per-class start/stop (on the stream the class was launched on)
 	double k_ms[WM_KSW_NCLASS]; uint64_t k_cells[WM_KSW_NCLASS], k_launches[WM_KSW_NCLASS];   // accumulated per kernel class
@@ -317,7 +321,8 @@ extern "C" int wm_ctx_create(int device, size_t arena_bytes, wm_ctx_t **out)
 	c->arena_bytes = arena_bytes;
 	HIPCHK(hipMalloc((void**)&c->arena, arena_bytes));
 	HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-	for (int i = 0; i < 4; ++i) HIPCHK(hipStreamCreateWithFlags(&c->kstream[i], hipStreamNonBlocking));
+	for (int i = 0; i < 4; ++i) c->kstream[i] = 0;
+	c->side_pool = 0; c->n_side_pool = 0; c->side_next = 0;
 	for (int i = 0; i < 5; ++i) HIPCHK(hipEventCreateWithFlags(&c->kev[i], hipEventDisableTiming));
 	for (int k = 0; k < WM_KSW_NCLASS; ++k) { HIPCHK(hipEventCreate(&c->cev[k][0])); HIPCHK(hipEventCreate(&c->cev[k][1])); c->k_ms[k] = 0; c->k_cells[k] = c->k_launches[k] = 0; }
 	for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
@@ -341,7 +346,8 @@ extern "C" void wm_ctx_destroy(wm_ctx_t *c)
 	hipStreamDestroy(c->stream);
 	if (c->pin) hipHostFree(c->pin);
 	if (c->pin_small) hipHostFree(c->pin_small);
-	for (int i = 0; i < 4; ++i) hipStreamDestroy(c->kstream[i]);
+	for (int i = 0; i < 4; ++i) if (c->kstream[i]) hipStreamDestroy(c->kstream[i]);
+	for (hipStream_t st : c->owned_pool) hipStreamDestroy(st);
 	for (int i = 0; i < 5; ++i) hipEventDestroy(c->kev[i]);
 	for (int k = 0; k < WM_KSW_NCLASS; ++k) { hipEventDestroy(c->cev[k][0]); hipEventDestroy(c->cev[k][1]); }
 	hipFree(c->arena);
@@ -602,10 +608,16 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	const bool fan = n_nonempty > 1 && !trace_k && n_side > 0;
 	if (fan) HIPCHK(hipEventRecord(c->kev[4], c->stream));
 	hipStream_t ks = c->stream;
+	hipStream_t side[4] = {0, 0, 0, 0};          // the side streams of this call: from the mapper's pool, else the context's own
+	const int n_use = c->side_pool ? std::min(n_side, c->n_side_pool) : n_side;
+	if (fan && n_use > 0) {
+		if (c->side_pool) { const unsigned b0 = c->side_next->fetch_add((unsigned)n_use); for (int i = 0; i < n_use; ++i) side[i] = c->side_pool[(b0 + (unsigned)i) % (unsigned)c->n_side_pool]; }
+		else for (int i = 0; i < n_use; ++i) { if (!c->kstream[i]) HIPCHK(hipStreamCreateWithFlags(&c->kstream[i], hipStreamNonBlocking)); side[i] = c->kstream[i]; }
+	}
 	auto next_stream = [&]() {
-		if (!fan) return;
-		const int si = rr++ % n_side;
-		ks = c->kstream[si];
+		if (!fan || n_use <= 0) return;
+		const int si = rr++ % n_use;
+		ks = side[si];
 		if (!(used_mask >> si & 1)) { hipStreamWaitEvent(ks, c->kev[4], 0); used_mask |= 1 << si; }
 	};
 	int offs[WM_KSW_NCLASS + 1];
@@ -654,7 +666,7 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		}
 	}
 	for (int si = 0; si < 4; ++si)
-		if (used_mask >> si & 1) { HIPCHK(hipEventRecord(c->kev[si], c->kstream[si])); HIPCHK(hipStreamWaitEvent(c->stream, c->kev[si], 0)); }
+		if (used_mask >> si & 1) { HIPCHK(hipEventRecord(c->kev[si], side[si])); HIPCHK(hipStreamWaitEvent(c->stream, c->kev[si], 0)); }
 	HIPCHK(hipEventRecord(c->ev[1], c->stream));
 	hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, b->d_jobs, b->d_tb, b->d_res, b->d_cig, b->d_err);
 	hipLaunchKernelGGL(ksw_scan_kernel, dim3(1), dim3(1024), 0, c->stream, n, b->d_res, b->d_off, b->d_total);
@@ -1720,6 +1732,18 @@ extern "C" int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena
 		w->have_index = true; w->owns_index = false;
 		w->host_threads = m->c->host_threads;
 		m->workers.push_back(w);
+	}
+	// side streams: one pool for all contexts, so that main streams + pool = the hardware queues (WM_SIDE_POOL overrides the pool size)
+	{
+		const int hwq = getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
+		int P = getenv("WM_SIDE_POOL") ? atoi(getenv("WM_SIDE_POOL")) : std::max(0, hwq - C);
+		if (C == 1) P = 0;                                   // a single context keeps its own side streams
+		wm_ctx_t *c0 = m->c;                                  // (the pool lives and dies with the mapper's first context)
+		HIPCHK(hipStreamSynchronize(c0->stream));
+		while ((int)c0->owned_pool.size() > P) { hipStreamDestroy(c0->owned_pool.back()); c0->owned_pool.pop_back(); }
+		while ((int)c0->owned_pool.size() < P) { hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); c0->owned_pool.push_back(st); }
+		c0->side_pool = P > 0 ? c0->owned_pool.data() : 0; c0->n_side_pool = P; c0->side_next = &c0->owned_next;
+		for (wm_ctx_t *w : m->workers) { w->side_pool = c0->side_pool; w->n_side_pool = P; w->side_next = &c0->owned_next; }
 	}
 	// the pinned staging slabs are allocated now, not inside the first mapping call (page-locking a few GB takes a noticeable fraction of a second)
 	{ size_t mark = 0; if (pin_take(m->c, 1, &mark)) pin_release(m->c, mark); }
