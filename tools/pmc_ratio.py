@@ -19,12 +19,12 @@ def counters(d, name):
 def classes(log):
     m = re.search(r'\{"metric".*\}', open(os.path.join(src, log)).read())
     cl = json.loads(m.group(0))["roofline"]["classes"]
-    return {k.replace("ksw_dp_kernel<", "ksw_dps_kernel<"): v for k, v in cl.items()}      # (older logs named the striped kernels ksw_dp_kernel)
+    return cl
 
 
 def key(kernel_name):        # "void ksw_dp_kernel<16, true, false>(...)" -> "ksw_dp_kernel<16,true,false>"
     m = re.search(r"(ksw_[a-z_]+kernel(<[^>]*>)?)", kernel_name)
-    return m.group(1).replace(" ", "") if m else None
+    return m.group(1) if m else None              # (spelled like bench.py's class names, spaces included)
 
 
 fetch, write = counters("pmc1", "FETCH_SIZE"), counters("pmc2", "WRITE_SIZE")

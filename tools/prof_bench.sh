@@ -1,22 +1,23 @@
 #!/bin/bash
 # usage: tools/prof_bench.sh <tag> [bench args...]
-# 1) plain bench.py run (the JSON line), 2) the same command under rocprofv3 --kernel-trace --stats,
-# 3) (optional, PMC=1) separate --pmc passes for HBM traffic of the ksw kernels. Everything lands in gpurun_out/prof_<tag>/;
-# tools/prof_summary.py turns the .db files into profiles/<tag>.txt.
+# 0) (PMC=1) separate rocprofv3 --pmc passes for the HBM traffic of the ksw kernels -> profiles/pmc_bytes_per_cell.json (read by bench.py),
+# 1) plain bench.py run (the JSON line), 2) the same command under rocprofv3 --kernel-trace --stats (PROF_ARGS appended, default --cpu-sample 0),
+# 3) GPU timeline. Everything lands in gpurun_out/prof_<tag>/; tools/prof_summary.py turns the .db files into profiles/<tag>.txt.
 TAG=${1:-r01_bench}; shift
 export TMPDIR=/tmp
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
-python bench.py "$@" > $OUT/bench.json 2> $OUT/bench.log
-tail -3 $OUT/bench.log; cat $OUT/bench.json
-( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python $ROOT/bench.py "$@" ${PROF_ARGS:---cpu-sample 0} > $OUT/bench_prof.json 2> $OUT/bench_prof.log )
-cat $OUT/bench_prof.json
-for f in $OUT/stats/*.db; do python $ROOT/tools/gpu_timeline.py $f 0.35 > $OUT/timeline.txt 2>&1; done; cat $OUT/timeline.txt
 if [ "${PMC:-0}" = "1" ]; then
   # HBM traffic (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE, in their own passes, no trace domains)
   # (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950; a reduced batch keeps the serialised counter runs short)
   ( cd /tmp && WM_BENCH_CPU_SAMPLE=0 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc1 -o bench -- python $ROOT/bench.py --steps 1 --warmup 0 --reads-per-step 1024 > $OUT/pmc1.log 2>&1 )
   ( cd /tmp && WM_BENCH_CPU_SAMPLE=0 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc2 -o bench -- python $ROOT/bench.py --steps 1 --warmup 0 --reads-per-step 1024 > $OUT/pmc2.log 2>&1 )
+  ( cd $ROOT && python tools/pmc_ratio.py gpurun_out/prof_$TAG > $OUT/pmc_ratio.txt 2>&1; cat $OUT/pmc_ratio.txt; cp profiles/pmc_bytes_per_cell.json $OUT/ )
 fi
+python bench.py "$@" > $OUT/bench.json 2> $OUT/bench.log
+grep -v "^W2026" $OUT/bench.log | tail -6; cat $OUT/bench.json
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python $ROOT/bench.py "$@" ${PROF_ARGS:---cpu-sample 0} > $OUT/bench_prof.json 2> $OUT/bench_prof.log )
+cat $OUT/bench_prof.json
+for f in $OUT/stats/*.db; do python $ROOT/tools/gpu_timeline.py $f 0.35 > $OUT/timeline.txt 2>&1; done; cat $OUT/timeline.txt
 cd $ROOT && python tools/prof_summary.py $TAG gpurun_out/prof_$TAG > /dev/null && cp profiles/$TAG.txt $OUT/ && head -30 profiles/$TAG.txt
