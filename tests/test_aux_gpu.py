@@ -25,6 +25,8 @@ def env():
     L.wm_chain_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, W.u64p, W.i32p, C.c_void_p, W.u64p, W.u64p, W.i32p, W.i32p]
     L.wm_index_get.restype = C.POINTER(C.c_uint64)
     L.wm_index_get.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_int)]
+    # the expectation of the seed test comes from the REFERENCE's index when oracle/_ref is there (mm_idx_get, src/index.c:88), not from the product's
+    L._wm_ref_index = (W.ref(), W.ref().refshim_idx_build((tmp + "/ref.fa").encode(), (tmp + "/rep.txt").encode(), 15, 50, 4)) if W.have_ref() else None
     yield ctx, idx, ref, W.o_bloom(km), L
     idx.close()
     ctx.close()
@@ -79,7 +81,13 @@ def test_sketch_seed_chain_kernels(env):
         for j in range(len(m)):
             x, y = int(m["x"][j]), int(m["y"][j])
             t = C.c_int()
-            p = L.wm_index_get(idx._h, x >> 8, C.byref(t))
+            if L._wm_ref_index is not None:
+                R, mi = L._wm_ref_index
+                pbuf = np.zeros(8192, np.uint64)
+                t.value = R.refshim_idx_get(mi, x >> 8, pbuf, len(pbuf))
+                p = pbuf
+            else:
+                p = L.wm_index_get(idx._h, x >> 8, C.byref(t))
             qpos, span = y & 0xffffffff, x & 0xff
             if t.value >= 5000:
                 en = (qpos >> 1) + 1

@@ -19,5 +19,5 @@ python bench.py "$@" > $OUT/bench.json 2> $OUT/bench.log
 grep -v "^W2026" $OUT/bench.log | tail -6; cat $OUT/bench.json
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python $ROOT/bench.py "$@" ${PROF_ARGS:---cpu-sample 0} > $OUT/bench_prof.json 2> $OUT/bench_prof.log )
 cat $OUT/bench_prof.json
-for f in $OUT/stats/*.db; do python $ROOT/tools/gpu_timeline.py $f 0.35 > $OUT/timeline.txt 2>&1; done; cat $OUT/timeline.txt
+for f in $OUT/stats/*.db; do python $ROOT/tools/gpu_timeline.py $f > $OUT/timeline.txt 2>&1; done; cat $OUT/timeline.txt
 cd $ROOT && python tools/prof_summary.py $TAG gpurun_out/prof_$TAG > /dev/null && cp profiles/$TAG.txt $OUT/ && head -30 profiles/$TAG.txt
