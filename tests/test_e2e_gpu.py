@@ -166,3 +166,32 @@ def test_workload_scale_properties(ctx):
     assert ok >= 0.97 * len(truth), ok
     m.close()
     idx.close()
+
+
+def test_small_arena_splits_batches_and_gives_the_same_records():
+    """Batches are sized by demand (the hub takes whole queues), not by HBM: with an arena far smaller than a batch needs, the sketch / seed /
+    chain calls are served in halves and the ksw call in traceback-sized chunks (each uploading only its own operands). Same records as
+    with a comfortable arena."""
+    from winnowmap_amd import synth
+    tmp = tempfile.mkdtemp()
+    ref = synth.make_reference(2, 1_000_000, 51, repeat_frac=0.10)
+    fa = tmp + "/ref.fa"
+    synth.write_fasta(fa, ref)
+    km, cnt = synth.repetitive_kmers(ref, 15)
+    kf = tmp + "/rep.txt"
+    synth.write_kmer_list(kf, km, cnt, 15)
+    reads, _ = synth.make_reads(ref, 200, 12000, 52, profile="ont", sv_frac=0.05)
+    names = [b"r%d" % i for i in range(len(reads))]
+    seqs = [synth.codes_to_ascii(r) for r in reads]
+    out = []
+    for arena in (2 << 30, 48 << 20):
+        c = gpu.Context(0, arena)
+        idx = gpu.Index(fa, kf, k=15, w=50, n_threads=4)
+        idx.upload(c)
+        m = gpu.Mapper(c, idx, "map-ont", gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
+        m.set_threads(4, arena)
+        text, hits, cigars, first = m.map(names, seqs)
+        out.append((text, hits.copy(), cigars.copy(), first.copy()))
+        m.close(); idx.close(); c.close()
+    assert len(out[0][1]) >= 200
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])

@@ -1624,9 +1624,19 @@ struct GpuOps : wm::DeviceOps {
 		{ std::lock_guard<std::mutex> lk(mu); free_.push_back(i); }
 		cv.notify_one();
 	}
-	void sketch_batch(int w, int k, std::vector<wm::SketchReq*> &reqs) override { with([&](GpuOpsCtx &x) { x.sketch_batch(w, k, reqs); }); }
-	void seed_batch(std::vector<wm::SeedReq*> &reqs) override { with([&](GpuOpsCtx &x) { x.seed_batch(reqs); }); }
-	void chain_batch(std::vector<wm::ChainReq*> &reqs) override { with([&](GpuOpsCtx &x) { x.chain_batch(reqs); }); }
+	// a batch whose buffers do not fit the context's arena is served in halves (recursively): the hub sizes batches by demand, not by HBM
+	template <class R, class F> static void run_split(GpuOpsCtx &x, std::vector<R*> &reqs, F f)
+	{
+		f(reqs);
+		if (x.error.empty() || reqs.size() < 2 || x.error.find("does not fit the arena") == std::string::npos) return;
+		x.error.clear();
+		std::vector<R*> a(reqs.begin(), reqs.begin() + reqs.size() / 2), b(reqs.begin() + reqs.size() / 2, reqs.end());
+		run_split(x, a, f);
+		if (x.error.empty()) run_split(x, b, f);
+	}
+	void sketch_batch(int w, int k, std::vector<wm::SketchReq*> &reqs) override { with([&](GpuOpsCtx &x) { run_split(x, reqs, [&](std::vector<wm::SketchReq*> &part) { x.sketch_batch(w, k, part); }); }); }
+	void seed_batch(std::vector<wm::SeedReq*> &reqs) override { with([&](GpuOpsCtx &x) { run_split(x, reqs, [&](std::vector<wm::SeedReq*> &part) { x.seed_batch(part); }); }); }
+	void chain_batch(std::vector<wm::ChainReq*> &reqs) override { with([&](GpuOpsCtx &x) { run_split(x, reqs, [&](std::vector<wm::ChainReq*> &part) { x.chain_batch(part); }); }); }
 	void ksw_batch(const wm_ksw_score_t &sc, std::vector<wm::KswReq*> &reqs) override { with([&](GpuOpsCtx &x) { x.ksw_batch(sc, reqs); }); }
 };
 
