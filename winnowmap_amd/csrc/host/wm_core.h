@@ -107,6 +107,9 @@ bool take_internal_error(std::string &msg);          // true + message if one wa
 // unpacking): the hub (wm_fiber.h) installs a hook for the duration of the call; parallel_for uses it when present.
 struct ParHook { virtual ~ParHook() {} virtual void run(size_t n, const std::function<void(size_t)> &fn) = 0; };
 inline ParHook *&tl_par_hook() { static thread_local ParHook *p = 0; return p; }
+// a label for the NEXT parallel_for of this thread (diagnostics: the hub accounts the CPU time of shared loops per label)
+inline const char *&tl_par_site() { static thread_local const char *s = 0; return s; }
+#define WM_SITE(name) (::wm::tl_par_site() = (name))
 
 // host-side helper: fn(i) for i in [0, n) on up to n_threads threads (dynamic chunks); used for packing / unpacking batches
 template <class F> inline void parallel_for(int n_threads, size_t n, F fn)

@@ -45,7 +45,7 @@ inline double thread_cpu_s() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_I
 inline double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // a host-side loop of a batched call that idle workers help with (ParHook, wm_core.h)
-struct HelpTask { const std::function<void(size_t)> *fn; size_t n, chunk; std::atomic<size_t> next; int helpers; };
+struct HelpTask { const std::function<void(size_t)> *fn; size_t n, chunk; std::atomic<size_t> next; int helpers; const char *site; };
 
 struct Hub {
 	Hub(DeviceOps *ops_, const wm_ksw_score_t &sc_, int w_, int k_) : ops(ops_), sc(sc_), w(w_), k(k_) { max_inflight = ops->max_inflight(); if (max_inflight < 1) max_inflight = 1; read_env(); par.H = this; }
@@ -62,6 +62,8 @@ struct Hub {
 	int n_workers = 1, n_idle = 0;          // workers of the mapping call; workers asleep with nothing runnable
 	std::vector<HelpTask*> help;            // loops of running batched calls that still have chunks to hand out
 	double cpu_help = 0;                    // CPU seconds idle workers spent inside such loops
+	std::vector<std::pair<const char*, double>> site_cpu;   // ... and the CPU seconds of every labelled loop (WM_SITE), dispatcher + helpers
+	void add_site(const char *site, double s) { if (!site) site = "(unlabelled)"; for (auto &e : site_cpu) if (e.first == site) { e.second += s; return; } site_cpu.emplace_back(site, s); }
 	static void help_work(HelpTask &t)
 	{
 		for (;;) { const size_t b = t.next.fetch_add(t.chunk); if (b >= t.n) break; const size_t e = b + t.chunk < t.n ? b + t.chunk : t.n; for (size_t i = b; i < e; ++i) (*t.fn)(i); }
@@ -72,13 +74,16 @@ struct Hub {
 		void run(size_t n, const std::function<void(size_t)> &fn) override
 		{
 			HelpTask t;
-			t.fn = &fn; t.n = n; t.next.store(0); t.helpers = 0;
+			t.fn = &fn; t.n = n; t.next.store(0); t.helpers = 0; t.site = tl_par_site(); tl_par_site() = 0;
 			t.chunk = n / (size_t)(4 * (H->n_workers > 0 ? H->n_workers : 1));
 			if (t.chunk < 16) t.chunk = 16;
 			{ std::lock_guard<std::mutex> lk(H->mu); H->help.push_back(&t); }
 			H->cv.notify_all();
+			const double c0 = thread_cpu_s();
 			help_work(t);
+			const double dc = thread_cpu_s() - c0;
 			std::unique_lock<std::mutex> lk(H->mu);
+			H->add_site(t.site, dc);
 			for (size_t i = 0; i < H->help.size(); ++i) if (H->help[i] == &t) { H->help.erase(H->help.begin() + i); break; }
 			while (t.helpers > 0) H->cv.wait(lk);          // (helpers announce themselves and leave under the hub mutex)
 		}
@@ -174,7 +179,7 @@ public:
 						Hub::help_work(*ht);
 						const double hc = thread_cpu_s() - hc0;
 						lk.lock();
-						H.cpu_help += hc;
+						H.cpu_help += hc; H.add_site(ht->site, hc);
 						if (--ht->helpers == 0) H.cv.notify_all();
 						continue;
 					}

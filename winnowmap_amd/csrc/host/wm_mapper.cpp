@@ -277,6 +277,7 @@ void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::v
 	if (stats) {
 		stats->n_flush += hub.n_batches[OP_SKETCH] + hub.n_batches[OP_SEED] + hub.n_batches[OP_CHAIN] + hub.n_batches[OP_KSW] + hub.n_batches[OP_KSW_HEAVY] + hub.n_batches[OP_KSW_HUGE];
 		stats->n_ksw += hub.n_reqs[OP_KSW] + hub.n_reqs[OP_KSW_HEAVY] + hub.n_reqs[OP_KSW_HUGE]; stats->n_chain += hub.n_reqs[OP_CHAIN]; stats->n_seed += hub.n_reqs[OP_SEED]; stats->n_sketch += hub.n_reqs[OP_SKETCH];
+		if (getenv("WM_TRACE")) { for (auto &e : hub.site_cpu) fprintf(stderr, "[site] %-28s %8.2f s CPU\n", e.first, e.second); }
 		stats->cpu_fiber += hub.cpu_fiber; stats->wall_idle += hub.wall_idle; stats->cpu_help += hub.cpu_help;
 		for (int op = 0; op < OP_N; ++op) {           // (the heavy alignment queue is reported with the ksw operation)
 			const int o = op >= OP_KSW_HEAVY ? OP_KSW : op;

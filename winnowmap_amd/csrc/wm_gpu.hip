@@ -419,6 +419,7 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 			tot += ql + tl;
 		}
 		std::atomic<int> badp(-1);
+		WM_SITE("ksw.positions");
 		wm::parallel_for(c->host_threads, (size_t)n_jobs, [&](size_t i) {
 			const wm_ksw_pos_t &s = pos[i];
 			memset(&dsrc[i], 0, sizeof(dsrc[i]));
@@ -453,6 +454,7 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 	uint64_t tb_off = 0, cig_off = 0;
 	std::vector<uint64_t> cells(n_jobs, 0), bands(n_jobs, 0);
 	std::atomic<int> bad(-1);
+	WM_SITE("ksw.classify");
 	wm::parallel_for(c->host_threads, (size_t)n_jobs, [&](size_t i) {          // per-job classification (byte jobs: scans both sequences for N)
 		wm_ksw_djob_t &d = b->jobs[i];
 		int32_t qlen, tlen, w, zdrop, end_bonus, flag;
@@ -704,6 +706,7 @@ try {
 	HIPCHK(hipMemcpyAsync(off.data(), b->d_off, n * 4, hipMemcpyDeviceToHost, c->stream));
 	if (b->total_ops) HIPCHK(hipMemcpyAsync(cigar_pool, b->d_pool, (size_t)b->total_ops * 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(ctx_sync(c));
+	WM_SITE("ksw.results");
 	wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 		wm_ksw_result_t &o = results[i];
 		const wm_ksw_dres_t &r = res[i];
@@ -1339,6 +1342,7 @@ try {
 			used += res[t].n_anchors;
 			done_t.push_back(t);
 		}
+		WM_SITE("seed.copy+radix_sort");
 		wm::parallel_for(c->host_threads, done_t.size(), [&](size_t k) {
 			const size_t t = done_t[k];
 			wm128_t *dst = out + out_off[todo[t]];
@@ -1367,6 +1371,7 @@ try {
 	for (int i = 0; i < n; ++i) tot = std::max<uint64_t>(tot, a_off[i] + n_a[i]);
 	std::vector<wm_chain_job_t> jb(n);
 	std::vector<int> order(n);
+	WM_SITE("chain.jobs+avg_qspan");
 	wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 		jb[i].a_off = a_off[i]; jb[i].n = n_a[i];
 		jb[i].max_dist_x = par[i].max_dist_x; jb[i].min_dist_x = par[i].min_dist_x; jb[i].max_dist_y = par[i].max_dist_y; jb[i].bw = par[i].bw;
@@ -1377,6 +1382,7 @@ try {
 	// jobs larger than the small windows: DENSE if a sample of anchors has more than ~900 predecessors within max_dist_x (satellite
 	// arrays, no -W list) -> multi-wave kernel with the 4096-anchor window; otherwise one wave with a 1024-anchor window
 	std::vector<uint8_t> dense(n, 0);
+	WM_SITE("chain.dense_probe");
 	wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 		const int m = n_a[i];
 		if (m <= 1024) return;
@@ -1428,6 +1434,7 @@ try {
 	const double tt3 = trace ? now_ms() : 0;
 	// chain extraction (src/chain.c:93-165): O(n) bookkeeping on the fill's f/p/v
 	std::vector<std::vector<uint64_t>> uus(n);
+	WM_SITE("chain.extract");
 	wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 		const int *f = fpvt.data() + a_off[i] * 4, *p = f + n_a[i];
 		int *v = fpvt.data() + a_off[i] * 4 + 2 * (size_t)n_a[i];
@@ -1474,6 +1481,7 @@ struct GpuOpsCtx {
 			else { off[i] = tot; tot += reqs[i]->len; }
 		}
 		UBuf<uint8_t> seqs(tot + 1, c);
+		WM_SITE("sketch.stage");
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { if (!res[i]) memcpy(seqs.data() + off[i], reqs[i]->seq, reqs[i]->len); });
 		UBuf<wm128_t> out(tot_all / 8 + (size_t)17 * n + 64, c);          // the batch tries len/8 + 16 slots per sequence first
 		const double ts = now_ms();
@@ -1490,6 +1498,7 @@ struct GpuOpsCtx {
 		if (rc) { fail("sketch"); return; }
 		t_sketch += now_ms() - ts;
 		aux_us += c->aux_ms * 1e3;
+		WM_SITE("sketch.unpack");
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { reqs[i]->mini.assign(out.begin() + ooff[i], out.begin() + ooff[i] + cnt[i]); });
 	}
 	void seed_batch(std::vector<wm::SeedReq*> &reqs)
@@ -1501,6 +1510,7 @@ struct GpuOpsCtx {
 		size_t tot = 0;
 		for (int i = 0; i < n; ++i) { moff[i] = tot; nm[i] = reqs[i]->n_mini; ql[i] = reqs[i]->qlen; tot += reqs[i]->n_mini; }
 		UBuf<wm128_t> mini(tot + 1, c);
+		WM_SITE("seed.pack");
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { memcpy(mini.data() + moff[i], reqs[i]->mini, (size_t)reqs[i]->n_mini * sizeof(wm128_t)); });
 		size_t cap = tot * 3 + 4096;               // anchors per minimizer: ~1.15 on the bench reference; repeats are retried at 8x
 		for (int attempt = 0; attempt < 6; ++attempt) {
@@ -1530,11 +1540,13 @@ struct GpuOpsCtx {
 		}
 		UBuf<wm128_t> a(tot + 1, c);
 		UBuf<uint64_t> u(tot + 1, c);
+		WM_SITE("chain.pack");
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) { memcpy(a.data() + aoff[i], reqs[i]->a.data(), reqs[i]->a.size() * sizeof(wm128_t)); });
 		const double ts = now_ms();
 		if (wm_chain_batch(c, n, a.data(), aoff.data(), na.data(), par.data(), u.data(), uoff.data(), nu.data(), nv.data())) { fail("chain"); return; }
 		t_chain += now_ms() - ts;
 		aux_us += c->aux_ms * 1e3;
+		WM_SITE("chain.unpack");
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 			reqs[i]->u.assign(u.begin() + uoff[i], u.begin() + uoff[i] + nu[i]);
 			reqs[i]->a.assign(a.begin() + aoff[i], a.begin() + aoff[i] + nv[i]);
@@ -1555,6 +1567,7 @@ struct GpuOpsCtx {
 		double t1;
 		if (all_res) {          // operands as positions in the resident reads / packed reference: nothing is copied or shipped per alignment
 			UBuf<wm_ksw_pos_t> jobs(n + 1, c);
+			WM_SITE("ksw.pos_jobs");
 			wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 				const wm::KswReq &r = *reqs[i];
 				wm_ksw_pos_t &j = jobs[i];
@@ -1582,6 +1595,7 @@ struct GpuOpsCtx {
 		const double t2 = now_ms();
 		ksw_us += c->last_ms * 1e3;
 		cells += c->acc_cells;
+		WM_SITE("ksw.unpack");
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 			reqs[i]->ez = res[i];
 			reqs[i]->cigar.assign(pool.begin() + res[i].cig_off, pool.begin() + res[i].cig_off + res[i].n_cigar);
