@@ -846,6 +846,27 @@ __global__ __launch_bounds__(64) void seed_kernel(wm_index_view_t ix, const wm_s
 	wmk::seed_wave(ix, jobs[j], mini, anchors, occ_scratch + occ_off[j], res + j);
 }
 
+// anchors of a seed batch as keys (x) / values (y) for the device sort; and back, with a per-job flag "two anchors share a key" (their
+// relative order is then decided by the reference's unstable radix sort, src/ksort.h:101-151: such jobs are re-sorted on the host)
+__global__ __launch_bounds__(256) void seed_split_kernel(const wm128_t *__restrict__ a, uint64_t n, uint64_t *__restrict__ k, uint64_t *__restrict__ v)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) { const wm128_t e = a[i]; k[i] = e.x; v[i] = e.y; }
+}
+__global__ __launch_bounds__(64) void seed_merge_kernel(const uint32_t *__restrict__ beg, const uint32_t *__restrict__ end, const uint64_t *__restrict__ k, const uint64_t *__restrict__ v,
+                                                         wm128_t *__restrict__ out, int *__restrict__ tie)
+{
+	const int j = blockIdx.x;
+	const uint32_t b = beg[j], e = end[j];
+	bool t = false;
+	for (uint32_t i = b + threadIdx.x; i < e; i += 64) {
+		wm128_t o; o.x = k[i]; o.y = v[i];
+		out[i] = o;
+		t |= i > b && k[i - 1] == o.x;
+	}
+	if (__any(t) && threadIdx.x == 0) tie[j] = 1;
+}
+
 // chain DP fill: one wave per anchor set, LDS window of W anchors (28 B each: x, y, f, p, t); f and p go to fpvt
 __global__ __launch_bounds__(64) void chain_kernel(const wm_chain_job_t *jobs, const int *order, const wm128_t *anchors, int *fpvt, int W)
 {
@@ -1326,9 +1347,7 @@ try {
 		hipLaunchKernelGGL(seed_kernel, dim3((int)jb.size()), dim3(64), 0, c->stream, ix, d_jobs, d_mini, d_out, d_occ, d_occ_off, d_res);
 		HIPCHK(hipEventRecord(c->ev[1], c->stream));
 		UBuf<wm_seed_res_t> res(jb.size() + 1, c);
-		UBuf<wm128_t> tmp(tot + 1, c);
 		HIPCHK(hipMemcpyAsync(res.data(), d_res, jb.size() * sizeof(wm_seed_res_t), hipMemcpyDeviceToHost, c->stream));
-		HIPCHK(hipMemcpyAsync(tmp.data(), d_out, tot * sizeof(wm128_t), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(ctx_sync(c));
 		HIPCHK(hipGetLastError());
 		float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); ms_total += ms;
@@ -1342,11 +1361,56 @@ try {
 			used += res[t].n_anchors;
 			done_t.push_back(t);
 		}
+		// sort by x (src/map.c:252). On the device: a segmented radix sort of all jobs at once gives THE order whenever the keys of a job are
+		// distinct; a job in which two anchors share a key (the same reference position reached from two query positions) gets the tie
+		// permutation of the reference's in-place unstable radix sort, which is sequential by nature -> those jobs are re-sorted on the host.
+		// WM_SEED_HOST_SORT=1: everything on the host (A/B).
+		static const bool host_sort = getenv("WM_SEED_HOST_SORT") != 0;
+		UBuf<wm128_t> tmp(tot + 1, c);
+		UBuf<int> tie(jb.size() + 1, c);
+		bool dev_sorted = false;
+		if (!host_sort && tot > 0 && tot < ((uint64_t)1 << 32) && !done_t.empty()) {
+			uint64_t *d_k = (uint64_t*)arena_take(c, (tot + 1) * 8), *d_v = (uint64_t*)arena_take(c, (tot + 1) * 8);
+			uint64_t *d_k2 = (uint64_t*)arena_take(c, (tot + 1) * 8), *d_v2 = (uint64_t*)arena_take(c, (tot + 1) * 8);
+			wm128_t *d_sorted = (wm128_t*)arena_take(c, (tot + 1) * sizeof(wm128_t));
+			uint32_t *d_beg = (uint32_t*)arena_take(c, jb.size() * 4 + 64), *d_end = (uint32_t*)arena_take(c, jb.size() * 4 + 64);
+			int *d_tie = (int*)arena_take(c, jb.size() * 4 + 64);
+			size_t tmp_bytes = 0;
+			if (d_k && d_v && d_k2 && d_v2 && d_sorted && d_beg && d_end && d_tie &&
+			    rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, d_k, d_k2, d_v, d_v2, (unsigned)tot, (unsigned)jb.size(), d_beg, d_end, 0, 64, c->stream) == hipSuccess) {
+				void *d_tmp = arena_take(c, tmp_bytes + 256);
+				if (d_tmp) {
+					UBuf<uint32_t> hb(2 * jb.size() + 2, c);
+					uint32_t *hbeg = hb.data(), *hend = hb.data() + jb.size();
+					for (size_t t = 0; t < jb.size(); ++t) { hbeg[t] = (uint32_t)jb[t].out_off; hend[t] = (uint32_t)jb[t].out_off; }       // (jobs to be retried: empty segments)
+					for (size_t t : done_t) hend[t] = (uint32_t)(jb[t].out_off + (uint64_t)res[t].n_anchors);
+					HIPCHK(hipMemcpyAsync(d_beg, hbeg, jb.size() * 4, hipMemcpyHostToDevice, c->stream));
+					HIPCHK(hipMemcpyAsync(d_end, hend, jb.size() * 4, hipMemcpyHostToDevice, c->stream));
+					HIPCHK(hipMemsetAsync(d_tie, 0, jb.size() * 4, c->stream));
+					hipLaunchKernelGGL(seed_split_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, d_out, tot, d_k, d_v);
+					HIPCHK(rocprim::segmented_radix_sort_pairs(d_tmp, tmp_bytes, d_k, d_k2, d_v, d_v2, (unsigned)tot, (unsigned)jb.size(), d_beg, d_end, 0, 64, c->stream));
+					hipLaunchKernelGGL(seed_merge_kernel, dim3((unsigned)jb.size()), dim3(64), 0, c->stream, d_beg, d_end, d_k2, d_v2, d_sorted, d_tie);
+					HIPCHK(hipMemcpyAsync(tie.data(), d_tie, jb.size() * 4, hipMemcpyDeviceToHost, c->stream));
+					HIPCHK(hipMemcpyAsync(tmp.data(), d_sorted, tot * sizeof(wm128_t), hipMemcpyDeviceToHost, c->stream));
+					HIPCHK(ctx_sync(c));
+					HIPCHK(hipGetLastError());
+					dev_sorted = true;
+				}
+			}
+		}
+		bool any_tie = false;
+		if (dev_sorted) for (size_t t : done_t) any_tie |= tie[t] != 0;
+		UBuf<wm128_t> raw(!dev_sorted || any_tie ? tot + 1 : 1, dev_sorted ? 0 : c);       // the unsorted anchors: for the host sort
+		if (!dev_sorted || any_tie) {
+			HIPCHK(hipMemcpyAsync(raw.data(), d_out, tot * sizeof(wm128_t), hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(ctx_sync(c));
+		}
 		WM_SITE("seed.copy+radix_sort");
 		wm::parallel_for(c->host_threads, done_t.size(), [&](size_t k) {
 			const size_t t = done_t[k];
 			wm128_t *dst = out + out_off[todo[t]];
-			memcpy(dst, tmp.data() + jb[t].out_off, (size_t)res[t].n_anchors * sizeof(wm128_t));
+			if (dev_sorted && !tie[t]) { memcpy(dst, tmp.data() + jb[t].out_off, (size_t)res[t].n_anchors * sizeof(wm128_t)); return; }
+			memcpy(dst, raw.data() + jb[t].out_off, (size_t)res[t].n_anchors * sizeof(wm128_t));
 			// the reference's in-place unstable radix sort (src/map.c:252); its tie permutation is sequential by nature
 			wm::radix_sort_128x(dst, dst + res[t].n_anchors);
 		});
