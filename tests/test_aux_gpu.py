@@ -48,7 +48,11 @@ def _windows(ref):
 M128 = np.dtype([("x", np.uint64), ("y", np.uint64)])
 
 
-def test_sketch_seed_chain_kernels(env):
+@pytest.mark.parametrize("device_sort", [0, 1])
+def test_sketch_seed_chain_kernels(env, device_sort, monkeypatch):
+    """device_sort = 1: the anchors are sorted by a segmented radix sort on the device (WM_SEED_DEVICE_SORT), jobs with equal keys fall back to the
+    reference's sequential sort on the host — same expectation (the periodic sequences below produce such ties)"""
+    monkeypatch.setenv("WM_SEED_DEVICE_SORT", str(device_sort))
     ctx, idx, ref, bloom, L = env
     seqs = _windows(ref)
     n = len(seqs)

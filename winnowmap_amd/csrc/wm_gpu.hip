@@ -1364,8 +1364,9 @@ try {
 		// sort by x (src/map.c:252). On the device: a segmented radix sort of all jobs at once gives THE order whenever the keys of a job are
 		// distinct; a job in which two anchors share a key (the same reference position reached from two query positions) gets the tie
 		// permutation of the reference's in-place unstable radix sort, which is sequential by nature -> those jobs are re-sorted on the host.
-		// WM_SEED_HOST_SORT=1: everything on the host (A/B).
-		static const bool host_sort = getenv("WM_SEED_HOST_SORT") != 0;
+		// Opt-in (WM_SEED_DEVICE_SORT=1): on BASELINE config 2 the extra device pass + synchronisation costs about what the host sort on idle
+		// workers costs (0.165 vs 0.174 Gbp/s, profiles/r02x_bench_device_seed_sort.json); it pays when single jobs hold 10^5..10^6 anchors.
+		const bool host_sort = !(getenv("WM_SEED_DEVICE_SORT") && atoi(getenv("WM_SEED_DEVICE_SORT")) != 0);
 		UBuf<wm128_t> tmp(tot + 1, c);
 		UBuf<int> tie(jb.size() + 1, c);
 		bool dev_sorted = false;
