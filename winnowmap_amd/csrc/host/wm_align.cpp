@@ -215,6 +215,21 @@ static void fix_bad_ends(const Reg &r, const m128 *a, int bw, int min_match, int
 	}
 }
 
+// how many leading positions of t[0..n) and q[0..n) hold the same unambiguous base (codes < 4): eight at a time
+static inline uint32_t match_run(const uint8_t *t, const uint8_t *q, uint32_t n)
+{
+	uint32_t l = 0;
+	while (l + 8 <= n) {
+		uint64_t a, b;
+		memcpy(&a, t + l, 8); memcpy(&b, q + l, 8);
+		const uint64_t bad = (a ^ b) | (a & 0xFCFCFCFCFCFCFCFCULL);
+		if (bad) return l + (uint32_t)(__builtin_ctzll(bad) >> 3);
+		l += 8;
+	}
+	while (l < n && t[l] == q[l] && t[l] < 4) ++l;
+	return l;
+}
+
 static void append_cigar(Reg &r, const std::vector<uint32_t> &c)
 {   // mm_append_cigar, src/align.c:288-311
 	if (c.empty()) return;
@@ -238,7 +253,19 @@ static int test_zdrop(const MapOpt &opt, const uint8_t *qseq, const uint8_t *tse
 	for (uint32_t c : cigar) {
 		const uint32_t op = c & 0xf, len = c >> 4;
 		if (op == 0) {
-			for (uint32_t l = 0; l < len; ++l) { score += mat[tseq[i + l] * 5 + qseq[j + l]]; upd(score, i + l, j + l); }
+			// (a run of matches only raises the score: inside a dip the drop z = max - score - diff * e shrinks, so nothing can be recorded
+			// there, and above the old maximum the last base of the run is where max_i / max_j end up — one update per run is exact)
+			const int match_sc = mat[0];
+			for (uint32_t l = 0; l < len;) {
+				const uint32_t run = match_sc > 0 ? match_run(tseq + i + l, qseq + j + l, len - l) : 0;
+				if (run) {
+					score += (int32_t)run * match_sc; l += run;
+					if (score >= max) max = score, max_i = i + (int)l - 1, max_j = j + (int)l - 1;
+					continue;
+				}
+				score += mat[tseq[i + l] * 5 + qseq[j + l]]; upd(score, i + l, j + l);
+				++l;
+			}
 			i += len, j += len;
 		} else if (op == 1 || op == 2 || op == 3) {
 			score -= opt.q + opt.e * len;
@@ -327,12 +354,16 @@ static void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const
 		const uint32_t op = c & 0xf, len = c >> 4;
 		if (op == 0) {
 			int n_ambi = 0, n_diff = 0;
-			for (uint32_t l = 0; l < len; ++l) {
+			const int match_sc = mat[0];
+			for (uint32_t l = 0; l < len;) {
+				const uint32_t run = match_sc > 0 ? match_run(tseq + toff + l, qseq + qoff + l, len - l) : 0;
+				if (run) { s += (int32_t)run * match_sc; max = max > s ? max : s; l += run; continue; }   // (s only grows along the run)
 				const int cq = qseq[qoff + l], ct = tseq[toff + l];
 				if (ct > 3 || cq > 3) ++n_ambi;
 				else if (ct != cq) ++n_diff;
 				s += mat[ct * 5 + cq];
 				if (s < 0) s = 0; else max = max > s ? max : s;
+				++l;
 			}
 			r.blen += len - n_ambi, r.mlen += len - (n_ambi + n_diff), r.n_ambi += n_ambi;
 			toff += len, qoff += len;
@@ -521,6 +552,12 @@ static void finish_reg(const AlnEnv &E, RegAln &A, m128 *a, const std::vector<Ks
 	const int qlen = E.qlen;
 	int32_t rs1, qs1, re1, qe1;
 	bool dropped = false;
+	{   // one allocation for the stitched CIGAR
+		size_t tot = A.left_job >= 0 ? jobs[A.left_job].cigar.size() : 0;
+		for (const Fill &f : A.fills) tot += (f.redo_job >= 0 ? redo[f.redo_job] : jobs[f.job]).cigar.size();
+		if (A.right_job >= 0) tot += jobs[A.right_job].cigar.size();
+		r.cigar.reserve(tot);
+	}
 	if (A.left_job >= 0) {
 		const KswReq &j = jobs[A.left_job];
 		if (j.ez.n_cigar > 0) { append_cigar(r, j.cigar); r.dp_score += j.ez.max; }

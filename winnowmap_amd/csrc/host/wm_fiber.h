@@ -18,7 +18,9 @@
 // sketch, seed, chain, align — in demand at the same time instead of in lock-step phases.
 // Results do not depend on how requests are batched (every job is independent), so the output is deterministic.
 #pragma once
+#if !defined(__x86_64__)
 #include <ucontext.h>
+#endif
 #include <functional>
 #include <deque>
 #include <vector>
@@ -35,7 +37,28 @@
 namespace wm {
 
 class Scheduler;
-struct Fiber { ucontext_t ctx; char *stack; std::function<void()> fn; bool done; Scheduler *owner; int pending; };   // pending: batches this fiber still waits for
+// Context switch. glibc's swapcontext saves and restores the signal mask with a system call on every switch (~200 ns; a read makes ~150
+// switches); fibers never touch signal masks, so on x86-64 the switch is the textbook one: push the callee-saved registers, swap the stack
+// pointers, pop, return. Other targets keep ucontext.
+#if defined(__x86_64__)
+extern "C" void wm_fiber_switch(void **save_sp, void *load_sp);
+__asm__(
+	".text\n"
+	".p2align 4\n"
+	".globl wm_fiber_switch\n"
+	".type wm_fiber_switch,@function\n"
+	"wm_fiber_switch:\n"
+	"	pushq %rbp\n	pushq %rbx\n	pushq %r12\n	pushq %r13\n	pushq %r14\n	pushq %r15\n"
+	"	movq %rsp, (%rdi)\n"
+	"	movq %rsi, %rsp\n"
+	"	popq %r15\n	popq %r14\n	popq %r13\n	popq %r12\n	popq %rbx\n	popq %rbp\n"
+	"	ret\n"
+	".size wm_fiber_switch,.-wm_fiber_switch\n");
+struct FiberCtx { void *sp; };
+#else
+struct FiberCtx { ucontext_t uc; };
+#endif
+struct Fiber { FiberCtx ctx; char *stack; std::function<void()> fn; bool done; Scheduler *owner; int pending; };   // pending: batches this fiber still waits for
 // OP_KSW_HEAVY: alignments whose single-wave run time is long (many rows x many lanes). They get their own queue so that the tail of a
 // batch of heavy jobs (tens of milliseconds for ONE alignment) never delays the bulk of short gap fills.
 // OP_KSW_HUGE: the few alignments that run for a large fraction of a second (unbanded fills across structural variants): a third queue,
@@ -135,10 +158,21 @@ public:
 			f = new Fiber(); f->stack = slabs_.back() + kStack * (size_t)(kSlab - slab_left_--);
 		}
 		f->fn = std::move(fn); f->done = false;
-		getcontext(&f->ctx);
-		f->ctx.uc_stack.ss_sp = f->stack; f->ctx.uc_stack.ss_size = kStack; f->ctx.uc_link = &main_;
+#if defined(__x86_64__)
+		{   // a fresh stack that "returns" into the trampoline: six zeroed callee-saved registers, then the entry address; the slot above it
+			// keeps the stack 16-byte aligned at the trampoline's entry as the ABI expects after a call
+			void **top = (void**)(((uintptr_t)f->stack + kStack) & ~(uintptr_t)15);
+			top[-1] = 0;
+			top[-2] = (void*)&Scheduler::trampoline;
+			for (int i = 3; i <= 8; ++i) top[-i] = 0;
+			f->ctx.sp = (void*)(top - 8);
+		}
+#else
+		getcontext(&f->ctx.uc);
+		f->ctx.uc.uc_stack.ss_sp = f->stack; f->ctx.uc.uc_stack.ss_size = kStack; f->ctx.uc.uc_link = &main_.uc;
 		const uintptr_t p = (uintptr_t)f;
-		makecontext(&f->ctx, (void (*)())&Scheduler::entry, 3, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32), 0);
+		makecontext(&f->ctx.uc, (void (*)())&Scheduler::entry, 3, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32), 0);
+#endif
 		f->owner = this;
 		ready_.push_back(f);
 		hub_->live.fetch_add(1);
@@ -152,11 +186,14 @@ public:
 	{
 		Hub &H = *hub_;
 		double cpu_fiber = 0, wall_idle = 0;
+#if defined(__x86_64__)
+		tl_running() = this;
+#endif
 		for (;;) {
 			const double c0 = thread_cpu_s();
 			while (!ready_.empty()) {
 				cur_ = ready_.front(); ready_.pop_front();
-				swapcontext(&main_, &cur_->ctx);
+				switch_to(main_, cur_->ctx);
 				if (cur_->done) { cur_->fn = nullptr; pool_.push_back(cur_); H.live.fetch_sub(1); }
 				cur_ = 0;
 			}
@@ -223,18 +260,34 @@ public:
 private:
 	static constexpr size_t kStack = 256 * 1024;
 	static constexpr int kSlab = 64;
+#if defined(__x86_64__)
+	static Scheduler *&tl_running() { static thread_local Scheduler *s = 0; return s; }
+	static void switch_to(FiberCtx &from, FiberCtx &to) { wm_fiber_switch(&from.sp, to.sp); }
+	static void trampoline()                // first activation of a fiber: runs on the fiber's own stack, never returns
+	{
+		Scheduler *self = tl_running();
+		Fiber *f = self->cur_;
+		f->fn();
+		f->done = true;
+		self = tl_running();                // (the fiber may have been resumed by the same worker only: owners do not migrate)
+		switch_to(f->ctx, self->main_);
+		__builtin_trap();
+	}
+#else
+	static void switch_to(FiberCtx &from, FiberCtx &to) { swapcontext(&from.uc, &to.uc); }
 	static void entry(unsigned lo, unsigned hi, unsigned)
 	{
 		Fiber *f = (Fiber*)((uintptr_t)lo | (uintptr_t)hi << 32);
 		f->fn();
 		f->done = true;                     // uc_link returns to the scheduler
 	}
+#endif
 	void wait(int ops)                      // ops: bit set of the operations this fiber filed requests for
 	{
 		Fiber *me = cur_;
 		me->pending = 0;
 		for (int op = 0; op < OP_N; ++op) if (ops >> op & 1) { l_wait_[op].push_back(me); ++me->pending; }
-		swapcontext(&me->ctx, &main_);
+		switch_to(me->ctx, main_);
 	}
 	void publish_locked()
 	{
@@ -308,7 +361,7 @@ private:
 
 	Hub *hub_;
 	int rank_;
-	ucontext_t main_;
+	FiberCtx main_;
 	Fiber *cur_ = 0;
 	std::deque<Fiber*> ready_;
 	std::vector<Fiber*> pool_;
