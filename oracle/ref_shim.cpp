@@ -151,6 +151,23 @@ void *refshim_mapopt(const char *preset, int64_t flag_extra, void *mi)
 	mm_mapopt_update(&g_mo, (mm_idx_t*)mi);
 	return &g_mo;
 }
+// every mm_mapopt_t field that wm_mapopt_t mirrors (include/wm_gpu.h), in that struct's order, after mm_set_opt(0) + mm_set_opt(preset)
+int refshim_preset_fields(const char *preset, double *o, int cap)
+{
+	mm_idxopt_t io; mm_mapopt_t m;
+	mm_set_opt(0, &io, &m);
+	if (preset && preset[0] && mm_set_opt(preset, &io, &m) < 0) return -1;
+	const double v[] = { (double)m.flag, (double)m.seed, (double)m.sdust_thres, (double)m.max_qlen, (double)m.bw, (double)m.max_gap, (double)m.max_gap_ref, (double)m.min_gap_ref, (double)m.max_frag_len,
+		(double)m.max_chain_skip, (double)m.max_chain_iter, (double)m.min_cnt, (double)m.min_chain_score, (double)m.chain_gap_scale, (double)m.SVaware, (double)m.SVawareMinReadLength,
+		(double)m.suffixSampleOffset, (double)m.min_mapq, (double)m.min_qcov, (double)m.minPrefixLength, (double)m.maxPrefixLength, (double)m.prefixIncrementFactor, (double)m.stage2_bw,
+		(double)m.stage2_zdrop_inv, (double)m.stage2_max_gap, (double)m.mask_level, (double)m.mask_len, (double)m.pri_ratio, (double)m.best_n, (double)m.max_join_long, (double)m.max_join_short,
+		(double)m.min_join_flank_sc, (double)m.min_join_flank_ratio, (double)m.alt_drop, (double)m.a, (double)m.b, (double)m.q, (double)m.e, (double)m.q2, (double)m.e2, (double)m.sc_ambi,
+		(double)m.zdrop, (double)m.zdrop_inv, (double)m.end_bonus, (double)m.min_dp_max, (double)m.min_ksw_len, (double)m.max_clip_ratio, (double)m.mid_occ_frac, (double)m.min_mid_occ,
+		(double)m.mid_occ, (double)m.max_occ, (double)m.mini_batch_size, (double)m.max_sw_mat, (double)io.k, (double)io.w };
+	const int n = (int)(sizeof(v) / sizeof(v[0]));
+	for (int i = 0; i < n && i < cap; ++i) o[i] = v[i];
+	return n;
+}
 int refshim_preset_k(const char *preset) { mm_idxopt_t io; mm_mapopt_t mo; mm_set_opt(0, &io, &mo); mm_set_opt(preset, &io, &mo); return io.k; }
 int refshim_preset_w(const char *preset) { mm_idxopt_t io; mm_mapopt_t mo; mm_set_opt(0, &io, &mo); mm_set_opt(preset, &io, &mo); return io.w; }
 

@@ -56,3 +56,39 @@ def test_product_does_not_reference_oracle():
                         if needle in ls:
                             bad.append((f, ls))
     assert not bad, bad
+
+
+def test_presets_equal_the_references_mm_set_opt():
+    """wm_mapopt_preset (host code of the library, no GPU needed) against mm_set_opt of the real reference (oracle/_ref): every mirrored
+    mm_mapopt_t field, and k / w, for every preset the library accepts."""
+    import ctypes as C
+    import numpy as np
+    import pytest
+    import wmtest as W
+    if not W.have_ref():
+        pytest.skip("oracle/_ref not built")
+    R = W.ref()
+    R.refshim_preset_fields.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
+    build.build_gpu()
+    L = C.CDLL(gpu.LIB_PATH)
+
+    class MapOpt(C.Structure):
+        _fields_ = [("flag", C.c_int64)] + [(n, C.c_int32) for n in ("seed", "sdust_thres", "max_qlen", "bw", "max_gap", "max_gap_ref", "min_gap_ref", "max_frag_len",
+                                                                      "max_chain_skip", "max_chain_iter", "min_cnt", "min_chain_score")] + \
+                   [("chain_gap_scale", C.c_float)] + [(n, C.c_int32) for n in ("SVaware", "SVawareMinReadLength", "suffixSampleOffset", "min_mapq")] + [("min_qcov", C.c_float)] + \
+                   [(n, C.c_int32) for n in ("minPrefixLength", "maxPrefixLength")] + [("prefixIncrementFactor", C.c_float)] + \
+                   [(n, C.c_int32) for n in ("stage2_bw", "stage2_zdrop_inv", "stage2_max_gap")] + [("mask_level", C.c_float), ("mask_len", C.c_int32), ("pri_ratio", C.c_float), ("best_n", C.c_int32)] + \
+                   [(n, C.c_int32) for n in ("max_join_long", "max_join_short", "min_join_flank_sc")] + [("min_join_flank_ratio", C.c_float), ("alt_drop", C.c_float)] + \
+                   [(n, C.c_int32) for n in ("a", "b", "q", "e", "q2", "e2", "sc_ambi", "zdrop", "zdrop_inv", "end_bonus", "min_dp_max", "min_ksw_len")] + \
+                   [("max_clip_ratio", C.c_float), ("mid_occ_frac", C.c_float)] + [(n, C.c_int32) for n in ("min_mid_occ", "mid_occ", "max_occ")] + [("mini_batch_size", C.c_int64), ("max_sw_mat", C.c_int64)]
+    L.wm_mapopt_preset.argtypes = [C.c_char_p, C.POINTER(MapOpt), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    for preset in (b"", b"map-ont", b"map-pb", b"map-pb-clr", b"asm5", b"asm10", b"asm20"):
+        o = MapOpt(); k = C.c_int(); w = C.c_int()
+        assert L.wm_mapopt_preset(preset, C.byref(o), C.byref(k), C.byref(w)) == 0
+        ours = [float(getattr(o, n)) for n, _ in MapOpt._fields_] + [float(k.value), float(w.value)]
+        ref = np.zeros(64)
+        n = R.refshim_preset_fields(preset, ref.ctypes.data, 64)
+        assert n == len(ours), (n, len(ours))
+        for (name, _), a, b_ in zip(list(MapOpt._fields_) + [("k", 0), ("w", 0)], ours, ref[:n]):
+            assert a == np.float32(b_) or a == b_, (preset, name, a, b_)
+    assert L.wm_mapopt_preset(b"no-such-preset", C.byref(MapOpt()), None, None) != 0
