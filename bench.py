@@ -10,10 +10,13 @@ satellite arrays), `-W` list = canonical 15-mers above the 0.9998-distinct thres
 A STEP = one mini-batch of reads (--reads-per-step per rank; default 65 536 x 15 kb = 0.98 Gbase, the reference's own
 mini-batch size `-K 1G`, src/options.c:50) through the full path: sketch → seed → chain → ksw kernels with
 the host MCAS glue in between; reads shard across ranks (weak scaling: per-GPU work is fixed), no data-path collective.
-The reference index is built by rank 0 and broadcast with RCCL (torch.distributed "nccl") as flat arrays.
+The `-W` list is counted and the reference index is built by rank 0 ON ITS GPU (wm_write_repetitive_kmers_gpu, wm_index_build_gpu: one
+wavefront per contig sketches the reference) and broadcast with RCCL (torch.distributed "nccl") as flat arrays — outside the timed region.
 
 `value` = read bases of all ranks mapped in the timed steps / wall time, inputs resident on the host as the C-ABI takes
-host buffers for reads (the PCIe-inclusive figure is therefore what is reported).
+host buffers for reads (the PCIe-inclusive figure is therefore what is reported). Inside a step the read codes
+are uploaded once and every alignment / sketch request refers to positions in them and in the packed reference.
+`host`: where the host time of the timed region went (per-read glue, batched calls, helpers, idle) against the usable cores.
 `roofline`: dominant kernel = ksw_dp (1 B of traceback per DP cell is > 99 % of the path's algorithmic bytes);
 achieved = DP cells of the timed steps ÷ the kernels' summed duration (HIP events on their streams).
 `cpu_baseline`: the REAL reference (oracle/_ref/winnowmap_ref, built from /root/reference) mapping ONE FULL STEP of the
