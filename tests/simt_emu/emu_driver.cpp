@@ -4,6 +4,7 @@
 #include "simt.h"                    // the emulator (this directory is first on the include path)
 #include "ksw_kernel.h"              // winnowmap_amd/csrc
 #include "ksw_packed_kernel.h"
+#include "ksw_packed_multi_kernel.h"
 #include "ksw_plan.h"
 #include "sketch_kernel.h"
 #include "seedchain_kernel.h"
@@ -28,6 +29,36 @@ template <int BP> static void run_dpp(int variant, const wm_ksw_score_t &sc, con
 	}
 }
 
+// the packed multi-wave kernel: NWV emulated wavefronts (one host thread each) around a shared barrier
+template <int BP, int NWV> static void run_pmulti(int variant, const wm_ksw_score_t &sc, const wm_ksw_djob_t &jb, const uint8_t *seqs, uint8_t *tb, wm_ksw_dres_t *res)
+{
+	const bool exact = variant & 4, clip = variant & 2, hasn = variant & 1;
+	std::vector<int> lds(wmk::ksw_pmulti_lds<BP, NWV>::INTS, 0x5a5a5a5a);
+	pthread_barrier_t bar;
+	pthread_barrier_init(&bar, 0, NWV);
+	simt::block_barrier() = &bar;
+	std::vector<std::thread> th;
+	for (int w = 0; w < NWV; ++w)
+		th.emplace_back([&, w]() {
+			simt::wave_slot() = w; simt::exec_mask() = ~0ull;
+			const uint8_t *q_ = seqs + jb.q_off, *t_ = seqs + jb.t_off;
+			if (exact) {
+				if (clip && hasn) wmk::ksw_dp_pmulti<BP, NWV, true, true, true>(sc, jb, q_, t_, tb, lds.data(), res);
+				else if (clip) wmk::ksw_dp_pmulti<BP, NWV, true, false, true>(sc, jb, q_, t_, tb, lds.data(), res);
+				else if (hasn) wmk::ksw_dp_pmulti<BP, NWV, false, true, true>(sc, jb, q_, t_, tb, lds.data(), res);
+				else wmk::ksw_dp_pmulti<BP, NWV, false, false, true>(sc, jb, q_, t_, tb, lds.data(), res);
+			} else {
+				if (clip && hasn) wmk::ksw_dp_pmulti<BP, NWV, true, true, false>(sc, jb, q_, t_, tb, lds.data(), res);
+				else if (clip) wmk::ksw_dp_pmulti<BP, NWV, true, false, false>(sc, jb, q_, t_, tb, lds.data(), res);
+				else if (hasn) wmk::ksw_dp_pmulti<BP, NWV, false, true, false>(sc, jb, q_, t_, tb, lds.data(), res);
+				else wmk::ksw_dp_pmulti<BP, NWV, false, false, false>(sc, jb, q_, t_, tb, lds.data(), res);
+			}
+		});
+	for (auto &t : th) t.join();
+	simt::block_barrier() = 0;
+	pthread_barrier_destroy(&bar);
+}
+
 extern "C" {
 
 // force_klass < 0: choose like the product host; otherwise use that class (to exercise CLIP/HASN variants on any input)
@@ -45,6 +76,8 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 	memset(&jb, 0, sizeof(jb));
 	jb.q_off = 0; jb.t_off = qlen; jb.qlen = qlen; jb.tlen = tlen; jb.w = w; jb.zdrop = zdrop; jb.end_bonus = end_bonus; jb.flag = flag;
 	bool emu_blk3_small = false, emu_blk_lds = false, emu_bp2 = false;
+	int emu_pmulti = 0;      // 200 + geometry * 10 + (CLIP * 2 + HASN): the packed multi-wave kernel; geometry 0 = <1,2> (256 lanes), 1 = <2,3> (768), 2 = <4,4> (2048), 3 = <8,4> (4096), 4 = <4,8> (4096) and 5 = <8,8> (8192): the product's WM_KSW_PMULTI geometries
+	if (force_klass >= 200 && force_klass < 260) { emu_pmulti = 1 + (force_klass - 200) / 10; force_klass = WM_KSW_P4 + (force_klass - 200) % 10; }
 	// force_klass: -1 = choose like the product host; 0..23 = that register class (window and CLIP / HASN bits as given, EXACT always follows
 	// the job's flag); 100 + (CLIP*2 + HASN) = the 2-pair window (256 lanes: many re-bases and pair boundaries on small inputs; tests only);
 	// 24..27 = that wide class; 124 / 125 = the LDS-state block kernel at the BLOCK / BLOCK2 size; 126 = BLOCK3 with a small geometry
@@ -53,7 +86,7 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 	if (force_klass == 125) { emu_blk_lds = true; force_klass = WM_KSW_BLOCK2; }
 	if (force_klass == 126) { emu_blk3_small = true; force_klass = WM_KSW_BLOCK3; }
 	int n_col, klass = wm_ksw_classify(qlen, tlen, w, wm_ksw_has_n(query, qlen) | wm_ksw_has_n(target, tlen), flag, &n_col);
-	if (force_klass >= 0) {
+	if (force_klass >= 0 && !emu_pmulti) {
 		if (force_klass < WM_KSW_BLOCK) {
 			if (klass >= WM_KSW_BLOCK || (force_klass & ~7) < (klass & ~7)) return -1;      // window too small for this job
 			if ((klass & 3) & ~(force_klass & 3)) return -1;                               // the job needs CLIP / HASN and the forced variant lacks it
@@ -64,13 +97,31 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 		}
 	}
 	if (emu_bp2 && n_col > 128 * 2 - 16) return -1;
+	if (emu_pmulti) {
+		static const int lanes[6] = { 256, 768, 2048, 4096, 4096, 8192 };
+		n_col = wm_ksw_ncol(qlen, tlen, w);
+		if (n_col > lanes[emu_pmulti - 1] - 16) return -1;
+		const int has_n = wm_ksw_has_n(query, qlen) | wm_ksw_has_n(target, tlen);
+		int ww = w < 0 ? (tlen > qlen ? tlen : qlen) : w;
+		const int need = (!(ww >= qlen && ww >= tlen) ? 2 : 0) | (has_n ? 1 : 0);
+		if (need & ~(force_klass & 3)) return -1;
+		klass = (force_klass & 3) | ((flag & 0x08) ? 0 : 4);
+	}
 	*klass_out = klass;
 	if (emu_blk3_small && n_col + 16 > 128 * WM_KSW_BLK_MAXC) return -1;
 	jb.n_col = n_col; jb.tb_off = 0; jb.klass = klass;
 	std::vector<uint8_t> tb((size_t)(qlen + tlen - 1) * n_col + 64, 0xEE);
 	wm_ksw_dres_t res;
 	memset(&res, 0, sizeof(res));
-	if (klass == WM_KSW_BLOCK || klass == WM_KSW_BLOCK2 || klass == WM_KSW_BLOCK3) {
+	if (emu_pmulti) {
+		const int variant = (klass & 4) | ((klass & 2) || (klass & 1) ? 2 : 0) | (klass & 1);      // (jobs with an N run on the CLIP instantiation, as in the product)
+		if (emu_pmulti == 1) run_pmulti<1, 2>(variant, sc, jb, seqs.data(), tb.data(), &res);
+		else if (emu_pmulti == 2) run_pmulti<2, 3>(variant, sc, jb, seqs.data(), tb.data(), &res);
+		else if (emu_pmulti == 3) run_pmulti<4, 4>(variant, sc, jb, seqs.data(), tb.data(), &res);
+		else if (emu_pmulti == 4) run_pmulti<8, 4>(variant, sc, jb, seqs.data(), tb.data(), &res);
+		else if (emu_pmulti == 5) run_pmulti<4, 8>(variant, sc, jb, seqs.data(), tb.data(), &res);
+		else run_pmulti<8, 8>(variant, sc, jb, seqs.data(), tb.data(), &res);
+	} else if (klass == WM_KSW_BLOCK || klass == WM_KSW_BLOCK2 || klass == WM_KSW_BLOCK3) {
 		constexpr int NWV = WM_KSW_BLK_NWV;
 		const int WN = klass == WM_KSW_BLOCK ? WM_KSW_BLK_WN : klass == WM_KSW_BLOCK2 ? WM_KSW_BLK2_WN : (int)wm_ksw_blk3_wn(tlen);
 		std::vector<int> W0(WN, 0x5a5a5a5a), W1(WN, 0x5a5a5a5a), Hm(WN, 0x5a5a5a5a), pub(WM_KSW_BLK_PUB);   // the state starts as garbage

@@ -1,5 +1,6 @@
 """Kernel logic on the CPU: the product kernel headers compiled against the host wavefront emulator
 (tests/simt_emu) must agree bit-for-bit with the oracle. This is how kernel bugs are found without a GPU."""
+import collections
 import ctypes as C
 import numpy as np
 import pytest
@@ -193,3 +194,59 @@ def test_seed_and_chain_kernels_emulated_match_oracle(emu, small_index):
             assert np.array_equal(u[:nu.value], ou) and np.array_equal(bx[:nv], obx) and np.array_equal(by[:nv], oby), (wi, n, win, nwv)
             n_chain += 1
     assert n_chain >= 24
+
+
+def test_packed_multiwave_ksw_kernel_matches_oracle(emu):
+    """ksw_dp_pmulti (ksw_packed_multi_kernel.h): the packed two-cells-per-lane machine over several wavefronts. Small geometries (2 waves x 1
+    pair = 256 lanes, 3 waves x 2 pairs = 768 lanes) force many re-bases, pair boundaries on every wavefront and hulls that sweep across the
+    whole window on small random cases of every flag / band / scoring combination; the production geometries (4 x 4 pairs = 2048 lanes,
+    4 x 8 = 4096 lanes) run on natively wide bands."""
+    from winnowmap_amd import synth
+    n_run = collections.Counter()
+    for c in kswcases.make_cases(7, 80, max_len=500):
+        o = W.o_ksw_extd2(c["q"], c["t"], mat=W.simple_mat(c["a"], c["b"], 1), q=c["q_"], e=c["e"], q2=c["q2"], e2=c["e2"],
+                          w=c["w"], zdrop=c["zdrop"], end_bonus=c["end_bonus"], flag=c["flag"])
+        for force in (200, 202, 203, 210, 212, 213, 222):
+            n, ez, cig, klass = emu_ksw(emu, c, force)
+            if n < 0:
+                continue
+            n_run[force // 10] += 1
+            assert [int(x) for x in ez] == [o[k] for k in W.EZ_FIELDS], (force, len(c["q"]), len(c["t"]), c["flag"], c["w"], c["zdrop"])
+            assert np.array_equal(cig, o["cigar"]), (force, len(c["q"]), len(c["t"]), c["flag"], c["w"])
+    # the band sitting on the last target lane when that lane starts a 16-lane group (en0 == st == tlen - 1 on rows that do not re-base):
+    # H of the lane below the window is then the value the LAST re-base left (a bug of the first version of this kernel)
+    rng = np.random.default_rng(5)
+    for it, (ql, tl) in enumerate(((214, 209), (489, 193), (150, 129), (333, 321), (90, 65))):
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        q = np.concatenate([synth.mutate_codes(t, rng, 0.03, 0.02, 0.02), rng.integers(0, 4, ql).astype(np.uint8)])[:ql]
+        c = dict(q=q, t=t, a=1, b=4, q_=6, e=2, q2=26, e2=1, w=[5, 5, 3, 9, 5][it], zdrop=[200, 400, -1, 100, 50][it], end_bonus=0, flag=[0x80, 0, 0x40, 0x80, 0][it])
+        o = W.o_ksw_extd2(c["q"], c["t"], mat=W.simple_mat(c["a"], c["b"], 1), q=c["q_"], e=c["e"], q2=c["q2"], e2=c["e2"],
+                          w=c["w"], zdrop=c["zdrop"], end_bonus=c["end_bonus"], flag=c["flag"])
+        for force in (2, 3, 202, 203, 212, 213, 223):
+            n, ez, cig, klass = emu_ksw(emu, c, force)
+            assert n >= 0, (force, ql, tl)
+            assert [int(x) for x in ez] == [o[k] for k in W.EZ_FIELDS], (force, ql, tl, c["flag"], c["w"], c["zdrop"])
+            assert np.array_equal(cig, o["cigar"]), (force, ql, tl)
+    rng = np.random.default_rng(19)
+    wide = []
+    for it in range(4):
+        tl = int(rng.integers(1300, 2200))
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        q = synth.mutate_codes(t, rng, 0.04, 0.04, 0.05) if it else rng.integers(0, 4, 1500).astype(np.uint8)
+        if it == 3:
+            q[700] = 4
+        wide.append(dict(q=q, t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=[3001, 1200, 3001, 900][it], zdrop=[400, 200, -1, 400][it], end_bonus=[-1, 10, -1, 0][it], flag=[0x08, 0x40, 0xC2, 0x00][it]))
+    for tl, fl, w in ((5200, 0x08, -1), (6100, 0x40, -1), (3900, 0x00, -1), (6000, 0x88, 4500)):       # hulls of 3900..6100 lanes: the 4096- and 8192-lane geometries
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        wide.append(dict(q=synth.mutate_codes(t, rng, 0.03, 0.03, 0.03), t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=w, zdrop=400, end_bonus=-1, flag=fl))
+    for c in wide:
+        o = W.o_ksw_extd2(c["q"], c["t"], mat=W.simple_mat(c["a"], c["b"], 1), q=c["q_"], e=c["e"], q2=c["q2"], e2=c["e2"],
+                          w=c["w"], zdrop=c["zdrop"], end_bonus=c["end_bonus"], flag=c["flag"])
+        for force in (220, 222, 223, 230, 232, 233, 243, 253):          # (243 / 253: the CLIP + HASN instantiations of <4,8> and <8,8>, what WM_KSW_PMULTI launches)
+            n, ez, cig, klass = emu_ksw(emu, c, force)
+            if n < 0:
+                continue
+            n_run[force // 10] += 1
+            assert [int(x) for x in ez] == [o[k] for k in W.EZ_FIELDS], (force, len(c["q"]), len(c["t"]), c["flag"], c["w"])
+            assert np.array_equal(cig, o["cigar"]), (force, len(c["q"]), len(c["t"]), c["flag"], c["w"])
+    assert n_run[20] > 30 and n_run[21] > 60 and n_run[22] >= 4 and n_run[23] >= 4 and n_run[24] >= 5 and n_run[25] >= 8, n_run

@@ -1,4 +1,5 @@
 """GPU parity: the HIP ksw kernels (through the C-ABI) vs the oracle, bit-exact (integer DP)."""
+import os
 import numpy as np
 import pytest
 import wmtest as W
@@ -117,6 +118,13 @@ def test_wide_band_jobs_block_and_generic_kernels(ctx):
         cases.append(dict(q=synth.mutate_codes(t, rng, 0.03, 0.03, 0.03), t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=-1, zdrop=400, end_bonus=-1, flag=fl))
     bad = _run_group(ctx, cases)
     assert not bad, bad[:3]
+
+
+@pytest.mark.skipif(os.environ.get("WM_TEST_PMULTI", "0") != "1", reason="ksw_dp_pmulti is opt-in until it has run on a GPU: set WM_TEST_PMULTI=1")
+def test_wide_band_jobs_packed_multiwave_kernel(ctx, monkeypatch):
+    """WM_KSW_PMULTI=1 routes the BLOCK / BLOCK2 classes to ksw_pmulti_kernel<4,8> / <8,8> (ksw_packed_multi_kernel.h): same cases, same bar."""
+    monkeypatch.setenv("WM_KSW_PMULTI", "1")
+    test_wide_band_jobs_block_and_generic_kernels(ctx)
 
 
 def test_position_jobs_equal_byte_jobs(tmp_path):

@@ -44,6 +44,7 @@ static inline double now_ms() { return std::chrono::duration<double, std::milli>
 #include "simt.h"
 #include "ksw_kernel.h"
 #include "ksw_packed_kernel.h"
+#include "ksw_packed_multi_kernel.h"
 #include "ksw_plan.h"
 #include "sketch_kernel.h"
 #include "seedchain_kernel.h"
@@ -122,6 +123,32 @@ __global__ __launch_bounds__(64 * NWV) void ksw_multi_kernel(wm_ksw_score_t sc, 
 		wmk::ksw_dp_multi<WM_KSW_MULTI_B, NWV, true, true>(sc, jb, sq, st, tb, lds, res + j);
 	} else
 		wmk::ksw_dp_multi<WM_KSW_MULTI_B, NWV, true, true>(sc, jb, seqs + jb.q_off, seqs + jb.t_off, tb, lds, res + j);
+}
+
+// BLOCK / BLOCK2 classes, opt-in (WM_KSW_PMULTI=1): the packed two-cells-per-lane machine over 8 wavefronts (ksw_dp_pmulti<4,8>: 4096 lanes,
+// <8,8>: 8192 lanes). Bit-exact on the wavefront emulator; not the default until it has been run and timed on a GPU. Same dynamic LDS
+// layout as ksw_multi_kernel: exchange areas, then the staged sequences
+template <int BP, int NWV>
+__global__ __launch_bounds__(64 * NWV) void ksw_pmulti_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
+                                                                         const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res, int seq_cap)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	typedef wmk::ksw_pmulti_lds<BP, NWV> L;
+	int *lds = (int*)smem;
+	uint8_t *sq = (uint8_t*)(lds + L::INTS);
+	const int j = order[blockIdx.x];
+	const wm_ksw_djob_t jb = jobs[j];
+	const int qpad = (jb.qlen + 15) & ~15;
+	const uint8_t *qp = seqs + jb.q_off, *tp = seqs + jb.t_off;
+	if (qpad + jb.tlen <= seq_cap) {
+		uint8_t *st = sq + qpad;
+		for (int i = threadIdx.x; i < jb.qlen; i += blockDim.x) sq[i] = seqs[jb.q_off + i];
+		for (int i = threadIdx.x; i < jb.tlen; i += blockDim.x) st[i] = seqs[jb.t_off + i];
+		__syncthreads();
+		qp = sq; tp = st;
+	}
+	if (jb.flag & KSW_F_APPROX_MAX) wmk::ksw_dp_pmulti<BP, NWV, true, true, false>(sc, jb, qp, tp, tb, lds, res + j);
+	else wmk::ksw_dp_pmulti<BP, NWV, true, true, true>(sc, jb, qp, tp, tb, lds, res + j);
 }
 
 // operands of position jobs (wm_ksw_batch_pos): expand query and target of job blockIdx.x into the batch's sequence slab. Query = two-strand
@@ -640,7 +667,19 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		struct Done { decltype(class_done) &f; int k; double t; hipEvent_t e; hipStream_t s; ~Done() { hipEventRecord(e, s); f(k, t); } } done_guard{ class_done, k, tk0, c->cev[k][1], ks };
 		if (k == WM_KSW_BLOCK || k == WM_KSW_BLOCK2 || k == WM_KSW_BLOCK3) {
 			const size_t fixed = (size_t)WM_KSW_BLK_PUB * 4;
-			if (k == WM_KSW_BLOCK) {
+			const char *pm_env = getenv("WM_KSW_PMULTI");
+			if ((k == WM_KSW_BLOCK || k == WM_KSW_BLOCK2) && pm_env && atoi(pm_env) > 0) {
+				const int seq_cap = 64 * 1024;
+				if (k == WM_KSW_BLOCK) {
+					const size_t lds = (size_t)wmk::ksw_pmulti_lds<4, 8>::INTS * 4 + seq_cap;
+					HIPCHK(hipFuncSetAttribute((const void*)ksw_pmulti_kernel<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+					hipLaunchKernelGGL((ksw_pmulti_kernel<4, 8>), dim3(nk), dim3(64 * 8), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, seq_cap);
+				} else {
+					const size_t lds = (size_t)wmk::ksw_pmulti_lds<8, 8>::INTS * 4 + seq_cap;
+					HIPCHK(hipFuncSetAttribute((const void*)ksw_pmulti_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+					hipLaunchKernelGGL((ksw_pmulti_kernel<8, 8>), dim3(nk), dim3(64 * 8), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, seq_cap);
+				}
+			} else if (k == WM_KSW_BLOCK) {
 				const int seq_cap = 64 * 1024;
 				const size_t lds = (size_t)wmk::ksw_multi_lds<WM_KSW_MULTI_B, WM_KSW_MULTI_NWV>::INTS * 4 + seq_cap;
 				HIPCHK(hipFuncSetAttribute((const void*)ksw_multi_kernel<WM_KSW_MULTI_NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
