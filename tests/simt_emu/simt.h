@@ -14,6 +14,7 @@
 
 #define WM_SIMT_EMU 1
 #define WM_DEV inline
+#define WM_KEEP_BRANCH() ((void)0)
 #define WM_EMU_ASSERT(x) do { if (!(x)) { fprintf(stderr, "EMU ASSERT %s:%d: %s\n", __FILE__, __LINE__, #x); abort(); } } while (0)
 
 namespace simt {
@@ -150,6 +151,7 @@ inline V<int> pk_lshr(const V<int> &a, int k) { V<int> r; for (int i = 0; i < WA
 inline V<int> lshr(const V<int> &a, int k) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = lshr(a.v[i], k); return r; }
 inline V<int> pk_mad(const V<int> &a, int b, const V<int> &c) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = pk_mad(a.v[i], b, c.v[i]); return r; }
 inline V<int> pk_mad(const V<int> &a, int b, int c) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = pk_mad(a.v[i], b, c); return r; }
+inline V<int> perm(const V<int> &a, const V<int> &b, const V<int> &sel) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = perm(a.v[i], b.v[i], sel.v[i]); return r; }
 inline V<int> perm(const V<int> &a, const V<int> &b, int sel) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = perm(a.v[i], b.v[i], sel); return r; }
 inline V<int> bfi(const V<int> &m, const V<int> &a, const V<int> &b) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = bfi(m.v[i], a.v[i], b.v[i]); return r; }
 inline V<int> bfi(int m, const V<int> &a, const V<int> &b) { return bfi(V<int>(m), a, b); }
@@ -163,6 +165,7 @@ template <class T> V<T> shr1(const V<T> &x, T fill) { V<T> r; r.v[0] = fill; for
 template <class T> V<T> shr1(const V<T> &x, const V<T> &fill) { V<T> r; r.v[0] = fill.v[0]; for (int i = 1; i < WAVE; ++i) r.v[i] = x.v[i - 1]; return r; }
 template <class T> V<T> shift_down(const V<T> &x, int k, T fill) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = i + k < WAVE ? x.v[i + k] : fill; return r; }
 template <class T> V<T> shift_down(const V<T> &x, int k, const V<T> &fill) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = i + k < WAVE ? x.v[i + k] : fill.v[i]; return r; }
+template <class T> V<T> ror1(const V<T> &x) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = x.v[(i + WAVE - 1) & (WAVE - 1)]; return r; }
 template <class T> V<T> rot_down(const V<T> &x, int k) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = x.v[(i + k) & (WAVE - 1)]; return r; }
 template <class T> V<T> shr_n(const V<T> &x, int o) { V<T> r; for (int i = 0; i < WAVE; ++i) r.v[i] = i >= o ? x.v[i - o] : x.v[i]; return r; }
 template <class T> T readlane(const V<T> &x, int l) { WM_EMU_ASSERT(l >= 0 && l < WAVE); return x.v[l]; }

@@ -9,15 +9,28 @@ import kswcases
 from winnowmap_amd import build
 
 
-@pytest.fixture(scope="module")
-def emu():
-    E = C.CDLL(build.build_emu())
+def _load_emu(defines=()):
+    E = C.CDLL(build.build_emu(defines))
     E.emu_ksw_extd2.argtypes = [C.c_int, W.u8p, C.c_int, W.u8p, W.i8p] + [C.c_int] * 9 + [W.i32p, W.u32p, C.c_int, C.POINTER(C.c_int)]
     E.emu_sketch.argtypes = [C.c_int, W.u8p, W.u64p, W.i32p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, W.u64p, W.u64p, W.u64p, W.i32p, W.i32p]
     E.emu_sketch_coop.argtypes = E.emu_sketch.argtypes
     E.emu_seed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, W.u64p, W.u64p, C.c_int, C.c_int, C.c_int, C.c_int, W.u64p, W.u64p, C.c_int, W.i32p]
     E.emu_chain_fill.argtypes = [C.c_int64, W.u64p, W.u64p] + [C.c_int] * 6 + [C.c_float, C.c_float, W.i32p, W.i32p, W.i32p]
     return E
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return _load_emu()
+
+
+# kernel variants that are compiled in but not the library default yet (winnowmap_amd/build.py WM_KERNEL_DEFINES): same tests, same bar
+KSW_VARIANTS = {"default": (), "ror": ("WM_KSW_ROR=1",)}
+
+
+@pytest.fixture(scope="module", params=sorted(KSW_VARIANTS))
+def emu_v(request):
+    return _load_emu(KSW_VARIANTS[request.param])
 
 
 def emu_ksw(E, c, force=-1):
@@ -30,7 +43,8 @@ def emu_ksw(E, c, force=-1):
 
 
 @pytest.mark.parametrize("seed", [1, 2])
-def test_ksw_emulated_kernel_matches_oracle(emu, seed):
+def test_ksw_emulated_kernel_matches_oracle(emu_v, seed):
+    emu = emu_v
     seen = set()
     for c in kswcases.make_cases(seed, 90, max_len=600):
         o = W.o_ksw_extd2(c["q"], c["t"], mat=W.simple_mat(c["a"], c["b"], 1), q=c["q_"], e=c["e"], q2=c["q2"], e2=c["e2"],
@@ -196,11 +210,12 @@ def test_seed_and_chain_kernels_emulated_match_oracle(emu, small_index):
     assert n_chain >= 24
 
 
-def test_packed_multiwave_ksw_kernel_matches_oracle(emu):
+def test_packed_multiwave_ksw_kernel_matches_oracle(emu_v):
     """ksw_dp_pmulti (ksw_packed_multi_kernel.h): the packed two-cells-per-lane machine over several wavefronts. Small geometries (2 waves x 1
     pair = 256 lanes, 3 waves x 2 pairs = 768 lanes) force many re-bases, pair boundaries on every wavefront and hulls that sweep across the
     whole window on small random cases of every flag / band / scoring combination; the production geometries (4 x 4 pairs = 2048 lanes,
     4 x 8 = 4096 lanes) run on natively wide bands."""
+    emu = emu_v
     from winnowmap_amd import synth
     n_run = collections.Counter()
     for c in kswcases.make_cases(7, 80, max_len=500):

@@ -125,6 +125,22 @@ def test_wide_band_jobs_packed_multiwave_kernel(ctx, monkeypatch):
     """WM_KSW_PMULTI=1 routes the BLOCK / BLOCK2 classes to ksw_pmulti_kernel<4,8> / <8,8> (ksw_packed_multi_kernel.h): same cases, same bar."""
     monkeypatch.setenv("WM_KSW_PMULTI", "1")
     test_wide_band_jobs_block_and_generic_kernels(ctx)
+    # 2: the 16-pair register classes (hulls of 1009..2032 lanes) run on ksw_pmulti_kernel<4,4> as well
+    monkeypatch.setenv("WM_KSW_PMULTI", "2")
+    test_wide_band_jobs_block_and_generic_kernels(ctx)
+    rng = np.random.default_rng(8)
+    from winnowmap_amd import synth
+    cases = []
+    for it in range(24):
+        tl = int(rng.integers(1050, 2000))
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        q = synth.mutate_codes(t, rng, 0.04, 0.04, 0.05)
+        if it % 6 == 2:
+            t[int(rng.integers(0, tl))] = 4
+        cases.append(dict(q=q, t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=[-1, 2500, 1100, 700][it % 4], zdrop=[400, 200, -1][it % 3],
+                          end_bonus=[-1, 10][it % 2], flag=kswcases.FLAGS[it % 6]))
+    bad = _run_group(ctx, cases)
+    assert not bad, bad[:3]
 
 
 def test_position_jobs_equal_byte_jobs(tmp_path):

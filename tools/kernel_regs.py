@@ -1,6 +1,8 @@
 #!/usr/bin/env python
-"""VGPR / SGPR / spill / LDS per kernel from the device assembly of wm_gpu.hip (hipcc -S --cuda-device-only).
-  python tools/kernel_regs.py [out.txt]"""
+"""VGPR / SGPR / spill / LDS / scratch and static instruction counts per kernel, from the device assembly of wm_gpu.hip
+(hipcc -S --cuda-device-only with the library's flags, winnowmap_amd/build.py HIP_FLAGS).
+  python tools/kernel_regs.py [out.txt]
+  python tools/kernel_regs.py --compare [out.txt]     the same table without / with -mllvm -disable-promote-alloca-to-vector"""
 import os
 import re
 import subprocess
@@ -8,23 +10,74 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tmp = tempfile.mkdtemp()
-asm = os.path.join(tmp, "wm.s")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-w",
-                       "--cuda-device-only", "-S", "-o", asm, os.path.join(ROOT, "winnowmap_amd", "csrc", "wm_gpu.hip")])
-txt = open(asm).read()
-meta = txt[txt.index("amdhsa.kernels:"):]
-rows = []
-for blk in re.split(r"\n  - \.agpr_count", meta)[1:]:
-    g = lambda k: (re.search(r"\.%s:\s+(\S+)" % k, blk) or [None, "?"])[1]
-    name = subprocess.run(["c++filt", g("name")], capture_output=True, text=True).stdout.strip()
-    name = re.sub(r"\(.*", "", name).replace("void ", "")
-    v = int(g("vgpr_count"))
-    alloc = (v + 7) // 8 * 8
-    rows.append((name, v, min(8, 512 // max(alloc, 1)), g("sgpr_count"), g("vgpr_spill_count"), g("group_segment_fixed_size"), g("private_segment_fixed_size")))
-out = "%-52s %5s %10s %5s %6s %8s %8s\n" % ("kernel", "vgpr", "waves/SIMD", "sgpr", "spill", "lds", "scratch")
-for r in sorted(rows):
-    out += "%-52s %5d %10d %5s %6s %8s %8s\n" % r
+sys.path.insert(0, ROOT)
+from winnowmap_amd.build import HIP_FLAGS  # noqa: E402
+
+PROMOTE = ["-mllvm", "-disable-promote-alloca-to-vector"]
+
+
+def device_asm(flags):
+    asm = os.path.join(tempfile.mkdtemp(), "wm.s")
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-w", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", asm,
+                           os.path.join(ROOT, "winnowmap_amd", "csrc", "wm_gpu.hip")])
+    return open(asm).read()
+
+
+def parse(txt):
+    """{mangled name: dict(vgpr, sgpr, spill, lds, scratch, valu, salu, mov64)}"""
+    meta = txt[txt.index("amdhsa.kernels:"):]
+    out = {}
+    for blk in re.split(r"\n  - \.agpr_count", meta)[1:]:
+        g = lambda k: (re.search(r"\.%s:\s+(\S+)" % k, blk) or [None, "0"])[1]
+        out[g("name")] = dict(vgpr=int(g("vgpr_count")), sgpr=int(g("sgpr_count")), spill=int(g("vgpr_spill_count")),
+                              lds=int(g("group_segment_fixed_size")), scratch=int(g("private_segment_fixed_size")), valu=0, salu=0, mov64=0)
+    cur = None
+    for line in txt.split("\n"):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = out.get(m.group(1))
+        elif "s_endpgm" in line:
+            cur = None
+        elif cur is not None:
+            if line.startswith("\tv_"):
+                cur["valu"] += 1
+                cur["mov64"] += "v_mov_b64" in line
+            elif line.startswith("\ts_"):
+                cur["salu"] += 1
+    return out
+
+
+def pretty(names):
+    dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+    return {n: re.sub(r"\(.*", "", d).replace("void ", "") for n, d in zip(names, dem)}
+
+
+def waves(v):
+    return min(8, 512 // max((v + 7) // 8 * 8, 1))
+
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+if "--compare" in sys.argv:
+    base = [f for f in HIP_FLAGS if f not in PROMOTE]
+    a, b = parse(device_asm(base)), parse(device_asm(base + PROMOTE))
+    nm = pretty(list(a))
+    out = "static per-kernel figures of wm_gpu.hip without -> with  -mllvm -disable-promote-alloca-to-vector  (VALU / v_mov_b64 = instructions in the code object)\n"
+    out += "%-48s %11s %11s %13s %13s %11s\n" % ("kernel", "vgpr", "waves/SIMD", "VALU", "v_mov_b64", "scratch B")
+    for k in sorted(a, key=lambda k: nm[k]):
+        if "rocprim" in nm[k] and a[k]["scratch"] == b[k]["scratch"]:
+            continue
+        x, y = a[k], b[k]
+        out += "%-48s %4d ->%4d %4d ->%4d %5d ->%5d %5d ->%5d %4d ->%4d\n" % (nm[k][:48], x["vgpr"], y["vgpr"], waves(x["vgpr"]), waves(y["vgpr"]),
+                                                                           x["valu"], y["valu"], x["mov64"], y["mov64"], x["scratch"], y["scratch"])
+else:
+    a = parse(device_asm(HIP_FLAGS))
+    nm = pretty(list(a))
+    out = "%-52s %5s %10s %5s %6s %8s %8s %6s %6s\n" % ("kernel", "vgpr", "waves/SIMD", "sgpr", "spill", "lds", "scratch", "VALU", "SALU")
+    for k in sorted(a, key=lambda k: nm[k]):
+        if "rocprim" in nm[k]:
+            continue
+        x = a[k]
+        out += "%-52s %5d %10d %5d %6d %8d %8d %6d %6d\n" % (nm[k][:52], x["vgpr"], waves(x["vgpr"]), x["sgpr"], x["spill"], x["lds"], x["scratch"], x["valu"], x["salu"])
 print(out)
-if len(sys.argv) > 1:
-    open(sys.argv[1], "w").write(out)
+if args:
+    open(args[0], "w").write(out)

@@ -17,12 +17,21 @@ def _newer(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+# -disable-promote-alloca-to-vector: the ksw kernels keep their per-lane state in small register arrays indexed by fully unrolled loops.
+# AMDGPUPromoteAllocaToVector runs BEFORE the unroller, turns each array into one <N x i32> value, and every uniform branch that assigns an
+# element then copies the whole vector at its join: 1536 v_mov_b64 (37 % of the VALU instructions) and 31 extra VGPRs in
+# ksw_dpp_kernel<16,false,false,true>. Without the pass SROA splits the arrays into scalars after unrolling; no kernel of the library gains
+# scratch (tools/kernel_regs.py; two rocPRIM sort kernels of the k-mer counter take 64 B). profiles/r02z_codegen_flag.txt
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-mllvm", "-disable-promote-alloca-to-vector"]
+
+
 def build_gpu(force=False, verbose=False):
     srcs = [os.path.join(d, f) for d, _, fs in os.walk(CSRC) for f in fs] + [os.path.join(ROOT, "include", "wm_gpu.h")]
     if not force and not _newer(LIB, srcs):
         return LIB
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
-           "-Wno-unused-value", "-o", LIB, os.path.join(CSRC, "wm_gpu.hip"), "-lz", "-lpthread"]
+    # WM_KERNEL_DEFINES="WM_KSW_ROR=1 ...": kernel variants under evaluation (A/B on a GPU box); the default build defines nothing
+    defs = ["-D" + d for d in os.environ.get("WM_KERNEL_DEFINES", "").split()]
+    cmd = [HIPCC] + HIP_FLAGS + defs + ["-shared", "-fPIC", "-o", LIB, os.path.join(CSRC, "wm_gpu.hip"), "-lz", "-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
@@ -38,13 +47,16 @@ def build_oracle():
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "wm", "subst", "-j8"], stdout=subprocess.DEVNULL)
 
 
-def build_emu():
+def build_emu(defines=()):
+    """tests/simt_emu/libwm_emu[_<defines>].so: the kernel headers compiled for the host against the wavefront emulator. `defines` selects
+    kernel variants that are not the library default yet (e.g. ("WM_KSW_ROR=1",)), so that the tests cover them as well."""
     emu = os.path.join(ROOT, "tests", "simt_emu")
-    out = os.path.join(emu, "libwm_emu.so")
+    tag = "".join("_" + "".join(ch if ch.isalnum() else "_" for ch in d) for d in defines)
+    out = os.path.join(emu, "libwm_emu%s.so" % tag)
     srcs = [os.path.join(emu, f) for f in ("emu_driver.cpp", "simt.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     if _newer(out, srcs):
-        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
-                               "-I" + emu, "-I" + CSRC, "-o", out, os.path.join(emu, "emu_driver.cpp")])
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas"] +
+                              ["-D" + d for d in defines] + ["-I" + emu, "-I" + CSRC, "-o", out, os.path.join(emu, "emu_driver.cpp")])
     return out
 
 

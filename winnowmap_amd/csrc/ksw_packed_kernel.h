@@ -24,15 +24,32 @@
 //   * EXACT selects the exact row maximum (H per lane in 32 bits, z-drop, mqe/mte) or the reference's approximate
 //     one-track maximum (KSW_EZ_APPROX_MAX, :359-375): gap filling — most of the cells — never carries H or S.
 //
-// VALU work per pair and row (CLIP = HASN = EXACT = false): 39 packed ops for the two cells + 3 (scores) + 9 (neighbours)
-// = 51 per 128 cells, against ~45 per 64 cells in the 32-bit kernel. Registers: 6 per pair (+1 with CLIP, +2 with EXACT).
+// VALU work per pair and row, counted in the gfx950 code object (CLIP = HASN = EXACT = false, a pair inside the hull): 35 packed ops for the
+// two cells and their traceback byte + 6 (new u, v and the four gap states) + 5 (scores) + 15 (neighbours: 6 v_readlane, 3 v_mov, 3
+// v_alignbit, 3 DPP) = 61 per 128 cells (76 before the round-2 restructuring; 53 with WM_KSW_ROR=1, where the neighbours cost 3 DPP
+// rotations + 3 byte permutes). EXACT adds 2 per chunk inside the band (H += v through SDWA, running maximum). Only the pair that holds the
+// hull end (`top`) pays for lane masks, the boundary lane and predicated stores. Registers: 6 per pair (+1 with CLIP, +2 with EXACT).
+//
+// Code generation (profiles/r02z_codegen_flag.txt): the library is built with -mllvm -disable-promote-alloca-to-vector. The state arrays are
+// indexed by fully unrolled loops; AMDGPUPromoteAllocaToVector runs before the unroller and would turn each array into one <N x i32>
+// value that every uniform branch copies as a whole at its join (1536 v_mov_b64 in the EXACT 16-pair kernel). For the same reason the pair
+// loop is a compile-time loop (static_for_desc) and its uniform special cases are real branches (WM_KEEP_BRANCH) around small blocks.
 #pragma once
 #ifndef WM_DEV
 #error "include simt.h before ksw_packed_kernel.h"
 #endif
 #include "ksw_kernel.h"
+#ifndef WM_KSW_ROR
+#define WM_KSW_ROR 0          // 1: neighbour values through wave_ror:1 + v_perm_b32 (emulator-validated; to be A/B-tested on a GPU before it becomes the default)
+#endif
+#include <type_traits>
+#include <utility>
 
 namespace wmk {
+
+// f(integral_constant<int, N-1>) ... f(integral_constant<int, 0>): a loop whose index is a constant expression inside the body
+template <class F, int... Is> WM_DEV void static_for_desc_impl(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, (int)sizeof...(Is) - 1 - Is>{}), ...); }
+template <int N, class F> WM_DEV void static_for_desc(F &&f) { static_for_desc_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // int8 value -> high byte of both 16-bit halves; 16-bit pattern -> both halves
 WM_DEV int tb16(int v) { const unsigned h = ((unsigned)v & 0xffu) << 8; return (int)(h | h << 16); }
@@ -57,10 +74,11 @@ WM_DEV void ksw_pcell(const ksw_pcell_cst_t &c, const V<int> os, const V<int> x1
 	const V<int> tmp = pk_sub(z, c.Q), tmp2 = pk_sub(z, c.Q2);
 	a = pk_sub(a, tmp); b = pk_sub(b, tmp); a2 = pk_sub(a2, tmp2); b2 = pk_sub(b2, tmp2);
 	// "gap continues" flags: the sign of sat(h - a) is the compare a > h; p = 2p + flag
-	p = pk_mad(p, 0x00020002, pk_lshr(pk_subsat(c.hA, a), 15));
-	p = pk_mad(p, 0x00020002, pk_lshr(pk_subsat(c.hB, b), 15));
-	p = pk_mad(p, 0x00020002, pk_lshr(pk_subsat(c.hA2, a2), 15));
-	p = pk_mad(p, 0x00020002, pk_lshr(pk_subsat(c.hB2, b2), 15));
+	// (p holds at most 7 bits per half, so the shifts can run on the whole word: v_lshl_or_b32)
+	p = (p << 1) | pk_lshr(pk_subsat(c.hA, a), 15);
+	p = (p << 1) | pk_lshr(pk_subsat(c.hB, b), 15);
+	p = (p << 1) | pk_lshr(pk_subsat(c.hA2, a2), 15);
+	p = (p << 1) | pk_lshr(pk_subsat(c.hB2, b2), 15);
 	nx = pk_max(a, c.tA); ny = pk_max(b, c.tB); nx2 = pk_max(a2, c.tA2); ny2 = pk_max(b2, c.tB2);
 }
 
@@ -107,6 +125,7 @@ WM_DEV void ksw_dp_packed(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 	const int hA = right ? tA - 1 : tA, hB = right ? tB - 1 : tB, hA2 = right ? tA2 - 1 : tA2, hB2 = right ? tB2 - 1 : tB2;
 	const int MCHt = (((int)sc.match & 0xff) << 8) | tS, MISt = (((int)sc.mismatch & 0xff) << 8) | tS;
 	const int NNt = (((sc.sc_ambi == 0 ? -e2 : (int)sc.sc_ambi) & 0xff) << 8) | tS;
+	const int one2 = (int)sc.match > -128 ? 0x00010001 : 0x00020002;       // 1 | 1 << 16, opaque to the compiler: min(x, 1) * k + c would otherwise become compares and selects
 	const ksw_pcell_cst_t cc = { tb16(qe), tb16(qe2), tb16(q), tb16(q2), tb16(sc.match), rep16(tA), rep16(tB), rep16(tA2), rep16(tB2),
 	                             rep16(hA), rep16(hB), rep16(hA2), rep16(hB2) };
 	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
@@ -115,6 +134,10 @@ WM_DEV void ksw_dp_packed(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 
 	const V<int> ln = lane();
 	const vbool low48 = ln < 48;
+#if WM_KSW_ROR
+	const V<int> rsel = sel(ln == 0, 0x05040302, 0x07060504);      // v_perm_b32 selectors: {own.lo, prev.hi} for thread 0, own elsewhere
+	const V<int> qsel = sel(ln == 0, 0x06050403, 0x07060504);      // code words: thread 0 takes {own bytes 2..0, prev byte 3}
+#endif
 	int base = 0;
 	V<int> U[BP], Vv[BP], X[BP], Y[BP], X2[BP], Y2[BP];
 	V<int> S[CLIP ? BP : 1];
@@ -207,6 +230,15 @@ WM_DEV void ksw_dp_packed(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 				}
 				newc = readlane(QB, qi0 - qb0);
 			}
+#if WM_KSW_ROR
+			// rotate every word by one thread; thread 0 (which received thread 63) shifts its four chunk bytes up by one and takes byte 3 of the
+			// word below (or the new code) as byte 0
+			V<int> rq[NW];
+#pragma unroll
+			for (int wd = 0; wd < NW; ++wd) rq[wd] = ror1(QP[wd]);
+#pragma unroll
+			for (int wd = 0; wd < NW; ++wd) QP[wd] = perm(rq[wd], wd ? rq[wd ? wd - 1 : 0] : V<int>(newc << 24), qsel);
+#else
 			int q63[NW];
 #pragma unroll
 			for (int wd = 0; wd < NW; ++wd) q63[wd] = readlane(QP[wd], 63);
@@ -215,18 +247,17 @@ WM_DEV void ksw_dp_packed(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 				const int fill = (int)(((unsigned)q63[wd] << 8) | (wd ? (unsigned)q63[wd ? wd - 1 : 0] >> 24 : (unsigned)newc));
 				QP[wd] = shr1(QP[wd], fill);
 			}
+#endif
 		}
 
-		// ---- first-column / first-row boundary of lane r (:152-155)
+		WM_EMU_ASSERT(base == st);
+		// ---- first-column / first-row boundary of lane r (:152-155): applied inside the top pair's body (lane r shares its 16-lane group, hence
+		// its pair, with the hull end `en`); bm selects the half of thread (r - base) & 63 that holds it
+		V<int> bm = 0;
 		if (en >= r) {
-			const int o = r - base, jr = o & 63, c = o >> 6, ip = c >> 1;
-			const int hm = (c & 1) ? (int)0xffff0000 : 0x0000ffff;
-			WM_EMU_ASSERT(o >= 0 && o < 128 * BP);
-			WM_IF(ln == jr)
-#pragma unroll
-				for (int i = 0; i < BP; ++i)
-					if (ip == i) { Y[i] = bfi(hm, rep16(tB), Y[i]); Y2[i] = bfi(hm, rep16(tB2), Y2[i]); U[i] = bfi(hm, tb16(sched), U[i]); }
-			WM_END
+			const int o = r - base;
+			WM_EMU_ASSERT(o >= 0 && o < 128 * BP && (o >> 7) == ((en - base) >> 7));
+			bm = sel(ln == (o & 63), (o & 64) ? (int)0xffff0000 : 0x0000ffff, 0);
 		}
 
 		const int cend = st0 + (en0 - st0) / 16 * 16 + 15;           // last lane of the rewritten score chunks (:158-173)
@@ -234,89 +265,150 @@ WM_DEV void ksw_dp_packed(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 		const int NS = CLIP ? ((((cend > en ? cend : en) - base) >> 7) + 1) : NI;
 		WM_EMU_ASSERT(NS <= BP);
 		V<int> hmax = KSW_NEG_INF;
-		uint8_t *trow = tbp + (size_t)r * jb.n_col + (base - st);
+		uint8_t *trow = tbp + (size_t)r * jb.n_col;                    // column of lane t = t - st = t - base
+#if WM_KSW_ROR
+		V<int> crx = 0, crv = 0, crx2 = 0;                             // rotations handed from pair i + 1 to pair i
+#endif
+		int h_en0 = KSW_NEG_INF;                                       // exact mode: the new H of lane en0, when that is the last target lane
+		int d0 = 0, d1 = 0;                                            // approximate-max track: new v of lane last_H0_t, new u of lane last_H0_t + 1 (int8)
 
-#pragma unroll
-		for (int i = BP - 1; i >= 0; --i) {
-			if (i >= NS) continue;
-			const int c0 = base + 128 * i;
-			const V<int> t_lo = ln + c0, t_hi = ln + (c0 + 64);
-			// match / mismatch scores of the two chunks: bytes (2i & 3), (2i & 3) + 1 of the code words, spread to the halves
-			const int wd = i >> 1, psel = (i & 1) ? 0x0c030c02 : 0x0c010c00;
+		// match / mismatch (/ ambiguous) scores of pair i, tie-break tag in the low bits
+		auto pair_scores = [&](auto IC) {
+			constexpr int i = decltype(IC)::value;
+			// bytes (2i & 3), (2i & 3) + 1 of the code words, spread to the halves
+			constexpr int wd = i >> 1, psel = (i & 1) ? 0x0c030c02 : 0x0c010c00;
 			const V<int> xq = TP[wd] ^ QP[wd];
-			V<int> sv = pk_mad(pk_minu(perm(xq, xq, psel), 0x00010001), rep16(MISt - MCHt), rep16(MCHt));
+			V<int> sv = pk_mad(pk_minu(perm(xq, xq, psel), one2), rep16(MISt - MCHt), rep16(MCHt));
 			if constexpr (HASN) {
 				const V<int> oq = TP[wd] | QP[wd];
 				const V<int> isn = pk_lshr(perm(oq, oq, psel) & 0x00040004, 2);           // 1 where either code is 4
 				sv = bfi(pk_sub(0, isn), rep16(NNt), sv);
 			}
 			if constexpr (CLIP) {   // the score row is persistent and only [st0, cend] is rewritten
-				const V<int> m = sel(t_lo >= st0 && t_lo <= cend, 0x0000ffff, 0) | sel(t_hi >= st0 && t_hi <= cend, (int)0xffff0000, 0);
-				S[i] = bfi(m, sv, S[i]); sv = S[i];
+				const int c0 = base + 128 * i;
+				if (c0 >= st0 && c0 + 127 <= cend) S[i] = sv;
+				else {
+					const V<int> t_lo = ln + c0, t_hi = ln + (c0 + 64);
+					const V<int> m = sel(t_lo >= st0 && t_lo <= cend, 0x0000ffff, 0) | sel(t_hi >= st0 && t_hi <= cend, (int)0xffff0000, 0);
+					S[i] = bfi(m, sv, S[i]);
+				}
+				sv = S[i];
 			}
-			if (i >= NI) continue;
+			return sv;
+		};
+		// one pair of chunks: 128 cells. `top` (uniform) = the pair that holds the hull end: the only one with lanes beyond the hull (masked
+		// stores, stale lanes when the band clips), with the boundary lane r and with lane en0 (whose H comes from its left neighbour)
+		auto pair_body = [&](auto IC) {
+			constexpr int i = decltype(IC)::value;
+			const bool top = i == NI - 1;
+			const int c0 = base + 128 * i;
+			const V<int> t_lo = ln + c0, t_hi = ln + (c0 + 64);
+			const V<int> sv = pair_scores(IC);
+			int hprev = KSW_NEG_INF;                                   // H of lane en0 - 1 in the previous row
+			if (top) {
+				WM_KEEP_BRANCH();
+				Y[i] = bfi(bm, rep16(tB), Y[i]); Y2[i] = bfi(bm, rep16(tB2), Y2[i]); U[i] = bfi(bm, tb16(sched), U[i]);
+				if constexpr (EXACT) {
+					const int le = en0 - 1 - c0;                           // lane en0 - 1 relative to the pair: -1 .. 126
+					WM_EMU_ASSERT(le >= -1 && le < 127);
+					if (le < 0) hprev = i ? readlane(H[i ? 2 * i - 1 : 0], 63) : Hbelow;
+					else hprev = le < 64 ? readlane(H[2 * i], le & 63) : readlane(H[2 * i + 1], le & 63);
+				}
+			}
 			// previous-row values of lane t-1
+#if WM_KSW_ROR
+			// rotate the packed register by one thread (thread 0 receives thread 63: {hi: lane c0+127, lo: lane c0+63}); thread 0 then takes its
+			// low half from the high half of pair i-1's rotation (lane c0-1) and its high half from its own low half (lane c0+63): one byte
+			// permute with a per-thread selector. The rotation of pair i-1 is kept for that pair's own turn.
+			if (top) { WM_KEEP_BRANCH(); crx = ror1(X[i]); crv = ror1(Vv[i]); crx2 = ror1(X2[i]); }
+			const V<int> rxo = crx, rvo = crv, rx2o = crx2;
+			if constexpr (i > 0) { crx = ror1(X[i ? i - 1 : 0]); crv = ror1(Vv[i ? i - 1 : 0]); crx2 = ror1(X2[i ? i - 1 : 0]); }
+			else { crx = f_x << 16; crv = f_v << 16; crx2 = f_x2 << 16; }
+			const V<int> x1 = perm(rxo, crx, rsel), v1 = perm(rvo, crv, rsel), x21 = perm(rx2o, crx2, rsel);
+#else
 			const int px = i ? lshr(readlane(X[i ? i - 1 : 0], 63), 16) : f_x, pv = i ? lshr(readlane(Vv[i ? i - 1 : 0], 63), 16) : f_v;
 			const int px2 = i ? lshr(readlane(X2[i ? i - 1 : 0], 63), 16) : f_x2;
 			const V<int> x1 = shr1(X[i], (int)((unsigned)readlane(X[i], 63) << 16 | (unsigned)px));
 			const V<int> v1 = shr1(Vv[i], (int)((unsigned)readlane(Vv[i], 63) << 16 | (unsigned)pv));
 			const V<int> x21 = shr1(X2[i], (int)((unsigned)readlane(X2[i], 63) << 16 | (unsigned)px2));
-			V<int> hl_lo = KSW_NEG_INF, hl_hi = KSW_NEG_INF;
-			if constexpr (EXACT) {
-				hl_lo = shr1(H[2 * i], i ? readlane(H[i ? 2 * i - 1 : 0], 63) : Hbelow);
-				hl_hi = shr1(H[2 * i + 1], readlane(H[2 * i], 63));
-			}
+#endif
 			const V<int> ou = U[i];
 			V<int> nu, nv, nx, ny, nx2, ny2, p;
 			ksw_pcell(cc, sv, x1, v1, x21, Y[i], ou, Y2[i], nu, nv, nx, ny, nx2, ny2, p);
-			if (!CLIP || c0 + 127 <= en) {     // (unclipped band: lanes beyond the hull never matter — see the header)
-				U[i] = nu; Vv[i] = nv; X[i] = nx; Y[i] = ny; X2[i] = nx2; Y2[i] = ny2;
-			} else {                           // lanes beyond the hull keep their stale values (they feed back when the band is clipped)
-				const V<int> m = sel(t_lo <= en, 0x0000ffff, 0) | sel(t_hi <= en, (int)0xffff0000, 0);
+			if constexpr (CLIP) {              // lanes beyond the hull keep their stale values (they feed back when the band is clipped)
+				V<int> m = -1;
+				if (top) { WM_KEEP_BRANCH(); m = sel(t_lo <= en, 0x0000ffff, 0) | sel(t_hi <= en, (int)0xffff0000, 0); }
 				U[i] = bfi(m, nu, U[i]); Vv[i] = bfi(m, nv, Vv[i]); X[i] = bfi(m, nx, X[i]); Y[i] = bfi(m, ny, Y[i]);
 				X2[i] = bfi(m, nx2, X2[i]); Y2[i] = bfi(m, ny2, Y2[i]);
+			} else {                           // (unclipped band: lanes beyond the hull never matter — see the header)
+				U[i] = nu; Vv[i] = nv; X[i] = nx; Y[i] = ny; X2[i] = nx2; Y2[i] = ny2;
 			}
-			WM_IF(t_lo <= en) gst(trow, t_lo - base, cast<uint8_t>(p)); WM_END
-			WM_IF(t_hi <= en) gst(trow, t_hi - base, cast<uint8_t>(lshr(p, 16))); WM_END
-			if constexpr (EXACT) if (r > 0) {
+			if (top) {
+				WM_IF(t_lo <= en) gst(trow, ln + 128 * i, cast<uint8_t>(p)); WM_END
+				WM_IF(t_hi <= en) gst(trow, ln + (128 * i + 64), cast<uint8_t>(lshr(p, 16))); WM_END
+			} else {
+				gst(trow, ln + 128 * i, cast<uint8_t>(p));
+				gst(trow, ln + (128 * i + 64), cast<uint8_t>(lshr(p, 16)));
+			}
+			if constexpr (EXACT) {
+				// H += v (:320-345). Lanes outside the band keep their H; lane en0 takes H of its left neighbour + u. (Row 0 runs through here
+				// as well: its only band lane is rewritten below, and hmax is not used.)
+				const int en0x = en0 > 0 ? en0 : -1;
 #pragma unroll
 				for (int hf = 1; hf >= 0; --hf) {
 					const int ci = 2 * i + hf, cb = c0 + 64 * hf;
-					if (cb > en) continue;
-					const V<int> t = hf ? t_hi : t_lo;
 					const V<int> v8 = hf ? vhi8(Vv[i]) : vlo8(Vv[i]);
+					V<int> hn = H[ci] + v8;
 					if (cb >= st0 && cb + 63 < en0) {               // chunk strictly inside the band: every lane is a plain update
-						H[ci] = H[ci] + v8;
-						hmax = vmax(hmax, H[ci]);
+						H[ci] = hn;
+						hmax = vmax(hmax, hn);
 					} else {
+						WM_KEEP_BRANCH();
+						const V<int> t = hf ? t_hi : t_lo;
 						const V<int> u8 = hf ? vhi8(U[i]) : vlo8(U[i]);
-						const V<int> hl = hf ? hl_hi : hl_lo;
-						V<int> hn = H[ci] + v8;
-						hn = sel(t == en0, en0 > 0 ? V<int>(hl + u8) : hn, hn);
+						hn = sel(t == en0x, V<int>(u8 + hprev), hn);
 						const vbool inb = t >= st0 && t <= en0;
 						H[ci] = sel(inb, hn, H[ci]);
-						hmax = vmax(hmax, sel(inb, H[ci], V<int>(KSW_NEG_INF)));
+						hmax = vmax(hmax, sel(inb, hn, V<int>(KSW_NEG_INF)));
 					}
 				}
+				if (top && en0 == tlen - 1) {
+					WM_KEEP_BRANCH();
+					const int oe = en0 - c0;
+					h_en0 = oe < 64 ? readlane(H[2 * i], oe & 63) : readlane(H[2 * i + 1], oe & 63);
+				}
+			} else {
+				// the approximate-max track reads two neighbouring lanes of this row (:359-375)
+				const int o0 = last_H0_t - c0, o1 = o0 + 1;
+				if ((unsigned)o0 < 128u) { const int rr = readlane(Vv[i], o0 & 63); d0 = ((o0 & 64) ? rr >> 16 : (int)(short)(rr & 0xffff)) >> 8; }
+				if ((unsigned)o1 < 128u) { const int rr = readlane(U[i], o1 & 63); d1 = ((o1 & 64) ? rr >> 16 : (int)(short)(rr & 0xffff)) >> 8; }
+			}
+		};
+		if constexpr (CLIP) {
+			if (NS > NI) {                 // the rewritten score chunks reach one pair beyond the hull (cend - en < 16): its score row only
+				WM_EMU_ASSERT(NS == NI + 1);
+				static_for_desc<BP>([&](auto IC) { if (decltype(IC)::value == NI) pair_scores(IC); });
 			}
 		}
+		static_for_desc<BP>([&](auto IC) {
+			if (decltype(IC)::value < NI) pair_body(IC);
+		});
 
 		if constexpr (EXACT) {   // ---- exact max: 32-bit wave maximum, then the lanes that reach it
 			int max_H, max_t;
-			const int NC = ((en - base) >> 6) + 1;
 			if (r > 0) {
 				max_H = wave_max_i32(hmax);
 				const int en1 = st0 + (en0 - st0) / 4 * 4;
+				const int cfirst = (st0 - base) >> 6, clast = (en0 - base) >> 6;          // the chunks that intersect the band
 				int best_pri = -1;
 				max_t = en0;
-#pragma unroll
-				for (int i = 0; i < B; ++i) {
-					if (i >= NC) continue;
-					const int c0 = base + 64 * i;
-					if (c0 > en0 || c0 + 63 < st0) continue;
-					const int lo = st0 > c0 ? st0 - c0 : 0, hi = en0 - c0 < 63 ? en0 - c0 : 63;
-					const uint64_t band = (hi == 63 ? ~(uint64_t)0 : (((uint64_t)1 << (hi + 1)) - 1)) & ~(((uint64_t)1 << lo) - 1);
-					uint64_t m = ballot(H[i] == max_H) & band;
+				static_for_desc<B>([&](auto CC) {
+					constexpr int ci = B - 1 - decltype(CC)::value;
+					if (ci < cfirst || ci > clast) return;
+					const int c0 = base + 64 * ci;
+					uint64_t m;
+					if (c0 >= st0 && c0 + 63 <= en0) m = ballot(H[ci] == max_H);
+					else { const V<int> t = ln + c0; m = ballot(H[ci] == max_H && t >= st0 && t <= en0); }
 					while (m) {                                   // priority on ties: en0, then residue groups 0..3 of [st0,en1), then the tail
 						const int tt = c0 + __builtin_ctzll(m);
 						m &= m - 1;
@@ -324,34 +416,34 @@ WM_DEV void ksw_dp_packed(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 						const int pri = (grp << 20) | (0xfffff - tt);
 						if (pri > best_pri) best_pri = pri, max_t = tt;
 					}
-				}
+				});
 			} else {
 				WM_IF(ln == 0) H[0] = vlo8(Vv[0]) - qe; WM_END
 				max_H = readlane(H[0], 0); max_t = 0;
+				h_en0 = max_H;
 			}
-			if (en0 == tlen - 1) { const int h = get_lane_striped<B>(H, base, en0); if (h > ez_mte) ez_mte = h, ez_mte_q = r - en; }
-			if (r - st0 == qlen - 1) { const int h = get_lane_striped<B>(H, base, st0); if (h > ez_mqe) ez_mqe = h, ez_mqe_t = st0; }
+			if (en0 == tlen - 1) { if (h_en0 > ez_mte) ez_mte = h_en0, ez_mte_q = r - en; }
+			if (r - st0 == qlen - 1) { const int h = readlane(H[0], st0 - base); if (h > ez_mqe) ez_mqe = h, ez_mqe_t = st0; }      // (base = st: lane st0 is in chunk 0)
 			if (max_H > ez_max) {
 				ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
 			} else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
 				const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
 				if (zdrop >= 0 && ez_max - max_H > zdrop + l * e2) { ez_zdropped = 1; break; }
 			}
-			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = get_lane_striped<B>(H, base, tlen - 1);
-		} else {        // ---- approximate max: follow one diagonal-ish track (:359-375)
+			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = h_en0;
+		} else {        // ---- approximate max: follow one diagonal-ish track (:359-375); d0 / d1 were picked up by the pair bodies
 			if (r > 0) {
 				const bool in0 = last_H0_t >= st0 && last_H0_t <= en0, in1 = last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0;
 				if (in0 && in1) {
-					const int d0 = get_half<BP>(Vv, base, last_H0_t) >> 8, d1 = get_half<BP>(U, base, last_H0_t + 1) >> 8;
 					if (d0 > d1) H0 += d0;
 					else H0 += d1, ++last_H0_t;
 				} else if (in0) {
-					H0 += get_half<BP>(Vv, base, last_H0_t) >> 8;
+					H0 += d0;
 				} else {
 					++last_H0_t;
-					H0 += get_half<BP>(U, base, last_H0_t) >> 8;
+					H0 += d1;
 				}
-			} else H0 = (get_half<BP>(Vv, base, 0) >> 8) - qe, last_H0_t = 0;
+			} else H0 = d0 - qe, last_H0_t = 0;
 			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = H0;
 		}
 	}

@@ -9,6 +9,8 @@
 #include <stdint.h>
 
 #define WM_DEV __device__ __forceinline__
+// keeps a uniform branch a branch: without it the compiler turns `if (uniform) x = f(x)` into selects that every iteration pays
+#define WM_KEEP_BRANCH() asm volatile("")
 #define WM_IF(c) if (c) {
 #define WM_ELSE } else {
 #define WM_END }
@@ -51,7 +53,7 @@ WM_DEV int pk_lshr(int a, int k) { return __builtin_bit_cast(int, as_u16x2(a) >>
 WM_DEV int pk_mad(int a, int b, int c) { return __builtin_bit_cast(int, as_u16x2(a) * as_u16x2(b) + as_u16x2(c)); }     // v_pk_mad_u16 (wrapping)
 // byte permute: result byte k = byte sel[k] of the 8 bytes {hi word a : lo word b} (selector 0..3 -> b, 4..7 -> a, 0x0c -> 0x00)
 WM_DEV int perm(int a, int b, int sel) { return (int)__builtin_amdgcn_perm((unsigned)a, (unsigned)b, (unsigned)sel); }
-WM_DEV int bfi(int mask, int a, int b) { return (a & mask) | (b & ~mask); }                                           // v_bfi_b32
+WM_DEV int bfi(int mask, int a, int b) { return b ^ ((a ^ b) & mask); }                                               // (a & mask) | (b & ~mask): v_bfi_b32 (this form has no shared ~mask for the selector to split off)
 WM_DEV int alignbit(int hi, int lo, int sh) { return (int)__builtin_amdgcn_alignbit((unsigned)hi, (unsigned)lo, (unsigned)sh); }   // ({hi,lo} >> sh)[31:0]
 WM_DEV int lshr(int a, int k) { return (int)((unsigned)a >> k); }
 
@@ -60,6 +62,8 @@ WM_DEV int lshr(int a, int k) { return (int)((unsigned)a >> k); }
 template <int CTRL, int ROW_MASK> WM_DEV int dpp_mov(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, ROW_MASK, 0xf, false); }
 // value of lane-1 (lane 0 receives `fill`): wave_shr:1
 WM_DEV int shr1(int x, int fill) { return dpp_mov<0x138, 0xf>(fill, x); }
+// value of lane-1, lane 0 receives lane 63: wave_ror:1
+WM_DEV int ror1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x13c, 0xf, 0xf, true); }
 // inclusive wave scans: row_shr:1,2,4,8 inside the 16-lane rows, then row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3)
 #define WM_SCAN(NAME, OP, ID) \
 WM_DEV int NAME(int x) \

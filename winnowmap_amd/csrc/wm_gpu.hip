@@ -703,7 +703,15 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		switch (k & ~7) {
 		case WM_KSW_P4: launch_dpp<4>(k & 7, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
 		case WM_KSW_P8: launch_dpp<8>(k & 7, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
-		default: launch_dpp<16>(k & 7, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
+		default:
+			if (getenv("WM_KSW_PMULTI") && atoi(getenv("WM_KSW_PMULTI")) >= 2) {      // opt-in: 4 wavefronts per alignment for the 16-pair classes too (shorter batch tails)
+				const int seq_cap = 32 * 1024;
+				const size_t lds = (size_t)wmk::ksw_pmulti_lds<4, 4>::INTS * 4 + seq_cap;
+				HIPCHK(hipFuncSetAttribute((const void*)ksw_pmulti_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+				hipLaunchKernelGGL((ksw_pmulti_kernel<4, 4>), dim3(nk), dim3(64 * 4), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, seq_cap);
+			} else
+				launch_dpp<16>(k & 7, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res);
+			break;
 		}
 	}
 	for (int si = 0; si < 4; ++si)
