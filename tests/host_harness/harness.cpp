@@ -177,6 +177,13 @@ void h_radix_sort_128x(uint64_t *x, uint64_t *y, int64_t n)
 	radix_sort_128x(a.data(), a.data() + n);
 	for (int64_t i = 0; i < n; ++i) x[i] = a[i].x, y[i] = a[i].y;
 }
+void h_radix_sort_128x_parallel(uint64_t *x, uint64_t *y, int64_t n, int n_threads)
+{
+	std::vector<m128> a(n);
+	for (int64_t i = 0; i < n; ++i) a[i].x = x[i], a[i].y = y[i];
+	radix_sort_128x_parallel(a.data(), a.data() + n, n_threads);
+	for (int64_t i = 0; i < n; ++i) x[i] = a[i].x, y[i] = a[i].y;
+}
 int h_ll_i16(int qlen, const uint8_t *q, int tlen, const uint8_t *t, const int8_t *mat, int gapo, int gape, int *qe, int *te) { return ll_i16(qlen, q, tlen, t, mat, gapo, gape, qe, te); }
 
 int64_t h_chain_extract(int64_t n, const uint64_t *ax, const uint64_t *ay, const int32_t *f, const int32_t *p, const int32_t *v, int min_cnt, int min_sc,

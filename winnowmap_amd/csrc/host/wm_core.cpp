@@ -78,10 +78,24 @@ template <class T, class KeyFn> struct FlagSort {
 			*j = held;
 		}
 	}
-	void pass(T *beg, T *end, int shift) const
+	// one digit of one range: skips constant digits, counts, permutes in place; tail[d] = end of bucket d. Returns the digit's shift, or -1
+	// if every remaining digit is constant (nothing to do).
+	int digit(T *beg, T *end, int shift, T **tail) const
 	{
+		// A digit that is the same in every key leaves the range as it is (one bucket, every element already in place) and hands the whole
+		// range to the next digit: skip such digits without counting them. (Anchor keys are strand | contig | position: four of the eight
+		// digits are constant within a job, more within a bucket.)
+		{
+			uint64_t all_or = 0, all_and = ~(uint64_t)0;
+			for (const T *i = beg; i != end; ++i) { const uint64_t k = key(*i); all_or |= k; all_and &= k; }
+			const uint64_t diff = all_or ^ all_and;
+			while (!(diff >> shift & 0xff)) {
+				if (shift == 0) return -1;
+				shift = shift > 8 ? shift - 8 : 0;
+			}
+		}
 		size_t hist[256] = {0};
-		T *head[256], *tail[256];
+		T *head[256];
 		for (T *i = beg; i != end; ++i) ++hist[key(*i) >> shift & 0xff];
 		T *cur = beg;
 		for (int d = 0; d < 256; ++d) { head[d] = cur; cur += hist[d]; tail[d] = cur; }
@@ -97,9 +111,15 @@ template <class T, class KeyFn> struct FlagSort {
 			}
 			*head[d]++ = held;
 		}
-		if (shift == 0) return;
+		return shift;
+	}
+	void pass(T *beg, T *end, int shift) const
+	{
+		T *tail[256];
+		shift = digit(beg, end, shift, tail);
+		if (shift <= 0) return;
 		const int next = shift > 8 ? shift - 8 : 0;
-		cur = beg;
+		T *cur = beg;
 		for (int d = 0; d < 256; ++d) {
 			T *stop = tail[d];
 			if (stop - cur > 64) pass(cur, stop, next);
@@ -112,10 +132,43 @@ template <class T, class KeyFn> struct FlagSort {
 		if (end - beg <= 64) insertion(beg, end);
 		else pass(beg, end, 56);
 	}
+	// The same sort — the same swaps in the same order within every range — with the ranges of one level spread over threads: a range's digit
+	// is sequential by nature (its swap sequence fixes the order of equal keys), but its buckets are independent of each other. Levels are
+	// expanded until there are enough ranges; then every range is finished by the sequential recursion.
+	void run_parallel(T *beg, T *end, int n_threads) const
+	{
+		if (end - beg <= 64) { insertion(beg, end); return; }
+		struct Range { T *b, *e; int shift; };
+		std::vector<Range> level(1, Range{beg, end, 56});
+		for (int depth = 0; depth < 3 && level.size() < 4 * (size_t)n_threads; ++depth) {
+			std::vector<std::vector<Range>> kids(level.size());
+			parallel_tasks(n_threads, level.size(), [&](size_t i) {
+				const Range r = level[i];
+				T *tail[256];
+				const int shift = digit(r.b, r.e, r.shift, tail);
+				if (shift <= 0) return;
+				const int next = shift > 8 ? shift - 8 : 0;
+				T *cur = r.b;
+				for (int d = 0; d < 256; ++d) {
+					T *stop = tail[d];
+					if (stop - cur > 64) kids[i].push_back(Range{cur, stop, next});
+					else if (stop - cur > 1) insertion(cur, stop);
+					cur = stop;
+				}
+			});
+			std::vector<Range> nxt;
+			for (auto &k : kids) nxt.insert(nxt.end(), k.begin(), k.end());
+			level.swap(nxt);
+			if (level.empty()) return;
+		}
+		std::sort(level.begin(), level.end(), [](const Range &x, const Range &y) { return x.e - x.b > y.e - y.b; });       // largest first
+		parallel_tasks(n_threads, level.size(), [&](size_t i) { pass(level[i].b, level[i].e, level[i].shift); });
+	}
 };
 struct KeyX { uint64_t operator()(const m128 &a) const { return a.x; } };
 struct KeyId { uint64_t operator()(uint64_t a) const { return a; } };
 void radix_sort_128x(m128 *beg, m128 *end) { FlagSort<m128, KeyX>().run(beg, end); }
+void radix_sort_128x_parallel(m128 *beg, m128 *end, int n_threads) { FlagSort<m128, KeyX>().run_parallel(beg, end, n_threads); }
 void radix_sort_64(uint64_t *beg, uint64_t *end) { FlagSort<uint64_t, KeyId>().run(beg, end); }
 
 uint64_t hash64_masked(uint64_t key, uint64_t mask)

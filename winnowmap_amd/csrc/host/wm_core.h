@@ -86,6 +86,8 @@ struct Reg {
 
 // ---- sorts with the reference's exact (unstable) permutation, src/ksort.h:101-151 ----
 void radix_sort_128x(m128 *beg, m128 *end);
+// identical result (incl. the order of equal keys); the independent buckets of large inputs are sorted on up to n_threads threads
+void radix_sort_128x_parallel(m128 *beg, m128 *end, int n_threads);
 void radix_sort_64(uint64_t *beg, uint64_t *end);
 
 // ---- hashing, src/sketch.c:43-63 and khash.h Wang / X31 used for the per-read tie-break hash (src/map.c:355-357) ----
@@ -111,6 +113,9 @@ inline ParHook *&tl_par_hook() { static thread_local ParHook *p = 0; return p; }
 inline const char *&tl_par_site() { static thread_local const char *s = 0; return s; }
 #define WM_SITE(name) (::wm::tl_par_site() = (name))
 
+// chunk size for the NEXT hooked loop of this thread (0 = the hook's default): 1 for loops over a few coarse tasks
+inline size_t &tl_par_chunk() { static thread_local size_t c = 0; return c; }
+
 // host-side helper: fn(i) for i in [0, n) on up to n_threads threads (dynamic chunks); used for packing / unpacking batches
 template <class F> inline void parallel_for(int n_threads, size_t n, F fn)
 {
@@ -120,6 +125,20 @@ template <class F> inline void parallel_for(int n_threads, size_t n, F fn)
 	const size_t chunk = n / (T * 8) > 0 ? n / (T * 8) : 1;
 	std::atomic<size_t> next(0);
 	auto body = [&]() { for (;;) { const size_t b = next.fetch_add(chunk); if (b >= n) break; const size_t e = b + chunk < n ? b + chunk : n; for (size_t i = b; i < e; ++i) fn(i); } };
+	std::vector<std::thread> th;
+	for (size_t t = 1; t < T; ++t) th.emplace_back(body);
+	body();
+	for (auto &x : th) x.join();
+}
+
+// fn(i) for a few coarse tasks, one at a time per thread (largest first is the caller's business)
+template <class F> inline void parallel_tasks(int n_threads, size_t n, F fn)
+{
+	if (n >= 2) if (ParHook *h = tl_par_hook()) { const std::function<void(size_t)> f = fn; tl_par_chunk() = 1; h->run(n, f); return; }
+	if (n_threads <= 1 || n < 2) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+	const size_t T = (size_t)n_threads < n ? (size_t)n_threads : n;
+	std::atomic<size_t> next(0);
+	auto body = [&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= n) break; fn(i); } };
 	std::vector<std::thread> th;
 	for (size_t t = 1; t < T; ++t) th.emplace_back(body);
 	body();

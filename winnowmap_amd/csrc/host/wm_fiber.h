@@ -100,6 +100,7 @@ struct Hub {
 			t.fn = &fn; t.n = n; t.next.store(0); t.helpers = 0; t.site = tl_par_site(); tl_par_site() = 0;
 			t.chunk = n / (size_t)(4 * (H->n_workers > 0 ? H->n_workers : 1));
 			if (t.chunk < 16) t.chunk = 16;
+			if (tl_par_chunk()) { t.chunk = tl_par_chunk(); tl_par_chunk() = 0; }         // (coarse tasks: parallel_tasks)
 			{ std::lock_guard<std::mutex> lk(H->mu); H->help.push_back(&t); }
 			H->cv.notify_all();
 			const double c0 = thread_cpu_s();

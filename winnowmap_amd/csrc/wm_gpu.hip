@@ -1453,9 +1453,20 @@ try {
 			HIPCHK(hipMemcpyAsync(raw.data(), d_out, tot * sizeof(wm128_t), hipMemcpyDeviceToHost, c->stream));
 			HIPCHK(ctx_sync(c));
 		}
+		// jobs with very many anchors (reads inside a repeat family: 10^5..10^6 hits) one at a time, each spread over the threads: sorted by one
+		// thread such a job alone would keep the whole call — and its device context — waiting
+		std::vector<size_t> rest_t;
+		rest_t.reserve(done_t.size());
+		for (size_t t : done_t) {
+			if (res[t].n_anchors < (1 << 16) || (dev_sorted && !tie[t])) { rest_t.push_back(t); continue; }
+			wm128_t *dst = out + out_off[todo[t]];
+			memcpy(dst, raw.data() + jb[t].out_off, (size_t)res[t].n_anchors * sizeof(wm128_t));
+			WM_SITE("seed.giant_radix_sort");
+			wm::radix_sort_128x_parallel(dst, dst + res[t].n_anchors, c->host_threads);
+		}
 		WM_SITE("seed.copy+radix_sort");
-		wm::parallel_for(c->host_threads, done_t.size(), [&](size_t k) {
-			const size_t t = done_t[k];
+		wm::parallel_for(c->host_threads, rest_t.size(), [&](size_t k) {
+			const size_t t = rest_t[k];
 			wm128_t *dst = out + out_off[todo[t]];
 			if (dev_sorted && !tie[t]) { memcpy(dst, tmp.data() + jb[t].out_off, (size_t)res[t].n_anchors * sizeof(wm128_t)); return; }
 			memcpy(dst, raw.data() + jb[t].out_off, (size_t)res[t].n_anchors * sizeof(wm128_t));
