@@ -50,6 +50,7 @@ WM_DEV void ksw_dp_pmulti(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 	const int hA = right ? tA - 1 : tA, hB = right ? tB - 1 : tB, hA2 = right ? tA2 - 1 : tA2, hB2 = right ? tB2 - 1 : tB2;
 	const int MCHt = (((int)sc.match & 0xff) << 8) | tS, MISt = (((int)sc.mismatch & 0xff) << 8) | tS;
 	const int NNt = (((sc.sc_ambi == 0 ? -e2 : (int)sc.sc_ambi) & 0xff) << 8) | tS;
+	const int one2 = (int)sc.match > -128 ? 0x00010001 : 0x00020002;       // 1 | 1 << 16, opaque to the compiler (see ksw_dp_packed)
 	const ksw_pcell_cst_t cc = { tb16(qe), tb16(qe2), tb16(q), tb16(q2), tb16(sc.match), rep16(tA), rep16(tB), rep16(tA2), rep16(tB2),
 	                             rep16(hA), rep16(hB), rep16(hA2), rep16(hB2) };
 	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
@@ -172,18 +173,14 @@ WM_DEV void ksw_dp_pmulti(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 			}
 		}
 
-		// ---- first-column / first-row boundary of lane r (:152-155)
+		WM_EMU_ASSERT(base == st);
+		// ---- first-column / first-row boundary of lane r (:152-155): applied by the owner of the pair that holds the hull end (lane r shares
+		// its 16-lane group, hence its pair, with `en`); bm selects the half of thread (r - base) & 63 that holds it
+		V<int> bm = 0;
 		if (en >= r) {
-			const int o = r - base, jr = o & 63, c = o >> 6, g = c >> 1;
-			const int hm = (c & 1) ? (int)0xffff0000 : 0x0000ffff;
-			WM_EMU_ASSERT(o >= 0 && o < 128 * NP);
-			if (g % NWV == wv) {
-				WM_IF(ln == jr)
-#pragma unroll
-					for (int s = 0; s < BP; ++s)
-						if (g / NWV == s) { Y[s] = bfi(hm, rep16(tB), Y[s]); Y2[s] = bfi(hm, rep16(tB2), Y2[s]); U[s] = bfi(hm, tb16(sched), U[s]); }
-				WM_END
-			}
+			const int o = r - base;
+			WM_EMU_ASSERT(o >= 0 && o < 128 * NP && (o >> 7) == ((en - base) >> 7));
+			bm = sel(ln == (o & 63), (o & 64) ? (int)0xffff0000 : 0x0000ffff, 0);
 		}
 
 		const int cend = st0 + (en0 - st0) / 16 * 16 + 15;           // last lane of the rewritten score chunks (:158-173)
@@ -191,12 +188,14 @@ WM_DEV void ksw_dp_pmulti(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 		const int NS = CLIP ? ((((cend > en ? cend : en) - base) >> 7) + 1) : NI;
 		WM_EMU_ASSERT(NS <= NP);
 		V<int> hmax = KSW_NEG_INF;
-		uint8_t *trow = tbp + (size_t)r * jb.n_col + (base - st);
+		uint8_t *trow = tbp + (size_t)r * jb.n_col;                    // column of lane t = t - st = t - base
+		const int en0x = en0 > 0 ? en0 : -1;
 
 #pragma unroll
 		for (int s = 0; s < BP; ++s) {
 			const int g = s * NWV + wv;
 			if (g >= NS) continue;
+			const bool top = g == NI - 1;          // the pair that holds the hull end: lane masks, the boundary lane, lane en0
 			const int c0 = base + 128 * g;
 			const V<int> t_lo = ln + c0, t_hi = ln + (c0 + 64);
 			// query codes of the two chunks in this row: query[r - t]
@@ -208,54 +207,71 @@ WM_DEV void ksw_dp_pmulti(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 			}
 			const V<int> qc = q0 | (q1 << 16);
 			const V<int> xq = TC[s] ^ qc;
-			V<int> sv = pk_mad(pk_minu(xq, 0x00010001), rep16(MISt - MCHt), rep16(MCHt));
+			V<int> sv = pk_mad(pk_minu(xq, one2), rep16(MISt - MCHt), rep16(MCHt));
 			if constexpr (HASN) {
 				const V<int> isn = pk_lshr((TC[s] | qc) & 0x00040004, 2);
 				sv = bfi(pk_sub(0, isn), rep16(NNt), sv);
 			}
 			if constexpr (CLIP) {   // the score row is persistent and only [st0, cend] is rewritten
-				const V<int> m = sel(t_lo >= st0 && t_lo <= cend, 0x0000ffff, 0) | sel(t_hi >= st0 && t_hi <= cend, (int)0xffff0000, 0);
-				S[s] = bfi(m, sv, S[s]); sv = S[s];
+				if (c0 >= st0 && c0 + 127 <= cend) S[s] = sv;
+				else {
+					const V<int> m = sel(t_lo >= st0 && t_lo <= cend, 0x0000ffff, 0) | sel(t_hi >= st0 && t_hi <= cend, (int)0xffff0000, 0);
+					S[s] = bfi(m, sv, S[s]);
+				}
+				sv = S[s];
 			}
 			if (g >= NI) continue;
+			int hprev = KSW_NEG_INF;                                   // H of lane en0 - 1 in the previous row
+			if (top) {
+				WM_KEEP_BRANCH();
+				Y[s] = bfi(bm, rep16(tB), Y[s]); Y2[s] = bfi(bm, rep16(tB2), Y2[s]); U[s] = bfi(bm, tb16(sched), U[s]);
+				if constexpr (EXACT) {
+					const int le = en0 - 1 - c0;                           // lane en0 - 1 relative to the pair: -1 .. 126
+					WM_EMU_ASSERT(le >= -1 && le < 127);
+					if (le < 0) hprev = ph[s];
+					else hprev = le < 64 ? readlane(H[2 * s], le & 63) : readlane(H[2 * s + 1], le & 63);
+				}
+			}
 			const V<int> x1 = shr1(X[s], (int)((unsigned)readlane(X[s], 63) << 16 | (unsigned)px[s]));
 			const V<int> v1 = shr1(Vv[s], (int)((unsigned)readlane(Vv[s], 63) << 16 | (unsigned)pv[s]));
 			const V<int> x21 = shr1(X2[s], (int)((unsigned)readlane(X2[s], 63) << 16 | (unsigned)px2[s]));
-			V<int> hl_lo = KSW_NEG_INF, hl_hi = KSW_NEG_INF;
-			if constexpr (EXACT) {
-				hl_lo = shr1(H[2 * s], ph[s]);
-				hl_hi = shr1(H[2 * s + 1], readlane(H[2 * s], 63));
-			}
 			const V<int> ou = U[s];
 			V<int> nu, nv, nx, ny, nx2, ny2, p;
 			ksw_pcell(cc, sv, x1, v1, x21, Y[s], ou, Y2[s], nu, nv, nx, ny, nx2, ny2, p);
-			if (!CLIP || c0 + 127 <= en) {
-				U[s] = nu; Vv[s] = nv; X[s] = nx; Y[s] = ny; X2[s] = nx2; Y2[s] = ny2;
-			} else {                           // lanes beyond the hull keep their stale values (they feed back when the band is clipped)
-				const V<int> m = sel(t_lo <= en, 0x0000ffff, 0) | sel(t_hi <= en, (int)0xffff0000, 0);
+			if constexpr (CLIP) {              // lanes beyond the hull keep their stale values (they feed back when the band is clipped)
+				V<int> m = -1;
+				if (top) { WM_KEEP_BRANCH(); m = sel(t_lo <= en, 0x0000ffff, 0) | sel(t_hi <= en, (int)0xffff0000, 0); }
 				U[s] = bfi(m, nu, U[s]); Vv[s] = bfi(m, nv, Vv[s]); X[s] = bfi(m, nx, X[s]); Y[s] = bfi(m, ny, Y[s]);
 				X2[s] = bfi(m, nx2, X2[s]); Y2[s] = bfi(m, ny2, Y2[s]);
+			} else {
+				U[s] = nu; Vv[s] = nv; X[s] = nx; Y[s] = ny; X2[s] = nx2; Y2[s] = ny2;
 			}
-			WM_IF(t_lo <= en) gst(trow, t_lo - base, cast<uint8_t>(p)); WM_END
-			WM_IF(t_hi <= en) gst(trow, t_hi - base, cast<uint8_t>(lshr(p, 16))); WM_END
-			if constexpr (EXACT) if (r > 0) {
+			if (top) {
+				WM_IF(t_lo <= en) gst(trow, t_lo - base, cast<uint8_t>(p)); WM_END
+				WM_IF(t_hi <= en) gst(trow, t_hi - base, cast<uint8_t>(lshr(p, 16))); WM_END
+			} else {
+				gst(trow, t_lo - base, cast<uint8_t>(p));
+				gst(trow, t_hi - base, cast<uint8_t>(lshr(p, 16)));
+			}
+			if constexpr (EXACT) {
+				// H += v (:320-345). Lanes outside the band keep their H; lane en0 takes H of its left neighbour + u. (Row 0 runs through here as
+				// well: its only band lane is rewritten below, and hmax is not used.)
 #pragma unroll
 				for (int hf = 1; hf >= 0; --hf) {
 					const int ci = 2 * s + hf, cb = c0 + 64 * hf;
-					if (cb > en) continue;
-					const V<int> t = hf ? t_hi : t_lo;
 					const V<int> v8 = hf ? vhi8(Vv[s]) : vlo8(Vv[s]);
+					V<int> hn = H[ci] + v8;
 					if (cb >= st0 && cb + 63 < en0) {
-						H[ci] = H[ci] + v8;
-						hmax = vmax(hmax, H[ci]);
+						H[ci] = hn;
+						hmax = vmax(hmax, hn);
 					} else {
+						WM_KEEP_BRANCH();
+						const V<int> t = hf ? t_hi : t_lo;
 						const V<int> u8 = hf ? vhi8(U[s]) : vlo8(U[s]);
-						const V<int> hl = hf ? hl_hi : hl_lo;
-						V<int> hn = H[ci] + v8;
-						hn = sel(t == en0, en0 > 0 ? V<int>(hl + u8) : hn, hn);
+						hn = sel(t == en0x, V<int>(u8 + hprev), hn);
 						const vbool inb = t >= st0 && t <= en0;
 						H[ci] = sel(inb, hn, H[ci]);
-						hmax = vmax(hmax, sel(inb, H[ci], V<int>(KSW_NEG_INF)));
+						hmax = vmax(hmax, sel(inb, hn, V<int>(KSW_NEG_INF)));
 					}
 				}
 			}
