@@ -129,6 +129,16 @@ int refshim_ksw_extz2(int qlen, const uint8_t *query, int tlen, const uint8_t *t
 	ksw_extz2_sse(0, qlen, query, tlen, target, 5, mat, q, e, w, zdrop, end_bonus, flag, &ez);
 	return pack_ez(&ez, ez_out, cigar_out, cigar_cap);
 }
+// ---- src/ksw2.h:63-64 ksw_exts2_sse (junc may be NULL) ----
+int refshim_ksw_exts2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat,
+					  int q, int e, int q2, int noncan, int zdrop, int junc_bonus, int flag, const uint8_t *junc,
+					  int32_t *ez_out, uint32_t *cigar_out, int cigar_cap)
+{
+	ksw_extz_t ez;
+	memset(&ez, 0, sizeof(ez));
+	ksw_exts2_sse(0, qlen, query, tlen, target, 5, mat, q, e, q2, noncan, zdrop, junc_bonus, flag, junc, &ez);
+	return pack_ez(&ez, ez_out, cigar_out, cigar_cap);
+}
 // ---- src/ksw2.h:82-83 ksw_ll_qinit + ksw_ll_i16 ----
 int refshim_ksw_ll_i16(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int gapo, int gape, int *qe, int *te)
 {

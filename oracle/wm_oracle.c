@@ -571,6 +571,252 @@ void wmo_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * ksw_exts2_sse (src/ksw2_exts2_sse.c:18-407): the splice-aware variant — one gap class with extension (q, e), one long
+ * deletion class without extension (q2: an intron) whose opening is paid at the donor site and whose closing adds the acceptor
+ * signal; no band, no second insertion class. Lane-exact scalar emulation like wmo_ksw_extd2; backtrack = src/ksw2.h:119-151
+ * with min_intron_len = long_thres (state 3 -> N). `junc` (optional, tlen bytes) = annotated junction bits (src/index.c:690-803).
+ * Flags: 0x01 score only, 0x02 right-align gaps, 0x04 generic scores, 0x08 approximate max, 0x10 approximate drop,
+ * 0x40 extension only, 0x80 reverse CIGAR, 0x100 / 0x200 forward / reverse transcript strand, 0x400 flanking base of the signal.
+ * ---------------------------------------------------------------------------------------------- */
+static int backtrack_intron(int is_rev, int min_intron_len, const uint8_t *p, const int *off, const int *off_end, int n_col, int i0, int j0, uint32_t *cig)
+{ /* src/ksw2.h:119-151 with is_rot = 1 */
+	int n = 0, i = i0, j = j0, state = 0, k;
+	while (i >= 0 && j >= 0) {
+		int r = i + j, force = -1;
+		uint32_t d;
+		if (i < off[r]) force = 2;
+		if (i > off_end[r]) force = 1;
+		d = force < 0 ? p[(size_t)r * n_col + i - off[r]] : 0;
+		if (state == 0) state = d & 7;
+		else if (!(d >> (state + 2) & 1)) state = 0;
+		if (state == 0) state = d & 7;
+		if (force >= 0) state = force;
+		if (state == 0) n = push_op(cig, n, 0, 1), --i, --j;
+		else if (state == 1 || (state == 3 && min_intron_len <= 0)) n = push_op(cig, n, 2, 1), --i;
+		else if (state == 3 && min_intron_len > 0) n = push_op(cig, n, 3, 1), --i;
+		else n = push_op(cig, n, 1, 1), --j;
+	}
+	if (i >= 0) n = push_op(cig, n, min_intron_len > 0 && i >= min_intron_len ? 3 : 2, i + 1);
+	if (j >= 0) n = push_op(cig, n, 1, j + 1);
+	if (!is_rev)
+		for (k = 0; k < n >> 1; ++k) { uint32_t x = cig[k]; cig[k] = cig[n - 1 - k]; cig[n - 1 - k] = x; }
+	return n;
+}
+
+/* donor[t] / acceptor[t] (:110-166): the cost of opening an intron right after target base t / closing one at base t */
+void wmo_exts2_signals(int tlen, const uint8_t *target, int noncan, int junc_bonus, int flag, const uint8_t *junc, int8_t *donor, int8_t *acceptor)
+{
+	const int fwd = !!(flag & 0x100), rev = !!(flag & 0x200), semi = (flag & 0x400) ? -noncan / 2 : 0;
+	int t;
+	for (t = 0; t < tlen; ++t) donor[t] = acceptor[t] = I8(-noncan);
+	if (!(flag & (0x100 | 0x200))) { for (t = 0; t < tlen; ++t) donor[t] = acceptor[t] = 0; return; }   /* (arrays stay zeroed: kcalloc) */
+	if (!(flag & 0x80)) {                         /* the target is read left to right: GT[AG] ... [CT]AG (forward), CT[AG] ... [CT]AC (reverse) */
+		for (t = 0; t < tlen - 4; ++t) {
+			int can = 0;
+			if (fwd && target[t + 1] == 2 && target[t + 2] == 3) can = 1;
+			if (rev && target[t + 1] == 1 && target[t + 2] == 3) can = 1;
+			if (can && (target[t + 3] == 0 || target[t + 3] == 2)) can = 2;
+			if (can) donor[t] = can == 2 ? 0 : I8(semi);
+		}
+		if (junc) for (t = 0; t < tlen - 1; ++t) if ((fwd && (junc[t + 1] & 1)) || (rev && (junc[t + 1] & 8))) donor[t] = I8(donor[t] + junc_bonus);
+		for (t = 2; t < tlen; ++t) {
+			int can = 0;
+			if (fwd && target[t - 1] == 0 && target[t] == 2) can = 1;
+			if (rev && target[t - 1] == 0 && target[t] == 1) can = 1;
+			if (can && (target[t - 2] == 1 || target[t - 2] == 3)) can = 2;
+			if (can) acceptor[t] = can == 2 ? 0 : I8(semi);
+		}
+		if (junc) for (t = 0; t < tlen; ++t) if ((fwd && (junc[t] & 2)) || (rev && (junc[t] & 4))) acceptor[t] = I8(acceptor[t] + junc_bonus);
+	} else {                                      /* left extension: the target arrives reversed, so do the signals */
+		for (t = 0; t < tlen - 4; ++t) {
+			int can = 0;
+			if (fwd && target[t + 1] == 2 && target[t + 2] == 0) can = 1;
+			if (rev && target[t + 1] == 1 && target[t + 2] == 0) can = 1;
+			if (can && (target[t + 3] == 1 || target[t + 3] == 3)) can = 2;
+			if (can) donor[t] = can == 2 ? 0 : I8(semi);
+		}
+		if (junc) for (t = 0; t < tlen - 1; ++t) if ((fwd && (junc[t + 1] & 2)) || (rev && (junc[t + 1] & 4))) donor[t] = I8(donor[t] + junc_bonus);
+		for (t = 2; t < tlen; ++t) {
+			int can = 0;
+			if (fwd && target[t - 1] == 3 && target[t] == 2) can = 1;
+			if (rev && target[t - 1] == 3 && target[t] == 1) can = 1;
+			if (can && (target[t - 2] == 0 || target[t - 2] == 2)) can = 2;
+			if (can) acceptor[t] = can == 2 ? 0 : I8(semi);
+		}
+		if (junc) for (t = 0; t < tlen; ++t) if ((fwd && (junc[t] & 1)) || (rev && (junc[t] & 8))) acceptor[t] = I8(acceptor[t] + junc_bonus);
+	}
+}
+
+void wmo_ksw_exts2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
+                   int q_, int e_, int q2_, int noncan_, int zdrop, int junc_bonus_, int flag, const uint8_t *junc,
+                   wmo_ez_t *ez, uint32_t *cigar_out)
+{
+	const int8_t q = (int8_t)q_, e = (int8_t)e_, q2 = (int8_t)q2_, noncan = (int8_t)noncan_, junc_bonus = (int8_t)junc_bonus_;
+	const int approx = !!(flag & 0x08), right = !!(flag & 0x02), extz_only = !!(flag & 0x40), rev_cigar = !!(flag & 0x80);
+	const int generic = !!(flag & 0x04), with_cigar = !(flag & 0x01), approx_drop = !!(flag & 0x10);
+	const int qe = q + e;
+	int r, t, T, n_col, last_st = -1, last_en = -1, long_thres, long_diff, max_sc, min_sc;
+	int8_t *blk, *u, *v, *x, *y, *x2, *donor, *acceptor, *s, sc_mch, sc_mis, sc_N;
+	uint8_t *sf, *qr, *p = 0;
+	int32_t *H = 0, H0 = 0, last_H0_t = 0;
+	int *off = 0, *off_end = 0;
+
+	reset_ez(ez);
+	if (m <= 1 || qlen <= 0 || tlen <= 0 || q2 <= q + e) return;                       /* :66 */
+	sc_mch = mat[0], sc_mis = mat[1];
+	sc_N = mat[m * m - 1] == 0 ? (int8_t)-e : mat[m * m - 1];                           /* :74 */
+	T = (tlen + 15) / 16 * 16;
+	n_col = (((qlen < tlen ? qlen : tlen) + 15) / 16 + 1) * 16;                         /* :78, in bytes */
+	for (t = 1, max_sc = mat[0], min_sc = mat[1]; t < m * m; ++t) {
+		if (mat[t] > max_sc) max_sc = mat[t];
+		if (mat[t] < min_sc) min_sc = mat[t];
+	}
+	if (-min_sc > 2 * (q + e)) return;                                                  /* :84 */
+	long_thres = (q2 - q) / e - 1;                                                      /* :86-89 */
+	if (q2 > q + e + long_thres * e) ++long_thres;
+	long_diff = long_thres * e - (q2 - q);
+
+	/* one block like the reference's (:91-96): u v x y x2 donor acceptor s | sf | qr — the score pass writes s in 16-byte chunks that start
+	 * at st0 and may run past its end into sf, and reads sf / qr past their ends */
+	blk = (int8_t*)calloc((size_t)9 * T + ((size_t)(qlen + 15) / 16 + 1) * 16 + 16, 1);
+	u = blk, v = u + T, x = v + T, y = x + T, x2 = y + T, donor = x2 + T, acceptor = donor + T, s = acceptor + T;
+	sf = (uint8_t*)(s + T), qr = sf + T;
+	memset(u, -q - e, (size_t)T * 4);
+	memset(x2, -q2, T);
+	if (!approx) {
+		H = (int32_t*)malloc((size_t)T * 4);
+		for (t = 0; t < T; ++t) H[t] = WMO_NEG_INF;
+	}
+	if (with_cigar) {
+		p = (uint8_t*)malloc((size_t)(qlen + tlen - 1) * n_col + 16);
+		off = (int*)malloc((size_t)(qlen + tlen - 1) * sizeof(int) * 2);
+		off_end = off + qlen + tlen - 1;
+	}
+	for (t = 0; t < qlen; ++t) qr[t] = query[qlen - 1 - t];
+	memcpy(sf, target, tlen);
+	if (flag & (0x100 | 0x200)) {                                                        /* :109-166 (whole 16-lane groups get -noncan) */
+		memset(donor, -noncan, T); memset(acceptor, -noncan, T);
+		{
+			int8_t *d2 = (int8_t*)malloc(tlen), *a2 = (int8_t*)malloc(tlen);
+			wmo_exts2_signals(tlen, target, noncan, junc_bonus, flag, junc, d2, a2);
+			memcpy(donor, d2, tlen); memcpy(acceptor, a2, tlen);
+			free(d2); free(a2);
+		}
+	}
+
+	for (r = 0; r < qlen + tlen - 1; ++r) {
+		int st = 0, en = tlen - 1, st0, en0;
+		int8_t x1, x21, v1;
+		const uint8_t *qrr = qr + (qlen - 1 - r);
+		if (st < r - qlen + 1) st = r - qlen + 1;
+		if (en > r) en = r;
+		st0 = st, en0 = en;
+		st = st / 16 * 16, en = (en + 16) / 16 * 16 - 1;
+		if (st > 0) {                                                                    /* :178-186 */
+			if (st - 1 >= last_st && st - 1 <= last_en) x1 = x[st - 1], x21 = x2[st - 1], v1 = v[st - 1];
+			else x1 = I8(-q - e), x21 = I8(-q2), v1 = I8(-q - e);
+		} else {
+			x1 = I8(-q - e), x21 = I8(-q2);
+			v1 = r == 0 ? I8(-q - e) : r < long_thres ? I8(-e) : r == long_thres ? I8(long_diff) : 0;
+		}
+		if (en >= r) {                                                                   /* :187-190 */
+			y[r] = I8(-q - e);
+			u[r] = r == 0 ? I8(-q - e) : r < long_thres ? I8(-e) : r == long_thres ? I8(long_diff) : 0;
+		}
+		if (!generic) {                                                                  /* :192-209, 16-byte chunks from st0 */
+			for (t = st0; t <= en0; t += 16) {
+				int8_t tmp16[16];
+				int i;
+				for (i = 0; i < 16; ++i) {
+					uint8_t a = sf[t + i], b = qrr[t + i];
+					tmp16[i] = (a == (uint8_t)(m - 1) || b == (uint8_t)(m - 1)) ? sc_N : a == b ? sc_mch : sc_mis;
+				}
+				memcpy(s + t, tmp16, 16);
+			}
+		} else {
+			for (t = st0; t <= en0; ++t) s[t] = mat[sf[t] * m + qrr[t]];
+		}
+		if (with_cigar) off[r] = st, off_end[r] = en;
+		for (t = st; t <= en; ++t) {                                                     /* :211-333 lane by lane */
+			int8_t z = s[t], xo = x[t], vo = v[t], x2o = x2[t], ut = u[t];
+			int8_t a = I8(x1 + v1), b = I8(y[t] + ut), a2 = I8(x21 + v1), a2a = I8(a2 + acceptor[t]), tmp, dn;
+			uint8_t d;
+			if (!right) {
+				d = a > z ? 1 : 0;   z = z > a ? z : a;
+				d = b > z ? 2 : d;   z = z > b ? z : b;
+				d = a2a > z ? 3 : d; z = z > a2a ? z : a2a;
+			} else {
+				d = z > a ? 0 : 1;   z = z > a ? z : a;
+				d = z > b ? d : 2;   z = z > b ? z : b;
+				d = z > a2a ? d : 3; z = z > a2a ? z : a2a;
+			}
+			u[t] = I8(z - v1); v[t] = I8(z - ut);                                       /* (no clamp to the match score here) */
+			tmp = I8(z - q); a = I8(a - tmp); b = I8(b - tmp);
+			a2 = I8(a2 - I8(z - q2));
+			dn = donor[t];
+			if (!right) {
+				x[t] = I8((a > 0 ? a : 0) - qe);   d |= a > 0 ? 0x08 : 0;
+				y[t] = I8((b > 0 ? b : 0) - qe);   d |= b > 0 ? 0x10 : 0;
+				x2[t] = I8((a2 > dn ? a2 : dn) - q2); d |= a2 > dn ? 0x20 : 0;
+			} else {
+				x[t] = I8((a >= 0 ? a : 0) - qe);  d |= a >= 0 ? 0x08 : 0;
+				y[t] = I8((b >= 0 ? b : 0) - qe);  d |= b >= 0 ? 0x10 : 0;
+				x2[t] = I8((dn > a2 ? dn : a2) - q2); d |= dn > a2 ? 0 : 0x20;
+			}
+			if (with_cigar) p[(size_t)r * n_col + (t - st)] = d;
+			x1 = xo, v1 = vo, x21 = x2o;
+		}
+		if (!approx) {                                                                   /* exact max :334-381 */
+			int32_t max_H, max_t;
+			if (r > 0) {
+				int32_t HH[4], tt[4], en1 = st0 + (en0 - st0) / 4 * 4, i;
+				max_H = H[en0] = en0 > 0 ? H[en0 - 1] + u[en0] : H[en0] + v[en0];
+				max_t = en0;
+				for (i = 0; i < 4; ++i) HH[i] = max_H, tt[i] = max_t;
+				for (t = st0; t < en1; t += 4)
+					for (i = 0; i < 4; ++i) {
+						H[t + i] += v[t + i];
+						if (H[t + i] > HH[i]) HH[i] = H[t + i], tt[i] = t;
+					}
+				for (i = 0; i < 4; ++i)
+					if (max_H < HH[i]) max_H = HH[i], max_t = tt[i] + i;
+				for (; t < en0; ++t) {
+					H[t] += (int32_t)v[t];
+					if (H[t] > max_H) max_H = H[t], max_t = t;
+				}
+			} else H[0] = v[0] - qe, max_H = H[0], max_t = 0;
+			if (en0 == tlen - 1 && H[en0] > ez->mte) ez->mte = H[en0], ez->mte_q = r - en;
+			if (r - st0 == qlen - 1 && H[st0] > ez->mqe) ez->mqe = H[st0], ez->mqe_t = st0;
+			if (apply_zdrop(ez, max_H, r, max_t, zdrop, 0)) break;
+			if (r == qlen + tlen - 2 && en0 == tlen - 1) ez->score = H[tlen - 1];
+		} else {                                                                         /* approximate :382-398 */
+			if (r > 0) {
+				if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
+					int32_t d0 = v[last_H0_t], d1 = u[last_H0_t + 1];
+					if (d0 > d1) H0 += d0;
+					else H0 += d1, ++last_H0_t;
+				} else if (last_H0_t >= st0 && last_H0_t <= en0) {
+					H0 += v[last_H0_t];
+				} else {
+					++last_H0_t, H0 += u[last_H0_t];
+				}
+			} else H0 = v[0] - qe, last_H0_t = 0;
+			if (approx_drop && apply_zdrop(ez, H0, r, last_H0_t, zdrop, 0)) break;
+			if (r == qlen + tlen - 2 && en0 == tlen - 1) ez->score = H0;
+		}
+		last_st = st, last_en = en;
+	}
+	if (with_cigar) {                                                                    /* :400-406 */
+		if (!ez->zdropped && !extz_only)
+			ez->n_cigar = backtrack_intron(rev_cigar, long_thres, p, off, off_end, n_col, tlen - 1, qlen - 1, cigar_out);
+		else if (ez->max_t >= 0 && ez->max_q >= 0)
+			ez->n_cigar = backtrack_intron(rev_cigar, long_thres, p, off, off_end, n_col, ez->max_t, ez->max_q, cigar_out);
+		free(p); free(off);
+	}
+	free(blk); free(H);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * ksw_ll_qinit + ksw_ll_i16 (src/ksw2_ll_sse.c:32-147): striped (Farrar) local SW, int16 lanes,
  * signed saturating add / unsigned saturating subtract; emulated lane by lane (8 lanes per vector).
  * ---------------------------------------------------------------------------------------------- */

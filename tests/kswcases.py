@@ -45,3 +45,56 @@ def ont_segments(seed, n, mean=300, w=751):
         flag = 0x40 if r == 0 else 0xC2 if r == 1 else 0x08
         out.append(dict(q=q, t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=w, zdrop=400, end_bonus=-1, flag=flag))
     return out
+
+
+# ---- splice-aware extension (ksw_exts2_sse): a transcript-like query against a target with introns --------------------------------
+SPLICE_FLAGS = (0x100, 0x200, 0x100 | 0x400, 0x200 | 0x400 | 0x80, 0x100 | 0x02, 0x100 | 0x08, 0x100 | 0x40, 0x200 | 0x40 | 0x80, 0x100 | 0x200, 0x00)
+
+
+def make_splice_cases(seed, n, max_exon=120, max_intron=400):
+    """exons joined in the query, separated by introns (canonical GT..AG, CT..AC for the reverse strand, or random) in the target; optional
+    annotated junction bits; N bases; scoring = the splice preset (src/options.c:117-127) or a variant"""
+    import numpy as np
+    from winnowmap_amd import synth
+    rng = np.random.default_rng(seed)
+    out = []
+    for it in range(n):
+        n_exon = int(rng.integers(1, 5))
+        q_parts, t_parts, junc = [], [], []
+        t_len = 0
+        flank = rng.integers(0, 4, int(rng.integers(0, 30))).astype(np.uint8)
+        t_parts.append(flank); t_len += len(flank)
+        for x in range(n_exon):
+            ex = rng.integers(0, 4, int(rng.integers(8, max_exon))).astype(np.uint8)
+            q_parts.append(synth.mutate_codes(ex, rng, 0.03, 0.01, 0.01) if it % 3 else ex)
+            t_parts.append(ex); t_len += len(ex)
+            if x + 1 < n_exon:
+                intron = rng.integers(0, 4, int(rng.integers(20, max_intron))).astype(np.uint8)
+                kind = int(rng.integers(0, 4))
+                if kind == 0 and len(intron) >= 6:
+                    intron[:3] = (2, 3, int(rng.integers(0, 4))); intron[-3:] = (int(rng.integers(0, 4)), 0, 2)      # GT. ... .AG
+                elif kind == 1 and len(intron) >= 6:
+                    intron[:3] = (1, 3, int(rng.integers(0, 4))); intron[-3:] = (int(rng.integers(0, 4)), 0, 1)      # CT. ... .AC
+                junc.append((t_len, t_len + len(intron) - 1))
+                t_parts.append(intron); t_len += len(intron)
+        tail = rng.integers(0, 4, int(rng.integers(0, 30))).astype(np.uint8)
+        t_parts.append(tail)
+        q = np.concatenate(q_parts); t = np.concatenate(t_parts)
+        if it % 7 == 3:
+            t[int(rng.integers(0, len(t)))] = 4
+        if it % 11 == 5:
+            q[int(rng.integers(0, len(q)))] = 4
+        flag = SPLICE_FLAGS[it % len(SPLICE_FLAGS)]
+        if flag & 0x80:
+            q = q[::-1].copy(); t = t[::-1].copy()
+        jn = None
+        if it % 2 == 0:
+            jn = np.zeros(len(t), np.uint8)
+            for (a, b) in junc:      # donor / acceptor bits on both strands (src/index.c:690-803: 1 | 8 at the intron start, 2 | 4 at its end)
+                if flag & 0x80:
+                    a, b = len(t) - 1 - b, len(t) - 1 - a
+                jn[a] |= 1 | 8; jn[b] |= 2 | 4
+        sc = [(1, 2, 2, 1, 32, 9, 9), (1, 2, 2, 1, 32, 9, 0), (2, 4, 4, 2, 40, 5, 3), (1, 1, 3, 1, 24, 7, 2)][it % 4]
+        out.append(dict(q=q, t=t, a=sc[0], b=sc[1], q_=sc[2], e=sc[3], q2=sc[4], noncan=sc[5], junc_bonus=sc[6],
+                        zdrop=[200, 50, -1, 400][it % 4], flag=flag, junc=jn))
+    return out

@@ -176,3 +176,21 @@ def test_chain_vs_reference(ref_index):
             ou, obx, oby = W.o_chain_dp(ax, ay, **prm)
             ru, rbx, rby = W.r_chain_dp(ax, ay, **prm)
             assert np.array_equal(ou, ru) and np.array_equal(obx, rbx) and np.array_equal(oby, rby)
+
+
+def test_exts2_oracle_vs_reference():
+    """wmo_ksw_exts2 (oracle/wm_oracle.c) against the reference's own ksw_exts2_sse (src/ksw2_exts2_sse.c) on transcript-like inputs: every
+    splice flag, left / right gap alignment, approximate and exact maximum, extension-only, reversed operands, junction annotation, N."""
+    _need_ref()
+    import kswcases
+    n_intron = 0
+    for c in kswcases.make_splice_cases(3, 400):
+        kw = dict(mat=W.simple_mat(c["a"], c["b"], 1), q=c["q_"], e=c["e"], q2=c["q2"], noncan=c["noncan"], zdrop=c["zdrop"],
+                  junc_bonus=c["junc_bonus"], flag=c["flag"], junc=c["junc"])
+        o = W.o_ksw_exts2(c["q"], c["t"], **kw)
+        r = W.r_ksw_exts2(c["q"], c["t"], **kw)
+        for k in W.EZ_FIELDS:
+            assert o[k] == r[k], (k, o[k], r[k], hex(c["flag"]), len(c["q"]), len(c["t"]))
+        assert np.array_equal(o["cigar"], r["cigar"]), (hex(c["flag"]), W.cigar_str(o["cigar"]), W.cigar_str(r["cigar"]))
+        n_intron += any((int(x) & 0xf) == 3 for x in o["cigar"])
+    assert n_intron > 100, n_intron                      # the cases do exercise the intron state

@@ -153,6 +153,23 @@ def o_ksw_extd2(query, target, mat=None, q=4, e=2, q2=24, e2=1, w=751, zdrop=400
     return d
 
 
+def o_ksw_exts2(query, target, mat=None, q=2, e=1, q2=32, noncan=9, zdrop=200, junc_bonus=9, flag=0, junc=None):
+    """oracle restatement of ksw_exts2_sse (splice preset: a=1 b=2 q=2 e=1 q2=32 noncan=9, src/options.c:117-127)"""
+    L = oracle()
+    L.wmo_ksw_exts2.argtypes = [C.c_int, u8p, C.c_int, u8p, C.c_int, i8p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, u32p]
+    mat = simple_mat(1, 2, 1) if mat is None else mat
+    query = np.ascontiguousarray(query, np.uint8)
+    target = np.ascontiguousarray(target, np.uint8)
+    ez = EZ()
+    cig = np.zeros(len(query) + len(target) + 4, np.uint32)
+    jn = None if junc is None else np.ascontiguousarray(junc, np.uint8)
+    L.wmo_ksw_exts2(len(query), query, len(target), target, 5, mat, q, e, q2, noncan, zdrop, junc_bonus, flag,
+                    None if jn is None else jn.ctypes.data, C.cast(C.byref(ez), C.c_void_p), cig)
+    d = {n: getattr(ez, n) for n in EZ_FIELDS}
+    d["cigar"] = cig[:ez.n_cigar].copy()
+    return d
+
+
 def o_ksw_ll(query, target, mat=None, gapo=4, gape=2):
     L = oracle()
     mat = simple_mat() if mat is None else mat
@@ -247,6 +264,22 @@ def r_ksw_extd2(query, target, mat=None, q=4, e=2, q2=24, e2=1, w=751, zdrop=400
     ez = np.zeros(10, np.int32)
     cig = np.zeros(len(query) + len(target) + 4, np.uint32)
     n = ref().refshim_ksw_extd2(len(query), query, len(target), target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez, cig, len(cig))
+    d = {name: int(ez[i]) for i, name in enumerate(EZ_FIELDS)}
+    d["cigar"] = cig[:n].copy()
+    return d
+
+
+def r_ksw_exts2(query, target, mat=None, q=2, e=1, q2=32, noncan=9, zdrop=200, junc_bonus=9, flag=0, junc=None):
+    R = ref()
+    R.refshim_ksw_exts2.argtypes = [C.c_int, u8p, C.c_int, u8p, i8p] + [C.c_int] * 7 + [C.c_void_p, i32p, u32p, C.c_int]
+    mat = simple_mat(1, 2, 1) if mat is None else mat
+    query = np.ascontiguousarray(query, np.uint8)
+    target = np.ascontiguousarray(target, np.uint8)
+    ez = np.zeros(10, np.int32)
+    cig = np.zeros(len(query) + len(target) + 4, np.uint32)
+    jn = None if junc is None else np.ascontiguousarray(junc, np.uint8)
+    n = R.refshim_ksw_exts2(len(query), query, len(target), target, mat, q, e, q2, noncan, zdrop, junc_bonus, flag,
+                            None if jn is None else jn.ctypes.data, ez, cig, len(cig))
     d = {name: int(ez[i]) for i, name in enumerate(EZ_FIELDS)}
     d["cigar"] = cig[:n].copy()
     return d
