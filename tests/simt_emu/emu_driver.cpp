@@ -5,6 +5,7 @@
 #include "ksw_kernel.h"              // winnowmap_amd/csrc
 #include "ksw_packed_kernel.h"
 #include "ksw_packed_multi_kernel.h"
+#include "ksw_exts2_kernel.h"
 #include "ksw_plan.h"
 #include "sketch_kernel.h"
 #include "seedchain_kernel.h"
@@ -168,6 +169,39 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 	return n;
 }
 
+
+// ksw_exts2_sse through the emulated splice kernel + its backtrack; junc may be null
+int emu_ksw_exts2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int q, int e, int q2, int noncan, int zdrop,
+                  int junc_bonus, int flag, const uint8_t *junc, int32_t *ez_out, uint32_t *cigar_out, int cigar_cap)
+{
+	wm_ksw_score_t sc;
+	memset(&sc, 0, sizeof(sc));
+	sc.match = mat[0]; sc.mismatch = mat[1]; sc.sc_ambi = mat[24]; sc.q = (int8_t)q; sc.e = (int8_t)e; sc.q2 = (int8_t)q2; sc.e2 = 0;
+	std::vector<uint8_t> seqs((size_t)qlen + tlen + 64, 0), jn;
+	memcpy(seqs.data(), query, qlen); memcpy(seqs.data() + qlen, target, tlen);
+	if (junc) { jn.assign((size_t)qlen + tlen + 64, 0); memcpy(jn.data() + qlen, junc, tlen); }
+	wm_ksw_djob_t jb;
+	memset(&jb, 0, sizeof(jb));
+	jb.q_off = 0; jb.t_off = qlen; jb.qlen = qlen; jb.tlen = tlen; jb.w = -1; jb.zdrop = zdrop; jb.end_bonus = 0; jb.flag = flag;
+	jb.n_col = (((qlen < tlen ? qlen : tlen) + 15) / 16 + 1) * 16; jb.tb_off = 0;
+	std::vector<uint8_t> tb((size_t)(qlen + tlen - 1) * jb.n_col + 64, 0xEE);
+	const int T = (tlen + 15) / 16 * 16;
+	std::vector<signed char> mem((size_t)8 * T + 64, 0x5a);
+	std::vector<int> Hm(T + 16, 0x5a5a5a5a);
+	wm_ksw_dres_t res;
+	memset(&res, 0, sizeof(res));
+	simt::exec_mask() = ~0ull;
+	wmk::ksw_dp_exts2<true>(sc, noncan, junc_bonus, jb, seqs.data(), junc ? jn.data() : 0, tb.data(), mem.data(), Hm.data(), &res);
+	int n = 0;
+	if (res.bt_i >= 0) {
+		n = wmk::ksw_exts2_backtrack_thread(sc, jb, tb.data(), res.bt_i, res.bt_j, cigar_out, cigar_cap);
+		if (n < 0) return -3;
+		if (!(flag & KSW_F_REV_CIGAR)) std::reverse(cigar_out, cigar_out + n);
+	}
+	ez_out[0] = res.max; ez_out[1] = res.zdropped; ez_out[2] = res.max_q; ez_out[3] = res.max_t; ez_out[4] = res.mqe;
+	ez_out[5] = res.mqe_t; ez_out[6] = res.mte; ez_out[7] = res.mte_q; ez_out[8] = res.score; ez_out[9] = res.reach_end;
+	return n;
+}
 
 // mm_sketch through the emulated sketch kernel: n sequences (codes) packed in seqs; returns per-sequence counts and minimizers
 int emu_sketch(int n, const uint8_t *seqs, const uint64_t *offs, const int32_t *lens, int w, int k, uint32_t table_bits, uint32_t salt0, uint32_t salt1,

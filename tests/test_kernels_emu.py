@@ -265,3 +265,25 @@ def test_packed_multiwave_ksw_kernel_matches_oracle(emu_v):
             assert [int(x) for x in ez] == [o[k] for k in W.EZ_FIELDS], (force, len(c["q"]), len(c["t"]), c["flag"], c["w"])
             assert np.array_equal(cig, o["cigar"]), (force, len(c["q"]), len(c["t"]), c["flag"], c["w"])
     assert n_run[20] > 30 and n_run[21] > 60 and n_run[22] >= 4 and n_run[23] >= 4 and n_run[24] >= 5 and n_run[25] >= 8, n_run
+
+
+def test_exts2_splice_kernel_emulated_matches_oracle(emu):
+    """ksw_dp_exts2 + ksw_exts2_backtrack_thread (ksw_exts2_kernel.h) against the oracle's ksw_exts2_sse restatement, which
+    tests/test_oracle_vs_ref.py pins to the reference's own function: every splice flag, both gap alignments, exact / approximate maximum,
+    extension-only, reversed operands, junction annotation, N bases, introns up to 2 kb (several 64-lane sweeps per row)."""
+    emu.emu_ksw_exts2.argtypes = [C.c_int, W.u8p, C.c_int, W.u8p, W.i8p] + [C.c_int] * 7 + [C.c_void_p, W.i32p, W.u32p, C.c_int]
+    n_intron = 0
+    cases = kswcases.make_splice_cases(5, 160) + kswcases.make_splice_cases(6, 40, max_exon=300, max_intron=2000)
+    for c in cases:
+        o = W.o_ksw_exts2(c["q"], c["t"], mat=W.simple_mat(c["a"], c["b"], 1), q=c["q_"], e=c["e"], q2=c["q2"], noncan=c["noncan"], zdrop=c["zdrop"],
+                          junc_bonus=c["junc_bonus"], flag=c["flag"], junc=c["junc"])
+        ez = np.zeros(10, np.int32)
+        cig = np.zeros(len(c["q"]) + len(c["t"]) + 4, np.uint32)
+        jn = None if c["junc"] is None else np.ascontiguousarray(c["junc"], np.uint8)
+        n = emu.emu_ksw_exts2(len(c["q"]), c["q"], len(c["t"]), c["t"], W.simple_mat(c["a"], c["b"], 1), c["q_"], c["e"], c["q2"], c["noncan"], c["zdrop"],
+                              c["junc_bonus"], c["flag"], None if jn is None else jn.ctypes.data, ez, cig, len(cig))
+        assert n >= 0
+        assert [int(x) for x in ez] == [o[k] for k in W.EZ_FIELDS], (hex(c["flag"]), len(c["q"]), len(c["t"]), [int(x) for x in ez], [o[k] for k in W.EZ_FIELDS])
+        assert np.array_equal(cig[:n], o["cigar"]), (hex(c["flag"]), W.cigar_str(cig[:n]), W.cigar_str(o["cigar"]))
+        n_intron += any((int(x) & 0xf) == 3 for x in o["cigar"])
+    assert n_intron > 60, n_intron
