@@ -98,6 +98,16 @@ int wm_reads_upload(wm_ctx_t *ctx, const uint8_t *codes, size_t n);
 int wm_ksw_batch_pos(wm_ctx_t *ctx, const wm_ksw_score_t *sc, int n_jobs, const wm_ksw_pos_t *jobs,
                      wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used);
 
+/* ksw_exts2_sse as a batch (replaces src/ksw2.h:63-64, called at src/align.c:326-327 when MM_F_SPLICE is set): the splice-aware
+ * extension. sc->q / e = gap open / extension, sc->q2 = the price of an intron (no extension), sc->e2 unused; noncan = the penalty of a
+ * non-canonical splice site, junc_bonus = the bonus of an annotated junction; flag = KSW_EZ_* incl. SPLICE_FOR 0x100, SPLICE_REV 0x200,
+ * SPLICE_FLANK 0x400 (job.w and job.end_bonus are ignored: the reference's function has no band and no end bonus). junc: NULL, or
+ * seqs_bytes bytes parallel to seqs whose entries at a job's target hold the junction bits of mm_idx_bed_junc (src/index.c:690-803).
+ * CIGAR op 3 = N. Results, pool and errors as wm_ksw_batch. Not used by wm_map_reads (no splice mode in the host glue yet). */
+int wm_ksw_exts2_batch(wm_ctx_t *ctx, const wm_ksw_score_t *sc, int noncan, int junc_bonus, int n_jobs, const wm_ksw_job_t *jobs,
+                       const uint8_t *seqs, size_t seqs_bytes, const uint8_t *junc,
+                       wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used);
+
 /* Same computation with the inputs already resident in HBM (device pointers from wm_dev_alloc /
  * wm_dev_upload); results stay on the device until wm_ksw_fetch. Used by bench.py so that the timed
  * region contains kernels only, and by the batched mapper which keeps reads and reference resident. */

@@ -45,6 +45,7 @@ static inline double now_ms() { return std::chrono::duration<double, std::milli>
 #include "ksw_kernel.h"
 #include "ksw_packed_kernel.h"
 #include "ksw_packed_multi_kernel.h"
+#include "ksw_exts2_kernel.h"
 #include "ksw_plan.h"
 #include "sketch_kernel.h"
 #include "seedchain_kernel.h"
@@ -394,6 +395,9 @@ static void *arena_take(wm_ctx_t *c, size_t bytes)
 	c->arena_used = a + bytes;
 	return c->arena + a;
 }
+
+// releases what a batched call took from the arena when the call returns
+struct ArenaMark { wm_ctx_t *c; size_t m; ArenaMark(wm_ctx_t *c_) : c(c_), m(c_->arena_used) {} ~ArenaMark() { c->arena_used = m; } };
 
 // variant = EXACT*4 + CLIP*2 + HASN; jobs with an N run on the CLIP instantiation (a superset: exact emulation of stale lanes)
 template <int BP> static void launch_dpp(int variant, int n, hipStream_t s, const wm_ksw_score_t &sc, const wm_ksw_djob_t *jobs, const int *order,
@@ -852,6 +856,119 @@ extern "C" int wm_ksw_extd2(wm_ctx_t *c, int qlen, const uint8_t *query, int tle
 	return WM_OK;
 }
 
+// ---- ksw_exts2_sse (src/ksw2.h:63-64): the splice-aware extension as a batch. One wavefront per alignment, state in a global scratch
+// slab (ksw_exts2_kernel.h). Not used by the mapper (the host glue has no splice mode); validated on the wavefront emulator.
+__global__ __launch_bounds__(64) void ksw_exts2_kernel(wm_ksw_score_t sc, int noncan, int junc_bonus, const wm_ksw_djob_t *__restrict__ jobs,
+                                                        const uint8_t *__restrict__ seqs, const uint8_t *__restrict__ junc, uint8_t *__restrict__ tb,
+                                                        uint8_t *scratch, const uint64_t *__restrict__ scratch_off, wm_ksw_dres_t *__restrict__ res)
+{
+	const int j = blockIdx.x;
+	const wm_ksw_djob_t jb = jobs[j];
+	const uint64_t T = ((uint64_t)jb.tlen + 15) / 16 * 16;
+	signed char *mem = (signed char*)(scratch + scratch_off[j]);
+	wmk::ksw_dp_exts2<true>(sc, noncan, junc_bonus, jb, seqs, junc, tb, mem, (int*)(mem + 8 * T), res + j);
+}
+__global__ __launch_bounds__(64) void ksw_exts2_backtrack_kernel(wm_ksw_score_t sc, int n, const wm_ksw_djob_t *__restrict__ jobs, const uint8_t *__restrict__ tb,
+                                                                  wm_ksw_dres_t *__restrict__ res, uint32_t *__restrict__ cig_scratch, int *__restrict__ err)
+{
+	const int j = blockIdx.x * 64 + threadIdx.x;
+	if (j >= n) return;
+	wm_ksw_dres_t r = res[j];
+	int nc = 0;
+	if (r.bt_i >= 0) {
+		nc = wmk::ksw_exts2_backtrack_thread(sc, jobs[j], tb, r.bt_i, r.bt_j, cig_scratch + jobs[j].cig_off, jobs[j].cig_cap);
+		if (nc < 0) { atomicExch(err, 1); nc = 0; }
+	}
+	res[j].n_cigar = nc;
+}
+
+extern "C" int wm_ksw_exts2_batch(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int noncan, int junc_bonus, int n_jobs, const wm_ksw_job_t *jobs,
+                                  const uint8_t *seqs, size_t seqs_bytes, const uint8_t *junc,
+                                  wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used)
+try {
+	if (!c) return set_err(WM_EINVAL, "null context");
+	if (cigar_used) *cigar_used = 0;
+	if (n_jobs < 0) return set_err(WM_EINVAL, "n_jobs < 0");
+	if (n_jobs == 0) return WM_OK;
+	if (!sc_in || !jobs || !seqs || !results) return set_err(WM_EINVAL, "null argument");
+	const wm_ksw_score_t sc = *sc_in;
+	if (sc.e <= 0 || sc.q2 <= sc.q + sc.e) return set_err(WM_EINVAL, "ksw_exts2 needs e > 0 and q2 > q + e (src/ksw2_exts2_sse.c:66)");
+	if (-(int)sc.mismatch > 2 * (sc.q + sc.e)) return set_err(WM_EINVAL, "mismatch penalty above 2 (q + e): the reference returns without aligning (src/ksw2_exts2_sse.c:84)");
+	if (noncan < -127 || noncan > 127 || junc_bonus < -127 || junc_bonus > 127) return set_err(WM_EINVAL, "noncan / junc_bonus are int8 in the reference");
+	HIPCHK(hipSetDevice(c->device));
+	ArenaMark mark(c);
+	std::vector<wm_ksw_djob_t> dj(n_jobs);
+	std::vector<uint64_t> soff(n_jobs);
+	uint64_t tb_off = 0, cig_off = 0, sc_off = 0;
+	for (int i = 0; i < n_jobs; ++i) {
+		const wm_ksw_job_t &jb = jobs[i];
+		if (jb.qlen <= 0 || jb.tlen <= 0) return set_err(WM_EINVAL, "job %d: empty operand", i);
+		if ((uint64_t)jb.q_off + jb.qlen > seqs_bytes || (uint64_t)jb.t_off + jb.tlen > seqs_bytes) return set_err(WM_EINVAL, "job %d: operands outside seqs", i);
+		if (jb.flag & (0x01 | 0x04 | 0x10)) return set_err(WM_EINVAL, "job %d: KSW_EZ_SCORE_ONLY / GENERIC_SC / APPROX_DROP are not supported", i);
+		wm_ksw_djob_t &d = dj[i];
+		memset(&d, 0, sizeof(d));
+		d.q_off = jb.q_off; d.t_off = jb.t_off; d.qlen = jb.qlen; d.tlen = jb.tlen; d.w = -1; d.zdrop = jb.zdrop; d.end_bonus = 0; d.flag = jb.flag;
+		d.n_col = (((jb.qlen < jb.tlen ? jb.qlen : jb.tlen) + 15) / 16 + 1) * 16;               // src/ksw2_exts2_sse.c:78
+		d.tb_off = tb_off;
+		tb_off += ((uint64_t)(jb.qlen + jb.tlen - 1) * d.n_col + 15) & ~(uint64_t)15;
+		d.cig_off = (uint32_t)cig_off; d.cig_cap = jb.qlen + jb.tlen + 2;
+		cig_off += d.cig_cap;
+		soff[i] = sc_off;
+		sc_off += (12 * (((uint64_t)jb.tlen + 15) / 16 * 16) + 256 + 255) & ~(uint64_t)255;
+	}
+	if (cig_off >= ((uint64_t)1 << 32)) return set_err(WM_ENOMEM, "ksw_exts2: batch too large (split it)");
+	const size_t nj = (size_t)n_jobs;
+	wm_ksw_djob_t *d_jobs = (wm_ksw_djob_t*)arena_take(c, nj * sizeof(wm_ksw_djob_t));
+	uint64_t *d_soff = (uint64_t*)arena_take(c, nj * 8);
+	wm_ksw_dres_t *d_res = (wm_ksw_dres_t*)arena_take(c, nj * sizeof(wm_ksw_dres_t));
+	uint32_t *d_off = (uint32_t*)arena_take(c, nj * 4 + 64);
+	uint32_t *d_total = (uint32_t*)arena_take(c, 64);
+	int *d_err = (int*)arena_take(c, 64);
+	uint8_t *d_seqs = (uint8_t*)arena_take(c, seqs_bytes + 64);
+	uint8_t *d_junc = junc ? (uint8_t*)arena_take(c, seqs_bytes + 64) : 0;
+	uint32_t *d_cig = (uint32_t*)arena_take(c, (cig_off + 16) * 4);
+	uint32_t *d_pool = (uint32_t*)arena_take(c, (cig_off + 16) * 4);
+	uint8_t *d_scratch = (uint8_t*)arena_take(c, sc_off + 256);
+	uint8_t *d_tb = (uint8_t*)arena_take(c, tb_off + 64);
+	if (!d_jobs || !d_soff || !d_res || !d_off || !d_total || !d_err || !d_seqs || (junc && !d_junc) || !d_cig || !d_pool || !d_scratch || !d_tb)
+		return set_err(WM_ENOMEM, "ksw_exts2: batch does not fit the arena (%llu traceback bytes); split it", (unsigned long long)tb_off);
+	HIPCHK(hipMemcpyAsync(d_jobs, dj.data(), nj * sizeof(wm_ksw_djob_t), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(d_soff, soff.data(), nj * 8, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream));
+	if (junc) HIPCHK(hipMemcpyAsync(d_junc, junc, seqs_bytes, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemsetAsync(d_err, 0, 4, c->stream));
+	hipLaunchKernelGGL(ksw_exts2_kernel, dim3(n_jobs), dim3(64), 0, c->stream, sc, noncan, junc_bonus, d_jobs, d_seqs, d_junc, d_tb, d_scratch, d_soff, d_res);
+	hipLaunchKernelGGL(ksw_exts2_backtrack_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, c->stream, sc, n_jobs, d_jobs, d_tb, d_res, d_cig, d_err);
+	hipLaunchKernelGGL(ksw_scan_kernel, dim3(1), dim3(1024), 0, c->stream, n_jobs, d_res, d_off, d_total);
+	hipLaunchKernelGGL(ksw_gather_kernel, dim3(n_jobs), dim3(64), 0, c->stream, d_jobs, d_res, d_off, d_cig, d_pool, (uint32_t)(cig_off + 16));
+	HIPCHK(hipGetLastError());
+	UBuf<wm_ksw_dres_t> res(nj, c);
+	UBuf<uint32_t> off(nj, c);
+	UBuf<uint32_t> small(4, c);
+	HIPCHK(hipMemcpyAsync(res.data(), d_res, nj * sizeof(wm_ksw_dres_t), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(off.data(), d_off, nj * 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(small.data(), d_total, 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(small.data() + 1, d_err, 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(ctx_sync(c));
+	if (small[1]) return set_err(WM_EINTERNAL, "cigar slot overflow in backtrack");
+	const uint32_t total = small[0];
+	if (cigar_used) *cigar_used = total;
+	if (total > cigar_cap) return set_err(WM_ENOMEM, "cigar_pool too small: need %u ops", total);
+	if (total) {
+		if (!cigar_pool) return set_err(WM_EINVAL, "null cigar_pool");
+		HIPCHK(hipMemcpyAsync(cigar_pool, d_pool, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(ctx_sync(c));
+	}
+	for (int i = 0; i < n_jobs; ++i) {
+		wm_ksw_result_t &o = results[i];
+		const wm_ksw_dres_t &r = res[i];
+		o.max = r.max; o.zdropped = r.zdropped; o.max_q = r.max_q; o.max_t = r.max_t; o.mqe = r.mqe; o.mqe_t = r.mqe_t;
+		o.mte = r.mte; o.mte_q = r.mte_q; o.score = r.score; o.reach_end = r.reach_end; o.n_cigar = r.n_cigar; o.cig_off = off[i];
+	}
+	return WM_OK;
+}
+catch (const std::bad_alloc &) { return set_err(WM_ENOMEM, "out of host memory"); }
+
 // ======================================================================================================
 // sketch / seed / chain kernels and their batched entry points
 // ======================================================================================================
@@ -1240,7 +1357,6 @@ extern "C" int wm_index_build_gpu(wm_ctx_t *c, const char *fasta, const char *km
 	return WM_OK;
 }
 
-struct ArenaMark { wm_ctx_t *c; size_t m; ArenaMark(wm_ctx_t *c_) : c(c_), m(c_->arena_used) {} ~ArenaMark() { c->arena_used = m; } };
 
 // resident (optional, n flags): sequence i starts at code seq_off[i] of the resident read codes (wm_reads_upload) instead of `seqs`
 static int sketch_batch_impl(wm_ctx_t *c, int n, const uint8_t *seqs, size_t seqs_bytes, const uint64_t *seq_off, const int32_t *len, const uint8_t *resident,

@@ -88,6 +88,22 @@ class Context:
                                 res.ctypes.data, pool.ctypes.data, cap, C.byref(used)))
         return res, pool[:used.value]
 
+    def ksw_exts2_batch(self, score, noncan, junc_bonus, jobs, seqs, junc=None):
+        """wm_ksw_exts2_batch: the splice-aware extension (ksw_exts2_sse); junc = None or uint8 array parallel to seqs"""
+        jobs = np.ascontiguousarray(jobs, KSW_JOB_DTYPE)
+        seqs = np.ascontiguousarray(seqs, np.uint8)
+        jn = None if junc is None else np.ascontiguousarray(junc, np.uint8)
+        assert jn is None or jn.nbytes == seqs.nbytes
+        res = np.zeros(len(jobs), KSW_RES_DTYPE)
+        cap = int((jobs["qlen"].astype(np.int64) + jobs["tlen"] + 2).sum()) + 16
+        pool = np.zeros(cap, np.uint32)
+        used = C.c_size_t(0)
+        lib().wm_ksw_exts2_batch.argtypes = [C.c_void_p, C.POINTER(KswScore), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        _chk(lib().wm_ksw_exts2_batch(self._h, C.byref(score), noncan, junc_bonus, len(jobs), jobs.ctypes.data, seqs.ctypes.data, seqs.nbytes,
+                                      None if jn is None else jn.ctypes.data, res.ctypes.data, pool.ctypes.data, cap, C.byref(used)))
+        return res, pool[:used.value]
+
     def reads_upload(self, codes):
         """0..4 codes of the current mini-batch, kept resident for position jobs (wm_reads_upload)"""
         codes = np.ascontiguousarray(codes, np.uint8)
