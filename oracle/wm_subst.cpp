@@ -4,11 +4,12 @@
 // ALL of its objects, in which the C symbols
 //     mm_sketch        src/mmpriv.h:61      ksw_extd2_sse    src/ksw2.h:60-61
 //     mm_chain_dp      src/mmpriv.h:73      ksw_extz2_sse    src/ksw2.h:54-55
+//                                           ksw_exts2_sse    src/ksw2.h:63-64
 // have been renamed to ref_<name> (objcopy --redefine-sym on copies of sketch.o / chain.o / ksw2_dispatch.o) and are DEFINED HERE with the
 // exact signatures, ownership and kalloc conventions of the reference, each as a one-job call of the batched device operation behind it
-// (wm_sketch_batch, wm_chain_batch, wm_ksw_batch). So mm_map_frag, mm_align_skeleton, the index builder … all run unchanged on top of the
+// (wm_sketch_batch, wm_chain_batch, wm_ksw_batch, wm_ksw_exts2_batch). So mm_map_frag, mm_align_skeleton, the index builder … all run unchanged on top of the
 // device kernels — slowly (one launch per call), which is the point of the batched entry points, but it proves the symbols are drop-ins.
-// Cases the kernels do not cover (HPC sketching, cDNA / multi-segment chaining, score-only or splice DP) go to the renamed originals.
+// Cases the kernels do not cover (HPC sketching, cDNA / multi-segment chaining, score-only DP) go to the renamed originals.
 // WM_SUBST=off in the environment routes everything to the originals (A/B inside one binary). tests/test_binding_gpu.py diffs the output.
 #include <stdio.h>
 #include <stdlib.h>
@@ -31,6 +32,8 @@ void ref_ksw_extd2_sse(void *km, int qlen, const uint8_t *query, int tlen, const
                        int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, ksw_extz_t *ez);
 void ref_ksw_extz2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                        int8_t q, int8_t e, int w, int zdrop, int end_bonus, int flag, ksw_extz_t *ez);
+void ref_ksw_exts2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                       int8_t q, int8_t e, int8_t q2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc, ksw_extz_t *ez);
 }
 
 namespace {
@@ -126,6 +129,36 @@ extern "C" void ksw_extz2_sse(void *km, int qlen, const uint8_t *query, int tlen
 {   // single-affine = the dual-affine recursion with equal pieces (pinned against ksw_extz2_sse in tests/test_oracle_vs_ref.py)
 	if (off()) { ref_ksw_extz2_sse(km, qlen, query, tlen, target, m, mat, q, e, w, zdrop, end_bonus, flag, ez); return; }
 	ksw_extd2_sse(km, qlen, query, tlen, target, m, mat, q, e, q, e, w, zdrop, end_bonus, flag, ez);
+}
+
+extern "C" void ksw_exts2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                              int8_t q, int8_t e, int8_t q2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc, ksw_extz_t *ez)
+{   // the splice-aware extension (selected at src/align.c:326-327): one job of wm_ksw_exts2_batch
+	if (off() || m != 5 || qlen <= 0 || tlen <= 0 || q2 <= q + e || -(int)mat[1] > 2 * (q + e) || (flag & (KSW_EZ_SCORE_ONLY | KSW_EZ_GENERIC_SC | KSW_EZ_APPROX_DROP))) {
+		ref_ksw_exts2_sse(km, qlen, query, tlen, target, m, mat, q, e, q2, noncan, zdrop, junc_bonus, flag, junc, ez);
+		return;
+	}
+	const wm_ksw_score_t sc = { mat[0], mat[1], mat[24], q, e, q2, 0 };
+	const wm_ksw_job_t jb = { 0, (uint32_t)qlen, qlen, tlen, -1, zdrop, 0, flag };
+	std::vector<uint8_t> seqs((size_t)qlen + tlen), jn;
+	memcpy(seqs.data(), query, qlen); memcpy(seqs.data() + qlen, target, tlen);
+	if (junc) { jn.assign((size_t)qlen + tlen, 0); memcpy(jn.data() + qlen, junc, tlen); }
+	std::vector<uint32_t> cig((size_t)qlen + tlen + 4);
+	wm_ksw_result_t r;
+	size_t used = 0;
+	{
+		std::lock_guard<std::mutex> lk(g_mu);
+		if (wm_ksw_exts2_batch(ctx(), &sc, noncan, junc_bonus, 1, &jb, seqs.data(), seqs.size(), junc ? jn.data() : 0, &r, cig.data(), cig.size(), &used)) die("ksw_exts2_sse");
+	}
+	ksw_reset_extz(ez);
+	ez->max = r.max; ez->zdropped = r.zdropped; ez->max_q = r.max_q; ez->max_t = r.max_t; ez->mqe = r.mqe; ez->mqe_t = r.mqe_t;
+	ez->mte = r.mte; ez->mte_q = r.mte_q; ez->score = r.score; ez->reach_end = r.reach_end;
+	if (r.n_cigar > ez->m_cigar) {
+		ez->m_cigar = r.n_cigar + (r.n_cigar >> 1) + 4;
+		ez->cigar = (uint32_t*)krealloc(km, ez->cigar, (size_t)ez->m_cigar << 2);
+	}
+	if (r.n_cigar) memcpy(ez->cigar, cig.data() + r.cig_off, (size_t)r.n_cigar * 4);
+	ez->n_cigar = r.n_cigar;
 }
 
 __attribute__((destructor)) static void wm_subst_fini() { if (g_ctx) wm_ctx_destroy(g_ctx); }

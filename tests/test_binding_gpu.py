@@ -149,3 +149,25 @@ def test_link_level_substitutes_of_the_hot_functions():
     d = parity.diff_texts(want, got, sam=False)
     assert d["reads"] == 8 and d["hits"] >= 8 and d["mismatches"] == 0, d
     assert parity.diff_texts(want, _run(SUBST_BIN, args, env={"WM_SUBST": "off"}), sam=False)["mismatches"] == 0
+
+
+@need_ref
+@pytest.mark.skipif(not os.path.exists(SUBST_BIN), reason="oracle/_ref/winnowmap_subst not built")
+@pytest.mark.skipif(os.environ.get("WM_TEST_EXTS2", "0") != "1", reason="the splice kernel is opt-in until it has run on a GPU: set WM_TEST_EXTS2=1")
+def test_splice_mode_through_the_substituted_ksw_exts2():
+    """`-ax splice` of the reference with ksw_exts2_sse (src/ksw2.h:63-64, called at src/align.c:326-327) replaced by the one-job form of
+    wm_ksw_exts2_batch (oracle/wm_subst.cpp): spliced reads with canonical and non-canonical introns, both strands; the records — CIGARs with
+    N operations, ts:A tags — must be the reference's. (Sketching runs on the device as well; cDNA chaining stays with the reference.)"""
+    tmp = tempfile.mkdtemp()
+    ref = synth.make_reference(2, 300000, 51, repeat_frac=0.0)
+    reads = synth.make_transcripts(ref, 60, 7)
+    fa = os.path.join(tmp, "ref.fa")
+    synth.write_fasta(fa, ref, prefix="chr")
+    rq = os.path.join(tmp, "reads.fa")
+    _write_reads(rq, reads, prefix="t")
+    args = ["-t", "2", "-cx", "splice", fa, rq]
+    want = _run(REF_BIN, args)
+    got = _run(SUBST_BIN, args)
+    d = parity.diff_texts(want, got, sam=False)
+    assert d["reads"] == 60 and d["hits"] >= 55 and d["mismatches"] == 0, d
+    assert sum(1 for ln in got.decode().splitlines() if "N" in ln.split("cg:Z:")[-1].split("\t")[0]) >= 50

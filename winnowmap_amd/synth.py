@@ -152,3 +152,26 @@ def write_kmer_list(path, kmers, counts, k):
     with open(path, "w") as f:
         for x, c in zip(kmers, counts):
             f.write("%s\t%d\n" % (kmer_to_str(x, k), int(c)))
+
+
+def make_transcripts(ref, n, seed, sub=0.02, ins=0.01, dele=0.01, canonical=0.8):
+    """n spliced reads: 2..5 exons of 80..300 bases separated by introns of 150..3000 bases, taken from `ref` (list of code arrays, MODIFIED in
+    place: GT..AG is planted at a fraction `canonical` of the introns), every second read from the reverse strand. For splice-mode tests."""
+    rng = np.random.default_rng(seed)
+    reads = []
+    for g in range(n):
+        seq = ref[int(rng.integers(0, len(ref)))]
+        pos = int(rng.integers(1000, len(seq) - 30000))
+        parts = []
+        for _ in range(int(rng.integers(2, 6))):
+            el = int(rng.integers(80, 300))
+            parts.append(seq[pos:pos + el].copy())
+            pos += el
+            il = int(rng.integers(150, 3000))
+            if rng.random() < canonical:
+                seq[pos:pos + 2] = (2, 3)
+                seq[pos + il - 2:pos + il] = (0, 2)
+            pos += il
+        tr = mutate_codes(np.concatenate(parts), rng, sub, ins, dele)
+        reads.append(revcomp_codes(tr) if g % 2 else tr)
+    return reads
