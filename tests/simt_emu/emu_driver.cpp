@@ -60,6 +60,7 @@ template <int BP, int NWV> static void run_pmulti(int variant, const wm_ksw_scor
 	pthread_barrier_destroy(&bar);
 }
 
+static int g_coop_backtrack = 0;
 extern "C" {
 
 // force_klass < 0: choose like the product host; otherwise use that class (to exercise CLIP/HASN variants on any input)
@@ -160,7 +161,11 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 	}
 	int n = 0;
 	if (res.bt_i >= 0) {
-		n = wmk::ksw_backtrack_thread(jb, tb.data(), res.bt_i, res.bt_j, cigar_out, cigar_cap);
+		if (g_coop_backtrack) {
+			std::vector<uint8_t> tile((size_t)KSW_BT_ROWS * 64, 0xAB);
+			simt::exec_mask() = ~0ull;
+			n = wmk::ksw_backtrack_wave(jb, tb.data(), res.bt_i, res.bt_j, cigar_out, cigar_cap, tile.data());
+		} else n = wmk::ksw_backtrack_thread(jb, tb.data(), res.bt_i, res.bt_j, cigar_out, cigar_cap);
 		if (n < 0) return -3;
 		if (!(flag & KSW_F_REV_CIGAR)) std::reverse(cigar_out, cigar_out + n);
 	}
@@ -168,6 +173,7 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 	ez_out[5] = res.mqe_t; ez_out[6] = res.mte; ez_out[7] = res.mte_q; ez_out[8] = res.score; ez_out[9] = res.reach_end;
 	return n;
 }
+void emu_set_coop_backtrack(int on) { g_coop_backtrack = on; }       // 1: ksw_backtrack_wave instead of ksw_backtrack_thread
 
 
 // ksw_exts2_sse through the emulated splice kernel + its backtrack; junc may be null

@@ -287,3 +287,30 @@ def test_exts2_splice_kernel_emulated_matches_oracle(emu):
         assert np.array_equal(cig[:n], o["cigar"]), (hex(c["flag"]), W.cigar_str(cig[:n]), W.cigar_str(o["cigar"]))
         n_intron += any((int(x) & 0xf) == 3 for x in o["cigar"])
     assert n_intron > 60, n_intron
+
+
+def test_wave_cooperative_backtrack_equals_the_single_thread_walk(emu):
+    """ksw_backtrack_wave (one wavefront per alignment, traceback tiles through LDS) must produce the CIGAR of ksw_backtrack_thread, i.e. the
+    oracle's: every flag / band / scoring combination, paths that leave the hull (forced states), re-fetches after 32 rows / 64 lanes."""
+    from winnowmap_amd import synth
+    emu.emu_set_coop_backtrack(1)
+    try:
+        cases = kswcases.make_cases(31, 120, max_len=700)
+        rng = np.random.default_rng(4)
+        for it in range(6):                     # long alignments with long gaps: many tiles, horizontal and vertical runs
+            tl = int(rng.integers(1200, 2600))
+            t = rng.integers(0, 4, tl).astype(np.uint8)
+            q = synth.mutate_codes(t, rng, 0.05, 0.04, 0.05)
+            if it % 2:
+                q = np.concatenate([q[:400], q[400 + 150 * it:]])        # a long deletion
+            else:
+                q = np.concatenate([q[:500], rng.integers(0, 4, 90 * (it + 1)).astype(np.uint8), q[500:]])   # a long insertion
+            cases.append(dict(q=q, t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=[3001, 900, -1][it % 3], zdrop=[400, -1, 200][it % 3], end_bonus=-1, flag=[0x08, 0x40, 0x82, 0x00, 0x48, 0x88][it]))
+        for c in cases:
+            o = W.o_ksw_extd2(c["q"], c["t"], mat=W.simple_mat(c["a"], c["b"], 1), q=c["q_"], e=c["e"], q2=c["q2"], e2=c["e2"],
+                              w=c["w"], zdrop=c["zdrop"], end_bonus=c["end_bonus"], flag=c["flag"])
+            n, ez, cig, klass = emu_ksw(emu, c, -1)
+            assert n >= 0
+            assert np.array_equal(cig, o["cigar"]), (klass, len(c["q"]), len(c["t"]), hex(c["flag"]), c["w"], W.cigar_str(cig)[:80], W.cigar_str(o["cigar"])[:80])
+    finally:
+        emu.emu_set_coop_backtrack(0)

@@ -120,7 +120,10 @@ def test_wide_band_jobs_block_and_generic_kernels(ctx):
     assert not bad, bad[:3]
 
 
-@pytest.mark.skipif(os.environ.get("WM_TEST_PMULTI", "0") != "1", reason="ksw_dp_pmulti is opt-in until it has run on a GPU: set WM_TEST_PMULTI=1")
+OPTIN = os.environ.get("WM_TEST_OPTIN", "0") == "1"      # kernels that are bit-exact on the emulator but have not run on a GPU yet (tools/r03_first_run.sh)
+
+
+@pytest.mark.skipif(not (OPTIN or os.environ.get("WM_TEST_PMULTI", "0") == "1"), reason="ksw_dp_pmulti is opt-in until it has run on a GPU: set WM_TEST_OPTIN=1")
 def test_wide_band_jobs_packed_multiwave_kernel(ctx, monkeypatch):
     """WM_KSW_PMULTI=1 routes the BLOCK / BLOCK2 classes to ksw_pmulti_kernel<4,8> / <8,8> (ksw_packed_multi_kernel.h): same cases, same bar."""
     monkeypatch.setenv("WM_KSW_PMULTI", "1")
@@ -141,6 +144,16 @@ def test_wide_band_jobs_packed_multiwave_kernel(ctx, monkeypatch):
                           end_bonus=[-1, 10][it % 2], flag=kswcases.FLAGS[it % 6]))
     bad = _run_group(ctx, cases)
     assert not bad, bad[:3]
+
+
+@pytest.mark.skipif(not OPTIN, reason="ksw_backtrack_wave is opt-in until it has run on a GPU: set WM_TEST_OPTIN=1")
+def test_wave_cooperative_backtrack(ctx, monkeypatch):
+    """WM_KSW_COOP_BT=1: one wavefront per alignment walks the traceback through LDS tiles (ksw_backtrack_wave); same cases, same bar."""
+    monkeypatch.setenv("WM_KSW_COOP_BT", "1")
+    test_random_cases_all_flags(ctx, 0)
+    test_band_clipped_and_stale_lanes(ctx)
+    test_wide_band_jobs_block_and_generic_kernels(ctx)
+    test_degenerate_and_tiny(ctx)
 
 
 def test_position_jobs_equal_byte_jobs(tmp_path):

@@ -8,7 +8,7 @@ import wmtest as W
 import kswcases
 from winnowmap_amd import gpu
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("WM_TEST_EXTS2", "0") != "1", reason="opt-in until run on a GPU: set WM_TEST_EXTS2=1")]
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("WM_TEST_EXTS2", os.environ.get("WM_TEST_OPTIN", "0")) != "1", reason="opt-in until run on a GPU: set WM_TEST_OPTIN=1")]
 
 
 @pytest.mark.parametrize("with_junc", [False, True])

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The first GPU call of round 3 — validates and times what round 2 prepared after its GPU minutes were spent:
-#   gpurun --timeout 3000 -- 'bash tools/r03_first_run.sh'
+#   gpurun --timeout 3300 -- 'bash tools/r03_first_run.sh'
 # 1) the whole GPU suite incl. the opt-in tests (packed multi-wave kernel, splice kernel);
 # 2) bench.py (config 2) with the library as built: the restructured single-wave kernels + -disable-promote-alloca-to-vector;
 # 3) the same with WM_KSW_PMULTI=1 (BLOCK / BLOCK2 classes on ksw_dp_pmulti) and =2 (the 16-pair classes as well);
@@ -18,12 +18,13 @@ run_bench() { # tag, env...
   ( env "$@" python bench.py --steps $STEPS --warmup 1 > $OUT/bench_$tag.json 2> $OUT/bench_$tag.log ); echo "[$tag] rc=$? $(cut -c1-400 $OUT/bench_$tag.json)"
 }
 echo "== 1. GPU tests incl. opt-in =="
-WM_TEST_PMULTI=1 WM_TEST_EXTS2=1 timeout 1500 python -m pytest tests -m gpu -q -x > $OUT/gputest.txt 2>&1; echo "rc=$?"; tail -5 $OUT/gputest.txt
+WM_TEST_OPTIN=1 timeout 1500 python -m pytest tests -m gpu -q -x > $OUT/gputest.txt 2>&1; echo "rc=$?"; tail -5 $OUT/gputest.txt
 echo "== 2. bench, library as built =="
 run_bench default WM_DUMMY=1
 echo "== 3. packed multi-wave kernel =="
 run_bench pmulti1 WM_KSW_PMULTI=1 WM_BENCH_CPU_SAMPLE=0
 run_bench pmulti2 WM_KSW_PMULTI=2 WM_BENCH_CPU_SAMPLE=0
+run_bench coopbt WM_KSW_COOP_BT=1 WM_BENCH_CPU_SAMPLE=0
 echo "== 5. ksw probe (default build) =="
 timeout 600 python tools/ksw_probe.py > $OUT/ksw_probe_default.txt 2>&1; tail -8 $OUT/ksw_probe_default.txt
 echo "== 4. WM_KSW_ROR build =="

@@ -931,4 +931,79 @@ WM_DEV int ksw_backtrack_thread(const wm_ksw_djob_t jb, const uint8_t *__restric
 	return n <= cap ? n : -n;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The same backtrack by one WAVEFRONT per alignment. The walk itself is sequential, but a thread that follows it alone pays one
+// dependent global load per step (~0.6 us: 4 ms per batch, tens of ms for the longest alignments). Here the 64 lanes first fetch a tile
+// of the traceback matrix — the next KSW_BT_ROWS anti-diagonals, 64 target lanes ending at the current one — into LDS with independent
+// loads, then every lane replays the same scalar walk on LDS bytes until it leaves the tile (at least KSW_BT_ROWS / 2 steps later).
+// `tile` = KSW_BT_ROWS * 64 bytes of LDS per wavefront. Same op stream as ksw_backtrack_thread. Opt-in (WM_KSW_COOP_BT=1) until it has
+// been run and timed on a GPU; bit-exact on the wavefront emulator.
+// ------------------------------------------------------------------------------------------------------
+#define KSW_BT_ROWS 32
+WM_DEV int ksw_backtrack_wave(const wm_ksw_djob_t jb, const uint8_t *__restrict__ tb_arena, int i0, int j0,
+                              uint32_t *__restrict__ cig, int cap, uint8_t *tile)
+{
+	const uint8_t *p = tb_arena + jb.tb_off;
+	const int qlen = jb.qlen, tlen = jb.tlen, n_col = jb.n_col;
+	const int w = jb.w < 0 ? (tlen > qlen ? tlen : qlen) : jb.w;
+	const bool right = (jb.flag & KSW_F_RIGHT) != 0;
+	const V<int> ln = lane();
+	int n = 0, i = i0, j = j0, state = 0;
+	uint32_t cur_op = 0xf, cur_len = 0;
+	auto hull = [&](int r, int &off, int &off_end) {
+		int st0 = 0, en0 = tlen - 1;
+		if (st0 < r - qlen + 1) st0 = r - qlen + 1;
+		if (en0 > r) en0 = r;
+		if (st0 < (r - w + 1) >> 1) st0 = (r - w + 1) >> 1;
+		if (en0 > (r + w) >> 1) en0 = (r + w) >> 1;
+		off = st0 / 16 * 16; off_end = (en0 + 16) / 16 * 16 - 1;
+	};
+#define WM_PUSH(op_, len_) do { if ((uint32_t)(op_) == cur_op) cur_len += (len_); else { if (cur_len) { if (n < cap) { WM_IF(ln == 0) gst(cig, (long long)n, (uint32_t)(cur_len << 4 | cur_op)); WM_END } ++n; } cur_op = (op_); cur_len = (len_); } } while (0)
+	while (i >= 0 && j >= 0) {
+		// ---- fetch the tile: rows r0, r0-1, .. r0-KSW_BT_ROWS+1; lane l holds target lane c = i - 63 + l ----
+		const int r0 = i + j, c_lo = i - 63;
+		const V<int> c = ln + c_lo;
+#pragma unroll 4
+		for (int k = 0; k < KSW_BT_ROWS; ++k) {
+			const int rr = r0 - k;
+			V<int> b = 0;
+			if (rr >= 0) {
+				int off, off_end;
+				hull(rr, off, off_end);
+				WM_IF(c >= off && c <= off_end && c >= 0) b = cast<int>(gld(p + (size_t)rr * n_col, c - off)); WM_END
+			}
+			gst(tile, ln + 64 * k, cast<uint8_t>(b));
+		}
+		lds_sync();
+		// ---- walk inside the tile ----
+		while (i >= 0 && j >= 0) {
+			const int r = i + j, k = r0 - r, col = i - c_lo;
+			if (k >= KSW_BT_ROWS || col < 0) break;
+			int off, off_end, force = -1, d, ext;
+			hull(r, off, off_end);
+			if (i < off) force = 2;
+			if (i > off_end) force = 1;
+			if (force < 0) {
+				const int raw = (int)gld(tile, (long long)(64 * k + col));
+				const int code = raw >> 4;
+				d = right ? code : 4 - code;
+				ext = (raw >> 3 & 1) | (raw >> 2 & 1) << 1 | (raw >> 1 & 1) << 2 | (raw & 1) << 3;
+			} else d = 0, ext = 0;
+			if (state == 0) state = d;
+			else if (!(ext >> (state - 1) & 1)) state = 0;
+			if (state == 0) state = d;
+			if (force >= 0) state = force;
+			if (state == 0) { WM_PUSH(0u, 1u); --i; --j; }
+			else if (state == 1 || state == 3) { WM_PUSH(2u, 1u); --i; }
+			else { WM_PUSH(1u, 1u); --j; }
+		}
+		lds_sync();
+	}
+	if (i >= 0) WM_PUSH(2u, (uint32_t)(i + 1));
+	if (j >= 0) WM_PUSH(1u, (uint32_t)(j + 1));
+	if (cur_len) { if (n < cap) { WM_IF(ln == 0) gst(cig, (long long)n, (uint32_t)(cur_len << 4 | cur_op)); WM_END } ++n; }
+#undef WM_PUSH
+	return n <= cap ? n : -n;
+}
+
 } // namespace wmk

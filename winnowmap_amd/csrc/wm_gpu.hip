@@ -190,6 +190,21 @@ __global__ __launch_bounds__(64) void ksw_backtrack_kernel(int n, const wm_ksw_d
 	res[j].n_cigar = nc;
 }
 
+// the same walk by one wavefront per alignment, traceback tiles through LDS (ksw_backtrack_wave); opt-in: WM_KSW_COOP_BT=1
+__global__ __launch_bounds__(64) void ksw_backtrack_coop_kernel(int n, const wm_ksw_djob_t *__restrict__ jobs, const uint8_t *__restrict__ tb,
+                                                                 wm_ksw_dres_t *__restrict__ res, uint32_t *__restrict__ cig_scratch, int *__restrict__ err)
+{
+	__shared__ uint8_t tile[KSW_BT_ROWS * 64];
+	const int j = blockIdx.x;
+	const int bt_i = res[j].bt_i, bt_j = res[j].bt_j;
+	int nc = 0;
+	if (bt_i >= 0) {
+		nc = wmk::ksw_backtrack_wave(jobs[j], tb, bt_i, bt_j, cig_scratch + jobs[j].cig_off, jobs[j].cig_cap, tile);
+		if (nc < 0) { if (threadIdx.x == 0) atomicExch(err, 1); nc = 0; }
+	}
+	if (threadIdx.x == 0) res[j].n_cigar = nc;
+}
+
 // exclusive prefix sum of n_cigar (single block; n is at most a few hundred thousand)
 __global__ __launch_bounds__(1024) void ksw_scan_kernel(int n, const wm_ksw_dres_t *__restrict__ res, uint32_t *__restrict__ off, uint32_t *__restrict__ total)
 {
@@ -721,7 +736,10 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	for (int si = 0; si < 4; ++si)
 		if (used_mask >> si & 1) { HIPCHK(hipEventRecord(c->kev[si], side[si])); HIPCHK(hipStreamWaitEvent(c->stream, c->kev[si], 0)); }
 	HIPCHK(hipEventRecord(c->ev[1], c->stream));
-	hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, b->d_jobs, b->d_tb, b->d_res, b->d_cig, b->d_err);
+	if (getenv("WM_KSW_COOP_BT") && atoi(getenv("WM_KSW_COOP_BT")) > 0)
+		hipLaunchKernelGGL(ksw_backtrack_coop_kernel, dim3(n), dim3(64), 0, c->stream, n, b->d_jobs, b->d_tb, b->d_res, b->d_cig, b->d_err);
+	else
+		hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, b->d_jobs, b->d_tb, b->d_res, b->d_cig, b->d_err);
 	hipLaunchKernelGGL(ksw_scan_kernel, dim3(1), dim3(1024), 0, c->stream, n, b->d_res, b->d_off, b->d_total);
 	hipLaunchKernelGGL(ksw_gather_kernel, dim3(n), dim3(64), 0, c->stream, b->d_jobs, b->d_res, b->d_off, b->d_cig, b->d_pool, (uint32_t)b->pool_cap);
 	HIPCHK(hipEventRecord(c->ev[2], c->stream));
