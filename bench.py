@@ -205,13 +205,16 @@ def make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1):
         "config": {"workload": "BASELINE config %d: %d x %d bp %s reads per step per GPU vs %.0f Mb synthetic reference (10%% repeats), -W repetitive_k15.txt -x %s, CIGAR on"
                                % (args.config, args.reads_per_step, args.read_len, CONFIGS[args.config]["label"], args.ref_mb, CONFIGS[args.config]["preset"]),
                    "reads_per_step_per_gpu": args.reads_per_step, "read_len": args.read_len, "ref_mb": args.ref_mb, "host_threads": n_threads,
-                   "reads_per_s": total_bases / args.read_len / elapsed, "hits": hits, "parallelism": "reads sharded over %d rank(s), index broadcast" % world},
+                   "reads_per_s": total_bases / args.read_len / elapsed, "hits": hits, "parallelism": "reads sharded over %d rank(s), index broadcast" % world,
+                   # which kernel variants ran (tools/r03_first_run.sh A/Bs them): build-time defines and run-time switches
+                   "variants": {"kernel_defines": os.environ.get("WM_KERNEL_DEFINES", ""),
+                                **{k: os.environ[k] for k in ("WM_KSW_PMULTI", "WM_KSW_COOP_BT", "WM_SEED_DEVICE_SORT", "WM_CONTEXTS") if k in os.environ}}},
         "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
                      "traffic_source": (pmc or {}).get("source") if traffic is not None else None, "classes": classes,
                      "kernel": kname, "algorithmic_bytes": "1 B traceback per DP cell (sequence bytes are < 1 %)",
                      "launches": d_launch, "avg_launch_ms": d_ms / max(1, d_launch), "cells_per_launch": d_cells / max(1, d_launch),
                      "gcups_dominant": d_cells / max(d_ms, 1e-9) / 1e6, "gcups_all_ksw_classes": all_cells / max(all_ms, 1e-9) / 1e6,
-                     "note": "int8 DP is VALU-issue bound (about 33 lane-ops per cell), not HBM bound; launch durations include overlap with other streams"},
+                     "note": "int8 DP is VALU-issue bound (61 packed instructions per 128 cells in the register classes), not HBM bound; launch durations include overlap with other streams"},
     }
 
 
