@@ -128,6 +128,15 @@ struct OracleOps : DeviceOps {
 			std::vector<uint8_t> q(r->ql > 0 ? r->ql : 0), t(r->tl > 0 ? r->tl : 0);
 			r->copy_query(q.data()); r->copy_target(t.data());
 			check_positions(*r, q, t);
+			if (const char *dp = getenv("WM_DUMP_KSW")) {        // real alignment jobs of a mapping run, for replays through the kernel emulator
+				static std::mutex mu;
+				std::lock_guard<std::mutex> lk(mu);
+				if (FILE *f = fopen(dp, "ab")) {
+					const int32_t hdr[10] = { (int32_t)q.size(), (int32_t)t.size(), r->w, r->zdrop, r->end_bonus, r->flag, sc.match, sc.mismatch, sc.q | sc.e << 8 | sc.q2 << 16 | sc.e2 << 24, sc.sc_ambi };
+					fwrite(hdr, 4, 10, f); fwrite(q.data(), 1, q.size(), f); fwrite(t.data(), 1, t.size(), f);
+					fclose(f);
+				}
+			}
 			std::vector<uint32_t> cig(q.size() + t.size() + 4);
 			wmo_ksw_extd2((int)q.size(), q.data(), (int)t.size(), t.data(), 5, mat, sc.q, sc.e, sc.q2, sc.e2, r->w, r->zdrop, r->end_bonus, r->flag, &ez, cig.data(), 0);
 			r->ez.max = ez.max; r->ez.zdropped = ez.zdropped; r->ez.max_q = ez.max_q; r->ez.max_t = ez.max_t; r->ez.mqe = ez.mqe; r->ez.mqe_t = ez.mqe_t;
