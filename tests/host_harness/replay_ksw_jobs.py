@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import wmtest as W
 from winnowmap_amd import build
-path = sys.argv[1]; variants = sys.argv[2].split(","); limit = int(sys.argv[3]) if len(sys.argv) > 3 else 10**9
+path = sys.argv[1]; variants = sys.argv[2].split(","); limit = int(sys.argv[3]) if len(sys.argv) > 3 else 10**9; force = int(sys.argv[4]) if len(sys.argv) > 4 else -1      # force: a class code of emu_ksw_extd2 (e.g. 223 = ksw_dp_pmulti<4,4>, CLIP + HASN)
 libs = {}
 for v in variants:
     E = C.CDLL(build.build_emu(() if v == "default" else ("WM_KSW_ROR=1",)))
@@ -28,8 +28,9 @@ while pos < len(data) and n < limit:
     o = W.o_ksw_extd2(q, t, mat=mat, q=qq, e=e, q2=q2, e2=e2, w=w, zdrop=zdrop, end_bonus=end_bonus, flag=flag)
     for v, E in libs.items():
         ez = np.zeros(10, np.int32); cig = np.zeros(ql + tl + 4, np.uint32); k = C.c_int()
-        m = E.emu_ksw_extd2(ql, q, tl, t, mat, qq, e, q2, e2, w, zdrop, end_bonus, flag, -1, ez, cig, len(cig), C.byref(k))
+        m = E.emu_ksw_extd2(ql, q, tl, t, mat, qq, e, q2, e2, w, zdrop, end_bonus, flag, force, ez, cig, len(cig), C.byref(k))
         klass[k.value] += 1
+        if m == -1 and force >= 0: continue
         if m < 0 or [int(x) for x in ez] != [o[kk] for kk in W.EZ_FIELDS] or not np.array_equal(cig[:max(m,0)], o["cigar"]):
             bad += 1; print("MISMATCH", v, n, ql, tl, w, zdrop, end_bonus, hex(flag), k.value, flush=True)
     n += 1; cells += ql * tl
