@@ -136,6 +136,19 @@ extern "C" void ksw_exts2_sse(void *km, int qlen, const uint8_t *query, int tlen
 {   // the splice-aware extension (selected at src/align.c:326-327): one job of wm_ksw_exts2_batch
 	if (off() || m != 5 || qlen <= 0 || tlen <= 0 || q2 <= q + e || -(int)mat[1] > 2 * (q + e) || (flag & (KSW_EZ_SCORE_ONLY | KSW_EZ_GENERIC_SC | KSW_EZ_APPROX_DROP))) {
 		ref_ksw_exts2_sse(km, qlen, query, tlen, target, m, mat, q, e, q2, noncan, zdrop, junc_bonus, flag, junc, ez);
+		if (const char *dp = getenv("WM_DUMP_EXTS2")) {     // tests: the reference's own splice-mode jobs and results, for replays through the oracle / the kernel emulator
+			std::lock_guard<std::mutex> lk(g_mu);
+			if (FILE *f = fopen(dp, "ab")) {
+				const int32_t hdr[24] = { qlen, tlen, m, mat[0], mat[1], mat[24], q, e, q2, noncan, zdrop, junc_bonus, flag, junc ? 1 : 0,
+				                          ez->max, ez->zdropped, ez->max_q, ez->max_t, ez->mqe, ez->mqe_t, ez->mte, ez->mte_q, ez->score, ez->n_cigar };
+				fwrite(hdr, 4, 24, f);
+				if (qlen > 0) fwrite(query, 1, qlen, f);
+				if (tlen > 0) fwrite(target, 1, tlen, f);
+				if (junc && tlen > 0) fwrite(junc, 1, tlen, f);
+				if (ez->n_cigar > 0) fwrite(ez->cigar, 4, ez->n_cigar, f);
+				fclose(f);
+			}
+		}
 		return;
 	}
 	const wm_ksw_score_t sc = { mat[0], mat[1], mat[24], q, e, q2, 0 };
