@@ -193,6 +193,24 @@ void h_radix_sort_128x_parallel(uint64_t *x, uint64_t *y, int64_t n, int n_threa
 	radix_sort_128x_parallel(a.data(), a.data() + n, n_threads);
 	for (int64_t i = 0; i < n; ++i) x[i] = a[i].x, y[i] = a[i].y;
 }
+// parallel_tasks (wm_core.h): every index exactly once, on the plain path and through a ParHook with the coarse-task chunk hint
+int h_parallel_tasks_selftest(int n_threads, int n)
+{
+	std::vector<std::atomic<int>> hit(n);
+	for (auto &h : hit) h.store(0);
+	parallel_tasks(n_threads, (size_t)n, [&](size_t i) { hit[i].fetch_add(1); });
+	for (auto &h : hit) if (h.load() != 1) return -1;
+	struct Hook : ParHook {
+		size_t chunk_seen = 0;
+		void run(size_t m, const std::function<void(size_t)> &fn) override { chunk_seen = tl_par_chunk(); tl_par_chunk() = 0; for (size_t i = 0; i < m; ++i) fn(i); }
+	} hook;
+	tl_par_hook() = &hook;
+	parallel_tasks(n_threads, (size_t)n, [&](size_t i) { hit[i].fetch_add(1); });
+	tl_par_hook() = 0;
+	for (auto &h : hit) if (h.load() != 2) return -2;
+	if (n >= 2 && hook.chunk_seen != 1) return -3;          // coarse tasks ask the hook for chunks of one
+	return tl_par_chunk() == 0 ? 0 : -4;
+}
 int h_ll_i16(int qlen, const uint8_t *q, int tlen, const uint8_t *t, const int8_t *mat, int gapo, int gape, int *qe, int *te) { return ll_i16(qlen, q, tlen, t, mat, gapo, gape, qe, te); }
 
 int64_t h_chain_extract(int64_t n, const uint64_t *ax, const uint64_t *ay, const int32_t *f, const int32_t *p, const int32_t *v, int min_cnt, int min_sc,
