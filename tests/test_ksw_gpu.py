@@ -59,6 +59,21 @@ def test_band_clipped_and_stale_lanes(ctx):
     assert not bad, bad[:3]
 
 
+def test_band_sitting_on_the_last_target_lane(ctx):
+    # target lengths of 16k + 1 with narrow bands: en0 == st == tlen - 1 on rows that do not re-base, so lane en0 takes H from the lane below the
+    # window as the LAST re-base left it (a bug of the first multi-wave packed kernel, found on the emulator)
+    from winnowmap_amd import synth
+    rng = np.random.default_rng(5)
+    cases = []
+    for it, (ql, tl) in enumerate(((214, 209), (489, 193), (150, 129), (333, 321), (90, 65), (700, 641), (1500, 1297), (260, 257))):
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        q = np.concatenate([synth.mutate_codes(t, rng, 0.03, 0.02, 0.02), rng.integers(0, 4, ql).astype(np.uint8)])[:ql]
+        cases.append(dict(q=q, t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=[5, 5, 3, 9, 5, 17, 33, 2][it], zdrop=[200, 400, -1, 100, 50, 400, 200, -1][it],
+                          end_bonus=[0, -1, 10][it % 3], flag=[0x80, 0, 0x40, 0x80, 0, 0x42, 0x00, 0xC0][it]))
+    bad = _run_group(ctx, cases)
+    assert not bad, bad[:3]
+
+
 def test_degenerate_and_tiny(ctx):
     sc = gpu.KswScore(2, -4, -1, 4, 2, 24, 1)
     one = np.array([2], np.uint8)
