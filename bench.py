@@ -150,7 +150,7 @@ def cpu_reference_baseline(fa, kf, names, seqs, preset, tmp, n_cores):
                       "mapping phase %.2f s = best of the -t sweep (index build %.1f s excluded)" % (len(seqs), bases / 1e9, t_best, preset, t_map, t_idx)}, outp
 
 
-KSW_WIDE_CLASSES = {24: "ksw_multi_kernel<8>", 25: "ksw_multi_kernel<16>", 26: "ksw_block_kernel<7, 0>", 27: "ksw_generic_kernel"}
+KSW_WIDE_CLASSES = {24: "ksw_pmulti_kernel<4, 8>", 25: "ksw_pmulti_kernel<8, 8>", 26: "ksw_block_kernel<7, 0>", 27: "ksw_generic_kernel"}
 
 
 def ksw_class_name(k):

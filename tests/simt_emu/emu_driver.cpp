@@ -123,12 +123,15 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 		else if (emu_pmulti == 4) run_pmulti<8, 4>(variant, sc, jb, seqs.data(), tb.data(), &res);
 		else if (emu_pmulti == 5) run_pmulti<4, 8>(variant, sc, jb, seqs.data(), tb.data(), &res);
 		else run_pmulti<8, 8>(variant, sc, jb, seqs.data(), tb.data(), &res);
+	} else if ((klass == WM_KSW_BLOCK || klass == WM_KSW_BLOCK2) && !emu_blk_lds) {      // the product's kernels for these classes: ksw_dp_pmulti<4,8> / <8,8>, CLIP instantiation
+		const int variant = ((flag & 0x08) ? 0 : 4) | 2 | ((wm_ksw_has_n(query, qlen) | wm_ksw_has_n(target, tlen)) ? 1 : 0);
+		if (klass == WM_KSW_BLOCK) run_pmulti<4, 8>(variant, sc, jb, seqs.data(), tb.data(), &res);
+		else run_pmulti<8, 8>(variant, sc, jb, seqs.data(), tb.data(), &res);
 	} else if (klass == WM_KSW_BLOCK || klass == WM_KSW_BLOCK2 || klass == WM_KSW_BLOCK3) {
 		constexpr int NWV = WM_KSW_BLK_NWV;
 		const int WN = klass == WM_KSW_BLOCK ? WM_KSW_BLK_WN : klass == WM_KSW_BLOCK2 ? WM_KSW_BLK2_WN : (int)wm_ksw_blk3_wn(tlen);
 		std::vector<int> W0(WN, 0x5a5a5a5a), W1(WN, 0x5a5a5a5a), Hm(WN, 0x5a5a5a5a), pub(WM_KSW_BLK_PUB);   // the state starts as garbage
-		std::vector<int> mlds(wmk::ksw_multi_lds<WM_KSW_MULTI_B, WM_KSW_MULTI_NWV>::INTS, 0x5a5a5a5a), mlds2(wmk::ksw_multi_lds<WM_KSW_MULTI_B, 2 * WM_KSW_MULTI_NWV>::INTS, 0x5a5a5a5a);
-		const int nw = klass == WM_KSW_BLOCK3 && emu_blk3_small ? 2 : (klass == WM_KSW_BLOCK && !emu_blk_lds) ? WM_KSW_MULTI_NWV : NWV;
+		const int nw = klass == WM_KSW_BLOCK3 && emu_blk3_small ? 2 : NWV;
 		pthread_barrier_t bar;
 		pthread_barrier_init(&bar, 0, nw);
 		simt::block_barrier() = &bar;
@@ -137,9 +140,7 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 			th.emplace_back([&, w]() {
 				simt::wave_slot() = w; simt::exec_mask() = ~0ull;
 				const uint8_t *q_ = seqs.data() + jb.q_off, *t_ = seqs.data() + jb.t_off;
-				if (klass == WM_KSW_BLOCK && !emu_blk_lds) { if (w < WM_KSW_MULTI_NWV) wmk::ksw_dp_multi<WM_KSW_MULTI_B, WM_KSW_MULTI_NWV, true, true>(sc, jb, q_, t_, tb.data(), mlds.data(), &res); }
-				else if (klass == WM_KSW_BLOCK) wmk::ksw_dp_block<NWV, WM_KSW_BLK_K, false>(sc, jb, q_, t_, tb.data(), W0.data(), W1.data(), Hm.data(), WN, pub.data(), &res);
-				else if (klass == WM_KSW_BLOCK2 && !emu_blk_lds) wmk::ksw_dp_multi<WM_KSW_MULTI_B, 2 * WM_KSW_MULTI_NWV, true, true>(sc, jb, q_, t_, tb.data(), mlds2.data(), &res);
+				if (klass == WM_KSW_BLOCK) wmk::ksw_dp_block<NWV, WM_KSW_BLK_K, false>(sc, jb, q_, t_, tb.data(), W0.data(), W1.data(), Hm.data(), WN, pub.data(), &res);
 				else if (klass == WM_KSW_BLOCK2) wmk::ksw_dp_block<NWV, WM_KSW_BLK2_K, false>(sc, jb, q_, t_, tb.data(), W0.data(), W1.data(), Hm.data(), WN, pub.data(), &res);
 				else if (emu_blk3_small) wmk::ksw_dp_block<2, 1, true>(sc, jb, q_, t_, tb.data(), W0.data(), W1.data(), Hm.data(), WN, pub.data(), &res);
 				else wmk::ksw_dp_block<NWV, WM_KSW_BLK2_K, true>(sc, jb, q_, t_, tb.data(), W0.data(), W1.data(), Hm.data(), WN, pub.data(), &res);

@@ -153,7 +153,6 @@ def test_link_level_substitutes_of_the_hot_functions():
 
 @need_ref
 @pytest.mark.skipif(not os.path.exists(SUBST_BIN), reason="oracle/_ref/winnowmap_subst not built")
-@pytest.mark.skipif(os.environ.get("WM_TEST_EXTS2", os.environ.get("WM_TEST_OPTIN", "0")) != "1", reason="the splice kernel is opt-in until it has run on a GPU: set WM_TEST_OPTIN=1")
 def test_splice_mode_through_the_substituted_ksw_exts2():
     """`-ax splice` of the reference with ksw_exts2_sse (src/ksw2.h:63-64, called at src/align.c:326-327) replaced by the one-job form of
     wm_ksw_exts2_batch (oracle/wm_subst.cpp): spliced reads with canonical and non-canonical introns, both strands; the records — CIGARs with

@@ -135,12 +135,8 @@ def test_wide_band_jobs_block_and_generic_kernels(ctx):
     assert not bad, bad[:3]
 
 
-OPTIN = os.environ.get("WM_TEST_OPTIN", "0") == "1"      # kernels that are bit-exact on the emulator but have not run on a GPU yet (tools/r03_first_run.sh)
-
-
-@pytest.mark.skipif(not (OPTIN or os.environ.get("WM_TEST_PMULTI", "0") == "1"), reason="ksw_dp_pmulti is opt-in until it has run on a GPU: set WM_TEST_OPTIN=1")
 def test_wide_band_jobs_packed_multiwave_kernel(ctx, monkeypatch):
-    """WM_KSW_PMULTI=1 routes the BLOCK / BLOCK2 classes to ksw_pmulti_kernel<4,8> / <8,8> (ksw_packed_multi_kernel.h): same cases, same bar."""
+    """(first run on a GPU: round 3, profiles/r03a_first_run.txt; WM_KSW_PMULTI=2 is the library default since) WM_KSW_PMULTI=1 routes the BLOCK / BLOCK2 classes to ksw_pmulti_kernel<4,8> / <8,8> (ksw_packed_multi_kernel.h): same cases, same bar."""
     monkeypatch.setenv("WM_KSW_PMULTI", "1")
     test_wide_band_jobs_block_and_generic_kernels(ctx)
     # 2: the 16-pair register classes (hulls of 1009..2032 lanes) run on ksw_pmulti_kernel<4,4> as well
@@ -161,7 +157,6 @@ def test_wide_band_jobs_packed_multiwave_kernel(ctx, monkeypatch):
     assert not bad, bad[:3]
 
 
-@pytest.mark.skipif(not OPTIN, reason="ksw_backtrack_wave is opt-in until it has run on a GPU: set WM_TEST_OPTIN=1")
 def test_wave_cooperative_backtrack(ctx, monkeypatch):
     """WM_KSW_COOP_BT=1: one wavefront per alignment walks the traceback through LDS tiles (ksw_backtrack_wave); same cases, same bar."""
     monkeypatch.setenv("WM_KSW_COOP_BT", "1")

@@ -1,6 +1,6 @@
 """GPU parity of the splice-aware extension: wm_ksw_exts2_batch (ksw_exts2_kernel.h through the C-ABI) vs the oracle's restatement of
 ksw_exts2_sse, which tests/test_oracle_vs_ref.py pins to the reference's own function. The kernel is bit-exact on the wavefront emulator
-(tests/test_kernels_emu.py) but has not run on a GPU yet, and the mapper does not use it: the test is opt-in (WM_TEST_EXTS2=1) until it has."""
+(tests/test_kernels_emu.py) and on the GPU (first run: round 3, profiles/r03a_first_run.txt)."""
 import os
 import numpy as np
 import pytest
@@ -8,7 +8,7 @@ import wmtest as W
 import kswcases
 from winnowmap_amd import gpu
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("WM_TEST_EXTS2", os.environ.get("WM_TEST_OPTIN", "0")) != "1", reason="opt-in until run on a GPU: set WM_TEST_OPTIN=1")]
+pytestmark = [pytest.mark.gpu]
 
 
 @pytest.mark.parametrize("with_junc", [False, True])

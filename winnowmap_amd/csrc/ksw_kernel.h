@@ -270,15 +270,9 @@ WM_DEV void ksw_cell(const ksw_cell_cst_t &c, const V<int> os, const V<int> x1, 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// ksw_dp_striped: the register-resident machine with a STRIPED lane layout — thread j holds lanes base + 64*i + j
-// (i = 0..B-1, "chunk" i = 64 consecutive lanes). A row only executes the chunks that intersect the hull, so the
-// work follows the hull width (which ramps up and down along an alignment) instead of the window capacity 64*B;
-// chunks are processed from the top one down, so a chunk still sees the previous-row values of the chunk below
-// (lane 63 of chunk i-1 is the left neighbour of lane 0 of chunk i; inside a chunk the neighbour is one DPP shift).
-// The window re-base (hull start +16 lanes) rotates every register by 16 threads and carries the low 16 threads of
-// chunk i+1 into chunk i. Packed characters: byte k of word w belongs to chunk 4w+k.
-// The exact row maximum is found as a 32-bit wave maximum followed by a ballot of the lanes that reach it; the
-// reference's SIMD tie rule (src/ksw2_extd2_sse.c:315-358) is only evaluated when more than one lane ties.
+// Helpers of the STRIPED lane layout used by ksw_dp_packed (ksw_packed_kernel.h): thread j holds lanes base + 64*i + j (i = 0..B-1,
+// "chunk" i = 64 consecutive lanes). The window re-base (hull start +16 lanes) rotates every register by 16 threads and carries the low
+// 16 threads of chunk i+1 into chunk i.
 // ------------------------------------------------------------------------------------------------------
 template <int B> WM_DEV int get_lane_striped(const V<int> (&a)[B], int base, int t)
 {
@@ -302,353 +296,6 @@ template <int B> WM_DEV void rebase_striped(V<int> (&a)[B], const V<int> fresh, 
 		cur = nxt;
 	}
 }
-
-// ------------------------------------------------------------------------------------------------------
-// ksw_dp_multi: the SAME register-resident machine as ksw_dp_wave, spread over NWV wavefronts of one workgroup: global
-// thread J = 64*wave + lane holds lanes base+B*J .. base+B*J+B-1, so the window is 64*NWV*B lanes (16 waves x 4 = 4096:
-// the stage-2 fills and whole-read extensions of map-ont / map-pb with w = 3001) and a row costs every SIMD only its
-// share. What crosses a wave boundary goes through LDS:
-//   * the previous-row values of the lane below a wave's first lane (x, v, x2, H, query char): lane 63 of every wave
-//     publishes them at the end of a row (xch, double-buffered by row parity);
-//   * the window re-base (every 32 rows): the first D threads of wave k+1 hand all their registers to the last D threads
-//     of wave k (rb);
-//   * what the scalar bookkeeping needs (row maximum with the reference's tie rule, H at en0 / st0, the approximate-max
-//     track): published by the owning threads, replayed identically by every wave after the row's single barrier.
-// CLIP and HASN as in ksw_dp_wave. LDS: xch 2*NWV*5 ints | pub 2*(2*NWV+4) ints | rb NWV*D*(8*B+2*NW+5) ints.
-// ------------------------------------------------------------------------------------------------------
-template <int B, int NWV> struct ksw_multi_lds { enum { D = 16 / B, NW = B / 4, NREG = 8 * B + 2 * NW + 5, XCH = 2 * NWV * 5, PUB = 2 * (2 * NWV + 4), RB = NWV * D * NREG, INTS = XCH + PUB + RB }; };
-
-template <int B, int NWV, bool CLIP, bool HASN>
-WM_DEV void ksw_dp_multi(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const uint8_t *query, const uint8_t *target,
-                         uint8_t *__restrict__ tb_arena, int *lds, wm_ksw_dres_t *__restrict__ res)
-{
-	typedef ksw_multi_lds<B, NWV> L;
-	constexpr int NW = B / 4, D = 16 / B, NT = 64 * NWV;
-	static_assert(B == 4 || B == 8 || B == 16, "B");
-	int *xch = lds, *pub = lds + L::XCH, *rb = pub + L::PUB;
-	const int qlen = jb.qlen, tlen = jb.tlen, flag = jb.flag, zdrop = jb.zdrop;
-	const int w = jb.w < 0 ? (tlen > qlen ? tlen : qlen) : jb.w;
-	const bool approx = (flag & KSW_F_APPROX_MAX) != 0, right = (flag & KSW_F_RIGHT) != 0;
-	uint32_t *tbw = (uint32_t*)(tb_arena + jb.tb_off);
-	const int n_colw = jb.n_col >> 2;
-	const int q = sc.q, e = sc.e, q2 = sc.q2, e2 = sc.e2, qe = q + e, qe2 = q2 + e2;
-	const int Q = tb8(q), Q2 = tb8(q2), QE = tb8(qe), QE2 = tb8(qe2);
-	const int tS = right ? 0 : 4, tA = right ? 1 : 3, tB = 2, tA2 = right ? 3 : 1, tB2 = right ? 4 : 0;
-	const int hA = right ? tA - 1 : tA, hB = right ? tB - 1 : tB, hA2 = right ? tA2 - 1 : tA2, hB2 = right ? tB2 - 1 : tB2;
-	const int MCH = tb8(sc.match), MCHt = MCH | tS, MISt = tb8(sc.mismatch) | tS;
-	const int NNt = tb8(sc.sc_ambi == 0 ? -e2 : sc.sc_ambi) | tS;
-	const ksw_cell_cst_t cc = { Q, Q2, QE, QE2, MCH, tA, tB, tA2, tB2, hA, hB, hA2, hB2 };
-	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
-	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
-	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
-
-	const V<int> ln = lane();
-	const int wv = wave_in_block();
-	const V<int> J = ln + 64 * wv;                           // global thread index
-	int base = 0;
-	V<int> U[B], Vv[B], X[B], Y[B], X2[B], Y2[B], S[B], H[B];
-	V<int> TP[NW], QP[NW];
-#pragma unroll
-	for (int i = 0; i < B; ++i) {
-		U[i] = tb8(-qe); Vv[i] = tb8(-qe); X[i] = tA; Y[i] = tB; X2[i] = tA2; Y2[i] = tB2;
-		S[i] = tS; H[i] = KSW_NEG_INF;
-	}
-#pragma unroll
-	for (int wd = 0; wd < NW; ++wd) {
-		V<int> pk = 0;
-#pragma unroll
-		for (int b = 0; b < 4; ++b) {
-			V<int> t = J * B + (wd * 4 + b);
-			V<int> c = 0;
-			WM_IF(t < tlen) c = cast<int>(gld(target, t)); WM_END
-			pk = pk | (c << (8 * b));
-		}
-		TP[wd] = pk; QP[wd] = 0;
-	}
-	// "previous row" of row 0: the initial state (parity 1 = row -1)
-	WM_IF(ln == 63)
-		int *x = xch + (1 * NWV + wv) * 5;
-		gst(x, V<int>(0), V<int>(tA)); gst(x, V<int>(1), V<int>(tb8(-qe))); gst(x, V<int>(2), V<int>(tA2)); gst(x, V<int>(3), V<int>(KSW_NEG_INF)); gst(x, V<int>(4), V<int>(0));
-	WM_END
-	block_sync_lds();
-
-	int ez_max = 0, ez_zdropped = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1;
-	int ez_mte = KSW_NEG_INF, ez_mte_q = -1, ez_score = KSW_NEG_INF;
-	int H0 = 0, last_H0_t = 0, Hbelow = KSW_NEG_INF;
-	const int n_rows = qlen + tlen - 1;
-
-	for (int r = 0; r < n_rows; ++r) {
-		int st0 = 0, en0 = tlen - 1;
-		if (st0 < r - qlen + 1) st0 = r - qlen + 1;
-		if (en0 > r) en0 = r;
-		if (st0 < (r - w + 1) >> 1) st0 = (r - w + 1) >> 1;
-		if (en0 > (r + w) >> 1) en0 = (r + w) >> 1;
-		if (st0 > en0) { ez_zdropped = 1; break; }
-		const int st = st0 / 16 * 16, en = (en0 + 16) / 16 * 16 - 1;
-		const int sched = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
-		const int par = r & 1, ppar = par ^ 1;
-		int *pubr = pub + par * (2 * NWV + 4);               // wave maxima (lo,hi) | h_en0, h_st0, d0, d1
-
-		// ---- neighbour inputs from the previous row (lane t-1): inside the wave by DPP, across waves from xch ----------
-		V<int> XL = shr1(X[B - 1], tA);
-		V<int> VL = shr1(Vv[B - 1], st == 0 ? tb8(sched) : tb8(-qe));
-		V<int> X2L = shr1(X2[B - 1], tA2);
-		V<int> HL = shr1(H[B - 1], Hbelow);
-		V<int> QL = shr1(cast<int>(cast<unsigned>(QP[NW - 1]) >> 24), 0);
-		if (wv > 0) {
-			const int *x = xch + (ppar * NWV + (wv - 1)) * 5;
-			WM_IF(ln == 0) XL = gld(x, V<int>(0)); VL = gld(x, V<int>(1)); X2L = gld(x, V<int>(2)); HL = gld(x, V<int>(3)); QL = gld(x, V<int>(4)); WM_END
-		}
-
-		// ---- re-base the window when the hull start moves up by one 16-lane block -----------------------------------------
-		if (st > base) {
-			WM_EMU_ASSERT(st == base + 16);
-			if (wv == 0) Hbelow = readlane(H[B - 1], D - 1);
-			// the first D threads of every wave publish their registers for the wave below
-			WM_IF(ln < D)
-				int *o = rb + (wv * D) * L::NREG;
-				const V<int> ob = ln * (int)L::NREG;
-				int k = 0;
-#pragma unroll
-				for (int i = 0; i < B; ++i) {
-					gst(o, ob + (k + 0), U[i]); gst(o, ob + (k + 1), Vv[i]); gst(o, ob + (k + 2), X[i]); gst(o, ob + (k + 3), Y[i]);
-					gst(o, ob + (k + 4), X2[i]); gst(o, ob + (k + 5), Y2[i]); gst(o, ob + (k + 6), S[i]); gst(o, ob + (k + 7), H[i]);
-					k += 8;
-				}
-#pragma unroll
-				for (int wd = 0; wd < NW; ++wd) { gst(o, ob + (k + 0), TP[wd]); gst(o, ob + (k + 1), QP[wd]); k += 2; }
-				gst(o, ob + (k + 0), XL); gst(o, ob + (k + 1), VL); gst(o, ob + (k + 2), X2L); gst(o, ob + (k + 3), HL); gst(o, ob + (k + 4), QL);
-			WM_END
-			block_sync_lds();
-			const bool last = wv == NWV - 1;
-			const V<int> tnew = J * B + st;                   // first lane of each thread after the shift
-			// fills for the top D threads of this wave: the next wave's first D threads, or (last wave) fresh lanes
-			V<int> fU[B], fV[B], fX[B], fY[B], fX2[B], fY2[B], fS[B], fH[B], fTP[NW], fQP[NW];
-			V<int> fXL = tA, fVL = tb8(-qe), fX2L = tA2, fHL = KSW_NEG_INF, fQL = 0;
-#pragma unroll
-			for (int i = 0; i < B; ++i) { fU[i] = tb8(-qe); fV[i] = tb8(-qe); fX[i] = tA; fY[i] = tB; fX2[i] = tA2; fY2[i] = tB2; fS[i] = tS; fH[i] = KSW_NEG_INF; }
-#pragma unroll
-			for (int wd = 0; wd < NW; ++wd) { fTP[wd] = 0; fQP[wd] = 0; }
-			if (!last) {
-				WM_IF(ln >= 64 - D)
-					const int *o = rb + ((wv + 1) * D) * L::NREG;
-					const V<int> ob = (ln - (64 - D)) * (int)L::NREG;
-					int k = 0;
-#pragma unroll
-					for (int i = 0; i < B; ++i) {
-						fU[i] = gld(o, ob + (k + 0)); fV[i] = gld(o, ob + (k + 1)); fX[i] = gld(o, ob + (k + 2)); fY[i] = gld(o, ob + (k + 3));
-						fX2[i] = gld(o, ob + (k + 4)); fY2[i] = gld(o, ob + (k + 5)); fS[i] = gld(o, ob + (k + 6)); fH[i] = gld(o, ob + (k + 7));
-						k += 8;
-					}
-#pragma unroll
-					for (int wd = 0; wd < NW; ++wd) { fTP[wd] = gld(o, ob + (k + 0)); fQP[wd] = gld(o, ob + (k + 1)); k += 2; }
-					fXL = gld(o, ob + (k + 0)); fVL = gld(o, ob + (k + 1)); fX2L = gld(o, ob + (k + 2)); fHL = gld(o, ob + (k + 3)); fQL = gld(o, ob + (k + 4));
-				WM_END
-			} else {
-				WM_IF(ln >= 64 - D)
-#pragma unroll
-					for (int wd = 0; wd < NW; ++wd) {
-						V<int> tp = 0, qp = 0;
-#pragma unroll
-						for (int b = 0; b < 4; ++b) {
-							V<int> t = tnew + (wd * 4 + b);
-							V<int> c = 0, d = 0;
-							WM_IF(t < tlen) c = cast<int>(gld(target, t)); WM_END
-							V<int> qi = (r - 1) - t;
-							WM_IF(qi >= 0 && qi < qlen) d = cast<int>(gld(query, qi)); WM_END
-							tp = tp | (c << (8 * b)); qp = qp | (d << (8 * b));
-						}
-						fTP[wd] = tp; fQP[wd] = qp;
-					}
-					// the top thread's left-neighbour char after the shift belongs to lane tnew-1 at row r-1
-					V<int> qi = (r - 1) - (tnew - 1);
-					WM_IF(qi >= 0 && qi < qlen) fQL = cast<int>(gld(query, qi)); WM_END
-				WM_END
-			}
-#pragma unroll
-			for (int i = 0; i < B; ++i) {
-				U[i] = shift_down(U[i], D, fU[i]); Vv[i] = shift_down(Vv[i], D, fV[i]);
-				X[i] = shift_down(X[i], D, fX[i]); Y[i] = shift_down(Y[i], D, fY[i]);
-				X2[i] = shift_down(X2[i], D, fX2[i]); Y2[i] = shift_down(Y2[i], D, fY2[i]);
-				if (CLIP) S[i] = shift_down(S[i], D, fS[i]);
-				if (!approx) H[i] = shift_down(H[i], D, fH[i]);
-			}
-#pragma unroll
-			for (int wd = 0; wd < NW; ++wd) { TP[wd] = shift_down(TP[wd], D, fTP[wd]); QP[wd] = shift_down(QP[wd], D, fQP[wd]); }
-			if (last) {
-				// (last wave: the neighbour values of the fresh top threads are the plain fills, except the query char)
-				XL = shift_down(XL, D, V<int>(tA)); VL = shift_down(VL, D, V<int>(tb8(-qe))); X2L = shift_down(X2L, D, V<int>(tA2));
-				HL = shift_down(HL, D, V<int>(KSW_NEG_INF));
-				const V<int> qsh = shift_down(QL, D, V<int>(0));
-				QL = sel(ln >= 64 - D, fQL, qsh);
-			} else {
-				XL = shift_down(XL, D, fXL); VL = shift_down(VL, D, fVL); X2L = shift_down(X2L, D, fX2L); HL = shift_down(HL, D, fHL); QL = shift_down(QL, D, fQL);
-			}
-			base = st;
-		}
-		const V<int> t0 = J * B + base;
-
-		// ---- advance the query codes to row r (systolic) -----------------------------------------------------------------------
-		{
-			const int qi0 = r - base;
-			const int newc = qi0 >= 0 && qi0 < qlen ? (int)gld(query, qi0) : 0;
-			V<int> carry = sel(J == 0, V<int>(newc), QL);
-#pragma unroll
-			for (int wd = 0; wd < NW; ++wd) {
-				V<int> nxt = cast<int>(cast<unsigned>(QP[wd]) >> 24);
-				QP[wd] = (QP[wd] << 8) | carry;
-				carry = nxt;
-			}
-		}
-
-		// ---- first-column / first-row boundary of lane r ------------------------------------------------------------------------
-		if (en >= r) {
-			const int o = r - base, jr = o / B, ir = o % B;
-			WM_EMU_ASSERT(o >= 0 && o < NT * B);
-			WM_IF(J == jr)
-#pragma unroll
-				for (int i = 0; i < B; ++i)
-					if (ir == i) { Y[i] = tB; Y2[i] = tB2; U[i] = tb8(sched); }
-			WM_END
-		}
-
-		// ---- scores -----------------------------------------------------------------------------------------------------------------
-		V<int> Sc[B];
-		{
-			const int cend = st0 + (en0 - st0) / 16 * 16 + 15;
-#pragma unroll
-			for (int i = 0; i < B; ++i) {
-				const int wd = i >> 2, sh = 8 * (i & 3);
-				V<int> tc = (TP[wd] >> sh) & 0xff, qc = (QP[wd] >> sh) & 0xff;
-				V<int> s = sel(tc == qc, MCHt, MISt);
-				if (HASN) s = sel((tc == 4) || (qc == 4), NNt, s);
-				if (CLIP) {
-					V<int> t = t0 + i;
-					S[i] = sel(t >= st0 && t <= cend, s, S[i]);
-					Sc[i] = S[i];
-				} else Sc[i] = s;
-			}
-		}
-
-		// ---- the DP cells of this thread (only threads inside the hull) ------------------------------------------------------
-		WM_IF(t0 <= en)
-			V<int> pk[NW];
-#pragma unroll
-			for (int wd = 0; wd < NW; ++wd) pk[wd] = 0;
-#pragma unroll
-			for (int i = B - 1; i >= 0; --i) {          // descending: lane i reads the OLD state of lane i-1
-				const V<int> x1 = i ? X[i - 1] : XL, v1 = i ? Vv[i - 1] : VL, x21 = i ? X2[i - 1] : X2L;
-				V<int> nu, nv, nx, ny, nx2, ny2, p;
-				ksw_cell(cc, Sc[i], x1, v1, x21, Y[i], U[i], Y2[i], nu, nv, nx, ny, nx2, ny2, p);
-				U[i] = nu; Vv[i] = nv; X[i] = nx; Y[i] = ny; X2[i] = nx2; Y2[i] = ny2;
-				pk[i >> 2] = pk[i >> 2] | (p << (8 * (i & 3)));
-			}
-			uint32_t *trow = tbw + (size_t)r * n_colw;
-#pragma unroll
-			for (int wd = 0; wd < NW; ++wd)
-				gst(trow, J * NW + wd, cast<uint32_t>(pk[wd]));
-		WM_END
-
-		const int wbase = base + B * 64 * wv;                 // first lane of this wave
-		if (!approx) {   // ---- exact max: per-wave 32-bit maximum, tie rule only among the lanes that reach it -------------------
-			long long kk = -0x7fffffffffffffffLL - 1;
-			if (r > 0) {
-				const int en1 = st0 + (en0 - st0) / 4 * 4;
-				V<int> hmax = KSW_NEG_INF;
-#pragma unroll
-				for (int i = B - 1; i >= 0; --i) {
-					const V<int> t = t0 + i, v8 = Vv[i] >> 24, u8 = U[i] >> 24;
-					const V<int> hl = i ? H[i - 1] : HL;
-					V<int> hn = H[i] + v8;
-					hn = sel(t == en0, en0 > 0 ? V<int>(hl + u8) : hn, hn);
-					const vbool inb = t >= st0 && t <= en0;
-					H[i] = sel(inb, hn, H[i]);
-					hmax = vmax(hmax, sel(inb, H[i], V<int>(KSW_NEG_INF)));
-				}
-				const int hm = wave_max_i32(hmax);
-				if (hm > KSW_NEG_INF) {
-					int best_pri = -1;
-#pragma unroll
-					for (int i = 0; i < B; ++i) {
-						const V<int> t = t0 + i;
-						uint64_t m = ballot(t >= st0 && t <= en0 && H[i] == hm);
-						while (m) {                                   // priority on ties: en0, residue groups 0..3 of [st0,en1), then the tail
-							const int tt = wbase + B * __builtin_ctzll(m) + i;
-							m &= m - 1;
-							const int grp = tt == en0 ? 5 : tt < en1 ? 4 - ((tt - st0) & 3) : 0;
-							const int pri = (grp << 20) | (0xfffff - tt);
-							if (pri > best_pri) best_pri = pri;
-						}
-					}
-					if (best_pri >= 0) kk = (long long)hm * 4294967296LL + (long long)best_pri;
-				}
-			} else {
-				WM_IF(J == 0) H[0] = (Vv[0] >> 24) - qe; WM_END
-				if (wv == 0) kk = (long long)readlane(H[0], 0) * 4294967296LL + (long long)((5 << 20) | 0xfffff);
-			}
-			// H of lanes en0 / st0 for the mte / mqe bookkeeping: published by the wave that owns them
-			if (en0 >= wbase && en0 < wbase + 64 * B) { const int h = get_lane<B>(H, wbase, en0); WM_IF(ln == 0) gst(pubr, V<int>(2 * NWV + 0), V<int>(h)); WM_END }
-			if (st0 >= wbase && st0 < wbase + 64 * B) { const int h = get_lane<B>(H, wbase, st0); WM_IF(ln == 0) gst(pubr, V<int>(2 * NWV + 1), V<int>(h)); WM_END }
-			WM_IF(ln == 0) gst(pubr, V<int>(2 * wv), V<int>((int)(unsigned)(kk & 0xffffffffLL))); gst(pubr, V<int>(2 * wv + 1), V<int>((int)(kk >> 32))); WM_END
-		} else {         // ---- approximate max: the owners of lanes last_H0_t / last_H0_t+1 publish v / u ---------------------
-			if (last_H0_t >= wbase && last_H0_t < wbase + 64 * B) { const int d = get_lane<B>(Vv, wbase, last_H0_t) >> 24; WM_IF(ln == 0) gst(pubr, V<int>(2 * NWV + 2), V<int>(d)); WM_END }
-			if (last_H0_t + 1 >= wbase && last_H0_t + 1 < wbase + 64 * B) { const int d = get_lane<B>(U, wbase, last_H0_t + 1) >> 24; WM_IF(ln == 0) gst(pubr, V<int>(2 * NWV + 3), V<int>(d)); WM_END }
-		}
-		// the next row's cross-wave neighbour values
-		WM_IF(ln == 63)
-			int *x = xch + (par * NWV + wv) * 5;
-			gst(x, V<int>(0), X[B - 1]); gst(x, V<int>(1), Vv[B - 1]); gst(x, V<int>(2), X2[B - 1]); gst(x, V<int>(3), H[B - 1]);
-			gst(x, V<int>(4), cast<int>(cast<unsigned>(QP[NW - 1]) >> 24));
-		WM_END
-		block_sync_lds();
-
-		// ---- scalar bookkeeping, identical in every wave ----------------------------------------------------------------------------
-		if (!approx) {
-			long long kk = -0x7fffffffffffffffLL - 1;
-			for (int w2 = 0; w2 < NWV; ++w2) {
-				const long long k2 = (long long)(((unsigned long long)(unsigned)gld(pubr, (long long)(2 * w2 + 1)) << 32) | (unsigned)gld(pubr, (long long)(2 * w2)));
-				if (k2 > kk) kk = k2;
-			}
-			const int max_H = (int)(kk >> 32), pri = (int)(kk & 0xffffffffLL);
-			const int max_t = 0xfffff - (pri & 0xfffff);
-			if (en0 == tlen - 1) { const int h = gld(pubr, (long long)(2 * NWV)); if (h > ez_mte) ez_mte = h, ez_mte_q = r - en; }
-			if (r - st0 == qlen - 1) { const int h = gld(pubr, (long long)(2 * NWV + 1)); if (h > ez_mqe) ez_mqe = h, ez_mqe_t = st0; }
-			if (max_H > ez_max) {
-				ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
-			} else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
-				const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
-				if (zdrop >= 0 && ez_max - max_H > zdrop + l * e2) { ez_zdropped = 1; break; }
-			}
-			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = gld(pubr, (long long)(2 * NWV));
-		} else {
-			if (r > 0) {
-				const bool in0 = last_H0_t >= st0 && last_H0_t <= en0, in1 = last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0;
-				if (in0 && in1) {
-					const int d0 = gld(pubr, (long long)(2 * NWV + 2)), d1 = gld(pubr, (long long)(2 * NWV + 3));
-					if (d0 > d1) H0 += d0;
-					else H0 += d1, ++last_H0_t;
-				} else if (in0) H0 += gld(pubr, (long long)(2 * NWV + 2));
-				else { ++last_H0_t; H0 += gld(pubr, (long long)(2 * NWV + 3)); }
-			} else H0 = gld(pubr, (long long)(2 * NWV + 2)) - qe, last_H0_t = 0;
-			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = H0;
-		}
-	}
-
-	int bt_i = -1, bt_j = -1, reach_end = 0;
-	if (!ez_zdropped && !(flag & KSW_F_EXTZ_ONLY)) bt_i = tlen - 1, bt_j = qlen - 1;
-	else if (!ez_zdropped && (flag & KSW_F_EXTZ_ONLY) && ez_mqe + jb.end_bonus > ez_max) reach_end = 1, bt_i = ez_mqe_t, bt_j = qlen - 1;
-	else if (ez_max_t >= 0 && ez_max_q >= 0) bt_i = ez_max_t, bt_j = ez_max_q;
-	if (wv == 0) {
-		WM_IF(ln == 0)
-			wm_ksw_dres_t o;
-			o.max = ez_max; o.zdropped = ez_zdropped; o.max_q = ez_max_q; o.max_t = ez_max_t;
-			o.mqe = ez_mqe; o.mqe_t = ez_mqe_t; o.mte = ez_mte; o.mte_q = ez_mte_q;
-			o.score = ez_score; o.reach_end = reach_end; o.n_cigar = 0; o.bt_i = bt_i; o.bt_j = bt_j;
-			*res = o;
-		WM_END
-	}
-}
-
 
 // Hulls wider than one sweep of the block (CH = 64*NWV*K lanes) are processed in CHUNKS of CH lanes per row: the only
 // cross-chunk dependency is the previous-row state of the lane just below a chunk, which one lane per chunk boundary
@@ -936,8 +583,8 @@ WM_DEV int ksw_backtrack_thread(const wm_ksw_djob_t jb, const uint8_t *__restric
 // dependent global load per step (~0.6 us: 4 ms per batch, tens of ms for the longest alignments). Here the 64 lanes first fetch a tile
 // of the traceback matrix — the next KSW_BT_ROWS anti-diagonals, 64 target lanes ending at the current one — into LDS with independent
 // loads, then every lane replays the same scalar walk on LDS bytes until it leaves the tile (at least KSW_BT_ROWS / 2 steps later).
-// `tile` = KSW_BT_ROWS * 64 bytes of LDS per wavefront. Same op stream as ksw_backtrack_thread. Opt-in (WM_KSW_COOP_BT=1) until it has
-// been run and timed on a GPU; bit-exact on the wavefront emulator.
+// `tile` = KSW_BT_ROWS * 64 bytes of LDS per wavefront. Same op stream as ksw_backtrack_thread. Bit-exact on the emulator and on the GPU; timed in round 3
+// (profiles/r03a_first_run.txt): no gain on BASELINE config 2 (0.184 vs 0.187 Gbp/s), so it stays behind WM_KSW_COOP_BT=1.
 // ------------------------------------------------------------------------------------------------------
 #define KSW_BT_ROWS 32
 WM_DEV int ksw_backtrack_wave(const wm_ksw_djob_t jb, const uint8_t *__restrict__ tb_arena, int i0, int j0,

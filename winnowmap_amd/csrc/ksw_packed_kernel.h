@@ -2,7 +2,7 @@
 // DP cells per 32-bit lane with packed 16-bit integer instructions (VOP3P: v_pk_add_u16 / v_pk_sub_u16 / v_pk_max_i16 /
 // v_pk_min_i16 / v_pk_sub_i16 clamp / v_pk_mad_u16 — full rate on gfx950, profiles/r02_valu_bench.txt).
 //
-// Same machine as ksw_dp_striped (ksw_kernel.h): one wavefront owns one alignment, walks the anti-diagonals r = i + j and
+// One wavefront owns one alignment, walks the anti-diagonals r = i + j and
 // keeps the reference's persistent per-target-lane int8 state (u, v, x, y, x2, y2, and the score row when the band clips)
 // for a sliding window of lanes that starts at the 16-aligned hull start `base`. What changes is the representation:
 //
@@ -40,7 +40,7 @@
 #endif
 #include "ksw_kernel.h"
 #ifndef WM_KSW_ROR
-#define WM_KSW_ROR 0          // 1: neighbour values through wave_ror:1 + v_perm_b32 (emulator-validated; to be A/B-tested on a GPU before it becomes the default)
+#define WM_KSW_ROR 1          // 1 (default since round 3: +4 % in the isolated probe, +2 % in the bench, profiles/r03a_first_run.txt): neighbour values through wave_ror:1 + v_perm_b32; 0: v_readlane + scalar fill
 #endif
 #include <type_traits>
 #include <utility>

@@ -1,12 +1,10 @@
 // ksw_packed_multi_kernel.h — ksw_extd2_sse (src/ksw2_extd2_sse.c:26-393) for band hulls wider than one wavefront's register window:
 // the packed two-cells-per-lane machine of ksw_packed_kernel.h spread over the NWV wavefronts of one workgroup.
 //
-// STATUS: validated bit-for-bit against the oracle on the wavefront emulator (tests/test_kernels_emu.py, every geometry incl. the product's
-// <4,8> and <8,8>), compiles for gfx950 without scratch (104 / 178 VGPRs), NOT YET RUN ON A GPU (round 2 ran out of GPU time). It is therefore
-// opt-in: WM_KSW_PMULTI=1 routes the BLOCK / BLOCK2 classes to it (wm_gpu.hip, ksw_pmulti_kernel); tests/test_ksw_gpu.py holds the GPU parity
-// test behind WM_TEST_PMULTI=1. It is meant to replace ksw_dp_multi<8, 8 | 16> (one barrier per row as well, but 8 unpacked cells per lane:
-// 24 GCUPS on the 10 % of the DP cells that live in hulls of 2033..8176 lanes) and then to take the long single-wave jobs of the 16-pair
-// class, whose 30..50 ms per alignment are the tail of every batch of heavy alignments.
+// STATUS: bit-exact against the oracle on the wavefront emulator (tests/test_kernels_emu.py, every geometry) and on the GPU
+// (tests/test_ksw_gpu.py; first hardware run in round 3, profiles/r03a_first_run.txt). 104 / 178 VGPRs, no scratch. It serves the BLOCK / BLOCK2
+// classes (hulls of 2033..8176 lanes) as <4,8> / <8,8> and, by default (WM_KSW_PMULTI=2), the 16-pair register classes as <4,4>: the long
+// single-wave jobs whose 30..50 ms per alignment were the tail of every batch of heavy alignments.
 //
 // Layout: the window of 128 * BP * NWV lanes starting at the hull start `base` is striped over chunk PAIRS; pair g (lanes base + 128 g ..
 // + 127: low halves = the first 64, high halves = the next 64) lives in register slot g / NWV of wavefront g % NWV, so the pairs that

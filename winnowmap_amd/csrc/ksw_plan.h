@@ -9,7 +9,7 @@ enum {            // register classes (ksw_dp_packed<BP,...>): klass = window*8 
 	WM_KSW_P4 = 0, WM_KSW_P8 = 8, WM_KSW_P16 = 16, WM_KSW_BLOCK = 24, WM_KSW_BLOCK2 = 25, WM_KSW_BLOCK3 = 26, WM_KSW_GENERIC = 27, WM_KSW_NCLASS = 28
 };
 // geometry of the block kernels (ksw_dp_block<NWV, K>): NWV waves x K tiles x 64 lanes per row, LDS window of WN lanes
-enum { WM_KSW_MULTI_B = 8, WM_KSW_MULTI_NWV = 8,                          // BLOCK: register-resident multi-wave kernel ksw_dp_multi<8, 8>: hulls up to 4080 lanes
+enum { WM_KSW_MULTI_B = 8, WM_KSW_MULTI_NWV = 8,                          // BLOCK: hulls up to 64 * 8 * 8 - 16 = 4080 lanes (ksw_dp_pmulti<4, 8>), BLOCK2: up to 8176 (<8, 8>)
        WM_KSW_BLK_NWV = 16, WM_KSW_BLK_K = 3, WM_KSW_BLK_WN = 4096,        // (LDS-state kernel at the same size: kept for tests)
        WM_KSW_BLK2_K = 7, WM_KSW_BLK2_WN = 8192 };                         // hulls up to 7168 lanes (unbanded fills across structural variants)
 // bytes of LDS left for the staged sequences next to the state window (160 KB per CU, one block per CU for these classes)
@@ -69,7 +69,7 @@ static inline int wm_ksw_classify(int qlen, int tlen, int w, int has_n, int flag
 	else if (n_col <= 128 * 8 - 16) k = WM_KSW_P8;
 	else if (n_col <= 128 * 16 - 16) k = WM_KSW_P16;
 	else if (n_col + 16 <= 64 * WM_KSW_MULTI_NWV * WM_KSW_MULTI_B) return WM_KSW_BLOCK;
-	else if (n_col + 16 <= 64 * 2 * WM_KSW_MULTI_NWV * WM_KSW_MULTI_B) return WM_KSW_BLOCK2;     // ksw_dp_multi<8,16>: 8192 lanes
+	else if (n_col + 16 <= 64 * 2 * WM_KSW_MULTI_NWV * WM_KSW_MULTI_B) return WM_KSW_BLOCK2;     // ksw_dp_pmulti<8,8>: 8192 lanes
 	else if (n_col + 16 <= 64 * WM_KSW_BLK_NWV * WM_KSW_BLK2_K * WM_KSW_BLK_MAXC) return WM_KSW_BLOCK3;
 	else return WM_KSW_GENERIC;
 	return k + exact * 4 + clip * 2 + (has_n ? 1 : 0);

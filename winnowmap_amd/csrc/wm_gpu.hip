@@ -103,32 +103,9 @@ __global__ __launch_bounds__(64 * WM_KSW_BLK_NWV) void ksw_block_kernel(wm_ksw_s
 		wmk::ksw_dp_block<WM_KSW_BLK_NWV, K, GLOBAL>(sc, jb, seqs + jb.q_off, seqs + jb.t_off, tb, W0, W1, Hm, wn, pub, res + j);
 }
 
-// BLOCK / BLOCK2 classes: 8 / 16 waves per alignment, state in registers (ksw_dp_multi<8,NWV>: 4096 / 8192 lanes); dynamic LDS = exchange areas, then the staged
-// sequences (if they fit in seq_cap bytes)
-template <int NWV>
-__global__ __launch_bounds__(64 * NWV) void ksw_multi_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
-                                                                         const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res, int seq_cap)
-{
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	typedef wmk::ksw_multi_lds<WM_KSW_MULTI_B, NWV> L;
-	int *lds = (int*)smem;
-	uint8_t *sq = (uint8_t*)(lds + L::INTS);
-	const int j = order[blockIdx.x];
-	const wm_ksw_djob_t jb = jobs[j];
-	const int qpad = (jb.qlen + 15) & ~15;
-	if (qpad + jb.tlen <= seq_cap) {
-		uint8_t *st = sq + qpad;
-		for (int i = threadIdx.x; i < jb.qlen; i += blockDim.x) sq[i] = seqs[jb.q_off + i];
-		for (int i = threadIdx.x; i < jb.tlen; i += blockDim.x) st[i] = seqs[jb.t_off + i];
-		__syncthreads();
-		wmk::ksw_dp_multi<WM_KSW_MULTI_B, NWV, true, true>(sc, jb, sq, st, tb, lds, res + j);
-	} else
-		wmk::ksw_dp_multi<WM_KSW_MULTI_B, NWV, true, true>(sc, jb, seqs + jb.q_off, seqs + jb.t_off, tb, lds, res + j);
-}
-
-// BLOCK / BLOCK2 classes, opt-in (WM_KSW_PMULTI=1): the packed two-cells-per-lane machine over 8 wavefronts (ksw_dp_pmulti<4,8>: 4096 lanes,
-// <8,8>: 8192 lanes). Bit-exact on the wavefront emulator; not the default until it has been run and timed on a GPU. Same dynamic LDS
-// layout as ksw_multi_kernel: exchange areas, then the staged sequences
+// BLOCK / BLOCK2 classes (and, with WM_KSW_PMULTI >= 2, the 16-pair register classes on <4,4>): the packed two-cells-per-lane machine over
+// 8 wavefronts (ksw_dp_pmulti<4,8>: 4096 lanes, <8,8>: 8192 lanes). Dynamic LDS: exchange areas, then the staged sequences (if they fit).
+// It replaced the unpacked ksw_dp_multi<8, 8|16> in round 3 (24 / 3 GCUPS, the <16> form spilled 377 VGPRs; profiles/r03a_first_run.txt)
 template <int BP, int NWV>
 __global__ __launch_bounds__(64 * NWV) void ksw_pmulti_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
                                                                          const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res, int seq_cap)
@@ -626,6 +603,10 @@ extern "C" int wm_reads_upload(wm_ctx_t *c, const uint8_t *codes, size_t n)
 	return WM_OK;
 }
 
+// WM_KSW_PMULTI: 1 = only the BLOCK / BLOCK2 classes run on the packed multi-wave kernel (ksw_pmulti_kernel<4,8> / <8,8>); 2 (default:
+// +7 % on BASELINE config 2, profiles/r03a_first_run.txt) = the 16-pair register classes run on ksw_pmulti_kernel<4,4> as well
+static int ksw_pmulti_level() { const char *e = getenv("WM_KSW_PMULTI"); return e ? atoi(e) : 2; }
+
 extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 {
 	HIPCHK(hipSetDevice(c->device));
@@ -686,8 +667,7 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		struct Done { decltype(class_done) &f; int k; double t; hipEvent_t e; hipStream_t s; ~Done() { hipEventRecord(e, s); f(k, t); } } done_guard{ class_done, k, tk0, c->cev[k][1], ks };
 		if (k == WM_KSW_BLOCK || k == WM_KSW_BLOCK2 || k == WM_KSW_BLOCK3) {
 			const size_t fixed = (size_t)WM_KSW_BLK_PUB * 4;
-			const char *pm_env = getenv("WM_KSW_PMULTI");
-			if ((k == WM_KSW_BLOCK || k == WM_KSW_BLOCK2) && pm_env && atoi(pm_env) > 0) {
+			if (k == WM_KSW_BLOCK || k == WM_KSW_BLOCK2) {
 				const int seq_cap = 64 * 1024;
 				if (k == WM_KSW_BLOCK) {
 					const size_t lds = (size_t)wmk::ksw_pmulti_lds<4, 8>::INTS * 4 + seq_cap;
@@ -698,16 +678,6 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 					HIPCHK(hipFuncSetAttribute((const void*)ksw_pmulti_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 					hipLaunchKernelGGL((ksw_pmulti_kernel<8, 8>), dim3(nk), dim3(64 * 8), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, seq_cap);
 				}
-			} else if (k == WM_KSW_BLOCK) {
-				const int seq_cap = 64 * 1024;
-				const size_t lds = (size_t)wmk::ksw_multi_lds<WM_KSW_MULTI_B, WM_KSW_MULTI_NWV>::INTS * 4 + seq_cap;
-				HIPCHK(hipFuncSetAttribute((const void*)ksw_multi_kernel<WM_KSW_MULTI_NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-				hipLaunchKernelGGL(ksw_multi_kernel<WM_KSW_MULTI_NWV>, dim3(nk), dim3(64 * WM_KSW_MULTI_NWV), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, seq_cap);
-			} else if (k == WM_KSW_BLOCK2) {
-				const int seq_cap = 64 * 1024;
-				const size_t lds = (size_t)wmk::ksw_multi_lds<WM_KSW_MULTI_B, 2 * WM_KSW_MULTI_NWV>::INTS * 4 + seq_cap;
-				HIPCHK(hipFuncSetAttribute((const void*)ksw_multi_kernel<2 * WM_KSW_MULTI_NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-				hipLaunchKernelGGL(ksw_multi_kernel<2 * WM_KSW_MULTI_NWV>, dim3(nk), dim3(64 * 2 * WM_KSW_MULTI_NWV), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, seq_cap);
 			} else {
 				const size_t lds = fixed + WM_KSW_BLK3_SEQ_LDS;
 				HIPCHK(hipFuncSetAttribute((const void*)ksw_block_kernel<WM_KSW_BLK2_K, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -723,7 +693,7 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		case WM_KSW_P4: launch_dpp<4>(k & 7, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
 		case WM_KSW_P8: launch_dpp<8>(k & 7, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
 		default:
-			if (getenv("WM_KSW_PMULTI") && atoi(getenv("WM_KSW_PMULTI")) >= 2) {      // opt-in: 4 wavefronts per alignment for the 16-pair classes too (shorter batch tails)
+			if (ksw_pmulti_level() >= 2) {      // 4 wavefronts per alignment for the 16-pair classes too (shorter batch tails)
 				const int seq_cap = 32 * 1024;
 				const size_t lds = (size_t)wmk::ksw_pmulti_lds<4, 4>::INTS * 4 + seq_cap;
 				HIPCHK(hipFuncSetAttribute((const void*)ksw_pmulti_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
