@@ -158,6 +158,8 @@ def ksw_class_name(k):
     spelled as rocprofv3 prints the instantiation ksw_dpp_kernel<BP, CLIP, HASN, EXACT> (jobs with an N run on the CLIP instantiation)"""
     if k >= 24:
         return KSW_WIDE_CLASSES[k]
+    if k >= 16 and int(os.environ.get("WM_KSW_PMULTI", 2)) >= 2:       # the 16-pair classes run on 4 wavefronts per alignment (library default)
+        return "ksw_pmulti_kernel<4, 4>"
     bp = (4, 8, 16)[k >> 3]
     exact, clip, hasn = bool(k & 4), bool(k & 2) or bool(k & 1), bool(k & 1)
     return "ksw_dpp_kernel<%d, %s, %s, %s>" % (bp, str(clip).lower(), str(hasn).lower(), str(exact).lower())
@@ -179,15 +181,19 @@ def host_report(hs0, hs1, ru0, ru1, elapsed, n_cores):
 def make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1):
     """The JSON line (without cpu_baseline). ks0/ks1: Mapper.kernel_stats() before/after the timed region."""
     value = total_bases / elapsed / 1e9
-    # dominant kernel = the ksw class with the largest summed launch time in the timed region (HIP events on its stream)
-    cls = {k: (ks1[k][0] - ks0[k][0], ks1[k][1] - ks0[k][1], ks1[k][2] - ks0[k][2]) for k in ks1}
-    dom = max(cls, key=lambda k: cls[k][0])
-    d_ms, d_cells, d_launch = cls[dom]
-    kname = ksw_class_name(dom)
+    # dominant kernel = the ksw kernel (instantiation) with the largest summed launch time in the timed region (HIP events on its stream);
+    # several job classes can share one kernel (the 16-pair classes all run on ksw_pmulti_kernel<4, 4>)
+    cls = {}
+    for k in ks1:
+        v = (ks1[k][0] - ks0[k][0], ks1[k][1] - ks0[k][1], ks1[k][2] - ks0[k][2])
+        o = cls.get(ksw_class_name(k), (0.0, 0.0, 0))
+        cls[ksw_class_name(k)] = (o[0] + v[0], o[1] + v[1], o[2] + v[2])
+    kname = max(cls, key=lambda k: cls[k][0])
+    d_ms, d_cells, d_launch = cls[kname]
     ach = d_cells / max(d_ms, 1e-9) / 1e6       # 1 B of traceback per DP cell: bytes per ms / 1e6 = GB/s
     all_ms = sum(v[0] for v in cls.values())
     all_cells = sum(v[1] for v in cls.values())
-    classes = {ksw_class_name(k): {"ms": round(v[0], 3), "cells": v[1], "launches": v[2]} for k, v in cls.items() if v[2] > 0}
+    classes = {k: {"ms": round(v[0], 3), "cells": v[1], "launches": v[2]} for k, v in cls.items() if v[2] > 0}
     # HBM traffic per DP cell of each kernel, measured in separate rocprofv3 --pmc passes (tools/pmc_ratio.py -> profiles/)
     traffic = None
     pmc = None

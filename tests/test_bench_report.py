@@ -20,7 +20,7 @@ def test_report_has_contract_keys_for_any_dominant_class():
     n_classes = 28                     # WM_KSW_NCLASS (winnowmap_amd/csrc/ksw_plan.h): what Mapper.kernel_stats() returns
     zero = {k: (0.0, 0.0, 0) for k in range(n_classes)}
     assert B.ksw_class_name(0) == "ksw_dpp_kernel<4, false, false, false>" and B.ksw_class_name(14) == "ksw_dpp_kernel<8, true, false, true>"
-    assert B.ksw_class_name(21) == "ksw_dpp_kernel<16, true, true, true>" and B.ksw_class_name(24) == "ksw_multi_kernel<8>"
+    assert B.ksw_class_name(21) == "ksw_pmulti_kernel<4, 4>" and B.ksw_class_name(24) == "ksw_pmulti_kernel<4, 8>"
     for dom in range(n_classes):
         after = dict(zero)
         after[dom] = (500.0, 5e10, 40)
