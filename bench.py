@@ -169,7 +169,7 @@ def host_report(hs0, hs1, ru0, ru1, elapsed, n_cores):
     """Where the host time of the timed region went (rank 0): the per-read glue and the batched calls, against the usable cores."""
     d = lambda a, b: b - a  # noqa: E731
     cpu = d(ru0.ru_utime, ru1.ru_utime) + d(ru0.ru_stime, ru1.ru_stime)
-    ops = ("sketch", "seed", "chain", "ksw")
+    ops = ("window", "ksw")
     return {"usable_cores": n_cores, "process_cpu_s": round(cpu, 2), "cpu_utilisation": round(cpu / max(elapsed, 1e-9) / max(1, n_cores), 3),
             "glue_cpu_s": round(d(hs0["cpu_glue_s"], hs1["cpu_glue_s"]), 2), "help_cpu_s": round(d(hs0["cpu_help_s"], hs1["cpu_help_s"]), 2), "idle_wall_s": round(d(hs0["idle_wall_s"], hs1["idle_wall_s"]), 2),
             "batched_cpu_s": {o: round(d(hs0["cpu_batched_s"][o], hs1["cpu_batched_s"][o]), 2) for o in ops},

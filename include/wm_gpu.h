@@ -14,6 +14,8 @@
  *   wm_seed_batch         ← collect_seed_hits src/map.c:222-254 (mm_idx_get src/index.c:88,
  *                           radix_sort_128x src/ksort.h:101-151)
  *   wm_chain_batch        ← mm_chain_dp src/mmpriv.h:73 (src/chain.c:22-167)
+ *   wm_window_batch       ← the three above back to back for one MCAS window / stage-2 pass (src/map.c:69-84, 222-254, 375-430),
+ *                           resident in HBM from the read codes to the chains: what wm_map_reads uses
  *   wm_map_reads          ← kt_for(worker_for) → mm_map_frag, src/map.c:1164, 1008, 279-974
  *   wm_index_upload       ← the in-memory mm_idx_t (src/minimap.h:66-77) flattened for HBM.
  *
@@ -184,7 +186,24 @@ int wm_seed_batch(wm_ctx_t *ctx, int n, const wm128_t *mini, const uint64_t *min
 typedef struct { int32_t max_dist_x, min_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc; float gap_scale; } wm_chain_par_t;
 int wm_chain_batch(wm_ctx_t *ctx, int n, wm128_t *a, const uint64_t *a_off, const int32_t *n_a, const wm_chain_par_t *par,
                    uint64_t *u, uint64_t *u_off, int32_t *n_u, int32_t *n_v);
-/* kernel time of the last sketch/seed/chain batch call (HIP events on the context stream), ms */
+/* One device call per MCAS window or stage-2 pass (src/map.c:334-341, 700-900): mm_sketch → collect_seed_hits (incl. radix_sort_128x with the
+ * reference's tie permutation, src/ksort.h:101-151) → mm_chain_dp (fill AND extraction, src/chain.c:22-167), nothing leaving HBM in between.
+ * Job i: its sequence is len codes starting at code seq_off of the resident read codes (wm_reads_upload) when seq_off >= 0, at seqs + stage_off
+ * when seq_off == -1 (e.g. stage 2's masked copy of a read), or absent (seq_off == -2). n_pre anchors pre[pre_off ..) are handed in (stage 2:
+ * the anchors collected in stage 1, src/map.c:739-781); the seeded anchors are appended to them and, when both are present, the union is sorted
+ * again (src/map.c:818-833). The anchors are then chained with `par`. Results: res[i] (rep_len as src/map.c:126), chains of job i =
+ * u_pool[res[i].u_off .. + n_u), their anchors regrouped by chain = a_pool[res[i].a_off .. + n_v). *u_used / *a_used receive the pool sizes
+ * needed; WM_ENOMEM if a capacity is too small (call again with larger pools). */
+typedef struct {
+	int64_t seq_off;
+	uint64_t stage_off, pre_off;
+	int32_t len, n_pre;
+	wm_chain_par_t par;
+} wm_window_job_t;
+typedef struct { int32_t n_anchors, rep_len, n_mini, n_u, n_v; uint32_t u_off, a_off; } wm_window_res_t;
+int wm_window_batch(wm_ctx_t *ctx, int n, const wm_window_job_t *jobs, const uint8_t *seqs, size_t seqs_bytes, const wm128_t *pre, size_t n_pre_total,
+                    int max_occ, int64_t flag, wm_window_res_t *res, uint64_t *u_pool, size_t u_cap, size_t *u_used, wm128_t *a_pool, size_t a_cap, size_t *a_used);
+/* kernel time of the last sketch/seed/chain/window batch call (HIP events on the context stream), ms */
 float wm_last_aux_ms(const wm_ctx_t *ctx);
 
 /* ---- the mapper: replacement of kt_for(worker_for) (src/map.c:1164) ---------------------------------- */
@@ -254,7 +273,7 @@ int wm_mapper_stats(const wm_mapper_t *m, uint64_t *out9);
 int wm_mapper_kernel_stats(const wm_mapper_t *m, double *out, int cap, int *n_classes);
 /* where the host time of the mapping calls went since wm_mapper_create (seconds, summed over the worker threads; the host replaces
  * kt_for(worker_for), src/map.c:1164): out[0] = CPU time running the per-read glue, out[1] = wall time asleep waiting for device results,
- * out[2..5] = CPU time inside the batched sketch / seed / chain / ksw calls, out[6..9] = their wall time, out[10..13] = number of
+ * out[2..5] = CPU time inside the batched window (sketch → seed → sort → chain, one call) / seed / chain / ksw calls, out[6..9] = their wall time, out[10..13] = number of
  * batched calls, out[14] = wall time of the mapping phase, out[15] = wall time formatting records, out[16] = worker threads, out[17] = CPU time idle workers spent helping the host-side loops of running batched calls. cap >= 18. */
 int wm_mapper_host_stats(const wm_mapper_t *m, double *out, int cap);
 /* SAM header lines (@SQ.., @PG) as mm_write_sam_hdr (src/format.c:118-139) */

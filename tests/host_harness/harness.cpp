@@ -9,6 +9,7 @@
 #include "../../winnowmap_amd/csrc/host/wm_align.cpp"
 #include "../../winnowmap_amd/csrc/host/wm_mapper.cpp"
 #include "../../winnowmap_amd/csrc/host/wm_chain.cpp"
+#include "../../winnowmap_amd/csrc/host/wm_ops.cpp"
 #include "../../winnowmap_amd/csrc/host/wm_format.cpp"
 #include "../../winnowmap_amd/csrc/host/wm_pipeline.cpp"
 #include "../../oracle/wm_oracle.h"

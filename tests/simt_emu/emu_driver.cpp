@@ -9,6 +9,7 @@
 #include "ksw_plan.h"
 #include "sketch_kernel.h"
 #include "seedchain_kernel.h"
+#include "window_kernel.h"
 #include <vector>
 #include <algorithm>
 #include <thread>
@@ -299,6 +300,80 @@ int emu_chain_fill(int64_t n, const uint64_t *ax, const uint64_t *ay, int max_di
 		wmk::chain_wave(jb, a.data(), W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), f, p, gt.data());
 	for (int64_t i = 0; i < n; ++i) v[i] = p[i] >= 0 && v[p[i]] > f[i] ? v[p[i]] : f[i];   // the peak score is derived by the caller (as wm_chain_batch does)
 	return 0;
+}
+
+// ---- the fused window path (window_kernel.h) ----
+// collect_seed_hits through win_seed_wave: n_pre handed-in anchors first, then the seeded ones (unsorted); res_out = n_a, rep_len, err
+int emu_win_seed(const uint64_t *hkey, const uint64_t *hval, const uint64_t *P, int hbits, const uint64_t *mx, const uint64_t *my, int n_mini, int qlen,
+                 int max_occ, int flag, int n_pre, const uint64_t *px, const uint64_t *py, uint64_t *ax, uint64_t *ay, int cap, int32_t *res_out)
+{
+	wm_index_view_t ix = { hkey, hval, P, hbits, 0 };
+	std::vector<wm128_t> mini(n_mini + 1), pre(n_pre + 1), pool(cap + 64);
+	for (int i = 0; i < n_mini; ++i) mini[i].x = mx[i], mini[i].y = my[i];
+	for (int i = 0; i < n_pre; ++i) pre[i].x = px[i], pre[i].y = py[i];
+	wm_win_job_t jb;
+	memset(&jb, 0, sizeof(jb));
+	jb.seq_off = 0; jb.len = qlen; jb.n_pre = n_pre; jb.max_occ = max_occ; jb.seed_flag = flag;
+	std::vector<int> occ(n_mini + 1), emit(n_mini + 1);
+	std::vector<uint32_t> first(n_mini + 1);
+	uint64_t used = 7;                          // (the pool is shared by the jobs of a call: this job does not start at 0)
+	wm_win_res_t res;
+	memset(&res, 0, sizeof(res));
+	simt::exec_mask() = ~0ull;
+	wmk::win_seed_wave(ix, jb, mini.data(), n_mini, pre.data(), occ.data(), first.data(), emit.data(), pool.data(), &used, (uint64_t)cap, &res);
+	for (int i = 0; i < res.n_a; ++i) ax[i] = pool[res.a_off + i].x, ay[i] = pool[res.a_off + i].y;
+	res_out[0] = res.n_a; res_out[1] = res.rep_len; res_out[2] = res.err;
+	return 0;
+}
+
+// radix_sort_128x through win_sort_wave (in place); global != 0: the global-memory instantiation
+int emu_win_sort(int n, uint64_t *x, uint64_t *y, int global)
+{
+	std::vector<wm128_t> a(n + 1);
+	for (int i = 0; i < n; ++i) a[i].x = x[i], a[i].y = y[i];
+	std::vector<int> ws(wmk::WIN_WS_INTS, 0x5a5a5a5a);
+	simt::exec_mask() = ~0ull;
+	if (global) wmk::win_sort_wave<true>(a.data(), n, ws.data()); else wmk::win_sort_wave<false>(a.data(), n, ws.data());
+	for (int i = 0; i < n; ++i) x[i] = a[i].x, y[i] = a[i].y;
+	return 0;
+}
+
+// avg_qspan + kernel class of the fill through win_plan_wave
+int emu_win_plan(int n, const uint64_t *x, const uint64_t *y, int max_dist_x, float *avg_out, int *klass_out)
+{
+	std::vector<wm128_t> a(n + 1);
+	for (int i = 0; i < n; ++i) a[i].x = x[i], a[i].y = y[i];
+	wm_win_job_t jb;
+	memset(&jb, 0, sizeof(jb));
+	jb.max_dist_x = max_dist_x;
+	wm_chain_job_t cj[1];
+	int lists[4] = { -1, -1, -1, -1 }, counts[4] = { 0, 0, 0, 0 };
+	simt::exec_mask() = ~0ull;
+	wmk::win_plan_wave(jb, 0, 0, n, a.data(), cj, lists, counts, 1);
+	*avg_out = cj[0].avg_qspan;
+	*klass_out = -1;
+	for (int k = 0; k < 4; ++k) if (counts[k] == 1 && lists[k] == 0) *klass_out = k;
+	return 0;
+}
+
+// mm_chain_dp after the fill (src/chain.c:89-165) through win_extract_wave; a is overwritten with the chained anchors; returns n_v
+int emu_win_extract(int n, uint64_t *ax, uint64_t *ay, const int32_t *f_in, const int32_t *p_in, int min_cnt, int min_sc, int global, int *n_u_out, uint64_t *u_out)
+{
+	std::vector<wm128_t> a(n + 1), b(n + 1), wb(n + 1);
+	for (int i = 0; i < n; ++i) a[i].x = ax[i], a[i].y = ay[i];
+	std::vector<int> f(f_in, f_in + n), p(p_in, p_in + n), v(n + 1, 0x5a5a5a5a), t(n + 1, 0x5a5a5a5a);
+	f.push_back(0); p.push_back(0);
+	std::vector<uint64_t> zu(2 * (size_t)n + 2, 0x5a5a5a5a5a5a5a5aull);
+	std::vector<int> ws(wmk::WIN_WS_INTS, 0x5a5a5a5a);
+	wm_win_res_t res;
+	memset(&res, 0, sizeof(res));
+	simt::exec_mask() = ~0ull;
+	if (global) wmk::win_extract_wave<true>(n, min_cnt, min_sc, a.data(), f.data(), p.data(), v.data(), t.data(), zu.data(), b.data(), wb.data(), ws.data(), &res);
+	else wmk::win_extract_wave<false>(n, min_cnt, min_sc, a.data(), f.data(), p.data(), v.data(), t.data(), zu.data(), b.data(), wb.data(), ws.data(), &res);
+	*n_u_out = res.n_u;
+	for (int i = 0; i < res.n_u; ++i) u_out[i] = zu[(size_t)n + i];
+	for (int i = 0; i < res.n_v; ++i) ax[i] = a[i].x, ay[i] = a[i].y;
+	return res.n_v;
 }
 
 } // extern "C"

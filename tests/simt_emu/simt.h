@@ -200,4 +200,16 @@ inline int cld(int *p, long long idx) { return p[idx]; }
 template <class I> void cst(int *p, const V<I> &idx, const V<int> &v) { gst(p, idx, v); }
 inline void cst(int *p, long long idx, int v) { if (exec_mask()) p[idx] = v; }
 
+// ---- additions for the fused window kernels ---------------------------------------------------------------------------------
+#define WM_LANE0_BEGIN {
+#define WM_LANE0_END }
+inline uint64_t wave_or_u64(const V<uint64_t> &k) { WM_EMU_ASSERT(exec_mask() == ~0ull); uint64_t m = 0; for (int i = 0; i < WAVE; ++i) m |= k.v[i]; return m; }
+inline uint64_t wave_and_u64(const V<uint64_t> &k) { WM_EMU_ASSERT(exec_mask() == ~0ull); uint64_t m = ~0ull; for (int i = 0; i < WAVE; ++i) m &= k.v[i]; return m; }
+inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
+template <class I> void atomic_inc(int *p, const V<I> &idx) { for (int i = 0; i < WAVE; ++i) if (on(i)) ++p[idx.v[i]]; }
+inline uint64_t wave_alloc(uint64_t *counter, uint64_t n) { return __atomic_fetch_add(counter, n, __ATOMIC_RELAXED); }
+inline int wave_append(int *counter) { return __atomic_fetch_add(counter, 1, __ATOMIC_RELAXED); }
+
+inline V<int> mbcnt(uint64_t mask) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = __builtin_popcountll(mask & ((i ? ((uint64_t)1 << i) : (uint64_t)1) - 1)); return r; }
+
 } // namespace simt

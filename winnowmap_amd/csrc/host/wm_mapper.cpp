@@ -26,9 +26,10 @@ inline uint32_t read_hash(const char *qname, int qlen, int seed)
 	return wang_hash32(h);
 }
 
-// chaining + region generation + alignment + MAPQ on a given sorted anchor set (src/map.c:375-430 and :880-933)
-void chain_and_align(Scheduler &sch, const Index &idx, const MapOpt &o, float gap_scale, const uint8_t *codes, int64_t dev_off, int qlen, uint32_t hash,
-                     std::vector<m128> &&anchors, int rep_len, Segment &out, int *frag_gap)
+// One window from its codes to aligned regions: sketch → seed → [anchors handed in] → chain in ONE device call (WindowReq), then region
+// generation + alignment + MAPQ on the chains (src/map.c:69-84, 222-254, 375-430 and :880-933)
+void window_and_align(Scheduler &sch, const Index &idx, const MapOpt &o, float gap_scale, const uint8_t *seq_codes, int64_t seq_dev_off, bool sketch_it,
+                      const uint8_t *codes, int64_t dev_off, int qlen, uint32_t hash, std::vector<m128> &&pre, int *rep_len_io, Segment &out, int *frag_gap)
 {
 	const int max_gap_qry = o.max_gap;
 	int max_gap_ref;
@@ -38,15 +39,19 @@ void chain_and_align(Scheduler &sch, const Index &idx, const MapOpt &o, float ga
 	const int min_gap_ref = o.min_gap_ref < max_gap_ref ? o.min_gap_ref : max_gap_ref;
 	if (frag_gap) *frag_gap = max_gap_ref;
 
-	ChainReq cr;
-	cr.max_dist_x = max_gap_ref; cr.min_dist_x = min_gap_ref; cr.max_dist_y = max_gap_qry; cr.bw = o.bw;
-	cr.max_skip = o.max_chain_skip; cr.max_iter = o.max_chain_iter; cr.min_cnt = o.min_cnt; cr.min_sc = o.min_chain_score;
-	cr.gap_scale = gap_scale;
-	cr.a = std::move(anchors);
-	if (!cr.a.empty()) sch.chain(cr);
-	out.a = std::move(cr.a);
+	WindowReq wr;
+	if (sketch_it) { wr.seq = seq_codes; wr.len = qlen; wr.dev_off = seq_dev_off; }
+	wr.pre = std::move(pre);
+	wr.max_occ = o.mid_occ; wr.flag = o.flag;
+	wr.max_dist_x = max_gap_ref; wr.min_dist_x = min_gap_ref; wr.max_dist_y = max_gap_qry; wr.bw = o.bw;
+	wr.max_skip = o.max_chain_skip; wr.max_iter = o.max_chain_iter; wr.min_cnt = o.min_cnt; wr.min_sc = o.min_chain_score;
+	wr.gap_scale = gap_scale;
+	if (wr.len > 0 || !wr.pre.empty()) sch.window(wr);
+	if (sketch_it) *rep_len_io = wr.rep_len;
+	const int rep_len = *rep_len_io;
+	out.a = std::move(wr.a);
 	out.rep_len = rep_len;
-	out.regs = gen_regs(hash, qlen, (int)cr.u.size(), cr.u.data(), out.a.data());
+	out.regs = gen_regs(hash, qlen, (int)wr.u.size(), wr.u.data(), out.a.data());
 	// chain_post (src/map.c:256-265)
 	if (!(o.flag & F_ALL_CHAINS)) {
 		set_parent(o.mask_level, o.mask_len, out.regs, o.a * 2 + o.b, (o.flag & F_HARD_MLEVEL) != 0);
@@ -63,17 +68,6 @@ void chain_and_align(Scheduler &sch, const Index &idx, const MapOpt &o, float ga
 		}
 	}
 	set_mapq(out.regs, o.min_chain_score, o.a, rep_len, 0);
-}
-
-// sketch → seed: collect_minimizers + collect_seed_hits (src/map.c:69-84, 222-254)
-void sketch_and_seed(Scheduler &sch, const MapOpt &o, const uint8_t *codes, int64_t dev_off, int len, std::vector<m128> &anchors, int *rep_len)
-{
-	SketchReq sk; sk.seq = codes; sk.len = len; sk.dev_off = dev_off;
-	sch.sketch(sk);
-	SeedReq sd; sd.mini = sk.mini.data(); sd.n_mini = (int)sk.mini.size(); sd.qlen = len; sd.max_occ = o.mid_occ; sd.flag = o.flag;
-	if (sd.n_mini > 0) sch.seed(sd);
-	anchors = std::move(sd.a);
-	*rep_len = sd.rep_len;
 }
 
 struct ReadTask {
@@ -98,11 +92,9 @@ void stage1_position(Scheduler &sch, const Index &idx, const MapOpt &opt, const 
 			const int start = dir == 0 ? sub_begin : sub_begin - sub_len + 1;
 			if (dir == 0 ? (sub_begin + sub_len > L) : (start < 0)) continue;
 			Segment S;
-			std::vector<m128> anchors;
 			int rep_len = 0;
 			const int64_t dev = T.dev_off >= 0 ? T.dev_off + start : -1;
-			sketch_and_seed(sch, o2, T.codes + start, dev, sub_len, anchors, &rep_len);
-			chain_and_align(sch, idx, o2, opt.chain_gap_scale, T.codes + start, dev, sub_len, read_hash(qname, sub_len, o2.seed), std::move(anchors), rep_len, S, 0);
+			window_and_align(sch, idx, o2, opt.chain_gap_scale, T.codes + start, dev, true, T.codes + start, dev, sub_len, read_hash(qname, sub_len, o2.seed), std::vector<m128>(), &rep_len, S, 0);
 			for (const Reg &r : S.regs) {
 				if ((int)r.mapq >= o2.min_mapq && r.blen >= o2.min_qcov * sub_len && r.cnt > 0) {
 					found = true;
@@ -148,21 +140,17 @@ void stage2(Scheduler &sch, const Index &idx, const MapOpt &opt, ReadTask &T)
 	} }
 	size_t unmapped = 0;
 	for (int i = 0; i < L; ++i) unmapped += T.mapped[i] == 0;
-	if (!a.empty() && unmapped > 0) {                                  // seeds from the stretches stage 1 left unmapped (:786-846)
-		std::vector<uint8_t> masked(T.codes, T.codes + L);
-		for (int i = 0; i < L; ++i) if (T.mapped[i]) masked[i] = 4;
-		std::vector<m128> rest;
-		sketch_and_seed(sch, o3, masked.data(), -1, L, rest, &rep_len);             // (a masked copy: not resident)
-		a.insert(a.end(), rest.begin(), rest.end());
-		radix_sort_128x(a.data(), a.data() + a.size());
-	}
-	if (a.empty()) {                                                   // plain minimap2-style mapping with the user's options (:849-865)
-		o3 = opt;
-		sketch_and_seed(sch, o3, T.codes, T.dev_off, L, a, &rep_len);
-	}
 	Segment S;
 	int frag_gap = 0;
-	chain_and_align(sch, idx, o3, opt.chain_gap_scale, T.codes, T.dev_off, L, hash, std::move(a), rep_len, S, &frag_gap);
+	if (!a.empty() && unmapped > 0) {                                  // seeds from the stretches stage 1 left unmapped join the collected anchors (:786-846)
+		std::vector<uint8_t> masked(T.codes, T.codes + L);
+		for (int i = 0; i < L; ++i) if (T.mapped[i]) masked[i] = 4;
+		window_and_align(sch, idx, o3, opt.chain_gap_scale, masked.data(), -1, true, T.codes, T.dev_off, L, hash, std::move(a), &rep_len, S, &frag_gap);   // (a masked copy: not resident)
+	} else if (a.empty()) {                                            // plain minimap2-style mapping with the user's options (:849-865)
+		o3 = opt;
+		window_and_align(sch, idx, o3, opt.chain_gap_scale, T.codes, T.dev_off, true, T.codes, T.dev_off, L, hash, std::vector<m128>(), &rep_len, S, &frag_gap);
+	} else                                                             // the collected anchors cover the read: chain them as they are
+		window_and_align(sch, idx, o3, opt.chain_gap_scale, 0, -1, false, T.codes, T.dev_off, L, hash, std::move(a), &rep_len, S, &frag_gap);
 	T.out->regs = std::move(S.regs);
 	T.out->rep_len = rep_len;
 	T.out->frag_gap = frag_gap;
@@ -275,12 +263,13 @@ void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::v
 	work(0);
 	for (auto &x : th) x.join();
 	if (stats) {
-		stats->n_flush += hub.n_batches[OP_SKETCH] + hub.n_batches[OP_SEED] + hub.n_batches[OP_CHAIN] + hub.n_batches[OP_KSW] + hub.n_batches[OP_KSW_HEAVY] + hub.n_batches[OP_KSW_HUGE];
-		stats->n_ksw += hub.n_reqs[OP_KSW] + hub.n_reqs[OP_KSW_HEAVY] + hub.n_reqs[OP_KSW_HUGE]; stats->n_chain += hub.n_reqs[OP_CHAIN]; stats->n_seed += hub.n_reqs[OP_SEED]; stats->n_sketch += hub.n_reqs[OP_SKETCH];
+		for (int op = 0; op < OP_N; ++op) stats->n_flush += hub.n_batches[op];
+		stats->n_ksw += hub.n_reqs[OP_KSW] + hub.n_reqs[OP_KSW_HEAVY] + hub.n_reqs[OP_KSW_HUGE]; stats->n_chain += hub.n_reqs[OP_CHAIN]; stats->n_seed += hub.n_reqs[OP_SEED];
+		stats->n_sketch += hub.n_reqs[OP_SKETCH] + hub.n_reqs[OP_WINDOW];           // (windows: every window is sketched, seeded and chained in one call)
 		if (getenv("WM_TRACE")) { for (auto &e : hub.site_cpu) fprintf(stderr, "[site] %-28s %8.2f s CPU\n", e.first, e.second); }
 		stats->cpu_fiber += hub.cpu_fiber; stats->wall_idle += hub.wall_idle; stats->cpu_help += hub.cpu_help;
-		for (int op = 0; op < OP_N; ++op) {           // (the heavy alignment queue is reported with the ksw operation)
-			const int o = op >= OP_KSW_HEAVY ? OP_KSW : op;
+		for (int op = 0; op < OP_N; ++op) {           // (the heavy alignment queues are reported with the ksw operation, the fused window call in the first slot)
+			const int o = op == OP_WINDOW ? 0 : op >= OP_KSW_HEAVY ? OP_KSW : op;
 			stats->n_batches[o] += hub.n_batches[op]; stats->cpu_op[o] += hub.cpu_op[op]; stats->wall_op[o] += hub.wall_op[op];
 		}
 	}

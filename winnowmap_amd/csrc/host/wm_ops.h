@@ -1,5 +1,5 @@
 // wm_ops.h — the batched device operations the host mapper is written against. The product wires the HIP
-// implementation (GpuOps in wm_gpu_ops.cpp → libwmgpu kernels). The interface exists so that the host glue can be
+// implementation (GpuOps in wm_gpu.hip → libwmgpu kernels). The interface exists so that the host glue can be
 // exercised by the test-suite with a checker-backed implementation (tests/host_harness) on a machine with no GPU;
 // nothing in the product constructs anything but GpuOps.
 #pragma once
@@ -30,6 +30,22 @@ struct ChainReq {                  // mm_chain_dp (src/chain.c:22); consumes `a`
 	std::vector<uint64_t> u;       // out: score<<32 | count per chain
 };
 
+// One MCAS window or stage-2 pass from the sequence to the chains (src/map.c:69-84, 222-254, 375-430; src/chain.c:22-167): mm_sketch of
+// `seq` (if any), collect_seed_hits, the handed-in anchors `pre` (stage 2: what stage 1 collected, already sorted) in front of the seeded
+// ones and the union sorted again when both are present (src/map.c:818-833), then mm_chain_dp. A device implementation keeps everything
+// between the codes and the chains in HBM (wm_window_batch).
+struct WindowReq {
+	const uint8_t *seq = 0; int len = 0;   // 0..4 codes (host view); len == 0: no sequence, only `pre` is chained
+	int64_t dev_off = -1;                  // offset of seq[0] in the resident read codes, -1 = not resident (the view is staged)
+	std::vector<m128> pre;                 // in
+	int max_occ = 0; int64_t flag = 0;     // collect_seed_hits
+	int max_dist_x = 0, min_dist_x = 0, max_dist_y = 0, bw = 0, max_skip = 0, max_iter = 0, min_cnt = 0, min_sc = 0;   // mm_chain_dp
+	float gap_scale = 1.0f;
+	std::vector<m128> a;                   // out: anchors grouped by chain
+	std::vector<uint64_t> u;               // out: score<<32 | count per chain
+	int rep_len = 0, n_anchors = 0;        // out: src/map.c:126; anchors before chaining
+};
+
 struct KswReq {                    // ksw_extd2_sse (src/ksw2.h:60)
 	// host views: element i of the query is qp[i * step], of the target tp[i * step]; step = -1 for the left extension, which aligns
 	// both sequences reversed (src/align.c:690-705). Valid while the request is pending.
@@ -42,7 +58,7 @@ struct KswReq {                    // ksw_extd2_sse (src/ksw2.h:60)
 	int64_t qwin_off = -1; int32_t qwin_len = 0, q_pos = 0, rid = -1, t_pos = 0;
 	bool has_n = true;
 	int w = 0, zdrop = 0, end_bonus = 0, flag = 0;
-	wm_ksw_result_t ez;            // out
+	wm_ksw_result_t ez = {};       // out
 	std::vector<uint32_t> cigar;   // out
 	int qlen() const { return ql; }
 	int tlen() const { return tl; }
@@ -65,6 +81,9 @@ struct DeviceOps {
 	virtual void seed_batch(std::vector<SeedReq*> &reqs) = 0;
 	virtual void chain_batch(std::vector<ChainReq*> &reqs) = 0;
 	virtual void ksw_batch(const wm_ksw_score_t &sc, std::vector<KswReq*> &reqs) = 0;
+	// the whole window in one call. The default composes it from the three operations above (checker-backed implementations in the
+	// test-suite); the product's GpuOps overrides it with the HBM-resident wm_window_batch.
+	virtual void window_batch(int w, int k, std::vector<WindowReq*> &reqs);
 };
 
 } // namespace wm

@@ -143,4 +143,48 @@ WM_DEV void cst8(signed char *p, long long i, int v) { __hip_atomic_store(p + i,
 WM_DEV int cld(int *p, long long i) { return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 WM_DEV void cst(int *p, long long i, int v) { __hip_atomic_store(p + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// ---- additions for the fused window kernels (window_kernel.h) ----------------------------------------------------------------
+// a section executed by lane 0 only, written as plain scalar C++ on raw pointers (no V<> values inside): the sequential parts of the
+// reference's algorithms (the cycle-leader permutation of radix_sort_128x, chain backtracking) run literally, one lane per wavefront
+#define WM_LANE0_BEGIN if ((threadIdx.x & 63u) == 0u) {
+#define WM_LANE0_END }
+WM_DEV uint64_t readlane(uint64_t x, int l)
+{
+	const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(x >> 32), l);
+	return (uint64_t)hi << 32 | lo;
+}
+WM_DEV uint64_t wave_or_u64(uint64_t k)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) k |= (uint64_t)__shfl_xor((long long)k, o, 64);
+	return k;
+}
+WM_DEV uint64_t wave_and_u64(uint64_t k)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) k &= (uint64_t)__shfl_xor((long long)k, o, 64);
+	return k;
+}
+WM_DEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
+// per-lane atomic add on an LDS (or global) counter; the old value is not needed
+WM_DEV void atomic_inc(int *p, int idx) { atomicAdd(p + idx, 1); }
+// wave-uniform bump allocation: lane 0 adds `n` to the global counter, every lane receives the old value
+WM_DEV uint64_t wave_alloc(uint64_t *counter, uint64_t n)
+{
+	uint64_t old = 0;
+	if ((threadIdx.x & 63u) == 0u) old = (uint64_t)atomicAdd((unsigned long long*)counter, (unsigned long long)n);
+	const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)old), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(old >> 32));
+	return (uint64_t)hi << 32 | lo;
+}
+// wave-uniform append to a device list: returns the slot index
+WM_DEV int wave_append(int *counter)
+{
+	int old = 0;
+	if ((threadIdx.x & 63u) == 0u) old = atomicAdd(counter, 1);
+	return __builtin_amdgcn_readfirstlane(old);
+}
+
+// number of set bits of `mask` below this lane (v_mbcnt)
+WM_DEV int mbcnt(uint64_t mask) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u)); }
+
 } // namespace simt

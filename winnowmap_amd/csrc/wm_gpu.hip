@@ -49,6 +49,7 @@ static inline double now_ms() { return std::chrono::duration<double, std::milli>
 #include "ksw_plan.h"
 #include "sketch_kernel.h"
 #include "seedchain_kernel.h"
+#include "window_kernel.h"
 
 // ======================================================================================================
 // kernels
@@ -965,6 +966,7 @@ catch (const std::bad_alloc &) { return set_err(WM_ENOMEM, "out of host memory")
 #include "host/wm_seqio.cpp"
 #include "host/wm_hit.cpp"
 #include "host/wm_chain.cpp"
+#include "host/wm_ops.cpp"
 #include "host/wm_align.cpp"
 #include "host/wm_mapper.cpp"
 #include "host/wm_format.cpp"
@@ -1684,6 +1686,298 @@ try {
 catch (const std::bad_alloc &) { return set_err(WM_ENOMEM, "out of host memory"); }
 
 // ======================================================================================================
+// wm_window_batch: sketch → seed → sort → chain fill → chain extraction of n jobs, resident in HBM (window_kernel.h)
+// ======================================================================================================
+__global__ __launch_bounds__(64) void win_seed_kernel(wm_index_view_t ix, const wm_win_job_t *__restrict__ jobs, const wm_sketch_job_t *__restrict__ sj, const int *__restrict__ mcnt,
+                                                       const wm128_t *__restrict__ mini_pool, const wm128_t *__restrict__ pre_pool, int *occ, uint32_t *first, int *emit,
+                                                       wm128_t *anchors, uint64_t *used, uint64_t cap, wm_win_res_t *res)
+{
+	const int j = blockIdx.x;
+	const wm_win_job_t jb = jobs[j];
+	const wm_sketch_job_t s = sj[j];
+	int n_mini = jb.seq_off >= 0 ? mcnt[j] : 0;
+	const bool over = n_mini > s.cap;                       // the minimizer slot was too small: the caller retries with full-size slots
+	if (over) n_mini = 0;
+	wmk::win_seed_wave(ix, jb, mini_pool + s.out_off, n_mini, pre_pool + jb.pre_off, occ + s.out_off, first + s.out_off, emit + s.out_off, anchors, used, cap, res + j);
+	if (over && threadIdx.x == 0) res[j].err = 1;
+}
+
+// radix_sort_128x of the seeded anchors (src/map.c:252), of the union with the handed-in ones (src/map.c:833), then avg_qspan + the fill's class.
+// lds_cap = anchors that fit the dynamic LDS of this launch; a job runs in the launch whose range (lo, lds_cap] holds its size, the last launch
+// (lds_cap = 0) takes the rest in global memory
+__global__ __launch_bounds__(64) void win_sort_kernel(const wm_win_job_t *__restrict__ jobs, const wm_win_res_t *res, wm128_t *anchors, wm_chain_job_t *cj,
+                                                       int *lists, int *counts, int n_jobs, int lo, int lds_cap)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	int *ws = (int*)smem;
+	wm128_t *stage = (wm128_t*)(ws + ((wmk::WIN_WS_INTS + 3) & ~3));
+	const int j = blockIdx.x;
+	const wm_win_res_t r = res[j];
+	const int n = r.n_a;
+	if (n <= lo || (lds_cap > 0 && n > lds_cap) || r.err) return;
+	const wm_win_job_t jb = jobs[j];
+	wm128_t *a = anchors + r.a_off;
+	const bool seeded = jb.seq_off >= 0;
+	const int n_pre = jb.n_pre < n ? jb.n_pre : n;
+	if (lds_cap > 0) {
+		uint64_t *ga = (uint64_t*)a, *la = (uint64_t*)stage;
+		if (seeded) {
+			for (int i = threadIdx.x; i < 2 * n; i += 64) la[i] = ga[i];
+			simt::lds_sync();
+			wmk::win_sort_wave<false>(stage + n_pre, n - n_pre, ws);
+			if (n_pre > 0) wmk::win_sort_wave<false>(stage, n, ws);
+			simt::lds_sync();
+			for (int i = threadIdx.x; i < 2 * n; i += 64) ga[i] = la[i];
+			wmk::win_plan_wave(jb, j, r.a_off, n, stage, cj, lists, counts, n_jobs);
+		} else wmk::win_plan_wave(jb, j, r.a_off, n, a, cj, lists, counts, n_jobs);
+	} else {
+		if (seeded) {
+			wmk::win_sort_wave<true>(a + n_pre, n - n_pre, ws);
+			if (n_pre > 0) wmk::win_sort_wave<true>(a, n, ws);
+			simt::mem_sync_agent();
+		}
+		wmk::win_plan_wave(jb, j, r.a_off, n, a, cj, lists, counts, n_jobs);
+	}
+}
+
+// the fills of seedchain_kernel.h over a device-side job list (block b serves list[b]; blocks beyond *count leave)
+__global__ __launch_bounds__(64) void win_chain_kernel(const wm_chain_job_t *jobs, const int *list, const int *count, const wm128_t *anchors, int *fpvt, int W)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	if ((int)blockIdx.x >= *count) return;
+	const wm_chain_job_t jb = jobs[list[blockIdx.x]];
+	uint64_t *sx = (uint64_t*)smem, *sy = sx + W;
+	int *sf = (int*)(sy + W), *sp = sf + W, *st = sp + W;
+	int *gf = fpvt + jb.a_off * 4, *gp = gf + jb.n, *gt = gp + 2 * (size_t)jb.n;
+	wmk::chain_wave(jb, anchors, W, sx, sy, sf, sp, st, gf, gp, gt);
+}
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void win_chain_kernel_block(const wm_chain_job_t *jobs, const int *list, const int *count, const wm128_t *anchors, int *fpvt, int W)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	if ((int)blockIdx.x >= *count) return;
+	const wm_chain_job_t jb = jobs[list[blockIdx.x]];
+	uint64_t *sx = (uint64_t*)smem, *sy = sx + W;
+	int *sf = (int*)(sy + W), *sp = sf + W, *st = sp + W, *pub = st + W;
+	int *gf = fpvt + jb.a_off * 4, *gp = gf + jb.n, *gt = gp + 2 * (size_t)jb.n;
+	wmk::chain_block(jb, anchors, NWV, W, sx, sy, sf, sp, st, pub, gf, gp, gt);
+}
+
+// src/chain.c:89-165 per job; f, p staged in LDS when the job fits (lo, lds_cap], global slab otherwise (lds_cap = 0)
+__global__ __launch_bounds__(64) void win_extract_kernel(const wm_win_job_t *__restrict__ jobs, wm_win_res_t *res, wm128_t *anchors, int *fpvt, uint64_t *zu, wm128_t *bbuf, wm128_t *wbuf,
+                                                          int lo, int lds_cap)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	int *ws = (int*)smem;
+	const int j = blockIdx.x;
+	const wm_win_res_t r = res[j];
+	const int n = r.n_a;
+	if (n <= lo || (lds_cap > 0 && n > lds_cap) || r.err) return;
+	const wm_win_job_t jb = jobs[j];
+	int *gf = fpvt + r.a_off * 4, *gp = gf + n, *gv = gp + n, *gt = gv + n;
+	if (lds_cap > 0) {
+		int *lf = ws + ((wmk::WIN_WS_INTS + 3) & ~3), *lp = lf + lds_cap, *lv = lp + lds_cap, *lt = lv + lds_cap;
+		for (int i = threadIdx.x; i < n; i += 64) { lf[i] = gf[i]; lp[i] = gp[i]; }
+		simt::lds_sync();
+		wmk::win_extract_wave<false>(n, jb.min_cnt, jb.min_sc, anchors + r.a_off, lf, lp, lv, lt, zu + 2 * r.a_off, bbuf + r.a_off, wbuf + r.a_off, ws, res + j);
+	} else
+		wmk::win_extract_wave<true>(n, jb.min_cnt, jb.min_sc, anchors + r.a_off, gf, gp, gv, gt, zu + 2 * r.a_off, bbuf + r.a_off, wbuf + r.a_off, ws, res + j);
+}
+
+// exclusive prefix sums of n_u and n_v over the jobs (single block) -> res[j].u_out / v_out, totals[0..1]; totals[2] = worst err
+__global__ __launch_bounds__(1024) void win_scan_kernel(int n, wm_win_res_t *res, uint32_t *totals)
+{
+	__shared__ uint32_t pu[1024], pv[1024];
+	__shared__ int perr[1024];
+	const int tid = threadIdx.x, per = (n + 1023) / 1024, b = tid * per, e = b + per < n ? b + per : n;
+	uint32_t su = 0, sv = 0; int er = 0;
+	for (int i = b; i < e; ++i) { su += (uint32_t)res[i].n_u; sv += (uint32_t)res[i].n_v; er = res[i].err > er ? res[i].err : er; }
+	pu[tid] = su; pv[tid] = sv; perr[tid] = er;
+	__syncthreads();
+	if (tid == 0) {
+		uint32_t au = 0, av = 0; int ae = 0;
+		for (int i = 0; i < 1024; ++i) { uint32_t t = pu[i]; pu[i] = au; au += t; t = pv[i]; pv[i] = av; av += t; ae = perr[i] > ae ? perr[i] : ae; }
+		totals[0] = au; totals[1] = av; totals[2] = (uint32_t)ae;
+	}
+	__syncthreads();
+	su = pu[tid]; sv = pv[tid];
+	for (int i = b; i < e; ++i) { res[i].u_out = su; res[i].v_out = sv; su += (uint32_t)res[i].n_u; sv += (uint32_t)res[i].n_v; }
+}
+__global__ __launch_bounds__(64) void win_gather_kernel(const wm_win_res_t *__restrict__ res, const wm128_t *__restrict__ anchors, const uint64_t *__restrict__ zu,
+                                                         uint64_t *__restrict__ u_pool, wm128_t *__restrict__ v_pool)
+{
+	const int j = blockIdx.x;
+	const wm_win_res_t r = res[j];
+	const uint64_t *u2 = zu + 2 * r.a_off + r.n_a;
+	const wm128_t *a = anchors + r.a_off;
+	for (int i = threadIdx.x; i < r.n_u; i += 64) u_pool[r.u_out + i] = u2[i];
+	for (int i = threadIdx.x; i < r.n_v; i += 64) v_pool[r.v_out + i] = a[i];
+}
+
+// device side of one call: everything up to the dense result pools; the caller copies them out. slot_full: full-size minimizer slots (retry)
+struct WinDev { wm_win_res_t *d_res; uint64_t *d_upool; wm128_t *d_vpool; uint32_t *d_tot; uint32_t tot[3]; };
+static int window_launch(wm_ctx_t *c, int n, const wm_window_job_t *jobs, const uint8_t *seqs, size_t seqs_bytes, const wm128_t *pre, size_t n_pre_total,
+                         int max_occ, int64_t flag, bool slot_full, WinDev &D)
+{
+	const int w = c->skp.w;
+	(void)w;
+	// host tables
+	UBuf<wm_win_job_t> jb(n, c);
+	UBuf<wm_sketch_job_t> sj(n, c);
+	UBuf<int> ord(n, c);
+	uint64_t slots = 0, mtot = 0, stage_hi = 0, pre_hi = 0;
+	int bad = -1;
+	for (int i = 0; i < n; ++i) {
+		const wm_window_job_t &s = jobs[i];
+		wm_win_job_t &d = jb[i];
+		const bool has_seq = s.seq_off >= -1 && s.len > 0;
+		if (s.len < 0 || s.n_pre < 0 || (s.n_pre > 0 && s.pre_off + (uint64_t)s.n_pre > n_pre_total) || s.seq_off < -2 ||
+		    (s.seq_off >= 0 && (!c->d_reads || (uint64_t)s.seq_off + (uint64_t)s.len > c->reads_bytes)) ||
+		    (s.seq_off == -1 && s.stage_off + (uint64_t)s.len > seqs_bytes)) { if (bad < 0) bad = i; }
+		d.seq_off = has_seq ? 0 : -1; d.pre_off = s.pre_off; d.len = s.len; d.n_pre = s.n_pre; d.max_occ = max_occ; d.seed_flag = (int32_t)(flag & (0x100000 | 0x200000));
+		d.max_dist_x = s.par.max_dist_x; d.min_dist_x = s.par.min_dist_x; d.max_dist_y = s.par.max_dist_y; d.bw = s.par.bw; d.max_skip = s.par.max_skip; d.max_iter = s.par.max_iter;
+		d.min_cnt = s.par.min_cnt; d.min_sc = s.par.min_sc; d.gap_scale = s.par.gap_scale; d.pad = 0;
+		wm_sketch_job_t &k = sj[i];
+		k.len = has_seq ? s.len : 0;
+		k.cap = has_seq ? (slot_full ? s.len + 1 : s.len / 8 + 16) : 0;
+		k.out_off = mtot; mtot += (uint64_t)k.cap;
+		k.scratch_off = slots; slots += (uint64_t)k.len;
+		k.seq_off = 0;
+		if (s.seq_off == -1 && has_seq) stage_hi = std::max<uint64_t>(stage_hi, s.stage_off + (uint64_t)s.len);
+		if (s.n_pre > 0) pre_hi = std::max<uint64_t>(pre_hi, s.pre_off + (uint64_t)s.n_pre);
+		ord[i] = i;
+	}
+	if (bad >= 0) return set_err(WM_EINVAL, "window job %d: sequence / anchors outside their buffers (or wm_reads_upload missing)", bad);
+	if (!(c->skp.k & 1) || c->skp.k < 2) return set_err(WM_EINVAL, "wm_window_batch needs an odd k (got %d)", c->skp.k);
+	std::sort(ord.begin(), ord.end(), [&](int x, int y) { return sj[x].len != sj[y].len ? sj[x].len > sj[y].len : x < y; });     // sketch: longest first
+	// device buffers
+	wm_win_job_t *d_jobs = (wm_win_job_t*)arena_take(c, (size_t)n * sizeof(wm_win_job_t));
+	wm_sketch_job_t *d_sj = (wm_sketch_job_t*)arena_take(c, (size_t)n * sizeof(wm_sketch_job_t));
+	int *d_ord = (int*)arena_take(c, (size_t)n * 4 + 64);
+	uint8_t *d_seqs = (uint8_t*)arena_take(c, stage_hi + 64);
+	wm128_t *d_pre = (wm128_t*)arena_take(c, (pre_hi + 1) * sizeof(wm128_t));
+	double *d_so = (double*)arena_take(c, (slots + 1) * 8);
+	uint64_t *d_sx = (uint64_t*)arena_take(c, (slots + 1) * 8);
+	uint32_t *d_sy = (uint32_t*)arena_take(c, (slots + 1) * 4), *d_sl = (uint32_t*)arena_take(c, (slots + 1) * 4);
+	wm128_t *d_mini = (wm128_t*)arena_take(c, (mtot + 1) * sizeof(wm128_t));
+	int *d_mcnt = (int*)arena_take(c, (size_t)n * 4 + 64);
+	int *d_occ = (int*)arena_take(c, (mtot + 1) * 4), *d_emit = (int*)arena_take(c, (mtot + 1) * 4);
+	uint32_t *d_first = (uint32_t*)arena_take(c, (mtot + 1) * 4);
+	D.d_res = (wm_win_res_t*)arena_take(c, (size_t)n * sizeof(wm_win_res_t) + 64);
+	wm_chain_job_t *d_cj = (wm_chain_job_t*)arena_take(c, (size_t)n * sizeof(wm_chain_job_t) + 64);
+	int *d_lists = (int*)arena_take(c, (size_t)n * 4 * 4 + 64);
+	uint64_t *d_ctr = (uint64_t*)arena_take(c, 64);          // [0] anchors used; ints at +8: the four class counts; uint32 at +32: totals
+	if (!d_jobs || !d_sj || !d_ord || !d_seqs || !d_pre || !d_so || !d_sx || !d_sy || !d_sl || !d_mini || !d_mcnt || !d_occ || !d_emit || !d_first || !D.d_res || !d_cj || !d_lists || !d_ctr)
+		return set_err(WM_ENOMEM, "window batch does not fit the arena");
+	int *d_counts = (int*)(d_ctr + 1);
+	D.d_tot = (uint32_t*)(d_ctr + 4);
+	// the rest of the arena is the anchor pool: 80 B per anchor (anchors 16, f|p|v|t 16, z/u 16, b 16, w 16) + the two dense result pools (24)
+	const size_t left = c->arena_bytes - ((c->arena_used + 255) & ~(size_t)255);
+	const uint64_t cap = left > 4096 ? (left - 4096) / 104 : 0;
+	wm128_t *d_a = (wm128_t*)arena_take(c, (cap + 1) * 16);
+	int *d_fpvt = (int*)arena_take(c, (cap + 1) * 16);
+	uint64_t *d_zu = (uint64_t*)arena_take(c, (cap + 1) * 16);
+	wm128_t *d_b = (wm128_t*)arena_take(c, (cap + 1) * 16), *d_w = (wm128_t*)arena_take(c, (cap + 1) * 16);
+	D.d_upool = (uint64_t*)arena_take(c, (cap + 1) * 8);
+	D.d_vpool = (wm128_t*)arena_take(c, (cap + 1) * 16);
+	if (cap < 1024 || !d_a || !d_fpvt || !d_zu || !d_b || !d_w || !D.d_upool || !D.d_vpool) return set_err(WM_ENOMEM, "window batch does not fit the arena");
+	if (cap >= ((uint64_t)1 << 31)) return set_err(WM_EINTERNAL, "anchor pool beyond 2^31 entries");      // (32-bit offsets in the result table)
+	HIPCHK(hipMemcpyAsync(d_jobs, jb.data(), (size_t)n * sizeof(wm_win_job_t), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(d_ord, ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+	if (stage_hi) HIPCHK(hipMemcpyAsync(d_seqs, seqs, stage_hi, hipMemcpyHostToDevice, c->stream));
+	if (pre_hi) HIPCHK(hipMemcpyAsync(d_pre, pre, pre_hi * sizeof(wm128_t), hipMemcpyHostToDevice, c->stream));
+	// sequences are addressed relative to the staged slab (one base pointer for the sketch kernel): resident ones through the pointer difference
+	const uint64_t res_delta = c->d_reads ? (uint64_t)((uintptr_t)c->d_reads - (uintptr_t)d_seqs) : 0;
+	for (int i = 0; i < n; ++i) if (sj[i].len > 0) sj[i].seq_off = jobs[i].seq_off >= 0 ? res_delta + (uint64_t)jobs[i].seq_off : jobs[i].stage_off;
+	HIPCHK(hipMemcpyAsync(d_sj, sj.data(), (size_t)n * sizeof(wm_sketch_job_t), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemsetAsync(D.d_res, 0, (size_t)n * sizeof(wm_win_res_t), c->stream));
+	HIPCHK(hipMemsetAsync(d_ctr, 0, 64, c->stream));
+	HIPCHK(hipEventRecord(c->ev[0], c->stream));
+	hipLaunchKernelGGL(sketch_coop_kernel, dim3(n), dim3(64), 0, c->stream, c->skp, d_sj, d_ord, d_seqs, c->d_bloom, d_so, d_sx, d_sy, d_sl, d_mini, d_mcnt);
+	wm_index_view_t ix = { c->d_hkey, c->d_hval, c->d_P, c->hbits, 0 };
+	hipLaunchKernelGGL(win_seed_kernel, dim3(n), dim3(64), 0, c->stream, ix, d_jobs, d_sj, d_mcnt, d_mini, d_pre, d_occ, d_first, d_emit, d_a, d_ctr, cap, D.d_res);
+	const size_t ws_bytes = (size_t)((wmk::WIN_WS_INTS + 3) & ~3) * 4;
+	static const int kSmall = 256, kLarge = 4096;
+	HIPCHK(hipFuncSetAttribute((const void*)win_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	hipLaunchKernelGGL(win_sort_kernel, dim3(n), dim3(64), ws_bytes + (size_t)kSmall * 16, c->stream, d_jobs, D.d_res, d_a, d_cj, d_lists, d_counts, n, 0, kSmall);
+	hipLaunchKernelGGL(win_sort_kernel, dim3(n), dim3(64), ws_bytes + (size_t)kLarge * 16, c->stream, d_jobs, D.d_res, d_a, d_cj, d_lists, d_counts, n, kSmall, kLarge);
+	hipLaunchKernelGGL(win_sort_kernel, dim3(n), dim3(64), ws_bytes, c->stream, d_jobs, D.d_res, d_a, d_cj, d_lists, d_counts, n, kLarge, 0);
+	{   // the fill, per class list: 0 dense (8 waves, W 4096) | 1 large sparse (1 wave, W 1024) | 2 n <= 1024 | 3 n <= 256
+		HIPCHK(hipFuncSetAttribute((const void*)win_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		constexpr int NWV = 8;
+		HIPCHK(hipFuncSetAttribute((const void*)win_chain_kernel_block<NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		hipLaunchKernelGGL(win_chain_kernel_block<NWV>, dim3(n), dim3(64 * NWV), (size_t)4096 * 28 + NWV * 69 * 4 + 64, c->stream, d_cj, d_lists, d_counts, d_a, d_fpvt, 4096);
+		hipLaunchKernelGGL(win_chain_kernel, dim3(n), dim3(64), (size_t)1024 * 28, c->stream, d_cj, d_lists + n, d_counts + 1, d_a, d_fpvt, 1024);
+		hipLaunchKernelGGL(win_chain_kernel, dim3(n), dim3(64), (size_t)1024 * 28, c->stream, d_cj, d_lists + 2 * (size_t)n, d_counts + 2, d_a, d_fpvt, 1024);
+		hipLaunchKernelGGL(win_chain_kernel, dim3(n), dim3(64), (size_t)256 * 28, c->stream, d_cj, d_lists + 3 * (size_t)n, d_counts + 3, d_a, d_fpvt, 256);
+	}
+	HIPCHK(hipFuncSetAttribute((const void*)win_extract_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	hipLaunchKernelGGL(win_extract_kernel, dim3(n), dim3(64), ws_bytes + (size_t)kSmall * 16, c->stream, d_jobs, D.d_res, d_a, d_fpvt, d_zu, d_b, d_w, 0, kSmall);
+	hipLaunchKernelGGL(win_extract_kernel, dim3(n), dim3(64), ws_bytes + (size_t)kLarge * 16, c->stream, d_jobs, D.d_res, d_a, d_fpvt, d_zu, d_b, d_w, kSmall, kLarge);
+	hipLaunchKernelGGL(win_extract_kernel, dim3(n), dim3(64), ws_bytes, c->stream, d_jobs, D.d_res, d_a, d_fpvt, d_zu, d_b, d_w, kLarge, 0);
+	hipLaunchKernelGGL(win_scan_kernel, dim3(1), dim3(1024), 0, c->stream, n, D.d_res, D.d_tot);
+	hipLaunchKernelGGL(win_gather_kernel, dim3(n), dim3(64), 0, c->stream, D.d_res, d_a, d_zu, D.d_upool, D.d_vpool);
+	HIPCHK(hipEventRecord(c->ev[1], c->stream));
+	HIPCHK(hipGetLastError());
+	uint32_t *h_tot = c->pin_small ? (uint32_t*)(c->pin_small + 8) : D.tot;
+	HIPCHK(hipMemcpyAsync(h_tot, D.d_tot, 12, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(ctx_sync(c));                  // (also: the host tables above are read by the copies until here)
+	memcpy(D.tot, h_tot, 12);
+	float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->aux_ms += ms;
+	return WM_OK;
+}
+
+// copies the result table and the two dense pools of a launched call to the host (pools sized by the caller from D.tot)
+static int window_fetch(wm_ctx_t *c, const WinDev &D, int n, wm_window_res_t *res, uint64_t *u_pool, wm128_t *a_pool)
+{
+	UBuf<wm_win_res_t> hr(n, c);
+	HIPCHK(hipMemcpyAsync(hr.data(), D.d_res, (size_t)n * sizeof(wm_win_res_t), hipMemcpyDeviceToHost, c->stream));
+	if (D.tot[0]) HIPCHK(hipMemcpyAsync(u_pool, D.d_upool, (size_t)D.tot[0] * 8, hipMemcpyDeviceToHost, c->stream));
+	if (D.tot[1]) HIPCHK(hipMemcpyAsync(a_pool, D.d_vpool, (size_t)D.tot[1] * 16, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(ctx_sync(c));
+	for (int i = 0; i < n; ++i) {
+		const wm_win_res_t &r = hr[i];
+		res[i].n_anchors = r.n_a; res[i].rep_len = r.rep_len; res[i].n_mini = r.n_mini; res[i].n_u = r.n_u; res[i].n_v = r.n_v; res[i].u_off = r.u_out; res[i].a_off = r.v_out;
+	}
+	return WM_OK;
+}
+// verdict of a launched call: 0 = fetch, 1 = launch again with full-size minimizer slots, < 0 = error
+static int window_verdict(const WinDev &D, int round)
+{
+	if (D.tot[2] == 2) return set_err(WM_ENOMEM, "window batch does not fit the arena (anchor pool)");
+	if (D.tot[2] == 1) return round == 0 ? 1 : set_err(WM_EINTERNAL, "minimizer slot overflow at full size");
+	return 0;
+}
+
+extern "C" int wm_window_batch(wm_ctx_t *c, int n, const wm_window_job_t *jobs, const uint8_t *seqs, size_t seqs_bytes, const wm128_t *pre, size_t n_pre_total,
+                               int max_occ, int64_t flag, wm_window_res_t *res, uint64_t *u_pool, size_t u_cap, size_t *u_used, wm128_t *a_pool, size_t a_cap, size_t *a_used)
+try {
+	if (u_used) *u_used = 0;
+	if (a_used) *a_used = 0;
+	if (!c || !c->have_index) return set_err(WM_EINVAL, "wm_index_upload has not been called on this context");
+	if (n <= 0) return WM_OK;
+	if (!jobs || !res) return set_err(WM_EINVAL, "null argument");
+	HIPCHK(hipSetDevice(c->device));
+	c->aux_ms = 0;
+	for (int round = 0; round < 2; ++round) {
+		ArenaMark mark(c);
+		WinDev D;
+		int rc = window_launch(c, n, jobs, seqs, seqs_bytes, pre, n_pre_total, max_occ, flag, round == 1, D);
+		if (rc) return rc;
+		rc = window_verdict(D, round);
+		if (rc < 0) return rc;
+		if (rc == 1) continue;
+		if (u_used) *u_used = D.tot[0];
+		if (a_used) *a_used = D.tot[1];
+		if (D.tot[0] > u_cap || D.tot[1] > a_cap) return set_err(WM_ENOMEM, "result pools too small: need %u chains and %u anchors", D.tot[0], D.tot[1]);
+		if ((D.tot[0] && !u_pool) || (D.tot[1] && !a_pool)) return set_err(WM_EINVAL, "null result pool");
+		return window_fetch(c, D, n, res, u_pool, a_pool);
+	}
+	return set_err(WM_EINTERNAL, "window retry did not converge");
+}
+catch (const std::bad_alloc &) { return set_err(WM_ENOMEM, "out of host memory"); }
+
+// ======================================================================================================
 // GpuOps: the product implementation of the mapper's device operations
 // ======================================================================================================
 // one device context (stream + arena + staging slab) worth of batched operations; GpuOps below hands the contexts out
@@ -1779,6 +2073,68 @@ struct GpuOpsCtx {
 			reqs[i]->a.assign(a.begin() + aoff[i], a.begin() + aoff[i] + nv[i]);
 		});
 	}
+	// the whole window on the device (wm_window_batch's machinery; the result pools are sized after the launch, in the pinned slab)
+	void window_batch(std::vector<wm::WindowReq*> &reqs)
+	{
+		const int n = (int)reqs.size();
+		if (n == 0) return;
+		for (int i = 1; i < n; ++i)             // collect_seed_hits takes one (max_occ, flag) per call: requests that differ go in their own call
+			if (reqs[i]->max_occ != reqs[0]->max_occ || reqs[i]->flag != reqs[0]->flag) {
+				std::vector<wm::WindowReq*> same, rest;
+				for (wm::WindowReq *r : reqs) (r->max_occ == reqs[0]->max_occ && r->flag == reqs[0]->flag ? same : rest).push_back(r);
+				window_batch(same);
+				if (error.empty()) window_batch(rest);
+				return;
+			}
+		const double ts = now_ms();
+		UBuf<wm_window_job_t> jobs(n, c);
+		size_t stage = 0, npre = 0;
+		for (int i = 0; i < n; ++i) {
+			const wm::WindowReq &r = *reqs[i];
+			wm_window_job_t &j = jobs[i];
+			j.len = r.len; j.n_pre = (int32_t)r.pre.size(); j.pre_off = npre; npre += r.pre.size();
+			j.stage_off = 0;
+			if (r.len <= 0) j.seq_off = -2;
+			else if (resident && r.dev_off >= 0) j.seq_off = r.dev_off;
+			else { j.seq_off = -1; j.stage_off = stage; stage += (size_t)r.len; }
+			j.par = { r.max_dist_x, r.min_dist_x, r.max_dist_y, r.bw, r.max_skip, r.max_iter, r.min_cnt, r.min_sc, r.gap_scale };
+		}
+		UBuf<uint8_t> seqs(stage + 1, c);
+		UBuf<wm128_t> pre(npre + 1, c);
+		UBuf<wm_window_res_t> res(n, c);
+		WM_SITE("window.stage");
+		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
+			const wm::WindowReq &r = *reqs[i];
+			if (jobs[i].seq_off == -1) memcpy(seqs.data() + jobs[i].stage_off, r.seq, (size_t)r.len);
+			if (!r.pre.empty()) memcpy(pre.data() + jobs[i].pre_off, r.pre.data(), r.pre.size() * sizeof(wm128_t));
+		});
+		if (hipSetDevice(c->device) != hipSuccess) { error = "hipSetDevice failed"; return; }
+		c->aux_ms = 0;
+		for (int round = 0; round < 2; ++round) {
+			ArenaMark mark(c);
+			WinDev D;
+			int rc = window_launch(c, n, jobs.data(), seqs.data(), stage, pre.data(), npre, reqs[0]->max_occ, reqs[0]->flag, round == 1, D);
+			if (!rc) rc = window_verdict(D, round);
+			if (rc < 0) { fail("window"); return; }
+			if (rc == 1) continue;
+			UBuf<uint64_t> up((size_t)D.tot[0] + 1, c);
+			UBuf<wm128_t> ap((size_t)D.tot[1] + 1, c);
+			if (window_fetch(c, D, n, res.data(), up.data(), ap.data())) { fail("window"); return; }
+			t_sketch += now_ms() - ts;
+			aux_us += c->aux_ms * 1e3;
+			WM_SITE("window.unpack");
+			wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
+				wm::WindowReq &r = *reqs[i];
+				const wm_window_res_t &o = res[i];
+				r.rep_len = o.rep_len; r.n_anchors = o.n_anchors;
+				r.u.assign(up.begin() + o.u_off, up.begin() + o.u_off + o.n_u);
+				r.a.resize((size_t)o.n_v);
+				if (o.n_v) memcpy(r.a.data(), ap.data() + o.a_off, (size_t)o.n_v * sizeof(wm128_t));
+			});
+			return;
+		}
+		error = "window retry did not converge";
+	}
 	void ksw_batch(const wm_ksw_score_t &sc, std::vector<wm::KswReq*> &reqs)
 	{
 		const double t0 = now_ms();
@@ -1868,9 +2224,10 @@ struct GpuOps : wm::DeviceOps {
 	// a batch whose buffers do not fit the context's arena is served in halves (recursively): the hub sizes batches by demand, not by HBM
 	template <class R, class F> static void run_split(GpuOpsCtx &x, std::vector<R*> &reqs, F f)
 	{
+		if (!x.error.empty()) return;          // an earlier call on this context failed for good: nothing more is attempted (and nothing is cleared)
 		f(reqs);
 		if (x.error.empty() || reqs.size() < 2 || x.error.find("does not fit the arena") == std::string::npos) return;
-		x.error.clear();
+		x.error.clear();                       // (set by THIS call: the context was clean on entry)
 		std::vector<R*> a(reqs.begin(), reqs.begin() + reqs.size() / 2), b(reqs.begin() + reqs.size() / 2, reqs.end());
 		run_split(x, a, f);
 		if (x.error.empty()) run_split(x, b, f);
@@ -1879,6 +2236,8 @@ struct GpuOps : wm::DeviceOps {
 	void seed_batch(std::vector<wm::SeedReq*> &reqs) override { with([&](GpuOpsCtx &x) { run_split(x, reqs, [&](std::vector<wm::SeedReq*> &part) { x.seed_batch(part); }); }); }
 	void chain_batch(std::vector<wm::ChainReq*> &reqs) override { with([&](GpuOpsCtx &x) { run_split(x, reqs, [&](std::vector<wm::ChainReq*> &part) { x.chain_batch(part); }); }); }
 	void ksw_batch(const wm_ksw_score_t &sc, std::vector<wm::KswReq*> &reqs) override { with([&](GpuOpsCtx &x) { x.ksw_batch(sc, reqs); }); }
+	// collect_seed_hits takes one (max_occ, flag) per call: the mapper's requests of one mapping call all share them
+	void window_batch(int, int, std::vector<wm::WindowReq*> &reqs) override { with([&](GpuOpsCtx &x) { run_split(x, reqs, [&](std::vector<wm::WindowReq*> &part) { x.window_batch(part); }); }); }
 };
 
 struct wm_mapper_s {

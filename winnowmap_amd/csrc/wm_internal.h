@@ -66,3 +66,23 @@ typedef struct {
 	float avg_qspan, gap_scale;
 	int32_t pad;
 } wm_chain_job_t;
+
+// ---- one MCAS window / stage-2 pass on the device: sketch → seed → sort → chain → extraction (window_kernel.h) ----
+typedef struct {
+	int64_t seq_off;      // first 0..4 code relative to the call's sequence base pointer (as wm_sketch_job_t::seq_off); < 0: no sequence, only handed-in anchors
+	uint64_t pre_off;     // first handed-in anchor in the call's `pre` pool
+	int32_t len, n_pre;
+	int32_t max_occ, seed_flag;                                                        // collect_seed_hits: mid_occ, MM_F_FOR_ONLY / MM_F_REV_ONLY bits
+	int32_t max_dist_x, min_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc;   // mm_chain_dp
+	float gap_scale;
+	int32_t pad;
+} wm_win_job_t;
+
+typedef struct {          // per job on the device: where its anchors live and what came out
+	uint64_t a_off;       // first slot of the job's region in the anchor pool (x 4 ints: in the f|p|v|t slab; x 2 uint64: in the u scratch)
+	int32_t n_a;          // anchors before chaining (handed in + seeded)
+	int32_t rep_len, n_mini;
+	int32_t n_u, n_v;     // chains; anchors kept
+	int32_t err;          // 1: the minimizer slot overflowed (retry with full-size slots), 2: the anchor pool overflowed
+	uint32_t u_out, v_out;    // offsets in the dense output pools (after the scan)
+} wm_win_res_t;
