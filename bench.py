@@ -213,7 +213,7 @@ def make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1):
                    "reads_per_step_per_gpu": args.reads_per_step, "read_len": args.read_len, "ref_mb": args.ref_mb, "host_threads": n_threads,
                    "reads_per_s": total_bases / args.read_len / elapsed, "hits": hits, "parallelism": "reads sharded over %d rank(s), index broadcast" % world,
                    # which kernel variants ran (tools/r03_first_run.sh A/Bs them): build-time defines and run-time switches
-                   "variants": {"kernel_defines": os.environ.get("WM_KERNEL_DEFINES", ""),
+                   "variants": {"kernel_defines": gpu.build_defines(),
                                 **{k: os.environ[k] for k in ("WM_KSW_PMULTI", "WM_KSW_COOP_BT", "WM_SEED_DEVICE_SORT", "WM_CONTEXTS") if k in os.environ}}},
         "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
                      "traffic_source": (pmc or {}).get("source") if traffic is not None else None, "classes": classes,

@@ -48,6 +48,8 @@ typedef struct { uint64_t x, y; } wm128_t;
 int wm_ctx_create(int device, size_t arena_bytes, wm_ctx_t **out);
 void wm_ctx_destroy(wm_ctx_t *ctx);
 const char *wm_last_error(void);
+/* the kernel-variant defines (WM_KERNEL_DEFINES of winnowmap_amd/build.py) this library was compiled with; "" for the default build */
+const char *wm_build_defines(void);
 int wm_device_count(void);
 /* time of the last batch call's kernels on the context's stream, measured with HIP events (ms) */
 float wm_last_kernel_ms(const wm_ctx_t *ctx);

@@ -25,16 +25,30 @@ def _newer(target, sources):
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-mllvm", "-disable-promote-alloca-to-vector"]
 
 
-def build_gpu(force=False, verbose=False):
+def build_gpu(force=False, verbose=False, out=None):
+    """libwmgpu.so (or `out`: a variant library for A/B runs, selected with WM_LIBWMGPU=<path>; built here so that no GPU minute is spent compiling)"""
+    global LIB
+    if out is not None:
+        saved, LIB = LIB, out
+        try:
+            return build_gpu(force, verbose)
+        finally:
+            LIB = saved
     srcs = [os.path.join(d, f) for d, _, fs in os.walk(CSRC) for f in fs] + [os.path.join(ROOT, "include", "wm_gpu.h")]
-    if not force and not _newer(LIB, srcs):
+    # WM_KERNEL_DEFINES="WM_KSW_ROR=0 ...": kernel variants under evaluation (A/B on a GPU box); the default build defines nothing. The defines a
+    # library was built with are part of its staleness check (sidecar stamp) and are compiled into it (wm_build_defines(), recorded by bench.py)
+    defines = " ".join(os.environ.get("WM_KERNEL_DEFINES", "").split())
+    stamp = LIB + ".defines"
+    have = open(stamp).read() if os.path.exists(stamp) else ""
+    if not force and not _newer(LIB, srcs) and have == defines:
         return LIB
-    # WM_KERNEL_DEFINES="WM_KSW_ROR=1 ...": kernel variants under evaluation (A/B on a GPU box); the default build defines nothing
-    defs = ["-D" + d for d in os.environ.get("WM_KERNEL_DEFINES", "").split()]
+    defs = ["-D" + d for d in defines.split()] + ['-DWM_BUILD_DEFINES="%s"' % defines]
     cmd = [HIPCC] + HIP_FLAGS + defs + ["-shared", "-fPIC", "-o", LIB, os.path.join(CSRC, "wm_gpu.hip"), "-lz", "-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(defines)
     return LIB
 
 

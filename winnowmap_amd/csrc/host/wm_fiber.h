@@ -43,7 +43,7 @@ class Scheduler;
 #if defined(__x86_64__)
 extern "C" void wm_fiber_switch(void **save_sp, void *load_sp);
 __asm__(
-	".text\n"
+	".pushsection .text\n"
 	".p2align 4\n"
 	".globl wm_fiber_switch\n"
 	".type wm_fiber_switch,@function\n"
@@ -53,7 +53,8 @@ __asm__(
 	"	movq %rsi, %rsp\n"
 	"	popq %r15\n	popq %r14\n	popq %r13\n	popq %r12\n	popq %rbx\n	popq %rbp\n"
 	"	ret\n"
-	".size wm_fiber_switch,.-wm_fiber_switch\n");
+	".size wm_fiber_switch,.-wm_fiber_switch\n"
+	".popsection\n");
 struct FiberCtx { void *sp; };
 #else
 struct FiberCtx { ucontext_t uc; };

@@ -220,7 +220,7 @@ WM_DEV void sketch_coop(const wm_sketch_params_t P, const wm_sketch_job_t jb, co
 			gst(so, i, co); gst(sx, i, cx); gst(sy, i, cy); gst(sl, i, cast<uint32_t>(l));
 		WM_END
 	}
-	mem_sync_agent();                                // phase 2 reads what other lanes of this wave wrote
+	mem_sync();                                      // phase 2 reads what other lanes of this wave wrote (same CU: a workgroup-scope fence; no L2 write-back per job)
 	// ---- phase 2 ----
 	int m = 0, n_out = 0;
 	double om = 2.0;

@@ -26,7 +26,11 @@ using namespace simt;
 
 // lane 0 stores one int (uniform bookkeeping that lives in LDS)
 WM_DEV void ust(int *p, int i, int v) { WM_IF(lane() == 0) gst(p, V<long long>((long long)i), V<int>(v)); WM_END }
-template <bool G> WM_DEV void win_sync() { if (G) mem_sync_agent(); else lds_sync(); }
+// Cross-lane traffic of ONE wavefront through global memory: the lanes share a CU and its write-through L1, so what is needed is that the
+// stores have left the wave (s_waitcnt) and that the compiler keeps the order — a WORKGROUP-scope fence. (An agent-scope release would write
+// the XCD's L2 back and invalidate it — per job, a million times per mini-batch, under every other kernel's feet.)
+WM_DEV void win_fence() { mem_sync(); }
+template <bool G> WM_DEV void win_sync() { if (G) win_fence(); else lds_sync(); }
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // collect_seed_hits (src/map.c:222-251) for one job, in two passes over the job's minimizers:
@@ -396,7 +400,7 @@ template <bool G> WM_DEV void win_extract_wave(int n, int min_cnt, int min_sc, w
 		WM_END
 		n_z += popc64(em);
 	}
-	mem_sync_agent();
+	win_fence();
 	if (n_z == 0) { WM_IF(ln == 0) gst(&res->n_u, V<long long>(0LL), V<int>(0)); gst(&res->n_v, V<long long>(0LL), V<int>(0)); WM_END return; }
 	// radix_sort_64 (:112) then reversed (:113-116): equal values are indistinguishable, so any exact sort gives the reference's array.
 	// Through (z, 0) pairs in b: the 128x machinery sorts them; written back in descending order
@@ -404,19 +408,19 @@ template <bool G> WM_DEV void win_extract_wave(int n, int min_cnt, int min_sc, w
 		const V<int> i = ln + i0;
 		WM_IF(i < n_z) gst(b, cast<long long>(i) * 2LL, gld(zu, cast<long long>(i))); gst(b, cast<long long>(i) * 2LL + 1LL, V<uint64_t>((uint64_t)0)); WM_END
 	}
-	mem_sync_agent();
+	win_fence();
 	win_sort_wave<true>(b_, n_z, ws);
-	mem_sync_agent();
+	win_fence();
 	for (int i0 = 0; i0 < n_z; i0 += 64) {
 		const V<int> i = ln + i0;
 		WM_IF(i < n_z) gst(zu, cast<long long>(i), gld(b, cast<long long>(V<int>(n_z - 1) - i) * 2LL)); WM_END
 	}
 	for (int i0 = 0; i0 < n; i0 += 64) { const V<int> i = ln + i0; WM_IF(i < n) gst(t, i, V<int>(0)); WM_END }       // :119
-	mem_sync_agent();
+	win_fence();
 	win_sync<G>();
 	int *cnts = ws + WIN_WS_FRAME;                                            // two ints handed from lane 0 to the wave
 	WM_LANE0_BEGIN win_backtrack(n_z, zu, f, p, t, v, min_cnt, min_sc, cnts, cnts + 1); WM_LANE0_END
-	mem_sync_agent();
+	win_fence();
 	win_sync<false>();
 	const int n_u = uniform(gld(cnts, 0LL)), n_v = uniform(gld(cnts, 1LL));
 	WM_IF(ln == 0) gst(&res->n_u, V<long long>(0LL), V<int>(n_u)); gst(&res->n_v, V<long long>(0LL), V<int>(n_v)); WM_END
@@ -441,9 +445,9 @@ template <bool G> WM_DEV void win_extract_wave(int n, int min_cnt, int min_sc, w
 			k0 += ni;
 		}
 	}
-	mem_sync_agent();
+	win_fence();
 	win_sort_wave<true>(wbuf_, n_u, ws);                                      // :155 radix_sort_128x(w): ties possible, exact permutation
-	mem_sync_agent();
+	win_fence();
 	{
 		int k = 0;
 		uint64_t *u2 = zu + n;

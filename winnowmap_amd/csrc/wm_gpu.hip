@@ -54,12 +54,26 @@ static inline double now_ms() { return std::chrono::duration<double, std::milli>
 // ======================================================================================================
 // kernels
 // ======================================================================================================
+// Wave priority (s_setprio: the SIMD's arbiter issues the ready wave with the highest priority first). The path mixes two kinds of kernels on
+// one chip: the bulk DP classes — tens of thousands of independent waves, throughput work — and LATENCY-bound serial chains that a whole
+// batched call waits for (one alignment over thousands of rows with a barrier per row, the window kernels' lane-0 sections, the traceback walk).
+// Sharing a SIMD with seven bulk waves slows a serial chain several times while it costs the bulk nothing to yield: the chains run at
+// raised priority, the bulk at the default 0 (profiles/r03c_window_profile.txt: a kernel's duration under load vs alone). WM_PRIO=0 (build define) turns it off for A/B.
+#ifndef WM_PRIO
+#define WM_PRIO 1
+#endif
+#if WM_PRIO
+#define WM_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define WM_SETPRIO(n) ((void)0)
+#endif
 // register classes: one wave per alignment, two DP cells per lane (ksw_dp_packed, ksw_packed_kernel.h)
 template <int BP, bool CLIP, bool HASN, bool EXACT>
 __global__ __launch_bounds__(64) void ksw_dpp_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs,
                                                       const int *__restrict__ order, const uint8_t *__restrict__ seqs,
                                                       uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res)
 {
+	if constexpr (EXACT || CLIP || BP >= 16) WM_SETPRIO(2);
 	const int j = order[blockIdx.x];
 	wmk::ksw_dp_packed<BP, CLIP, HASN, EXACT>(sc, jobs[j], seqs, tb, res + j);
 }
@@ -69,6 +83,7 @@ __global__ __launch_bounds__(64) void ksw_generic_kernel(wm_ksw_score_t sc, cons
                                                           const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, uint8_t *scratch,
                                                           const uint64_t *__restrict__ scratch_off, wm_ksw_dres_t *__restrict__ res)
 {
+	WM_SETPRIO(3);
 	const int j = order[blockIdx.x];
 	const wm_ksw_djob_t jb = jobs[j];
 	const int T = (jb.tlen + 15) / 16 * 16;
@@ -85,6 +100,7 @@ __global__ __launch_bounds__(64 * WM_KSW_BLK_NWV) void ksw_block_kernel(wm_ksw_s
                                                                          const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res, int seq_cap,
                                                                          int *gstate, const uint64_t *__restrict__ gstate_off)
 {
+	WM_SETPRIO(3);
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr bool GLOBAL = WN == 0;
 	const int j = order[blockIdx.x];
@@ -111,6 +127,7 @@ template <int BP, int NWV>
 __global__ __launch_bounds__(64 * NWV) void ksw_pmulti_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
                                                                          const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res, int seq_cap)
 {
+	WM_SETPRIO(3);
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	typedef wmk::ksw_pmulti_lds<BP, NWV> L;
 	int *lds = (int*)smem;
@@ -135,8 +152,10 @@ __global__ __launch_bounds__(64 * NWV) void ksw_pmulti_kernel(wm_ksw_score_t sc,
 __global__ __launch_bounds__(64) void ksw_expand_kernel(const wm_ksw_djob_t *__restrict__ jobs, const wm_ksw_dsrc_t *__restrict__ src,
                                                          const uint8_t *__restrict__ reads, const uint32_t *__restrict__ S, uint8_t *__restrict__ seqs)
 {
+	WM_SETPRIO(1);
 	const int j = blockIdx.x;
 	const wm_ksw_djob_t jb = jobs[j];
+	if (jb.klass < 0) return;                   // degenerate job (an empty operand, src/ksw2_extd2_sse.c:68): it has no slot in the slab
 	const wm_ksw_dsrc_t sr = src[j];
 	const int64_t L = sr.qwin_len;
 	uint8_t *q = seqs + jb.q_off, *t = seqs + jb.t_off;
@@ -157,6 +176,7 @@ __global__ __launch_bounds__(64) void ksw_expand_kernel(const wm_ksw_djob_t *__r
 __global__ __launch_bounds__(64) void ksw_backtrack_kernel(int n, const wm_ksw_djob_t *__restrict__ jobs, const uint8_t *__restrict__ tb,
                                                             wm_ksw_dres_t *__restrict__ res, uint32_t *__restrict__ cig_scratch, int *__restrict__ err)
 {
+	WM_SETPRIO(3);
 	const int j = blockIdx.x * 64 + threadIdx.x;
 	if (j >= n) return;
 	wm_ksw_dres_t r = res[j];
@@ -172,6 +192,7 @@ __global__ __launch_bounds__(64) void ksw_backtrack_kernel(int n, const wm_ksw_d
 __global__ __launch_bounds__(64) void ksw_backtrack_coop_kernel(int n, const wm_ksw_djob_t *__restrict__ jobs, const uint8_t *__restrict__ tb,
                                                                  wm_ksw_dres_t *__restrict__ res, uint32_t *__restrict__ cig_scratch, int *__restrict__ err)
 {
+	WM_SETPRIO(3);
 	__shared__ uint8_t tile[KSW_BT_ROWS * 64];
 	const int j = blockIdx.x;
 	const int bt_i = res[j].bt_i, bt_j = res[j].bt_j;
@@ -186,6 +207,7 @@ __global__ __launch_bounds__(64) void ksw_backtrack_coop_kernel(int n, const wm_
 // exclusive prefix sum of n_cigar (single block; n is at most a few hundred thousand)
 __global__ __launch_bounds__(1024) void ksw_scan_kernel(int n, const wm_ksw_dres_t *__restrict__ res, uint32_t *__restrict__ off, uint32_t *__restrict__ total)
 {
+	WM_SETPRIO(3);
 	__shared__ uint32_t part[1024];
 	const int tid = threadIdx.x, per = (n + 1023) / 1024, b = tid * per, e = b + per < n ? b + per : n;
 	uint32_t s = 0;
@@ -207,6 +229,7 @@ __global__ __launch_bounds__(64) void ksw_gather_kernel(const wm_ksw_djob_t *__r
                                                          const uint32_t *__restrict__ off, const uint32_t *__restrict__ cig_scratch,
                                                          uint32_t *__restrict__ pool, uint32_t pool_cap)
 {
+	WM_SETPRIO(3);
 	const int j = blockIdx.x, n = res[j].n_cigar;
 	const uint32_t *src = cig_scratch + jobs[j].cig_off;
 	const bool rev = (jobs[j].flag & KSW_F_REV_CIGAR) != 0;
@@ -298,6 +321,10 @@ struct wm_ksw_dev_batch_s {
 };
 
 extern "C" const char *wm_last_error(void) { return g_err; }
+#ifndef WM_BUILD_DEFINES
+#define WM_BUILD_DEFINES ""
+#endif
+extern "C" const char *wm_build_defines(void) { return WM_BUILD_DEFINES; }      // kernel-variant defines this library was compiled with (winnowmap_amd/build.py)
 
 // wait for everything queued on the context's stream WITHOUT burning a host core: hipStreamSynchronize — and, on the GPU boxes, also
 // hipEventSynchronize on a blocking-sync event (thread CPU time == wall time inside the batched calls, profiles/r02c_bench_hub.json) —
@@ -988,6 +1015,7 @@ __global__ __launch_bounds__(64) void sketch_kernel(wm_sketch_params_t P, const 
 __global__ __launch_bounds__(64) void sketch_coop_kernel(wm_sketch_params_t P, const wm_sketch_job_t *jobs, const int *order, const uint8_t *seqs, const uint8_t *bloom,
                                                           double *so, uint64_t *sx, uint32_t *sy, uint32_t *sl, wm128_t *out, int *counts)
 {
+	WM_SETPRIO(2);
 	const int j = order[blockIdx.x];
 	const wm_sketch_job_t jb = jobs[j];
 	wmk::sketch_coop(P, jb, seqs, bloom, so + jb.scratch_off, sx + jb.scratch_off, sy + jb.scratch_off, sl + jb.scratch_off, out, counts + j);
@@ -1692,6 +1720,7 @@ __global__ __launch_bounds__(64) void win_seed_kernel(wm_index_view_t ix, const 
                                                        const wm128_t *__restrict__ mini_pool, const wm128_t *__restrict__ pre_pool, int *occ, uint32_t *first, int *emit,
                                                        wm128_t *anchors, uint64_t *used, uint64_t cap, wm_win_res_t *res)
 {
+	WM_SETPRIO(2);
 	const int j = blockIdx.x;
 	const wm_win_job_t jb = jobs[j];
 	const wm_sketch_job_t s = sj[j];
@@ -1708,6 +1737,7 @@ __global__ __launch_bounds__(64) void win_seed_kernel(wm_index_view_t ix, const 
 __global__ __launch_bounds__(64) void win_sort_kernel(const wm_win_job_t *__restrict__ jobs, const wm_win_res_t *res, wm128_t *anchors, wm_chain_job_t *cj,
                                                        int *lists, int *counts, int n_jobs, int lo, int lds_cap)
 {
+	WM_SETPRIO(2);
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	int *ws = (int*)smem;
 	wm128_t *stage = (wm128_t*)(ws + ((wmk::WIN_WS_INTS + 3) & ~3));
@@ -1734,7 +1764,7 @@ __global__ __launch_bounds__(64) void win_sort_kernel(const wm_win_job_t *__rest
 		if (seeded) {
 			wmk::win_sort_wave<true>(a + n_pre, n - n_pre, ws);
 			if (n_pre > 0) wmk::win_sort_wave<true>(a, n, ws);
-			simt::mem_sync_agent();
+			wmk::win_fence();
 		}
 		wmk::win_plan_wave(jb, j, r.a_off, n, a, cj, lists, counts, n_jobs);
 	}
@@ -1743,6 +1773,7 @@ __global__ __launch_bounds__(64) void win_sort_kernel(const wm_win_job_t *__rest
 // the fills of seedchain_kernel.h over a device-side job list (block b serves list[b]; blocks beyond *count leave)
 __global__ __launch_bounds__(64) void win_chain_kernel(const wm_chain_job_t *jobs, const int *list, const int *count, const wm128_t *anchors, int *fpvt, int W)
 {
+	WM_SETPRIO(2);
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	if ((int)blockIdx.x >= *count) return;
 	const wm_chain_job_t jb = jobs[list[blockIdx.x]];
@@ -1754,6 +1785,7 @@ __global__ __launch_bounds__(64) void win_chain_kernel(const wm_chain_job_t *job
 template <int NWV>
 __global__ __launch_bounds__(64 * NWV) void win_chain_kernel_block(const wm_chain_job_t *jobs, const int *list, const int *count, const wm128_t *anchors, int *fpvt, int W)
 {
+	WM_SETPRIO(2);
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	if ((int)blockIdx.x >= *count) return;
 	const wm_chain_job_t jb = jobs[list[blockIdx.x]];
@@ -1767,6 +1799,7 @@ __global__ __launch_bounds__(64 * NWV) void win_chain_kernel_block(const wm_chai
 __global__ __launch_bounds__(64) void win_extract_kernel(const wm_win_job_t *__restrict__ jobs, wm_win_res_t *res, wm128_t *anchors, int *fpvt, uint64_t *zu, wm128_t *bbuf, wm128_t *wbuf,
                                                           int lo, int lds_cap)
 {
+	WM_SETPRIO(2);
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	int *ws = (int*)smem;
 	const int j = blockIdx.x;
@@ -1787,6 +1820,7 @@ __global__ __launch_bounds__(64) void win_extract_kernel(const wm_win_job_t *__r
 // exclusive prefix sums of n_u and n_v over the jobs (single block) -> res[j].u_out / v_out, totals[0..1]; totals[2] = worst err
 __global__ __launch_bounds__(1024) void win_scan_kernel(int n, wm_win_res_t *res, uint32_t *totals)
 {
+	WM_SETPRIO(3);
 	__shared__ uint32_t pu[1024], pv[1024];
 	__shared__ int perr[1024];
 	const int tid = threadIdx.x, per = (n + 1023) / 1024, b = tid * per, e = b + per < n ? b + per : n;
@@ -1806,6 +1840,7 @@ __global__ __launch_bounds__(1024) void win_scan_kernel(int n, wm_win_res_t *res
 __global__ __launch_bounds__(64) void win_gather_kernel(const wm_win_res_t *__restrict__ res, const wm128_t *__restrict__ anchors, const uint64_t *__restrict__ zu,
                                                          uint64_t *__restrict__ u_pool, wm128_t *__restrict__ v_pool)
 {
+	WM_SETPRIO(3);
 	const int j = blockIdx.x;
 	const wm_win_res_t r = res[j];
 	const uint64_t *u2 = zu + 2 * r.a_off + r.n_a;

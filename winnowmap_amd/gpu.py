@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libwmgpu.so")
+LIB_PATH = os.environ.get("WM_LIBWMGPU") or os.path.join(HERE, "libwmgpu.so")      # (WM_LIBWMGPU: a variant build for A/B runs, winnowmap_amd/build.py)
 
 
 class WmError(RuntimeError):
@@ -154,6 +154,12 @@ class KswDevBatch:
         if self._h:
             lib().wm_ksw_dev_free(self.ctx._h, self._h)
             self._h = None
+
+
+def build_defines():
+    """the kernel-variant defines the loaded library was compiled with (wm_build_defines)"""
+    lib().wm_build_defines.restype = C.c_char_p
+    return lib().wm_build_defines().decode()
 
 
 def pack_jobs(pairs, w=751, zdrop=400, end_bonus=-1, flag=0):
