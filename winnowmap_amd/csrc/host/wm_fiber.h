@@ -79,6 +79,7 @@ struct Hub {
 	wm_ksw_score_t sc;
 	int w, k;
 	int max_inflight;                       // batched device calls that may run concurrently (device contexts of the ops object)
+	int64_t max_sw_mat = 0;                 // mm_mapopt_t::max_sw_mat (--cap-sw-mat): pairs with more DP cells are not aligned (src/align.c:323-325)
 	std::mutex mu;
 	std::condition_variable cv;
 	// published requests and the fibers waiting for them (taken whole by a dispatcher)
@@ -246,12 +247,17 @@ public:
 		int ops = 0;
 		const long hu = hub_->heavy_units, xu = hub_->huge_units;
 		for (KswReq &r : rs) {
+			if (hub_->max_sw_mat > 0 && (int64_t)r.tlen() * r.qlen() > hub_->max_sw_mat) {      // --cap-sw-mat (src/align.c:323-325): not aligned, reported as z-dropped
+				r.ez = wm_ksw_result_t(); r.ez.max_q = r.ez.max_t = r.ez.mqe_t = r.ez.mte_q = -1; r.ez.score = r.ez.mqe = r.ez.mte = -0x40000000; r.ez.zdropped = 1;
+				r.cigar.clear();
+				continue;
+			}
 			const long un = ksw_units(r);
 			const int op = xu > 0 && un > xu ? OP_KSW_HUGE : hu > 0 && un > hu ? OP_KSW_HEAVY : OP_KSW;
 			(op == OP_KSW_HUGE ? l_kswx_ : op == OP_KSW_HEAVY ? l_kswh_ : l_ksw_).push_back(&r);
 			ops |= 1 << op;
 		}
-		wait(ops);
+		if (ops) wait(ops);
 	}
 	// serial work of one alignment on its wavefront: anti-diagonals x 128-lane register pairs of the band hull
 	static long ksw_units(const KswReq &r)

@@ -232,6 +232,7 @@ void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::v
 	const size_t window = std::max<size_t>(1, (size_t)(inflight_env > 0 ? inflight_env : 16384) / (size_t)T);
 	Hub hub(ops, sc, idx.w, idx.k);
 	hub.n_workers = T;
+	hub.max_sw_mat = opt.max_sw_mat;
 	std::vector<std::unique_ptr<Scheduler>> sch(T);
 	for (int t = 0; t < T; ++t) sch[t].reset(new Scheduler(&hub, t));
 	// worker t owns reads t, t+T, ...: it admits `window` of them and one more whenever one finishes
