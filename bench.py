@@ -165,12 +165,25 @@ def ksw_class_name(k):
     return "ksw_dpp_kernel<%d, %s, %s, %s>" % (bp, str(clip).lower(), str(hasn).lower(), str(exact).lower())
 
 
+def cgroup_throttle():
+    """(periods throttled, seconds throttled) of this container's CPU quota so far (cgroup v2 cpu.stat; zeros when unreadable)"""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            kv = dict(l.split() for l in open(path).read().splitlines() if len(l.split()) == 2)
+            return int(kv.get("nr_throttled", 0)), float(kv.get("throttled_usec", kv.get("throttled_time", 0))) * (1e-6 if "throttled_usec" in kv else 1e-9)
+        except (OSError, ValueError):
+            continue
+    return 0, 0.0
+
+
 def host_report(hs0, hs1, ru0, ru1, elapsed, n_cores):
     """Where the host time of the timed region went (rank 0): the per-read glue and the batched calls, against the usable cores."""
     d = lambda a, b: b - a  # noqa: E731
     cpu = d(ru0.ru_utime, ru1.ru_utime) + d(ru0.ru_stime, ru1.ru_stime)
     ops = ("window", "ksw")
     return {"usable_cores": n_cores, "process_cpu_s": round(cpu, 2), "cpu_utilisation": round(cpu / max(elapsed, 1e-9) / max(1, n_cores), 3),
+            "glue_wall_s": round(d(hs0["glue_wall_s"], hs1["glue_wall_s"]), 2), "lock_wait_wall_s": round(d(hs0["lock_wait_wall_s"], hs1["lock_wait_wall_s"]), 2),
+            "workers_wall_s": round(d(hs0["workers_wall_s"], hs1["workers_wall_s"]), 2),
             "glue_cpu_s": round(d(hs0["cpu_glue_s"], hs1["cpu_glue_s"]), 2), "help_cpu_s": round(d(hs0["cpu_help_s"], hs1["cpu_help_s"]), 2), "idle_wall_s": round(d(hs0["idle_wall_s"], hs1["idle_wall_s"]), 2),
             "batched_cpu_s": {o: round(d(hs0["cpu_batched_s"][o], hs1["cpu_batched_s"][o]), 2) for o in ops},
             "batched_wall_s": {o: round(d(hs0["wall_batched_s"][o], hs1["wall_batched_s"][o]), 2) for o in ops},
@@ -315,6 +328,7 @@ def main():
     sync()
     ks0 = mapper.kernel_stats()
     hs0 = mapper.host_stats()
+    thr0 = cgroup_throttle()
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t_start = time.time()
     cells = ksw_us = aux_us = bases = hits = 0
@@ -339,6 +353,8 @@ def main():
         if dist is not None:
             out["config"]["rccl_world_size"] = dist.get_world_size()
         out["host"] = host_report(hs0, hs1, ru0, ru1, elapsed, n_cores)
+        thr1 = cgroup_throttle()
+        out["host"]["cpu_quota_throttled"] = {"periods": thr1[0] - thr0[0], "seconds": round(thr1[1] - thr0[1], 3)}
         if world == 1 and args.cpu_sample != 0:
             # one full step (the first timed batch) through the REAL reference on this host's cores: CPU baseline + parity
             bn, bs = batches[args.warmup]

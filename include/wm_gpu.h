@@ -276,7 +276,8 @@ int wm_mapper_kernel_stats(const wm_mapper_t *m, double *out, int cap, int *n_cl
 /* where the host time of the mapping calls went since wm_mapper_create (seconds, summed over the worker threads; the host replaces
  * kt_for(worker_for), src/map.c:1164): out[0] = CPU time running the per-read glue, out[1] = wall time asleep waiting for device results,
  * out[2..5] = CPU time inside the batched window (sketch → seed → sort → chain, one call) / seed / chain / ksw calls, out[6..9] = their wall time, out[10..13] = number of
- * batched calls, out[14] = wall time of the mapping phase, out[15] = wall time formatting records, out[16] = worker threads, out[17] = CPU time idle workers spent helping the host-side loops of running batched calls. cap >= 18. */
+ * batched calls, out[14] = wall time of the mapping phase, out[15] = wall time formatting records, out[16] = worker threads, out[17] = CPU time idle workers spent helping the host-side loops of running batched calls; with cap >= 21 also out[18] = WALL time running
+ * the glue (far above out[0]: the workers are being descheduled), out[19] = wall time waiting for the hub's mutex, out[20] = wall time of the workers in total. cap >= 18. */
 int wm_mapper_host_stats(const wm_mapper_t *m, double *out, int cap);
 /* SAM header lines (@SQ.., @PG) as mm_write_sam_hdr (src/format.c:118-139) */
 int wm_sam_header(const wm_index_t *idx, int argc, const char *const *argv, const char **text, size_t *text_len);

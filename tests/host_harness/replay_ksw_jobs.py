@@ -12,7 +12,7 @@ from winnowmap_amd import build
 path = sys.argv[1]; variants = sys.argv[2].split(","); limit = int(sys.argv[3]) if len(sys.argv) > 3 else 10**9; force = int(sys.argv[4]) if len(sys.argv) > 4 else -1      # force: a class code of emu_ksw_extd2 (e.g. 223 = ksw_dp_pmulti<4,4>, CLIP + HASN)
 libs = {}
 for v in variants:
-    E = C.CDLL(build.build_emu(() if v == "default" else ("WM_KSW_ROR=1",)))
+    E = C.CDLL(build.build_emu(() if v == "default" else ("WM_KSW_ROR=0",)))
     E.emu_ksw_extd2.argtypes = [C.c_int, W.u8p, C.c_int, W.u8p, W.i8p] + [C.c_int] * 9 + [W.i32p, W.u32p, C.c_int, C.POINTER(C.c_int)]
     libs[v] = E
 data = open(path, 'rb').read(); pos = 0; n = 0; bad = 0; cells = 0

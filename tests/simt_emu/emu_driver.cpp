@@ -363,16 +363,44 @@ int emu_win_extract(int n, uint64_t *ax, uint64_t *ay, const int32_t *f_in, cons
 	for (int i = 0; i < n; ++i) a[i].x = ax[i], a[i].y = ay[i];
 	std::vector<int> f(f_in, f_in + n), p(p_in, p_in + n), v(n + 1, 0x5a5a5a5a), t(n + 1, 0x5a5a5a5a);
 	f.push_back(0); p.push_back(0);
-	std::vector<uint64_t> zu(2 * (size_t)n + 2, 0x5a5a5a5a5a5a5a5aull);
+	std::vector<uint64_t> zu((size_t)n + 2, 0x5a5a5a5a5a5a5a5aull), up((size_t)n + 16);
+	std::vector<wm128_t> vp((size_t)n + 16);
 	std::vector<int> ws(wmk::WIN_WS_INTS, 0x5a5a5a5a);
+	uint64_t ctr[2] = { 3, 5 };                 // (the pools are shared by the jobs of a call: this job does not start at 0)
 	wm_win_res_t res;
 	memset(&res, 0, sizeof(res));
 	simt::exec_mask() = ~0ull;
-	if (global) wmk::win_extract_wave<true>(n, min_cnt, min_sc, a.data(), f.data(), p.data(), v.data(), t.data(), zu.data(), b.data(), wb.data(), ws.data(), &res);
-	else wmk::win_extract_wave<false>(n, min_cnt, min_sc, a.data(), f.data(), p.data(), v.data(), t.data(), zu.data(), b.data(), wb.data(), ws.data(), &res);
+	if (global) wmk::win_extract_wave<true>(n, min_cnt, min_sc, a.data(), f.data(), p.data(), v.data(), t.data(), zu.data(), b.data(), wb.data(), ws.data(), &res, up.data(), vp.data(), ctr);
+	else wmk::win_extract_wave<false>(n, min_cnt, min_sc, a.data(), f.data(), p.data(), v.data(), t.data(), zu.data(), b.data(), wb.data(), ws.data(), &res, up.data(), vp.data(), ctr);
 	*n_u_out = res.n_u;
-	for (int i = 0; i < res.n_u; ++i) u_out[i] = zu[(size_t)n + i];
-	for (int i = 0; i < res.n_v; ++i) ax[i] = a[i].x, ay[i] = a[i].y;
+	if (res.n_u && (res.u_out != 3 || res.v_out != 5 || ctr[0] != 3 + (uint64_t)res.n_u || ctr[1] != 5 + (uint64_t)res.n_v)) return -1;
+	for (int i = 0; i < res.n_u; ++i) u_out[i] = up[res.u_out + i];
+	for (int i = 0; i < res.n_v; ++i) ax[i] = vp[res.v_out + i].x, ay[i] = vp[res.v_out + i].y;
+	return res.n_v;
+}
+
+// a small job from its unsorted anchors to its chains by one wavefront in LDS (win_small_wave): n_pre handed-in anchors first; seeded != 0: the job
+// has a sequence (its seeded part is sorted, then the union). Returns n_v; chains in u_out, chained anchors in ax / ay
+int emu_win_small(int n, int n_pre, int seeded, uint64_t *ax, uint64_t *ay, int max_dist_x, int min_dist_x, int max_dist_y, int bw, int max_skip, int max_iter,
+                  int min_cnt, int min_sc, float gap_scale, int *n_u_out, uint64_t *u_out)
+{
+	if (n > wmk::WIN_SMALL) return -2;
+	std::vector<wm128_t> a(n + 1), vp((size_t)n + 16);
+	for (int i = 0; i < n; ++i) a[i].x = ax[i], a[i].y = ay[i];
+	std::vector<uint64_t> up((size_t)n + 16);
+	std::vector<unsigned char> lds(wmk::WIN_SMALL_LDS, 0x5a);
+	wm_win_job_t jb;
+	memset(&jb, 0, sizeof(jb));
+	jb.seq_off = seeded ? 0 : -1; jb.n_pre = n_pre; jb.max_dist_x = max_dist_x; jb.min_dist_x = min_dist_x; jb.max_dist_y = max_dist_y; jb.bw = bw;
+	jb.max_skip = max_skip; jb.max_iter = max_iter; jb.min_cnt = min_cnt; jb.min_sc = min_sc; jb.gap_scale = gap_scale;
+	uint64_t ctr[2] = { 0, 0 };
+	wm_win_res_t res;
+	memset(&res, 0, sizeof(res));
+	simt::exec_mask() = ~0ull;
+	wmk::win_small_wave(jb, n, a.data(), lds.data(), &res, up.data(), vp.data(), ctr);
+	*n_u_out = res.n_u;
+	for (int i = 0; i < res.n_u; ++i) u_out[i] = up[res.u_out + i];
+	for (int i = 0; i < res.n_v; ++i) ax[i] = vp[res.v_out + i].x, ay[i] = vp[res.v_out + i].y;
 	return res.n_v;
 }
 

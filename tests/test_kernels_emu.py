@@ -24,8 +24,9 @@ def emu():
     return _load_emu()
 
 
-# kernel variants that are compiled in but not the library default yet (winnowmap_amd/build.py WM_KERNEL_DEFINES): same tests, same bar
-KSW_VARIANTS = {"default": (), "ror": ("WM_KSW_ROR=1",)}
+# kernel variants next to the library default (winnowmap_amd/build.py WM_KERNEL_DEFINES): same tests, same bar. The default build has
+# WM_KSW_ROR=1 since round 3; "readlane" is the former default (neighbour values through v_readlane + scalar fill)
+KSW_VARIANTS = {"default": (), "readlane": ("WM_KSW_ROR=0",)}
 
 
 @pytest.fixture(scope="module", params=sorted(KSW_VARIANTS))

@@ -16,6 +16,7 @@ def emu():
     E.emu_win_sort.argtypes = [C.c_int, W.u64p, W.u64p, C.c_int]
     E.emu_win_plan.argtypes = [C.c_int, W.u64p, W.u64p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     E.emu_win_extract.argtypes = [C.c_int, W.u64p, W.u64p, W.i32p, W.i32p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), W.u64p]
+    E.emu_win_small.argtypes = [C.c_int, C.c_int, C.c_int, W.u64p, W.u64p] + [C.c_int] * 8 + [C.c_float, C.POINTER(C.c_int), W.u64p]
     return E
 
 
@@ -77,6 +78,7 @@ def test_seed_plan_sort_extract_chain_on_real_windows(emu, small_index):
     H = S["H"]
     windows = [r[st:st + 2000].copy() for r in S["reads"][:2] for st in range(0, 14000, 3500)] + [S["reads"][2], S["reads"][3]]
     n_chain = 0
+    n_small = [0]
     for wi, s in enumerate(windows):
         mx, my = W.o_sketch(bytes(s), 50, 15, bloom=S["bloom"])
         ex, ey, rep = _expected_anchors(S, mx, my, len(s))
@@ -106,6 +108,21 @@ def test_seed_plan_sort_extract_chain_on_real_windows(emu, small_index):
         emu.emu_win_plan(len(sx), sx, sy, 5000, C.byref(avg), C.byref(kl))
         assert avg.value == H.h_avg_qspan(len(sx), sy) and kl.value == (3 if len(sx) <= 256 else 2 if len(sx) <= 1024 else kl.value)
         prm = [dict(max_dist_x=5000, min_dist_x=1000, max_dist_y=5000, bw=500), dict(max_dist_x=16000, min_dist_x=1000, max_dist_y=16000, bw=2000)][wi % 2]
+        # the same job through the one-wavefront LDS path (at most 256 anchors): unsorted seeds (+ handed-in anchors in front) -> chains
+        for npre_s in (0, 9):
+            jx, jy = ex.copy(), ey.copy()
+            if npre_s:
+                jx, jy = np.concatenate([px[:npre_s], jx]), np.concatenate([py[:npre_s], jy])
+            if 0 < len(jx) <= 256 and (not npre_s or n_pre >= npre_s):
+                if npre_s:
+                    wx, wy = W.o_radix_sort_128x(np.concatenate([px[:npre_s], sx]), np.concatenate([py[:npre_s], sy]))
+                else:
+                    wx, wy = sx, sy
+                ou, obx, oby = W.o_chain_dp(wx, wy, **prm)
+                nu = C.c_int(); u = np.zeros(len(jx), np.uint64)
+                nv = emu.emu_win_small(len(jx), npre_s, 1, jx, jy, prm["max_dist_x"], prm["min_dist_x"], prm["max_dist_y"], prm["bw"], 25, 5000, 3, 40, 1.0, C.byref(nu), u)
+                assert nu.value == len(ou) and nv == len(obx) and np.array_equal(u[:nu.value], ou) and np.array_equal(jx[:nv], obx) and np.array_equal(jy[:nv], oby), (wi, npre_s)
+                n_small[0] += 1
         nn = len(sx)
         fa = np.zeros(nn, np.int32); pa = np.zeros(nn, np.int32); va = np.zeros(nn, np.int32)
         emu.emu_chain_fill(nn, sx, sy, prm["max_dist_x"], prm["min_dist_x"], prm["max_dist_y"], prm["bw"], 25, 5000, avg.value, 1.0, fa, pa, va)
@@ -118,7 +135,7 @@ def test_seed_plan_sort_extract_chain_on_real_windows(emu, small_index):
                 assert nu.value == len(ou) and nv == len(obx), (wi, min_cnt, min_sc, glob, nu.value, len(ou), nv, len(obx))
                 assert np.array_equal(u[:nu.value], ou) and np.array_equal(bx[:nv], obx) and np.array_equal(by[:nv], oby), (wi, min_cnt, min_sc, glob)
                 n_chain += 1
-    assert n_chain >= 40
+    assert n_chain >= 40 and n_small[0] >= 8, (n_chain, n_small)
 
 
 def test_extract_on_synthetic_forests(emu):

@@ -9,9 +9,13 @@ import kswcases
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 ctx = gpu.Context(0, 24 << 30)
 sc = gpu.KswScore(2, -4, -1, 4, 2, 24, 1)
-for name, mean, w in (("ont300", 300, 751), ("ont150", 150, 751), ("ont600", 600, 751), ("ont600clip", 600, 500)):
+# ...x = the same shapes as extensions: exact maximum + z-drop (KSW_EZ_EXTZ_ONLY), the EXACT kernel instantiations
+for name, mean, w in (("ont300", 300, 751), ("ont150", 150, 751), ("ont600", 600, 751), ("ont600clip", 600, 500), ("ont300x", 300, 751), ("ont600x", 600, 751), ("ont600clipx", 600, 300)):
     t0 = time.time()
     base = kswcases.ont_segments(1, 2000, mean=mean, w=w)
+    if name.endswith("x"):
+        for c in base:
+            c["flag"] = 0x40
     cases = [base[i % len(base)] for i in range(n)]
     jobs, seqs = gpu.pack_jobs([(c["q"], c["t"], dict(w=c["w"], zdrop=c["zdrop"], end_bonus=c["end_bonus"], flag=c["flag"])) for c in cases])
     tgen = time.time() - t0

@@ -121,6 +121,7 @@ struct Hub {
 	// where the host time goes (seconds, summed over the workers): CPU time running fibers, CPU and wall time inside the batched
 	// calls per operation, wall time asleep waiting for results
 	double cpu_fiber = 0, cpu_op[OP_N] = {0, 0, 0, 0, 0, 0, 0}, wall_op[OP_N] = {0, 0, 0, 0, 0, 0, 0}, wall_idle = 0;
+	double wall_fiber = 0, wall_lock = 0, wall_total = 0;     // wall time running fibers (>> cpu_fiber: the workers are being descheduled), waiting for the hub mutex, inside run()
 	size_t pending(int op) const { return op == OP_SKETCH ? q_sketch.size() : op == OP_SEED ? q_seed.size() : op == OP_CHAIN ? q_chain.size() : op == OP_KSW ? q_ksw.size() : op == OP_KSW_HEAVY ? q_kswh.size() : op == OP_KSW_HUGE ? q_kswx.size() : q_window.size(); }
 	// scheduling knobs (environment, read once per mapping call): a further concurrent batch of an operation that is already in flight is
 	// issued when at least min_more[op] requests are pending and fewer than max_op[op] batches of it are running
@@ -190,12 +191,13 @@ public:
 	void run()
 	{
 		Hub &H = *hub_;
-		double cpu_fiber = 0, wall_idle = 0;
+		double cpu_fiber = 0, wall_idle = 0, wall_fiber = 0, wall_lock = 0;
+		const double run_w0 = wall_s();
 #if defined(__x86_64__)
 		tl_running() = this;
 #endif
 		for (;;) {
-			const double c0 = thread_cpu_s();
+			const double c0 = thread_cpu_s(), fw0 = wall_s();
 			while (!ready_.empty()) {
 				cur_ = ready_.front(); ready_.pop_front();
 				switch_to(main_, cur_->ctx);
@@ -203,11 +205,14 @@ public:
 				cur_ = 0;
 			}
 			cpu_fiber += thread_cpu_s() - c0;
+			const double lw0 = wall_s();
+			wall_fiber += lw0 - fw0;
 			std::unique_lock<std::mutex> lk(H.mu);
+			wall_lock += wall_s() - lw0;
 			publish_locked();
 			for (;;) {
 				if (!inbox_.empty()) { for (Fiber *f : inbox_) ready_.push_back(f); inbox_.clear(); break; }
-				if (H.live.load() == 0) { H.cpu_fiber += cpu_fiber; H.wall_idle += wall_idle; H.cv.notify_all(); return; }
+				if (H.live.load() == 0) { H.cpu_fiber += cpu_fiber; H.wall_idle += wall_idle; H.wall_fiber += wall_fiber; H.wall_lock += wall_lock; H.wall_total += wall_s() - run_w0; H.cv.notify_all(); return; }
 				double wake_in = 1e9;
 				const int op = pick_locked(&wake_in);
 				if (op >= 0) { dispatch(op, lk); continue; }      // (returns with the lock held again)

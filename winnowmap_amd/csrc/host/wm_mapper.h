@@ -15,7 +15,8 @@ struct ReadOut { std::vector<Reg> regs; int rep_len = 0, frag_gap = 0; };
 struct MapStats {
 	uint64_t n_flush = 0, n_ksw = 0, n_chain = 0, n_seed = 0, n_sketch = 0;
 	uint64_t n_batches[4] = {0, 0, 0, 0};                  // batched device calls per operation (window = sketch → seed → chain in one call, seed, chain, ksw)
-	double cpu_fiber = 0, cpu_op[4] = {0, 0, 0, 0}, wall_op[4] = {0, 0, 0, 0}, wall_idle = 0, cpu_help = 0;   // host time accounting (wm_fiber.h), seconds over all workers
+	double cpu_fiber = 0, cpu_op[4] = {0, 0, 0, 0}, wall_op[4] = {0, 0, 0, 0}, wall_idle = 0, cpu_help = 0;
+	double wall_fiber = 0, wall_lock = 0, wall_total = 0;   // host time accounting (wm_fiber.h), seconds over all workers
 };
 
 // Maps reads[i] → out[i] (out is resized). The caller chooses the batch (the reference uses ≤ 1 Gbase mini-batches).

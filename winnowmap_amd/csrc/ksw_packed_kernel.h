@@ -394,29 +394,35 @@ WM_DEV void ksw_dp_packed(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 			if (decltype(IC)::value < NI) pair_body(IC);
 		});
 
-		if constexpr (EXACT) {   // ---- exact max: 32-bit wave maximum, then the lanes that reach it
-			int max_H, max_t;
+		if constexpr (EXACT) {   // ---- exact max: 32-bit wave maximum, then — only when it matters — the lane that reaches it
+			int max_H, max_t = en0;
 			if (r > 0) {
 				max_H = wave_max_i32(hmax);
-				const int en1 = st0 + (en0 - st0) / 4 * 4;
-				const int cfirst = (st0 - base) >> 6, clast = (en0 - base) >> 6;          // the chunks that intersect the band
-				int best_pri = -1;
-				max_t = en0;
-				static_for_desc<B>([&](auto CC) {
-					constexpr int ci = B - 1 - decltype(CC)::value;
-					if (ci < cfirst || ci > clast) return;
-					const int c0 = base + 64 * ci;
-					uint64_t m;
-					if (c0 >= st0 && c0 + 63 <= en0) m = ballot(H[ci] == max_H);
-					else { const V<int> t = ln + c0; m = ballot(H[ci] == max_H && t >= st0 && t <= en0); }
-					while (m) {                                   // priority on ties: en0, then residue groups 0..3 of [st0,en1), then the tail
-						const int tt = c0 + __builtin_ctzll(m);
-						m &= m - 1;
-						const int grp = tt == en0 ? 5 : tt < en1 ? 4 - ((tt - st0) & 3) : 0;
-						const int pri = (grp << 20) | (0xfffff - tt);
-						if (pri > best_pri) best_pri = pri, max_t = tt;
-					}
-				});
+				// max_t is consumed by a new maximum (:src/ksw2.h:160-163) or by a z-drop test that can fire: ez_max - max_H > zdrop + l * e2 needs
+				// ez_max - max_H > zdrop (l >= 0). Every other row leaves it alone — most rows of a long extension.
+				const bool need_t = max_H > ez_max || (zdrop >= 0 && ez_max - max_H > zdrop);
+				if (need_t) {
+					WM_KEEP_BRANCH();
+					// The reference's SIMD tie rule (src/ksw2_extd2_sse.c:315-358) as a lane priority: en0 first, then residue groups 0..3 of [st0, en1),
+					// then the tail [en1, en0); inside a group the lower lane. Chunk starts are multiples of 4, so the residue is the same in every chunk.
+					// Chunks that do not hold the maximum cost one compare and a branch; no per-chunk scalar bookkeeping.
+					const int en1 = st0 + (en0 - st0) / 4 * 4;
+					const V<int> g4 = (4 - ((ln + (base - st0)) & 3)) << 20;
+					V<int> best = -1;
+					static_for_desc<B>([&](auto CC) {
+						constexpr int ci = decltype(CC)::value;
+						if (ci >= 2 * NI) return;
+						const V<int> t = ln + (base + 64 * ci);
+						const vbool hit = H[ci] == max_H && cast<unsigned>(t - st0) <= (unsigned)(en0 - st0);
+						if (any(hit)) {
+							WM_KEEP_BRANCH();
+							V<int> pri = sel(t < en1, g4, V<int>(0));
+							pri = sel(t == en0, V<int>(5 << 20), pri) | (V<int>(0xfffff) - t);
+							best = vmax(best, sel(hit, pri, V<int>(-1)));
+						}
+					});
+					max_t = 0xfffff - (wave_max_i32(best) & 0xfffff);
+				}
 			} else {
 				WM_IF(ln == 0) H[0] = vlo8(Vv[0]) - qe; WM_END
 				max_H = readlane(H[0], 0); max_t = 0;

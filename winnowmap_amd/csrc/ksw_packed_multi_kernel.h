@@ -299,22 +299,31 @@ WM_DEV void ksw_dp_pmulti(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 			if (r > 0) {
 				const int hm = wave_max_i32(hmax);
 				if (hm > KSW_NEG_INF) {
-					const int en1 = st0 + (en0 - st0) / 4 * 4;
-					int best_pri = -1;
+					// The lane that holds the maximum is consumed by a new maximum or by a z-drop test that can fire (ez_max - max_H > zdrop + l * e2 needs
+					// ez_max - max_H > zdrop). Each wavefront decides with ITS maximum hm <= max_H: hm > ez_max (it may hold a new maximum), or
+					// ez_max - hm > zdrop (a z-drop row needs this of every wavefront); a wavefront for which neither holds cannot be the holder of a
+					// maximum anybody looks at, and publishes priority 0 (below every real one). The tie rule (src/ksw2_extd2_sse.c:315-358) as a lane
+					// priority, evaluated on the vector unit only in chunks that hold the maximum (see ksw_dp_packed).
+					int best_pri = 0;
+					if (hm > ez_max || (zdrop >= 0 && ez_max - hm > zdrop)) {
+						WM_KEEP_BRANCH();
+						const int en1 = st0 + (en0 - st0) / 4 * 4;
+						const V<int> g4 = (4 - ((ln + (base - st0)) & 3)) << 20;
+						V<int> best = -1;
 #pragma unroll
-					for (int ci = 0; ci < 2 * BP; ++ci) {
-						const int g = (ci >> 1) * NWV + wv, c0 = base + 128 * g + 64 * (ci & 1);
-						if (g >= NI || c0 > en0 || c0 + 63 < st0) continue;
-						const int lo = st0 > c0 ? st0 - c0 : 0, hi = en0 - c0 < 63 ? en0 - c0 : 63;
-						const uint64_t band = (hi == 63 ? ~(uint64_t)0 : (((uint64_t)1 << (hi + 1)) - 1)) & ~(((uint64_t)1 << lo) - 1);
-						uint64_t m = ballot(H[ci] == hm) & band;
-						while (m) {                                   // priority on ties: en0, then residue groups 0..3 of [st0,en1), then the tail
-							const int tt = c0 + __builtin_ctzll(m);
-							m &= m - 1;
-							const int grp = tt == en0 ? 5 : tt < en1 ? 4 - ((tt - st0) & 3) : 0;
-							const int pri = (grp << 20) | (0xfffff - tt);
-							if (pri > best_pri) best_pri = pri;
+						for (int ci = 0; ci < 2 * BP; ++ci) {
+							const int g = (ci >> 1) * NWV + wv, c0 = base + 128 * g + 64 * (ci & 1);
+							if (g >= NI) continue;
+							const V<int> t = ln + c0;
+							const vbool hit = H[ci] == hm && cast<unsigned>(t - st0) <= (unsigned)(en0 - st0);
+							if (any(hit)) {
+								WM_KEEP_BRANCH();
+								V<int> pri = sel(t < en1, g4, V<int>(0));
+								pri = sel(t == en0, V<int>(5 << 20), pri) | (V<int>(0xfffff) - t);
+								best = vmax(best, sel(hit, pri, V<int>(-1)));
+							}
 						}
+						best_pri = wave_max_i32(best);
 					}
 					if (best_pri >= 0) kk = (long long)hm * 4294967296LL + (long long)best_pri;
 				}

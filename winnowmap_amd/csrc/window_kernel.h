@@ -298,18 +298,26 @@ template <bool G> WM_DEV void win_sort_wave(wm128_t *a_, int n, int *ws)
 // ------------------------------------------------------------------------------------------------------------------------------
 // what mm_chain_dp needs before its fill (src/chain.c:36-40 avg_qspan) and the kernel class of the fill; appended to the class's list
 // ------------------------------------------------------------------------------------------------------------------------------
-WM_DEV void win_plan_wave(const wm_win_job_t jb, int j, uint64_t a_off, int n, const wm128_t *a_, wm_chain_job_t *cj, int *lists, int *counts, int n_jobs)
+// avg_qspan (src/chain.c:36-40): (float)sum / n with an exact integer sum
+WM_DEV float win_avg_qspan(const wm128_t *a_, int n)
 {
 	const V<int> ln = lane();
 	const uint64_t *a = (const uint64_t*)a_;
-	if (n <= 0) return;
 	V<int> part = 0;
 	for (int i0 = 0; i0 < n; i0 += 64) {
 		const V<int> i = ln + i0;
 		WM_IF(i < n) part = part + cast<int>(gld(a, cast<long long>(i) * 2LL + 1LL) >> 32 & (uint64_t)0xff); WM_END
 	}
 	const int sum = readlane(wave_sum_i32(part), 0);                          // (spans are < 256: the sum fits 32 bits below 8.4 M anchors, far beyond what a call's anchor pool holds per job)
-	const float avg = (float)(uint64_t)(uint32_t)sum / (float)(long long)n;
+	return (float)(uint64_t)(uint32_t)sum / (float)(long long)n;
+}
+
+WM_DEV void win_plan_wave(const wm_win_job_t jb, int j, uint64_t a_off, int n, const wm128_t *a_, wm_chain_job_t *cj, int *lists, int *counts, int n_jobs)
+{
+	const V<int> ln = lane();
+	const uint64_t *a = (const uint64_t*)a_;
+	if (n <= 0) return;
+	const float avg = win_avg_qspan(a_, n);
 	int klass = n > 256 ? (n > 1024 ? 1 : 2) : 3;
 	if (n > 1024) {            // DENSE if a sample of anchors has more than ~900 predecessors within max_dist_x (satellite arrays): 8 waves, 4096-anchor window
 		V<int> worst = 0;
@@ -341,8 +349,9 @@ WM_DEV void win_plan_wave(const wm_win_job_t jb, int j, uint64_t a_off, int n, c
 // ------------------------------------------------------------------------------------------------------------------------------
 // mm_chain_dp after the fill (src/chain.c:89-165) for one job: peak scores, chain ends, backtracking with the shared-anchor cut, compaction,
 // chains ordered by their first anchor. f, p, v, t: the fill's arrays (LDS copies when G = false, the global slab when G = true; v and t are
-// scratch as in the reference). zu: 2 n uint64 of global scratch (z / u, then u2), b: n anchors of global scratch, wbuf: n_u <= n anchors
-// of global scratch, a: the job's sorted anchors in global memory — overwritten with the chained anchors, as the reference does (:158-163).
+// scratch as in the reference). zu: n uint64 of scratch (z / u), b: n anchors of scratch, wbuf: n_u <= n anchors of scratch, a: the job's
+// sorted anchors. The chains (u) and their anchors go straight to the call's dense result pools; the job takes its slots with one atomic
+// per pool (pool_ctr[0] chains, pool_ctr[1] anchors), so nothing has to be compacted afterwards.
 // ------------------------------------------------------------------------------------------------------------------------------
 // scalar pieces (lane 0)
 WM_DEV void win_peaks(int n, const int *f, const int *p, int *v)             // src/chain.c:89
@@ -364,11 +373,13 @@ WM_DEV void win_backtrack(int n_z, uint64_t *u, const int *f, const int *p, int 
 	*n_u_out = k; *n_v_out = n_v;
 }
 
-template <bool G> WM_DEV void win_extract_wave(int n, int min_cnt, int min_sc, wm128_t *a_, int *f, int *p, int *v, int *t,
-                                               uint64_t *zu, wm128_t *b_, wm128_t *wbuf_, int *ws, wm_win_res_t *res)
+template <bool G> WM_DEV void win_extract_wave(int n, int min_cnt, int min_sc, const wm128_t *a_, int *f, int *p, int *v, int *t,
+                                               uint64_t *zu, wm128_t *b_, wm128_t *wbuf_, int *ws, wm_win_res_t *res,
+                                               uint64_t *u_pool, wm128_t *v_pool_, uint64_t *pool_ctr)
 {
 	const V<int> ln = lane();
-	uint64_t *a = (uint64_t*)a_, *b = (uint64_t*)b_, *wb = (uint64_t*)wbuf_;
+	const uint64_t *a = (const uint64_t*)a_;
+	uint64_t *b = (uint64_t*)b_, *wb = (uint64_t*)wbuf_, *vp = (uint64_t*)v_pool_;
 	if (n <= 0) return;
 	WM_LANE0_BEGIN win_peaks(n, f, p, v); WM_LANE0_END
 	for (int i0 = 0; i0 < n; i0 += 64) { const V<int> i = ln + i0; WM_IF(i < n) gst(t, i, V<int>(0)); WM_END }
@@ -423,7 +434,12 @@ template <bool G> WM_DEV void win_extract_wave(int n, int min_cnt, int min_sc, w
 	win_fence();
 	win_sync<false>();
 	const int n_u = uniform(gld(cnts, 0LL)), n_v = uniform(gld(cnts, 1LL));
-	WM_IF(ln == 0) gst(&res->n_u, V<long long>(0LL), V<int>(n_u)); gst(&res->n_v, V<long long>(0LL), V<int>(n_v)); WM_END
+	// the job's slots in the dense result pools (what travels back to the host): one atomic per pool
+	const uint64_t u_out = n_u ? wave_alloc(pool_ctr, (uint64_t)n_u) : 0, v_out = n_u ? wave_alloc(pool_ctr + 1, (uint64_t)n_v) : 0;
+	WM_IF(ln == 0)
+		gst(&res->n_u, V<long long>(0LL), V<int>(n_u)); gst(&res->n_v, V<long long>(0LL), V<int>(n_v));
+		gst(&res->u_out, V<long long>(0LL), V<uint32_t>((uint32_t)u_out)); gst(&res->v_out, V<long long>(0LL), V<uint32_t>((uint32_t)v_out));
+	WM_END
 	if (n_u == 0) return;
 	// :141-150: anchors of every chain in ascending order into b; w[i] = (x of the chain's first anchor, start << 32 | i)
 	{
@@ -450,8 +466,9 @@ template <bool G> WM_DEV void win_extract_wave(int n, int min_cnt, int min_sc, w
 	win_fence();
 	{
 		int k = 0;
-		uint64_t *u2 = zu + n;
-		for (int i = 0; i < n_u; ++i) {                                       // :156-162
+		uint64_t *u2 = u_pool + u_out;
+		vp += 2 * v_out;
+		for (int i = 0; i < n_u; ++i) {                                       // :156-162 (written to the result pools instead of back over a)
 			const uint64_t wy = gld(wb, (long long)i * 2 + 1);
 			const int src = uniform((int)(uint32_t)wy), st = uniform((int)(wy >> 32));
 			const uint64_t uj = gld(zu, (long long)src);
@@ -460,12 +477,46 @@ template <bool G> WM_DEV void win_extract_wave(int n, int min_cnt, int min_sc, w
 			for (int j0 = 0; j0 < cnt; j0 += 64) {
 				const V<int> j = ln + j0;
 				WM_IF(j < cnt)
-					gst(a, cast<long long>(j + k) * 2LL, gld(b, cast<long long>(j + st) * 2LL)); gst(a, cast<long long>(j + k) * 2LL + 1LL, gld(b, cast<long long>(j + st) * 2LL + 1LL));
+					gst(vp, cast<long long>(j + k) * 2LL, gld(b, cast<long long>(j + st) * 2LL)); gst(vp, cast<long long>(j + k) * 2LL + 1LL, gld(b, cast<long long>(j + st) * 2LL + 1LL));
 				WM_END
 			}
 			k += cnt;
 		}
 	}
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Jobs of at most W = WIN_SMALL anchors (the bulk: one MCAS window yields ~100): everything after the seed expansion — both sorts, avg_qspan, the
+// chaining fill and the extraction — by ONE wavefront without leaving LDS. ga: the job's anchors as the seed kernel wrote them (global).
+// lds: WIN_SMALL_LDS bytes. The results go to the call's result pools like those of win_extract_wave.
+// ------------------------------------------------------------------------------------------------------------------------------
+enum { WIN_SMALL = 256, WIN_WS_PAD = (WIN_WS_INTS + 3) & ~3,
+       WIN_SMALL_LDS = WIN_WS_PAD * 4 + WIN_SMALL * (16 /* anchors */ + 28 /* fill window */ + 8 /* v, t */ + 8 /* z/u */ + 16 /* b */ + 16 /* w */) };
+WM_DEV void win_small_wave(const wm_win_job_t jb, int n, const wm128_t *ga_, unsigned char *lds, wm_win_res_t *res, uint64_t *u_pool, wm128_t *v_pool, uint64_t *pool_ctr)
+{
+	const V<int> ln = lane();
+	constexpr int W = WIN_SMALL;
+	int *ws = (int*)lds;
+	wm128_t *stage = (wm128_t*)(ws + WIN_WS_PAD);
+	uint64_t *sx = (uint64_t*)(stage + W), *sy = sx + W;
+	int *sf = (int*)(sy + W), *sp = sf + W, *st = sp + W, *lv = st + W, *lt = lv + W;
+	uint64_t *zu = (uint64_t*)(lt + W);
+	wm128_t *b = (wm128_t*)(zu + W), *wb = b + W;
+	const uint64_t *ga = (const uint64_t*)ga_;
+	uint64_t *la = (uint64_t*)stage;
+	for (int i0 = 0; i0 < 2 * n; i0 += 64) { const V<int> i = ln + i0; WM_IF(i < 2 * n) gst(la, i, gld(ga, i)); WM_END }
+	lds_sync();
+	if (jb.seq_off >= 0) {                                                    // src/map.c:252, then :833 when anchors were handed in
+		const int n_pre = jb.n_pre < n ? jb.n_pre : n;
+		win_sort_wave<false>(stage + n_pre, n - n_pre, ws);
+		if (n_pre > 0) win_sort_wave<false>(stage, n, ws);
+	}
+	wm_chain_job_t cj;
+	cj.a_off = 0; cj.n = n; cj.max_dist_x = jb.max_dist_x; cj.min_dist_x = jb.min_dist_x; cj.max_dist_y = jb.max_dist_y; cj.bw = jb.bw;
+	cj.max_skip = jb.max_skip; cj.max_iter = jb.max_iter; cj.avg_qspan = win_avg_qspan(stage, n); cj.gap_scale = jb.gap_scale; cj.pad = 0;
+	chain_wave(cj, stage, W, sx, sy, sf, sp, st, sf, sp, (int*)0);            // n <= W: nothing leaves the window; f and p stay where they are
+	lds_sync();
+	win_extract_wave<false>(n, jb.min_cnt, jb.min_sc, stage, sf, sp, lv, lt, zu, b, wb, ws, res, u_pool, v_pool, pool_ctr);
 }
 
 } // namespace wmk

@@ -1718,7 +1718,7 @@ catch (const std::bad_alloc &) { return set_err(WM_ENOMEM, "out of host memory")
 // ======================================================================================================
 __global__ __launch_bounds__(64) void win_seed_kernel(wm_index_view_t ix, const wm_win_job_t *__restrict__ jobs, const wm_sketch_job_t *__restrict__ sj, const int *__restrict__ mcnt,
                                                        const wm128_t *__restrict__ mini_pool, const wm128_t *__restrict__ pre_pool, int *occ, uint32_t *first, int *emit,
-                                                       wm128_t *anchors, uint64_t *used, uint64_t cap, wm_win_res_t *res)
+                                                       wm128_t *anchors, uint64_t *used, uint64_t cap, wm_win_res_t *res, int *worst_err)
 {
 	WM_SETPRIO(2);
 	const int j = blockIdx.x;
@@ -1728,7 +1728,23 @@ __global__ __launch_bounds__(64) void win_seed_kernel(wm_index_view_t ix, const 
 	const bool over = n_mini > s.cap;                       // the minimizer slot was too small: the caller retries with full-size slots
 	if (over) n_mini = 0;
 	wmk::win_seed_wave(ix, jb, mini_pool + s.out_off, n_mini, pre_pool + jb.pre_off, occ + s.out_off, first + s.out_off, emit + s.out_off, anchors, used, cap, res + j);
-	if (over && threadIdx.x == 0) res[j].err = 1;
+	if (threadIdx.x == 0) {
+		if (over) res[j].err = 1;
+		const int e = res[j].err;
+		if (e) atomicMax(worst_err, e);
+	}
+}
+
+// jobs of at most WIN_SMALL anchors: sorts, fill and extraction by one wavefront in LDS (win_small_wave); larger ones take the kernels below
+__global__ __launch_bounds__(64) void win_small_kernel(const wm_win_job_t *__restrict__ jobs, wm_win_res_t *res, const wm128_t *__restrict__ anchors,
+                                                        uint64_t *u_pool, wm128_t *v_pool, uint64_t *pool_ctr)
+{
+	WM_SETPRIO(2);
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int j = blockIdx.x;
+	const wm_win_res_t r = res[j];
+	if (r.n_a <= 0 || r.n_a > wmk::WIN_SMALL || r.err) return;
+	wmk::win_small_wave(jobs[j], r.n_a, anchors + r.a_off, smem, res + j, u_pool, v_pool, pool_ctr);
 }
 
 // radix_sort_128x of the seeded anchors (src/map.c:252), of the union with the handed-in ones (src/map.c:833), then avg_qspan + the fill's class.
@@ -1797,7 +1813,7 @@ __global__ __launch_bounds__(64 * NWV) void win_chain_kernel_block(const wm_chai
 
 // src/chain.c:89-165 per job; f, p staged in LDS when the job fits (lo, lds_cap], global slab otherwise (lds_cap = 0)
 __global__ __launch_bounds__(64) void win_extract_kernel(const wm_win_job_t *__restrict__ jobs, wm_win_res_t *res, wm128_t *anchors, int *fpvt, uint64_t *zu, wm128_t *bbuf, wm128_t *wbuf,
-                                                          int lo, int lds_cap)
+                                                          int lo, int lds_cap, uint64_t *u_pool, wm128_t *v_pool, uint64_t *pool_ctr)
 {
 	WM_SETPRIO(2);
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1812,45 +1828,13 @@ __global__ __launch_bounds__(64) void win_extract_kernel(const wm_win_job_t *__r
 		int *lf = ws + ((wmk::WIN_WS_INTS + 3) & ~3), *lp = lf + lds_cap, *lv = lp + lds_cap, *lt = lv + lds_cap;
 		for (int i = threadIdx.x; i < n; i += 64) { lf[i] = gf[i]; lp[i] = gp[i]; }
 		simt::lds_sync();
-		wmk::win_extract_wave<false>(n, jb.min_cnt, jb.min_sc, anchors + r.a_off, lf, lp, lv, lt, zu + 2 * r.a_off, bbuf + r.a_off, wbuf + r.a_off, ws, res + j);
+		wmk::win_extract_wave<false>(n, jb.min_cnt, jb.min_sc, anchors + r.a_off, lf, lp, lv, lt, zu + r.a_off, bbuf + r.a_off, wbuf + r.a_off, ws, res + j, u_pool, v_pool, pool_ctr);
 	} else
-		wmk::win_extract_wave<true>(n, jb.min_cnt, jb.min_sc, anchors + r.a_off, gf, gp, gv, gt, zu + 2 * r.a_off, bbuf + r.a_off, wbuf + r.a_off, ws, res + j);
-}
-
-// exclusive prefix sums of n_u and n_v over the jobs (single block) -> res[j].u_out / v_out, totals[0..1]; totals[2] = worst err
-__global__ __launch_bounds__(1024) void win_scan_kernel(int n, wm_win_res_t *res, uint32_t *totals)
-{
-	WM_SETPRIO(3);
-	__shared__ uint32_t pu[1024], pv[1024];
-	__shared__ int perr[1024];
-	const int tid = threadIdx.x, per = (n + 1023) / 1024, b = tid * per, e = b + per < n ? b + per : n;
-	uint32_t su = 0, sv = 0; int er = 0;
-	for (int i = b; i < e; ++i) { su += (uint32_t)res[i].n_u; sv += (uint32_t)res[i].n_v; er = res[i].err > er ? res[i].err : er; }
-	pu[tid] = su; pv[tid] = sv; perr[tid] = er;
-	__syncthreads();
-	if (tid == 0) {
-		uint32_t au = 0, av = 0; int ae = 0;
-		for (int i = 0; i < 1024; ++i) { uint32_t t = pu[i]; pu[i] = au; au += t; t = pv[i]; pv[i] = av; av += t; ae = perr[i] > ae ? perr[i] : ae; }
-		totals[0] = au; totals[1] = av; totals[2] = (uint32_t)ae;
-	}
-	__syncthreads();
-	su = pu[tid]; sv = pv[tid];
-	for (int i = b; i < e; ++i) { res[i].u_out = su; res[i].v_out = sv; su += (uint32_t)res[i].n_u; sv += (uint32_t)res[i].n_v; }
-}
-__global__ __launch_bounds__(64) void win_gather_kernel(const wm_win_res_t *__restrict__ res, const wm128_t *__restrict__ anchors, const uint64_t *__restrict__ zu,
-                                                         uint64_t *__restrict__ u_pool, wm128_t *__restrict__ v_pool)
-{
-	WM_SETPRIO(3);
-	const int j = blockIdx.x;
-	const wm_win_res_t r = res[j];
-	const uint64_t *u2 = zu + 2 * r.a_off + r.n_a;
-	const wm128_t *a = anchors + r.a_off;
-	for (int i = threadIdx.x; i < r.n_u; i += 64) u_pool[r.u_out + i] = u2[i];
-	for (int i = threadIdx.x; i < r.n_v; i += 64) v_pool[r.v_out + i] = a[i];
+		wmk::win_extract_wave<true>(n, jb.min_cnt, jb.min_sc, anchors + r.a_off, gf, gp, gv, gt, zu + r.a_off, bbuf + r.a_off, wbuf + r.a_off, ws, res + j, u_pool, v_pool, pool_ctr);
 }
 
 // device side of one call: everything up to the dense result pools; the caller copies them out. slot_full: full-size minimizer slots (retry)
-struct WinDev { wm_win_res_t *d_res; uint64_t *d_upool; wm128_t *d_vpool; uint32_t *d_tot; uint32_t tot[3]; };
+struct WinDev { wm_win_res_t *d_res; uint64_t *d_upool; wm128_t *d_vpool; uint64_t *d_ctr; uint64_t ctr[4]; uint32_t tot[3]; };
 static int window_launch(wm_ctx_t *c, int n, const wm_window_job_t *jobs, const uint8_t *seqs, size_t seqs_bytes, const wm128_t *pre, size_t n_pre_total,
                          int max_occ, int64_t flag, bool slot_full, WinDev &D)
 {
@@ -1901,17 +1885,17 @@ static int window_launch(wm_ctx_t *c, int n, const wm_window_job_t *jobs, const 
 	D.d_res = (wm_win_res_t*)arena_take(c, (size_t)n * sizeof(wm_win_res_t) + 64);
 	wm_chain_job_t *d_cj = (wm_chain_job_t*)arena_take(c, (size_t)n * sizeof(wm_chain_job_t) + 64);
 	int *d_lists = (int*)arena_take(c, (size_t)n * 4 * 4 + 64);
-	uint64_t *d_ctr = (uint64_t*)arena_take(c, 64);          // [0] anchors used; ints at +8: the four class counts; uint32 at +32: totals
+	uint64_t *d_ctr = (uint64_t*)arena_take(c, 64);          // [0] anchors used, [1] chains in the result pool, [2] anchors in the result pool, [3] worst err (int), [4..5] the four class counts (ints)
 	if (!d_jobs || !d_sj || !d_ord || !d_seqs || !d_pre || !d_so || !d_sx || !d_sy || !d_sl || !d_mini || !d_mcnt || !d_occ || !d_emit || !d_first || !D.d_res || !d_cj || !d_lists || !d_ctr)
 		return set_err(WM_ENOMEM, "window batch does not fit the arena");
-	int *d_counts = (int*)(d_ctr + 1);
-	D.d_tot = (uint32_t*)(d_ctr + 4);
-	// the rest of the arena is the anchor pool: 80 B per anchor (anchors 16, f|p|v|t 16, z/u 16, b 16, w 16) + the two dense result pools (24)
+	int *d_counts = (int*)(d_ctr + 4);
+	D.d_ctr = d_ctr;
+	// the rest of the arena is the anchor pool: 72 B per anchor (anchors 16, f|p|v|t 16, z/u 8, b 16, w 16) + the two dense result pools (24)
 	const size_t left = c->arena_bytes - ((c->arena_used + 255) & ~(size_t)255);
-	const uint64_t cap = left > 4096 ? (left - 4096) / 104 : 0;
+	const uint64_t cap = left > 4096 ? (left - 4096) / 96 : 0;
 	wm128_t *d_a = (wm128_t*)arena_take(c, (cap + 1) * 16);
 	int *d_fpvt = (int*)arena_take(c, (cap + 1) * 16);
-	uint64_t *d_zu = (uint64_t*)arena_take(c, (cap + 1) * 16);
+	uint64_t *d_zu = (uint64_t*)arena_take(c, (cap + 1) * 8);
 	wm128_t *d_b = (wm128_t*)arena_take(c, (cap + 1) * 16), *d_w = (wm128_t*)arena_take(c, (cap + 1) * 16);
 	D.d_upool = (uint64_t*)arena_take(c, (cap + 1) * 8);
 	D.d_vpool = (wm128_t*)arena_take(c, (cap + 1) * 16);
@@ -1930,11 +1914,13 @@ static int window_launch(wm_ctx_t *c, int n, const wm_window_job_t *jobs, const 
 	HIPCHK(hipEventRecord(c->ev[0], c->stream));
 	hipLaunchKernelGGL(sketch_coop_kernel, dim3(n), dim3(64), 0, c->stream, c->skp, d_sj, d_ord, d_seqs, c->d_bloom, d_so, d_sx, d_sy, d_sl, d_mini, d_mcnt);
 	wm_index_view_t ix = { c->d_hkey, c->d_hval, c->d_P, c->hbits, 0 };
-	hipLaunchKernelGGL(win_seed_kernel, dim3(n), dim3(64), 0, c->stream, ix, d_jobs, d_sj, d_mcnt, d_mini, d_pre, d_occ, d_first, d_emit, d_a, d_ctr, cap, D.d_res);
-	const size_t ws_bytes = (size_t)((wmk::WIN_WS_INTS + 3) & ~3) * 4;
-	static const int kSmall = 256, kLarge = 4096;
+	hipLaunchKernelGGL(win_seed_kernel, dim3(n), dim3(64), 0, c->stream, ix, d_jobs, d_sj, d_mcnt, d_mini, d_pre, d_occ, d_first, d_emit, d_a, d_ctr, cap, D.d_res, (int*)(d_ctr + 3));
+	const size_t ws_bytes = (size_t)wmk::WIN_WS_PAD * 4;
+	static const int kSmall = wmk::WIN_SMALL, kLarge = 4096;
+	// the bulk (jobs of at most WIN_SMALL anchors: one MCAS window yields ~100) finishes in one kernel; the rest goes class by class
+	HIPCHK(hipFuncSetAttribute((const void*)win_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	hipLaunchKernelGGL(win_small_kernel, dim3(n), dim3(64), (size_t)wmk::WIN_SMALL_LDS, c->stream, d_jobs, D.d_res, d_a, D.d_upool, D.d_vpool, d_ctr + 1);
 	HIPCHK(hipFuncSetAttribute((const void*)win_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	hipLaunchKernelGGL(win_sort_kernel, dim3(n), dim3(64), ws_bytes + (size_t)kSmall * 16, c->stream, d_jobs, D.d_res, d_a, d_cj, d_lists, d_counts, n, 0, kSmall);
 	hipLaunchKernelGGL(win_sort_kernel, dim3(n), dim3(64), ws_bytes + (size_t)kLarge * 16, c->stream, d_jobs, D.d_res, d_a, d_cj, d_lists, d_counts, n, kSmall, kLarge);
 	hipLaunchKernelGGL(win_sort_kernel, dim3(n), dim3(64), ws_bytes, c->stream, d_jobs, D.d_res, d_a, d_cj, d_lists, d_counts, n, kLarge, 0);
 	{   // the fill, per class list: 0 dense (8 waves, W 4096) | 1 large sparse (1 wave, W 1024) | 2 n <= 1024 | 3 n <= 256
@@ -1944,20 +1930,18 @@ static int window_launch(wm_ctx_t *c, int n, const wm_window_job_t *jobs, const 
 		hipLaunchKernelGGL(win_chain_kernel_block<NWV>, dim3(n), dim3(64 * NWV), (size_t)4096 * 28 + NWV * 69 * 4 + 64, c->stream, d_cj, d_lists, d_counts, d_a, d_fpvt, 4096);
 		hipLaunchKernelGGL(win_chain_kernel, dim3(n), dim3(64), (size_t)1024 * 28, c->stream, d_cj, d_lists + n, d_counts + 1, d_a, d_fpvt, 1024);
 		hipLaunchKernelGGL(win_chain_kernel, dim3(n), dim3(64), (size_t)1024 * 28, c->stream, d_cj, d_lists + 2 * (size_t)n, d_counts + 2, d_a, d_fpvt, 1024);
-		hipLaunchKernelGGL(win_chain_kernel, dim3(n), dim3(64), (size_t)256 * 28, c->stream, d_cj, d_lists + 3 * (size_t)n, d_counts + 3, d_a, d_fpvt, 256);
+		// (class 3, at most 256 anchors: served by win_small_kernel)
 	}
 	HIPCHK(hipFuncSetAttribute((const void*)win_extract_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	hipLaunchKernelGGL(win_extract_kernel, dim3(n), dim3(64), ws_bytes + (size_t)kSmall * 16, c->stream, d_jobs, D.d_res, d_a, d_fpvt, d_zu, d_b, d_w, 0, kSmall);
-	hipLaunchKernelGGL(win_extract_kernel, dim3(n), dim3(64), ws_bytes + (size_t)kLarge * 16, c->stream, d_jobs, D.d_res, d_a, d_fpvt, d_zu, d_b, d_w, kSmall, kLarge);
-	hipLaunchKernelGGL(win_extract_kernel, dim3(n), dim3(64), ws_bytes, c->stream, d_jobs, D.d_res, d_a, d_fpvt, d_zu, d_b, d_w, kLarge, 0);
-	hipLaunchKernelGGL(win_scan_kernel, dim3(1), dim3(1024), 0, c->stream, n, D.d_res, D.d_tot);
-	hipLaunchKernelGGL(win_gather_kernel, dim3(n), dim3(64), 0, c->stream, D.d_res, d_a, d_zu, D.d_upool, D.d_vpool);
+	hipLaunchKernelGGL(win_extract_kernel, dim3(n), dim3(64), ws_bytes + (size_t)kLarge * 16, c->stream, d_jobs, D.d_res, d_a, d_fpvt, d_zu, d_b, d_w, kSmall, kLarge, D.d_upool, D.d_vpool, d_ctr + 1);
+	hipLaunchKernelGGL(win_extract_kernel, dim3(n), dim3(64), ws_bytes, c->stream, d_jobs, D.d_res, d_a, d_fpvt, d_zu, d_b, d_w, kLarge, 0, D.d_upool, D.d_vpool, d_ctr + 1);
 	HIPCHK(hipEventRecord(c->ev[1], c->stream));
 	HIPCHK(hipGetLastError());
-	uint32_t *h_tot = c->pin_small ? (uint32_t*)(c->pin_small + 8) : D.tot;
-	HIPCHK(hipMemcpyAsync(h_tot, D.d_tot, 12, hipMemcpyDeviceToHost, c->stream));
+	uint64_t *h_ctr = c->pin_small ? (uint64_t*)(c->pin_small + 8) : D.ctr;
+	HIPCHK(hipMemcpyAsync(h_ctr, d_ctr, 32, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(ctx_sync(c));                  // (also: the host tables above are read by the copies until here)
-	memcpy(D.tot, h_tot, 12);
+	memcpy(D.ctr, h_ctr, 32);
+	D.tot[0] = (uint32_t)D.ctr[1]; D.tot[1] = (uint32_t)D.ctr[2]; D.tot[2] = (uint32_t)(D.ctr[3] & 0xffffffffu);
 	float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->aux_ms += ms;
 	return WM_OK;
 }
@@ -2283,7 +2267,7 @@ struct wm_mapper_s {
 	std::string text;
 	std::vector<int32_t> hits; std::vector<uint32_t> cigars; std::vector<int64_t> first;
 	uint64_t stats[9];
-	double host_stats[18] = {0};
+	double host_stats[24] = {0};
 	bool sam_header = true;                // wm_map_file writes the @SQ / @PG lines (wm_mapper_set_sam_header)
 	std::vector<std::string> cmdline;      // argv of the front end, for the @PG line of SAM files (wm_mapper_set_cmdline)
 };
@@ -2470,6 +2454,7 @@ static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double
 	m->host_stats[0] += st.cpu_fiber; m->host_stats[1] += st.wall_idle;
 	for (int op = 0; op < 4; ++op) { m->host_stats[2 + op] += st.cpu_op[op]; m->host_stats[6 + op] += st.wall_op[op]; m->host_stats[10 + op] += (double)st.n_batches[op]; }
 	m->host_stats[14] += (tm2 - tm1) * 1e-3; m->host_stats[15] += (now_ms() - tm2) * 1e-3; m->host_stats[16] = m->n_threads; m->host_stats[17] += st.cpu_help;
+	m->host_stats[18] += st.wall_fiber; m->host_stats[19] += st.wall_lock; m->host_stats[20] += st.wall_total;
 	if (trace_m) fprintf(stderr, "[host] fibers cpu %.2f s | idle wall %.2f s | batched calls cpu/wall/n: sketch %.2f/%.2f/%llu seed %.2f/%.2f/%llu chain %.2f/%.2f/%llu ksw %.2f/%.2f/%llu\n", st.cpu_fiber, st.wall_idle,
 	                     st.cpu_op[0], st.wall_op[0], (unsigned long long)st.n_batches[0], st.cpu_op[1], st.wall_op[1], (unsigned long long)st.n_batches[1],
 	                     st.cpu_op[2], st.wall_op[2], (unsigned long long)st.n_batches[2], st.cpu_op[3], st.wall_op[3], (unsigned long long)st.n_batches[3]);
@@ -2532,7 +2517,7 @@ extern "C" int wm_mapper_kernel_stats(const wm_mapper_t *m, double *out, int cap
 extern "C" int wm_mapper_host_stats(const wm_mapper_t *m, double *out, int cap)
 {
 	if (cap < 18) return set_err(WM_EINVAL, "need room for 18 doubles");
-	memcpy(out, m->host_stats, sizeof(m->host_stats));
+	memcpy(out, m->host_stats, (size_t)(cap < 24 ? cap : 24) * sizeof(double));
 	return WM_OK;
 }
 

@@ -371,13 +371,14 @@ class Mapper:
 
     def host_stats(self):
         """host time accounting since the mapper was created (wm_mapper_host_stats), seconds summed over the worker threads"""
-        a = np.zeros(18, np.float64)
+        a = np.zeros(24, np.float64)
         lib().wm_mapper_host_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _chk(lib().wm_mapper_host_stats(self._h, a.ctypes.data, len(a)))
         ops = ("window", "seed", "chain", "ksw")     # (the mapper issues fused window calls and ksw calls; the per-stage slots stay 0)
         return {"cpu_glue_s": float(a[0]), "idle_wall_s": float(a[1]), "cpu_batched_s": {o: float(a[2 + i]) for i, o in enumerate(ops)},
                 "wall_batched_s": {o: float(a[6 + i]) for i, o in enumerate(ops)}, "batched_calls": {o: int(a[10 + i]) for i, o in enumerate(ops)},
-                "map_wall_s": float(a[14]), "format_wall_s": float(a[15]), "threads": int(a[16]), "cpu_help_s": float(a[17])}
+                "map_wall_s": float(a[14]), "format_wall_s": float(a[15]), "threads": int(a[16]), "cpu_help_s": float(a[17]),
+                "glue_wall_s": float(a[18]), "lock_wait_wall_s": float(a[19]), "workers_wall_s": float(a[20])}
 
     def close(self):
         if self._h:
