@@ -135,16 +135,21 @@ __global__ __launch_bounds__(64 * NWV) void ksw_pmulti_kernel(wm_ksw_score_t sc,
 	const int j = order[blockIdx.x];
 	const wm_ksw_djob_t jb = jobs[j];
 	const int qpad = (jb.qlen + 15) & ~15;
-	const uint8_t *qp = seqs + jb.q_off, *tp = seqs + jb.t_off;
+	// Two copies of the machine, one per address space of the sequences: a pointer that is LDS or global at run time would make every query
+	// fetch of every row a FLAT load, whose s_waitcnt vmcnt(0) also drains the row's traceback stores — a memory round trip per row
+	// (6 us per row measured, profiles/r03c_window_profile.txt: 22 GCUPS). With the LDS copy the row loop never waits for its stores.
 	if (qpad + jb.tlen <= seq_cap) {
 		uint8_t *st = sq + qpad;
 		for (int i = threadIdx.x; i < jb.qlen; i += blockDim.x) sq[i] = seqs[jb.q_off + i];
 		for (int i = threadIdx.x; i < jb.tlen; i += blockDim.x) st[i] = seqs[jb.t_off + i];
 		__syncthreads();
-		qp = sq; tp = st;
+		if (jb.flag & KSW_F_APPROX_MAX) wmk::ksw_dp_pmulti<BP, NWV, true, true, false>(sc, jb, sq, st, tb, lds, res + j);
+		else wmk::ksw_dp_pmulti<BP, NWV, true, true, true>(sc, jb, sq, st, tb, lds, res + j);
+	} else {
+		const uint8_t *qp = seqs + jb.q_off, *tp = seqs + jb.t_off;
+		if (jb.flag & KSW_F_APPROX_MAX) wmk::ksw_dp_pmulti<BP, NWV, true, true, false>(sc, jb, qp, tp, tb, lds, res + j);
+		else wmk::ksw_dp_pmulti<BP, NWV, true, true, true>(sc, jb, qp, tp, tb, lds, res + j);
 	}
-	if (jb.flag & KSW_F_APPROX_MAX) wmk::ksw_dp_pmulti<BP, NWV, true, true, false>(sc, jb, qp, tp, tb, lds, res + j);
-	else wmk::ksw_dp_pmulti<BP, NWV, true, true, true>(sc, jb, qp, tp, tb, lds, res + j);
 }
 
 // operands of position jobs (wm_ksw_batch_pos): expand query and target of job blockIdx.x into the batch's sequence slab. Query = two-strand
