@@ -279,6 +279,9 @@ def main():
     n_cores = wmdist.available_cores()       # hardware threads, affinity and the container CPU quota
     # host threads per rank: the ranks of one node share its cores — divide them explicitly
     n_threads = args.threads or wmdist.host_threads_per_rank(n_cores, world)
+    if rank == 0 and world > 1 and n_threads < 8:
+        log("WARNING: %d usable host cores shared by %d ranks = %d host threads per GPU; the per-read glue needs about %s CPU-s per Gbase (see the `host` block of a 1-GPU run), "
+            "so this node's host side, not its GPUs, bounds the scaling curve" % (n_cores, world, n_threads, "35"))
     tmp = tempfile.mkdtemp(prefix="wmbench_")
 
     # ---- reference + index: rank 0 builds, RCCL broadcasts the flat arrays ----
@@ -353,6 +356,11 @@ def main():
         if dist is not None:
             out["config"]["rccl_world_size"] = dist.get_world_size()
         out["host"] = host_report(hs0, hs1, ru0, ru1, elapsed, n_cores)
+        # what the host side alone allows: read bases per CPU-second spent (all threads of this rank) x the cores this rank may use
+        cpu_per_base = out["host"]["process_cpu_s"] / max(1.0, float(bases))
+        out["host"]["host_threads"] = n_threads
+        out["host"]["host_bound_gbps_per_rank"] = round(min(n_threads, n_cores) / max(cpu_per_base, 1e-12) / 1e9, 4)
+        out["host"]["host_bound_note"] = "bases per CPU-second of this rank x its host threads: the rate at which the host glue alone could feed one GPU; with N ranks on one node the usable cores are divided by N"
         thr1 = cgroup_throttle()
         out["host"]["cpu_quota_throttled"] = {"periods": thr1[0] - thr0[0], "seconds": round(thr1[1] - thr0[1], 3)}
         if world == 1 and args.cpu_sample != 0:

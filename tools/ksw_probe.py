@@ -31,3 +31,25 @@ for name, mean, w in (("ont300", 300, 751), ("ont150", 150, 751), ("ont600", 600
           (name, n, best["cells"], best["dp_ms"], best["bt_ms"], best["wall_ms"], best["cells"] / best["dp_ms"] / 1e6,
            best["tb_bytes"] / best["dp_ms"] / 1e6, tgen), flush=True)
     b.free()
+# wide hulls: the multi-wave classes alone on the chip (ksw_pmulti_kernel<4,4> / <4,8> / <8,8>) — their rate here against their rate inside the
+# mapper (bench.py `classes`) separates what the kernel costs from what sharing the chip costs
+from winnowmap_amd import synth
+rng = np.random.default_rng(3)
+for name, L, njob, flag in (("p16_1500x", 1500, 256, 0x40), ("blk_3000x", 3000, 96, 0x40), ("blk_3000a", 3000, 96, 0x08), ("blk2_6000x", 6000, 32, 0x40)):
+    cases = []
+    for it in range(njob):
+        t = rng.integers(0, 4, L).astype(np.uint8)
+        q = synth.mutate_codes(t, rng, 0.03, 0.03, 0.04)
+        cases.append((q, t, dict(w=L + 1, zdrop=400, end_bonus=-1, flag=flag)))
+    jobs, seqs = gpu.pack_jobs(cases)
+    b = ctx.ksw_prepare(sc, jobs, seqs)
+    b.run()
+    best = None
+    for rep in range(2):
+        t1 = time.time(); b.run(); wall = time.time() - t1
+        s = b.stats()
+        if best is None or s["dp_ms"] < best["dp_ms"]:
+            best = dict(s, wall_ms=wall * 1e3)
+    print("%-11s jobs=%d cells=%.3e dp=%.2f ms bt=%.2f ms wall=%.2f ms  -> %.1f GCUPS (dp), %.2f us per row" %
+          (name, njob, best["cells"], best["dp_ms"], best["bt_ms"], best["wall_ms"], best["cells"] / best["dp_ms"] / 1e6, best["dp_ms"] * 1e3 / (2 * L)), flush=True)
+    b.free()
