@@ -404,4 +404,29 @@ int emu_win_small(int n, int n_pre, int seeded, uint64_t *ax, uint64_t *ay, int 
 	return res.n_v;
 }
 
+// the workgroup-level stable LSD sort of large anchor sets (win_bigsort_block) on nwv emulated wavefronts; returns the tie flag, x / y sorted
+int emu_win_bigsort(int n, uint64_t *x, uint64_t *y, int nwv)
+{
+	std::vector<wm128_t> a(n + 1), b0(n + 1), b1(n + 1);
+	for (int i = 0; i < n; ++i) a[i].x = x[i], a[i].y = y[i];
+	std::vector<int> lds(WIN_BIG_INTS(nwv), 0x5a5a5a5a);
+	std::vector<int> cur(nwv, -7), tie(nwv, -7);
+	pthread_barrier_t bar;
+	pthread_barrier_init(&bar, 0, nwv);
+	simt::block_barrier() = &bar;
+	std::vector<std::thread> th;
+	for (int w = 0; w < nwv; ++w)
+		th.emplace_back([&, w]() {
+			simt::wave_slot() = w; simt::exec_mask() = ~0ull;
+			cur[w] = wmk::win_bigsort_block(nwv, a.data(), b0.data(), b1.data(), n, lds.data(), &tie[w]);
+		});
+	for (auto &t : th) t.join();
+	simt::block_barrier() = 0;
+	pthread_barrier_destroy(&bar);
+	for (int w = 1; w < nwv; ++w) if (cur[w] != cur[0] || tie[w] != tie[0]) return -100;      // the result must be uniform over the workgroup
+	const wm128_t *r = cur[0] < 0 ? a.data() : cur[0] == 0 ? b0.data() : b1.data();
+	for (int i = 0; i < n; ++i) x[i] = r[i].x, y[i] = r[i].y;
+	return tie[0];
+}
+
 } // extern "C"

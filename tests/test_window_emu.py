@@ -16,6 +16,7 @@ def emu():
     E.emu_win_sort.argtypes = [C.c_int, W.u64p, W.u64p, C.c_int]
     E.emu_win_plan.argtypes = [C.c_int, W.u64p, W.u64p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     E.emu_win_extract.argtypes = [C.c_int, W.u64p, W.u64p, W.i32p, W.i32p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), W.u64p]
+    E.emu_win_bigsort.argtypes = [C.c_int, W.u64p, W.u64p, C.c_int]
     E.emu_win_small.argtypes = [C.c_int, C.c_int, C.c_int, W.u64p, W.u64p] + [C.c_int] * 8 + [C.c_float, C.POINTER(C.c_int), W.u64p]
     return E
 
@@ -219,3 +220,29 @@ def _py_extract(x, y, f, p, min_cnt, min_sc):
         j = int(sy[i]) & 0xffffffff; st = int(sy[i]) >> 32; cnt = u[j] & 0xffffffff
         ou.append(u[j]); ox += bx[st:st + cnt]; oy += by[st:st + cnt]
     return np.array(ou, np.uint64), np.array(ox, np.uint64), np.array(oy, np.uint64)
+
+
+@pytest.mark.parametrize("nwv", [1, 3, 8])
+def test_workgroup_sort_of_large_anchor_sets_is_the_stable_sort_and_flags_ties(emu, nwv):
+    """win_bigsort_block: a stable LSD radix sort by a whole workgroup. Without ties it is the reference's order (any exact sort is); ties are
+    reported so that the caller replays the reference's unstable permutation instead."""
+    rng = np.random.default_rng(50 + nwv)
+    for n in (0, 1, 2, 63, 64, 65, 500, 4097, 9000, 20011):
+        for tie in (0.0, 0.05):
+            for shape in range(2):
+                x = _anchor_like_keys(rng, n, tie) if shape == 0 else rng.integers(0, 1 << 62, n, dtype=np.int64).astype(np.uint64)
+                if shape == 1 and tie and n > 3:
+                    x[n // 2] = x[n // 3]
+                if tie == 0.0 and n:
+                    x = np.unique(x); rng.shuffle(x)          # distinct keys
+                m = len(x)
+                y = np.arange(m, dtype=np.uint64)
+                o = np.argsort(x, kind="stable")
+                gx, gy = x.copy(), y.copy()
+                flag = emu.emu_win_bigsort(m, gx, gy, nwv)
+                assert flag in (0, 1), flag
+                assert np.array_equal(gx, x[o]) and np.array_equal(gy, y[o]), (n, tie, shape, nwv)
+                assert flag == int(m > 1 and len(np.unique(x)) < m)
+                if flag == 0:
+                    ex, ey = W.o_radix_sort_128x(x, y)
+                    assert np.array_equal(gx, ex) and np.array_equal(gy, ey)

@@ -296,6 +296,119 @@ template <bool G> WM_DEV void win_sort_wave(wm128_t *a_, int n, int *ws)
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// Anchor sets beyond the LDS classes (reads inside a repeat family: 10^4 .. 10^6 anchors) sorted by a whole WORKGROUP: a stable LSD radix
+// sort, 8 bits per pass, constant digits skipped. Wavefront w owns the w-th contiguous chunk of the array (stability = chunk order, then
+// position): per pass every wavefront counts its chunk (LDS atomics), the counts are prefixed digit-major / wavefront-minor, and every
+// wavefront scatters its chunk tile by tile — the rank of an element among the equal digits of its tile is a popcount over a match mask
+// built from 8 ballots. Two workgroup barriers per pass, no global atomics. The result is the reference's order whenever the keys are
+// distinct; if two keys tie (*tie != 0: found by comparing neighbours after the last pass) the order of equal keys is decided by the reference's
+// unstable sort and the caller falls back to the literal replay (win_sort_wave) on the untouched input.
+// src: n elements (not modified), b0 / b1: n elements each (ping-pong). Returns (uniform) 0 / 1 = the buffer that holds the sorted array, -1 = src
+// itself (nothing to do). lds: WIN_BIG_INTS(NWV) ints.
+// ------------------------------------------------------------------------------------------------------------------------------
+#define WIN_BIG_INTS(NWV) ((NWV) * 256 + 256 + 4 * (NWV) + 8)
+WM_DEV int win_bigsort_block(int NWV, const wm128_t *src_, wm128_t *b0_, wm128_t *b1_, int n, int *lds, int *tie)
+{
+	const V<int> ln = lane();
+	const int wv = wave_in_block();
+	int *hist = lds, *tot = lds + NWV * 256, *red = tot + 256, *flag = red + 4 * NWV;
+	const uint64_t *src = (const uint64_t*)src_;
+	uint64_t *buf[2] = { (uint64_t*)b0_, (uint64_t*)b1_ };
+	const int per = (n + 64 * NWV - 1) / (64 * NWV) * 64;
+	const int beg = wv * per < n ? wv * per : n, end = beg + per < n ? beg + per : n;
+	// which digits vary
+	V<uint64_t> vo = (uint64_t)0, va = ~(uint64_t)0;
+	for (int i0 = beg; i0 < end; i0 += 64) {
+		const V<int> i = ln + i0;
+		WM_IF(i < end) const V<uint64_t> k = gld(src, cast<long long>(i) * 2LL); vo = vo | k; va = va & k; WM_END
+	}
+	{
+		const uint64_t o = wave_or_u64(vo), a = wave_and_u64(va);
+		ust(red, 4 * wv, (int)(uint32_t)o); ust(red, 4 * wv + 1, (int)(uint32_t)(o >> 32)); ust(red, 4 * wv + 2, (int)(uint32_t)a); ust(red, 4 * wv + 3, (int)(uint32_t)(a >> 32));
+		if (wv == 0) ust(flag, 0, 0);
+	}
+	block_sync_lds();
+	uint64_t all_or = 0, all_and = ~(uint64_t)0;
+	for (int w = 0; w < NWV; ++w) {
+		all_or |= (uint64_t)(uint32_t)uniform(gld(red, (long long)(4 * w))) | (uint64_t)(uint32_t)uniform(gld(red, (long long)(4 * w + 1))) << 32;
+		all_and &= (uint64_t)(uint32_t)uniform(gld(red, (long long)(4 * w + 2))) | (uint64_t)(uint32_t)uniform(gld(red, (long long)(4 * w + 3))) << 32;
+	}
+	const uint64_t diff = all_or ^ all_and;
+	int cur = -1;                                                             // where the array is now: -1 = src
+	for (int shift = 0; shift < 64; shift += 8) {
+		if (!(diff >> shift & 0xff)) continue;
+		const uint64_t *in = cur < 0 ? src : buf[cur];
+		uint64_t *out = buf[cur == 0 ? 1 : 0];
+		int *myh = hist + wv * 256;
+#pragma unroll
+		for (int q = 0; q < 4; ++q) gst(myh, ln * 4 + q, V<int>(0));
+		lds_sync();
+		for (int i0 = beg; i0 < end; i0 += 64) {
+			const V<int> i = ln + i0;
+			WM_IF(i < end) atomic_inc(myh, cast<int>(gld(in, cast<long long>(i) * 2LL) >> shift & (uint64_t)0xff)); WM_END
+		}
+		block_sync_lds();
+		// digit d: the chunks' counts become exclusive offsets inside the digit (wavefront-minor), tot[d] the digit's size
+		for (int d0 = wv * 64; d0 < 256; d0 += 64 * NWV) {
+			const V<int> d = ln + d0;
+			V<int> run = 0;
+			for (int w = 0; w < NWV; ++w) { const V<int> t = gld(hist + w * 256, d); gst(hist + w * 256, d, run); run = run + t; }
+			gst(tot, d, run);
+		}
+		block_sync_lds();
+		if (wv == 0) {                                                        // exclusive scan over the 256 digit sizes
+			V<int> c[4];
+#pragma unroll
+			for (int q = 0; q < 4; ++q) c[q] = gld(tot, ln * 4 + q);
+			const V<int> s = c[0] + c[1] + c[2] + c[3];
+			V<int> h = wave_scan_add(s) - s;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { gst(tot, ln * 4 + q, h); h = h + c[q]; }
+		}
+		block_sync_lds();
+		for (int i0 = beg; i0 < end; i0 += 64) {                                // stable scatter of this wavefront's chunk, tile by tile
+			const V<int> i = ln + i0;
+			const vbool have = i < end;
+			V<uint64_t> kx = (uint64_t)0, ky = (uint64_t)0;
+			WM_IF(have) kx = gld(in, cast<long long>(i) * 2LL); ky = gld(in, cast<long long>(i) * 2LL + 1LL); WM_END
+			const V<int> d = cast<int>(kx >> shift & (uint64_t)0xff);
+			V<uint64_t> peers = ballot(have);
+#pragma unroll
+			for (int bit = 0; bit < 8; ++bit) {
+				const vbool on = ((d >> bit) & 1) != 0;
+				const uint64_t m = ballot(have && on);
+				peers = peers & sel(on, V<uint64_t>(m), V<uint64_t>(~m));
+			}
+			const V<int> rank = vpopc64(peers & lanemask_lt());
+			WM_IF(have)
+				const V<int> pos = gld(tot, d) + gld(myh, d) + rank;
+				gst(out, cast<long long>(pos) * 2LL, kx); gst(out, cast<long long>(pos) * 2LL + 1LL, ky);
+			WM_END
+			lds_sync();
+			WM_IF(have && rank == 0) gst(myh, d, gld(myh, d) + vpopc64(peers)); WM_END
+			lds_sync();
+		}
+		cur = cur == 0 ? 1 : 0;
+		win_fence();
+		block_sync_lds();
+	}
+	// equal neighbours?
+	{
+		const uint64_t *res = cur < 0 ? src : buf[cur];
+		vbool t = ln != ln;
+		for (int i0 = beg; i0 < end; i0 += 64) {
+			const V<int> i = ln + i0;
+			WM_IF(i < end && i + 1 < n) t = t || gld(res, cast<long long>(i) * 2LL) == gld(res, cast<long long>(i + 1) * 2LL); WM_END
+		}
+		if (any(t)) ust(flag, 0, 1);
+	}
+	block_sync_lds();
+	*tie = uniform(gld(flag, 0LL));
+	block_sync_lds();
+	return cur;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // what mm_chain_dp needs before its fill (src/chain.c:36-40 avg_qspan) and the kernel class of the fill; appended to the class's list
 // ------------------------------------------------------------------------------------------------------------------------------
 // avg_qspan (src/chain.c:36-40): (float)sum / n with an exact integer sum
