@@ -224,7 +224,7 @@ def make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1):
         "config": {"workload": "BASELINE config %d: %d x %d bp %s reads per step per GPU vs %.0f Mb synthetic reference (10%% repeats), -W repetitive_k15.txt -x %s, CIGAR on"
                                % (args.config, args.reads_per_step, args.read_len, CONFIGS[args.config]["label"], args.ref_mb, CONFIGS[args.config]["preset"]),
                    "reads_per_step_per_gpu": args.reads_per_step, "read_len": args.read_len, "ref_mb": args.ref_mb, "host_threads": n_threads,
-                   "reads_per_s": total_bases / args.read_len / elapsed, "hits": hits, "parallelism": "reads sharded over %d rank(s), index broadcast" % world,
+                   "reads_per_s": total_bases / args.read_len / elapsed, "hits": hits, "parallelism": "reads sharded over %d rank(s), index broadcast" % world, "mini_batches_in_flight": 2 if int(os.environ.get("WM_BENCH_PIPELINE", 1)) else 1,
                    # which kernel variants ran (tools/r03_first_run.sh A/Bs them): build-time defines and run-time switches
                    "variants": {"kernel_defines": gpu.build_defines(),
                                 **{k: os.environ[k] for k in ("WM_KSW_PMULTI", "WM_KSW_COOP_BT", "WM_SEED_DEVICE_SORT", "WM_CONTEXTS") if k in os.environ}}},
@@ -326,19 +326,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for b in mbatches[:args.warmup]:
-        mapper.map(b, copy_text=False)
+    # Consecutive steps (mini-batches) are mapped on the mapper's two slots by two host threads (wm_map_reads_slot): a mapping call spends its
+    # first and last few hundred milliseconds filling and draining its pipeline of dependent device calls, and with two mini-batches in flight those
+    # phases of one hide behind the steady state of the other. Every step is one mini-batch, mapped completely inside the timed region; the
+    # steps of a slot run in order. WM_BENCH_PIPELINE=0: one step at a time (A/B).
+    import threading
+    n_slots = 2 if int(os.environ.get("WM_BENCH_PIPELINE", 1)) else 1
+
+    def run_steps(step_batches):
+        """maps the given mini-batches, step i on slot i % n_slots; returns (hits, bases)"""
+        tot = [0] * n_slots
+        err = []
+
+        def worker(s):
+            try:
+                for b in step_batches[s::n_slots]:
+                    _, h, _, _ = mapper.map(b, copy_text=False, slot=s)        # the records stay in the library's buffer (no Python copy)
+                    tot[s] += len(h)
+            except Exception as e:  # noqa: BLE001
+                err.append(e)
+        th = [threading.Thread(target=worker, args=(s,)) for s in range(n_slots)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if err:
+            raise err[0]
+        return sum(tot), sum(int(b[3].sum()) for b in step_batches)
+
+    run_steps(mbatches[:args.warmup])
     sync()
     ks0 = mapper.kernel_stats()
     hs0 = mapper.host_stats()
     thr0 = cgroup_throttle()
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t_start = time.time()
-    cells = ksw_us = aux_us = bases = hits = 0
-    for b in mbatches[args.warmup:]:
-        text_len, h, _, _ = mapper.map(b, copy_text=False)        # the records stay in the library's buffer (no Python copy)
-        st = mapper.stats()
-        cells += st["dp_cells"]; ksw_us += st["ksw_kernel_us"]; aux_us += st["aux_kernel_us"]; bases += st["read_bases"]; hits += len(h)
+    hits, bases = run_steps(mbatches[args.warmup:])
     sync()
     elapsed = time.time() - t_start
     ru1 = resource.getrusage(resource.RUSAGE_SELF)

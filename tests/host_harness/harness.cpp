@@ -24,7 +24,7 @@ struct OracleOps : DeviceOps {
 	// served from their host views; the resident positions they carry are decoded as well and must give the same bytes.
 	const uint8_t *rd = 0; size_t rd_n = 0;
 	std::atomic<long> n_pos_checked{0}, n_pos_bad{0};
-	bool load_reads(const uint8_t *codes, size_t n) override { rd = codes; rd_n = n; return true; }
+	bool load_reads(const uint8_t *codes, size_t n, int, int64_t *base) override { rd = codes; rd_n = n; *base = 0; return true; }
 	uint8_t two_strand(const KswReq &r, int64_t p) const
 	{   // KswReq: [0,L) forward strand, [L,2L) reverse complement, negative = N padding
 		const int64_t L = r.qwin_len;

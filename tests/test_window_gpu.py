@@ -195,3 +195,60 @@ def test_window_batch_large_jobs_global_memory_paths(env):
         gu = up[int(r["u_off"]):int(r["u_off"]) + int(r["n_u"])]
         ga = ap[int(r["a_off"]):int(r["a_off"]) + int(r["n_v"])]
         assert np.array_equal(gu, ou) and np.array_equal(ga["x"], obx) and np.array_equal(ga["y"], oby), (i, len(a), r)
+
+
+def test_window_batch_giant_seeded_jobs_workgroup_sort_and_tie_fallback():
+    """reads inside a high-copy repeat: every minimizer hits hundreds of reference positions -> anchor sets of 10^4 .. 10^5 per window, sorted by
+    the workgroup kernel (win_bigsort_block); a read that holds the element twice makes every key tie -> the literal replay of the reference's
+    permutation (win_sort_wave) on a giant job. Expectation as above: the oracle's functions stage by stage."""
+    import tempfile
+    rng = np.random.default_rng(31)
+    elem = rng.integers(0, 4, 1500).astype(np.uint8)
+    contig = rng.integers(0, 4, 1500000).astype(np.uint8)
+    pos = np.sort(rng.choice(np.arange(2000, 1490000, 4000), 260, replace=False))
+    for p in pos:
+        contig[p:p + len(elem)] = elem
+    tmp = tempfile.mkdtemp()
+    synth.write_fasta(tmp + "/ref.fa", [contig])
+    ctx = gpu.Context(0, 6 << 30)
+    idx = gpu.Index(tmp + "/ref.fa", None, k=15, w=50)
+    idx.upload(ctx)
+    L = gpu.lib()
+    L.wm_index_get.restype = C.POINTER(C.c_uint64)
+    L.wm_index_get.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_int)]
+    L._wm_ref_index = None
+    L.wm_window_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int64, C.c_void_p,
+                                  C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    flank = lambda n: rng.integers(0, 4, n).astype(np.uint8)
+    seqs = [np.concatenate([flank(300), elem, flank(200)]),                                  # one copy: ~ 60 minimizers x 260 hits, distinct keys
+            np.concatenate([flank(100), elem, flank(50), elem, flank(100)]),                 # the element twice: every reference position is hit twice
+            np.concatenate([flank(100), elem[:700], flank(30), synth.revcomp_codes(elem), flank(10)]),   # both strands
+            contig[pos[3] - 400:pos[3] + 1900].copy()]
+    J = np.zeros(len(seqs), JOB)
+    spos = 0
+    for i, s in enumerate(seqs):
+        J[i]["seq_off"] = -1; J[i]["stage_off"] = spos; J[i]["len"] = len(s); spos += len(s)
+        J[i]["par"] = (5000, 1000, 5000, 500, 25, 5000, 3, 40); J[i]["gs"] = 1.0
+    stage = np.concatenate(seqs)
+    res = np.zeros(len(seqs), RES)
+    up = np.zeros(1 << 18, np.uint64); ap = np.zeros(1 << 20, M128)
+    uu, au = C.c_size_t(), C.c_size_t()
+    dummy = np.zeros(1, M128)
+    rc = L.wm_window_batch(ctx._h, len(seqs), J.ctypes.data, stage.ctypes.data, stage.nbytes, dummy.ctypes.data, 0, 5000, 0, res.ctypes.data,
+                           up.ctypes.data, len(up), C.byref(uu), ap.ctypes.data, len(ap), C.byref(au))
+    assert rc == 0, L.wm_last_error()
+    n_giant = n_tied = 0
+    for i, s in enumerate(seqs):
+        mx, my = W.o_sketch(bytes(s), 50, 15, rid=0, bloom=None)
+        ex, ey, rep = expected_seeds(L, idx, s, mx, my)
+        sx, sy = W.o_radix_sort_128x(ex, ey)
+        r = res[i]
+        assert r["n_anchors"] == len(sx) and r["rep_len"] == rep, (i, r, len(sx), rep)
+        ou, obx, oby = W.o_chain_dp(sx, sy)
+        gu = up[int(r["u_off"]):int(r["u_off"]) + int(r["n_u"])]
+        ga = ap[int(r["a_off"]):int(r["a_off"]) + int(r["n_v"])]
+        assert np.array_equal(gu, ou) and np.array_equal(ga["x"], obx) and np.array_equal(ga["y"], oby), (i, len(sx), r)
+        n_giant += int(len(sx) > 4096)
+        n_tied += int(len(sx) > 4096 and len(np.unique(sx)) < len(sx))
+    assert n_giant >= 3 and n_tied >= 1, (n_giant, n_tied)
+    idx.close(); ctx.close()

@@ -200,7 +200,7 @@ bool spawn_read(Scheduler &sch, const Index &idx, const MapOpt &opt, const MapOp
 } // namespace
 
 void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::vector<ReadIn> &reads, std::vector<ReadOut> &out, MapStats *stats, int n_threads,
-               const std::function<void(size_t)> *on_read_done)
+               const std::function<void(size_t)> *on_read_done, int slot)
 {
 	out.assign(reads.size(), ReadOut());
 	wm_ksw_score_t sc;
@@ -221,10 +221,12 @@ void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::v
 		const std::string &s = reads[i].seq;
 		for (size_t j = 0; j < s.size(); ++j) d[j] = nt4_table[(uint8_t)s[j]];
 	});
-	const bool resident = ops->load_reads(codes_all.get(), (size_t)code_off[reads.size()]);
+	int64_t dev_base = 0;
+	const bool resident = ops->load_reads(codes_all.get(), (size_t)code_off[reads.size()], slot, &dev_base);
+	struct Release { DeviceOps *o; int s; ~Release() { o->release_reads(s); } } release_guard{ ops, slot };
 	for (size_t i = 0; i < reads.size(); ++i) {
 		tasks[i].in = &reads[i]; tasks[i].out = &out[i]; tasks[i].qlen = (int)reads[i].seq.size();
-		tasks[i].codes = codes_all.get() + code_off[i]; tasks[i].dev_off = resident ? (int64_t)code_off[i] : -1;
+		tasks[i].codes = codes_all.get() + code_off[i]; tasks[i].dev_off = resident ? dev_base + (int64_t)code_off[i] : -1;
 	}
 	// reads in flight over all workers (WM_INFLIGHT): large enough for full device batches at every stage, small enough that the
 	// stages overlap instead of running in lock-step phases

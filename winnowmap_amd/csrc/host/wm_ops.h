@@ -76,7 +76,10 @@ struct DeviceOps {
 	virtual bool waits_asleep() const { return false; }
 	// the 0..4 codes of every read of the mini-batch, back to back (SketchReq::dev_off / KswReq::qwin_off index this buffer). Returns
 	// true if the implementation keeps them resident; false = requests must be served from their host views.
-	virtual bool load_reads(const uint8_t *codes, size_t n) { (void)codes; (void)n; return false; }
+	// `slot` (0 or 1): two mini-batches may be mapped concurrently by two calls that share one DeviceOps (the start-up and drain phases of one
+	// hide behind the other); each keeps its codes in its own slab and adds *base to its offsets. release_reads: the call is over.
+	virtual bool load_reads(const uint8_t *codes, size_t n, int slot, int64_t *base) { (void)codes; (void)n; (void)slot; *base = 0; return false; }
+	virtual void release_reads(int slot) { (void)slot; }
 	virtual void sketch_batch(int w, int k, std::vector<SketchReq*> &reqs) = 0;
 	virtual void seed_batch(std::vector<SeedReq*> &reqs) = 0;
 	virtual void chain_batch(std::vector<ChainReq*> &reqs) = 0;

@@ -1791,6 +1791,42 @@ __global__ __launch_bounds__(64) void win_sort_kernel(const wm_win_job_t *__rest
 	}
 }
 
+// anchor sets beyond the LDS classes: a whole workgroup sorts (win_bigsort_block: stable, exact whenever the keys are distinct); if two keys tie the
+// job falls back to the literal replay of the reference's permutation by one wavefront (win_sort_wave<true>) on the untouched input
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void win_bigsort_kernel(const wm_win_job_t *__restrict__ jobs, const wm_win_res_t *res, wm128_t *anchors, wm128_t *buf0, wm128_t *buf1,
+                                                               wm_chain_job_t *cj, int *lists, int *counts, int n_jobs, int lo)
+{
+	WM_SETPRIO(2);
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	int *big = (int*)smem, *ws = big + ((WIN_BIG_INTS(NWV) + 3) & ~3);
+	const int j = blockIdx.x;
+	const wm_win_res_t r = res[j];
+	const int n = r.n_a;
+	if (n <= lo || r.err) return;
+	const wm_win_job_t jb = jobs[j];
+	wm128_t *a = anchors + r.a_off;
+	const int wv = simt::wave_in_block();
+	if (jb.seq_off >= 0) {
+		const int n_pre = jb.n_pre < n ? jb.n_pre : n;
+		for (int round = 0; round < (n_pre > 0 ? 2 : 1); ++round) {           // the seeded anchors (src/map.c:252), then the union with the handed-in ones (:833)
+			wm128_t *rng = round == 0 ? a + n_pre : a;
+			const int m = round == 0 ? n - n_pre : n;
+			int tie = 0;
+			const int cur = wmk::win_bigsort_block(NWV, rng, buf0 + r.a_off, buf1 + r.a_off, m, big, &tie);
+			if (tie) { if (wv == 0) wmk::win_sort_wave<true>(rng, m, ws); }
+			else if (cur >= 0) {
+				const uint64_t *src = (const uint64_t*)((cur ? buf1 : buf0) + r.a_off);
+				uint64_t *dst = (uint64_t*)rng;
+				for (long long i = threadIdx.x; i < 2LL * m; i += 64 * NWV) dst[i] = src[i];
+			}
+			wmk::win_fence();
+			__syncthreads();
+		}
+	}
+	if (wv == 0) wmk::win_plan_wave(jb, j, r.a_off, n, a, cj, lists, counts, n_jobs);
+}
+
 // the fills of seedchain_kernel.h over a device-side job list (block b serves list[b]; blocks beyond *count leave)
 __global__ __launch_bounds__(64) void win_chain_kernel(const wm_chain_job_t *jobs, const int *list, const int *count, const wm128_t *anchors, int *fpvt, int W)
 {
@@ -1927,7 +1963,11 @@ static int window_launch(wm_ctx_t *c, int n, const wm_window_job_t *jobs, const 
 	hipLaunchKernelGGL(win_small_kernel, dim3(n), dim3(64), (size_t)wmk::WIN_SMALL_LDS, c->stream, d_jobs, D.d_res, d_a, D.d_upool, D.d_vpool, d_ctr + 1);
 	HIPCHK(hipFuncSetAttribute((const void*)win_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	hipLaunchKernelGGL(win_sort_kernel, dim3(n), dim3(64), ws_bytes + (size_t)kLarge * 16, c->stream, d_jobs, D.d_res, d_a, d_cj, d_lists, d_counts, n, kSmall, kLarge);
-	hipLaunchKernelGGL(win_sort_kernel, dim3(n), dim3(64), ws_bytes, c->stream, d_jobs, D.d_res, d_a, d_cj, d_lists, d_counts, n, kLarge, 0);
+	{
+		constexpr int NWV = 8;
+		const size_t big_bytes = (size_t)((WIN_BIG_INTS(NWV) + 3) & ~3) * 4 + ws_bytes;
+		hipLaunchKernelGGL(win_bigsort_kernel<NWV>, dim3(n), dim3(64 * NWV), big_bytes, c->stream, d_jobs, D.d_res, d_a, d_b, d_w, d_cj, d_lists, d_counts, n, kLarge);
+	}
 	{   // the fill, per class list: 0 dense (8 waves, W 4096) | 1 large sparse (1 wave, W 1024) | 2 n <= 1024 | 3 n <= 256
 		HIPCHK(hipFuncSetAttribute((const void*)win_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		constexpr int NWV = 8;
@@ -2222,20 +2262,39 @@ struct GpuOps : wm::DeviceOps {
 	void init(const std::vector<wm_ctx_t*> &cs) { ctxs.resize(cs.size()); for (size_t i = 0; i < cs.size(); ++i) { ctxs[i].c = cs[i]; free_.push_back((int)i); } }
 	int max_inflight() const override { return (int)ctxs.size(); }
 	bool waits_asleep() const override { return getenv("WM_SPIN_SYNC") == 0; }
-	// the mini-batch's read codes go to the device once (the first context owns the buffer, the others alias it: one device)
-	bool load_reads(const uint8_t *codes, size_t n) override
+	// The read codes of a mini-batch go to the device once. Two mini-batches can be in flight (two concurrent mapping calls, slots 0 and 1): one
+	// allocation of two slabs, owned by the first context and aliased by the others (one device); a call's offsets start at slot * slab.
+	std::mutex reads_mu;
+	size_t slab = 0;
+	bool slot_busy[2] = { false, false };
+	bool load_reads(const uint8_t *codes, size_t n, int slot, int64_t *base) override
 	{
+		*base = 0;
 		const bool off = getenv("WM_NO_RESIDENT") != 0;            // A/B switch: per-request staging as before
-		if (off || ctxs.empty()) return false;
+		if (off || ctxs.empty() || slot < 0 || slot > 1) return false;
 		wm_ctx_t *c0 = ctxs[0].c;
-		if (wm_reads_upload(c0, codes, n)) { ctxs[0].fail("reads upload"); return false; }
-		for (size_t i = 0; i < ctxs.size(); ++i) {
-			wm_ctx_t *c = ctxs[i].c;
-			if (i) { if (c->owns_reads && c->d_reads) hipFree(c->d_reads); c->d_reads = c0->d_reads; c->reads_bytes = c0->reads_bytes; c->reads_cap = 0; c->owns_reads = false; }
-			ctxs[i].resident = true;
+		std::lock_guard<std::mutex> lk(reads_mu);
+		if (hipSetDevice(c0->device) != hipSuccess) return false;
+		if (n + 64 > slab || !c0->d_reads || !c0->owns_reads) {
+			if (slot_busy[1 - slot]) return false;                  // the other mini-batch lives in the allocation: this one is served from its host views
+			if (c0->d_reads && c0->owns_reads) hipFree(c0->d_reads);
+			c0->d_reads = 0; c0->owns_reads = false; slab = 0;
+			const size_t want = (n + n / 8 + (1 << 20) + 255) & ~(size_t)255;
+			if (hipMalloc((void**)&c0->d_reads, 2 * want) != hipSuccess) { (void)hipGetLastError(); c0->d_reads = 0; return false; }
+			c0->owns_reads = true; c0->reads_cap = 2 * want; c0->reads_bytes = 2 * want; slab = want;
+			for (size_t i = 1; i < ctxs.size(); ++i) {
+				wm_ctx_t *c = ctxs[i].c;
+				if (c->owns_reads && c->d_reads) hipFree(c->d_reads);
+				c->d_reads = c0->d_reads; c->reads_bytes = c0->reads_bytes; c->reads_cap = 0; c->owns_reads = false;
+			}
 		}
+		if (n && hipMemcpy(c0->d_reads + (size_t)slot * slab, codes, n, hipMemcpyHostToDevice) != hipSuccess) { ctxs[0].fail("reads upload"); return false; }
+		for (GpuOpsCtx &x : ctxs) x.resident = true;
+		slot_busy[slot] = true;
+		*base = (int64_t)((size_t)slot * slab);
 		return true;
 	}
+	void release_reads(int slot) override { std::lock_guard<std::mutex> lk(reads_mu); if (slot >= 0 && slot <= 1) slot_busy[slot] = false; }
 	template <class F> void with(F f)
 	{
 		int i;
@@ -2269,10 +2328,12 @@ struct wm_mapper_s {
 	std::vector<wm_ctx_t*> workers;        // extra contexts (own stream + arena slice) for groups 1..G-1
 	int n_threads = 1;
 	wm::IdxOpt io; wm::MapOpt mo;
-	std::string text;
-	std::vector<int32_t> hits; std::vector<uint32_t> cigars; std::vector<int64_t> first;
+	// results of the last mapping call per slot (wm_map_reads = slot 0; wm_map_reads_slot: two calls may run concurrently)
+	struct Result { std::string text; std::vector<int32_t> hits; std::vector<uint32_t> cigars; std::vector<int64_t> first; } res[2];
 	uint64_t stats[9];
 	double host_stats[24] = {0};
+	std::mutex stats_mu;
+	std::unique_ptr<GpuOps> ops;           // the device contexts as a pool shared by the mapping calls (created on first use, rebuilt by wm_mapper_set_threads)
 	bool sam_header = true;                // wm_map_file writes the @SQ / @PG lines (wm_mapper_set_sam_header)
 	std::vector<std::string> cmdline;      // argv of the front end, for the @PG line of SAM files (wm_mapper_set_cmdline)
 };
@@ -2352,6 +2413,7 @@ extern "C" int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena
 	if (n_threads < 1) return set_err(WM_EINVAL, "n_threads < 1");
 	for (wm_ctx_t *w : m->workers) wm_ctx_destroy(w);
 	m->workers.clear();
+	m->ops.reset();
 	int C = getenv("WM_CONTEXTS") ? atoi(getenv("WM_CONTEXTS")) : (getenv("WM_GROUPS") ? atoi(getenv("WM_GROUPS")) : (n_threads >= 8 ? 6 : n_threads >= 2 ? 2 : 1));
 	if (C < 1) C = 1;
 	m->n_threads = n_threads;
@@ -2385,7 +2447,7 @@ extern "C" int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena
 	return WM_OK;
 }
 
-static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double tm0);
+static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double tm0, int slot = 0);
 
 extern "C" int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, const char *const *seqs, const int32_t *lens,
                             const char **text, size_t *text_len, const int32_t **hits, const uint32_t **cigars, const int64_t **hit_first)
@@ -2393,38 +2455,66 @@ extern "C" int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, con
 	const double tm0 = now_ms();
 	std::vector<wm::ReadIn> reads(n);
 	wm::parallel_for(m->n_threads, (size_t)n, [&](size_t i) { reads[i].name = names[i]; reads[i].seq.assign(seqs[i], lens[i]); });
-	const int rc = map_reads_impl(m, reads, tm0);
+	const int rc = map_reads_impl(m, reads, tm0, 0);
 	if (rc) return rc;
-	if (text) *text = m->text.data();
-	if (text_len) *text_len = m->text.size();
-	if (hits) *hits = m->hits.data();
-	if (cigars) *cigars = m->cigars.data();
-	if (hit_first) *hit_first = m->first.data();
+	if (text) *text = m->res[0].text.data();
+	if (text_len) *text_len = m->res[0].text.size();
+	if (hits) *hits = m->res[0].hits.data();
+	if (cigars) *cigars = m->res[0].cigars.data();
+	if (hit_first) *hit_first = m->res[0].first.data();
+	return WM_OK;
+}
+
+// wm_map_reads with its own result buffers and its own slab of resident read codes: calls with different slots (0 and 1) may run concurrently from two
+// host threads. A mapping call spends its first and last few hundred milliseconds filling and draining its pipeline of dependent device calls (window
+// -> align -> align -> window -> align ...): with two mini-batches in flight those phases of one hide behind the steady state of the other.
+extern "C" int wm_map_reads_slot(wm_mapper_t *m, int slot, int n, const char *const *names, const char *const *seqs, const int32_t *lens,
+                                 const char **text, size_t *text_len, const int32_t **hits, const uint32_t **cigars, const int64_t **hit_first)
+{
+	if (!m || slot < 0 || slot > 1) return set_err(WM_EINVAL, "slot must be 0 or 1");
+	const double tm0 = now_ms();
+	std::vector<wm::ReadIn> reads(n);
+	wm::parallel_for(m->n_threads, (size_t)n, [&](size_t i) { reads[i].name = names[i]; reads[i].seq.assign(seqs[i], lens[i]); });
+	const int rc = map_reads_impl(m, reads, tm0, slot);
+	if (rc) return rc;
+	wm_mapper_t::Result &R = m->res[slot];
+	if (text) *text = R.text.data();
+	if (text_len) *text_len = R.text.size();
+	if (hits) *hits = R.hits.data();
+	if (cigars) *cigars = R.cigars.data();
+	if (hit_first) *hit_first = R.first.data();
 	return WM_OK;
 }
 
 // maps `reads` in the given order; results land in m->text / hits / cigars / first / stats
-static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double tm0)
+static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double tm0, int slot)
 {
+	wm_mapper_t::Result &R = m->res[slot];
 	static const bool trace_m = getenv("WM_TRACE") != 0;
 	const int n = (int)reads.size();
 	uint64_t bases = 0;
 	for (int i = 0; i < n; ++i) bases += reads[i].seq.size();
 	std::vector<wm::ReadOut> out(n);
 	const double tm1 = now_ms();
-	GpuOps ops;
-	{ std::vector<wm_ctx_t*> cs; cs.push_back(m->c); cs.insert(cs.end(), m->workers.begin(), m->workers.end()); ops.init(cs); }
+	{
+		std::lock_guard<std::mutex> lk(m->stats_mu);
+		if (!m->ops) { m->ops.reset(new GpuOps()); std::vector<wm_ctx_t*> cs; cs.push_back(m->c); cs.insert(cs.end(), m->workers.begin(), m->workers.end()); m->ops->init(cs); }
+	}
+	GpuOps &ops = *m->ops;
+	uint64_t cells0 = 0; double ksw_us0 = 0, aux_us0 = 0;
+	for (GpuOpsCtx &x : ops.ctxs) { cells0 += x.cells; ksw_us0 += x.ksw_us; aux_us0 += x.aux_us; }      // (contexts are shared: this call's share = the difference; approximate when two calls overlap)
 	wm::MapStats st;
 	hipSetDevice(m->c->device);
 	// records are formatted by the worker that finishes a read, while the other reads are still being mapped
 	std::vector<std::string> texts(n);
 	const std::function<void(size_t)> fmt = [&](size_t i) { wm::write_read(texts[i], m->idx->ix, reads[i], out[i], m->mo.flag); };
-	wm::map_batch(m->idx->ix, m->mo, &ops, reads, out, &st, m->n_threads, &fmt);
+	wm::map_batch(m->idx->ix, m->mo, &ops, reads, out, &st, m->n_threads, &fmt, slot);
 	for (GpuOpsCtx &x : ops.ctxs)
-		if (!x.error.empty()) return set_err(WM_ENODEV, "%s", x.error.c_str());
+		if (!x.error.empty()) { const int rc = set_err(WM_ENODEV, "%s", x.error.c_str()); x.error.clear(); return rc; }
 	{ std::string ie; if (wm::take_internal_error(ie)) return set_err(WM_EINTERNAL, "%s", ie.c_str()); }
 	GpuOpsCtx tot; tot.c = m->c;
 	for (GpuOpsCtx &x : ops.ctxs) { tot.cells += x.cells; tot.ksw_us += x.ksw_us; tot.aux_us += x.aux_us; }
+	tot.cells -= cells0; tot.ksw_us -= ksw_us0; tot.aux_us -= aux_us0;
 	GpuOpsCtx &opsr = tot;
 	if (getenv("WM_TRACE")) {
 		double a[8] = {0};
@@ -2434,19 +2524,19 @@ static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double
 	const double tm2 = now_ms();
 	// output records (formatted above, per read), laid out in input order
 	std::vector<size_t> toff(n + 1, 0), coff(n + 1, 0);
-	m->first.assign(n + 1, 0);
+	R.first.assign(n + 1, 0);
 	for (int i = 0; i < n; ++i) {
 		toff[i + 1] = toff[i] + texts[i].size();
-		m->first[i + 1] = m->first[i] + (int64_t)out[i].regs.size();
+		R.first[i + 1] = R.first[i] + (int64_t)out[i].regs.size();
 		size_t nc = 0;
 		for (const wm::Reg &r : out[i].regs) nc += r.cigar.size();
 		coff[i + 1] = coff[i] + nc;
 	}
-	m->text.resize(toff[n]); m->hits.resize((size_t)m->first[n] * 16); m->cigars.resize(coff[n]);
+	R.text.resize(toff[n]); R.hits.resize((size_t)R.first[n] * 16); R.cigars.resize(coff[n]);
 	wm::parallel_for(m->n_threads, (size_t)n, [&](size_t i) {
-		if (!texts[i].empty()) memcpy(&m->text[toff[i]], texts[i].data(), texts[i].size());
-		int32_t *ho = m->hits.data() + (size_t)m->first[i] * 16;
-		uint32_t *co = m->cigars.data() + coff[i];
+		if (!texts[i].empty()) memcpy(&R.text[toff[i]], texts[i].data(), texts[i].size());
+		int32_t *ho = R.hits.data() + (size_t)R.first[i] * 16;
+		uint32_t *co = R.cigars.data() + coff[i];
 		for (const wm::Reg &r : out[i].regs) {
 			const int32_t o[16] = { r.rid, r.rs, r.re, r.qs, r.qe, (int32_t)r.rev, (int32_t)r.mapq, r.has_p ? (int32_t)r.cigar.size() : 0, r.score, r.cnt, r.mlen, r.blen,
 			                        r.dp_score, r.dp_max, r.dp_max2, (int32_t)((r.parent == r.id) | r.inv << 1 | r.sam_pri << 2 | r.split << 3) };
@@ -2455,6 +2545,7 @@ static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double
 		}
 	});
 	if (trace_m) fprintf(stderr, "[map_reads] n=%d ingest %.1f ms, map %.1f ms, format %.1f ms\n", n, tm1 - tm0, tm2 - tm1, now_ms() - tm2);
+	std::lock_guard<std::mutex> stats_lk(m->stats_mu);
 	m->stats[0] = st.n_flush; m->stats[1] = st.n_ksw; m->stats[2] = st.n_chain; m->stats[3] = st.n_seed; m->stats[4] = st.n_sketch;
 	m->host_stats[0] += st.cpu_fiber; m->host_stats[1] += st.wall_idle;
 	for (int op = 0; op < 4; ++op) { m->host_stats[2 + op] += st.cpu_op[op]; m->host_stats[6 + op] += st.wall_op[op]; m->host_stats[10 + op] += (double)st.n_batches[op]; }
@@ -2495,7 +2586,7 @@ extern "C" int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *o
 	const bool with_qual = (m->mo.flag & 0x8) != 0;                    // SAM output prints QUAL
 	const int rc = wm::map_file(reads_path, mini_batch_bases, with_qual, [&](std::vector<wm::ReadIn> &batch, std::string &text) {
 		const int r = map_reads_impl(m, batch, now_ms());
-		if (r == 0) text.swap(m->text);
+		if (r == 0) text.swap(m->res[0].text);
 		return r;
 	}, out, &fs, err);
 	if (out != stdout) fclose(out);

@@ -196,6 +196,7 @@ def _bind_map(L):
     L.wm_mapper_set_threads.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
     L.wm_map_reads.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p,
                                C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.wm_map_reads_slot.argtypes = [C.c_void_p, C.c_int] + list(L.wm_map_reads.argtypes[1:])
     L.wm_mapper_stats.argtypes = [C.c_void_p, C.c_void_p]
     L.wm_sam_header.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
     L.wm_last_aux_ms.restype = C.c_float
@@ -330,15 +331,16 @@ class Mapper:
         lens = np.array([len(s) for s in seqs], np.int32)
         return n, nm, sq, lens, (names, seqs)      # (the lists keep the pointed-to bytes alive)
 
-    def map(self, names, seqs=None, copy_text=True):
+    def map(self, names, seqs=None, copy_text=True, slot=0):
         """names: list of str/bytes; seqs: list of bytes (ASCII) — or names = the tuple Mapper.marshal() returned. Returns
         (text, hits[n_hits,16], cigars, first[n+1]).
-        copy_text=False returns the text LENGTH instead of a Python copy of the records (they stay in the library's buffer)."""
+        copy_text=False returns the text LENGTH instead of a Python copy of the records (they stay in the library's buffer).
+        slot (0 or 1): calls on different slots may run concurrently from two threads (wm_map_reads_slot; ctypes releases the GIL)."""
         L = lib()
         n, nm, sq, lens, _keep = names if seqs is None else Mapper.marshal(names, seqs)
         text, tlen = C.c_char_p(), C.c_size_t()
         hits, cig, first = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        _chk(L.wm_map_reads(self._h, n, nm, sq, lens.ctypes.data, C.byref(text), C.byref(tlen), C.byref(hits), C.byref(cig), C.byref(first)))
+        _chk(L.wm_map_reads_slot(self._h, slot, n, nm, sq, lens.ctypes.data, C.byref(text), C.byref(tlen), C.byref(hits), C.byref(cig), C.byref(first)))
         fa = np.ctypeslib.as_array(C.cast(first, C.POINTER(C.c_int64)), shape=(n + 1,)).copy()
         nh = int(fa[n])
         ha = np.ctypeslib.as_array(C.cast(hits, C.POINTER(C.c_int32)), shape=(nh, 16)).copy() if nh else np.zeros((0, 16), np.int32)
