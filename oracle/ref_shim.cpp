@@ -161,6 +161,7 @@ void *refshim_mapopt(const char *preset, int64_t flag_extra, void *mi)
 	mm_mapopt_update(&g_mo, (mm_idx_t*)mi);
 	return &g_mo;
 }
+void refshim_mapopt_set_max_sw_mat(void *opt, int64_t v) { ((mm_mapopt_t*)opt)->max_sw_mat = v; }     // (no command-line switch reaches it: the long-option table lacks --cap-sw-mat)
 // every mm_mapopt_t field that wm_mapopt_t mirrors (include/wm_gpu.h), in that struct's order, after mm_set_opt(0) + mm_set_opt(preset)
 int refshim_preset_fields(const char *preset, double *o, int cap)
 {

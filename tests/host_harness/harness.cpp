@@ -287,6 +287,9 @@ int h_map(void *hv, const char *preset, int64_t flag_extra, const char *seq, int
 // how many requests carried resident positions (checked against their host views) and how many of them disagreed
 void h_pos_check(long *checked, long *bad) { *checked = g_pos_checked.load(); *bad = g_pos_bad.load(); }
 
+static int64_t g_max_sw_mat = 0;
+void h_set_max_sw_mat(int64_t v) { g_max_sw_mat = v; }          // mm_mapopt_t::max_sw_mat for the h_map_many calls that follow (src/align.c:323-325)
+
 // several reads at once on a team of `n_threads` schedulers; hits of read i start at hit_first[i] (16 ints each)
 int h_map_many(void *hv, const char *preset, int64_t flag_extra, int n, const char *const *seqs, const int *lens, int n_threads,
                int32_t *hit_out, int hit_cap, int64_t *hit_first, uint32_t *cig_out, int64_t cig_cap, int64_t *n_cig_total)
@@ -296,6 +299,7 @@ int h_map_many(void *hv, const char *preset, int64_t flag_extra, int n, const ch
 	set_preset(0, io, mo);
 	if (preset && preset[0] && set_preset(preset, io, mo) < 0) return -1;
 	mo.flag |= flag_extra;
+	mo.max_sw_mat = g_max_sw_mat;
 	OracleOps ops; ops.idx = &h->idx; ops.bloom = h->bloom; ops.opt = &mo;
 	std::vector<ReadIn> reads(n);
 	for (int i = 0; i < n; ++i) { reads[i].name = "read" + std::to_string(i); reads[i].seq.assign(seqs[i], lens[i]); }

@@ -48,8 +48,9 @@ def test_reference_cli_bound_to_the_library_prints_the_references_output():
     reads += synth.make_reads(ref, 12, 3000, 33, profile="ont")[0]            # below the 10 kb MCAS gate
     rq = os.path.join(tmp, "reads.fa")
     _write_reads(rq, reads)
-    # PAF+CIGAR, SAM, individual options on top of the preset, --cap-sw-mat (max_sw_mat, src/align.c:323-325: large pairs are not aligned)
-    for fmt, extra in (("-cx", []), ("-ax", []), ("-cx", ["-N", "3", "-p", "0.5", "--cs"]), ("-cx", ["--cap-sw-mat", "60000"])):
+    # PAF+CIGAR, SAM, individual options on top of the preset (max_sw_mat has no reachable command-line switch in the reference — its option
+    # table lacks --cap-sw-mat although src/main.c:235 handles it; tests/test_e2e_host.py compares it through the reference's library instead)
+    for fmt, extra in (("-cx", []), ("-ax", []), ("-cx", ["-N", "3", "-p", "0.5", "--cs"])):
         args = ["-t", "4", "-W", kf] + extra + [fmt, "map-ont", fa, rq]
         sam = fmt == "-ax"
         want = _run(REF_BIN, args)

@@ -22,6 +22,7 @@
 #include <ucontext.h>
 #endif
 #include <functional>
+#include <exception>
 #include <deque>
 #include <vector>
 #include <memory>
@@ -71,7 +72,7 @@ inline double thread_cpu_s() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_I
 inline double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // a host-side loop of a batched call that idle workers help with (ParHook, wm_core.h)
-struct HelpTask { const std::function<void(size_t)> *fn; size_t n, chunk; std::atomic<size_t> next; int helpers; const char *site; };
+struct HelpTask { const std::function<void(size_t)> *fn; size_t n, chunk; std::atomic<size_t> next; int helpers; const char *site; std::exception_ptr err; std::mutex err_mu; };
 
 struct Hub {
 	Hub(DeviceOps *ops_, const wm_ksw_score_t &sc_, int w_, int k_) : ops(ops_), sc(sc_), w(w_), k(k_) { max_inflight = ops->max_inflight(); if (max_inflight < 1) max_inflight = 1; read_env(); par.H = this; }
@@ -91,9 +92,17 @@ struct Hub {
 	double cpu_help = 0;                    // CPU seconds idle workers spent inside such loops
 	std::vector<std::pair<const char*, double>> site_cpu;   // ... and the CPU seconds of every labelled loop (WM_SITE), dispatcher + helpers
 	void add_site(const char *site, double s) { if (!site) site = "(unlabelled)"; for (auto &e : site_cpu) if (e.first == site) { e.second += s; return; } site_cpu.emplace_back(site, s); }
+	// an exception in the loop body (staging buffers throw bad_alloc) is kept — the first one — and rethrown by the call's owner after every helper
+	// has left; the remaining chunks are skipped (a helper thread must never unwind into std::terminate, nor leave `helpers` raised)
 	static void help_work(HelpTask &t)
 	{
-		for (;;) { const size_t b = t.next.fetch_add(t.chunk); if (b >= t.n) break; const size_t e = b + t.chunk < t.n ? b + t.chunk : t.n; for (size_t i = b; i < e; ++i) (*t.fn)(i); }
+		try {
+			for (;;) { const size_t b = t.next.fetch_add(t.chunk); if (b >= t.n) break; const size_t e = b + t.chunk < t.n ? b + t.chunk : t.n; for (size_t i = b; i < e; ++i) (*t.fn)(i); }
+		} catch (...) {
+			std::lock_guard<std::mutex> lk(t.err_mu);
+			if (!t.err) t.err = std::current_exception();
+			t.next.store(t.n);
+		}
 	}
 	// the hook a dispatching worker installs around its batched call: the loop is shared with whoever is idle
 	struct Par : ParHook {
@@ -114,6 +123,8 @@ struct Hub {
 			H->add_site(t.site, dc);
 			for (size_t i = 0; i < H->help.size(); ++i) if (H->help[i] == &t) { H->help.erase(H->help.begin() + i); break; }
 			while (t.helpers > 0) H->cv.wait(lk);          // (helpers announce themselves and leave under the hub mutex)
+			lk.unlock();
+			if (t.err) std::rethrow_exception(t.err);      // (the task is deregistered and nobody refers to this frame any more)
 		}
 	} par;
 	std::atomic<int64_t> live{0};           // fibers alive + reads not yet admitted, over all workers: 0 = the mapping call is finished
@@ -363,11 +374,17 @@ private:
 		const double c0 = thread_cpu_s(), w0 = wall_s();
 		ParHook *const prev_hook = tl_par_hook();
 		tl_par_hook() = &H.par;
-		if (op == OP_SKETCH) H.ops->sketch_batch(H.w, H.k, a);
-		else if (op == OP_SEED) H.ops->seed_batch(b);
-		else if (op == OP_CHAIN) H.ops->chain_batch(c);
-		else if (op == OP_WINDOW) H.ops->window_batch(H.w, H.k, wq);
-		else H.ops->ksw_batch(H.sc, d);
+		try {
+			if (op == OP_SKETCH) H.ops->sketch_batch(H.w, H.k, a);
+			else if (op == OP_SEED) H.ops->seed_batch(b);
+			else if (op == OP_CHAIN) H.ops->chain_batch(c);
+			else if (op == OP_WINDOW) H.ops->window_batch(H.w, H.k, wq);
+			else H.ops->ksw_batch(H.sc, d);
+		} catch (const std::exception &e) {          // the waiters below are released in any case (their requests keep their zero-initialised results)
+			note_internal_error(e.what(), __FILE__, __LINE__);
+		} catch (...) {
+			note_internal_error("exception in a batched device call", __FILE__, __LINE__);
+		}
 		if (trace) fprintf(stderr, "[batch] worker %2d %s n=%zu %.1f ms\n", rank_, op == OP_SKETCH ? "sketch" : op == OP_SEED ? "seed" : op == OP_CHAIN ? "chain" : op == OP_KSW ? "ksw" : op == OP_KSW_HEAVY ? "ksw-heavy" : op == OP_KSW_HUGE ? "ksw-huge" : "window", n,
 		                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 		tl_par_hook() = prev_hook;
