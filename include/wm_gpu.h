@@ -185,7 +185,8 @@ int wm_seed_batch(wm_ctx_t *ctx, int n, const wm128_t *mini, const uint64_t *min
                   int max_occ, int64_t flag, wm128_t *out, size_t out_cap, uint64_t *out_off, int32_t *n_anchors, int32_t *rep_len);
 /* mm_chain_dp (src/mmpriv.h:73) for n anchor sets; chains of job i: u[u_off[i] .. +n_u[i]), anchors regrouped in
  * place: a[a_off[i] .. +n_v[i]). */
-typedef struct { int32_t max_dist_x, min_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc; float gap_scale; } wm_chain_par_t;
+typedef struct { int32_t max_dist_x, min_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc; float gap_scale;
+                 int32_t is_cdna; /* splice mode: the gap cost of src/chain.c:69-74 */ } wm_chain_par_t;
 int wm_chain_batch(wm_ctx_t *ctx, int n, wm128_t *a, const uint64_t *a_off, const int32_t *n_a, const wm_chain_par_t *par,
                    uint64_t *u, uint64_t *u_off, int32_t *n_u, int32_t *n_v);
 /* One device call per MCAS window or stage-2 pass (src/map.c:334-341, 700-900): mm_sketch → collect_seed_hits (incl. radix_sort_128x with the

@@ -228,6 +228,10 @@ static int ilog2_u32(uint32_t v) { int l = -1; while (v) { v >>= 1; ++l; } retur
 
 int64_t wmo_chain_stat[4]; /* diagnostics only: predecessors visited, sum of (i-st), max (i-st), 64-wide tiles touched */
 
+/* splice mode (is_cdna of src/chain.c:22): selected per thread before the call, so that the signature the tests bind stays as it is */
+static __thread int wmo_chain_cdna = 0;
+void wmo_chain_set_cdna(int is_cdna) { wmo_chain_cdna = is_cdna; }
+
 int64_t wmo_chain_dp(int max_dist_x, int min_dist_x, int max_dist_y, int bw, int max_skip, int max_iter,
                      int min_cnt, int min_sc, float gap_scale, int64_t n, const wmo128_t *a,
                      int *n_u_, uint64_t *u, wmo128_t *b)
@@ -262,6 +266,7 @@ int64_t wmo_chain_dp(int max_dist_x, int min_dist_x, int max_dist_y, int bw, int
 			{ int32_t md = dq < dr ? dq : (int32_t)dr; sc = md > span ? span : md; } /* :65-66 */
 			lg = dd ? ilog2_u32((uint32_t)dd) : 0;
 			gc = (int)(dd * .01 * avg_span) + (lg >> 1);               /* :76 */
+			if (wmo_chain_cdna && dr > dq) { int c_lin = (int)(dd * .01 * avg_span); gc = c_lin < lg ? c_lin : lg; }   /* :69-74, one segment */
 			sc -= (int)((double)gc * gap_scale + .499);                /* :77 */
 			sc += f[j];
 			if (sc > best) {

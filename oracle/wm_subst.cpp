@@ -77,13 +77,13 @@ extern "C" void mm_sketch(void *km, const char *str, int len, int w, int k, uint
 extern "C" mm128_t *mm_chain_dp(int max_dist_x, int min_dist_x, int max_dist_y, int bw, int max_skip, int max_iter, int min_cnt, int min_sc, float gap_scale,
                                 int is_cdna, int n_segs, int64_t n, mm128_t *a, int *n_u_, uint64_t **_u, void *km)
 {
-	if (off() || is_cdna || n_segs > 1 || n >= ((int64_t)1 << 31)) return ref_mm_chain_dp(max_dist_x, min_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc, gap_scale, is_cdna, n_segs, n, a, n_u_, _u, km);
+	if (off() || n_segs > 1 || n >= ((int64_t)1 << 31)) return ref_mm_chain_dp(max_dist_x, min_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc, gap_scale, is_cdna, n_segs, n, a, n_u_, _u, km);
 	if (_u) *_u = 0, *n_u_ = 0;
 	if (n == 0 || a == 0) { kfree(km, a); return 0; }                     // src/chain.c:33-36
 	std::vector<wm128_t> aa((size_t)n);
 	memcpy(aa.data(), a, (size_t)n * sizeof(mm128_t));
 	std::vector<uint64_t> u((size_t)n + 1);
-	wm_chain_par_t par = { max_dist_x, min_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc, gap_scale };
+	wm_chain_par_t par = { max_dist_x, min_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc, gap_scale, is_cdna ? 1 : 0 };
 	uint64_t a_off = 0, u_off = 0; int32_t na = (int32_t)n, nu = 0, nv = 0;
 	{
 		std::lock_guard<std::mutex> lk(g_mu);

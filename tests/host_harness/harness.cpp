@@ -110,6 +110,7 @@ struct OracleOps : DeviceOps {
 			}
 			extern int64_t wmo_chain_stat[4];
 			wmo_chain_stat[0] = wmo_chain_stat[1] = wmo_chain_stat[2] = wmo_chain_stat[3] = 0;
+			wmo_chain_set_cdna(r->is_cdna ? 1 : 0);
 			int64_t n_v = wmo_chain_dp(r->max_dist_x, r->min_dist_x, r->max_dist_y, r->bw, r->max_skip, r->max_iter, r->min_cnt, r->min_sc, r->gap_scale,
 			                           n, (const wmo128_t*)r->a.data(), &n_u, u.data(), b.data());
 			if (getenv("WM_CHAIN_STATS")) fprintf(stderr, "CHAINJOB %lld %lld %lld %lld %lld\n", (long long)n, (long long)wmo_chain_stat[0], (long long)wmo_chain_stat[1], (long long)wmo_chain_stat[2], (long long)wmo_chain_stat[3]);

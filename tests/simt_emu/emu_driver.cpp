@@ -277,6 +277,7 @@ int emu_chain_fill(int64_t n, const uint64_t *ax, const uint64_t *ay, int max_di
 	// test hook: bits 16.. of max_skip choose the LDS window (default 4096) so that wrap-around can be exercised on small inputs
 	int W = 4096;
 	if (max_skip >> 16) { W = max_skip >> 16; jb.max_skip &= 0xffff; }
+	if (jb.max_skip & 0x8000) { jb.is_cdna = 1; jb.max_skip &= 0x7fff; }        // test hook: bit 15 of max_skip = splice mode (src/chain.c:69-74)
 	std::vector<int> gt(n + 1), sf(W), sp(W), stt(W);
 	std::vector<uint64_t> sx(W), sy(W);
 	simt::exec_mask() = ~0ull;

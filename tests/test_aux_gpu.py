@@ -120,7 +120,7 @@ def test_sketch_seed_chain_kernels(env, device_sort, monkeypatch):
         assert na[i] == len(sx) and np.array_equal(g["x"], sx) and np.array_equal(g["y"], sy) and rl[i] == rep, i
         anchors.append(g.copy())
     # chain: stage-1 and stage-2 parameter sets
-    PAR = np.dtype([("p", np.int32, 8), ("gs", np.float32)])
+    PAR = np.dtype([("p", np.int32, 8), ("gs", np.float32), ("is_cdna", np.int32)])
     for prm in ((5000, 1000, 5000, 500), (16000, 1000, 16000, 2000)):
         nz = [a for a in anchors if len(a) > 0]
         na2 = np.array([len(a) for a in nz], np.int32)
@@ -160,7 +160,7 @@ def test_chain_large_sparse_and_dense_anchor_sets(env):
     ys = Y.ravel().astype(np.uint64)
     o = np.argsort(xs, kind="stable")
     sets.append((xs[o], ys[o] | np.uint64(15 << 32)))
-    PAR = np.dtype([("p", np.int32, 8), ("gs", np.float32)])
+    PAR = np.dtype([("p", np.int32, 8), ("gs", np.float32), ("is_cdna", np.int32)])
     for prm in ((5000, 1000, 5000, 500), (16000, 1000, 16000, 2000)):
         parts = []
         for x, y in sets:

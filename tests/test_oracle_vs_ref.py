@@ -172,7 +172,8 @@ def test_chain_vs_reference(ref_index):
     reads += synth.make_reads(ref, 6, 15000, 9)[0]
     for r in reads:
         ax, ay = ref_anchors(mi, synth.codes_to_ascii(r), 50, 15)
-        for prm in (dict(), dict(max_dist_x=16000, max_dist_y=16000, bw=2000)):
+        # (the last: splice mode — cDNA gap cost of src/chain.c:69-74 with the preset's intron-sized distances, src/options.c:122)
+        for prm in (dict(), dict(max_dist_x=16000, max_dist_y=16000, bw=2000), dict(max_dist_x=200000, max_dist_y=2000, bw=200000, is_cdna=1)):
             ou, obx, oby = W.o_chain_dp(ax, ay, **prm)
             ru, rbx, rby = W.r_chain_dp(ax, ay, **prm)
             assert np.array_equal(ou, ru) and np.array_equal(obx, rbx) and np.array_equal(oby, rby)

@@ -246,3 +246,37 @@ def test_workgroup_sort_of_large_anchor_sets_is_the_stable_sort_and_flags_ties(e
                 if flag == 0:
                     ex, ey = W.o_radix_sort_128x(x, y)
                     assert np.array_equal(gx, ex) and np.array_equal(gy, ey)
+
+
+def test_chain_fill_with_the_cdna_gap_cost_matches_the_oracle(emu, small_index):
+    """splice mode (is_cdna, src/chain.c:69-74): reference gaps cost min(linear, log). Transcript-like anchor sets: exons of a read placed
+    with intron-sized jumps on the reference."""
+    rng = np.random.default_rng(77)
+    n_cases = 0
+    for it in range(12):
+        xs, ys = [], []
+        rpos, qpos = 1000, 20
+        for ex in range(int(rng.integers(2, 7))):
+            for k in range(int(rng.integers(3, 40))):
+                step = int(rng.integers(5, 40))
+                rpos += step; qpos += step + int(rng.integers(-2, 3))
+                xs.append(rpos); ys.append(qpos)
+            rpos += int(rng.integers(80, 60000))          # an intron
+        xs = np.array(xs, np.uint64); ys = np.array(ys, np.uint64) | np.uint64(15 << 32)
+        noise = rng.integers(0, 200000, 10).astype(np.uint64)
+        xs = np.concatenate([xs, noise]); ys = np.concatenate([ys, rng.integers(0, 3000, 10).astype(np.uint64) | np.uint64(15 << 32)])
+        sx, sy = W.o_radix_sort_128x(xs, ys)
+        n = len(sx)
+        prm = dict(max_dist_x=200000, min_dist_x=1000, max_dist_y=2000, bw=200000)
+        avg = C.c_float(); kl = C.c_int()
+        emu.emu_win_plan(n, sx, sy, prm["max_dist_x"], C.byref(avg), C.byref(kl))
+        fa = np.zeros(n, np.int32); pa = np.zeros(n, np.int32); va = np.zeros(n, np.int32)
+        emu.emu_chain_fill(n, sx, sy, prm["max_dist_x"], prm["min_dist_x"], prm["max_dist_y"], prm["bw"], 25 | 0x8000, 5000, avg.value, 1.0, fa, pa, va)
+        ou, obx, oby = W.o_chain_dp(sx, sy, is_cdna=1, **prm)
+        ou0, _, _ = W.o_chain_dp(sx, sy, is_cdna=0, **prm)
+        bx, by = sx.copy(), sy.copy()
+        nu = C.c_int(); u = np.zeros(n, np.uint64)
+        nv = emu.emu_win_extract(n, bx, by, fa, pa, 3, 40, 0, C.byref(nu), u)
+        assert nu.value == len(ou) and np.array_equal(u[:nu.value], ou) and np.array_equal(bx[:nv], obx) and np.array_equal(by[:nv], oby), it
+        n_cases += int(len(ou) != len(ou0) or not np.array_equal(ou, ou0))
+    assert n_cases >= 3        # (the cDNA cost changes the chains in a good part of the cases: the test would not pass with the genomic cost)

@@ -12,7 +12,7 @@ from test_aux_gpu import env, _windows, M128  # noqa: F401
 pytestmark = pytest.mark.gpu
 
 JOB = np.dtype([("seq_off", np.int64), ("stage_off", np.uint64), ("pre_off", np.uint64), ("len", np.int32), ("n_pre", np.int32),
-                ("par", np.int32, 8), ("gs", np.float32), ("pad", np.int32)], align=False)
+                ("par", np.int32, 8), ("gs", np.float32), ("is_cdna", np.int32)], align=False)
 RES = np.dtype([("n_anchors", np.int32), ("rep_len", np.int32), ("n_mini", np.int32), ("n_u", np.int32), ("n_v", np.int32), ("u_off", np.uint32), ("a_off", np.uint32)])
 
 

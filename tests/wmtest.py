@@ -123,8 +123,9 @@ def o_radix_sort_128x(x, y):
 
 
 def o_chain_dp(ax, ay, max_dist_x=5000, min_dist_x=1000, max_dist_y=5000, bw=500, max_skip=25, max_iter=5000,
-               min_cnt=3, min_sc=40, gap_scale=1.0):
+               min_cnt=3, min_sc=40, gap_scale=1.0, is_cdna=0):
     L = oracle()
+    L.wmo_chain_set_cdna(int(is_cdna))
     n = len(ax)
     a = np.empty(n, dtype=[("x", np.uint64), ("y", np.uint64)])
     a["x"], a["y"] = ax, ay
@@ -244,7 +245,7 @@ def r_radix_sort_128x(x, y):
 
 
 def r_chain_dp(ax, ay, max_dist_x=5000, min_dist_x=1000, max_dist_y=5000, bw=500, max_skip=25, max_iter=5000,
-               min_cnt=3, min_sc=40, gap_scale=1.0):
+               min_cnt=3, min_sc=40, gap_scale=1.0, is_cdna=0):
     n = len(ax)
     ax = np.ascontiguousarray(ax, np.uint64)
     ay = np.ascontiguousarray(ay, np.uint64)
@@ -253,7 +254,7 @@ def r_chain_dp(ax, ay, max_dist_x=5000, min_dist_x=1000, max_dist_y=5000, bw=500
     by = np.zeros(max(n, 1), np.uint64)
     n_u = C.c_int(0)
     n_v = ref().refshim_chain_dp(max_dist_x, min_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc, gap_scale,
-                                 0, 1, n, ax, ay, C.byref(n_u), u, bx, by)
+                                 int(is_cdna), 1, n, ax, ay, C.byref(n_u), u, bx, by)
     return u[:n_u.value].copy(), bx[:n_v].copy(), by[:n_v].copy()
 
 

@@ -42,7 +42,16 @@ int set_preset(const char *p, IdxOpt &io, MapOpt &mo)
 	else if (s == "asm5") { io.flag = 0; io.k = 19; mo.a = 1; mo.b = 19; mo.q = 39; mo.q2 = 81; mo.e = 3; mo.e2 = 1; mo.zdrop = mo.zdrop_inv = 200; mo.min_dp_max = 200; }
 	else if (s == "asm10") { io.flag = 0; io.k = 19; mo.a = 1; mo.b = 9; mo.q = 16; mo.q2 = 41; mo.e = 2; mo.e2 = 1; mo.zdrop = mo.zdrop_inv = 200; mo.min_dp_max = 200; }
 	else if (s == "asm20") { io.flag = 0; io.k = 19; mo.a = 1; mo.b = 4; mo.q = 6; mo.q2 = 26; mo.e = 2; mo.e2 = 1; mo.zdrop = mo.zdrop_inv = 200; mo.min_dp_max = 200; }
-	else return -1;                          // splice*/cdna presets belong to ksw_exts2 (out of scope)
+	else if (s.compare(0, 6, "splice") == 0 || s == "cdna") {                              // src/options.c:116-129
+		mo.SVaware = false;
+		io.w = 25; io.flag = 0; io.k = 15;
+		mo.flag |= F_SPLICE | F_SPLICE_FOR | F_SPLICE_REV | F_SPLICE_FLANK;
+		mo.max_gap = 2000; mo.max_gap_ref = mo.bw = 200000;
+		mo.a = 1; mo.b = 2; mo.q = 2; mo.e = 1; mo.q2 = 32; mo.e2 = 0;
+		mo.noncan = 9; mo.junc_bonus = 9;
+		mo.zdrop = 200; mo.zdrop_inv = 100;
+		if (s == "splice:hq") { mo.junc_bonus = 5; mo.b = 4; mo.q = 6; mo.q2 = 24; }
+	} else return -1;
 	return 0;
 }
 

@@ -27,8 +27,8 @@ static const int PARENT_UNSET = -1, PARENT_TMP_PRI = -2;   // src/mmpriv.h:8-9
 // mm_mapopt_t::flag bits we honour, src/minimap.h:9-41
 enum : int64_t {
 	F_NO_DIAG = 0x001, F_NO_DUAL = 0x002, F_CIGAR = 0x004, F_OUT_SAM = 0x008, F_NO_QUAL = 0x010, F_OUT_CG = 0x020, F_OUT_CS = 0x040,
-	F_SPLICE = 0x080, F_NO_LJOIN = 0x400, F_OUT_CS_LONG = 0x800, F_SR = 0x1000, F_NO_PRINT_2ND = 0x4000, F_LONG_CIGAR = 0x10000,
-	F_SOFTCLIP = 0x80000, F_FOR_ONLY = 0x100000, F_REV_ONLY = 0x200000, F_HEAP_SORT = 0x400000, F_ALL_CHAINS = 0x800000,
+	F_SPLICE = 0x080, F_SPLICE_FOR = 0x100, F_SPLICE_REV = 0x200, F_NO_LJOIN = 0x400, F_OUT_CS_LONG = 0x800, F_SR = 0x1000, F_NO_PRINT_2ND = 0x4000, F_LONG_CIGAR = 0x10000,
+	F_SPLICE_FLANK = 0x40000, F_SOFTCLIP = 0x80000, F_FOR_ONLY = 0x100000, F_REV_ONLY = 0x200000, F_HEAP_SORT = 0x400000, F_ALL_CHAINS = 0x800000,
 	F_OUT_MD = 0x1000000, F_COPY_COMMENT = 0x2000000, F_EQX = 0x4000000, F_PAF_NO_HIT = 0x8000000, F_NO_END_FLT = 0x10000000,
 	F_HARD_MLEVEL = 0x20000000, F_SAM_HIT_ONLY = 0x40000000
 };
@@ -62,6 +62,8 @@ struct MapOpt {                            // mm_mapopt_t, src/minimap.h:112-175
 	int min_mid_occ = 0, mid_occ = 5000, max_occ = 0;
 	int64_t mini_batch_size = 1000000000;
 	int64_t max_sw_mat = 0;
+	int noncan = 0, junc_bonus = 0;        // splice mode: cost of a non-canonical splice site, bonus of an annotated junction (src/minimap.h:156-157)
+	int anchor_ext_len = 20, anchor_ext_shift = 6;   // mm_fix_bad_ends_splice (src/options.c:48)
 	std::string kmer_freq_filename;
 };
 
@@ -80,8 +82,9 @@ struct Reg {
 	bool has_p = false;                    // "r->p != 0"
 	int32_t dp_score = 0, dp_max = 0, dp_max2 = 0;
 	uint32_t n_ambi = 0;
+	uint32_t trans_strand = 0;             // mm_extra_t::trans_strand (splice mode): 1 +, 2 -, 3 undetermined
 	std::vector<uint32_t> cigar;
-	void drop_p() { has_p = false; dp_score = dp_max = dp_max2 = 0; n_ambi = 0; cigar.clear(); cigar.shrink_to_fit(); }
+	void drop_p() { has_p = false; dp_score = dp_max = dp_max2 = 0; n_ambi = 0; trans_strand = 0; cigar.clear(); cigar.shrink_to_fit(); }
 };
 
 // ---- sorts with the reference's exact (unstable) permutation, src/ksort.h:101-151 ----

@@ -46,6 +46,7 @@ void window_and_align(Scheduler &sch, const Index &idx, const MapOpt &o, float g
 	wr.max_dist_x = max_gap_ref; wr.min_dist_x = min_gap_ref; wr.max_dist_y = max_gap_qry; wr.bw = o.bw;
 	wr.max_skip = o.max_chain_skip; wr.max_iter = o.max_chain_iter; wr.min_cnt = o.min_cnt; wr.min_sc = o.min_chain_score;
 	wr.gap_scale = gap_scale;
+	wr.is_cdna = (o.flag & F_SPLICE) != 0;                              // is_splice of src/map.c:282
 	if (wr.len > 0 || !wr.pre.empty()) sch.window(wr);
 	if (sketch_it) *rep_len_io = wr.rep_len;
 	const int rep_len = *rep_len_io;

@@ -38,7 +38,7 @@ void DeviceOps::window_batch(int w, int k, std::vector<WindowReq*> &reqs)
 		}
 		r.n_anchors = (int)c.a.size();
 		c.max_dist_x = r.max_dist_x; c.min_dist_x = r.min_dist_x; c.max_dist_y = r.max_dist_y; c.bw = r.bw; c.max_skip = r.max_skip; c.max_iter = r.max_iter;
-		c.min_cnt = r.min_cnt; c.min_sc = r.min_sc; c.gap_scale = r.gap_scale;
+		c.min_cnt = r.min_cnt; c.min_sc = r.min_sc; c.gap_scale = r.gap_scale; c.is_cdna = r.is_cdna;
 		if (!c.a.empty()) chp.push_back(&c);
 	}
 	if (!chp.empty()) chain_batch(chp);

@@ -26,6 +26,7 @@ struct SeedReq {                   // collect_seed_hits (src/map.c:222-254): loo
 struct ChainReq {                  // mm_chain_dp (src/chain.c:22); consumes `a`
 	int max_dist_x = 0, min_dist_x = 0, max_dist_y = 0, bw = 0, max_skip = 0, max_iter = 0, min_cnt = 0, min_sc = 0;
 	float gap_scale = 1.0f;
+	bool is_cdna = false;          // splice mode: an intron-sized reference gap costs min(linear, log) (src/chain.c:69-74)
 	std::vector<m128> a;           // in: sorted anchors; out: anchors grouped by chain
 	std::vector<uint64_t> u;       // out: score<<32 | count per chain
 };
@@ -41,6 +42,7 @@ struct WindowReq {
 	int max_occ = 0; int64_t flag = 0;     // collect_seed_hits
 	int max_dist_x = 0, min_dist_x = 0, max_dist_y = 0, bw = 0, max_skip = 0, max_iter = 0, min_cnt = 0, min_sc = 0;   // mm_chain_dp
 	float gap_scale = 1.0f;
+	bool is_cdna = false;
 	std::vector<m128> a;                   // out: anchors grouped by chain
 	std::vector<uint64_t> u;               // out: score<<32 | count per chain
 	int rep_len = 0, n_anchors = 0;        // out: src/map.c:126; anchors before chaining

@@ -216,7 +216,8 @@ WM_DEV void chain_score(const wm_chain_job_t &jb, uint64_t ri, int qi, int span,
 	V<int> s0 = vmin(md, V<int>(span));                                                            // :65-66
 	const V<int> lg = sel(dd > 0, ilog2_pos(dd), 0);
 	const V<double> lin = cast<double>(dd) * .01 * (double)jb.avg_qspan;
-	const V<int> gc = cast<int>(lin) + (lg >> 1);                                                  // :76
+	V<int> gc = cast<int>(lin) + (lg >> 1);                                                        // :76
+	if (jb.is_cdna) gc = sel(dr > dql, vmin(cast<int>(lin), lg), gc);                              // :69-74: an intron (reference gap) costs min(linear, log)
 	s0 = s0 - cast<int>(cast<double>(gc) * (double)jb.gap_scale + .499);                           // :77
 	sc = s0 + fj;
 }
@@ -394,7 +395,8 @@ WM_DEV void chain_block(const wm_chain_job_t jb, const wm128_t *anchor_pool, int
 				V<int> s0 = vmin(md, V<int>(span));
 				const V<int> lg = sel(dd > 0, ilog2_pos(dd), 0);
 				const V<double> lin = cast<double>(dd) * .01 * (double)jb.avg_qspan;
-				const V<int> gc = cast<int>(lin) + (lg >> 1);
+				V<int> gc = cast<int>(lin) + (lg >> 1);
+				if (jb.is_cdna) gc = sel(dr > dql, vmin(cast<int>(lin), lg), gc);
 				s0 = s0 - cast<int>(cast<double>(gc) * (double)jb.gap_scale + .499);
 				sc = s0 + fj;
 				valid = ok;

@@ -452,7 +452,7 @@ WM_DEV void win_plan_wave(const wm_win_job_t jb, int j, uint64_t a_off, int n, c
 	WM_IF(ln == 0)
 		wm_chain_job_t o;
 		o.a_off = a_off; o.n = n; o.max_dist_x = jb.max_dist_x; o.min_dist_x = jb.min_dist_x; o.max_dist_y = jb.max_dist_y; o.bw = jb.bw;
-		o.max_skip = jb.max_skip; o.max_iter = jb.max_iter; o.avg_qspan = avg; o.gap_scale = jb.gap_scale; o.pad = 0;
+		o.max_skip = jb.max_skip; o.max_iter = jb.max_iter; o.avg_qspan = avg; o.gap_scale = jb.gap_scale; o.is_cdna = jb.is_cdna;
 		cj[j] = o;
 	WM_END
 	const int slot = wave_append(counts + klass);
@@ -626,7 +626,7 @@ WM_DEV void win_small_wave(const wm_win_job_t jb, int n, const wm128_t *ga_, uns
 	}
 	wm_chain_job_t cj;
 	cj.a_off = 0; cj.n = n; cj.max_dist_x = jb.max_dist_x; cj.min_dist_x = jb.min_dist_x; cj.max_dist_y = jb.max_dist_y; cj.bw = jb.bw;
-	cj.max_skip = jb.max_skip; cj.max_iter = jb.max_iter; cj.avg_qspan = win_avg_qspan(stage, n); cj.gap_scale = jb.gap_scale; cj.pad = 0;
+	cj.max_skip = jb.max_skip; cj.max_iter = jb.max_iter; cj.avg_qspan = win_avg_qspan(stage, n); cj.gap_scale = jb.gap_scale; cj.is_cdna = jb.is_cdna;
 	chain_wave(cj, stage, W, sx, sy, sf, sp, st, sf, sp, (int*)0);            // n <= W: nothing leaves the window; f and p stay where they are
 	lds_sync();
 	win_extract_wave<false>(n, jb.min_cnt, jb.min_sc, stage, sf, sp, lv, lt, zu, b, wb, ws, res, u_pool, v_pool, pool_ctr);

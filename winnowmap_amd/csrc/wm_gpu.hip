@@ -1637,7 +1637,7 @@ try {
 	wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 		jb[i].a_off = a_off[i]; jb[i].n = n_a[i];
 		jb[i].max_dist_x = par[i].max_dist_x; jb[i].min_dist_x = par[i].min_dist_x; jb[i].max_dist_y = par[i].max_dist_y; jb[i].bw = par[i].bw;
-		jb[i].max_skip = par[i].max_skip; jb[i].max_iter = par[i].max_iter; jb[i].gap_scale = par[i].gap_scale; jb[i].pad = 0;
+		jb[i].max_skip = par[i].max_skip; jb[i].max_iter = par[i].max_iter; jb[i].gap_scale = par[i].gap_scale; jb[i].is_cdna = par[i].is_cdna != 0;
 		jb[i].avg_qspan = n_a[i] > 0 ? wm::chain_avg_qspan(n_a[i], a + a_off[i]) : 0.f;
 		order[i] = (int)i;
 	});
@@ -1896,7 +1896,7 @@ static int window_launch(wm_ctx_t *c, int n, const wm_window_job_t *jobs, const 
 		    (s.seq_off == -1 && s.stage_off + (uint64_t)s.len > seqs_bytes)) { if (bad < 0) bad = i; }
 		d.seq_off = has_seq ? 0 : -1; d.pre_off = s.pre_off; d.len = s.len; d.n_pre = s.n_pre; d.max_occ = max_occ; d.seed_flag = (int32_t)(flag & (0x100000 | 0x200000));
 		d.max_dist_x = s.par.max_dist_x; d.min_dist_x = s.par.min_dist_x; d.max_dist_y = s.par.max_dist_y; d.bw = s.par.bw; d.max_skip = s.par.max_skip; d.max_iter = s.par.max_iter;
-		d.min_cnt = s.par.min_cnt; d.min_sc = s.par.min_sc; d.gap_scale = s.par.gap_scale; d.pad = 0;
+		d.min_cnt = s.par.min_cnt; d.min_sc = s.par.min_sc; d.gap_scale = s.par.gap_scale; d.is_cdna = s.par.is_cdna != 0;
 		wm_sketch_job_t &k = sj[i];
 		k.len = has_seq ? s.len : 0;
 		k.cap = has_seq ? (slot_full ? s.len + 1 : s.len / 8 + 16) : 0;
@@ -2121,7 +2121,7 @@ struct GpuOpsCtx {
 		for (int i = 0; i < n; ++i) {
 			aoff[i] = tot; na[i] = (int)reqs[i]->a.size(); tot += reqs[i]->a.size();
 			wm::ChainReq &r = *reqs[i];
-			par[i] = { r.max_dist_x, r.min_dist_x, r.max_dist_y, r.bw, r.max_skip, r.max_iter, r.min_cnt, r.min_sc, r.gap_scale };
+			par[i] = { r.max_dist_x, r.min_dist_x, r.max_dist_y, r.bw, r.max_skip, r.max_iter, r.min_cnt, r.min_sc, r.gap_scale, r.is_cdna ? 1 : 0 };
 		}
 		UBuf<wm128_t> a(tot + 1, c);
 		UBuf<uint64_t> u(tot + 1, c);
@@ -2161,7 +2161,7 @@ struct GpuOpsCtx {
 			if (r.len <= 0) j.seq_off = -2;
 			else if (resident && r.dev_off >= 0) j.seq_off = r.dev_off;
 			else { j.seq_off = -1; j.stage_off = stage; stage += (size_t)r.len; }
-			j.par = { r.max_dist_x, r.min_dist_x, r.max_dist_y, r.bw, r.max_skip, r.max_iter, r.min_cnt, r.min_sc, r.gap_scale };
+			j.par = { r.max_dist_x, r.min_dist_x, r.max_dist_y, r.bw, r.max_skip, r.max_iter, r.min_cnt, r.min_sc, r.gap_scale, r.is_cdna ? 1 : 0 };
 		}
 		UBuf<uint8_t> seqs(stage + 1, c);
 		UBuf<wm128_t> pre(npre + 1, c);

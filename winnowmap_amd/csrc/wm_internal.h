@@ -64,7 +64,7 @@ typedef struct {
 	uint64_t a_off;       // first anchor of this job in the anchor pool (sorted by x)
 	int32_t n, max_dist_x, min_dist_x, max_dist_y, bw, max_skip, max_iter;
 	float avg_qspan, gap_scale;
-	int32_t pad;
+	int32_t is_cdna;      // splice mode: the gap cost of src/chain.c:69-74
 } wm_chain_job_t;
 
 // ---- one MCAS window / stage-2 pass on the device: sketch → seed → sort → chain → extraction (window_kernel.h) ----
@@ -75,7 +75,7 @@ typedef struct {
 	int32_t max_occ, seed_flag;                                                        // collect_seed_hits: mid_occ, MM_F_FOR_ONLY / MM_F_REV_ONLY bits
 	int32_t max_dist_x, min_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc;   // mm_chain_dp
 	float gap_scale;
-	int32_t pad;
+	int32_t is_cdna;
 } wm_win_job_t;
 
 typedef struct {          // per job on the device: where its anchors live and what came out
