@@ -221,7 +221,8 @@ void wm_mapper_destroy(wm_mapper_t *m);
 int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena_bytes_per_group);
 /* Map n reads (ASCII). Output records (PAF, or SAM when MM_F_OUT_SAM) of all reads in input order are appended to
  * an internal buffer returned through *text / *text_len (valid until the next call). hits (optional, 16 int32 per
- * hit: rid rs re qs qe rev mapq n_cigar score cnt mlen blen dp_score dp_max dp_max2 flags) and their CIGARs are
+ * hit: rid rs re qs qe rev mapq n_cigar score cnt mlen blen dp_score dp_max dp_max2 flags; flags = primary | inv<<1 | sam_pri<<2 | split<<3 |
+ * trans_strand<<5) and their CIGARs are
  * returned for tests; hit_first[i] = index of read i's first hit, hit_first[n] = total. */
 int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, const char *const *seqs, const int32_t *lens,
                  const char **text, size_t *text_len, const int32_t **hits, const uint32_t **cigars, const int64_t **hit_first);
@@ -269,6 +270,8 @@ typedef struct {
 	float mid_occ_frac;
 	int32_t min_mid_occ, mid_occ, max_occ;
 	int64_t mini_batch_size, max_sw_mat;
+	int32_t noncan, junc_bonus;                 /* splice mode (src/minimap.h: mm_mapopt_t::noncan, junc_bonus) */
+	int32_t anchor_ext_len, anchor_ext_shift;   /* mm_fix_bad_ends_splice (src/align.c:545-563) */
 } wm_mapopt_t;
 int wm_mapopt_preset(const char *preset, wm_mapopt_t *out, int *k, int *w);
 int wm_mapper_create_opt(wm_ctx_t *ctx, const wm_index_t *idx, const wm_mapopt_t *opt, wm_mapper_t **out);

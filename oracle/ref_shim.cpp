@@ -150,7 +150,7 @@ int refshim_ksw_ll_i16(int qlen, const uint8_t *query, int tlen, const uint8_t *
 
 // ---- end-to-end: src/minimap.h:358 mm_map with a preset (src/options.c:89) ----
 // flag_extra is OR-ed into mm_mapopt_t::flag (MM_F_CIGAR=0x4 | MM_F_OUT_SAM=0x8 ...).
-// Output per hit, 16 int32: rid rs re qs qe rev mapq n_cigar | score cnt mlen blen dp_score dp_max dp_max2 flags(parent==id | inv<<1 | sam_pri<<2 | split<<3)
+// Output per hit, 16 int32: rid rs re qs qe rev mapq n_cigar | score cnt mlen blen dp_score dp_max dp_max2 flags(parent==id | inv<<1 | sam_pri<<2 | split<<3 | trans_strand<<5)
 // cigars are appended to cig_out. Returns n_regs.
 static mm_mapopt_t g_mo; static mm_idxopt_t g_io;
 void *refshim_mapopt(const char *preset, int64_t flag_extra, void *mi)
@@ -161,6 +161,7 @@ void *refshim_mapopt(const char *preset, int64_t flag_extra, void *mi)
 	mm_mapopt_update(&g_mo, (mm_idx_t*)mi);
 	return &g_mo;
 }
+void refshim_mapopt_clear_flag(void *opt, int64_t bits) { ((mm_mapopt_t*)opt)->flag &= ~bits; }     // e.g. -uf = MM_F_SPLICE_REV cleared (src/main.c)
 void refshim_mapopt_set_max_sw_mat(void *opt, int64_t v) { ((mm_mapopt_t*)opt)->max_sw_mat = v; }     // (no command-line switch reaches it: the long-option table lacks --cap-sw-mat)
 // every mm_mapopt_t field that wm_mapopt_t mirrors (include/wm_gpu.h), in that struct's order, after mm_set_opt(0) + mm_set_opt(preset)
 int refshim_preset_fields(const char *preset, double *o, int cap)
@@ -174,7 +175,8 @@ int refshim_preset_fields(const char *preset, double *o, int cap)
 		(double)m.stage2_zdrop_inv, (double)m.stage2_max_gap, (double)m.mask_level, (double)m.mask_len, (double)m.pri_ratio, (double)m.best_n, (double)m.max_join_long, (double)m.max_join_short,
 		(double)m.min_join_flank_sc, (double)m.min_join_flank_ratio, (double)m.alt_drop, (double)m.a, (double)m.b, (double)m.q, (double)m.e, (double)m.q2, (double)m.e2, (double)m.sc_ambi,
 		(double)m.zdrop, (double)m.zdrop_inv, (double)m.end_bonus, (double)m.min_dp_max, (double)m.min_ksw_len, (double)m.max_clip_ratio, (double)m.mid_occ_frac, (double)m.min_mid_occ,
-		(double)m.mid_occ, (double)m.max_occ, (double)m.mini_batch_size, (double)m.max_sw_mat, (double)io.k, (double)io.w };
+		(double)m.mid_occ, (double)m.max_occ, (double)m.mini_batch_size, (double)m.max_sw_mat,
+		(double)m.noncan, (double)m.junc_bonus, (double)m.anchor_ext_len, (double)m.anchor_ext_shift, (double)io.k, (double)io.w };
 	const int n = (int)(sizeof(v) / sizeof(v[0]));
 	for (int i = 0; i < n && i < cap; ++i) o[i] = v[i];
 	return n;
@@ -196,7 +198,7 @@ int refshim_map(void *mi, void *opt, const char *seq, int len, const char *name,
 			h[7] = r->p ? r->p->n_cigar : 0;
 			h[8] = r->score; h[9] = r->cnt; h[10] = r->mlen; h[11] = r->blen;
 			h[12] = r->p ? r->p->dp_score : 0; h[13] = r->p ? r->p->dp_max : 0; h[14] = r->p ? r->p->dp_max2 : 0;
-			h[15] = (r->parent == r->id) | r->inv << 1 | r->sam_pri << 2 | r->split << 3;
+			h[15] = (r->parent == r->id) | r->inv << 1 | r->sam_pri << 2 | r->split << 3 | (r->p ? r->p->trans_strand << 5 : 0);
 			if (r->p) for (uint32_t j = 0; j < r->p->n_cigar; ++j) { if (nc < cig_cap) cig_out[nc] = r->p->cigar[j]; ++nc; }
 		}
 		free(r->p);

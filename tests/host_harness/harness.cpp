@@ -146,6 +146,23 @@ struct OracleOps : DeviceOps {
 			r->cigar.assign(cig.begin(), cig.begin() + ez.n_cigar);
 		});
 	}
+	void exts2_batch(const wm_ksw_score_t &sc, int noncan, int junc_bonus, std::vector<KswReq*> &reqs) override
+	{   // splice mode: ksw_exts2_sse per request (src/align.c:326-327)
+		int8_t mat[25];
+		for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) mat[i * 5 + j] = (i == 4 || j == 4) ? sc.sc_ambi : i == j ? sc.match : sc.mismatch;
+		wm::parallel_for(4, reqs.size(), [&](size_t ri) {
+			KswReq *r = reqs[ri];
+			wmo_ez_t ez;
+			std::vector<uint8_t> q(r->ql > 0 ? r->ql : 0), t(r->tl > 0 ? r->tl : 0);
+			r->copy_query(q.data()); r->copy_target(t.data());
+			check_positions(*r, q, t);
+			std::vector<uint32_t> cig(q.size() + t.size() + 4);
+			wmo_ksw_exts2((int)q.size(), q.data(), (int)t.size(), t.data(), 5, mat, sc.q, sc.e, sc.q2, noncan, r->zdrop, junc_bonus, r->flag, 0, &ez, cig.data());
+			r->ez.max = ez.max; r->ez.zdropped = ez.zdropped; r->ez.max_q = ez.max_q; r->ez.max_t = ez.max_t; r->ez.mqe = ez.mqe; r->ez.mqe_t = ez.mqe_t;
+			r->ez.mte = ez.mte; r->ez.mte_q = ez.mte_q; r->ez.score = ez.score; r->ez.reach_end = ez.reach_end; r->ez.n_cigar = ez.n_cigar; r->ez.cig_off = 0;
+			r->cigar.assign(cig.begin(), cig.begin() + ez.n_cigar);
+		});
+	}
 };
 
 struct Harness { Index idx; wmo_bloom_t *bloom; };
@@ -254,6 +271,8 @@ void *h_index_load_mmi(const char *path, const char *kmer_file)
 }
 
 // same output layout as refshim_map (oracle/ref_shim.cpp)
+static int64_t g_max_sw_mat = 0, g_flag_clear = 0;
+void h_set_flag_clear(int64_t bits) { g_flag_clear = bits; }     // option bits the h_map* calls that follow clear after the preset (e.g. -uf clears MM_F_SPLICE_REV)
 int h_map(void *hv, const char *preset, int64_t flag_extra, const char *seq, int len, const char *name,
           int32_t *hit_out, int hit_cap, uint32_t *cig_out, int64_t cig_cap, int64_t *n_cig_total, uint64_t *stats_out)
 {
@@ -261,7 +280,8 @@ int h_map(void *hv, const char *preset, int64_t flag_extra, const char *seq, int
 	IdxOpt io; MapOpt mo;
 	set_preset(0, io, mo);
 	if (preset && preset[0] && set_preset(preset, io, mo) < 0) return -1;
-	mo.flag |= flag_extra;
+	mo.flag |= flag_extra; mo.flag &= ~g_flag_clear;
+	mapopt_update(mo, h->idx);
 	OracleOps ops; ops.idx = &h->idx; ops.bloom = h->bloom; ops.opt = &mo;
 	std::vector<ReadIn> reads(1);
 	reads[0].name = name; reads[0].seq.assign(seq, len);
@@ -278,7 +298,7 @@ int h_map(void *hv, const char *preset, int64_t flag_extra, const char *seq, int
 		int32_t *o = hit_out + 16 * i;
 		o[0] = r.rid; o[1] = r.rs; o[2] = r.re; o[3] = r.qs; o[4] = r.qe; o[5] = r.rev; o[6] = r.mapq; o[7] = r.has_p ? (int)r.cigar.size() : 0;
 		o[8] = r.score; o[9] = r.cnt; o[10] = r.mlen; o[11] = r.blen; o[12] = r.dp_score; o[13] = r.dp_max; o[14] = r.dp_max2;
-		o[15] = (r.parent == r.id) | r.inv << 1 | r.sam_pri << 2 | r.split << 3;
+		o[15] = (r.parent == r.id) | r.inv << 1 | r.sam_pri << 2 | r.split << 3 | (r.has_p ? r.trans_strand << 5 : 0);
 		for (uint32_t c : r.cigar) { if (nc < cig_cap) cig_out[nc] = c; ++nc; }
 	}
 	*n_cig_total = nc;
@@ -288,7 +308,6 @@ int h_map(void *hv, const char *preset, int64_t flag_extra, const char *seq, int
 // how many requests carried resident positions (checked against their host views) and how many of them disagreed
 void h_pos_check(long *checked, long *bad) { *checked = g_pos_checked.load(); *bad = g_pos_bad.load(); }
 
-static int64_t g_max_sw_mat = 0;
 void h_set_max_sw_mat(int64_t v) { g_max_sw_mat = v; }          // mm_mapopt_t::max_sw_mat for the h_map_many calls that follow (src/align.c:323-325)
 
 // several reads at once on a team of `n_threads` schedulers; hits of read i start at hit_first[i] (16 ints each)
@@ -299,8 +318,9 @@ int h_map_many(void *hv, const char *preset, int64_t flag_extra, int n, const ch
 	IdxOpt io; MapOpt mo;
 	set_preset(0, io, mo);
 	if (preset && preset[0] && set_preset(preset, io, mo) < 0) return -1;
-	mo.flag |= flag_extra;
+	mo.flag |= flag_extra; mo.flag &= ~g_flag_clear;
 	mo.max_sw_mat = g_max_sw_mat;
+	mapopt_update(mo, h->idx);
 	OracleOps ops; ops.idx = &h->idx; ops.bloom = h->bloom; ops.opt = &mo;
 	std::vector<ReadIn> reads(n);
 	for (int i = 0; i < n; ++i) { reads[i].name = "read" + std::to_string(i); reads[i].seq.assign(seqs[i], lens[i]); }
@@ -317,7 +337,7 @@ int h_map_many(void *hv, const char *preset, int64_t flag_extra, int n, const ch
 			int32_t *o = hit_out + 16 * (size_t)nh++;
 			o[0] = r.rid; o[1] = r.rs; o[2] = r.re; o[3] = r.qs; o[4] = r.qe; o[5] = r.rev; o[6] = r.mapq; o[7] = r.has_p ? (int)r.cigar.size() : 0;
 			o[8] = r.score; o[9] = r.cnt; o[10] = r.mlen; o[11] = r.blen; o[12] = r.dp_score; o[13] = r.dp_max; o[14] = r.dp_max2;
-			o[15] = (r.parent == r.id) | r.inv << 1 | r.sam_pri << 2 | r.split << 3;
+			o[15] = (r.parent == r.id) | r.inv << 1 | r.sam_pri << 2 | r.split << 3 | (r.has_p ? r.trans_strand << 5 : 0);
 			for (uint32_t c : r.cigar) { if (nc < cig_cap) cig_out[nc] = c; ++nc; }
 		}
 	}
@@ -334,7 +354,8 @@ int64_t h_map_text(void *hv, const char *preset, int64_t flag_extra, int n, cons
 	IdxOpt io; MapOpt mo;
 	set_preset(0, io, mo);
 	if (preset && preset[0] && set_preset(preset, io, mo) < 0) return -1;
-	mo.flag |= flag_extra;
+	mo.flag |= flag_extra; mo.flag &= ~g_flag_clear;
+	mapopt_update(mo, h->idx);
 	OracleOps ops; ops.idx = &h->idx; ops.bloom = h->bloom; ops.opt = &mo;
 	std::vector<ReadIn> reads(n);
 	for (int i = 0; i < n; ++i) { reads[i].name = names[i]; reads[i].seq.assign(seqs[i], lens[i]); }
@@ -356,7 +377,8 @@ int h_map_file(void *hv, const char *preset, int64_t flag_extra, const char *rea
 	IdxOpt io; MapOpt mo;
 	set_preset(0, io, mo);
 	if (preset && preset[0] && set_preset(preset, io, mo) < 0) return -1;
-	mo.flag |= flag_extra;
+	mo.flag |= flag_extra; mo.flag &= ~g_flag_clear;
+	mapopt_update(mo, h->idx);
 	OracleOps ops; ops.idx = &h->idx; ops.bloom = h->bloom; ops.opt = &mo;
 	FILE *out = fopen(out_path, "wb");
 	if (!out) return -2;

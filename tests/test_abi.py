@@ -80,9 +80,10 @@ def test_presets_equal_the_references_mm_set_opt():
                    [(n, C.c_int32) for n in ("stage2_bw", "stage2_zdrop_inv", "stage2_max_gap")] + [("mask_level", C.c_float), ("mask_len", C.c_int32), ("pri_ratio", C.c_float), ("best_n", C.c_int32)] + \
                    [(n, C.c_int32) for n in ("max_join_long", "max_join_short", "min_join_flank_sc")] + [("min_join_flank_ratio", C.c_float), ("alt_drop", C.c_float)] + \
                    [(n, C.c_int32) for n in ("a", "b", "q", "e", "q2", "e2", "sc_ambi", "zdrop", "zdrop_inv", "end_bonus", "min_dp_max", "min_ksw_len")] + \
-                   [("max_clip_ratio", C.c_float), ("mid_occ_frac", C.c_float)] + [(n, C.c_int32) for n in ("min_mid_occ", "mid_occ", "max_occ")] + [("mini_batch_size", C.c_int64), ("max_sw_mat", C.c_int64)]
+                   [("max_clip_ratio", C.c_float), ("mid_occ_frac", C.c_float)] + [(n, C.c_int32) for n in ("min_mid_occ", "mid_occ", "max_occ")] + [("mini_batch_size", C.c_int64), ("max_sw_mat", C.c_int64)] + \
+                   [(n, C.c_int32) for n in ("noncan", "junc_bonus", "anchor_ext_len", "anchor_ext_shift")]
     L.wm_mapopt_preset.argtypes = [C.c_char_p, C.POINTER(MapOpt), C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    for preset in (b"", b"map-ont", b"map-pb", b"map-pb-clr", b"asm5", b"asm10", b"asm20"):
+    for preset in (b"", b"map-ont", b"map-pb", b"map-pb-clr", b"asm5", b"asm10", b"asm20", b"splice", b"splice:hq", b"cdna"):
         o = MapOpt(); k = C.c_int(); w = C.c_int()
         assert L.wm_mapopt_preset(preset, C.byref(o), C.byref(k), C.byref(w)) == 0
         ours = [float(getattr(o, n)) for n, _ in MapOpt._fields_] + [float(k.value), float(w.value)]

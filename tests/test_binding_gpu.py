@@ -172,3 +172,33 @@ def test_splice_mode_through_the_substituted_ksw_exts2():
     d = parity.diff_texts(want, got, sam=False)
     assert d["reads"] == 60 and d["hits"] >= 55 and d["mismatches"] == 0, d
     assert sum(1 for ln in got.decode().splitlines() if "N" in ln.split("cg:Z:")[-1].split("\t")[0]) >= 50
+
+
+@need_ref
+def test_splice_mode_of_the_mapper_matches_the_reference_cli():
+    """`-cx splice` (src/options.c:116-128) through wm_map_reads: cDNA chaining cost in the window kernels, every alignment through
+    wm_ksw_exts2_batch, two passes per region (one per transcript strand, src/align.c:884-904), ts:A and N in the records. Compared with the
+    untouched reference binary, then once more with -uf-like options (one pass) through the option struct."""
+    tmp = tempfile.mkdtemp()
+    ref = synth.make_reference(2, 300000, 41, repeat_frac=0.05)
+    reads = synth.make_transcripts(ref, 200, 42)
+    fa = os.path.join(tmp, "ref.fa")
+    synth.write_fasta(fa, ref, prefix="chr")
+    rq = os.path.join(tmp, "reads.fa")
+    _write_reads(rq, reads)
+    ctx = gpu.Context(0, 8 << 30)
+    idx = gpu.Index(fa, None, k=15, w=25, n_threads=8)
+    idx.upload(ctx)
+    names = [b"r%d" % i for i in range(len(reads))]
+    seqs = [synth.codes_to_ascii(r) for r in reads]
+    for preset in ("splice", "splice:hq"):
+        want = _run(REF_BIN, ["-t", "8", "-k", "15", "-w", "25", "-cx", preset, fa, rq])
+        m = gpu.Mapper(ctx, idx, preset, gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
+        m.set_threads(8, 4 << 30)
+        text, hits, _, _ = m.map(names, seqs)
+        d = parity.diff_texts(want, text, sam=False)
+        assert d["reads"] >= 180 and d["hits"] >= 180 and d["mismatches"] == 0, (preset, d)
+        import re
+        assert text.count(b"ts:A:+") > 20 and text.count(b"ts:A:-") > 20 and len(re.findall(rb"[0-9]N", text)) > 200
+        m.close()
+    idx.close(); ctx.close()

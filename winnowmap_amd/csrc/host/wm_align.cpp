@@ -8,7 +8,7 @@
 
 namespace wm {
 
-enum { EZ_RIGHT = 0x02, EZ_APPROX_MAX = 0x08, EZ_EXTZ_ONLY = 0x40, EZ_REV_CIGAR = 0x80 };   // src/ksw2.h:8-17
+enum { EZ_RIGHT = 0x02, EZ_APPROX_MAX = 0x08, EZ_EXTZ_ONLY = 0x40, EZ_REV_CIGAR = 0x80, EZ_SPLICE_FOR = 0x100, EZ_SPLICE_REV = 0x200, EZ_SPLICE_FLANK = 0x400 };   // src/ksw2.h:8-20
 
 static void gen_simple_mat(int8_t *mat, int a, int b, int sc_ambi)
 {   // ksw_gen_simple_mat, src/align.c:9-22 (m = 5)
@@ -216,6 +216,40 @@ static void fix_bad_ends(const Reg &r, const m128 *a, int bw, int min_match, int
 }
 
 // how many leading positions of t[0..n) and q[0..n) hold the same unambiguous base (codes < 4): eight at a time
+// mm_seed_ext_score (src/align.c:523-543): local alignment score (ksw_ll_i16) of one anchor stretched by anchor_ext_len to both sides
+static int seed_ext_score(const MapOpt &opt, const Index &mi, const int8_t *mat, int qlen, const uint8_t *const qseq0[2], const m128 &a)
+{
+	const int q_span = (int)(a.y >> 32 & 0xff), ext_len = opt.anchor_ext_len;
+	const int rid = (int)(a.x << 1 >> 33);
+	int re = (int32_t)a.x + 1, rs = re - q_span, qe = (int32_t)a.y + 1, qs = qe - q_span;
+	rs = rs - ext_len > 0 ? rs - ext_len : 0;
+	qs = qs - ext_len > 0 ? qs - ext_len : 0;
+	re = re + ext_len < (int32_t)mi.seq[rid].len ? re + ext_len : (int32_t)mi.seq[rid].len;
+	qe = qe + ext_len < qlen ? qe + ext_len : qlen;
+	std::vector<uint8_t> tseq(re - rs);
+	mi.getseq(rid, rs, re, tseq.data());
+	int q_off, t_off;
+	return ll_i16(qe - qs, qseq0[a.x >> 63] + qs, re - rs, tseq.data(), mat, opt.q, opt.e, &q_off, &t_off);
+}
+
+// mm_fix_bad_ends_splice (src/align.c:545-563): a boundary anchor that sits across a long gap must carry its own weight — its span, or
+// the score of the sequence around it, has to exceed log(gap) + anchor_ext_shift; otherwise it is a tiny terminal exon placed by chance
+static void fix_bad_ends_splice(const MapOpt &opt, const Index &mi, const Reg &r, const int8_t *mat, int qlen, const uint8_t *const qseq0[2], const m128 *a, int32_t *as1, int32_t *cnt1)
+{
+	*as1 = r.as, *cnt1 = r.cnt;
+	if (r.cnt < 3) return;
+	double log_gap = std::log((double)((int32_t)a[r.as + 1].x - (int32_t)a[r.as].x));
+	if ((double)(int)(a[r.as].y >> 32 & 0xff) < log_gap + opt.anchor_ext_shift) {
+		const int score = seed_ext_score(opt, mi, mat, qlen, qseq0, a[r.as]);
+		if ((double)score / mat[0] < log_gap + opt.anchor_ext_shift) ++(*as1), --(*cnt1);
+	}
+	log_gap = std::log((double)((int32_t)a[r.as + r.cnt - 1].x - (int32_t)a[r.as + r.cnt - 2].x));
+	if ((double)(int)(a[r.as + r.cnt - 1].y >> 32 & 0xff) < log_gap + opt.anchor_ext_shift) {
+		const int score = seed_ext_score(opt, mi, mat, qlen, qseq0, a[r.as + r.cnt - 1]);
+		if ((double)score / mat[0] < log_gap + opt.anchor_ext_shift) --(*cnt1);
+	}
+}
+
 static inline uint32_t match_run(const uint8_t *t, const uint8_t *q, uint32_t n)
 {
 	uint32_t l = 0;
@@ -413,7 +447,8 @@ static inline std::vector<uint8_t> ref_codes(const Index &idx, int rid, int st, 
 	return t;
 }
 
-static void plan_reg(const AlnEnv &E, RegAln &A, m128 *a, std::vector<KswReq> &jobs)
+// splice_flag: F_SPLICE_FOR / F_SPLICE_REV bits of the transcript strand this pass assumes (src/align.c:565, 602-606)
+static void plan_reg(const AlnEnv &E, RegAln &A, m128 *a, std::vector<KswReq> &jobs, int64_t splice_flag)
 {
 	WM_PROF("align.plan_reg");
 	const MapOpt &opt = *E.opt;
@@ -424,8 +459,17 @@ static void plan_reg(const AlnEnv &E, RegAln &A, m128 *a, std::vector<KswReq> &j
 	if (r.cnt == 0) { A.empty = true; return; }
 	A.rid = (int32_t)(a[r.as].x << 1 >> 33); A.rev = (int32_t)(a[r.as].x >> 63);
 	A.bw = (int)(opt.bw * 1.5 + 1.);
-	if (!(opt.flag & F_NO_END_FLT)) fix_bad_ends(r, a, opt.bw, opt.min_chain_score * 2, &A.as1, &A.cnt1);
-	else A.as1 = r.as, A.cnt1 = r.cnt;
+	const bool is_splice = (opt.flag & F_SPLICE) != 0;
+	if (!(opt.flag & F_NO_END_FLT)) {
+		if (is_splice) fix_bad_ends_splice(opt, mi, r, E.mat, qlen, E.qseq0, a, &A.as1, &A.cnt1);
+		else fix_bad_ends(r, a, opt.bw, opt.min_chain_score * 2, &A.as1, &A.cnt1);
+	} else A.as1 = r.as, A.cnt1 = r.cnt;
+	int extra_flag = 0;
+	if (is_splice) {                                                   // which strand carries GT..AG: in alignment (= reference) orientation
+		if (splice_flag & F_SPLICE_FOR) extra_flag |= A.rev ? EZ_SPLICE_REV : EZ_SPLICE_FOR;
+		if (splice_flag & F_SPLICE_REV) extra_flag |= A.rev ? EZ_SPLICE_FOR : EZ_SPLICE_REV;
+		if (opt.flag & F_SPLICE_FLANK) extra_flag |= EZ_SPLICE_FLANK;
+	}
 	filter_bad_seeds(A.as1, A.cnt1, a, 10, 40, opt.max_gap >> 1, 10);
 	filter_bad_seeds_alt(A.as1, A.cnt1, a, 30, opt.max_gap >> 1);
 	adjust_minier(mi, a[A.as1], &A.rs, &A.qs);
@@ -500,7 +544,7 @@ static void plan_reg(const AlnEnv &E, RegAln &A, m128 *a, std::vector<KswReq> &j
 	if (qs > 0 && rs > 0) {                                            // left extension on reversed sequences (:690-705)
 		KswReq j = make_job(E, A.rev, qs0, qs, rid, rs0, rs, tb, rs0, A.t_has_n, true);
 		j.w = A.bw; j.end_bonus = opt.end_bonus; j.zdrop = r.split_inv ? opt.zdrop_inv : opt.zdrop;
-		j.flag = EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR;
+		j.flag = extra_flag | EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR;
 		A.left_job = (int)jobs.size(); jobs.push_back(std::move(j));
 	}
 	for (i = 1; i < cnt1; ++i) {                                       // gap filling (:709-765), first pass
@@ -510,7 +554,7 @@ static void plan_reg(const AlnEnv &E, RegAln &A, m128 *a, std::vector<KswReq> &j
 			Fill f; f.idx = i; f.qs = qs; f.qe = qe; f.rs = rs; f.re = re; f.bw1 = A.bw; f.redo_job = -1;
 			if (a[as1 + i].y & SEED_LONG_JOIN) f.bw1 = qe - qs > re - rs ? qe - qs : re - rs;
 			KswReq j = make_job(E, A.rev, qs, qe, rid, rs, re, tb, rs0, A.t_has_n, false);
-			j.w = f.bw1; j.end_bonus = -1; j.zdrop = opt.zdrop; j.flag = EZ_APPROX_MAX;
+			j.w = f.bw1; j.end_bonus = -1; j.zdrop = opt.zdrop; j.flag = extra_flag | EZ_APPROX_MAX;
 			f.job = (int)jobs.size(); jobs.push_back(std::move(j));
 			A.fills.push_back(f);
 			rs = re, qs = qe;
@@ -519,7 +563,7 @@ static void plan_reg(const AlnEnv &E, RegAln &A, m128 *a, std::vector<KswReq> &j
 	A.re = re, A.qe = qe;                                              // coordinates of the last anchor
 	if (qe < qe0 && re < re0) {                                        // right extension (:767-778), used unless a fill z-drops
 		KswReq j = make_job(E, A.rev, qe, qe0, rid, re, re0, tb, rs0, A.t_has_n, false);
-		j.w = A.bw; j.end_bonus = opt.end_bonus; j.zdrop = opt.zdrop; j.flag = EZ_EXTZ_ONLY;
+		j.w = A.bw; j.end_bonus = opt.end_bonus; j.zdrop = opt.zdrop; j.flag = extra_flag | EZ_EXTZ_ONLY;
 		A.right_job = (int)jobs.size(); jobs.push_back(std::move(j));
 	}
 }
@@ -537,7 +581,7 @@ static void judge_reg(const AlnEnv &E, RegAln &A, const std::vector<KswReq> &job
 		A.redo_code[k] = code;
 		if (code != 0) {
 			KswReq d = j;                                                      // same operands, exact maximum this time
-			d.cigar.clear(); d.w = f.bw1; d.end_bonus = -1; d.zdrop = code == 2 ? E.opt->zdrop_inv : E.opt->zdrop; d.flag = 0;
+			d.cigar.clear(); d.w = f.bw1; d.end_bonus = -1; d.zdrop = code == 2 ? E.opt->zdrop_inv : E.opt->zdrop; d.flag = j.flag & ~EZ_APPROX_MAX;      // (keeps the splice bits)
 			f.redo_job = (int)redo.size(); redo.push_back(std::move(d));
 		}
 	}
@@ -680,21 +724,34 @@ void align_skeleton(Scheduler &sch, const MapOpt &opt, const Index &idx, int qle
 		std::vector<std::list<Node>::iterator> todo;
 		for (auto it = L.begin(); it != L.end(); ++it) if (it->pending) todo.push_back(it);
 		if (todo.empty()) break;
-		std::vector<RegAln> A(todo.size());
+		// splice mode with both transcript strands allowed: every region is aligned twice, once per assumed strand, and the better
+		// scoring pass is kept (src/align.c:884-900); the two passes are independent and run in the same batches
+		const bool is_splice = (opt.flag & F_SPLICE) != 0, two_strands = is_splice && (opt.flag & F_SPLICE_FOR) && (opt.flag & F_SPLICE_REV);
+		std::vector<RegAln> A(todo.size()), B(two_strands ? todo.size() : 0);
 		std::vector<KswReq> jobs, redo;
-		std::vector<std::pair<int, int>> span(todo.size());
 		for (size_t k = 0; k < todo.size(); ++k) {
+			if (two_strands) { B[k].r = todo[k]->r; B[k].n_a = n_a; }
 			A[k].r = std::move(todo[k]->r); A[k].n_a = n_a;
-			span[k].first = (int)jobs.size();
 			// job indices inside RegAln are relative to the shared vector
-			plan_reg(E, A[k], a, jobs);
-			span[k].second = (int)jobs.size();
+			plan_reg(E, A[k], a, jobs, two_strands ? (int64_t)F_SPLICE_FOR : opt.flag);
+			if (two_strands) plan_reg(E, B[k], a, jobs, F_SPLICE_REV);
 		}
 		sch.ksw(jobs);
-		for (size_t k = 0; k < todo.size(); ++k) judge_reg(E, A[k], jobs, redo);
+		for (size_t k = 0; k < todo.size(); ++k) { judge_reg(E, A[k], jobs, redo); if (two_strands) judge_reg(E, B[k], jobs, redo); }
 		sch.ksw(redo);
 		for (size_t k = 0; k < todo.size(); ++k) {
 			finish_reg(E, A[k], a, jobs, redo);
+			if (two_strands) {
+				finish_reg(E, B[k], a, jobs, redo);
+				// (the reference reads p->dp_score of both passes unconditionally; a pass without any CIGAR counts as 0 here)
+				const int s0 = A[k].r.has_p ? A[k].r.dp_score : 0, s1 = B[k].r.has_p ? B[k].r.dp_score : 0;
+				int which, trans_strand;
+				if (s0 > s1) which = 0, trans_strand = 1;
+				else if (s0 < s1) which = 1, trans_strand = 2;
+				else trans_strand = 3, which = (qlen + s0) & 1;
+				if (which == 1) std::swap(A[k], B[k]);
+				if (A[k].r.has_p) A[k].r.trans_strand = trans_strand;
+			} else if (is_splice && A[k].r.has_p) A[k].r.trans_strand = (opt.flag & F_SPLICE_FOR) ? 1 : 2;
 			auto it = todo[k];
 			it->r = std::move(A[k].r); it->pending = false;
 			auto after = std::next(it);

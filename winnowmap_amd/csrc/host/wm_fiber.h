@@ -80,6 +80,7 @@ struct Hub {
 	wm_ksw_score_t sc;
 	int w, k;
 	int max_inflight;                       // batched device calls that may run concurrently (device contexts of the ops object)
+	bool splice = false; int noncan = 0, junc_bonus = 0;     // MM_F_SPLICE: alignments go through DeviceOps::exts2_batch with these (src/align.c:326-327)
 	int64_t max_sw_mat = 0;                 // mm_mapopt_t::max_sw_mat (--cap-sw-mat): pairs with more DP cells are not aligned (src/align.c:323-325)
 	std::mutex mu;
 	std::condition_variable cv;
@@ -269,7 +270,7 @@ public:
 				continue;
 			}
 			const long un = ksw_units(r);
-			const int op = xu > 0 && un > xu ? OP_KSW_HUGE : hu > 0 && un > hu ? OP_KSW_HEAVY : OP_KSW;
+			const int op = hub_->splice ? OP_KSW : xu > 0 && un > xu ? OP_KSW_HUGE : hu > 0 && un > hu ? OP_KSW_HEAVY : OP_KSW;   // (splice mode: one queue, exts2 has no band to classify by)
 			(op == OP_KSW_HUGE ? l_kswx_ : op == OP_KSW_HEAVY ? l_kswh_ : l_ksw_).push_back(&r);
 			ops |= 1 << op;
 		}
@@ -379,6 +380,7 @@ private:
 			else if (op == OP_SEED) H.ops->seed_batch(b);
 			else if (op == OP_CHAIN) H.ops->chain_batch(c);
 			else if (op == OP_WINDOW) H.ops->window_batch(H.w, H.k, wq);
+			else if (H.splice) H.ops->exts2_batch(H.sc, H.noncan, H.junc_bonus, d);
 			else H.ops->ksw_batch(H.sc, d);
 		} catch (const std::exception &e) {          // the waiters below are released in any case (their requests keep their zero-initialised results)
 			note_internal_error(e.what(), __FILE__, __LINE__);

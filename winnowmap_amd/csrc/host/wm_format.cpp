@@ -27,6 +27,7 @@ static void write_tags(std::string &s, const Reg &r)
 		s += "\tms:i:"; put_int(s, r.dp_max);
 		s += "\tAS:i:"; put_int(s, r.dp_score);
 		s += "\tnn:i:"; put_int(s, r.n_ambi);
+		if (r.trans_strand == 1 || r.trans_strand == 2) { s += "\tts:A:"; s += "?+-?"[r.trans_strand]; }
 	}
 	s += "\ttp:A:"; s += type;
 	s += "\tcm:i:"; put_int(s, r.cnt);

@@ -444,4 +444,24 @@ int index_build_from_fasta(const IdxOpt &io, const std::string &fasta, const std
 	return index_build(io, names, seqs, kmer_file, n_threads, out, err);
 }
 
+int32_t Index::cal_max_occ(float f) const
+{
+	if (f <= 0.) return INT32_MAX;
+	std::vector<uint32_t> occ;
+	occ.reserve(n_keys);
+	for (size_t i = 0; i < hkey.size(); ++i) if (hkey[i] != UINT64_MAX) occ.push_back((uint32_t)hval[i]);   // (count of the key; 1 for singletons)
+	if (occ.empty()) return 1;                                         // (the reference reads a[0] of an empty array here)
+	size_t kth = (size_t)(uint32_t)((1. - f) * occ.size());
+	if (kth >= occ.size()) kth = occ.size() - 1;
+	std::nth_element(occ.begin(), occ.begin() + kth, occ.end());
+	return (int32_t)(occ[kth] + 1);
+}
+
+void mapopt_update(MapOpt &opt, const Index &ix)
+{
+	if ((opt.flag & F_SPLICE_FOR) || (opt.flag & F_SPLICE_REV)) opt.flag |= F_SPLICE;
+	if (opt.mid_occ_frac >= 0 && opt.mid_occ_frac < 1) opt.mid_occ = ix.cal_max_occ(opt.mid_occ_frac);
+	if (opt.mid_occ < opt.min_mid_occ) opt.mid_occ = opt.min_mid_occ;
+}
+
 } // namespace wm

@@ -44,6 +44,7 @@ struct Index {
 	std::vector<std::pair<uint64_t, uint64_t>> n_runs;
 	void scan_n_runs();
 	bool has_n(uint32_t rid, uint32_t st, uint32_t en) const;
+	int32_t cal_max_occ(float f) const;                            // mm_idx_cal_max_occ, src/index.c:173-194
 	static uint64_t slot_of(uint64_t key, int hbits) { return (key * 0x9E3779B97F4A7C15ULL) >> (64 - hbits); }
 };
 
@@ -52,6 +53,11 @@ struct Index {
 int index_build(const IdxOpt &io, const std::vector<std::string> &names, const std::vector<std::string> &seqs,
                 const std::string &kmer_file, int n_threads, Index &out, std::string &err);
 int index_build_from_fasta(const IdxOpt &io, const std::string &fasta, const std::string &kmer_file, int n_threads, Index &out, std::string &err);
+
+// mm_mapopt_update (src/options.c:71-82): the options that depend on the index (-f as a fraction → mid_occ, the --min-occ-floor clamp)
+// and the implied MM_F_SPLICE bit
+struct MapOpt;
+void mapopt_update(MapOpt &opt, const Index &ix);
 
 void index_table_from_minimizers(Index &ix, std::vector<m128> &all);
 // the two halves of index_build around the sketching of the contigs (so that a device can do that part): bloom filter from the -W list +

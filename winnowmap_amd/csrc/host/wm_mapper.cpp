@@ -236,6 +236,7 @@ void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::v
 	Hub hub(ops, sc, idx.w, idx.k);
 	hub.n_workers = T;
 	hub.max_sw_mat = opt.max_sw_mat;
+	hub.splice = (opt.flag & F_SPLICE) != 0; hub.noncan = opt.noncan; hub.junc_bonus = opt.junc_bonus;
 	std::vector<std::unique_ptr<Scheduler>> sch(T);
 	for (int t = 0; t < T; ++t) sch[t].reset(new Scheduler(&hub, t));
 	// worker t owns reads t, t+T, ...: it admits `window` of them and one more whenever one finishes

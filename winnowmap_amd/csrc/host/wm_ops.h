@@ -86,6 +86,9 @@ struct DeviceOps {
 	virtual void seed_batch(std::vector<SeedReq*> &reqs) = 0;
 	virtual void chain_batch(std::vector<ChainReq*> &reqs) = 0;
 	virtual void ksw_batch(const wm_ksw_score_t &sc, std::vector<KswReq*> &reqs) = 0;
+	// splice mode: the same requests through ksw_exts2_sse (src/align.c:326-327) — no band, no end bonus, sc.q2 = the price of an intron;
+	// KswReq::flag carries the KSW_EZ_SPLICE_* bits. No junction annotation (mm_idx_bed_junc: the BED reader is outside the path).
+	virtual void exts2_batch(const wm_ksw_score_t &sc, int noncan, int junc_bonus, std::vector<KswReq*> &reqs) = 0;
 	// the whole window in one call. The default composes it from the three operations above (checker-backed implementations in the
 	// test-suite); the product's GpuOps overrides it with the HBM-resident wm_window_batch.
 	virtual void window_batch(int w, int k, std::vector<WindowReq*> &reqs);

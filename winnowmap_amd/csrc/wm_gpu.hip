@@ -2249,6 +2249,42 @@ struct GpuOpsCtx {
 		});
 		t_pack += t1 - t0; t_unpack += now_ms() - t2; t_prep += c->t_prep; t_run += c->t_run; t_fetch += c->t_fetch;
 	}
+	// splice mode (src/align.c:326-327): the requests through wm_ksw_exts2_batch, in groups whose unbanded traceback matrices fit the arena
+	void exts2_batch(const wm_ksw_score_t &sc, int noncan, int junc_bonus, std::vector<wm::KswReq*> &reqs)
+	{
+		const size_t budget = (size_t)(c->arena_bytes * 0.6);
+		const int n = (int)reqs.size();
+		for (int i0 = 0; i0 < n;) {
+			size_t need = 0, tot = 0, cap = 16;
+			int i1 = i0;
+			for (; i1 < n; ++i1) {
+				const wm::KswReq &r = *reqs[i1];
+				const size_t n_col = (size_t)((((r.ql < r.tl ? r.ql : r.tl) + 15) / 16 + 1) * 16);
+				const size_t b = ((size_t)r.ql + r.tl) * (n_col + 10) + 16 * (size_t)r.tl + 1024;      // traceback + CIGAR slots + operands + row state
+				if (i1 > i0 && (need + b > budget || tot + r.ql + r.tl >= ((size_t)1 << 31))) break;
+				need += b; tot += (size_t)r.ql + r.tl; cap += (size_t)r.ql + r.tl + 2;
+			}
+			const int m = i1 - i0;
+			std::vector<wm_ksw_job_t> jobs(m);
+			std::vector<wm_ksw_result_t> res(m);
+			std::vector<uint8_t> seqs(tot + 1);
+			std::vector<uint32_t> pool(cap);
+			size_t off = 0, used = 0;
+			for (int i = 0; i < m; ++i) {
+				wm::KswReq &r = *reqs[i0 + i];
+				jobs[i].q_off = (uint32_t)off; off += (size_t)r.ql;
+				jobs[i].t_off = (uint32_t)off; off += (size_t)r.tl;
+				jobs[i].qlen = r.ql; jobs[i].tlen = r.tl; jobs[i].w = -1; jobs[i].zdrop = r.zdrop; jobs[i].end_bonus = 0; jobs[i].flag = r.flag;
+			}
+			wm::parallel_for(c->host_threads, (size_t)m, [&](size_t i) { reqs[i0 + i]->copy_query(seqs.data() + jobs[i].q_off); reqs[i0 + i]->copy_target(seqs.data() + jobs[i].t_off); });
+			if (wm_ksw_exts2_batch(c, &sc, noncan, junc_bonus, m, jobs.data(), seqs.data(), tot, 0, res.data(), pool.data(), cap, &used)) { fail("ksw_exts2"); return; }
+			for (int i = 0; i < m; ++i) {
+				reqs[i0 + i]->ez = res[i];
+				reqs[i0 + i]->cigar.assign(pool.begin() + res[i].cig_off, pool.begin() + res[i].cig_off + res[i].n_cigar);
+			}
+			i0 = i1;
+		}
+	}
 };
 
 // The product's DeviceOps: a pool of device contexts. Every batched call borrows a free context (its own HIP stream, arena and pinned
@@ -2319,6 +2355,7 @@ struct GpuOps : wm::DeviceOps {
 	void seed_batch(std::vector<wm::SeedReq*> &reqs) override { with([&](GpuOpsCtx &x) { run_split(x, reqs, [&](std::vector<wm::SeedReq*> &part) { x.seed_batch(part); }); }); }
 	void chain_batch(std::vector<wm::ChainReq*> &reqs) override { with([&](GpuOpsCtx &x) { run_split(x, reqs, [&](std::vector<wm::ChainReq*> &part) { x.chain_batch(part); }); }); }
 	void ksw_batch(const wm_ksw_score_t &sc, std::vector<wm::KswReq*> &reqs) override { with([&](GpuOpsCtx &x) { x.ksw_batch(sc, reqs); }); }
+	void exts2_batch(const wm_ksw_score_t &sc, int noncan, int junc_bonus, std::vector<wm::KswReq*> &reqs) override { with([&](GpuOpsCtx &x) { x.exts2_batch(sc, noncan, junc_bonus, reqs); }); }
 	// collect_seed_hits takes one (max_occ, flag) per call: the mapper's requests of one mapping call all share them
 	void window_batch(int, int, std::vector<wm::WindowReq*> &reqs) override { with([&](GpuOpsCtx &x) { run_split(x, reqs, [&](std::vector<wm::WindowReq*> &part) { x.window_batch(part); }); }); }
 };
@@ -2349,6 +2386,7 @@ extern "C" int wm_mapper_create(wm_ctx_t *c, const wm_index_t *idx, const char *
 	if (preset && preset[0] && wm::set_preset(preset, m->io, m->mo) < 0) { delete m; return set_err(WM_EINVAL, "unknown preset '%s'", preset); }
 	m->mo.flag |= flag;
 	m->io.k = idx->ix.k; m->io.w = idx->ix.w;
+	wm::mapopt_update(m->mo, idx->ix);
 	std::string err;
 	if (wm::check_opt(m->io, m->mo, err) < 0) { delete m; return set_err(WM_EINVAL, "%s", err.c_str()); }
 	memset(m->stats, 0, sizeof(m->stats));
@@ -2360,7 +2398,7 @@ extern "C" int wm_mapper_create(wm_ctx_t *c, const wm_index_t *idx, const char *
 	X(min_qcov) X(minPrefixLength) X(maxPrefixLength) X(prefixIncrementFactor) X(stage2_bw) X(stage2_zdrop_inv) X(stage2_max_gap) X(mask_level) \
 	X(mask_len) X(pri_ratio) X(best_n) X(max_join_long) X(max_join_short) X(min_join_flank_sc) X(min_join_flank_ratio) X(alt_drop) X(a) X(b) X(q) X(e) \
 	X(q2) X(e2) X(sc_ambi) X(zdrop) X(zdrop_inv) X(end_bonus) X(min_dp_max) X(min_ksw_len) X(max_clip_ratio) X(mid_occ_frac) X(min_mid_occ) X(mid_occ) \
-	X(max_occ) X(mini_batch_size) X(max_sw_mat)
+	X(max_occ) X(mini_batch_size) X(max_sw_mat) X(noncan) X(junc_bonus) X(anchor_ext_len) X(anchor_ext_shift)
 static void mapopt_to_c(const wm::MapOpt &o, wm_mapopt_t *c)
 {
 	memset(c, 0, sizeof(*c));
@@ -2396,6 +2434,7 @@ extern "C" int wm_mapper_create_opt(wm_ctx_t *c, const wm_index_t *idx, const wm
 	wm::set_preset(0, m->io, m->mo);
 	mapopt_from_c(opt, m->mo);
 	m->io.k = idx->ix.k; m->io.w = idx->ix.w;
+	wm::mapopt_update(m->mo, idx->ix);
 	std::string err;
 	if (wm::check_opt(m->io, m->mo, err) < 0) { delete m; return set_err(WM_EINVAL, "%s", err.c_str()); }
 	memset(m->stats, 0, sizeof(m->stats));
@@ -2539,7 +2578,7 @@ static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double
 		uint32_t *co = R.cigars.data() + coff[i];
 		for (const wm::Reg &r : out[i].regs) {
 			const int32_t o[16] = { r.rid, r.rs, r.re, r.qs, r.qe, (int32_t)r.rev, (int32_t)r.mapq, r.has_p ? (int32_t)r.cigar.size() : 0, r.score, r.cnt, r.mlen, r.blen,
-			                        r.dp_score, r.dp_max, r.dp_max2, (int32_t)((r.parent == r.id) | r.inv << 1 | r.sam_pri << 2 | r.split << 3) };
+			                        r.dp_score, r.dp_max, r.dp_max2, (int32_t)((r.parent == r.id) | r.inv << 1 | r.sam_pri << 2 | r.split << 3 | (r.has_p ? r.trans_strand << 5 : 0)) };
 			memcpy(ho, o, sizeof(o)); ho += 16;
 			if (!r.cigar.empty()) { memcpy(co, r.cigar.data(), r.cigar.size() * 4); co += r.cigar.size(); }
 		}
