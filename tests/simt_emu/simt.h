@@ -190,6 +190,7 @@ template <class T, class I> void gst(T *p, const V<I> &idx, const V<T> &v) { for
 template <class T, class I> void gst(T *p, const V<I> &idx, T v) { for (int i = 0; i < WAVE; ++i) if (on(i)) p[idx.v[i]] = v; }
 template <class T> void gst(T *p, long long idx, T v) { if (exec_mask()) p[idx] = v; }
 
+inline void loads_land() {}
 inline void mem_sync() {}
 inline void mem_sync_agent() {}
 template <class I> V<int> cld8(signed char *p, const V<I> &idx) { V<int> r(0); for (int i = 0; i < WAVE; ++i) if (on(i)) r.v[i] = p[idx.v[i]]; return r; }

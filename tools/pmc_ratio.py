@@ -27,6 +27,16 @@ def key(kernel_name):        # "void ksw_dp_kernel<16, true, false>(...)" -> "ks
     return m.group(1) if m else None              # (spelled like bench.py's class names, spaces included)
 
 
+# the --pmc passes serialise the dispatches: their durations are each kernel's time ALONE on the chip (no sharing with concurrent kernels)
+try:
+    db = sqlite3.connect(glob.glob(os.path.join(src, "pmc1", "*.db"))[0])
+    rows = list(db.execute("select name, total_calls, total_duration, average from top_kernels"))
+    tot = sum(r[2] for r in rows) or 1.0
+    print("kernel durations with serialised dispatches (pmc1 pass): name, calls, total ms, avg us, share")
+    for nm, calls, total, avg in rows[:24]:
+        print("  %-60s %6d %10.1f %10.1f %5.1f %%" % (nm[:60], calls, total / 1e3, avg, 100.0 * total / tot))
+except Exception as e:
+    print("no dispatch table:", e)
 fetch, write = counters("pmc1", "FETCH_SIZE"), counters("pmc2", "WRITE_SIZE")
 c1, c2 = classes("pmc1.log"), classes("pmc2.log")
 out = {}

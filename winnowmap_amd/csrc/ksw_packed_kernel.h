@@ -227,6 +227,7 @@ WM_DEV void ksw_dp_packed(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 					const V<int> qidx = ln + qb0;
 					QB = 0;
 					WM_IF(qidx < qlen) QB = cast<int>(gld(query, qidx)); WM_END
+					loads_land();               // (here, once per 48+ rows — not at the join below, where the wait would also drain every row's traceback stores)
 				}
 				newc = readlane(QB, qi0 - qb0);
 			}
@@ -343,6 +344,9 @@ WM_DEV void ksw_dp_packed(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 			} else {                           // (unclipped band: lanes beyond the hull never matter — see the header)
 				U[i] = nu; Vv[i] = nv; X[i] = nx; Y[i] = ny; X2[i] = nx2; Y2[i] = ny2;
 			}
+#ifdef WM_KSW_NOSTORE           // timing experiment only (tools/ksw_probe.py): the traceback bytes are computed but never stored — results are WRONG
+			if (!(flag & 0x40000000)) { WM_KEEP_BRANCH(); } else
+#endif
 			if (top) {
 				WM_IF(t_lo <= en) gst(trow, ln + 128 * i, cast<uint8_t>(p)); WM_END
 				WM_IF(t_hi <= en) gst(trow, ln + (128 * i + 64), cast<uint8_t>(lshr(p, 16))); WM_END

@@ -135,6 +135,13 @@ template <class T> WM_DEV void gst(T *p, long long i, T v) { p[i] = v; }
 
 // "coherent" scratch accessors: data written by one lane and read by another lane of the SAME wave through global
 // memory must not be served from a stale L1 line, so these go to L2 (relaxed agent-scope atomics = sc1 accesses).
+// loads_land(): s_waitcnt vmcnt(0) — every outstanding vector load of this wave has returned. Placed INSIDE the uniform branch that issues a
+// rare load: the compiler otherwise waits at the join of the branch, i.e. on every trip of the surrounding loop, and on gfx9 that wait also
+// drains the loop's outstanding STORES (one counter for both) — one store round trip per DP row (ksw_packed_kernel.h).
+#ifndef WM_LOADS_LAND
+#define WM_LOADS_LAND 1       // 0: the round-2 code (wait at the join) for A/B runs
+#endif
+WM_DEV void loads_land() { if (WM_LOADS_LAND) __builtin_amdgcn_s_waitcnt(0x0f70); }       // (simm16: vmcnt = 0, expcnt = 7, lgkmcnt = 15 = "do not wait")
 WM_DEV void mem_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 // agent-scope release + acquire: one lane's plain global stores become visible to the plain loads of every other lane of the wave (no stale L1 line)
 WM_DEV void mem_sync_agent() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
