@@ -384,9 +384,9 @@ int h_map_file(void *hv, const char *preset, int64_t flag_extra, const char *rea
 	if (!out) return -2;
 	std::string err;
 	FileStats fs;
-	const int rc = map_file(reads_path, mini_batch_bases, (mo.flag & 0x8) != 0, [&](std::vector<ReadIn> &batch, std::string &text) {
+	const int rc = map_file(reads_path, mini_batch_bases, (mo.flag & 0x8) != 0, [&](std::vector<ReadIn> &batch, std::string &text, int lane) {
 		std::vector<ReadOut> outv;
-		map_batch(h->idx, mo, &ops, batch, outv, 0, n_threads);
+		map_batch(h->idx, mo, &ops, batch, outv, 0, n_threads, 0, lane);
 		for (size_t i = 0; i < batch.size(); ++i) write_read(text, h->idx, batch[i], outv[i], mo.flag);
 		return 0;
 	}, out, &fs, err);

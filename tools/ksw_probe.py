@@ -12,7 +12,7 @@ NOSTORE = "WM_KSW_NOSTORE" in gpu.build_defines()      # timing-only variant: th
 
 def run(b):
     try:
-        run(b)
+        b.run()
     except gpu.WmError:
         if not NOSTORE:
             raise

@@ -7,6 +7,8 @@
 #include <chrono>
 #include <memory>
 #include <atomic>
+#include <map>
+#include <stdlib.h>
 
 namespace wm {
 
@@ -28,12 +30,18 @@ int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_
 	if (rd.open(reads_path, err) < 0) return -1;
 	if (mini_batch_bases <= 0) mini_batch_bases = 1000000000;               // src/options.c:50
 	typedef std::vector<ReadIn> Batch;
-	Slot<Batch> to_map;
-	Slot<std::string> to_write;
+	struct Item { uint64_t id; Batch reads; };
+	Slot<Item> to_map;
 	FileStats fs;
-	int rc = 0;
+	std::mutex fs_mu;
+	std::atomic<int> rc(0);
 	std::atomic<bool> stop(false), io_error(false);
+	// finished mini-batches wait here for their turn: the file lists them in input order
+	std::mutex omu; std::condition_variable ocv;
+	std::map<uint64_t, std::unique_ptr<std::string>> done;
+	uint64_t next_out = 0; int lanes_running = 0;
 	std::thread reader([&]() {
+		uint64_t id = 0;
 		for (;;) {
 			if (stop.load()) break;                                            // mapper or writer failed: stop parsing the input
 			const double t0 = now_s();
@@ -43,8 +51,9 @@ int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_
 			std::vector<std::pair<int, int>> key(b->size());
 			for (size_t i = 0; i < b->size(); ++i) key[i] = std::make_pair((int)(*b)[i].seq.size(), (int)i);
 			std::sort(key.begin(), key.end(), std::greater<std::pair<int, int>>());
-			std::unique_ptr<Batch> s(new Batch(b->size()));
-			for (size_t i = 0; i < key.size(); ++i) (*s)[i] = std::move((*b)[key[i].second]);
+			std::unique_ptr<Item> s(new Item());
+			s->id = id++; s->reads.resize(b->size());
+			for (size_t i = 0; i < key.size(); ++i) s->reads[i] = std::move((*b)[key[i].second]);
 			fs.t_read += now_s() - t0;
 			to_map.put(std::move(s));
 		}
@@ -52,8 +61,15 @@ int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_
 	});
 	std::thread writer([&]() {
 		for (;;) {
-			std::unique_ptr<std::string> t = to_write.take();
-			if (!t) break;
+			std::unique_ptr<std::string> t;
+			{
+				std::unique_lock<std::mutex> lk(omu);
+				ocv.wait(lk, [&] { return done.count(next_out) || (lanes_running == 0 && done.empty()) || (lanes_running == 0 && rc.load() != 0); });
+				auto it = done.find(next_out);
+				if (it == done.end()) break;
+				t = std::move(it->second); done.erase(it); ++next_out;
+				ocv.notify_all();
+			}
 			const double t0 = now_s();
 			// a full disk / closed pipe must not yield a silently truncated file (the reference aborts in mm_err_puts)
 			if (!io_error.load() && !t->empty() && fwrite(t->data(), 1, t->size(), out) != t->size()) { io_error = true; stop = true; }
@@ -61,25 +77,43 @@ int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_
 		}
 		if (fflush(out) != 0 || ferror(out)) io_error = true;
 	});
-	for (;;) {
-		std::unique_ptr<Batch> b = to_map.take();
-		if (!b) break;
-		const double t0 = now_s();
-		std::unique_ptr<std::string> text(new std::string());
-		if (rc == 0 && !io_error.load()) rc = map_fn(*b, *text);          // after an error: drain what the reader already queued
-		if (rc != 0) stop = true;
-		fs.t_map += now_s() - t0;
-		fs.n_batches += 1; fs.n_reads += b->size();
-		for (const ReadIn &r : *b) fs.n_bases += r.seq.size();
-		if (rc == 0) to_write.put(std::move(text));
-	}
-	to_write.close();
+	const char *le = getenv("WM_MAP_LANES");
+	const int n_lanes = le && atoi(le) == 1 ? 1 : 2;
+	{ std::lock_guard<std::mutex> lk(omu); lanes_running = n_lanes; }
+	auto lane_fn = [&](int lane) {
+		for (;;) {
+			std::unique_ptr<Item> b = to_map.take();
+			if (!b) break;
+			const double t0 = now_s();
+			std::unique_ptr<std::string> text(new std::string());
+			int r = 0;
+			if (rc.load() == 0 && !io_error.load()) r = map_fn(b->reads, *text, lane);       // after an error: drain what the reader already queued
+			if (r != 0) { int z = 0; rc.compare_exchange_strong(z, r); stop = true; std::lock_guard<std::mutex> lk(omu); ocv.notify_all(); }
+			uint64_t nb = 0;
+			for (const ReadIn &x : b->reads) nb += x.seq.size();
+			{ std::lock_guard<std::mutex> lk(fs_mu); fs.t_map += now_s() - t0; fs.n_batches += 1; fs.n_reads += b->reads.size(); fs.n_bases += nb; }
+			if (rc.load() == 0) {
+				std::unique_lock<std::mutex> lk(omu);
+				ocv.wait(lk, [&] { return b->id < next_out + 2 || rc.load() != 0; });          // (at most two finished texts wait for the writer)
+				done[b->id] = std::move(text);
+				ocv.notify_all();
+			}
+		}
+		std::lock_guard<std::mutex> lk(omu);
+		--lanes_running;
+		ocv.notify_all();
+	};
+	std::thread lane1;
+	if (n_lanes == 2) lane1 = std::thread(lane_fn, 1);
+	lane_fn(0);
+	if (lane1.joinable()) lane1.join();
 	reader.join();
 	writer.join();
 	if (st) *st = fs;
-	if (rc) err = "mapping failed";
-	else if (io_error.load()) { err = "write error on the output file"; rc = -2; }
-	return rc;
+	int ret = rc.load();
+	if (ret) err = "mapping failed";
+	else if (io_error.load()) { err = "write error on the output file"; ret = -2; }
+	return ret;
 }
 
 } // namespace wm

@@ -22,10 +22,12 @@ private:
 
 struct FileStats { uint64_t n_reads = 0, n_bases = 0, n_batches = 0; double t_read = 0, t_map = 0, t_write = 0; };
 
-// map_fn(batch, text): maps the reads of one mini-batch IN THE GIVEN ORDER and appends their records to text; returns 0 / error.
+// map_fn(batch, text, lane): maps the reads of one mini-batch IN THE GIVEN ORDER and appends their records to text; returns 0 / error.
 // Each mini-batch is ordered longest read first (ties: later read first) exactly like src/map.c:1124-1143, so the output
-// file equals the reference's.
-typedef std::function<int(std::vector<ReadIn> &batch, std::string &text)> MapFn;
+// file equals the reference's. Two mini-batches are mapped at a time (lane 0 and 1, two threads calling map_fn concurrently; WM_MAP_LANES=1:
+// one): a mapping call ramps up and drains its pipeline of dependent device calls over several hundred milliseconds, which the other lane's
+// steady state covers. Records are written in input order whatever lane finishes first.
+typedef std::function<int(std::vector<ReadIn> &batch, std::string &text, int lane)> MapFn;
 int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_qual, const MapFn &map_fn, FILE *out, FileStats *st, std::string &err);
 
 } // namespace wm

@@ -2623,9 +2623,9 @@ extern "C" int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *o
 	}
 	wm::FileStats fs;
 	const bool with_qual = (m->mo.flag & 0x8) != 0;                    // SAM output prints QUAL
-	const int rc = wm::map_file(reads_path, mini_batch_bases, with_qual, [&](std::vector<wm::ReadIn> &batch, std::string &text) {
-		const int r = map_reads_impl(m, batch, now_ms());
-		if (r == 0) text.swap(m->res[0].text);
+	const int rc = wm::map_file(reads_path, mini_batch_bases, with_qual, [&](std::vector<wm::ReadIn> &batch, std::string &text, int lane) {
+		const int r = map_reads_impl(m, batch, now_ms(), lane);             // (two mini-batches in flight: lane = result slot = slab of resident read codes)
+		if (r == 0) text.swap(m->res[lane].text);
 		return r;
 	}, out, &fs, err);
 	if (out != stdout) fclose(out);
