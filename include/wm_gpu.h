@@ -102,6 +102,12 @@ int wm_reads_upload(wm_ctx_t *ctx, const uint8_t *codes, size_t n);
 int wm_ksw_batch_pos(wm_ctx_t *ctx, const wm_ksw_score_t *sc, int n_jobs, const wm_ksw_pos_t *jobs,
                      wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used);
 
+/* ksw_ll_qinit + ksw_ll_i16 (src/ksw2.h:82-83, src/ksw2_ll_sse.c:32-147): local alignment SCORE of query vs target with affine gaps
+ * (16-bit striped lanes in the reference; ties and the striped layout's end coordinates are reproduced: *qe may be as low as -7 … see
+ * host/wm_align.cpp). m = 5, mat = 5x5. Runs on the HOST (the mapper needs it twice per inversion candidate / boundary exon only);
+ * exported so that the reference can be linked against it (oracle/wm_subst.cpp). Returns the score. */
+int wm_ksw_ll_i16(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat5x5, int gapo, int gape, int *qe, int *te);
+
 /* ksw_exts2_sse as a batch (replaces src/ksw2.h:63-64, called at src/align.c:326-327 when MM_F_SPLICE is set): the splice-aware
  * extension. sc->q / e = gap open / extension, sc->q2 = the price of an intron (no extension), sc->e2 unused; noncan = the penalty of a
  * non-canonical splice site, junc_bonus = the bonus of an annotated junction; flag = KSW_EZ_* incl. SPLICE_FOR 0x100, SPLICE_REV 0x200,

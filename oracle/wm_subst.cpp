@@ -4,8 +4,9 @@
 // ALL of its objects, in which the C symbols
 //     mm_sketch        src/mmpriv.h:61      ksw_extd2_sse    src/ksw2.h:60-61
 //     mm_chain_dp      src/mmpriv.h:73      ksw_extz2_sse    src/ksw2.h:54-55
-//                                           ksw_exts2_sse    src/ksw2.h:63-64
-// have been renamed to ref_<name> (objcopy --redefine-sym on copies of sketch.o / chain.o / ksw2_dispatch.o) and are DEFINED HERE with the
+//     mm_idx_get       src/mmpriv.h:71      ksw_exts2_sse    src/ksw2.h:63-64
+//                                           ksw_ll_qinit / ksw_ll_i16   src/ksw2.h:82-83
+// have been renamed to ref_<name> (objcopy --redefine-sym on copies of sketch.o / chain.o / index.o / ksw2_dispatch.o / ksw2_ll_sse.o) and are DEFINED HERE with the
 // exact signatures, ownership and kalloc conventions of the reference, each as a one-job call of the batched device operation behind it
 // (wm_sketch_batch, wm_chain_batch, wm_ksw_batch, wm_ksw_exts2_batch). So mm_map_frag, mm_align_skeleton, the index builder … all run unchanged on top of the
 // device kernels — slowly (one launch per call), which is the point of the batched entry points, but it proves the symbols are drop-ins.
@@ -14,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <mutex>
 #include <vector>
 #include "minimap.h"
@@ -34,6 +36,9 @@ void ref_ksw_extz2_sse(void *km, int qlen, const uint8_t *query, int tlen, const
                        int8_t q, int8_t e, int w, int zdrop, int end_bonus, int flag, ksw_extz_t *ez);
 void ref_ksw_exts2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                        int8_t q, int8_t e, int8_t q2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc, ksw_extz_t *ez);
+const uint64_t *ref_mm_idx_get(const mm_idx_t *mi, uint64_t minier, int *n);
+void *ref_ksw_ll_qinit(void *km, int size, int qlen, const uint8_t *query, int m, const int8_t *mat);
+int ref_ksw_ll_i16(void *q, int tlen, const uint8_t *target, int gapo, int gape, int *qe, int *te);
 }
 
 namespace {
@@ -175,3 +180,57 @@ extern "C" void ksw_exts2_sse(void *km, int qlen, const uint8_t *query, int tlen
 }
 
 __attribute__((destructor)) static void wm_subst_fini() { if (g_ctx) wm_ctx_destroy(g_ctx); }
+
+
+// ---- mm_idx_get (src/mmpriv.h:71, src/index.c:88-105): the library's flat table, built ONCE from the reference's finished index through the
+// reference's own file format (mm_idx_dump, src/index.c:515 → wm_index_load). The returned pointer aims into the library's position array
+// (same words as the reference's: rid<<32 | last position<<1 | strand), valid for the life of the process like the reference's.
+namespace {
+std::mutex g_idx_mu;
+const mm_idx_t *g_idx_of = 0;
+wm_index_t *g_idx = 0;
+const wm_index_t *flat_index(const mm_idx_t *mi)
+{
+	std::lock_guard<std::mutex> lk(g_idx_mu);
+	if (g_idx_of == mi) return g_idx;
+	if (g_idx) { wm_index_destroy(g_idx); g_idx = 0; }                 // (a multi-part index: the previous part is gone by now, src/main.c:398-425)
+	char tmpl[] = "/tmp/wm_subst_idx_XXXXXX";
+	const int fd = mkstemp(tmpl);
+	if (fd < 0) { fprintf(stderr, "[wm_subst] cannot create a temporary index file\n"); exit(1); }
+	FILE *fp = fdopen(fd, "wb");
+	mm_idx_dump(fp, mi);
+	fclose(fp);
+	const int rc = wm_index_load(tmpl, 0, &g_idx);
+	unlink(tmpl);
+	if (rc) die("mm_idx_get (wm_index_load)");
+	g_idx_of = mi;
+	return g_idx;
+}
+}
+
+extern "C" const uint64_t *mm_idx_get(const mm_idx_t *mi, uint64_t minier, int *n)
+{
+	if (off() || !mi->B) return ref_mm_idx_get(mi, minier, n);
+	return wm_index_get(flat_index(mi), minier, n);
+}
+
+// ---- ksw_ll_qinit / ksw_ll_i16 (src/ksw2.h:82-83): the query profile is opaque to its callers (src/align.c:78-79, 539-540, 824-825: create, one
+// ksw_ll_i16, kfree) — ours is ONE kalloc block holding the operands, and the score comes from the library's wm_ksw_ll_i16.
+namespace { struct LlProfile { int32_t magic, qlen, m, size; int8_t mat[25]; uint8_t query[1]; }; }
+
+extern "C" void *ksw_ll_qinit(void *km, int size, int qlen, const uint8_t *query, int m, const int8_t *mat)
+{
+	if (off() || m != 5 || size != 2) return ref_ksw_ll_qinit(km, size, qlen, query, m, mat);
+	LlProfile *p = (LlProfile*)kmalloc(km, sizeof(LlProfile) + (size_t)(qlen > 0 ? qlen : 0));
+	p->magic = 0x4c4c5157; p->qlen = qlen; p->m = m; p->size = size;
+	memcpy(p->mat, mat, 25);
+	if (qlen > 0) memcpy(p->query, query, (size_t)qlen);
+	return p;
+}
+
+extern "C" int ksw_ll_i16(void *q, int tlen, const uint8_t *target, int gapo, int gape, int *qe, int *te)
+{
+	const LlProfile *p = (const LlProfile*)q;
+	if (off() || p->magic != 0x4c4c5157) return ref_ksw_ll_i16(q, tlen, target, gapo, gape, qe, te);   // (a profile made by the original)
+	return wm_ksw_ll_i16(p->qlen, p->query, tlen, target, p->mat, gapo, gape, qe, te);
+}

@@ -3,7 +3,9 @@ include/wm_gpu.h declares, and fails loudly (no CPU fallback) when there is no G
 import ctypes as C
 import os
 import re
+import numpy as np
 import pytest
+import wmtest as W
 from winnowmap_amd import build, gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -93,3 +95,26 @@ def test_presets_equal_the_references_mm_set_opt():
         for (name, _), a, b_ in zip(list(MapOpt._fields_) + [("k", 0), ("w", 0)], ours, ref[:n]):
             assert a == np.float32(b_) or a == b_, (preset, name, a, b_)
     assert L.wm_mapopt_preset(b"no-such-preset", C.byref(MapOpt()), None, None) != 0
+
+
+@pytest.mark.skipif(not W.have_ref(), reason="oracle/_ref not built")
+def test_exported_ksw_ll_i16_equals_the_references():
+    """wm_ksw_ll_i16 (include/wm_gpu.h; host code, callable without a GPU) against ksw_ll_qinit + ksw_ll_i16 of the reference (src/ksw2.h:82-83):
+    score and both end coordinates, incl. the striped layout's negative query ends."""
+    build.build_gpu()
+    L = C.CDLL(gpu.LIB_PATH)
+    L.wm_ksw_ll_i16.restype = C.c_int
+    L.wm_ksw_ll_i16.argtypes = [C.c_int, W.u8p, C.c_int, W.u8p, W.i8p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    from winnowmap_amd import synth
+    rng = np.random.default_rng(12)
+    for it in range(300):
+        q = rng.integers(0, 5 if it % 7 == 0 else 4, int(rng.integers(1, 500))).astype(np.uint8)
+        t = rng.integers(0, 4, int(rng.integers(1, 500))).astype(np.uint8) if it % 2 == 0 else synth.mutate_codes(q, rng, 0.05, 0.05, 0.05)
+        if len(t) == 0:
+            t = q
+        a, b = (1, 4) if it % 3 else (2, 4)
+        mat = W.simple_mat(a, b, 1)
+        go, ge = (4, 2) if it % 3 else (6, 1)
+        qe, te = C.c_int(), C.c_int()
+        s = L.wm_ksw_ll_i16(len(q), q, len(t), t, mat, go, ge, C.byref(qe), C.byref(te))
+        assert (s, qe.value, te.value) == W.r_ksw_ll(q, t, mat, go, ge), it

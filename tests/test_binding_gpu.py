@@ -131,7 +131,7 @@ SUBST_BIN = os.path.join(ROOT, "oracle", "_ref", "winnowmap_subst")
 @need_ref
 @pytest.mark.skipif(not os.path.exists(SUBST_BIN), reason="oracle/_ref/winnowmap_subst not built")
 def test_link_level_substitutes_of_the_hot_functions():
-    """mm_sketch, mm_chain_dp, ksw_extd2_sse and ksw_extz2_sse with the reference's exact signatures, defined by oracle/wm_subst.cpp
+    """mm_sketch, mm_idx_get, mm_chain_dp, ksw_extd2_sse, ksw_extz2_sse and ksw_ll_qinit / ksw_ll_i16 with the reference's exact signatures, defined by oracle/wm_subst.cpp
     over the batched device operations and LINKED INTO THE REFERENCE in place of its own (oracle/_ref/winnowmap_subst; the originals are renamed
     ref_*): the reference's index build, mm_map_frag and mm_align_skeleton then run unchanged on the device kernels, one launch per call. The
     output must be the reference's. Small input: scalar calls are what the batched entry points exist to avoid."""
@@ -143,13 +143,18 @@ def test_link_level_substitutes_of_the_hot_functions():
     kf = os.path.join(tmp, "rep.txt")
     synth.write_kmer_list(kf, km, cnt, 15)
     reads = synth.make_reads(ref, 3, 11000, 42, profile="ont", sv_frac=0.3)[0] + synth.make_reads(ref, 5, 3000, 43, profile="ont")[0]
+    rng = np.random.default_rng(44)
+    for g in range(2):                                                       # an inversion in the middle: the z-drop test's ksw_ll_i16 (src/align.c:72-86) and mm_align1_inv
+        src = ref[g][50000 + 20000 * g:50000 + 20000 * g + 12000].copy()
+        src[5000:5600] = synth.revcomp_codes(src[5000:5600])
+        reads.append(synth.mutate_codes(src, rng, 0.02, 0.01, 0.01))
     rq = os.path.join(tmp, "reads.fa")
     _write_reads(rq, reads)
     args = ["-t", "2", "-W", kf, "-cx", "map-ont", fa, rq]
     want = _run(REF_BIN, args)
     got = _run(SUBST_BIN, args)
     d = parity.diff_texts(want, got, sam=False)
-    assert d["reads"] == 8 and d["hits"] >= 8 and d["mismatches"] == 0, d
+    assert d["reads"] == 10 and d["hits"] >= 10 and d["mismatches"] == 0, d
     assert parity.diff_texts(want, _run(SUBST_BIN, args, env={"WM_SUBST": "off"}), sam=False)["mismatches"] == 0
 
 

@@ -34,7 +34,9 @@ def simple_mat(a=2, b=4, sc_ambi=1):
 
 def build_oracle():
     if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(ORACLE_DIR, "wm_oracle.c")):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
+        from winnowmap_amd import build
+        with build._Lock(ORACLE_SO):          # (pytest-xdist workers: one make at a time)
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
 
 
 class EZ(C.Structure):

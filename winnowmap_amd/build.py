@@ -10,6 +10,34 @@ LIB = os.path.join(HERE, "libwmgpu.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
+class _Lock:
+    """one build of a given artefact at a time, across processes (pytest-xdist workers ask for the same libraries at once)"""
+
+    def __init__(self, target):
+        self.path = target + ".lock"
+
+    def __enter__(self):
+        import fcntl
+        self.f = open(self.path, "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+
+    def __exit__(self, *a):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+
+
+def _run_to(target, cmd_for):
+    """run cmd_for(tmp) and move tmp over `target` only when it succeeded: nobody ever loads a half-written library"""
+    tmp = target + ".tmp%d" % os.getpid()
+    try:
+        subprocess.check_call(cmd_for(tmp))
+        os.replace(tmp, target)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+
+
 def _newer(target, sources):
     if not os.path.exists(target):
         return True
@@ -39,26 +67,28 @@ def build_gpu(force=False, verbose=False, out=None):
     # library was built with are part of its staleness check (sidecar stamp) and are compiled into it (wm_build_defines(), recorded by bench.py)
     defines = " ".join(os.environ.get("WM_KERNEL_DEFINES", "").split())
     stamp = LIB + ".defines"
-    have = open(stamp).read() if os.path.exists(stamp) else ""
-    if not force and not _newer(LIB, srcs) and have == defines:
-        return LIB
-    defs = ["-D" + d for d in defines.split()] + ['-DWM_BUILD_DEFINES="%s"' % defines]
-    cmd = [HIPCC] + HIP_FLAGS + defs + ["-shared", "-fPIC", "-o", LIB, os.path.join(CSRC, "wm_gpu.hip"), "-lz", "-lpthread"]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
-    with open(stamp, "w") as f:
-        f.write(defines)
+    with _Lock(LIB):
+        have = open(stamp).read() if os.path.exists(stamp) else ""
+        if not force and not _newer(LIB, srcs) and have == defines:
+            return LIB
+        defs = ["-D" + d for d in defines.split()] + ['-DWM_BUILD_DEFINES="%s"' % defines]
+        cmd = lambda out_: [HIPCC] + HIP_FLAGS + defs + ["-shared", "-fPIC", "-o", out_, os.path.join(CSRC, "wm_gpu.hip"), "-lz", "-lpthread"]  # noqa: E731
+        if verbose:
+            print(" ".join(cmd(LIB)), file=sys.stderr)
+        _run_to(LIB, cmd)
+        with open(stamp, "w") as f:
+            f.write(defines)
     return LIB
 
 
 def build_oracle():
     """oracle/libwm_oracle.so always; oracle/_ref only where /root/reference exists (the build container)."""
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], stdout=subprocess.DEVNULL)
-    if os.path.exists("/root/reference/src/map.c"):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref", "-j8"], stdout=subprocess.DEVNULL)
-        if os.path.exists(LIB):      # the reference's CLI bound to / substituted by libwmgpu.so (oracle/wm_binding.cpp, oracle/wm_subst.cpp)
-            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "wm", "subst", "-j8"], stdout=subprocess.DEVNULL)
+    with _Lock(os.path.join(ROOT, "oracle", "libwm_oracle.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], stdout=subprocess.DEVNULL)
+        if os.path.exists("/root/reference/src/map.c"):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref", "-j8"], stdout=subprocess.DEVNULL)
+            if os.path.exists(LIB):      # the reference's CLI bound to / substituted by libwmgpu.so (oracle/wm_binding.cpp, oracle/wm_subst.cpp)
+                subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "wm", "subst", "-j8"], stdout=subprocess.DEVNULL)
 
 
 def build_emu(defines=()):
@@ -68,9 +98,10 @@ def build_emu(defines=()):
     tag = "".join("_" + "".join(ch if ch.isalnum() else "_" for ch in d) for d in defines)
     out = os.path.join(emu, "libwm_emu%s.so" % tag)
     srcs = [os.path.join(emu, f) for f in ("emu_driver.cpp", "simt.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    if _newer(out, srcs):
-        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas"] +
-                              ["-D" + d for d in defines] + ["-I" + emu, "-I" + CSRC, "-o", out, os.path.join(emu, "emu_driver.cpp")])
+    with _Lock(out):
+        if _newer(out, srcs):
+            _run_to(out, lambda o: ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas"] +
+                    ["-D" + d for d in defines] + ["-I" + emu, "-I" + CSRC, "-o", o, os.path.join(emu, "emu_driver.cpp")])
     return out
 
 
@@ -80,9 +111,10 @@ def build_harness():
     out = os.path.join(hd, "libwm_harness.so")
     srcs = [os.path.join(hd, "harness.cpp"), os.path.join(ROOT, "oracle", "wm_oracle.c")] + \
            [os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host"))]
-    if _newer(out, srcs):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-o", out,
-                               os.path.join(hd, "harness.cpp"), os.path.join(ROOT, "oracle", "wm_oracle.c"), "-lz", "-pthread"])
+    with _Lock(out):
+        if _newer(out, srcs):
+            _run_to(out, lambda o: ["g++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-o", o,
+                                    os.path.join(hd, "harness.cpp"), os.path.join(ROOT, "oracle", "wm_oracle.c"), "-lz", "-pthread"])
     return out
 
 

@@ -2634,6 +2634,15 @@ extern "C" int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *o
 	return WM_OK;
 }
 
+extern "C" int wm_ksw_ll_i16(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat5x5, int gapo, int gape, int *qe, int *te)
+{
+	int q = -1, t = -1;
+	const int sc = wm::ll_i16(qlen, query, tlen, target, mat5x5, gapo, gape, &q, &t);
+	if (qe) *qe = q;
+	if (te) *te = t;
+	return sc;
+}
+
 extern "C" int wm_mapper_stats(const wm_mapper_t *m, uint64_t *out9) { memcpy(out9, m->stats, sizeof(m->stats)); return WM_OK; }
 // per ksw kernel class (ksw_plan.h) since the mapper was created: out[3*k] = summed launch durations in ms (HIP events on the
 // launching stream), out[3*k+1] = DP cells, out[3*k+2] = launches; n_classes receives WM_KSW_NCLASS
