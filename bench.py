@@ -240,8 +240,8 @@ def make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)       # (an even number: two mini-batches are in flight, an odd step count ends with one lane alone)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=int(os.environ.get("WM_BENCH_CONFIG", 2)), choices=sorted(CONFIGS))
     ap.add_argument("--reads-per-step", type=int, default=int(os.environ.get("WM_BENCH_READS", 0)))
     ap.add_argument("--ref-mb", type=float, default=float(os.environ.get("WM_BENCH_REF_MB", 250)))
@@ -334,14 +334,21 @@ def main():
     n_slots = 2 if int(os.environ.get("WM_BENCH_PIPELINE", 1)) else 1
 
     def run_steps(step_batches):
-        """maps the given mini-batches, step i on slot i % n_slots; returns (hits, bases)"""
+        """maps the given mini-batches on n_slots lanes (each lane takes the next unmapped step, like wm_map_file's lanes); returns (hits, bases)"""
         tot = [0] * n_slots
         err = []
+        nxt = [0]
+        lock = threading.Lock()
 
         def worker(s):
             try:
-                for b in step_batches[s::n_slots]:
-                    _, h, _, _ = mapper.map(b, copy_text=False, slot=s)        # the records stay in the library's buffer (no Python copy)
+                while True:
+                    with lock:
+                        i = nxt[0]
+                        nxt[0] += 1
+                    if i >= len(step_batches):
+                        break
+                    _, h, _, _ = mapper.map(step_batches[i], copy_text=False, slot=s)        # the records stay in the library's buffer (no Python copy)
                     tot[s] += len(h)
             except Exception as e:  # noqa: BLE001
                 err.append(e)
