@@ -155,6 +155,12 @@ void wm_index_destroy(wm_index_t *idx);
 int wm_index_save(const wm_index_t *idx, const char *path);
 int wm_index_load(const char *path, const char *kmer_file, wm_index_t **out);
 int wm_index_upload(wm_ctx_t *ctx, const wm_index_t *idx);
+/* mm_idx_bed_read(mi, fn, 1) (src/index.c:756-766, `--junc-bed`, src/main.c:416): annotated introns (the gaps between the blocks of BED12
+ * records; plain BED intervals otherwise) for splice mode's junction bonus. wm_index_add_junc hands over intervals a front end has already
+ * parsed (the bound CLI: the reference's mi->I). The annotation stays on the host: the mapper attaches the bits of mm_idx_bed_junc to each
+ * alignment request (wm_ksw_exts2_batch's `junc`). */
+int wm_index_read_junc_bed(wm_index_t *idx, const char *path);
+int wm_index_add_junc(wm_index_t *idx, int ctg, int n, const int32_t *st, const int32_t *en, const int32_t *strand);
 int wm_index_n_seq(const wm_index_t *idx);
 const char *wm_index_seq_name(const wm_index_t *idx, int rid);
 int wm_index_seq_len(const wm_index_t *idx, int rid);

@@ -30,6 +30,26 @@ void *refshim_idx_build(const char *fasta, const char *kmer_file, int k, int w, 
 	return mi;
 }
 void refshim_idx_destroy(void *mi) { mm_idx_destroy((mm_idx_t*)mi); }
+// --junc-bed (src/main.c:416). NB: in this reference mm_idx_read_bed CRASHES on any input ("realloc(): invalid pointer" / SIGSEGV in the CLI):
+// src/index.c sees kstring_t = { unsigned l, m; char *s } (src/mmpriv.h:41-44) while ks_getuntil2, compiled in src/bseq.c, uses
+// { size_t l, m; char *s } (src/kseq.h:91-94) — 16 vs 24 bytes on the caller's stack. So the annotation is injected below instead of parsed.
+int refshim_idx_bed_read(void *mi, const char *fn) { return mm_idx_bed_read((mm_idx_t*)mi, fn, 1); }
+// the intervals of one contig straight into mi->I (layout of the private mm_idx_intv_s, src/index.c:40-48), sorted by start as mm_idx_bed_read leaves them
+int refshim_idx_set_junc(void *mi_, int ctg, int n, const int32_t *st, const int32_t *en, const int32_t *strand)
+{
+	struct Intv1 { int32_t st, en, max; int32_t score:30, strand:2; };
+	struct Intv { int32_t n, m; Intv1 *a; };
+	mm_idx_t *mi = (mm_idx_t*)mi_;
+	if (ctg < 0 || ctg >= (int)mi->n_seq) return -1;
+	if (!mi->I) mi->I = (struct mm_idx_intv_s*)calloc(mi->n_seq, sizeof(Intv));
+	Intv *r = (Intv*)mi->I + ctg;
+	free(r->a);
+	r->a = (Intv1*)calloc(n > 0 ? n : 1, sizeof(Intv1)); r->n = r->m = n;
+	for (int i = 0; i < n; ++i) { r->a[i].st = st[i]; r->a[i].en = en[i]; r->a[i].max = -1; r->a[i].score = 0; r->a[i].strand = strand[i]; }
+	for (int i = 1; i < n; ++i) for (int j = i; j > 0 && r->a[j].st < r->a[j - 1].st; --j) { Intv1 t = r->a[j]; r->a[j] = r->a[j - 1]; r->a[j - 1] = t; }
+	return 0;
+}
+int refshim_idx_bed_junc(void *mi, int ctg, int st, int en, uint8_t *s) { return mm_idx_bed_junc((const mm_idx_t*)mi, ctg, st, en, s); }
 // src/index.c:515-608 mm_idx_dump / mm_idx_load (the CLI's -d is disabled in this fork, the library functions are intact)
 int refshim_idx_dump(void *mi, const char *path) { FILE *fp = fopen(path, "wb"); if (!fp) return -1; mm_idx_dump(fp, (mm_idx_t*)mi); fclose(fp); return 0; }
 void *refshim_idx_load(const char *path) { FILE *fp = fopen(path, "rb"); if (!fp) return 0; mm_idx_t *mi = mm_idx_load(fp); fclose(fp); return mi; }

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 #include <unistd.h>
 #include "minimap.h"
 #include "../include/wm_gpu.h"
@@ -44,6 +45,7 @@ void copy_opt(const mm_mapopt_t *o, wm_mapopt_t *w)
 	CP(max_join_long); CP(max_join_short); CP(min_join_flank_sc); CP(min_join_flank_ratio); CP(alt_drop);
 	CP(a); CP(b); CP(q); CP(e); CP(q2); CP(e2); CP(sc_ambi); CP(zdrop); CP(zdrop_inv); CP(end_bonus); CP(min_dp_max); CP(min_ksw_len);
 	CP(max_clip_ratio); CP(mid_occ_frac); CP(min_mid_occ); CP(mid_occ); CP(max_occ); CP(mini_batch_size); CP(max_sw_mat);
+	CP(noncan); CP(junc_bonus); CP(anchor_ext_len); CP(anchor_ext_shift);
 #undef CP
 }
 
@@ -61,6 +63,18 @@ int open_backend(const mm_idx_t *mi, const mm_mapopt_t *opt, int n_threads)
 	unlink(tmpl);
 	if (rc) return -1;
 	if (wm_index_upload(g_be.ctx, g_be.idx)) return -1;
+	if (mi->I) {                                                         // --junc-bed: main has read the annotation into the index (src/main.c:416)
+		// (mm_idx_intv_s is private to src/index.c:40-48; in-tree this would be an accessor next to mm_idx_bed_junc)
+		struct Intv1 { int32_t st, en, max; int32_t score:30, strand:2; };
+		struct Intv { int32_t n, m; Intv1 *a; };
+		const Intv *I = (const Intv*)mi->I;
+		for (uint32_t c = 0; c < mi->n_seq; ++c) {
+			const Intv &r = I[c];
+			std::vector<int32_t> st(r.n), en(r.n), sd(r.n);
+			for (int32_t i = 0; i < r.n; ++i) st[i] = r.a[i].st, en[i] = r.a[i].en, sd[i] = r.a[i].strand;
+			if (r.n && wm_index_add_junc(g_be.idx, (int)c, r.n, st.data(), en.data(), sd.data())) return -1;
+		}
+	}
 	wm_mapopt_t wo;
 	copy_opt(opt, &wo);
 	if (wm_mapper_create_opt(g_be.ctx, g_be.idx, &wo, &g_be.mapper)) return -1;

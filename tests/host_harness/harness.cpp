@@ -157,7 +157,7 @@ struct OracleOps : DeviceOps {
 			r->copy_query(q.data()); r->copy_target(t.data());
 			check_positions(*r, q, t);
 			std::vector<uint32_t> cig(q.size() + t.size() + 4);
-			wmo_ksw_exts2((int)q.size(), q.data(), (int)t.size(), t.data(), 5, mat, sc.q, sc.e, sc.q2, noncan, r->zdrop, junc_bonus, r->flag, 0, &ez, cig.data());
+			wmo_ksw_exts2((int)q.size(), q.data(), (int)t.size(), t.data(), 5, mat, sc.q, sc.e, sc.q2, noncan, r->zdrop, junc_bonus, r->flag, r->junc.empty() ? 0 : r->junc.data(), &ez, cig.data());
 			r->ez.max = ez.max; r->ez.zdropped = ez.zdropped; r->ez.max_q = ez.max_q; r->ez.max_t = ez.max_t; r->ez.mqe = ez.mqe; r->ez.mqe_t = ez.mqe_t;
 			r->ez.mte = ez.mte; r->ez.mte_q = ez.mte_q; r->ez.score = ez.score; r->ez.reach_end = ez.reach_end; r->ez.n_cigar = ez.n_cigar; r->ez.cig_off = 0;
 			r->cigar.assign(cig.begin(), cig.begin() + ez.n_cigar);
@@ -183,6 +183,8 @@ void *h_index_build(const char *fasta, const char *kmer_file, int k, int w, int 
 	for (uint64_t x : kms) wmo_bloom_insert(h->bloom, x);
 	return h;
 }
+int h_index_read_bed(void *hv, const char *path) { std::string err; return index_read_bed(((Harness*)hv)->idx, path, true, err); }      // --junc-bed
+int h_bed_junc(void *hv, int ctg, int st, int en, uint8_t *out) { return ((Harness*)hv)->idx.bed_junc(ctg, st, en, out); }
 int h_getseq(void *hv, uint32_t rid, uint32_t st, uint32_t en, uint8_t *out) { return ((Harness*)hv)->idx.getseq(rid, st, en, out); }
 uint64_t h_index_n_minimizers(void *hv) { return ((Harness*)hv)->idx.n_minimizers; }
 int h_index_get(void *hv, uint64_t minier, uint64_t *out, int cap)

@@ -207,3 +207,49 @@ def test_splice_mode_of_the_mapper_matches_the_reference_cli():
         assert text.count(b"ts:A:+") > 20 and text.count(b"ts:A:-") > 20 and len(re.findall(rb"[0-9]N", text)) > 200
         m.close()
     idx.close(); ctx.close()
+
+
+@need_ref
+def test_splice_mode_with_a_junction_annotation_matches_the_reference_library():
+    """--junc-bed (src/main.c:416) through wm_index_read_junc_bed + wm_map_reads: the junction bits ride with every exts2 job to the device
+    (wm_ksw_exts2_batch's `junc`). The reference's CLI cannot be the yardstick — its BED reader crashes (oracle/ref_shim.cpp) — so the same
+    intervals are injected into the reference's index and its library maps the reads (refshim_map), hit by hit and CIGAR by CIGAR."""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import wmtest as W
+    from test_e2e_host import _transcripts_with_bed, _bed_introns
+    R = W.ref()
+    tmp = tempfile.mkdtemp()
+    ref = synth.make_reference(2, 300000, 51, repeat_frac=0.05)
+    bed = os.path.join(tmp, "anno.bed")
+    reads = _transcripts_with_bed(ref, 80, 52, bed)
+    fa = os.path.join(tmp, "ref.fa")
+    synth.write_fasta(fa, ref, prefix="ref")
+    seqs = [synth.codes_to_ascii(r) for r in reads]
+    mi = R.refshim_idx_build(fa.encode(), b"", 15, 25, 4)
+    R.refshim_idx_set_junc.argtypes = [C.c_void_p, C.c_int, C.c_int, W.i32p, W.i32p, W.i32p]
+    for ctg, iv in _bed_introns(bed, ["ref0", "ref1"]).items():
+        a = np.array(iv, np.int32).reshape(-1, 3)
+        assert R.refshim_idx_set_junc(mi, ctg, len(a), np.ascontiguousarray(a[:, 0]), np.ascontiguousarray(a[:, 1]), np.ascontiguousarray(a[:, 2])) == 0
+    opt = R.refshim_mapopt(b"splice", 0x4 | 0x20, mi)
+    ctx = gpu.Context(0, 8 << 30)
+    idx = gpu.Index(fa, None, k=15, w=25, n_threads=8)
+    idx.read_junc_bed(bed)
+    idx.upload(ctx)
+    m = gpu.Mapper(ctx, idx, "splice", gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
+    m.set_threads(8, 4 << 30)
+    text, hits, cigs, first = m.map([b"r%d" % i for i in range(len(seqs))], seqs)
+    n_hits = n_introns = 0
+    for i, s in enumerate(seqs):
+        rh = np.zeros(16 * 256, np.int32); rc = np.zeros(400000, np.uint32); rnc = C.c_int64()
+        rn = R.refshim_map(mi, opt, s, len(s), b"q", rh, 256, rc, len(rc), C.byref(rnc))
+        ours = hits[first[i]:first[i + 1]].copy(); want = rh[:16 * rn].reshape(-1, 16).copy()
+        ours[:, 6] = 0; want[:, 6] = 0                                       # MAPQ: see winnowmap_amd/parity.py
+        assert np.array_equal(ours, want), (i, ours.tolist(), want.tolist())
+        c0 = int(hits[:first[i], 7].sum()); c1 = c0 + int(ours[:, 7].sum())
+        assert np.array_equal(cigs[c0:c1], rc[:rnc.value]), i
+        n_hits += rn
+        n_introns += int(np.sum((rc[:rnc.value] & 0xf) == 3))
+    assert n_hits >= 70 and n_introns >= 100, (n_hits, n_introns)
+    m.close(); idx.close(); ctx.close()

@@ -108,6 +108,15 @@ static KswReq make_job(const AlnEnv &E, int rev, int32_t qs, int32_t qe, int32_t
 	return j;
 }
 
+// mm_idx_bed_junc for the target range of a splice-mode job (src/align.c:693, 723, 770)
+static void attach_junc(const AlnEnv &E, KswReq &j, int32_t rid, int32_t rs, int32_t re, bool reversed)
+{
+	if (!(E.opt->flag & F_SPLICE) || !E.idx->has_junc() || re <= rs) return;
+	j.junc.resize((size_t)(re - rs));
+	E.idx->bed_junc(rid, rs, re, j.junc.data());
+	if (reversed) std::reverse(j.junc.begin(), j.junc.end());
+}
+
 static inline void adjust_minier(const Index &idx, const m128 &a, int32_t *r, int32_t *q)
 {   // mm_adjust_minier, non-HPC branch (src/align.c:362-363)
 	*r = (int32_t)a.x - (idx.k >> 1);
@@ -545,6 +554,7 @@ static void plan_reg(const AlnEnv &E, RegAln &A, m128 *a, std::vector<KswReq> &j
 		KswReq j = make_job(E, A.rev, qs0, qs, rid, rs0, rs, tb, rs0, A.t_has_n, true);
 		j.w = A.bw; j.end_bonus = opt.end_bonus; j.zdrop = r.split_inv ? opt.zdrop_inv : opt.zdrop;
 		j.flag = extra_flag | EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR;
+		attach_junc(E, j, rid, rs0, rs, true);
 		A.left_job = (int)jobs.size(); jobs.push_back(std::move(j));
 	}
 	for (i = 1; i < cnt1; ++i) {                                       // gap filling (:709-765), first pass
@@ -555,6 +565,7 @@ static void plan_reg(const AlnEnv &E, RegAln &A, m128 *a, std::vector<KswReq> &j
 			if (a[as1 + i].y & SEED_LONG_JOIN) f.bw1 = qe - qs > re - rs ? qe - qs : re - rs;
 			KswReq j = make_job(E, A.rev, qs, qe, rid, rs, re, tb, rs0, A.t_has_n, false);
 			j.w = f.bw1; j.end_bonus = -1; j.zdrop = opt.zdrop; j.flag = extra_flag | EZ_APPROX_MAX;
+			attach_junc(E, j, rid, rs, re, false);
 			f.job = (int)jobs.size(); jobs.push_back(std::move(j));
 			A.fills.push_back(f);
 			rs = re, qs = qe;
@@ -564,6 +575,7 @@ static void plan_reg(const AlnEnv &E, RegAln &A, m128 *a, std::vector<KswReq> &j
 	if (qe < qe0 && re < re0) {                                        // right extension (:767-778), used unless a fill z-drops
 		KswReq j = make_job(E, A.rev, qe, qe0, rid, re, re0, tb, rs0, A.t_has_n, false);
 		j.w = A.bw; j.end_bonus = opt.end_bonus; j.zdrop = opt.zdrop; j.flag = extra_flag | EZ_EXTZ_ONLY;
+		attach_junc(E, j, rid, re, re0, false);
 		A.right_job = (int)jobs.size(); jobs.push_back(std::move(j));
 	}
 }

@@ -1,6 +1,10 @@
 // wm_index.cpp — host-side sketching (index build; the per-read sketch runs on the GPU) and the flat index.
 #include "wm_index.h"
 #include <math.h>
+#include <zlib.h>
+#include <ctype.h>
+#include <string.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <algorithm>
 #include <fstream>
@@ -462,6 +466,88 @@ void mapopt_update(MapOpt &opt, const Index &ix)
 	if ((opt.flag & F_SPLICE_FOR) || (opt.flag & F_SPLICE_REV)) opt.flag |= F_SPLICE;
 	if (opt.mid_occ_frac >= 0 && opt.mid_occ_frac < 1) opt.mid_occ = ix.cal_max_occ(opt.mid_occ_frac);
 	if (opt.mid_occ < opt.min_mid_occ) opt.mid_occ = opt.min_mid_occ;
+}
+
+// ---- junction annotation (src/index.c:690-803) ----
+int index_read_bed(Index &ix, const std::string &path, bool read_junc, std::string &err)
+{
+	gzFile fp = path == "-" ? gzdopen(0, "r") : gzopen(path.c_str(), "r");
+	if (!fp) { err = "failed to open file '" + path + "'"; return -1; }
+	std::vector<std::vector<JuncIntv>> I(ix.seq.size());
+	std::vector<char> buf(1 << 16);
+	std::string line, carry;
+	auto name2id = [&](const char *nm) { for (size_t i = 0; i < ix.seq.size(); ++i) if (ix.seq[i].name == nm) return (int)i; return -1; };
+	auto do_line = [&](std::string &ln) {
+		if (!ln.empty() && ln.back() == '\r') ln.pop_back();
+		JuncIntv t = { -1, -1, 0 };
+		int32_t id = -1, n_blk = 0, i = 0;
+		char *bl = 0, *bs = 0;
+		char *p, *q;
+		ln.push_back(0);
+		for (p = q = &ln[0];; ++p) {
+			if (*p == 0 || *p == '\t') {
+				const int c = *p;
+				*p = 0;
+				if (i == 0) { id = name2id(q); if (id < 0) break; }
+				else if (i == 1) { t.st = (int32_t)atol(q); if (t.st < 0) break; }
+				else if (i == 2) { t.en = (int32_t)atol(q); if (t.en < 0) break; }
+				else if (i == 5) t.strand = *q == '+' ? 1 : *q == '-' ? -1 : 0;
+				else if (i == 9) { if (!isdigit((unsigned char)*q)) break; n_blk = (int32_t)atol(q); }
+				else if (i == 10) bl = q;
+				else if (i == 11) { bs = q; break; }
+				if (c == 0) break;
+				++i, q = p + 1;
+			}
+		}
+		if (id < 0 || t.st < 0 || t.st >= t.en) return;
+		std::vector<JuncIntv> &r = I[id];
+		if (i >= 11 && read_junc) {                                    // BED12: the gaps between consecutive blocks
+			int32_t st = (int32_t)strtol(bs, &bs, 10); ++bs;
+			int32_t sz = (int32_t)strtol(bl, &bl, 10); ++bl;
+			int32_t en = t.st + st + sz;
+			for (int32_t b = 1; b < n_blk; ++b) {
+				JuncIntv s = t;
+				st = (int32_t)strtol(bs, &bs, 10); ++bs;
+				sz = (int32_t)strtol(bl, &bl, 10); ++bl;
+				s.st = en, s.en = t.st + st;
+				en = t.st + st + sz;
+				if (s.en > s.st) r.push_back(s);
+			}
+		} else r.push_back(t);
+	};
+	for (;;) {
+		const int n = gzread(fp, buf.data(), (unsigned)buf.size());
+		if (n <= 0) break;
+		size_t st = 0;
+		for (int k = 0; k < n; ++k)
+			if (buf[k] == '\n') { carry.append(buf.data() + st, k - st); do_line(carry); carry.clear(); st = (size_t)k + 1; }
+		carry.append(buf.data() + st, (size_t)n - st);
+	}
+	if (!carry.empty()) do_line(carry);
+	gzclose(fp);
+	for (auto &r : I) std::stable_sort(r.begin(), r.end(), [](const JuncIntv &a, const JuncIntv &b) { return a.st < b.st; });   // (order among equal starts does not matter: the bits are ORed)
+	ix.I.swap(I);
+	return 0;
+}
+
+int Index::bed_junc(int32_t ctg, int32_t st, int32_t en, uint8_t *s) const
+{   // mm_idx_bed_junc, src/index.c:768-803: bit 1 / 2 = first / last base of a + strand intron inside [st, en), 8 / 4 the same for the - strand
+	memset(s, 0, (size_t)(en > st ? en - st : 0));
+	if (I.empty() || ctg < 0 || ctg >= (int32_t)I.size()) return -1;
+	const std::vector<JuncIntv> &r = I[ctg];
+	int32_t left = 0, right = (int32_t)r.size();
+	while (right > left) {
+		const int32_t mid = left + ((right - left) >> 1);
+		if (r[mid].st >= st) right = mid; else left = mid + 1;
+	}
+	for (int32_t i = left; i < (int32_t)r.size(); ++i) {
+		if (r[i].st >= en) break;                                      // (sorted by start: nothing further right can lie inside; the reference scans on)
+		if (st <= r[i].st && en >= r[i].en && r[i].strand != 0) {
+			if (r[i].strand > 0) s[r[i].st - st] |= 1, s[r[i].en - 1 - st] |= 2;
+			else s[r[i].st - st] |= 8, s[r[i].en - 1 - st] |= 4;
+		}
+	}
+	return left;
 }
 
 } // namespace wm

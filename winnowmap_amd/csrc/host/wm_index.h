@@ -25,6 +25,8 @@ void sketch(const char *seq, int len, int w, int k, uint32_t rid, const Bloom *b
 
 struct RefSeq { std::string name; uint64_t offset; uint32_t len; };
 
+struct JuncIntv { int32_t st, en, strand; };     // mm_idx_intv1_t (src/minimap.h): an annotated intron [st, en) and the strand of its transcript
+
 struct Index {
 	int k = 15, w = 50, flag = 0;
 	std::vector<RefSeq> seq;                // mm_idx_seq_t
@@ -44,6 +46,10 @@ struct Index {
 	std::vector<std::pair<uint64_t, uint64_t>> n_runs;
 	void scan_n_runs();
 	bool has_n(uint32_t rid, uint32_t st, uint32_t en) const;
+	// junction annotation (--junc-bed, mm_idx_bed_read / mm_idx_bed_junc, src/index.c:690-803): per contig, sorted by start
+	std::vector<std::vector<JuncIntv>> I;
+	bool has_junc() const { return !I.empty(); }
+	int bed_junc(int32_t ctg, int32_t st, int32_t en, uint8_t *s) const;
 	int32_t cal_max_occ(float f) const;                            // mm_idx_cal_max_occ, src/index.c:173-194
 	static uint64_t slot_of(uint64_t key, int hbits) { return (key * 0x9E3779B97F4A7C15ULL) >> (64 - hbits); }
 };
@@ -58,6 +64,8 @@ int index_build_from_fasta(const IdxOpt &io, const std::string &fasta, const std
 // and the implied MM_F_SPLICE bit
 struct MapOpt;
 void mapopt_update(MapOpt &opt, const Index &ix);
+// mm_idx_bed_read (src/index.c:756-766): BED6 intervals, or with read_junc the introns between the blocks of BED12 records; 0 / -1 (cannot open)
+int index_read_bed(Index &ix, const std::string &path, bool read_junc, std::string &err);
 
 void index_table_from_minimizers(Index &ix, std::vector<m128> &all);
 // the two halves of index_build around the sketching of the contigs (so that a device can do that part): bloom filter from the -W list +

@@ -60,6 +60,9 @@ struct KswReq {                    // ksw_extd2_sse (src/ksw2.h:60)
 	int64_t qwin_off = -1; int32_t qwin_len = 0, q_pos = 0, rid = -1, t_pos = 0;
 	bool has_n = true;
 	int w = 0, zdrop = 0, end_bonus = 0, flag = 0;
+	// splice mode with a junction annotation (--junc-bed): the bits of mm_idx_bed_junc (src/index.c:768-803) for the target range, in the
+	// order the target is presented (reversed for the left extension, src/align.c:693-696); empty = no annotation
+	std::vector<uint8_t> junc;
 	wm_ksw_result_t ez = {};       // out
 	std::vector<uint32_t> cigar;   // out
 	int qlen() const { return ql; }

@@ -2267,17 +2267,24 @@ struct GpuOpsCtx {
 			const int m = i1 - i0;
 			std::vector<wm_ksw_job_t> jobs(m);
 			std::vector<wm_ksw_result_t> res(m);
-			std::vector<uint8_t> seqs(tot + 1);
+			std::vector<uint8_t> seqs(tot + 1), junc;
 			std::vector<uint32_t> pool(cap);
 			size_t off = 0, used = 0;
+			bool any_junc = false;
+			for (int i = 0; i < m; ++i) any_junc |= !reqs[i0 + i]->junc.empty();
+			if (any_junc) junc.assign(tot + 1, 0);                     // parallel to seqs: junction bits at the targets (mm_idx_bed_junc, src/index.c:768-803)
 			for (int i = 0; i < m; ++i) {
 				wm::KswReq &r = *reqs[i0 + i];
 				jobs[i].q_off = (uint32_t)off; off += (size_t)r.ql;
 				jobs[i].t_off = (uint32_t)off; off += (size_t)r.tl;
 				jobs[i].qlen = r.ql; jobs[i].tlen = r.tl; jobs[i].w = -1; jobs[i].zdrop = r.zdrop; jobs[i].end_bonus = 0; jobs[i].flag = r.flag;
 			}
-			wm::parallel_for(c->host_threads, (size_t)m, [&](size_t i) { reqs[i0 + i]->copy_query(seqs.data() + jobs[i].q_off); reqs[i0 + i]->copy_target(seqs.data() + jobs[i].t_off); });
-			if (wm_ksw_exts2_batch(c, &sc, noncan, junc_bonus, m, jobs.data(), seqs.data(), tot, 0, res.data(), pool.data(), cap, &used)) { fail("ksw_exts2"); return; }
+			wm::parallel_for(c->host_threads, (size_t)m, [&](size_t i) {
+				const wm::KswReq &r = *reqs[i0 + i];
+				r.copy_query(seqs.data() + jobs[i].q_off); r.copy_target(seqs.data() + jobs[i].t_off);
+				if (!r.junc.empty()) memcpy(junc.data() + jobs[i].t_off, r.junc.data(), r.junc.size());
+			});
+			if (wm_ksw_exts2_batch(c, &sc, noncan, junc_bonus, m, jobs.data(), seqs.data(), tot, any_junc ? junc.data() : 0, res.data(), pool.data(), cap, &used)) { fail("ksw_exts2"); return; }
 			for (int i = 0; i < m; ++i) {
 				reqs[i0 + i]->ez = res[i];
 				reqs[i0 + i]->cigar.assign(pool.begin() + res[i].cig_off, pool.begin() + res[i].cig_off + res[i].n_cigar);
@@ -2631,6 +2638,23 @@ extern "C" int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *o
 	if (out != stdout) fclose(out);
 	if (stats) { stats[0] = (double)fs.n_reads; stats[1] = (double)fs.n_bases; stats[2] = (double)fs.n_batches; stats[3] = fs.t_read; stats[4] = fs.t_map; stats[5] = fs.t_write; }
 	if (rc) return g_err[0] ? rc : set_err(WM_EINVAL, "%s", err.c_str());
+	return WM_OK;
+}
+
+extern "C" int wm_index_read_junc_bed(wm_index_t *idx, const char *path)
+{
+	if (!idx || !path) return set_err(WM_EINVAL, "null argument");
+	std::string err;
+	if (wm::index_read_bed(idx->ix, path, true, err) < 0) return set_err(WM_EINVAL, "%s", err.c_str());
+	return WM_OK;
+}
+extern "C" int wm_index_add_junc(wm_index_t *idx, int ctg, int n, const int32_t *st, const int32_t *en, const int32_t *strand)
+{
+	if (!idx || ctg < 0 || ctg >= (int)idx->ix.seq.size() || n < 0 || (n > 0 && (!st || !en || !strand))) return set_err(WM_EINVAL, "bad argument");
+	if (idx->ix.I.empty()) idx->ix.I.resize(idx->ix.seq.size());
+	std::vector<wm::JuncIntv> &r = idx->ix.I[ctg];
+	for (int i = 0; i < n; ++i) r.push_back(wm::JuncIntv{ st[i], en[i], strand[i] });
+	std::stable_sort(r.begin(), r.end(), [](const wm::JuncIntv &a, const wm::JuncIntv &b) { return a.st < b.st; });
 	return WM_OK;
 }
 

@@ -252,6 +252,12 @@ class Index:
         _chk(L.wm_index_build_gpu(ctx._h, os.fsencode(fasta), os.fsencode(kmer_file) if kmer_file else None, k, w, n_threads, C.byref(h), st.ctypes.data))
         return Index(_handle=h), {"read_pack_s": float(st[0]), "device_sketch_s": float(st[1]), "table_s": float(st[2]), "minimizers": int(st[3])}
 
+    def read_junc_bed(self, path):
+        """--junc-bed: annotated introns for splice mode's junction bonus (wm_index_read_junc_bed = mm_idx_bed_read, src/index.c:756)"""
+        L = lib()
+        L.wm_index_read_junc_bed.argtypes = [C.c_void_p, C.c_char_p]
+        _chk(L.wm_index_read_junc_bed(self._h, os.fsencode(path)))
+
     def export_arrays(self):
         """(sizes9, [S, hkey, hval, P, bloom, seq_meta, names]) as numpy arrays — the payload of the RCCL broadcast."""
         L = lib()
