@@ -42,6 +42,10 @@
 #ifndef WM_KSW_ROR
 #define WM_KSW_ROR 1          // 1 (default since round 3: +4 % in the isolated probe, +2 % in the bench, profiles/r03a_first_run.txt): neighbour values through wave_ror:1 + v_perm_b32; 0: v_readlane + scalar fill
 #endif
+#ifndef WM_KSW_EDGE_TRACK
+#define WM_KSW_EDGE_TRACK 1   // 1: unclipped approximate-max jobs (the bulk of the gap fills) follow the hull's first lane instead of the reference's greedy
+                              // track (same H at the end, see below) and skip the band terms of st0 / en0; 0: the round-3a code, for A/B runs
+#endif
 #include <type_traits>
 #include <utility>
 
@@ -177,9 +181,11 @@ WM_DEV void ksw_dp_packed(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 		int st0 = 0, en0 = tlen - 1;
 		if (st0 < r - qlen + 1) st0 = r - qlen + 1;
 		if (en0 > r) en0 = r;
-		if (st0 < (r - w + 1) >> 1) st0 = (r - w + 1) >> 1;
-		if (en0 > (r + w) >> 1) en0 = (r + w) >> 1;
-		if (st0 > en0) { ez_zdropped = 1; break; }
+		if (CLIP || !WM_KSW_EDGE_TRACK) {          // (CLIP = false: w >= qlen, tlen — the band terms never bind and the hull is never empty, ksw_plan.h)
+			if (st0 < (r - w + 1) >> 1) st0 = (r - w + 1) >> 1;
+			if (en0 > (r + w) >> 1) en0 = (r + w) >> 1;
+			if (st0 > en0) { ez_zdropped = 1; break; }
+		}
 		const int st = st0 / 16 * 16, en = (en0 + 16) / 16 * 16 - 1;
 		const int sched = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
 
@@ -221,7 +227,8 @@ WM_DEV void ksw_dp_packed(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 		{
 			const int qi0 = r - base;
 			int newc = 0;
-			if (qi0 >= 0 && qi0 < qlen) {
+			if (qi0 < qlen) {                              // (qi0 >= 0: base <= st0 <= r)
+				WM_EMU_ASSERT(qi0 >= 0);
 				if (qi0 < qb0 || qi0 >= qb0 + 64) {
 					qb0 = qi0 < 16 ? 0 : qi0 - 16;          // a re-base steps the index back by 16: keep that much behind
 					const V<int> qidx = ln + qb0;
@@ -381,7 +388,7 @@ WM_DEV void ksw_dp_packed(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 					const int oe = en0 - c0;
 					h_en0 = oe < 64 ? readlane(H[2 * i], oe & 63) : readlane(H[2 * i + 1], oe & 63);
 				}
-			} else {
+			} else if constexpr (CLIP || !WM_KSW_EDGE_TRACK) {
 				// the approximate-max track reads two neighbouring lanes of this row (:359-375)
 				const int o0 = last_H0_t - c0, o1 = o0 + 1;
 				if ((unsigned)o0 < 128u) { const int rr = readlane(Vv[i], o0 & 63); d0 = ((o0 & 64) ? rr >> 16 : (int)(short)(rr & 0xffff)) >> 8; }
@@ -441,6 +448,18 @@ WM_DEV void ksw_dp_packed(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 				if (zdrop >= 0 && ez_max - max_H > zdrop + l * e2) { ez_zdropped = 1; break; }
 			}
 			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = h_en0;
+		} else if constexpr (!CLIP && WM_KSW_EDGE_TRACK) {
+			// ---- approximate max when the band never clips (w >= qlen, tlen: the bulk of the gap fills). H0 of :359-375 is H followed along a greedy
+			// monotone track: staying in lane t adds v(r, t), stepping to lane t + 1 adds u(r, t + 1), so H0 == H(r, track lane) exactly as long as
+			// the track visits band cells — and here every lane of [st0, en0] is one. Only ez.score = H0 of the LAST row is ever consumed, and
+			// that row has a single cell: H there does not depend on the path. So follow the cheapest path instead — the hull's first lane st0
+			// (lane 0 down the first column, then one lane to the right per row along the last query row): one v_readlane per row in thread
+			// st0 - base of pair 0, no per-pair lookups, no track state.
+			const int o = st0 - base;                                      // 0..15: chunk 0, low half
+			const int rv = readlane(Vv[0], o), ru = readlane(U[0], o);
+			const int d = ((int)(short)((r < qlen ? rv : ru) & 0xffff)) >> 8;
+			H0 = r ? H0 + d : d - qe;
+			if (r == n_rows - 1) ez_score = H0;                            // (en0 == tlen - 1 on the last row of an unclipped band)
 		} else {        // ---- approximate max: follow one diagonal-ish track (:359-375); d0 / d1 were picked up by the pair bodies
 			if (r > 0) {
 				const bool in0 = last_H0_t >= st0 && last_H0_t <= en0, in1 = last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0;
