@@ -47,7 +47,7 @@ for name, mean, w in (("ont300", 300, 751), ("ont150", 150, 751), ("ont600", 600
 # mapper (bench.py `classes`) separates what the kernel costs from what sharing the chip costs
 from winnowmap_amd import synth
 rng = np.random.default_rng(3)
-for name, L, njob, flag in (("p16_1500x", 1500, 256, 0x40), ("blk_3000x", 3000, 96, 0x40), ("blk_3000a", 3000, 96, 0x08), ("blk2_6000x", 6000, 32, 0x40)):
+for name, L, njob, flag in (("p16_1500x", 1500, 256, 0x40), ("p16_1500a", 1500, 256, 0x08), ("blk_3000x", 3000, 96, 0x40), ("blk_3000a", 3000, 96, 0x08), ("blk2_6000x", 6000, 32, 0x40)):
     cases = []
     for it in range(njob):
         t = rng.integers(0, 4, L).astype(np.uint8)

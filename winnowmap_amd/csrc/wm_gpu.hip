@@ -123,7 +123,9 @@ __global__ __launch_bounds__(64 * WM_KSW_BLK_NWV) void ksw_block_kernel(wm_ksw_s
 // BLOCK / BLOCK2 classes (and, with WM_KSW_PMULTI >= 2, the 16-pair register classes on <4,4>): the packed two-cells-per-lane machine over
 // 8 wavefronts (ksw_dp_pmulti<4,8>: 4096 lanes, <8,8>: 8192 lanes). Dynamic LDS: exchange areas, then the staged sequences (if they fit).
 // It replaced the unpacked ksw_dp_multi<8, 8|16> in round 3 (24 / 3 GCUPS, the <16> form spilled 377 VGPRs; profiles/r03a_first_run.txt)
-template <int BP, int NWV>
+// CLIP / HASN: the 16-pair register classes know both per class (ksw_plan.h) and get the lean machine when the band never clips or no operand
+// holds an N (most alignments of 1009..2032 lanes: stage-2 fills and extensions inside the 3001-wide band); the BLOCK classes run <true, true>.
+template <int BP, int NWV, bool CLIP = true, bool HASN = true>
 __global__ __launch_bounds__(64 * NWV) void ksw_pmulti_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
                                                                          const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res, int seq_cap)
 {
@@ -143,12 +145,12 @@ __global__ __launch_bounds__(64 * NWV) void ksw_pmulti_kernel(wm_ksw_score_t sc,
 		for (int i = threadIdx.x; i < jb.qlen; i += blockDim.x) sq[i] = seqs[jb.q_off + i];
 		for (int i = threadIdx.x; i < jb.tlen; i += blockDim.x) st[i] = seqs[jb.t_off + i];
 		__syncthreads();
-		if (jb.flag & KSW_F_APPROX_MAX) wmk::ksw_dp_pmulti<BP, NWV, true, true, false>(sc, jb, sq, st, tb, lds, res + j);
-		else wmk::ksw_dp_pmulti<BP, NWV, true, true, true>(sc, jb, sq, st, tb, lds, res + j);
+		if (jb.flag & KSW_F_APPROX_MAX) wmk::ksw_dp_pmulti<BP, NWV, CLIP, HASN, false>(sc, jb, sq, st, tb, lds, res + j);
+		else wmk::ksw_dp_pmulti<BP, NWV, CLIP, HASN, true>(sc, jb, sq, st, tb, lds, res + j);
 	} else {
 		const uint8_t *qp = seqs + jb.q_off, *tp = seqs + jb.t_off;
-		if (jb.flag & KSW_F_APPROX_MAX) wmk::ksw_dp_pmulti<BP, NWV, true, true, false>(sc, jb, qp, tp, tb, lds, res + j);
-		else wmk::ksw_dp_pmulti<BP, NWV, true, true, true>(sc, jb, qp, tp, tb, lds, res + j);
+		if (jb.flag & KSW_F_APPROX_MAX) wmk::ksw_dp_pmulti<BP, NWV, CLIP, HASN, false>(sc, jb, qp, tp, tb, lds, res + j);
+		else wmk::ksw_dp_pmulti<BP, NWV, CLIP, HASN, true>(sc, jb, qp, tp, tb, lds, res + j);
 	}
 }
 
@@ -638,6 +640,8 @@ extern "C" int wm_reads_upload(wm_ctx_t *c, const uint8_t *codes, size_t n)
 
 // WM_KSW_PMULTI: 1 = only the BLOCK / BLOCK2 classes run on the packed multi-wave kernel (ksw_pmulti_kernel<4,8> / <8,8>); 2 (default:
 // +7 % on BASELINE config 2, profiles/r03a_first_run.txt) = the 16-pair register classes run on ksw_pmulti_kernel<4,4> as well
+// WM_KSW_PMULTI_LEAN=0: every 16-pair class on the <CLIP, HASN> = <true, true> machine (the code before this switch; A/B)
+static bool pmulti_lean() { static const bool v = !(getenv("WM_KSW_PMULTI_LEAN") && atoi(getenv("WM_KSW_PMULTI_LEAN")) == 0); return v; }
 static int ksw_pmulti_level() { const char *e = getenv("WM_KSW_PMULTI"); return e ? atoi(e) : 2; }
 
 extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
@@ -729,8 +733,18 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 			if (ksw_pmulti_level() >= 2) {      // 4 wavefronts per alignment for the 16-pair classes too (shorter batch tails)
 				const int seq_cap = 32 * 1024;
 				const size_t lds = (size_t)wmk::ksw_pmulti_lds<4, 4>::INTS * 4 + seq_cap;
-				HIPCHK(hipFuncSetAttribute((const void*)ksw_pmulti_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-				hipLaunchKernelGGL((ksw_pmulti_kernel<4, 4>), dim3(nk), dim3(64 * 4), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, seq_cap);
+				auto go = [&](auto kern) -> int {
+					HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+					hipLaunchKernelGGL(kern, dim3(nk), dim3(64 * 4), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, seq_cap);
+					return WM_OK;
+				};
+				int rc_;
+				if (!pmulti_lean()) rc_ = go(ksw_pmulti_kernel<4, 4, true, true>);
+				else if ((k & 2) && (k & 1)) rc_ = go(ksw_pmulti_kernel<4, 4, true, true>);
+				else if (k & 2) rc_ = go(ksw_pmulti_kernel<4, 4, true, false>);
+				else if (k & 1) rc_ = go(ksw_pmulti_kernel<4, 4, false, true>);
+				else rc_ = go(ksw_pmulti_kernel<4, 4, false, false>);
+				if (rc_) return rc_;
 			} else
 				launch_dpp<16>(k & 7, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res);
 			break;
