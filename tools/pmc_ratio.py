@@ -24,7 +24,11 @@ def classes(log):
 
 def key(kernel_name):        # "void ksw_dp_kernel<16, true, false>(...)" -> "ksw_dp_kernel<16,true,false>"
     m = re.search(r"(ksw_[a-z_]+kernel(<[^>]*>)?)", kernel_name)
-    return m.group(1) if m else None              # (spelled like bench.py's class names, spaces included)
+    if not m:
+        return None
+    k = m.group(1)
+    pm = re.match(r"ksw_pmulti_kernel<(\d+), (\d+)", k)      # the <CLIP, HASN> variants of one geometry are one class in bench.py
+    return "ksw_pmulti_kernel<%s, %s>" % pm.groups() if pm else k              # (spelled like bench.py's class names, spaces included)
 
 
 # the --pmc passes serialise the dispatches: their durations are each kernel's time ALONE on the chip (no sharing with concurrent kernels)
@@ -37,16 +41,22 @@ try:
         print("  %-60s %6d %10.1f %10.1f %5.1f %%" % (nm[:60], calls, total / 1e3, avg, 100.0 * total / tot))
 except Exception as e:
     print("no dispatch table:", e)
-fetch, write = counters("pmc1", "FETCH_SIZE"), counters("pmc2", "WRITE_SIZE")
+fetch_raw, write_raw = counters("pmc1", "FETCH_SIZE"), counters("pmc2", "WRITE_SIZE")
 c1, c2 = classes("pmc1.log"), classes("pmc2.log")
+fetch, write = collections.defaultdict(float), collections.defaultdict(float)
+for kn, v in fetch_raw.items():
+    fetch[key(kn)] += v
+for kn, v in write_raw.items():
+    write[key(kn)] += v
 out = {}
-for kn in set(list(fetch) + list(write)):
-    k = key(kn)
+for k in set(list(fetch) + list(write)):
+    kn = k
     if not k or k not in c1 or k not in c2 or not c1[k]["cells"]:
         continue
     rd = 2.0 * fetch.get(kn, 0.0) * 1024 / c1[k]["cells"]
     wr = write.get(kn, 0.0) * 1024 / c2[k]["cells"]
     out[k] = rd + wr
     print("%-36s read %.3f B/cell  write %.3f B/cell  (algorithmic: 1 B/cell written)" % (k, rd, wr))
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --steps 1 --warmup 0 --reads-per-step 1024 (%s), FETCH_SIZE x2 (gfx950), KiB units" % os.path.basename(src.rstrip("/")),
+m_ = re.search(r'"reads_per_step_per_gpu": (\d+)', open(os.path.join(src, "pmc1.log")).read())
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --steps 1 --warmup 0 --reads-per-step %s (%s), FETCH_SIZE x2 (gfx950), KiB units" % (m_.group(1) if m_ else "?", os.path.basename(src.rstrip("/"))),
            "bytes_per_cell": out}, open("profiles/pmc_bytes_per_cell.json", "w"), indent=1)
