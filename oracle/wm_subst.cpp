@@ -10,7 +10,7 @@
 // exact signatures, ownership and kalloc conventions of the reference, each as a one-job call of the batched device operation behind it
 // (wm_sketch_batch, wm_chain_batch, wm_ksw_batch, wm_ksw_exts2_batch). So mm_map_frag, mm_align_skeleton, the index builder … all run unchanged on top of the
 // device kernels — slowly (one launch per call), which is the point of the batched entry points, but it proves the symbols are drop-ins.
-// Cases the kernels do not cover (HPC sketching, cDNA / multi-segment chaining, score-only DP) go to the renamed originals.
+// Cases the kernels do not cover (HPC sketching, multi-segment chaining, score-only DP) go to the renamed originals.
 // WM_SUBST=off in the environment routes everything to the originals (A/B inside one binary). tests/test_binding_gpu.py diffs the output.
 #include <stdio.h>
 #include <stdlib.h>
