@@ -287,6 +287,15 @@ typedef struct {
 } wm_mapopt_t;
 int wm_mapopt_preset(const char *preset, wm_mapopt_t *out, int *k, int *w);
 int wm_mapper_create_opt(wm_ctx_t *ctx, const wm_index_t *idx, const wm_mapopt_t *opt, wm_mapper_t **out);
+/* A reference indexed in PARTS (`-I bases`, src/main.c:193; the parts are formed like src/index.c:289-300, 378-384 forms them) and the reads
+ * mapped against one part after the other with the hits merged at the end (`--split-prefix`: mm_split_merge / merge_hits, src/map.c:1050-1105,
+ * 1278-1321): contig ids shifted by the parts before, mm_hit_sort, mm_set_parent, mm_select_sub, mm_set_sam_pri, mm_set_mapq with the largest
+ * rep_len. The output file equals `winnowmap -I … --split-prefix …`'s (the reference keeps the per-part hits in <prefix>.NNNN.tmp files; here they
+ * stay in host memory). Every part is an index of its own: destroy each with wm_index_destroy. */
+int wm_index_build_parts(const char *fasta, const char *kmer_file, int k, int w, int n_threads, uint64_t batch_bases, wm_index_t **out, int cap, int *n_parts);
+int wm_map_file_split(wm_ctx_t *ctx, int n_parts, wm_index_t *const *parts, const wm_mapopt_t *opt, int n_threads, const char *reads_path, const char *out_path,
+                      int64_t mini_batch_bases, double *stats);
+
 /* wm_map_file prints the SAM header itself when MM_F_OUT_SAM is set; a front end that has already printed it (the reference's main does,
  * src/main.c:393) turns that off */
 int wm_mapper_set_sam_header(wm_mapper_t *m, int on);

@@ -397,4 +397,39 @@ int h_map_file(void *hv, const char *preset, int64_t flag_extra, const char *rea
 	return rc;
 }
 
+// a reference indexed in parts + the merge (host/wm_pipeline.cpp: map_file_split) over oracle-backed ops; returns the number of parts or < 0
+int h_map_file_split(const char *fasta, const char *kmer_file, int k, int w, int64_t batch_bases, const char *preset, int64_t flag_extra,
+                     const char *reads_path, const char *out_path, int64_t mini_batch_bases, int n_threads)
+{
+	IdxOpt io; MapOpt mo;
+	set_preset(0, io, mo);
+	if (preset && preset[0] && set_preset(preset, io, mo) < 0) return -1;
+	io.k = k; io.w = w;
+	mo.flag |= flag_extra; mo.flag &= ~g_flag_clear;
+	std::vector<Index> parts;
+	std::string err;
+	const int n_parts = index_build_parts_from_fasta(io, fasta, kmer_file ? kmer_file : "", n_threads, (uint64_t)batch_bases, parts, err);
+	if (n_parts < 0) { fprintf(stderr, "h_map_file_split: %s\n", err.c_str()); return -2; }
+	std::vector<uint64_t> kms;
+	if (kmer_file && kmer_file[0]) { std::ifstream in(kmer_file); std::string km; uint64_t f; while (in >> km >> f) kms.push_back(wmo_encode_kmer(km.c_str(), (int)km.size())); }
+	wmo_bloom_t *bloom = wmo_bloom_new(kms.size());
+	for (uint64_t x : kms) wmo_bloom_insert(bloom, x);
+	Index dict; dict.k = k; dict.w = w;
+	std::vector<SplitPart> sp;
+	for (const Index &p : parts) { for (const RefSeq &r : p.seq) dict.seq.push_back(r); sp.push_back(SplitPart{ (int)p.seq.size() }); }
+	FILE *out = fopen(out_path, "wb");
+	if (!out) return -3;
+	if (mo.flag & 0x8) { std::string hdr; write_sam_header(hdr, dict, 0, 0); fwrite(hdr.data(), 1, hdr.size(), out); }
+	std::unique_ptr<OracleOps> ops;
+	MapOpt cur = mo;
+	FileStats fs;
+	const int rc = map_file_split(reads_path, mini_batch_bases, mo, k, dict, sp,
+		[&](int j) -> int { cur = mo; mapopt_update(cur, parts[j]); ops.reset(new OracleOps()); ops->idx = &parts[j]; ops->bloom = bloom; ops->opt = &cur; return 0; },
+		[&](int j, std::vector<ReadIn> &batch, std::vector<ReadOut> &o, int lane) -> int { map_batch(parts[j], cur, ops.get(), batch, o, 0, n_threads, 0, lane); return 0; },
+		out, &fs, err);
+	fclose(out);
+	if (rc) { fprintf(stderr, "h_map_file_split: %s\n", err.c_str()); return -4; }
+	return n_parts;
+}
+
 } // extern "C"

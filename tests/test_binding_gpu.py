@@ -253,3 +253,39 @@ def test_splice_mode_with_a_junction_annotation_matches_the_reference_library():
         n_introns += int(np.sum((rc[:rnc.value] & 0xf) == 3))
     assert n_hits >= 70 and n_introns >= 100, (n_hits, n_introns)
     m.close(); idx.close(); ctx.close()
+
+
+@need_ref
+def test_reference_indexed_in_parts_matches_split_prefix_of_the_reference_cli():
+    """wm_index_build_parts + wm_map_file_split against `winnowmap_ref -t 1 -I 400k --split-prefix …` (mm_split_merge, src/map.c:1050-1105):
+    six 200-kb contigs = three index parts, a 30-kb duplication across two parts, 120 reads; the merged records must be the reference's."""
+    tmp = tempfile.mkdtemp()
+    ref = synth.make_reference(6, 200000, 81, repeat_frac=0.08)
+    ref[5][20000:50000] = ref[0][60000:90000]
+    fa = os.path.join(tmp, "ref.fa")
+    synth.write_fasta(fa, ref, prefix="chr")
+    km, cnt = synth.repetitive_kmers(ref, 15)
+    kf = os.path.join(tmp, "rep.txt")
+    synth.write_kmer_list(kf, km, cnt, 15)
+    reads, _ = synth.make_reads(ref, 90, 12000, 82, profile="ont", sv_frac=0.1)
+    reads += synth.make_reads(ref, 26, 3000, 83, profile="ont")[0]
+    rng = np.random.default_rng(84)
+    for s0 in (61000, 66000):
+        reads.append(synth.mutate_codes(ref[0][s0:s0 + 12000].copy(), rng, 0.03, 0.02, 0.02))
+        reads.append(synth.revcomp_codes(synth.mutate_codes(ref[5][s0 - 40000:s0 - 28000].copy(), rng, 0.03, 0.02, 0.02)))
+    rq = os.path.join(tmp, "reads.fa")
+    _write_reads(rq, reads)
+    want = _run(REF_BIN, ["-t", "1", "-I", "400k", "--split-prefix", os.path.join(tmp, "sp"), "-W", kf, "-cx", "map-ont", fa, rq])
+    ctx = gpu.Context(0, 8 << 30)
+    parts = gpu.build_index_parts(fa, kf, 15, 50, 400000)
+    assert len(parts) == 3
+    opt, _, _ = gpu.mapopt_preset("map-ont")
+    opt.flag |= gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG
+    outp = os.path.join(tmp, "ours.paf")
+    st = gpu.map_file_split(ctx, parts, opt, 8, rq, outp)
+    assert st["reads"] == len(reads)
+    d = parity.diff_texts(want, open(outp, "rb").read(), sam=False)
+    assert d["reads"] >= 100 and d["hits"] >= 110 and d["mismatches"] == 0, d
+    for p in parts:
+        p.close()
+    ctx.close()

@@ -135,3 +135,47 @@ def test_cs_and_md_tags_match_reference_binary(opt, flag, sam):
     assert len(a) == len(b) and any(("cs:Z:" in x or "MD:Z:" in x) for x in a)
     for x, y in zip(a, b):
         assert x == y, "\nref : %s\nours: %s" % (x[:300], y[:300])
+
+
+@pytest.mark.parametrize("sam", [False, True])
+def test_reference_indexed_in_parts_merges_like_split_prefix(sam):
+    """`-I <bases> --split-prefix <p>` (src/main.c:193, 232, 398-429): the reference is indexed in parts, the reads are mapped against one part
+    after the other and the hits are merged (mm_split_merge, src/map.c:1050-1105). Four 150-kb contigs with -I 200k = two parts; reads from
+    every contig, some with an exact copy of their source on another contig (so that hits of different parts compete). The reference runs
+    with -t 1: its part boundaries depend on the timing of its index pipeline otherwise (src/index.c:295 reads sum_len that step 1 updates)."""
+    from winnowmap_amd import synth
+    H = C.CDLL(build.build_harness())
+    H.h_map_file_split.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int64, C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p, C.c_int64, C.c_int]
+    tmp = tempfile.mkdtemp()
+    ref = synth.make_reference(4, 150000, 71, repeat_frac=0.08)
+    ref[3][20000:50000] = ref[0][60000:90000]                              # a 30-kb duplication across the part boundary
+    fa = os.path.join(tmp, "ref.fa")
+    synth.write_fasta(fa, ref, prefix="chr")
+    km, cnt = synth.repetitive_kmers(ref, 15)
+    kf = os.path.join(tmp, "rep.txt")
+    synth.write_kmer_list(kf, km, cnt, 15)
+    reads, _ = synth.make_reads(ref, 14, 11000, 72, profile="ont", sv_frac=0.2)
+    reads += synth.make_reads(ref, 6, 3000, 73, profile="ont")[0]
+    rng = np.random.default_rng(74)
+    reads.append(synth.mutate_codes(ref[0][62000:74000].copy(), rng, 0.03, 0.02, 0.02))      # inside the duplicated block
+    reads.append(synth.revcomp_codes(synth.mutate_codes(ref[3][21000:33000].copy(), rng, 0.03, 0.02, 0.02)))
+    rq = os.path.join(tmp, "reads.fa")
+    with open(rq, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b">rd%d\n" % i + synth.codes_to_ascii(r) + b"\n")
+    cmd = [REF_BIN, "-t", "1", "-I", "200k", "--split-prefix", os.path.join(tmp, "sp"), "-W", kf] + (["-ax", "map-ont"] if sam else ["-cx", "map-ont"]) + [fa, rq]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    ref_txt = p.stdout.decode()
+    outp = os.path.join(tmp, "ours.txt")
+    flag = 0x4 | (0x8 if sam else 0x20)
+    n_parts = H.h_map_file_split(fa.encode(), kf.encode(), 15, 50, 200000, b"map-ont", flag, rq.encode(), outp.encode(), 0, 2)
+    assert n_parts == 2, n_parts
+    ours = open(outp).read()
+    a = [x for x in (_mask(l, sam) for l in ref_txt.splitlines()) if x is not None]
+    b = [x for x in (_mask(l, sam) for l in ours.splitlines()) if x is not None]
+    assert len(a) == len(b) and len(a) >= len(reads), (len(a), len(b))
+    for x, y in zip(a, b):
+        assert x == y, "\nref : %s\nours: %s" % (x[:600], y[:600])
+    if sam:
+        assert sum(1 for x in b if x.startswith("@SQ")) == 4

@@ -448,6 +448,34 @@ int index_build_from_fasta(const IdxOpt &io, const std::string &fasta, const std
 	return index_build(io, names, seqs, kmer_file, n_threads, out, err);
 }
 
+int index_build_parts_from_fasta(const IdxOpt &io, const std::string &fasta, const std::string &kmer_file, int n_threads, uint64_t batch_bases,
+                                 std::vector<Index> &parts, std::string &err)
+{
+	extern int read_fastx(const std::string &fn, std::vector<std::string> &names, std::vector<std::string> &seqs, std::vector<std::string> *quals, std::vector<std::string> *comments, std::string &err);
+	std::vector<std::string> names, seqs;
+	if (read_fastx(fasta, names, seqs, 0, 0, err) < 0) return -1;
+	if (seqs.empty()) { err = "no sequences in " + fasta; return -1; }
+	const uint64_t mini = batch_bases < 50000000ULL ? batch_bases : 50000000ULL;      // mm_idx_gen: min(mini_batch_size, batch_size), src/index.c:383
+	parts.clear();
+	size_t i = 0;
+	while (i < seqs.size()) {
+		std::vector<std::string> pn, ps;
+		uint64_t sum = 0;
+		while (i < seqs.size() && sum <= batch_bases) {                // step 0 of the reference's pipeline: another mini-batch unless sum_len > batch_size (:295)
+			uint64_t mb = 0;
+			while (i < seqs.size()) {                                  // mm_bseq_read: sequences until the chunk reaches `mini` bases
+				mb += seqs[i].size();
+				pn.push_back(std::move(names[i])); ps.push_back(std::move(seqs[i])); ++i;
+				if (mb >= mini) break;
+			}
+			sum += mb;
+		}
+		parts.emplace_back();
+		if (index_build(io, pn, ps, kmer_file, n_threads, parts.back(), err) < 0) return -1;
+	}
+	return (int)parts.size();
+}
+
 int32_t Index::cal_max_occ(float f) const
 {
 	if (f <= 0.) return INT32_MAX;

@@ -59,6 +59,11 @@ struct Index {
 int index_build(const IdxOpt &io, const std::vector<std::string> &names, const std::vector<std::string> &seqs,
                 const std::string &kmer_file, int n_threads, Index &out, std::string &err);
 int index_build_from_fasta(const IdxOpt &io, const std::string &fasta, const std::string &kmer_file, int n_threads, Index &out, std::string &err);
+// `-I batch_bases` (src/main.c:193, src/index.c:289-300, 378-384): the reference reads the FASTA in mini-batches of min(50 M, batch_bases) bases
+// (whole sequences, until the mini-batch reaches that size) and closes an index part once its sequences exceed batch_bases; every part is an
+// index of its own (contig ids start at 0). Returns the number of parts (>= 1) or -1.
+int index_build_parts_from_fasta(const IdxOpt &io, const std::string &fasta, const std::string &kmer_file, int n_threads, uint64_t batch_bases,
+                                 std::vector<Index> &parts, std::string &err);
 
 // mm_mapopt_update (src/options.c:71-82): the options that depend on the index (-f as a fraction → mid_occ, the --min-occ-floor clamp)
 // and the implied MM_F_SPLICE bit

@@ -1,5 +1,7 @@
 // wm_pipeline.cpp — see wm_pipeline.h
 #include "wm_pipeline.h"
+#include "wm_hit.h"
+#include "wm_format.h"
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -25,6 +27,11 @@ template <class T> struct Slot {
 }
 
 int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_qual, const MapFn &map_fn, FILE *out, FileStats *st, std::string &err)
+{
+	return map_file_id(reads_path, mini_batch_bases, with_qual, [&](std::vector<ReadIn> &b, std::string &t, int lane, uint64_t) { return map_fn(b, t, lane); }, out, st, err);
+}
+
+int map_file_id(const std::string &reads_path, int64_t mini_batch_bases, bool with_qual, const MapFnId &map_fn, FILE *out, FileStats *st, std::string &err)
 {
 	FastxReader rd;
 	if (rd.open(reads_path, err) < 0) return -1;
@@ -72,10 +79,10 @@ int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_
 			}
 			const double t0 = now_s();
 			// a full disk / closed pipe must not yield a silently truncated file (the reference aborts in mm_err_puts)
-			if (!io_error.load() && !t->empty() && fwrite(t->data(), 1, t->size(), out) != t->size()) { io_error = true; stop = true; }
+			if (out && !io_error.load() && !t->empty() && fwrite(t->data(), 1, t->size(), out) != t->size()) { io_error = true; stop = true; }
 			fs.t_write += now_s() - t0;
 		}
-		if (fflush(out) != 0 || ferror(out)) io_error = true;
+		if (out && (fflush(out) != 0 || ferror(out))) io_error = true;
 	});
 	const char *le = getenv("WM_MAP_LANES");
 	const int n_lanes = le && atoi(le) == 1 ? 1 : 2;
@@ -87,7 +94,7 @@ int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_
 			const double t0 = now_s();
 			std::unique_ptr<std::string> text(new std::string());
 			int r = 0;
-			if (rc.load() == 0 && !io_error.load()) r = map_fn(b->reads, *text, lane);       // after an error: drain what the reader already queued
+			if (rc.load() == 0 && !io_error.load()) r = map_fn(b->reads, *text, lane, b->id);   // after an error: drain what the reader already queued
 			if (r != 0) { int z = 0; rc.compare_exchange_strong(z, r); stop = true; std::lock_guard<std::mutex> lk(omu); ocv.notify_all(); }
 			uint64_t nb = 0;
 			for (const ReadIn &x : b->reads) nb += x.seq.size();
@@ -114,6 +121,63 @@ int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_
 	if (ret) err = "mapping failed";
 	else if (io_error.load()) { err = "write error on the output file"; ret = -2; }
 	return ret;
+}
+
+int map_file_split(const std::string &reads_path, int64_t mini_batch_bases, const MapOpt &opt, int k, const Index &dict, const std::vector<SplitPart> &parts,
+                   const std::function<int(int part)> &begin_part,
+                   const std::function<int(int part, std::vector<ReadIn> &batch, std::vector<ReadOut> &out, int lane)> &map_part,
+                   FILE *out, FileStats *st, std::string &err)
+{
+	if (opt.flag & (F_OUT_CS | F_OUT_MD)) { err = "--cs or --MD doesn't work with a reference indexed in parts"; return -1; }      // src/options.c:139-141
+	const int n_parts = (int)parts.size();
+	const bool with_qual = (opt.flag & F_OUT_SAM) != 0;
+	// hits[part][mini-batch] = one ReadOut per read of the mini-batch, in the order the pipeline hands the reads over
+	std::vector<std::map<uint64_t, std::vector<ReadOut>>> hits(n_parts);
+	std::mutex hm;
+	FileStats fs_all;
+	for (int j = 0; j < n_parts; ++j) {
+		if (begin_part(j)) { err = "cannot set up index part " + std::to_string(j); return -1; }
+		FileStats fs;
+		const int rc = map_file_id(reads_path, mini_batch_bases, with_qual, [&](std::vector<ReadIn> &batch, std::string &, int lane, uint64_t id) {
+			std::vector<ReadOut> o;
+			const int r = map_part(j, batch, o, lane);
+			if (r) return r;
+			std::lock_guard<std::mutex> lk(hm);
+			hits[j][id] = std::move(o);
+			return 0;
+		}, 0, &fs, err);
+		if (rc) return rc;
+		fs_all.t_read += fs.t_read; fs_all.t_map += fs.t_map;
+	}
+	std::vector<int> rid_shift(n_parts, 0);
+	for (int j = 1; j < n_parts; ++j) rid_shift[j] = rid_shift[j - 1] + parts[j - 1].n_seq;
+	// the merge pass (merge_hits, src/map.c:1050-1105)
+	FileStats fs;
+	const int rc = map_file_id(reads_path, mini_batch_bases, with_qual, [&](std::vector<ReadIn> &batch, std::string &text, int, uint64_t id) {
+		for (size_t i = 0; i < batch.size(); ++i) {
+			ReadOut m;
+			for (int j = 0; j < n_parts; ++j) {
+				auto it = hits[j].find(id);
+				if (it == hits[j].end() || it->second.size() != batch.size()) return -1;
+				ReadOut &p = it->second[i];
+				if (p.rep_len > m.rep_len) m.rep_len = p.rep_len;
+				if (j == 0) m.frag_gap = p.frag_gap;
+				for (Reg &r : p.regs) { r.rid += rid_shift[j]; m.regs.push_back(std::move(r)); }
+				std::vector<Reg>().swap(p.regs);
+			}
+			hit_sort(m.regs);
+			set_parent(opt.mask_level, opt.mask_len, m.regs, opt.a * 2 + opt.b, (opt.flag & F_HARD_MLEVEL) != 0);
+			if (!(opt.flag & F_ALL_CHAINS)) {
+				select_sub(opt.pri_ratio, k * 2, opt.best_n, m.regs);
+				set_sam_pri(m.regs);
+			}
+			set_mapq(m.regs, opt.min_chain_score, opt.a, m.rep_len, (opt.flag & F_SR) != 0);
+			write_read(text, dict, batch[i], m, opt.flag);
+		}
+		return 0;
+	}, out, &fs, err);
+	if (st) { *st = fs; st->t_map += fs_all.t_map; st->t_read += fs_all.t_read; }
+	return rc;
 }
 
 } // namespace wm

@@ -29,5 +29,20 @@ struct FileStats { uint64_t n_reads = 0, n_bases = 0, n_batches = 0; double t_re
 // steady state covers. Records are written in input order whatever lane finishes first.
 typedef std::function<int(std::vector<ReadIn> &batch, std::string &text, int lane)> MapFn;
 int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_qual, const MapFn &map_fn, FILE *out, FileStats *st, std::string &err);
+// the same with the ordinal of the mini-batch (0, 1, …: the same reads file read again yields the same mini-batches in the same order)
+typedef std::function<int(std::vector<ReadIn> &batch, std::string &text, int lane, uint64_t batch_id)> MapFnId;
+int map_file_id(const std::string &reads_path, int64_t mini_batch_bases, bool with_qual, const MapFnId &map_fn, FILE *out, FileStats *st, std::string &err);
+
+// A reference indexed in several parts (`-I` smaller than the reference, `--split-prefix`; src/main.c:398-429): the reads are mapped against one
+// part after the other (begin_part(j) makes part j current — upload, mapper —, map_part maps one mini-batch against it), the hits of every read
+// are kept, and a last pass over the reads merges them exactly like mm_split_merge / merge_hits (src/map.c:1050-1105): part order, contig ids
+// shifted by the parts before, mm_hit_sort, mm_set_parent, mm_select_sub, mm_set_sam_pri, mm_set_mapq with the largest rep_len. `dict` = the
+// contigs of all parts in order (names and lengths only). The reference spills the per-part hits to <prefix>.NNNN.tmp files; here they stay in
+// memory. --cs / --MD are refused like the reference does (src/options.c:139-141).
+struct SplitPart { int n_seq; };
+int map_file_split(const std::string &reads_path, int64_t mini_batch_bases, const MapOpt &opt, int k, const Index &dict, const std::vector<SplitPart> &parts,
+                   const std::function<int(int part)> &begin_part,
+                   const std::function<int(int part, std::vector<ReadIn> &batch, std::vector<ReadOut> &out, int lane)> &map_part,
+                   FILE *out, FileStats *st, std::string &err);
 
 } // namespace wm

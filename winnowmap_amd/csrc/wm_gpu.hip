@@ -2655,6 +2655,84 @@ extern "C" int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *o
 	return WM_OK;
 }
 
+// ---- a reference indexed in parts (-I, --split-prefix; src/main.c:398-429, src/map.c:1050-1105, src/splitidx.c) ----
+extern "C" int wm_index_build_parts(const char *fasta, const char *kmer_file, int k, int w, int n_threads, uint64_t batch_bases, wm_index_t **out, int cap, int *n_parts)
+{
+	if (!fasta || !out || !n_parts || cap < 1 || batch_bases == 0) return set_err(WM_EINVAL, "bad argument");
+	*n_parts = 0;
+	wm::IdxOpt io; io.k = k; io.w = w;
+	wm::MapOpt mo; std::string err;
+	if (wm::check_opt(io, mo, err) < 0) return set_err(WM_EINVAL, "%s", err.c_str());
+	std::vector<wm::Index> parts;
+	const int n = wm::index_build_parts_from_fasta(io, fasta, kmer_file ? kmer_file : "", n_threads, batch_bases, parts, err);
+	if (n < 0) return set_err(WM_EINVAL, "%s", err.c_str());
+	if (n > cap) return set_err(WM_ENOMEM, "the reference has %d index parts, room for %d", n, cap);
+	for (int i = 0; i < n; ++i) { out[i] = new wm_index_t(); out[i]->ix = std::move(parts[i]); }
+	*n_parts = n;
+	return WM_OK;
+}
+
+// one mini-batch against the mapper's index, hits kept as they are (no records)
+static int map_reads_raw(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, std::vector<wm::ReadOut> &out, int slot)
+{
+	{
+		std::lock_guard<std::mutex> lk(m->stats_mu);
+		if (!m->ops) { m->ops.reset(new GpuOps()); std::vector<wm_ctx_t*> cs; cs.push_back(m->c); cs.insert(cs.end(), m->workers.begin(), m->workers.end()); m->ops->init(cs); }
+	}
+	GpuOps &ops = *m->ops;
+	wm::MapStats st;
+	hipSetDevice(m->c->device);
+	wm::map_batch(m->idx->ix, m->mo, &ops, reads, out, &st, m->n_threads, 0, slot);
+	for (GpuOpsCtx &x : ops.ctxs)
+		if (!x.error.empty()) { const int rc = set_err(WM_ENODEV, "%s", x.error.c_str()); x.error.clear(); return rc; }
+	{ std::string ie; if (wm::take_internal_error(ie)) return set_err(WM_EINTERNAL, "%s", ie.c_str()); }
+	return WM_OK;
+}
+
+extern "C" int wm_map_file_split(wm_ctx_t *c, int n_parts, wm_index_t *const *parts, const wm_mapopt_t *opt, int n_threads, const char *reads_path, const char *out_path,
+                                 int64_t mini_batch_bases, double *stats)
+{
+	g_err[0] = 0;
+	if (!c || n_parts < 1 || !parts || !opt || !reads_path || !out_path) return set_err(WM_EINVAL, "bad argument");
+	wm::MapOpt mo; wm::IdxOpt io;
+	wm::set_preset(0, io, mo);
+	mapopt_from_c(opt, mo);
+	wm::Index dict;                                                    // names and lengths of every contig, part after part (mm_split_merge_prep)
+	std::vector<wm::SplitPart> sp;
+	for (int j = 0; j < n_parts; ++j) {
+		if (!parts[j]) return set_err(WM_EINVAL, "null index part");
+		if (j == 0) { dict.k = parts[j]->ix.k; dict.w = parts[j]->ix.w; }
+		for (const wm::RefSeq &r : parts[j]->ix.seq) dict.seq.push_back(r);
+		sp.push_back(wm::SplitPart{ (int)parts[j]->ix.seq.size() });
+	}
+	FILE *out = strcmp(out_path, "-") == 0 ? stdout : fopen(out_path, "wb");
+	if (!out) return set_err(WM_EINVAL, "cannot open '%s' for writing", out_path);
+	if (mo.flag & 0x8) {                                               // SAM: the header lists every part's contigs (src/map.c:1296-1300)
+		std::string hdr;
+		wm::write_sam_header(hdr, dict, 0, 0);
+		fwrite(hdr.data(), 1, hdr.size(), out);
+	}
+	wm_mapper_t *m = 0;
+	wm::FileStats fs;
+	std::string err;
+	int rc_part = WM_OK;
+	const int rc = wm::map_file_split(reads_path, mini_batch_bases, mo, dict.k, dict, sp,
+		[&](int j) -> int {
+			if (m) { wm_mapper_destroy(m); m = 0; }
+			if (wm_index_upload(c, parts[j])) return -1;
+			if (wm_mapper_create_opt(c, parts[j], opt, &m)) return -1;
+			if (wm_mapper_set_threads(m, n_threads > 1 ? n_threads : 1, 0)) return -1;
+			return 0;
+		},
+		[&](int, std::vector<wm::ReadIn> &batch, std::vector<wm::ReadOut> &o, int lane) -> int { rc_part = map_reads_raw(m, batch, o, lane); return rc_part; },
+		out, &fs, err);
+	if (m) wm_mapper_destroy(m);
+	if (out != stdout) fclose(out);
+	if (stats) { stats[0] = (double)fs.n_reads; stats[1] = (double)fs.n_bases; stats[2] = (double)fs.n_batches; stats[3] = fs.t_read; stats[4] = fs.t_map; stats[5] = fs.t_write; }
+	if (rc) return g_err[0] ? (rc_part ? rc_part : WM_EINVAL) : set_err(WM_EINVAL, "%s", err.c_str());
+	return WM_OK;
+}
+
 extern "C" int wm_index_read_junc_bed(wm_index_t *idx, const char *path)
 {
 	if (!idx || !path) return set_err(WM_EINVAL, "null argument");

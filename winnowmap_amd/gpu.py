@@ -229,6 +229,50 @@ def write_repetitive_kmers_gpu(ctx, fasta, k, out_path, distinct=0.9998):
 _EXPORT_DTYPES = (np.uint32, np.uint64, np.uint64, np.uint64, np.uint8, np.uint64, np.uint8)
 
 
+class MapOpt(C.Structure):
+    """wm_mapopt_t (include/wm_gpu.h) = the mirrored fields of mm_mapopt_t, in that order"""
+    _fields_ = [("flag", C.c_int64)] + [(n, C.c_int32) for n in ("seed", "sdust_thres", "max_qlen", "bw", "max_gap", "max_gap_ref", "min_gap_ref", "max_frag_len",
+                                                                  "max_chain_skip", "max_chain_iter", "min_cnt", "min_chain_score")] + \
+               [("chain_gap_scale", C.c_float)] + [(n, C.c_int32) for n in ("SVaware", "SVawareMinReadLength", "suffixSampleOffset", "min_mapq")] + [("min_qcov", C.c_float)] + \
+               [(n, C.c_int32) for n in ("minPrefixLength", "maxPrefixLength")] + [("prefixIncrementFactor", C.c_float)] + \
+               [(n, C.c_int32) for n in ("stage2_bw", "stage2_zdrop_inv", "stage2_max_gap")] + [("mask_level", C.c_float), ("mask_len", C.c_int32), ("pri_ratio", C.c_float), ("best_n", C.c_int32)] + \
+               [(n, C.c_int32) for n in ("max_join_long", "max_join_short", "min_join_flank_sc")] + [("min_join_flank_ratio", C.c_float), ("alt_drop", C.c_float)] + \
+               [(n, C.c_int32) for n in ("a", "b", "q", "e", "q2", "e2", "sc_ambi", "zdrop", "zdrop_inv", "end_bonus", "min_dp_max", "min_ksw_len")] + \
+               [("max_clip_ratio", C.c_float), ("mid_occ_frac", C.c_float)] + [(n, C.c_int32) for n in ("min_mid_occ", "mid_occ", "max_occ")] + [("mini_batch_size", C.c_int64), ("max_sw_mat", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("noncan", "junc_bonus", "anchor_ext_len", "anchor_ext_shift")]
+
+
+def mapopt_preset(preset):
+    """wm_mapopt_preset = mm_set_opt(0) + mm_set_opt(preset): -> (MapOpt, k, w)"""
+    L = lib()
+    L.wm_mapopt_preset.argtypes = [C.c_char_p, C.POINTER(MapOpt), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    o = MapOpt(); k = C.c_int(); w = C.c_int()
+    _chk(L.wm_mapopt_preset((preset or "").encode(), C.byref(o), C.byref(k), C.byref(w)))
+    return o, k.value, w.value
+
+
+def build_index_parts(fasta, kmer_file, k, w, batch_bases, n_threads=8):
+    """wm_index_build_parts: the reference indexed in parts of `batch_bases` (the reference's -I) -> list of Index"""
+    L = lib()
+    _bind_map(L)
+    L.wm_index_build_parts.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]
+    cap = 4096
+    arr = (C.c_void_p * cap)()
+    n = C.c_int()
+    _chk(L.wm_index_build_parts(os.fsencode(fasta), os.fsencode(kmer_file) if kmer_file else None, k, w, n_threads, batch_bases, arr, cap, C.byref(n)))
+    return [Index(_handle=C.c_void_p(arr[i])) for i in range(n.value)]
+
+
+def map_file_split(ctx, parts, opt, n_threads, reads_path, out_path, mini_batch_bases=0):
+    """wm_map_file_split: the reads against every index part in turn, hits merged like `--split-prefix` (mm_split_merge)"""
+    L = lib()
+    L.wm_map_file_split.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(MapOpt), C.c_int, C.c_char_p, C.c_char_p, C.c_int64, C.c_void_p]
+    arr = (C.c_void_p * len(parts))(*[p._h for p in parts])
+    st = np.zeros(6, np.float64)
+    _chk(L.wm_map_file_split(ctx._h, len(parts), arr, C.byref(opt), n_threads, os.fsencode(reads_path), os.fsencode(out_path), mini_batch_bases, st.ctypes.data))
+    return dict(zip(("reads", "bases", "batches", "t_read", "t_map", "t_write"), (float(x) for x in st)))
+
+
 class Index:
     """Reference index (host build, mm_idx_gen semantics); `upload(ctx)` copies the flat arrays to HBM."""
 
