@@ -257,7 +257,7 @@ def test_splice_mode_with_a_junction_annotation_matches_the_reference_library():
 
 @need_ref
 def test_reference_indexed_in_parts_matches_split_prefix_of_the_reference_cli():
-    """wm_index_build_parts + wm_map_file_split against `winnowmap_ref -t 1 -I 400k --split-prefix …` (mm_split_merge, src/map.c:1050-1105):
+    """wm_index_build_parts + wm_map_file_split against `winnowmap_ref -t 1 -I 350k --split-prefix …` (mm_split_merge, src/map.c:1050-1105):
     six 200-kb contigs = three index parts, a 30-kb duplication across two parts, 120 reads; the merged records must be the reference's."""
     tmp = tempfile.mkdtemp()
     ref = synth.make_reference(6, 200000, 81, repeat_frac=0.08)
@@ -275,9 +275,9 @@ def test_reference_indexed_in_parts_matches_split_prefix_of_the_reference_cli():
         reads.append(synth.revcomp_codes(synth.mutate_codes(ref[5][s0 - 40000:s0 - 28000].copy(), rng, 0.03, 0.02, 0.02)))
     rq = os.path.join(tmp, "reads.fa")
     _write_reads(rq, reads)
-    want = _run(REF_BIN, ["-t", "1", "-I", "400k", "--split-prefix", os.path.join(tmp, "sp"), "-W", kf, "-cx", "map-ont", fa, rq])
+    want = _run(REF_BIN, ["-t", "1", "-I", "350k", "--split-prefix", os.path.join(tmp, "sp"), "-W", kf, "-cx", "map-ont", fa, rq])
     ctx = gpu.Context(0, 8 << 30)
-    parts = gpu.build_index_parts(fa, kf, 15, 50, 400000)
+    parts = gpu.build_index_parts(fa, kf, 15, 50, 350000)
     assert len(parts) == 3
     opt, _, _ = gpu.mapopt_preset("map-ont")
     opt.flag |= gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG
