@@ -89,8 +89,10 @@ extern "C" int __wrap_mm_map_file(const mm_idx_t *idx, const char *fn, const mm_
 {
 	const char *be = getenv("WM_BACKEND");
 	if (be && strcmp(be, "cpu") == 0) return __real_mm_map_file(idx, fn, opt, n_threads);
-	if (opt->flag & (MM_F_SPLICE | MM_F_SR | MM_F_FRAG_MODE) || opt->split_prefix) {
-		fprintf(stderr, "[wm_gpu] splice / short-read / multi-part modes are not covered by libwmgpu: using the CPU path\n");
+	if (opt->flag & (MM_F_SR | MM_F_FRAG_MODE) || opt->split_prefix) {
+		// (--split-prefix: the reference's main merges <prefix>.NNNN.tmp files that its own mm_map_file_frag writes; the library's twin of the whole
+		// flow is wm_index_build_parts + wm_map_file_split)
+		fprintf(stderr, "[wm_gpu] short-read / fragment / --split-prefix modes are not bound to libwmgpu: using the CPU path\n");
 		return __real_mm_map_file(idx, fn, opt, n_threads);
 	}
 	if (g_be.for_idx != idx && open_backend(idx, opt, n_threads)) {

@@ -64,6 +64,15 @@ def test_reference_cli_bound_to_the_library_prints_the_references_output():
         # the same binary on its CPU path (WM_BACKEND=cpu) is the reference (MAPQ / rl:i differ from run to run in the reference itself)
         if fmt == "-cx" and not extra:
             assert parity.diff_texts(want, _run(WM_BIN, args, env={"WM_BACKEND": "cpu"}), sam=False)["mismatches"] == 0
+    # splice mode through the same binding (every mm_mapopt_t field incl. noncan / junc_bonus / anchor_ext_* is handed over)
+    tr = synth.make_transcripts(ref, 60, 34)
+    fa2 = os.path.join(tmp, "ref2.fa")
+    synth.write_fasta(fa2, ref, prefix="chr")            # (make_transcripts planted splice signals in `ref`)
+    rq2 = os.path.join(tmp, "tr.fa")
+    _write_reads(rq2, tr, prefix="t")
+    args = ["-t", "4", "-cx", "splice", fa2, rq2]
+    d = parity.diff_texts(_run(REF_BIN, args), _run(WM_BIN, args), sam=False)
+    assert d["reads"] >= 50 and d["mismatches"] == 0, d
 
 
 def _at_scale(preset, k, w, ref, reads, kmer_list, threads=16):
