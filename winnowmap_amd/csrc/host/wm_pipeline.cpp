@@ -94,7 +94,11 @@ int map_file_id(const std::string &reads_path, int64_t mini_batch_bases, bool wi
 			const double t0 = now_s();
 			std::unique_ptr<std::string> text(new std::string());
 			int r = 0;
-			if (rc.load() == 0 && !io_error.load()) r = map_fn(b->reads, *text, lane, b->id);   // after an error: drain what the reader already queued
+			if (rc.load() == 0 && !io_error.load()) {                         // after an error: drain what the reader already queued
+				try { r = map_fn(b->reads, *text, lane, b->id); }
+				catch (const std::exception &e) { r = -1; std::lock_guard<std::mutex> lk(fs_mu); if (err.empty()) err = std::string("mapping failed: ") + e.what(); }
+				catch (...) { r = -1; }                                       // (a lane is a thread of its own: nothing may escape it)
+			}
 			if (r != 0) { int z = 0; rc.compare_exchange_strong(z, r); stop = true; std::lock_guard<std::mutex> lk(omu); ocv.notify_all(); }
 			uint64_t nb = 0;
 			for (const ReadIn &x : b->reads) nb += x.seq.size();
@@ -118,7 +122,7 @@ int map_file_id(const std::string &reads_path, int64_t mini_batch_bases, bool wi
 	writer.join();
 	if (st) *st = fs;
 	int ret = rc.load();
-	if (ret) err = "mapping failed";
+	if (ret && err.empty()) err = "mapping failed";
 	else if (io_error.load()) { err = "write error on the output file"; ret = -2; }
 	return ret;
 }
