@@ -24,11 +24,9 @@ def emu():
     return _load_emu()
 
 
-# kernel variants next to the library default (winnowmap_amd/build.py WM_KERNEL_DEFINES): same tests, same bar. "next" = the opt-in switches prepared
-# at the end of round 3 (lazy wave reduction in exact mode, edge track in the unclipped multi-wave instantiations); "readlane" (WM_KSW_ROR=0, the
-# round-2 neighbour exchange) and "greedy" (WM_KSW_EDGE_TRACK=0, the reference's own approximate-max track) are kept for tools/emu_fuzz.py
-KSW_VARIANTS = {"default": (), "next": ("WM_KSW_LAZY_RED=1", "WM_KSW_PMULTI_EDGE=1")}
-KSW_FUZZ_VARIANTS = dict(KSW_VARIANTS, readlane=("WM_KSW_ROR=0",), greedy=("WM_KSW_EDGE_TRACK=0",))
+# kernel variants next to the library default (winnowmap_amd/build.py WM_KERNEL_DEFINES): same tests, same bar. The default build has
+# WM_KSW_ROR=1 since round 3; "readlane" is the former default (neighbour values through v_readlane + scalar fill)
+KSW_VARIANTS = {"default": (), "readlane": ("WM_KSW_ROR=0",)}
 
 
 @pytest.fixture(scope="module", params=sorted(KSW_VARIANTS))

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import wmtest as W
 import kswcases
-from test_kernels_emu import _load_emu, emu_ksw, KSW_FUZZ_VARIANTS as KSW_VARIANTS
+from test_kernels_emu import _load_emu, emu_ksw, KSW_VARIANTS
 
 s0 = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 ns = int(sys.argv[2]) if len(sys.argv) > 2 else 20

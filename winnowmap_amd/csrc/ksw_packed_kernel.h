@@ -46,10 +46,6 @@
 #define WM_KSW_EDGE_TRACK 1   // 1: unclipped approximate-max jobs (the bulk of the gap fills) follow the hull's first lane instead of the reference's greedy
                               // track (same H at the end, see below) and skip the band terms of st0 / en0; 0: the round-3a code, for A/B runs
 #endif
-#ifndef WM_KSW_LAZY_RED
-#define WM_KSW_LAZY_RED 0     // 1 (measured in isolation only, profiles/r03t_*; not the default build of round 3): exact mode decides with two vector compares whether
-                              // a row can change the running maximum or trigger the z-drop, and reduces the row maximum over the wave only then
-#endif
 #include <type_traits>
 #include <utility>
 
@@ -411,11 +407,7 @@ WM_DEV void ksw_dp_packed(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 
 		if constexpr (EXACT) {   // ---- exact max: 32-bit wave maximum, then — only when it matters — the lane that reaches it
 			int max_H, max_t = en0;
-			bool quiet = false;                                            // the row neither beats ez_max nor can it z-drop: nothing to update
-			if (WM_KSW_LAZY_RED && r > 0) quiet = !any(hmax > ez_max) && !(zdrop >= 0 && !any(hmax >= ez_max - zdrop));
-			if (r > 0 && quiet) {
-				max_H = ez_max;                                            // (any value <= ez_max with ez_max - value <= zdrop leaves the state below untouched)
-			} else if (r > 0) {
+			if (r > 0) {
 				max_H = wave_max_i32(hmax);
 				// max_t is consumed by a new maximum (:src/ksw2.h:160-163) or by a z-drop test that can fire: ez_max - max_H > zdrop + l * e2 needs
 				// ez_max - max_H > zdrop (l >= 0). Every other row leaves it alone — most rows of a long extension.

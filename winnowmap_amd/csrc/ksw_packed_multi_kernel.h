@@ -26,11 +26,6 @@
 #endif
 #include "ksw_packed_kernel.h"
 
-#ifndef WM_KSW_PMULTI_EDGE
-#define WM_KSW_PMULTI_EDGE 0  // 1 (measured in isolation only, profiles/r03t_*; not the default build of round 3): the unclipped approximate-max instantiations follow the
-                              // hull's first lane like ksw_dp_packed does (one v_readlane in wavefront 0, nothing published, nothing replayed) and skip the band terms
-#endif
-
 namespace wmk {
 
 // LDS ints: xch 2 * NP * 4 | pub 2 * (2 * NWV + 4) | rb NP * (7 + 1) * 16   (NP = BP * NWV pairs)
@@ -106,11 +101,9 @@ WM_DEV void ksw_dp_pmulti(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 		int st0 = 0, en0 = tlen - 1;
 		if (st0 < r - qlen + 1) st0 = r - qlen + 1;
 		if (en0 > r) en0 = r;
-		if (CLIP || !WM_KSW_PMULTI_EDGE) {         // (CLIP = false: the band terms never bind, ksw_plan.h)
-			if (st0 < (r - w + 1) >> 1) st0 = (r - w + 1) >> 1;
-			if (en0 > (r + w) >> 1) en0 = (r + w) >> 1;
-			if (st0 > en0) { ez_zdropped = 1; break; }
-		}
+		if (st0 < (r - w + 1) >> 1) st0 = (r - w + 1) >> 1;
+		if (en0 > (r + w) >> 1) en0 = (r + w) >> 1;
+		if (st0 > en0) { ez_zdropped = 1; break; }
 		const int st = st0 / 16 * 16, en = (en0 + 16) / 16 * 16 - 1;
 		const int sched = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
 		const int par = r & 1, ppar = par ^ 1;
@@ -352,16 +345,6 @@ WM_DEV void ksw_dp_pmulti(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 				WM_IF(ln == 0) gst(pubr, V<int>(2 * NWV + 1), V<int>(h)); WM_END
 			}
 			WM_IF(ln == 0) gst(pubr, V<int>(2 * wv), V<int>((int)(unsigned)(kk & 0xffffffffLL))); gst(pubr, V<int>(2 * wv + 1), V<int>((int)(kk >> 32))); WM_END
-		} else if constexpr (!CLIP && WM_KSW_PMULTI_EDGE) {
-			// H at the end does not depend on the path when every lane of [st0, en0] is a DP cell (see ksw_dp_packed): follow lane st0, which lives in
-			// pair 0 = slot 0 of wavefront 0, thread st0 - base, low half. Only wavefront 0 writes the result, so only it keeps H0.
-			if (wv == 0) {
-				const int o = st0 - base;
-				const int rv = readlane(Vv[0], o), ru = readlane(U[0], o);
-				const int d = ((int)(short)((r < qlen ? rv : ru) & 0xffff)) >> 8;
-				H0 = r ? H0 + d : d - qe;
-				if (r == n_rows - 1) ez_score = H0;
-			}
 		} else {
 			int slot, half, thr;
 			if (last_H0_t >= base && last_H0_t < base + 128 * NP && owner(last_H0_t, slot, half, thr) == wv) { const int d = half_of(Vv, slot, half, thr) >> 8; WM_IF(ln == 0) gst(pubr, V<int>(2 * NWV + 2), V<int>(d)); WM_END }
@@ -387,8 +370,6 @@ WM_DEV void ksw_dp_pmulti(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 				if (zdrop >= 0 && ez_max - max_H > zdrop + l * e2) { ez_zdropped = 1; break; }
 			}
 			if (r == n_rows - 1 && en0 == tlen - 1) ez_score = gld(pubr, (long long)(2 * NWV));
-		} else if constexpr (!CLIP && WM_KSW_PMULTI_EDGE) {
-			// (nothing to replay: see above)
 		} else {
 			if (r > 0) {
 				const bool in0 = last_H0_t >= st0 && last_H0_t <= en0, in1 = last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0;
