@@ -113,7 +113,7 @@ int wm_ksw_ll_i16(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
  * non-canonical splice site, junc_bonus = the bonus of an annotated junction; flag = KSW_EZ_* incl. SPLICE_FOR 0x100, SPLICE_REV 0x200,
  * SPLICE_FLANK 0x400 (job.w and job.end_bonus are ignored: the reference's function has no band and no end bonus). junc: NULL, or
  * seqs_bytes bytes parallel to seqs whose entries at a job's target hold the junction bits of mm_idx_bed_junc (src/index.c:690-803).
- * CIGAR op 3 = N. Results, pool and errors as wm_ksw_batch. Not used by wm_map_reads (no splice mode in the host glue yet). */
+ * CIGAR op 3 = N. Results, pool and errors as wm_ksw_batch. wm_map_reads uses it for every alignment when MM_F_SPLICE is set. */
 int wm_ksw_exts2_batch(wm_ctx_t *ctx, const wm_ksw_score_t *sc, int noncan, int junc_bonus, int n_jobs, const wm_ksw_job_t *jobs,
                        const uint8_t *seqs, size_t seqs_bytes, const uint8_t *junc,
                        wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used);

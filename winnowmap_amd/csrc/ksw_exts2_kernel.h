@@ -13,8 +13,9 @@
 //   * the z-drop test ignores the diagonal distance (ksw_apply_zdrop with e = 0, :375), there is no end bonus / reach_end;
 //   * traceback bytes use the reference's own layout (state 0..3 | 0x08 | 0x10 | 0x20); ksw_exts2_backtrack_thread turns state 3 into N
 //     when long_thres > 0 (src/ksw2.h:119-151 with min_intron_len = long_thres).
-// STATUS: bit-exact against the oracle (which is pinned to the reference's function) on the wavefront emulator; reachable through
-// wm_ksw_exts2_batch; not yet run on a GPU and not used by the mapper (no splice mode in the host glue).
+// STATUS: bit-exact against the oracle (which is pinned to the reference's function) on the wavefront emulator and on the GPU
+// (tests/test_zz_exts2_gpu.py); serves every alignment of splice mode (DeviceOps::exts2_batch → wm_ksw_exts2_batch, tests/test_binding_gpu.py).
+// One wavefront per alignment, not tuned.
 #pragma once
 #ifndef WM_DEV
 #error "include simt.h before ksw_exts2_kernel.h"

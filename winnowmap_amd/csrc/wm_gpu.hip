@@ -892,7 +892,7 @@ extern "C" int wm_ksw_extd2(wm_ctx_t *c, int qlen, const uint8_t *query, int tle
 }
 
 // ---- ksw_exts2_sse (src/ksw2.h:63-64): the splice-aware extension as a batch. One wavefront per alignment, state in a global scratch
-// slab (ksw_exts2_kernel.h). Not used by the mapper (the host glue has no splice mode); validated on the wavefront emulator.
+// slab (ksw_exts2_kernel.h). Every alignment of splice mode goes through here (GpuOpsCtx::exts2_batch).
 __global__ __launch_bounds__(64) void ksw_exts2_kernel(wm_ksw_score_t sc, int noncan, int junc_bonus, const wm_ksw_djob_t *__restrict__ jobs,
                                                         const uint8_t *__restrict__ seqs, const uint8_t *__restrict__ junc, uint8_t *__restrict__ tb,
                                                         uint8_t *scratch, const uint64_t *__restrict__ scratch_off, wm_ksw_dres_t *__restrict__ res)
