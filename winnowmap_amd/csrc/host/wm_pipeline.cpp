@@ -46,7 +46,9 @@ int map_file_id(const std::string &reads_path, int64_t mini_batch_bases, bool wi
 	// finished mini-batches wait here for their turn: the file lists them in input order
 	std::mutex omu; std::condition_variable ocv;
 	std::map<uint64_t, std::unique_ptr<std::string>> done;
-	uint64_t next_out = 0; int lanes_running = 0;
+	const char *le = getenv("WM_MAP_LANES");
+	const int n_lanes = le && atoi(le) == 1 ? 1 : 2;
+	uint64_t next_out = 0; int lanes_running = n_lanes;                 // (set BEFORE the writer starts: it leaves when no lane is running and nothing is queued)
 	std::thread reader([&]() {
 		uint64_t id = 0;
 		for (;;) {
@@ -84,9 +86,6 @@ int map_file_id(const std::string &reads_path, int64_t mini_batch_bases, bool wi
 		}
 		if (out && (fflush(out) != 0 || ferror(out))) io_error = true;
 	});
-	const char *le = getenv("WM_MAP_LANES");
-	const int n_lanes = le && atoi(le) == 1 ? 1 : 2;
-	{ std::lock_guard<std::mutex> lk(omu); lanes_running = n_lanes; }
 	auto lane_fn = [&](int lane) {
 		for (;;) {
 			std::unique_ptr<Item> b = to_map.take();
