@@ -131,6 +131,13 @@ int wm_ksw_dev_fetch(wm_ctx_t *ctx, wm_ksw_dev_batch_t *b, wm_ksw_result_t *resu
 int wm_ksw_dev_stats(const wm_ksw_dev_batch_t *b, uint64_t *cells, uint64_t *tb_bytes, float *dp_ms, float *bt_ms);
 void wm_ksw_dev_free(wm_ctx_t *ctx, wm_ksw_dev_batch_t *b);
 
+/* Kernel routing knob (process-wide; results never depend on it): alignments of the 4-pair / 8-pair one-wavefront classes (traceback pitch <= 496 /
+ * <= 1008 lanes) with at least rows4 / rows8 DP rows (qlen + tlen - 1) run on the stripe-pipelined multi-wave kernel (csrc/ksw_stripe_kernel.h), like
+ * every wider hull does. 0 = never, < 0 = leave that threshold as it is; on = 0 switches the stripe classes off altogether (the barrier-per-row
+ * kernels of round 3), < 0 = leave. Defaults: WM_KSW_STRIPE_ROWS4 / WM_KSW_STRIPE_ROWS8 / WM_KSW_STRIPE from the environment. Not part of the
+ * reference's interface: tests force every job through every kernel with it, tools/ tune the thresholds. */
+void wm_ksw_set_routing(int on, int rows4, int rows8);
+
 /* Scalar drop-in with the reference's exact signature minus the kalloc handle (src/ksw2.h:60-61):
  * one alignment through the same kernels; cigar is malloc'd into *cigar_out (caller frees). */
 int wm_ksw_extd2(wm_ctx_t *ctx, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m,

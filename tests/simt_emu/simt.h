@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <pthread.h>
+#include <sched.h>
 
 #define WM_SIMT_EMU 1
 #define WM_DEV inline
@@ -215,5 +216,10 @@ inline V<int> mbcnt(uint64_t mask) { V<int> r; for (int i = 0; i < WAVE; ++i) r.
 
 inline V<int> vpopc64(const V<uint64_t> &m) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = __builtin_popcountll(m.v[i]); return r; }
 inline V<uint64_t> lanemask_lt() { V<uint64_t> r; for (int i = 0; i < WAVE; ++i) r.v[i] = ((uint64_t)1 << i) - 1; return r; }
+
+// cross-wavefront hand-over through LDS (one host thread per emulated wavefront): release / acquire atomics
+inline void lds_st_rel(int *p, long long i, int v) { if (exec_mask()) __atomic_store_n(p + i, v, __ATOMIC_SEQ_CST); }
+inline int lds_ld_acq(const int *p, long long i) { return __atomic_load_n(p + i, __ATOMIC_SEQ_CST); }
+inline void spin_pause() { sched_yield(); }
 
 } // namespace simt

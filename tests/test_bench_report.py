@@ -17,10 +17,11 @@ def _bench():
 def test_report_has_contract_keys_for_any_dominant_class():
     B = _bench()
     args = argparse.Namespace(steps=3, warmup=1, reads_per_step=16384, read_len=15000, ref_mb=250.0, config=2)
-    n_classes = 28                     # WM_KSW_NCLASS (winnowmap_amd/csrc/ksw_plan.h): what Mapper.kernel_stats() returns
+    n_classes = 44                     # WM_KSW_NCLASS (winnowmap_amd/csrc/ksw_plan.h): what Mapper.kernel_stats() returns
     zero = {k: (0.0, 0.0, 0) for k in range(n_classes)}
     assert B.ksw_class_name(0) == "ksw_dpp_kernel<4, false, false, false>" and B.ksw_class_name(14) == "ksw_dpp_kernel<8, true, false, true>"
     assert B.ksw_class_name(21) == "ksw_pmulti_kernel<4, 4>" and B.ksw_class_name(24) == "ksw_pmulti_kernel<4, 8>"
+    assert B.ksw_class_name(28) == "ksw_stripe_kernel<2, 4, false, false>" and B.ksw_class_name(28 + 2 * 4 + 3) == "ksw_stripe_kernel<4, 8, true, true>"
     for dom in range(n_classes):
         after = dict(zero)
         after[dom] = (500.0, 5e10, 40)

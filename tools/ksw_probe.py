@@ -47,12 +47,14 @@ for name, mean, w in (("ont300", 300, 751), ("ont150", 150, 751), ("ont600", 600
 # mapper (bench.py `classes`) separates what the kernel costs from what sharing the chip costs
 from winnowmap_amd import synth
 rng = np.random.default_rng(3)
-for name, L, njob, flag in (("p16_1500x", 1500, 256, 0x40), ("p16_1500a", 1500, 256, 0x08), ("blk_3000x", 3000, 96, 0x40), ("blk_3000a", 3000, 96, 0x08), ("blk2_6000x", 6000, 32, 0x40)):
+# ...ext_5000x: extensions inside the 751 band (8-pair class by pitch; long enough for the stripe kernel <2,4> by default routing)
+for name, L, njob, flag in (("p16_1500x", 1500, 256, 0x40), ("p16_1500a", 1500, 256, 0x08), ("blk_3000x", 3000, 96, 0x40), ("blk_3000a", 3000, 96, 0x08), ("blk2_6000x", 6000, 32, 0x40),
+                            ("ext_5000x", 5000, 256, 0x40), ("ext_5000a", 5000, 256, 0x08), ("ext_1500x", 1500, 1024, 0x40)):
     cases = []
     for it in range(njob):
         t = rng.integers(0, 4, L).astype(np.uint8)
         q = synth.mutate_codes(t, rng, 0.03, 0.03, 0.04)
-        cases.append((q, t, dict(w=L + 1, zdrop=400, end_bonus=-1, flag=flag)))
+        cases.append((q, t, dict(w=751 if name.startswith("ext") else L + 1, zdrop=400, end_bonus=-1, flag=flag)))
     jobs, seqs = gpu.pack_jobs(cases)
     b = ctx.ksw_prepare(sc, jobs, seqs)
     run(b)

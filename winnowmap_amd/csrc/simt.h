@@ -197,4 +197,24 @@ WM_DEV int mbcnt(uint64_t mask) { return (int)__builtin_amdgcn_mbcnt_hi((unsigne
 WM_DEV int vpopc64(uint64_t m) { return __builtin_popcountll(m); }                     // per lane
 WM_DEV uint64_t lanemask_lt() { return ((uint64_t)1 << (threadIdx.x & 63u)) - 1; }      // bits of the lanes below this one
 
+// ---- cross-wavefront hand-over through LDS without a barrier (ksw_stripe_kernel.h) --------------------------------------------
+// DS operations of one wavefront are issued and executed in order and LDS is one memory per CU, so "payload stores, then the stamp store"
+// by the writer and "stamp load, then payload loads" by the reader need no counter wait between them — only the compiler must keep the
+// order (volatile accesses + barriers). lds_st_rel: lane 0 stores a uniform value after everything before it; lds_ld_acq: a uniform load
+// that nothing after it may overtake. spin_pause: yield the issue slot while polling.
+WM_DEV void lds_st_rel(int *p, long long i, int v)
+{
+	asm volatile("" ::: "memory");
+	if ((threadIdx.x & 63u) == 0u) ((volatile int*)p)[i] = v;
+	asm volatile("" ::: "memory");
+}
+WM_DEV int lds_ld_acq(const int *p, long long i)
+{
+	asm volatile("" ::: "memory");
+	const int v = __builtin_amdgcn_readfirstlane(((const volatile int*)p)[i]);
+	asm volatile("" ::: "memory");
+	return v;
+}
+WM_DEV void spin_pause() { __builtin_amdgcn_s_sleep(1); }
+
 } // namespace simt

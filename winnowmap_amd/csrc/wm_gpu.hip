@@ -45,6 +45,7 @@ static inline double now_ms() { return std::chrono::duration<double, std::milli>
 #include "ksw_kernel.h"
 #include "ksw_packed_kernel.h"
 #include "ksw_packed_multi_kernel.h"
+#include "ksw_stripe_kernel.h"
 #include "ksw_exts2_kernel.h"
 #include "ksw_plan.h"
 #include "sketch_kernel.h"
@@ -152,6 +153,20 @@ __global__ __launch_bounds__(64 * NWV) void ksw_pmulti_kernel(wm_ksw_score_t sc,
 		if (jb.flag & KSW_F_APPROX_MAX) wmk::ksw_dp_pmulti<BP, NWV, CLIP, HASN, false>(sc, jb, qp, tp, tb, lds, res + j);
 		else wmk::ksw_dp_pmulti<BP, NWV, CLIP, HASN, true>(sc, jb, qp, tp, tb, lds, res + j);
 	}
+}
+
+// stripe classes (ksw_plan.h: WM_KSW_STRIPE..): NWV wavefronts per alignment, every wavefront a fixed stripe of 128 * BP target lanes in registers,
+// row-stamped messages through LDS instead of a barrier per row (ksw_stripe_kernel.h). Static LDS only (the rings: < 6 KB).
+template <int BP, int NWV, bool CLIP, bool HASN>
+__global__ __launch_bounds__(64 * NWV) void ksw_stripe_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
+                                                               const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res)
+{
+	WM_SETPRIO(2);
+	__shared__ int lds[wmk::ksw_stripe_lds<BP, NWV>::INTS];
+	const int j = order[blockIdx.x];
+	const wm_ksw_djob_t jb = jobs[j];
+	if (jb.flag & KSW_F_APPROX_MAX) wmk::ksw_dp_stripe<BP, NWV, CLIP, HASN, false>(sc, jb, seqs, tb, lds, res + j);
+	else wmk::ksw_dp_stripe<BP, NWV, CLIP, HASN, true>(sc, jb, seqs, tb, lds, res + j);
 }
 
 // operands of position jobs (wm_ksw_batch_pos): expand query and target of job blockIdx.x into the batch's sequence slab. Query = two-strand
@@ -443,6 +458,36 @@ template <int BP> static void launch_dpp(int variant, int n, hipStream_t s, cons
 	}
 }
 
+// WM_KSW_STRIPE_ROWS4 / WM_KSW_STRIPE_ROWS8: alignments of the 4- / 8-pair register classes with at least this many DP rows run on four wavefronts
+// (ksw_plan.h: wm_ksw_route); 0 = never. WM_KSW_STRIPE=0: no stripe classes at all (the round-3 kernels; A/B). wm_ksw_set_routing overrides.
+static std::atomic<int> g_stripe_on(-1), g_stripe_rows4(-1), g_stripe_rows8(-1);
+static int stripe_min_rows(int bp)
+{
+	if (g_stripe_on.load(std::memory_order_relaxed) < 0) {
+		g_stripe_rows4 = getenv("WM_KSW_STRIPE_ROWS4") ? std::max(0, atoi(getenv("WM_KSW_STRIPE_ROWS4"))) : 0;
+		g_stripe_rows8 = getenv("WM_KSW_STRIPE_ROWS8") ? std::max(0, atoi(getenv("WM_KSW_STRIPE_ROWS8"))) : 2048;
+		g_stripe_on = !(getenv("WM_KSW_STRIPE") && atoi(getenv("WM_KSW_STRIPE")) == 0);
+	}
+	return !g_stripe_on.load(std::memory_order_relaxed) ? 0 : bp == 4 ? g_stripe_rows4.load(std::memory_order_relaxed) : bp == 8 ? g_stripe_rows8.load(std::memory_order_relaxed) : 1;   // (bp == 0: are the stripe classes on at all)
+}
+extern "C" void wm_ksw_set_routing(int on, int rows4, int rows8)
+{
+	stripe_min_rows(0);
+	if (on >= 0) g_stripe_on = on != 0;
+	if (rows4 >= 0) g_stripe_rows4 = rows4;
+	if (rows8 >= 0) g_stripe_rows8 = rows8;
+}
+
+// variant = CLIP * 2 + HASN (0, 2, 3)
+template <int BP, int NWV> static void launch_stripe(int variant, int n, hipStream_t s, const wm_ksw_score_t &sc, const wm_ksw_djob_t *jobs, const int *order,
+                                                     const uint8_t *seqs, uint8_t *tb, wm_ksw_dres_t *res)
+{
+	dim3 g(n), b(64 * NWV);
+	if (variant & 1) hipLaunchKernelGGL((ksw_stripe_kernel<BP, NWV, true, true>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
+	else if (variant & 2) hipLaunchKernelGGL((ksw_stripe_kernel<BP, NWV, true, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
+	else hipLaunchKernelGGL((ksw_stripe_kernel<BP, NWV, false, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
+}
+
 // Plans one batch: kernel class, traceback pitch and arena offsets per job; uploads the job table and the operands. Operands are either
 // bytes (`jobs` + `seqs`: only the part of `seqs` the jobs refer to is uploaded) or positions in resident data (`pos`: expanded in HBM).
 static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs, const wm_ksw_job_t *jobs, const uint8_t *seqs, size_t seqs_bytes,
@@ -527,6 +572,7 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 		d.q_off = pos ? q_off : (uint32_t)(q_off - slab_lo); d.t_off = pos ? t_off : (uint32_t)(t_off - slab_lo);
 		int n_col;
 		d.klass = wm_ksw_classify(qlen, tlen, w, has_n, flag, &n_col);
+		if (stripe_min_rows(0)) d.klass = wm_ksw_route(d.klass, n_col, qlen, tlen, w, has_n, stripe_min_rows(4), stripe_min_rows(8));
 		d.n_col = n_col;
 		cells[i] = wm_ksw_cells(qlen, tlen, w, &bands[i]);
 	});
@@ -692,6 +738,7 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	// launch order: the classes with the longest single jobs first
 	int lorder[WM_KSW_NCLASS], nl = 0;
 	lorder[nl++] = WM_KSW_GENERIC; lorder[nl++] = WM_KSW_BLOCK3; lorder[nl++] = WM_KSW_BLOCK2; lorder[nl++] = WM_KSW_BLOCK;
+	for (int k = WM_KSW_NCLASS - 1; k >= WM_KSW_STRIPE; --k) lorder[nl++] = k;
 	for (int k = WM_KSW_BLOCK - 1; k >= 0; --k) lorder[nl++] = k;
 	for (int li = 0; li < nl; ++li) {
 		const int k = lorder[li];
@@ -719,6 +766,16 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 				const size_t lds = fixed + WM_KSW_BLK3_SEQ_LDS;
 				HIPCHK(hipFuncSetAttribute((const void*)ksw_block_kernel<WM_KSW_BLK2_K, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 				hipLaunchKernelGGL((ksw_block_kernel<WM_KSW_BLK2_K, 0>), dim3(nk), dim3(64 * WM_KSW_BLK_NWV), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, (int)WM_KSW_BLK3_SEQ_LDS, (int*)b->d_b3state, b->d_b3off);
+			}
+			continue;
+		}
+		if (k >= WM_KSW_STRIPE) {
+			const int var = (k - WM_KSW_STRIPE) & 3;
+			switch ((k - WM_KSW_STRIPE) >> 2) {
+			case 0: launch_stripe<2, 4>(var, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
+			case 1: launch_stripe<2, 8>(var, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
+			case 2: launch_stripe<4, 8>(var, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
+			default: launch_stripe<8, 8>(var, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
 			}
 			continue;
 		}

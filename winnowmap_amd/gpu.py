@@ -156,6 +156,13 @@ class KswDevBatch:
             self._h = None
 
 
+def set_ksw_routing(on=-1, rows4=-1, rows8=-1):
+    """wm_ksw_set_routing: which alignments run on the stripe-pipelined multi-wave kernels (results never depend on it)"""
+    lib().wm_ksw_set_routing.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib().wm_ksw_set_routing.restype = None
+    lib().wm_ksw_set_routing(on, rows4, rows8)
+
+
 def build_defines():
     """the kernel-variant defines the loaded library was compiled with (wm_build_defines)"""
     lib().wm_build_defines.restype = C.c_char_p
@@ -415,7 +422,7 @@ class Mapper:
 
     def kernel_stats(self):
         """per ksw kernel class: dict class -> (ms, cells, launches)"""
-        out = np.zeros(3 * 32, np.float64)
+        out = np.zeros(3 * 64, np.float64)
         n = C.c_int()
         lib().wm_mapper_kernel_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         _chk(lib().wm_mapper_kernel_stats(self._h, out.ctypes.data, len(out), C.byref(n)))
