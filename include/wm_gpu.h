@@ -261,6 +261,11 @@ int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *out_path, in
 /* argv of the calling front end: with MM_F_OUT_SAM, wm_map_file starts the file with the @SQ lines and the @PG line carrying this
  * command line, as mm_write_sam_hdr does before mapping (src/format.c:118-139, src/main.c:393). Optional (no CL: field without it). */
 int wm_mapper_set_cmdline(wm_mapper_t *m, int argc, const char *const *argv);
+/* The same for wm_map_file_split, which owns its mappers (one per index part): process-wide. The reference prints the @PG line (with CL:) when it meets
+ * the first of several index parts (mm_write_sam_hdr(0, ...), src/main.c:395) and the @SQ lines of every part in the merge pass (src/map.c:1304-1306):
+ * @PG comes first there, and so it does in wm_map_file_split's SAM output. argc < 0: the front end prints @PG itself (the reference's main does),
+ * wm_map_file_split then only lists the @SQ lines. */
+int wm_set_cmdline(int argc, const char *const *argv);
 /* All mapping options as plain data: the fields of mm_mapopt_t (src/minimap.h:112-175) this library honours, same names, same meaning, same
  * defaults (mm_mapopt_init / mm_set_opt, src/options.c:14-131). A front end that has parsed the reference's command line into an
  * mm_mapopt_t copies it field by field (oracle/wm_binding.cpp does exactly that inside the reference's own CLI).

@@ -7,7 +7,8 @@
 //   * the index the reference has just built (mm_idx_t) is handed over through the reference's own index file format (mm_idx_dump,
 //     src/index.c:515 → wm_index_load), the -W list through opt->kmer_freq_filename (the reference does not persist its bloom filter);
 //   * every field of mm_mapopt_t goes into wm_mapopt_t (same names), so presets AND individual command-line options carry over;
-//   * records are written by wm_map_file to stdout exactly where the reference writes them (the SAM header was printed by main already).
+//   * records are written by wm_map_file to stdout exactly where the reference writes them (the SAM header was printed by main already);
+//   * --split-prefix (a reference indexed in parts): mm_split_merge is wrapped as well and runs wm_map_file_split over the parts main presented.
 // WM_BACKEND=cpu in the environment runs the reference's own mm_map_file instead (A/B inside one binary).
 // tests/test_binding_gpu.py diffs `winnowmap_wm ...` against `winnowmap_ref ...`.
 #include <stdio.h>
@@ -19,6 +20,7 @@
 #include "../include/wm_gpu.h"
 
 extern "C" int __real_mm_map_file(const mm_idx_t *idx, const char *fn, const mm_mapopt_t *opt, int n_threads);
+extern "C" int __real_mm_split_merge(int n_segs, const char **fn, const mm_mapopt_t *opt, int n_split_idx);
 
 namespace {
 struct Backend {
@@ -49,19 +51,30 @@ void copy_opt(const mm_mapopt_t *o, wm_mapopt_t *w)
 #undef CP
 }
 
-int open_backend(const mm_idx_t *mi, const mm_mapopt_t *opt, int n_threads)
+// the reference's index -> the library's, through the reference's own index file format (mm_idx_dump, src/index.c:515)
+int take_index(const mm_idx_t *mi, const mm_mapopt_t *opt, wm_index_t **out)
 {
-	g_be.close();
-	if (wm_ctx_create(0, 0, &g_be.ctx)) return -1;                       // fails without a GPU: the library has no CPU path
 	char tmpl[] = "/tmp/wm_binding_XXXXXX";
 	const int fd = mkstemp(tmpl);
 	if (fd < 0) return -1;
 	FILE *fp = fdopen(fd, "wb");
-	mm_idx_dump(fp, mi);                                                 // src/index.c:515
+	mm_idx_dump(fp, mi);
 	fclose(fp);
-	const int rc = wm_index_load(tmpl, opt->kmer_freq_filename, &g_be.idx);
+	const int rc = wm_index_load(tmpl, opt->kmer_freq_filename, out);
 	unlink(tmpl);
-	if (rc) return -1;
+	return rc ? -1 : 0;
+}
+
+// --split-prefix (a reference indexed in parts, src/main.c:365-429): main calls mm_map_file once per index part and mm_split_merge at the end. Bound:
+// every part's index is taken over when main presents it (nothing is mapped yet, no <prefix>.NNNN.tmp is written), and the wrapped mm_split_merge
+// runs the library's twin of the whole flow, wm_map_file_split, over the parts.
+struct SplitState { std::vector<wm_index_t*> parts; std::vector<int> seen; int n_threads = 1; } g_split;       // seen: mm_idx_t::index, the part's ordinal
+
+int open_backend(const mm_idx_t *mi, const mm_mapopt_t *opt, int n_threads)
+{
+	g_be.close();
+	if (wm_ctx_create(0, 0, &g_be.ctx)) return -1;                       // fails without a GPU: the library has no CPU path
+	if (take_index(mi, opt, &g_be.idx)) return -1;
 	if (wm_index_upload(g_be.ctx, g_be.idx)) return -1;
 	if (mi->I) {                                                         // --junc-bed: main has read the annotation into the index (src/main.c:416)
 		// (mm_idx_intv_s is private to src/index.c:40-48; in-tree this would be an accessor next to mm_idx_bed_junc)
@@ -89,11 +102,18 @@ extern "C" int __wrap_mm_map_file(const mm_idx_t *idx, const char *fn, const mm_
 {
 	const char *be = getenv("WM_BACKEND");
 	if (be && strcmp(be, "cpu") == 0) return __real_mm_map_file(idx, fn, opt, n_threads);
-	if (opt->flag & (MM_F_SR | MM_F_FRAG_MODE) || opt->split_prefix) {
-		// (--split-prefix: the reference's main merges <prefix>.NNNN.tmp files that its own mm_map_file_frag writes; the library's twin of the whole
-		// flow is wm_index_build_parts + wm_map_file_split)
-		fprintf(stderr, "[wm_gpu] short-read / fragment / --split-prefix modes are not bound to libwmgpu: using the CPU path\n");
+	if (opt->flag & (MM_F_SR | MM_F_FRAG_MODE)) {
+		fprintf(stderr, "[wm_gpu] short-read / fragment modes are outside the library's path (single-segment long reads): using the CPU path\n");
 		return __real_mm_map_file(idx, fn, opt, n_threads);
+	}
+	if (opt->split_prefix) {                                             // one call per (index part, reads file): keep the part, map in mm_split_merge
+		if (g_split.seen.empty() || g_split.seen.back() != idx->index) {
+			wm_index_t *part = 0;
+			if (take_index(idx, opt, &part)) { fprintf(stderr, "[wm_gpu] %s\n", wm_last_error()); return -1; }
+			g_split.parts.push_back(part); g_split.seen.push_back(idx->index);
+		}
+		g_split.n_threads = n_threads;
+		return 0;
 	}
 	if (g_be.for_idx != idx && open_backend(idx, opt, n_threads)) {
 		fprintf(stderr, "[wm_gpu] %s\n", wm_last_error());
@@ -105,6 +125,28 @@ extern "C" int __wrap_mm_map_file(const mm_idx_t *idx, const char *fn, const mm_
 	if (rc) { fprintf(stderr, "[wm_gpu] %s\n", wm_last_error()); return -1; }
 	if (mm_verbose >= 3) fprintf(stderr, "[M::wm_gpu] mapped %.0f sequences (%.0f bases) in %.0f mini-batch(es) on the GPU\n", st[0], st[1], st[2]);
 	return 0;
+}
+
+extern "C" int __wrap_mm_split_merge(int n_segs, const char **fn, const mm_mapopt_t *opt, int n_split_idx)
+{
+	const char *be = getenv("WM_BACKEND");
+	if ((be && strcmp(be, "cpu") == 0) || g_split.parts.empty()) return __real_mm_split_merge(n_segs, fn, opt, n_split_idx);
+	wm_ctx_t *ctx = 0;
+	if (wm_ctx_create(0, 0, &ctx)) { fprintf(stderr, "[wm_gpu] %s\n", wm_last_error()); return -1; }
+	wm_mapopt_t wo;
+	copy_opt(opt, &wo);
+	wm_set_cmdline(-1, 0);                                               // main has printed the @PG line (mm_write_sam_hdr(0, ...), src/main.c:395)
+	fflush(stdout);
+	int rc = 0;
+	for (int i = 0; i < n_segs && !rc; ++i) {                            // (single-segment reads: one merged pass per reads file)
+		double st[6];
+		rc = wm_map_file_split(ctx, (int)g_split.parts.size(), g_split.parts.data(), &wo, g_split.n_threads > 1 ? g_split.n_threads : 1, fn[i], "-", opt->mini_batch_size, st);
+		if (rc) fprintf(stderr, "[wm_gpu] %s\n", wm_last_error());
+	}
+	for (wm_index_t *p : g_split.parts) wm_index_destroy(p);
+	g_split.parts.clear(); g_split.seen.clear();
+	wm_ctx_destroy(ctx);
+	return rc ? -1 : 0;
 }
 
 __attribute__((destructor)) static void wm_binding_fini() { g_be.close(); }

@@ -1,7 +1,8 @@
 """Generates the end-to-end golden fixtures by running the REAL reference (oracle/_ref, built from /root/reference)
 on seeded synthetic inputs. Run in the build container:  python tests/golden/make_golden.py
 The fixtures hold, per read, the reference's hits (rid rs re qs qe rev . n_cigar score cnt mlen blen dp_score dp_max
-dp_max2 flags; MAPQ zeroed because the reference itself does not reproduce it) and the CIGARs.
+dp_max2 flags; MAPQ kept for reads below the 10 kb MCAS gate and zeroed above it, where the reference does not reproduce it itself:
+uninitialised rep_len, src/map.c:281) and the CIGARs.
 The inputs are regenerated from the same seeds by the tests (winnowmap_amd/synth.py)."""
 import ctypes as C
 import os
@@ -54,7 +55,8 @@ def main():
             nc = C.c_int64()
             n = R.refshim_map(mi, opt, s, len(s), ("read%d" % i).encode(), h, 256, c, len(c), C.byref(nc))
             hh = h[:16 * n].reshape(-1, 16).copy()
-            hh[:, 6] = 0
+            if len(s) >= 10000:
+                hh[:, 6] = 0
             hits.append(hh)
             cigs.append(c[:nc.value].copy())
             first.append(first[-1] + n)

@@ -56,13 +56,27 @@ def test_gpus_n_without_gpus_fails_loudly():
     assert p.returncode != 0 and b"WORLD_SIZE=1" in p.stderr
 
 
-def test_parity_diff_masks_only_mapq_and_rl():
+def test_parity_diff_masks_mapq_and_rl_only_on_the_mcas_path():
     from winnowmap_amd import parity
-    ref = b"r1\t100\t0\t90\t+\tc\t1000\t5\t95\t80\t90\t60\ttp:A:P\trl:i:7\tcg:Z:90M\nr2\t50\t0\t40\t-\tc\t1000\t5\t45\t30\t40\t3\tcg:Z:40M\n"
-    ours = b"r2\t50\t0\t40\t-\tc\t1000\t5\t45\t30\t40\t0\tcg:Z:40M\nr1\t100\t0\t90\t+\tc\t1000\t5\t95\t80\t90\t0\ttp:A:P\trl:i:0\tcg:Z:90M\n"
+    # r1, r2: reads of >= 10 000 bases (the reference's MAPQ / rl:i come from an uninitialised rep_len there: masked); r4: below the gate (compared)
+    ref = (b"r1\t12000\t0\t90\t+\tc\t1000\t5\t95\t80\t90\t60\ttp:A:P\trl:i:7\tcg:Z:90M\nr2\t10000\t0\t40\t-\tc\t1000\t5\t45\t30\t40\t3\tcg:Z:40M\n"
+           b"r4\t9999\t0\t40\t-\tc\t1000\t5\t45\t30\t40\t33\trl:i:12\tcg:Z:40M\n")
+    ours = (b"r2\t10000\t0\t40\t-\tc\t1000\t5\t45\t30\t40\t0\tcg:Z:40M\nr1\t12000\t0\t90\t+\tc\t1000\t5\t95\t80\t90\t0\ttp:A:P\trl:i:0\tcg:Z:90M\n"
+            b"r4\t9999\t0\t40\t-\tc\t1000\t5\t45\t30\t40\t33\trl:i:12\tcg:Z:40M\n")
     d = parity.diff_texts(ref, ours)
-    assert d["mismatches"] == 0 and d["hits"] == 2 and d["reads"] == 2
+    assert d["mismatches"] == 0 and d["hits"] == 3 and d["reads"] == 3 and d["mapq_compared"] == 1
     d = parity.diff_texts(ref, ours.replace(b"cg:Z:90M", b"cg:Z:89M1I"))
     assert d["mismatches"] == 1 and d["examples"][0]["read"] == "r1"
     d = parity.diff_texts(ref, ours + b"r3\t50\t0\t40\t-\tc\t1000\t5\t45\t30\t40\t0\n")
     assert d["mismatches"] == 1
+    # below the gate a different MAPQ or rl:i is a mismatch; with mcas_gate=None (splice mode) it is one everywhere
+    assert parity.diff_texts(ref, ours.replace(b"\t33\trl:i:12", b"\t32\trl:i:12"))["mismatches"] == 1
+    assert parity.diff_texts(ref, ours.replace(b"rl:i:12", b"rl:i:11"))["mismatches"] == 1
+    assert parity.diff_texts(ref, ours, mcas_gate=None)["mismatches"] == 2
+    # SAM: the read length comes from the CIGAR incl. clips
+    assert parity.sam_query_len(b"5S90M3I2D10H") == 108
+    sam_ref = b"@SQ\tSN:c\tLN:1000\nq\t0\tc\t6\t60\t9000M1000S\t*\t0\t0\t*\t*\tNM:i:0\trl:i:5\nq2\t0\tc\t6\t17\t9000M\t*\t0\t0\t*\t*\tNM:i:0\n"
+    sam_our = b"q\t0\tc\t6\t0\t9000M1000S\t*\t0\t0\t*\t*\tNM:i:0\trl:i:0\nq2\t0\tc\t6\t17\t9000M\t*\t0\t0\t*\t*\tNM:i:0\n"
+    d = parity.diff_texts(sam_ref, sam_our, sam=True)
+    assert d["mismatches"] == 0 and d["mapq_compared"] == 1
+    assert parity.diff_texts(sam_ref, sam_our.replace(b"\t17\t", b"\t16\t"), sam=True)["mismatches"] == 1

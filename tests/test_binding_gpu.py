@@ -71,8 +71,8 @@ def test_reference_cli_bound_to_the_library_prints_the_references_output():
     rq2 = os.path.join(tmp, "tr.fa")
     _write_reads(rq2, tr, prefix="t")
     args = ["-t", "4", "-cx", "splice", fa2, rq2]
-    d = parity.diff_texts(_run(REF_BIN, args), _run(WM_BIN, args), sam=False)
-    assert d["reads"] >= 50 and d["mismatches"] == 0, d
+    d = parity.diff_texts(_run(REF_BIN, args), _run(WM_BIN, args), sam=False, mcas_gate=None)      # splice mode: MAPQ and rl:i compared on every record
+    assert d["reads"] >= 50 and d["mismatches"] == 0 and d["mapq_compared"] >= 50, d
 
 
 def _at_scale(preset, k, w, ref, reads, kmer_list, threads=16):
@@ -105,6 +105,18 @@ def test_parity_at_scale_config2_shape_ont():
     reads, _ = synth.make_reads(ref, 2048, 15000, 4, profile="ont", sv_frac=0.01)
     d, nh = _at_scale("map-ont", 15, 50, ref, reads, True)
     assert d["reads"] == 2048 and d["hits"] >= 2048 and d["mismatches"] == 0, d
+
+
+@need_ref
+def test_parity_below_the_mcas_gate_including_mapq():
+    """600 ONT reads of 1.5 .. 9.9 kb (below mm_mapopt_t::SVawareMinReadLength: the one-stage path, where the reference sets rep_len, src/map.c:859-861):
+    every PAF column INCLUDING MAPQ (mm_set_mapq, src/hit.c:463-508: fp32 + logf) and the rl:i tag against the reference binary, -W list, repeats, SVs."""
+    ref = synth.make_reference(2, 5_000_000, 13, repeat_frac=0.15)
+    reads = []
+    for i, L in enumerate((1500, 3000, 5000, 7000, 9000, 9999)):
+        reads += synth.make_reads(ref, 100, L, 14 + i, profile="ont", sv_frac=0.1)[0]
+    d, nh = _at_scale("map-ont", 15, 50, ref, reads, True)
+    assert d["reads"] == 600 and d["hits"] >= 600 and d["mismatches"] == 0 and d["mapq_compared"] >= 600, d
 
 
 @need_ref
@@ -183,7 +195,7 @@ def test_splice_mode_through_the_substituted_ksw_exts2():
     args = ["-t", "2", "-cx", "splice", fa, rq]
     want = _run(REF_BIN, args)
     got = _run(SUBST_BIN, args)
-    d = parity.diff_texts(want, got, sam=False)
+    d = parity.diff_texts(want, got, sam=False, mcas_gate=None)
     assert d["reads"] == 60 and d["hits"] >= 55 and d["mismatches"] == 0, d
     assert sum(1 for ln in got.decode().splitlines() if "N" in ln.split("cg:Z:")[-1].split("\t")[0]) >= 50
 
@@ -210,8 +222,8 @@ def test_splice_mode_of_the_mapper_matches_the_reference_cli():
         m = gpu.Mapper(ctx, idx, preset, gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
         m.set_threads(8, 4 << 30)
         text, hits, _, _ = m.map(names, seqs)
-        d = parity.diff_texts(want, text, sam=False)
-        assert d["reads"] >= 180 and d["hits"] >= 180 and d["mismatches"] == 0, (preset, d)
+        d = parity.diff_texts(want, text, sam=False, mcas_gate=None)              # MAPQ (mm_set_mapq, src/hit.c:463-508) and rl:i included
+        assert d["reads"] >= 180 and d["hits"] >= 180 and d["mismatches"] == 0 and d["mapq_compared"] >= 180, (preset, d)
         import re
         assert text.count(b"ts:A:+") > 20 and text.count(b"ts:A:-") > 20 and len(re.findall(rb"[0-9]N", text)) > 200
         m.close()
@@ -254,7 +266,6 @@ def test_splice_mode_with_a_junction_annotation_matches_the_reference_library():
         rh = np.zeros(16 * 256, np.int32); rc = np.zeros(400000, np.uint32); rnc = C.c_int64()
         rn = R.refshim_map(mi, opt, s, len(s), b"q", rh, 256, rc, len(rc), C.byref(rnc))
         ours = hits[first[i]:first[i + 1]].copy(); want = rh[:16 * rn].reshape(-1, 16).copy()
-        ours[:, 6] = 0; want[:, 6] = 0                                       # MAPQ: see winnowmap_amd/parity.py
         assert np.array_equal(ours, want), (i, ours.tolist(), want.tolist())
         c0 = int(hits[:first[i], 7].sum()); c1 = c0 + int(ours[:, 7].sum())
         assert np.array_equal(cigs[c0:c1], rc[:rnc.value]), i
@@ -294,7 +305,20 @@ def test_reference_indexed_in_parts_matches_split_prefix_of_the_reference_cli():
     st = gpu.map_file_split(ctx, parts, opt, 8, rq, outp)
     assert st["reads"] == len(reads)
     d = parity.diff_texts(want, open(outp, "rb").read(), sam=False)
-    assert d["reads"] >= 100 and d["hits"] >= 110 and d["mismatches"] == 0, d
+    assert d["reads"] >= 100 and d["hits"] >= 110 and d["mismatches"] == 0 and d["mapq_compared"] >= 26, d
     for p in parts:
         p.close()
     ctx.close()
+    # the same through the reference's own CLI bound to the library: main presents the parts, the wrapped mm_split_merge runs wm_map_file_split
+    # (oracle/wm_binding.cpp); PAF and SAM (header: @PG from main, then the @SQ lines of every part)
+    if os.path.exists(WM_BIN):
+        for fmt in ("-cx", "-ax"):
+            args = ["-t", "1", "-I", "350k", "--split-prefix", os.path.join(tmp, "sp2"), "-W", kf, fmt, "map-ont", fa, rq]
+            w2, g2 = _run(REF_BIN, args), _run(WM_BIN, args)
+            d = parity.diff_texts(w2, g2, sam=fmt == "-ax")
+            assert d["reads"] >= 100 and d["hits"] >= 110 and d["mismatches"] == 0, (fmt, d)
+            if fmt == "-ax":
+                hw = [l.split(b"\t")[0] for l in w2.split(b"\n") if l.startswith(b"@")]
+                hg = [l.split(b"\t")[0] for l in g2.split(b"\n") if l.startswith(b"@")]
+                assert hw == hg and hw[0] == b"@PG" and hw.count(b"@SQ") == 6, (hw, hg)
+                assert [l for l in w2.split(b"\n") if l.startswith(b"@SQ")] == [l for l in g2.split(b"\n") if l.startswith(b"@SQ")]

@@ -223,8 +223,16 @@ static std::mutex g_ie_mu;
 static std::string g_ie_msg;
 void note_internal_error(const char *expr, const char *file, int line)
 {
+	const char *b = strrchr(file, '/');
+	const std::string m = std::string("internal invariant violated: ") + expr + " (" + (b ? b + 1 : file) + ":" + std::to_string(line) + ")";
+	if (ErrorSink *sink = tl_error_sink()) { sink->put(m); return; }
 	std::lock_guard<std::mutex> lk(g_ie_mu);
-	if (g_ie_msg.empty()) { const char *b = strrchr(file, '/'); g_ie_msg = std::string("internal invariant violated: ") + expr + " (" + (b ? b + 1 : file) + ":" + std::to_string(line) + ")"; }
+	if (g_ie_msg.empty()) g_ie_msg = m;
+}
+void put_internal_error(const std::string &m)
+{
+	std::lock_guard<std::mutex> lk(g_ie_mu);
+	if (g_ie_msg.empty()) g_ie_msg = m;
 }
 bool take_internal_error(std::string &msg)
 {

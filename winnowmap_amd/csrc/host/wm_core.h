@@ -104,7 +104,12 @@ extern const uint8_t *const nt4_table;                                  // seq_n
 // Library code never aborts (include/wm_gpu.h: "integer return codes"): a violated internal invariant — the places where the
 // reference has assert() (src/align.c:166, :282, :645, :782) — is recorded here (first one wins) and surfaced by the C-ABI entry
 // point as WM_EINTERNAL after the batch.
+// Two mapping calls may run at once (wm_map_reads_slot): a worker thread of a call records into the call's own sink (installed by map_batch for
+// its workers); threads without one (a plain parallel_for helper) record into the process-wide slot that take_internal_error empties.
+struct ErrorSink { std::mutex mu; std::string msg; void put(const std::string &m) { std::lock_guard<std::mutex> lk(mu); if (msg.empty()) msg = m; } };
+inline ErrorSink *&tl_error_sink() { static thread_local ErrorSink *p = 0; return p; }
 void note_internal_error(const char *expr, const char *file, int line);
+void put_internal_error(const std::string &msg);     // an already formatted message into the process-wide slot
 bool take_internal_error(std::string &msg);          // true + message if one was recorded since the last call; clears it
 #define WM_INVARIANT(x) do { if (!(x)) ::wm::note_internal_error(#x, __FILE__, __LINE__); } while (0)
 

@@ -259,14 +259,22 @@ void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::v
 			if (on_read_done) (*on_read_done)(i);
 		}
 	};
+	ErrorSink sink;                                                      // this call's internal errors (two calls may share the process)
 	auto work = [&](int t) {
+		ErrorSink *const prev = tl_error_sink();
+		tl_error_sink() = &sink;
 		for (size_t k = 0; k < window; ++k) admit(t);
 		sch[t]->run();
+		tl_error_sink() = prev;
 	};
 	std::vector<std::thread> th;
 	for (int t = 1; t < T; ++t) th.emplace_back(work, t);
 	work(0);
 	for (auto &x : th) x.join();
+	if (!sink.msg.empty()) {
+		if (stats) stats->internal_error = sink.msg;
+		else put_internal_error(sink.msg);
+	}
 	if (stats) {
 		for (int op = 0; op < OP_N; ++op) stats->n_flush += hub.n_batches[op];
 		stats->n_ksw += hub.n_reqs[OP_KSW] + hub.n_reqs[OP_KSW_HEAVY] + hub.n_reqs[OP_KSW_HUGE]; stats->n_chain += hub.n_reqs[OP_CHAIN]; stats->n_seed += hub.n_reqs[OP_SEED];

@@ -17,6 +17,7 @@ struct MapStats {
 	uint64_t n_batches[4] = {0, 0, 0, 0};                  // batched device calls per operation (window = sketch → seed → chain in one call, seed, chain, ksw)
 	double cpu_fiber = 0, cpu_op[4] = {0, 0, 0, 0}, wall_op[4] = {0, 0, 0, 0}, wall_idle = 0, cpu_help = 0;
 	double wall_fiber = 0, wall_lock = 0, wall_total = 0;   // host time accounting (wm_fiber.h), seconds over all workers
+	std::string internal_error;                            // first violated invariant / exception of THIS call's workers (empty: none)
 };
 
 // Maps reads[i] → out[i] (out is resized). The caller chooses the batch (the reference uses ≤ 1 Gbase mini-batches).

@@ -175,6 +175,7 @@ int map_file_split(const std::string &reads_path, int64_t mini_batch_bases, cons
 				set_sam_pri(m.regs);
 			}
 			set_mapq(m.regs, opt.min_chain_score, opt.a, m.rep_len, (opt.flag & F_SR) != 0);
+			m.rep_len = 0;               // merge_hits keeps the merged rep_len in a local (src/map.c:1067) and never stores s->rep_len[k]: the records carry rl:i:0
 			write_read(text, dict, batch[i], m, opt.flag);
 		}
 		return 0;

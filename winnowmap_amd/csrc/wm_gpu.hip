@@ -2368,20 +2368,20 @@ struct GpuOpsCtx {
 // The product's DeviceOps: a pool of device contexts. Every batched call borrows a free context (its own HIP stream, arena and pinned
 // slab), so up to max_inflight() batches — of the same or of different operations — are on the device at once, issued by different
 // host threads (wm_fiber.h).
-struct GpuOps : wm::DeviceOps {
+struct GpuOps {                          // the device contexts of a mapper, shared by its (at most two concurrent) mapping calls: see CallOps
 	std::vector<GpuOpsCtx> ctxs;
 	std::vector<int> free_;
 	std::mutex mu;
 	std::condition_variable cv;
 	void init(const std::vector<wm_ctx_t*> &cs) { ctxs.resize(cs.size()); for (size_t i = 0; i < cs.size(); ++i) { ctxs[i].c = cs[i]; free_.push_back((int)i); } }
-	int max_inflight() const override { return (int)ctxs.size(); }
-	bool waits_asleep() const override { return getenv("WM_SPIN_SYNC") == 0; }
+	int max_inflight() const { return (int)ctxs.size(); }
+	bool waits_asleep() const { return getenv("WM_SPIN_SYNC") == 0; }
 	// The read codes of a mini-batch go to the device once. Two mini-batches can be in flight (two concurrent mapping calls, slots 0 and 1): one
 	// allocation of two slabs, owned by the first context and aliased by the others (one device); a call's offsets start at slot * slab.
 	std::mutex reads_mu;
 	size_t slab = 0;
 	bool slot_busy[2] = { false, false };
-	bool load_reads(const uint8_t *codes, size_t n, int slot, int64_t *base) override
+	bool load_reads(const uint8_t *codes, size_t n, int slot, int64_t *base, std::string &err)
 	{
 		*base = 0;
 		const bool off = getenv("WM_NO_RESIDENT") != 0;            // A/B switch: per-request staging as before
@@ -2402,26 +2402,32 @@ struct GpuOps : wm::DeviceOps {
 				c->d_reads = c0->d_reads; c->reads_bytes = c0->reads_bytes; c->reads_cap = 0; c->owns_reads = false;
 			}
 		}
-		if (n && hipMemcpy(c0->d_reads + (size_t)slot * slab, codes, n, hipMemcpyHostToDevice) != hipSuccess) { ctxs[0].fail("reads upload"); return false; }
+		if (n && hipMemcpy(c0->d_reads + (size_t)slot * slab, codes, n, hipMemcpyHostToDevice) != hipSuccess) { err = std::string("reads upload: ") + hipGetErrorString(hipGetLastError()); return false; }
 		for (GpuOpsCtx &x : ctxs) x.resident = true;
 		slot_busy[slot] = true;
 		*base = (int64_t)((size_t)slot * slab);
 		return true;
 	}
-	void release_reads(int slot) override { std::lock_guard<std::mutex> lk(reads_mu); if (slot >= 0 && slot <= 1) slot_busy[slot] = false; }
-	template <class F> void with(F f)
+	void release_reads(int slot) { std::lock_guard<std::mutex> lk(reads_mu); if (slot >= 0 && slot <= 1) slot_busy[slot] = false; }
+	// One batched call on a free context. A context belongs to exactly one call while it is out of the free list, so whatever the call leaves in
+	// the context's `error` is ITS error: it moves into the sink of the mapping call that issued the batch before the context is handed back
+	// (two mapping calls share the contexts, wm_map_reads_slot). A mapping call that has failed issues nothing more.
+	template <class F> void with(wm::ErrorSink &sink, F f)
 	{
+		{ std::lock_guard<std::mutex> lk(sink.mu); if (!sink.msg.empty()) return; }
 		int i;
 		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !free_.empty(); }); i = free_.back(); free_.pop_back(); }
+		ctxs[i].error.clear();
 		try { f(ctxs[i]); }
 		catch (const std::exception &e) { if (ctxs[i].error.empty()) ctxs[i].error = std::string("batched device call: ") + e.what(); }
+		if (!ctxs[i].error.empty()) { sink.put(ctxs[i].error); ctxs[i].error.clear(); }
 		{ std::lock_guard<std::mutex> lk(mu); free_.push_back(i); }
 		cv.notify_one();
 	}
 	// a batch whose buffers do not fit the context's arena is served in halves (recursively): the hub sizes batches by demand, not by HBM
 	template <class R, class F> static void run_split(GpuOpsCtx &x, std::vector<R*> &reqs, F f)
 	{
-		if (!x.error.empty()) return;          // an earlier call on this context failed for good: nothing more is attempted (and nothing is cleared)
+		if (!x.error.empty()) return;          // an earlier part of this call failed for good: nothing more is attempted (and nothing is cleared)
 		f(reqs);
 		if (x.error.empty() || reqs.size() < 2 || x.error.find("does not fit the arena") == std::string::npos) return;
 		x.error.clear();                       // (set by THIS call: the context was clean on entry)
@@ -2429,13 +2435,37 @@ struct GpuOps : wm::DeviceOps {
 		run_split(x, a, f);
 		if (x.error.empty()) run_split(x, b, f);
 	}
-	void sketch_batch(int w, int k, std::vector<wm::SketchReq*> &reqs) override { with([&](GpuOpsCtx &x) { run_split(x, reqs, [&](std::vector<wm::SketchReq*> &part) { x.sketch_batch(w, k, part); }); }); }
-	void seed_batch(std::vector<wm::SeedReq*> &reqs) override { with([&](GpuOpsCtx &x) { run_split(x, reqs, [&](std::vector<wm::SeedReq*> &part) { x.seed_batch(part); }); }); }
-	void chain_batch(std::vector<wm::ChainReq*> &reqs) override { with([&](GpuOpsCtx &x) { run_split(x, reqs, [&](std::vector<wm::ChainReq*> &part) { x.chain_batch(part); }); }); }
-	void ksw_batch(const wm_ksw_score_t &sc, std::vector<wm::KswReq*> &reqs) override { with([&](GpuOpsCtx &x) { x.ksw_batch(sc, reqs); }); }
-	void exts2_batch(const wm_ksw_score_t &sc, int noncan, int junc_bonus, std::vector<wm::KswReq*> &reqs) override { with([&](GpuOpsCtx &x) { x.exts2_batch(sc, noncan, junc_bonus, reqs); }); }
+	void sketch_batch(wm::ErrorSink &e, int w, int k, std::vector<wm::SketchReq*> &reqs) { with(e, [&](GpuOpsCtx &x) { run_split(x, reqs, [&](std::vector<wm::SketchReq*> &part) { x.sketch_batch(w, k, part); }); }); }
+	void seed_batch(wm::ErrorSink &e, std::vector<wm::SeedReq*> &reqs) { with(e, [&](GpuOpsCtx &x) { run_split(x, reqs, [&](std::vector<wm::SeedReq*> &part) { x.seed_batch(part); }); }); }
+	void chain_batch(wm::ErrorSink &e, std::vector<wm::ChainReq*> &reqs) { with(e, [&](GpuOpsCtx &x) { run_split(x, reqs, [&](std::vector<wm::ChainReq*> &part) { x.chain_batch(part); }); }); }
+	void ksw_batch(wm::ErrorSink &e, const wm_ksw_score_t &sc, std::vector<wm::KswReq*> &reqs) { with(e, [&](GpuOpsCtx &x) { x.ksw_batch(sc, reqs); }); }
+	void exts2_batch(wm::ErrorSink &e, const wm_ksw_score_t &sc, int noncan, int junc_bonus, std::vector<wm::KswReq*> &reqs) { with(e, [&](GpuOpsCtx &x) { x.exts2_batch(sc, noncan, junc_bonus, reqs); }); }
 	// collect_seed_hits takes one (max_occ, flag) per call: the mapper's requests of one mapping call all share them
-	void window_batch(int, int, std::vector<wm::WindowReq*> &reqs) override { with([&](GpuOpsCtx &x) { run_split(x, reqs, [&](std::vector<wm::WindowReq*> &part) { x.window_batch(part); }); }); }
+	void window_batch(wm::ErrorSink &e, std::vector<wm::WindowReq*> &reqs) { with(e, [&](GpuOpsCtx &x) { run_split(x, reqs, [&](std::vector<wm::WindowReq*> &part) { x.window_batch(part); }); }); }
+};
+
+// What ONE mapping call hands to wm::map_batch: the shared contexts behind it, and the call's own error sink — the first failed batch of this
+// call fails this call and no other (a per-context error field let the call that finished first take, and clear, its neighbour's).
+struct CallOps : wm::DeviceOps {
+	GpuOps &g;
+	wm::ErrorSink err;
+	explicit CallOps(GpuOps &g_) : g(g_) {}
+	int max_inflight() const override { return g.max_inflight(); }
+	bool waits_asleep() const override { return g.waits_asleep(); }
+	bool load_reads(const uint8_t *codes, size_t n, int slot, int64_t *base) override
+	{
+		std::string e;
+		const bool ok = g.load_reads(codes, n, slot, base, e);
+		if (!e.empty()) err.put(e);
+		return ok;
+	}
+	void release_reads(int slot) override { g.release_reads(slot); }
+	void sketch_batch(int w, int k, std::vector<wm::SketchReq*> &reqs) override { g.sketch_batch(err, w, k, reqs); }
+	void seed_batch(std::vector<wm::SeedReq*> &reqs) override { g.seed_batch(err, reqs); }
+	void chain_batch(std::vector<wm::ChainReq*> &reqs) override { g.chain_batch(err, reqs); }
+	void ksw_batch(const wm_ksw_score_t &sc, std::vector<wm::KswReq*> &reqs) override { g.ksw_batch(err, sc, reqs); }
+	void exts2_batch(const wm_ksw_score_t &sc, int noncan, int junc_bonus, std::vector<wm::KswReq*> &reqs) override { g.exts2_batch(err, sc, noncan, junc_bonus, reqs); }
+	void window_batch(int, int, std::vector<wm::WindowReq*> &reqs) override { g.window_batch(err, reqs); }
 };
 
 struct wm_mapper_s {
@@ -2453,11 +2483,21 @@ struct wm_mapper_s {
 	std::vector<std::string> cmdline;      // argv of the front end, for the @PG line of SAM files (wm_mapper_set_cmdline)
 };
 
+// what the mapper's device path cannot serve is refused when the mapper is made, not in the middle of a mapping call: an index built with
+// homopolymer compression (MM_I_HPC = 1, -H: src/sketch.c:152-163 is not implemented by the device sketch — silently sketching the reads without it
+// would seed nothing) and even k (the fused window call sketches with sketch_coop, which relies on k-mer != reverse complement, src/sketch.c:189)
+static int mapper_index_ok(const wm_index_t *idx)
+{
+	if (idx->ix.flag & 1) return set_err(WM_EINVAL, "the index was built with homopolymer compression (-H, MM_I_HPC): not supported by the device path");
+	if (!(idx->ix.k & 1)) return set_err(WM_EINVAL, "k = %d: the mapper's device path needs an odd k (every preset of the reference has one)", idx->ix.k);
+	return WM_OK;
+}
 extern "C" int wm_mapper_create(wm_ctx_t *c, const wm_index_t *idx, const char *preset, int64_t flag, wm_mapper_t **out)
 {
 	*out = 0;
 	if (!c || !idx) return set_err(WM_EINVAL, "null argument");
 	if (!c->have_index) return set_err(WM_EINVAL, "wm_index_upload has not been called on this context");
+	if (mapper_index_ok(idx)) return WM_EINVAL;
 	wm_mapper_t *m = new wm_mapper_t();
 	m->c = c; m->idx = idx;
 	wm::set_preset(0, m->io, m->mo);
@@ -2507,6 +2547,7 @@ extern "C" int wm_mapper_create_opt(wm_ctx_t *c, const wm_index_t *idx, const wm
 	*out = 0;
 	if (!c || !idx || !opt) return set_err(WM_EINVAL, "null argument");
 	if (!c->have_index) return set_err(WM_EINVAL, "wm_index_upload has not been called on this context");
+	if (mapper_index_ok(idx)) return WM_EINVAL;
 	wm_mapper_t *m = new wm_mapper_t();
 	m->c = c; m->idx = idx;
 	wm::set_preset(0, m->io, m->mo);
@@ -2625,10 +2666,11 @@ static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double
 	// records are formatted by the worker that finishes a read, while the other reads are still being mapped
 	std::vector<std::string> texts(n);
 	const std::function<void(size_t)> fmt = [&](size_t i) { wm::write_read(texts[i], m->idx->ix, reads[i], out[i], m->mo.flag); };
-	wm::map_batch(m->idx->ix, m->mo, &ops, reads, out, &st, m->n_threads, &fmt, slot);
-	for (GpuOpsCtx &x : ops.ctxs)
-		if (!x.error.empty()) { const int rc = set_err(WM_ENODEV, "%s", x.error.c_str()); x.error.clear(); return rc; }
-	{ std::string ie; if (wm::take_internal_error(ie)) return set_err(WM_EINTERNAL, "%s", ie.c_str()); }
+	CallOps call(ops);                       // this call's view of the shared contexts: its failed batches fail this call, nobody else's
+	wm::map_batch(m->idx->ix, m->mo, &call, reads, out, &st, m->n_threads, &fmt, slot);
+	if (!call.err.msg.empty()) return set_err(WM_ENODEV, "%s", call.err.msg.c_str());
+	if (!st.internal_error.empty()) return set_err(WM_EINTERNAL, "%s", st.internal_error.c_str());
+	{ std::string ie; if (wm::take_internal_error(ie)) return set_err(WM_EINTERNAL, "%s", ie.c_str()); }      // (recorded by a thread outside any call's team)
 	GpuOpsCtx tot; tot.c = m->c;
 	for (GpuOpsCtx &x : ops.ctxs) { tot.cells += x.cells; tot.ksw_us += x.ksw_us; tot.aux_us += x.aux_us; }
 	tot.cells -= cells0; tot.ksw_us -= ksw_us0; tot.aux_us -= aux_us0;
@@ -2679,12 +2721,32 @@ static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double
 // reference's default 1 Gbase), maps them and writes the records to out_path ("-" = stdout), reader / mapper / writer
 // overlapped. Every mini-batch is ordered like the reference orders it, so the file equals the reference's output.
 // stats (optional, 6 doubles): reads, bases, batches, seconds spent reading / mapping / writing.
+// the command line for the @PG line of wm_map_file_split (no mapper object outlives its parts); wm_mapper_set_cmdline stores it here as well
+static std::mutex g_cmdline_mu;
+static std::vector<std::string> g_cmdline;
+static bool g_split_pg = true;              // wm_map_file_split prints the @PG line itself
+extern "C" int wm_set_cmdline(int argc, const char *const *argv)
+{
+	if (argc > 0 && !argv) return set_err(WM_EINVAL, "bad argument");
+	std::lock_guard<std::mutex> lk(g_cmdline_mu);
+	g_split_pg = argc >= 0;                  // argc < 0: the front end has printed @PG already (the reference's main does, src/main.c:395)
+	g_cmdline.clear();
+	if (argc > 0) g_cmdline.assign(argv, argv + argc);
+	return WM_OK;
+}
 extern "C" int wm_mapper_set_cmdline(wm_mapper_t *m, int argc, const char *const *argv)
 {
 	if (!m || argc < 0 || (argc > 0 && !argv)) return set_err(WM_EINVAL, "bad argument");
 	m->cmdline.assign(argv, argv + argc);
 	return WM_OK;
 }
+
+// wm_last_error is per thread and the second mapping lane of the file loops is a thread of its own: a lane keeps the code and message of its
+// failed call here and the entry point re-issues them on the caller's thread (ENODEV / ENOMEM of lane 1 used to surface as "mapping failed")
+struct LaneError {
+	std::mutex mu; int code = 0; std::string msg;
+	void keep(int rc) { std::lock_guard<std::mutex> lk(mu); if (!code) { code = rc; msg = g_err; } }
+};
 
 extern "C" int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *out_path, int64_t mini_batch_bases, double *stats)
 {
@@ -2701,14 +2763,16 @@ extern "C" int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *o
 	}
 	wm::FileStats fs;
 	const bool with_qual = (m->mo.flag & 0x8) != 0;                    // SAM output prints QUAL
+	LaneError le;
 	const int rc = wm::map_file(reads_path, mini_batch_bases, with_qual, [&](std::vector<wm::ReadIn> &batch, std::string &text, int lane) {
 		const int r = map_reads_impl(m, batch, now_ms(), lane);             // (two mini-batches in flight: lane = result slot = slab of resident read codes)
 		if (r == 0) text.swap(m->res[lane].text);
+		else le.keep(r);
 		return r;
 	}, out, &fs, err);
 	if (out != stdout) fclose(out);
 	if (stats) { stats[0] = (double)fs.n_reads; stats[1] = (double)fs.n_bases; stats[2] = (double)fs.n_batches; stats[3] = fs.t_read; stats[4] = fs.t_map; stats[5] = fs.t_write; }
-	if (rc) return g_err[0] ? rc : set_err(WM_EINVAL, "%s", err.c_str());
+	if (rc) return le.code ? set_err(le.code, "%s", le.msg.c_str()) : set_err(WM_EINVAL, "%s", err.c_str());
 	return WM_OK;
 }
 
@@ -2739,9 +2803,10 @@ static int map_reads_raw(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, std::ve
 	GpuOps &ops = *m->ops;
 	wm::MapStats st;
 	hipSetDevice(m->c->device);
-	wm::map_batch(m->idx->ix, m->mo, &ops, reads, out, &st, m->n_threads, 0, slot);
-	for (GpuOpsCtx &x : ops.ctxs)
-		if (!x.error.empty()) { const int rc = set_err(WM_ENODEV, "%s", x.error.c_str()); x.error.clear(); return rc; }
+	CallOps call(ops);
+	wm::map_batch(m->idx->ix, m->mo, &call, reads, out, &st, m->n_threads, 0, slot);
+	if (!call.err.msg.empty()) return set_err(WM_ENODEV, "%s", call.err.msg.c_str());
+	if (!st.internal_error.empty()) return set_err(WM_EINTERNAL, "%s", st.internal_error.c_str());
 	{ std::string ie; if (wm::take_internal_error(ie)) return set_err(WM_EINTERNAL, "%s", ie.c_str()); }
 	return WM_OK;
 }
@@ -2764,15 +2829,23 @@ extern "C" int wm_map_file_split(wm_ctx_t *c, int n_parts, wm_index_t *const *pa
 	}
 	FILE *out = strcmp(out_path, "-") == 0 ? stdout : fopen(out_path, "wb");
 	if (!out) return set_err(WM_EINVAL, "cannot open '%s' for writing", out_path);
-	if (mo.flag & 0x8) {                                               // SAM: the header lists every part's contigs (src/map.c:1296-1300)
-		std::string hdr;
-		wm::write_sam_header(hdr, dict, 0, 0);
-		fwrite(hdr.data(), 1, hdr.size(), out);
+	if (mo.flag & 0x8) {
+		// SAM: the reference's main prints @PG (with CL:) when it sees the first of several parts (mm_write_sam_hdr(0, ...), src/main.c:395); the merge
+		// pass then lists every part's contigs (src/map.c:1304-1306) — @PG first, @SQ after it
+		std::string hdr, sq;
+		wm::Index none;
+		std::vector<const char*> av;
+		bool with_pg;
+		{ std::lock_guard<std::mutex> lk(g_cmdline_mu); for (const std::string &a : g_cmdline) av.push_back(a.c_str()); with_pg = g_split_pg; }
+		if (with_pg) wm::write_sam_header(hdr, none, (int)av.size(), av.data());
+		wm::write_sam_header(sq, dict, 0, 0);
+		hdr += sq.substr(0, sq.rfind("@PG"));
+		if (fwrite(hdr.data(), 1, hdr.size(), out) != hdr.size()) { if (out != stdout) fclose(out); return set_err(WM_EINVAL, "write error on '%s'", out_path); }
 	}
 	wm_mapper_t *m = 0;
 	wm::FileStats fs;
 	std::string err;
-	int rc_part = WM_OK;
+	LaneError le;
 	const int rc = wm::map_file_split(reads_path, mini_batch_bases, mo, dict.k, dict, sp,
 		[&](int j) -> int {
 			if (m) { wm_mapper_destroy(m); m = 0; }
@@ -2781,12 +2854,12 @@ extern "C" int wm_map_file_split(wm_ctx_t *c, int n_parts, wm_index_t *const *pa
 			if (wm_mapper_set_threads(m, n_threads > 1 ? n_threads : 1, 0)) return -1;
 			return 0;
 		},
-		[&](int, std::vector<wm::ReadIn> &batch, std::vector<wm::ReadOut> &o, int lane) -> int { rc_part = map_reads_raw(m, batch, o, lane); return rc_part; },
+		[&](int, std::vector<wm::ReadIn> &batch, std::vector<wm::ReadOut> &o, int lane) -> int { const int r = map_reads_raw(m, batch, o, lane); if (r) le.keep(r); return r; },
 		out, &fs, err);
 	if (m) wm_mapper_destroy(m);
 	if (out != stdout) fclose(out);
 	if (stats) { stats[0] = (double)fs.n_reads; stats[1] = (double)fs.n_bases; stats[2] = (double)fs.n_batches; stats[3] = fs.t_read; stats[4] = fs.t_map; stats[5] = fs.t_write; }
-	if (rc) return g_err[0] ? (rc_part ? rc_part : WM_EINVAL) : set_err(WM_EINVAL, "%s", err.c_str());
+	if (rc) return le.code ? set_err(le.code, "%s", le.msg.c_str()) : g_err[0] ? WM_EINVAL : set_err(WM_EINVAL, "%s", err.c_str());
 	return WM_OK;
 }
 

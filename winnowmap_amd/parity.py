@@ -1,16 +1,49 @@
 """Text-level parity of PAF / SAM records against the reference binary's output (bench.py's `parity` block and the
-at-scale GPU tests). Compared: every column and tag except MAPQ and `rl:i` (the reference computes both from an
-uninitialised `rep_len` on the MCAS stage-2 path, /root/reference/src/map.c:281, so it does not reproduce them itself),
-the MAPQ field inside SA:Z, and the @PG header line. Records are grouped by read name, so the two texts may list the
-reads in different orders (the reference prints a mini-batch longest read first, src/map.c:1124-1143); inside a read
-the order of the records must agree."""
+at-scale GPU tests). Compared: every column and tag. MAPQ, `rl:i` and the MAPQ field inside SA:Z are masked ONLY for reads the
+reference maps through its two-stage MCAS procedure — reads of at least `mcas_gate` bases (mm_mapopt_t::SVawareMinReadLength,
+10 000 by default) outside splice mode: there `mm_set_mapq` (/root/reference/src/hit.c:463-508) is fed an uninitialised `rep_len`
+(src/map.c:281, never assigned on that path, read at :933), so the reference does not reproduce the two fields itself. Below the
+gate (src/map.c:859-861 sets rep_len) and in splice mode every field is compared. The @PG header line is never compared. Records
+are grouped by read name, so the two texts may list the reads in different orders (the reference prints a mini-batch longest read
+first, src/map.c:1124-1143); inside a read the order of the records must agree."""
+
+MCAS_GATE = 10000
 
 
-def mask_record(line, sam):
-    """One output line with the non-reproducible fields removed; None for header lines that are not compared."""
+def sam_query_len(cigar):
+    """length of the whole read from a SAM CIGAR (M I S H = X consume the read; hard clips count: the read is longer than SEQ)"""
+    n = tot = 0
+    for ch in cigar:
+        if 48 <= ch <= 57:
+            n = n * 10 + ch - 48
+        else:
+            if ch in b"MISH=X":
+                tot += n
+            n = 0
+    return tot
+
+
+def record_query_len(f, sam):
+    """read length of a split record (None if it cannot be told: an unmapped SAM record gives len(SEQ))"""
+    try:
+        if not sam:
+            return int(f[1])
+        if f[5] == b"*":
+            return len(f[9]) if f[9] != b"*" else None
+        return sam_query_len(f[5])
+    except (IndexError, ValueError):
+        return None
+
+
+def mask_record(line, sam, mcas_gate=MCAS_GATE):
+    """One output line with the non-reproducible fields removed; None for header lines that are not compared.
+    mcas_gate: reads at least this long have MAPQ / rl:i masked; None: nothing is masked (splice mode, or MCAS switched off)."""
     if sam and line.startswith(b"@"):
         return None
     f = line.rstrip(b"\n").split(b"\t")
+    qlen = record_query_len(f, sam)
+    if mcas_gate is None or (qlen is not None and qlen < mcas_gate):
+        return b"\t".join(f)
     if sam:
         if len(f) > 4:
             f[4] = b"*"
@@ -26,12 +59,12 @@ def mask_record(line, sam):
     return b"\t".join(out)
 
 
-def group_by_read(text, sam=False):
+def group_by_read(text, sam=False, mcas_gate=MCAS_GATE):
     g = {}
     for line in text.split(b"\n"):
         if not line:
             continue
-        m = mask_record(line, sam)
+        m = mask_record(line, sam, mcas_gate)
         if m is None:
             continue
         name = m[:m.index(b"\t")] if b"\t" in m else m
@@ -39,16 +72,22 @@ def group_by_read(text, sam=False):
     return g
 
 
-def diff_texts(ref_text, our_text, sam=False, max_examples=3):
-    """-> dict(reads, hits, mismatches, cigar_ops, examples): `mismatches` counts reads whose record lists differ in any way."""
-    a = group_by_read(ref_text, sam)
-    b = group_by_read(our_text, sam)
+def diff_texts(ref_text, our_text, sam=False, max_examples=3, mcas_gate=MCAS_GATE):
+    """-> dict(reads, hits, mismatches, mapq_compared, examples): `mismatches` counts reads whose record lists differ in any way;
+    `mapq_compared` = records of the reference whose MAPQ (and rl:i) took part in the comparison."""
+    a = group_by_read(ref_text, sam, mcas_gate)
+    b = group_by_read(our_text, sam, mcas_gate)
     mism = 0
     hits = 0
+    with_mapq = 0
+    col = 4 if sam else 11
     examples = []
     for name in a.keys() | b.keys():
         ra, rb = a.get(name, []), b.get(name, [])
         hits += len(ra)
+        for rec in ra:
+            f = rec.split(b"\t")
+            with_mapq += len(f) > col and f[col] != b"*"
         if ra != rb:
             mism += 1
             if len(examples) < max_examples:
@@ -56,4 +95,4 @@ def diff_texts(ref_text, our_text, sam=False, max_examples=3):
                 examples.append({"read": name.decode(errors="replace"), "n_ref": len(ra), "n_ours": len(rb),
                                  "ref": (ra[k][:300].decode(errors="replace") if k < len(ra) else None),
                                  "ours": (rb[k][:300].decode(errors="replace") if k < len(rb) else None)})
-    return {"reads": len(a.keys() | b.keys()), "hits": hits, "mismatches": mism, "examples": examples}
+    return {"reads": len(a.keys() | b.keys()), "hits": hits, "mismatches": mism, "mapq_compared": with_mapq, "examples": examples}
