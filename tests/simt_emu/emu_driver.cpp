@@ -143,7 +143,7 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 		klass = (force_klass & 3) | ((flag & 0x08) ? 0 : 4);
 	}
 	if (emu_stripe) {
-		static const int max_ncol[8] = { 128 + 16, 2 * 128 + 16, 2 * 256 + 16, 3 * 256 + 16, 3 * 512 + 16, 7 * 512 + 16, 7 * 1024 + 16, 3 * 128 + 16 };
+		static const int max_ncol[8] = { 128, 2 * 128, 2 * 256, 3 * 256, 3 * 512, 7 * 512, 7 * 1024, 3 * 128 };
 		n_col = wm_ksw_ncol(qlen, tlen, w);
 		if (n_col > max_ncol[emu_stripe - 1]) return -1;
 		const int has_n = wm_ksw_has_n(query, qlen) | wm_ksw_has_n(target, tlen);

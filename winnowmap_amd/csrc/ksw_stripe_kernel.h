@@ -4,7 +4,7 @@
 // Why it can be barrier-free: in the anti-diagonal recurrence cell (r, t) reads lane t and lane t - 1 of row r - 1, nothing else — data only
 // flows from lower to higher target lanes. So the target is cut into STRIPES of SW = 128 * BP lanes in absolute coordinates; stripe s
 // (lanes s * SW ..) lives in the registers of wavefront s % NWV for as long as the 16-aligned band hull [st, en] touches it (the hull is at
-// most (NWV - 1) * SW + 16 lanes wide, so a wavefront is done with stripe s before stripe s + NWV is reached) and is never re-based. The only
+// most (NWV - 1) * SW lanes wide, so a wavefront is done with stripe s before stripe s + NWV is reached) and is never re-based. The only
 // thing a wavefront needs from somebody else is, once per row, the previous-row values (x, v, x2, H) of the lane just below its stripe:
 // one message per row from its left neighbour through an LDS ring, stamped with the row number. The wavefronts therefore run SKEWED — the
 // left neighbour is (at least) one message ahead — instead of meeting at an s_barrier every row (ksw_packed_multi_kernel.h: 2.5 us per row
@@ -26,6 +26,9 @@
 #error "include simt.h before ksw_stripe_kernel.h"
 #endif
 #include "ksw_packed_kernel.h"
+#ifndef WM_STRIPE_SPIN
+#define WM_STRIPE_SPIN(where, r, a, wv, extra) ((void)0)      // test hook: a watchdog for the polling loops
+#endif
 #ifndef WM_STRIPE_EVENT
 #define WM_STRIPE_EVENT(k) ((void)0)      // test hook (tests/simt_emu): counts how often the rare paths run
 #endif
@@ -38,8 +41,9 @@ template <int BP, int NWV> struct ksw_stripe_lds {
 	static constexpr int C_STOP = 0, C_RESTART = 1, C_EZL = 2;        // control words: a z-drop ended the alignment in this row | repeat in safe mode | stale ez.max
 	// message slot: stamp | x v x2 h | pm ppri hst0 | track H0, track lane (-1: no hand-over) | ez state (8 ints; only on rows where it may move)
 	static constexpr int M_STAMP = 0, M_X = 1, M_V = 2, M_X2 = 3, M_H = 4, M_PM = 5, M_PRI = 6, M_HST0 = 7, M_TH0 = 8, M_TL0 = 9, M_EZ = 10;
-	// widest 16-aligned hull (= traceback pitch n_col) this geometry can hold: it touches at most NWV stripes
-	static constexpr int MAX_NCOL = (NWV - 1) * SW + 16;
+	// widest traceback pitch n_col (>= the 16-aligned hull en - st + 1) this geometry can hold: hull plus the up to 15 lanes of score chunks beyond it
+	// (cend, CLIP) touch at most NWV stripes
+	static constexpr int MAX_NCOL = (NWV - 1) * SW;
 };
 
 struct ksw_geo_t { int st0, en0, st, en, cend; };
@@ -103,7 +107,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 
 	for (int safe = 0; safe < 2; ++safe) {
 		// ---- the workgroup's LDS state: no message yet, nobody has consumed anything, nothing stops ----
-		WM_IF(ln < R) gst(ring_out, ln * L::SLOT + L::M_STAMP, V<int>(-1)); WM_END
+		WM_IF(ln < R) lds_st(ring_out, ln * L::SLOT + L::M_STAMP, V<int>(-1)); WM_END
 		lds_st_rel(prog, wv, -1);
 		if (wv == 0) { lds_st_rel(ctrl, L::C_STOP, BIG); lds_st_rel(ctrl, L::C_RESTART, 0); lds_st_rel(ctrl, L::C_EZL, 0); }
 		block_sync_lds();
@@ -128,7 +132,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 		while (!all_done) {
 			// ================= find the first row that touches stripe s =================
 			const int a = s * SW;
-			if (a >= tlen) { lds_st_rel(prog, wv, BIG); break; }
+			if (a >= tlen) break;
 			ksw_geo_t g;
 			{   // no row before these can reach lane a - 15 (en0 <= r, en0 <= (r + w) >> 1): skip them without looking
 				int rmin = a - 15;
@@ -179,16 +183,16 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 					if (a > 0 && gp.st <= a - 1 && a - 1 <= gp.en) {      // lane a - 1 was computed in row r - 1: take its message
 						const int *m = ring_in + ((r - 1) % R) * L::SLOT;
 						bool gone = false;
-						while (lds_ld_acq(m, L::M_STAMP) != r - 1) { if (lds_ld_acq(ctrl, L::C_STOP) < r) { gone = true; break; } spin_pause(); }
+						while (lds_ld_acq(m, L::M_STAMP) != r - 1) { if (lds_ld_acq(ctrl, L::C_STOP) < r) { gone = true; break; } WM_STRIPE_SPIN(0, r, a, wv, lds_ld_acq(m, L::M_STAMP)); spin_pause(); }
 						if (gone) { all_done = true; break; }
-						m_x = gld(m, (long long)L::M_X); m_v = gld(m, (long long)L::M_V); m_x2 = gld(m, (long long)L::M_X2); m_h = gld(m, (long long)L::M_H);
+						m_x = lds_ld(m, (long long)L::M_X); m_v = lds_ld(m, (long long)L::M_V); m_x2 = lds_ld(m, (long long)L::M_X2); m_h = lds_ld(m, (long long)L::M_H);
 						have_left = true;
 						if (EXACT && gp.en == a - 1) { WM_STRIPE_EVENT(2);                      // the band's last lane sat right below this stripe: the bookkeeping state comes along
-							ez_max = gld(m, (long long)(L::M_EZ + 0)); ez_max_t = gld(m, (long long)(L::M_EZ + 1)); ez_max_q = gld(m, (long long)(L::M_EZ + 2));
-							ez_mqe = gld(m, (long long)(L::M_EZ + 3)); ez_mqe_t = gld(m, (long long)(L::M_EZ + 4)); ez_mte = gld(m, (long long)(L::M_EZ + 5));
-							ez_mte_q = gld(m, (long long)(L::M_EZ + 6)); ez_score = gld(m, (long long)(L::M_EZ + 7));
+							ez_max = lds_ld(m, (long long)(L::M_EZ + 0)); ez_max_t = lds_ld(m, (long long)(L::M_EZ + 1)); ez_max_q = lds_ld(m, (long long)(L::M_EZ + 2));
+							ez_mqe = lds_ld(m, (long long)(L::M_EZ + 3)); ez_mqe_t = lds_ld(m, (long long)(L::M_EZ + 4)); ez_mte = lds_ld(m, (long long)(L::M_EZ + 5));
+							ez_mte_q = lds_ld(m, (long long)(L::M_EZ + 6)); ez_score = lds_ld(m, (long long)(L::M_EZ + 7));
 						}
-						if (!EXACT && gld(m, (long long)L::M_TL0) >= 0) { trk = true; H0 = gld(m, (long long)L::M_TH0); last_H0_t = gld(m, (long long)L::M_TL0); }
+						if (!EXACT && lds_ld(m, (long long)L::M_TL0) >= 0) { trk = true; H0 = lds_ld(m, (long long)L::M_TH0); last_H0_t = lds_ld(m, (long long)L::M_TL0); }
 					}
 				}
 			}
@@ -380,17 +384,17 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 				bool stopped = false;
 				if (left_now) {
 					const int *m = ring_in + (r % R) * L::SLOT;
-					while (lds_ld_acq(m, L::M_STAMP) != r) { if (lds_ld_acq(ctrl, L::C_STOP) <= r) { stopped = true; break; } spin_pause(); }
+					while (lds_ld_acq(m, L::M_STAMP) != r) { if (lds_ld_acq(ctrl, L::C_STOP) <= r) { stopped = true; break; } WM_STRIPE_SPIN(1, r, a, wv, lds_ld_acq(m, L::M_STAMP)); spin_pause(); }
 					if (stopped) { all_done = true; break; }
-					m_x = gld(m, (long long)L::M_X); m_v = gld(m, (long long)L::M_V); m_x2 = gld(m, (long long)L::M_X2);
+					m_x = lds_ld(m, (long long)L::M_X); m_v = lds_ld(m, (long long)L::M_V); m_x2 = lds_ld(m, (long long)L::M_X2);
 					if constexpr (EXACT) {
-						m_h = gld(m, (long long)L::M_H); pm = gld(m, (long long)L::M_PM); ppri = gld(m, (long long)L::M_PRI); hst0 = gld(m, (long long)L::M_HST0);
+						m_h = lds_ld(m, (long long)L::M_H); pm = lds_ld(m, (long long)L::M_PM); ppri = lds_ld(m, (long long)L::M_PRI); hst0 = lds_ld(m, (long long)L::M_HST0);
 						if (en == a - 1) {                                   // (not a cell of this stripe yet: keep the newest bookkeeping state)
-							ez_max = gld(m, (long long)(L::M_EZ + 0)); ez_max_t = gld(m, (long long)(L::M_EZ + 1)); ez_max_q = gld(m, (long long)(L::M_EZ + 2));
-							ez_mqe = gld(m, (long long)(L::M_EZ + 3)); ez_mqe_t = gld(m, (long long)(L::M_EZ + 4)); ez_mte = gld(m, (long long)(L::M_EZ + 5));
-							ez_mte_q = gld(m, (long long)(L::M_EZ + 6)); ez_score = gld(m, (long long)(L::M_EZ + 7));
+							ez_max = lds_ld(m, (long long)(L::M_EZ + 0)); ez_max_t = lds_ld(m, (long long)(L::M_EZ + 1)); ez_max_q = lds_ld(m, (long long)(L::M_EZ + 2));
+							ez_mqe = lds_ld(m, (long long)(L::M_EZ + 3)); ez_mqe_t = lds_ld(m, (long long)(L::M_EZ + 4)); ez_mte = lds_ld(m, (long long)(L::M_EZ + 5));
+							ez_mte_q = lds_ld(m, (long long)(L::M_EZ + 6)); ez_score = lds_ld(m, (long long)(L::M_EZ + 7));
 						}
-					} else if (gld(m, (long long)L::M_TL0) >= 0) { in_th0 = gld(m, (long long)L::M_TH0); in_tl0 = gld(m, (long long)L::M_TL0); }
+					} else if (lds_ld(m, (long long)L::M_TL0) >= 0) { in_th0 = lds_ld(m, (long long)L::M_TH0); in_tl0 = lds_ld(m, (long long)L::M_TL0); }
 				}
 				have_left = left_now;
 
@@ -493,19 +497,19 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 
 				// ---- publish this row for the right neighbour ----
 				if (pub) {
-					while (lds_ld_acq(prog, right_wv) < r - R) { if (lds_ld_acq(ctrl, L::C_STOP) <= r) { stopped = true; break; } spin_pause(); }
+					while (lds_ld_acq(prog, right_wv) < r - R) { if (lds_ld_acq(ctrl, L::C_STOP) <= r) { stopped = true; break; } WM_STRIPE_SPIN(2, r, a, wv, lds_ld_acq(prog, right_wv)); spin_pause(); }
 					if (stopped) { all_done = true; break; }
 					int *m = ring_out + (r % R) * L::SLOT;
 					WM_IF(ln == 63)
-						gst(m, V<int>(L::M_X), lshr(X[BP - 1], 16)); gst(m, V<int>(L::M_V), lshr(Vv[BP - 1], 16)); gst(m, V<int>(L::M_X2), lshr(X2[BP - 1], 16));
+						lds_st(m, V<int>(L::M_X), lshr(X[BP - 1], 16)); lds_st(m, V<int>(L::M_V), lshr(Vv[BP - 1], 16)); lds_st(m, V<int>(L::M_X2), lshr(X2[BP - 1], 16));
 						if constexpr (EXACT) {
-							gst(m, V<int>(L::M_H), H[EXACT ? B - 1 : 0]); gst(m, V<int>(L::M_PM), V<int>(pm)); gst(m, V<int>(L::M_PRI), V<int>(ppri)); gst(m, V<int>(L::M_HST0), V<int>(hst0));
+							lds_st(m, V<int>(L::M_H), H[EXACT ? B - 1 : 0]); lds_st(m, V<int>(L::M_PM), V<int>(pm)); lds_st(m, V<int>(L::M_PRI), V<int>(ppri)); lds_st(m, V<int>(L::M_HST0), V<int>(hst0));
 							if (en == a + SW - 1) {
-								gst(m, V<int>(L::M_EZ + 0), V<int>(ez_max)); gst(m, V<int>(L::M_EZ + 1), V<int>(ez_max_t)); gst(m, V<int>(L::M_EZ + 2), V<int>(ez_max_q));
-								gst(m, V<int>(L::M_EZ + 3), V<int>(ez_mqe)); gst(m, V<int>(L::M_EZ + 4), V<int>(ez_mqe_t)); gst(m, V<int>(L::M_EZ + 5), V<int>(ez_mte));
-								gst(m, V<int>(L::M_EZ + 6), V<int>(ez_mte_q)); gst(m, V<int>(L::M_EZ + 7), V<int>(ez_score));
+								lds_st(m, V<int>(L::M_EZ + 0), V<int>(ez_max)); lds_st(m, V<int>(L::M_EZ + 1), V<int>(ez_max_t)); lds_st(m, V<int>(L::M_EZ + 2), V<int>(ez_max_q));
+								lds_st(m, V<int>(L::M_EZ + 3), V<int>(ez_mqe)); lds_st(m, V<int>(L::M_EZ + 4), V<int>(ez_mqe_t)); lds_st(m, V<int>(L::M_EZ + 5), V<int>(ez_mte));
+								lds_st(m, V<int>(L::M_EZ + 6), V<int>(ez_mte_q)); lds_st(m, V<int>(L::M_EZ + 7), V<int>(ez_score));
 							}
-						} else { gst(m, V<int>(L::M_TH0), V<int>(out_th0)); gst(m, V<int>(L::M_TL0), V<int>(out_tl0)); }
+						} else { lds_st(m, V<int>(L::M_TH0), V<int>(out_th0)); lds_st(m, V<int>(L::M_TL0), V<int>(out_tl0)); }
 					WM_END
 					lds_st_rel(m, L::M_STAMP, r);
 				}
@@ -516,6 +520,9 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 		}
 
 		// ---- the alignment is over: one wavefront holds the result ----
+		// (a wavefront that has left the row loop reads no message any more: its left neighbour may still be publishing — e.g. the band runs empty a
+		// few rows before the stripe this wavefront was waiting for is reached — and must not wait for it)
+		lds_st_rel(prog, wv, BIG);
 		block_sync_lds();
 		const int stop_row = lds_ld_acq(ctrl, L::C_STOP), restart = lds_ld_acq(ctrl, L::C_RESTART);
 		if (restart) { block_sync_lds(); continue; }

@@ -202,16 +202,23 @@ WM_DEV uint64_t lanemask_lt() { return ((uint64_t)1 << (threadIdx.x & 63u)) - 1;
 // by the writer and "stamp load, then payload loads" by the reader need no counter wait between them — only the compiler must keep the
 // order (volatile accesses + barriers). lds_st_rel: lane 0 stores a uniform value after everything before it; lds_ld_acq: a uniform load
 // that nothing after it may overtake. spin_pause: yield the issue slot while polling.
+// Every access goes through an address-space-3 pointer: a pointer whose address space the compiler cannot prove becomes a FLAT access, which (a) waits
+// for vmcnt(0) — the row's outstanding traceback stores — and (b) travels through the vector-memory path and is NOT ordered with the DS
+// instructions around it: a payload written FLAT and a stamp written with ds_write can become visible in the wrong order (measured in round 4:
+// 41 flat_ instructions in the first build of ksw_stripe_kernel, a hang under load).
+typedef __attribute__((address_space(3))) int wm_lds_int;
+WM_DEV int lds_ld(const int *p, long long i) { return ((const wm_lds_int*)p)[i]; }                 // plain load (uniform or per-lane index)
+WM_DEV void lds_st(int *p, long long i, int v) { ((wm_lds_int*)p)[i] = v; }                         // plain per-lane store under the current exec mask
 WM_DEV void lds_st_rel(int *p, long long i, int v)
 {
 	asm volatile("" ::: "memory");
-	if ((threadIdx.x & 63u) == 0u) ((volatile int*)p)[i] = v;
+	if ((threadIdx.x & 63u) == 0u) ((volatile wm_lds_int*)p)[i] = v;
 	asm volatile("" ::: "memory");
 }
 WM_DEV int lds_ld_acq(const int *p, long long i)
 {
 	asm volatile("" ::: "memory");
-	const int v = __builtin_amdgcn_readfirstlane(((const volatile int*)p)[i]);
+	const int v = __builtin_amdgcn_readfirstlane(((const volatile wm_lds_int*)p)[i]);
 	asm volatile("" ::: "memory");
 	return v;
 }

@@ -17,6 +17,7 @@
 #include <thread>
 #include <chrono>
 #include <atomic>
+#include <unistd.h>
 #include "host/wm_core.h"
 // large staging buffers: no value-initialisation (a std::vector would memset hundreds of MB per batch). When a context is
 // given, the buffer comes from that context's PINNED host slab (LIFO bump allocation): device copies to/from pinned memory run
@@ -330,11 +331,12 @@ struct wm_ksw_dev_batch_s {
 	std::vector<int> order[WM_KSW_NCLASS];      // job indices per class, largest first
 	std::vector<int> ord;                       // the classes' orders back to back (what the device sees)
 	std::vector<int> degenerate;                // jobs the reference returns from early (src/ksw2_extd2_sse.c:68,92)
+	std::vector<std::string> dumped;            // WM_KSW_DUMP: files written for this batch's stripe launches
 	// device pointers (inside the arena)
 	uint8_t *d_gscratch; uint64_t *d_goff; std::vector<uint64_t> goff;
 	uint8_t *d_b3state; uint64_t *d_b3off; std::vector<uint64_t> b3off;
 	wm_ksw_djob_t *d_jobs; int *d_order; uint8_t *d_seqs, *d_tb; wm_ksw_dres_t *d_res; uint32_t *d_cig, *d_off, *d_total, *d_pool; int *d_err;
-	size_t pool_cap, arena_mark;
+	size_t pool_cap, arena_mark, slab_bytes;
 	uint64_t cells, tb_bytes;
 	uint64_t class_cells[WM_KSW_NCLASS];
 	float dp_ms, bt_ms;
@@ -620,6 +622,7 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 	b->d_total = (uint32_t*)arena_take(c, 64);
 	b->d_err = (int*)arena_take(c, 64);
 	b->d_seqs = (uint8_t*)arena_take(c, slab_bytes + 64);
+	b->slab_bytes = slab_bytes;
 	wm_ksw_dsrc_t *d_src = pos ? (wm_ksw_dsrc_t*)arena_take(c, nj * sizeof(wm_ksw_dsrc_t)) : 0;
 	b->d_cig = (uint32_t*)arena_take(c, (cig_off + 16) * 4);
 	b->pool_cap = cig_off + 16;
@@ -771,6 +774,28 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		}
 		if (k >= WM_KSW_STRIPE) {
 			const int var = (k - WM_KSW_STRIPE) & 3;
+			// WM_KSW_DUMP=<dir> (diagnostics): the jobs of a stripe launch and their operands go to <dir>/stripe_<pid>_<n>.bin before the launch and the
+			// file is removed when the whole call has come back — what is left after a hang is the launch that hung, replayable on the emulator
+			// (tools/replay_stripe_dump.py)
+			static const char *dump_dir = getenv("WM_KSW_DUMP");
+			if (dump_dir) {
+				static std::atomic<int> seq(0);
+				std::vector<uint8_t> hs(b->slab_bytes + 64);
+				hipStreamSynchronize(c->stream);
+				hipMemcpy(hs.data(), b->d_seqs, b->slab_bytes, hipMemcpyDeviceToHost);
+				char path[512];
+				snprintf(path, sizeof(path), "%s/stripe_%d_%d.bin", dump_dir, (int)getpid(), seq++);
+				if (FILE *fp = fopen(path, "wb")) {
+					const int32_t hdr[4] = { k, nk, (int32_t)sizeof(wm_ksw_djob_t), (int32_t)sizeof(wm_ksw_score_t) };
+					fwrite(hdr, 4, 4, fp); fwrite(&b->sc, sizeof(b->sc), 1, fp);
+					for (int j : b->order[k]) {
+						const wm_ksw_djob_t &d = b->jobs[j];
+						fwrite(&d, sizeof(d), 1, fp); fwrite(hs.data() + d.q_off, 1, d.qlen, fp); fwrite(hs.data() + d.t_off, 1, d.tlen, fp);
+					}
+					fclose(fp);
+					b->dumped.push_back(path);
+				}
+			}
 			switch ((k - WM_KSW_STRIPE) >> 2) {
 			case 0: launch_stripe<2, 4>(var, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
 			case 1: launch_stripe<2, 8>(var, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
@@ -824,6 +849,8 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	HIPCHK(hipMemcpyAsync(h_total, b->d_total, 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(ctx_sync(c));
 	b->h_err = *h_small; b->total_ops = *h_total;
+	for (const std::string &f : b->dumped) unlink(f.c_str());
+	b->dumped.clear();
 	HIPCHK(hipEventElapsedTime(&b->dp_ms, c->ev[0], c->ev[1]));
 	HIPCHK(hipEventElapsedTime(&b->bt_ms, c->ev[1], c->ev[2]));
 	c->last_ms = b->dp_ms + b->bt_ms;
