@@ -220,6 +220,12 @@ inline V<uint64_t> lanemask_lt() { V<uint64_t> r; for (int i = 0; i < WAVE; ++i)
 // cross-wavefront hand-over through LDS (one host thread per emulated wavefront): release / acquire atomics
 inline void lds_st_rel(int *p, long long i, int v) { if (exec_mask()) __atomic_store_n(p + i, v, __ATOMIC_SEQ_CST); }
 inline int lds_ld_acq(const int *p, long long i) { return __atomic_load_n(p + i, __ATOMIC_SEQ_CST); }
+inline int lds_ld_msg(const int *p, int (&o)[8])
+{
+	const int s = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+	for (int i = 0; i < 8; ++i) o[i] = __atomic_load_n(p + 4 + i, __ATOMIC_SEQ_CST);
+	return s;
+}
 inline void spin_pause() { sched_yield(); }
 inline int lds_ld(const int *p, long long i) { return p[i]; }
 template <class I> void lds_st(int *p, const V<I> &idx, const V<int> &v) { gst(p, idx, v); }

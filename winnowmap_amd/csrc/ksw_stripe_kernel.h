@@ -39,8 +39,8 @@ namespace wmk {
 template <int BP, int NWV> struct ksw_stripe_lds {
 	static constexpr int SW = 128 * BP, R = 8, SLOT = 20, RING = NWV * R * SLOT, PROG = RING, CTRL = PROG + NWV, INTS = CTRL + 4;
 	static constexpr int C_STOP = 0, C_RESTART = 1, C_EZL = 2;        // control words: a z-drop ended the alignment in this row | repeat in safe mode | stale ez.max
-	// message slot: stamp | x v x2 h | pm ppri hst0 | track H0, track lane (-1: no hand-over) | ez state (8 ints; only on rows where it may move)
-	static constexpr int M_STAMP = 0, M_X = 1, M_V = 2, M_X2 = 3, M_H = 4, M_PM = 5, M_PRI = 6, M_HST0 = 7, M_TH0 = 8, M_TL0 = 9, M_EZ = 10;
+	// message slot: stamp, 3 free | x v x2 h | pm ppri hst0 (exact maximum) or track H0, track lane (-1: no hand-over), free | ez state (8 ints; only on rows where it may move)
+	static constexpr int M_STAMP = 0, M_X = 4, M_V = 5, M_X2 = 6, M_H = 7, M_PM = 8, M_PRI = 9, M_HST0 = 10, M_TH0 = 8, M_TL0 = 9, M_EZ = 12;      // (M_X and M_PM on 16-byte boundaries: lds_ld_msg)
 	// widest traceback pitch n_col (>= the 16-aligned hull en - st + 1) this geometry can hold: hull plus the up to 15 lanes of score chunks beyond it
 	// (cend, CLIP) touch at most NWV stripes
 	static constexpr int MAX_NCOL = (NWV - 1) * SW;
@@ -197,325 +197,357 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 				}
 			}
 
-			// ================= the rows of stripe s =================
-			for (;; ++r) {
+			// ================= the rows of stripe s, EPOCH by epoch =================
+			// An epoch = a run of rows over which the 16-aligned hull [st, en] does not move (st0 and en0 advance by at most one lane per row, so an
+			// epoch lasts ~8-16 rows). Everything that only depends on (st, en) — which pairs hold cells, which of them lie inside the hull with all
+			// their lanes, the lane masks of the two that do not, which 64-lane chunks are inside the band whatever the row — is worked out once per
+			// epoch; the row loop is left with the cells, one message in, one message out. (The first build evaluated all of it per row and pair:
+			// ~900 instructions per row for two pairs, profiles/r04b: a lone wavefront issues one instruction per ~4.4 cycles.)
+			bool leave = false;
+			while (!all_done && !leave) {
 				if (r >= n_rows) { all_done = true; break; }
-				const int stop_row = lds_ld_acq(ctrl, L::C_STOP);             // (consumed at the end of the row: the load's latency hides behind the cells)
-				const int ezl = EXACT ? lds_ld_acq(ctrl, L::C_EZL) : 0;
 				if (!ksw_geo<CLIP>(r, qlen, tlen, w, g)) { end_row = r; all_done = true; break; }
-				const int st0 = g.st0, en0 = g.en0, st = g.st, en = g.en, cend = g.cend;
-				if (st >= a + SW) { s += NWV; WM_STRIPE_EVENT(0); break; }                        // the hull has left this stripe for good
-				const bool moved = st > prev_st;                              // lane st - 1 was computed in the last row (:141-146)
-				prev_st = st;
-				const int sched = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
-
-				// ---- advance the query codes to row r: every lane takes the code of lane t - 1; the stripe's first lane takes query[r - a] ----
+				const int st = g.st, en = g.en;
+				if (st >= a + SW) { s += NWV; WM_STRIPE_EVENT(0); leave = true; break; }          // the hull has left this stripe for good
+				int r_end = n_rows;                                            // first row of the next epoch
 				{
-					const int qi0 = r - a;
-					int newc = 0;
-					if (qi0 >= 0 && qi0 < qlen) {
-						if (qi0 < qb0 || qi0 >= qb0 + 64) {
-							qb0 = qi0;
-							const V<int> qidx = ln + qb0;
-							QB = 0;
-							WM_IF(qidx < qlen) QB = cast<int>(gld(query, qidx)); WM_END
-							loads_land();
-						}
-						newc = readlane(QB, qi0 - qb0);
+					const int X = st + 16;                                     // st0 reaches X: r - qlen + 1 >= X, or (r - w + 1) >> 1 >= X
+					int rs = X + qlen - 1;
+					if (CLIP && 2 * X + w - 1 < rs) rs = 2 * X + w - 1;
+					if (rs < r_end) r_end = rs;
+					const int Y = en + 1;                                      // en0 reaches Y: Y <= tlen - 1, r >= Y and (r + w) >> 1 >= Y
+					if (Y <= tlen - 1) {
+						int re = Y;
+						if (CLIP && 2 * Y - w > re) re = 2 * Y - w;
+						if (re < r_end) r_end = re;
 					}
-					V<int> rq[NW];
-#pragma unroll
-					for (int wd = 0; wd < NW; ++wd) rq[wd] = ror1(QP[wd]);
-#pragma unroll
-					for (int wd = 0; wd < NW; ++wd) QP[wd] = perm(rq[wd], wd ? rq[wd ? wd - 1 : 0] : V<int>(newc << 24), qsel);
 				}
-
-				// ---- which pairs of this stripe hold cells of the hull ----
+				WM_EMU_ASSERT(r_end > r);
 				const bool have_cells = a <= en;
 				const int i_lo = st > a ? (st - a) >> 7 : 0;
 				const int i_hi = have_cells ? ((en - a) >> 7 < BP ? (en - a) >> 7 : BP - 1) : -1;
 				const bool top_here = have_cells && en < a + SW;                // the pair i_hi holds the hull end
 				const bool first_here = st >= a;                                // the pair i_lo holds the hull start
-				// previous-row values of the lane below the stripe: the left neighbour's message, or the constants of :141-151 when that lane was not
-				// computed in the last row (which is also the case "hull start on the stripe's first lane and it did not move")
-				int px = tA, pv = (st == 0 ? sched & 0xff : (-qe) & 0xff) << 8, px2 = tA2, ph = KSW_NEG_INF;
-				if (have_left) { px = m_x; pv = m_v; px2 = m_x2; ph = m_h; }
-				// first-column / first-row boundary of lane r (:152-155); it shares its 16-lane group, hence its pair, with the hull end
-				V<int> bm = 0;
-				if (en >= r && r >= a && r < a + SW) {
-					const int o = r - a;
-					WM_EMU_ASSERT(top_here && (o >> 7) == i_hi);
-					bm = sel(ln == (o & 63), (o & 64) ? (int)0xffff0000 : 0x0000ffff, 0);
-				}
-				// hull start strictly inside a pair (or on a pair boundary inside the stripe) and not moved: lane st takes the constants, not lane st - 1
-				const bool inject = first_here && !moved && st > a;
-				V<int> sm = 0;
-				if (inject) { const int o = st - a; sm = sel(ln == (o & 63), (o & 64) ? (int)0xffff0000 : 0x0000ffff, 0); }
-
-				V<int> hmax = KSW_NEG_INF;
-				uint8_t *trow = tbp + (size_t)r * jb.n_col;                    // column of lane t = t - st
-				V<int> crx = 0, crv = 0, crx2 = 0;                             // rotations handed from pair i + 1 to pair i
-				int h_en0 = KSW_NEG_INF;
-
-				auto pair_scores = [&](auto IC) {
-					constexpr int i = decltype(IC)::value;
-					constexpr int wd = i >> 1, psel = (i & 1) ? 0x0c030c02 : 0x0c010c00;
-					const V<int> xq = TP[wd] ^ QP[wd];
-					V<int> sv = pk_mad(pk_minu(perm(xq, xq, psel), one2), rep16(MISt - MCHt), rep16(MCHt));
-					if constexpr (HASN) {
-						const V<int> oq = TP[wd] | QP[wd];
-						const V<int> isn = pk_lshr(perm(oq, oq, psel) & 0x00040004, 2);           // 1 where either code is 4
-						sv = bfi(pk_sub(0, isn), rep16(NNt), sv);
-					}
-					if constexpr (CLIP) {   // the score row is persistent and only [st0, cend] is rewritten
-						const int c0 = a + 128 * i;
-						if (c0 >= st0 && c0 + 127 <= cend) S[i] = sv;
-						else {
-							const V<int> t_lo = ln + c0, t_hi = ln + (c0 + 64);
-							const V<int> m = sel(t_lo >= st0 && t_lo <= cend, 0x0000ffff, 0) | sel(t_hi >= st0 && t_hi <= cend, (int)0xffff0000, 0);
-							S[i] = bfi(m, sv, S[i]);
-						}
-						sv = S[i];
-					}
-					return sv;
-				};
-				auto pair_body = [&](auto IC) {
-					constexpr int i = decltype(IC)::value;
-					const bool top = top_here && i == i_hi, first = first_here && i == i_lo;
+				const bool pub = a + SW - 1 <= en;                              // this stripe's last lane is computed: the right neighbour wants it
+				const bool left_now = a > 0 && st <= a - 1 && a - 1 <= en;      // the left neighbour publishes a message for every row of the epoch
+				// per pair: inside the hull with every lane (no lane mask anywhere)? its score row rewritten whole in every row? per chunk: strictly
+				// inside the band in every row (st0 < st + 16, en0 >= en - 15)?
+				int full_bits = 0, sfull_bits = 0, hin_bits = 0;
+				V<int> vm[BP];                                                 // lanes of the pair inside [st, en], as a bit-field-insert mask (0: the pair is outside)
+				V<int> smv[BP];                                                // the lane that holds the hull start, when that is strictly inside the stripe
+#pragma unroll
+				for (int i = 0; i < BP; ++i) {
 					const int c0 = a + 128 * i;
-					const V<int> t_lo = ln + c0, t_hi = ln + (c0 + 64);
-					const V<int> sv = pair_scores(IC);
-					int hprev = KSW_NEG_INF;                                   // H of lane en0 - 1 in the previous row
-					if (top) {
-						WM_KEEP_BRANCH();
-						Y[i] = bfi(bm, rep16(tB), Y[i]); Y2[i] = bfi(bm, rep16(tB2), Y2[i]); U[i] = bfi(bm, tb16(sched), U[i]);
-						if constexpr (EXACT) {
-							const int le = en0 - 1 - c0;                           // lane en0 - 1 relative to the pair: -1 .. 126
-							WM_EMU_ASSERT(le >= -1 && le < 127);
-							if (le < 0) hprev = i ? readlane(H[i ? 2 * i - 1 : 0], 63) : ph;
-							else hprev = le < 64 ? readlane(H[2 * i], le & 63) : readlane(H[2 * i + 1], le & 63);
-						}
+					vm[i] = -1; smv[i] = 0;
+					if (c0 >= st && c0 + 127 <= en) full_bits |= 1 << i;
+					else {
+						const V<int> t_lo = ln + c0, t_hi = ln + (c0 + 64);
+						vm[i] = sel(t_lo >= st && t_lo <= en, 0x0000ffff, 0) | sel(t_hi >= st && t_hi <= en, (int)0xffff0000, 0);
 					}
-					// previous-row values of lane t - 1 (see ksw_dp_packed): one rotation per register, thread 0 patched from the pair below
-					if (i == i_hi) { WM_KEEP_BRANCH(); crx = ror1(X[i]); crv = ror1(Vv[i]); crx2 = ror1(X2[i]); }
-					const V<int> rxo = crx, rvo = crv, rx2o = crx2;
-					if constexpr (i > 0) { crx = ror1(X[i ? i - 1 : 0]); crv = ror1(Vv[i ? i - 1 : 0]); crx2 = ror1(X2[i ? i - 1 : 0]); }
-					else { crx = px << 16; crv = pv << 16; crx2 = px2 << 16; }
-					V<int> x1 = perm(rxo, crx, rsel), v1 = perm(rvo, crv, rsel), x21 = perm(rx2o, crx2, rsel);
-					if (first && inject) {
-						WM_KEEP_BRANCH(); WM_STRIPE_EVENT(1);
-						x1 = bfi(sm, rep16(tA), x1); v1 = bfi(sm, rep16(negqe16), v1); x21 = bfi(sm, rep16(tA2), x21);
-					}
-					const V<int> ou = U[i];
-					V<int> nu, nv, nx, ny, nx2, ny2, p;
-					ksw_pcell(cc, sv, x1, v1, x21, Y[i], ou, Y2[i], nu, nv, nx, ny, nx2, ny2, p);
-					if constexpr (CLIP) {              // lanes beyond the hull keep their stale values (they feed back when the band is clipped)
-						V<int> m = -1;
-						if (top) { WM_KEEP_BRANCH(); m = sel(t_lo <= en, 0x0000ffff, 0) | sel(t_hi <= en, (int)0xffff0000, 0); }
-						U[i] = bfi(m, nu, U[i]); Vv[i] = bfi(m, nv, Vv[i]); X[i] = bfi(m, nx, X[i]); Y[i] = bfi(m, ny, Y[i]);
-						X2[i] = bfi(m, nx2, X2[i]); Y2[i] = bfi(m, ny2, Y2[i]);
-					} else {
-						U[i] = nu; Vv[i] = nv; X[i] = nx; Y[i] = ny; X2[i] = nx2; Y2[i] = ny2;
-					}
-					// traceback: column t - st; lanes below the hull start (first pair) and beyond its end (top pair) are not part of the row
-					if (top || first) {
-						WM_IF(t_lo <= en && t_lo >= st) gst(trow, t_lo - st, cast<uint8_t>(p)); WM_END
-						WM_IF(t_hi <= en && t_hi >= st) gst(trow, t_hi - st, cast<uint8_t>(lshr(p, 16))); WM_END
-					} else {
-						gst(trow, t_lo - st, cast<uint8_t>(p));
-						gst(trow, t_hi - st, cast<uint8_t>(lshr(p, 16)));
-					}
-					if constexpr (EXACT) {
-						// H += v (:320-345). Lanes outside the band keep their H; lane en0 takes H of its left neighbour + u
-						const int en0x = en0 > 0 ? en0 : -1;
-#pragma unroll
-						for (int hf = 1; hf >= 0; --hf) {
-							const int ci = 2 * i + hf, cb = c0 + 64 * hf;
-							const V<int> v8 = hf ? vhi8(Vv[i]) : vlo8(Vv[i]);
-							V<int> hn = H[ci] + v8;
-							if (cb >= st0 && cb + 63 < en0) {               // chunk strictly inside the band: every lane is a plain update
-								H[ci] = hn;
-								hmax = vmax(hmax, hn);
-							} else {
-								WM_KEEP_BRANCH();
-								const V<int> t = hf ? t_hi : t_lo;
-								const V<int> u8 = hf ? vhi8(U[i]) : vlo8(U[i]);
-								hn = sel(t == en0x, V<int>(u8 + hprev), hn);
-								const vbool inb = t >= st0 && t <= en0;
-								H[ci] = sel(inb, hn, H[ci]);
-								hmax = vmax(hmax, sel(inb, hn, V<int>(KSW_NEG_INF)));
-							}
-						}
-						if (top && en0 == tlen - 1) {
-							WM_KEEP_BRANCH();
-							const int oe = en0 - c0;
-							h_en0 = oe < 64 ? readlane(H[2 * i], oe & 63) : readlane(H[2 * i + 1], oe & 63);
-						}
-					}
-				};
-				static_for_desc<BP>([&](auto IC) {
-					constexpr int i = decltype(IC)::value;
-					if (i >= i_lo && i <= i_hi) pair_body(IC);
-					else if constexpr (CLIP) {                 // only the score row of a pair outside the hull (cend reaches up to 15 lanes beyond en)
-						const int c0 = a + 128 * i;
-						if (c0 <= cend && c0 + 127 >= st0) pair_scores(IC);
-					}
-				});
-
-				// ---- the lane (uniform) of this stripe as (register, half, thread) ----
-				auto half_of = [&](const V<int> (&arr)[BP], int t) { return get_half<BP>(arr, a, t); };
-				auto h_of = [&](int t) {
-					const int o = t - a, ci = o >> 6;
-					int hh = 0;
-#pragma unroll
-					for (int k = 0; k < (EXACT ? B : 1); ++k) if (ci == k) hh = readlane(H[k], o & 63);
-					return hh;
-				};
-
-				// ---- this stripe's share of the row's bookkeeping ----
-				const bool is_last = have_cells && en0 < a + SW;                // the band's last lane is here: this wavefront closes the row
-				const bool left_now = a > 0 && st <= a - 1 && a - 1 <= en;      // the left neighbour publishes a message for this row
-				const bool pub = a + SW - 1 <= en;                              // this stripe's last lane was computed: the right neighbour wants it
-				int hm = KSW_NEG_INF;
-				if constexpr (EXACT) { if (r > 0 && have_cells) hm = wave_max_i32(hmax); }
-				// the left message of this row: values for the next row, and the row-wide quantities accumulated so far
-				int pm = KSW_NEG_INF, ppri = -1, hst0 = KSW_NEG_INF;
-				int in_th0 = 0, in_tl0 = -1;
-				bool stopped = false;
-				if (left_now) {
-					const int *m = ring_in + (r % R) * L::SLOT;
-					while (lds_ld_acq(m, L::M_STAMP) != r) { if (lds_ld_acq(ctrl, L::C_STOP) <= r) { stopped = true; break; } WM_STRIPE_SPIN(1, r, a, wv, lds_ld_acq(m, L::M_STAMP)); spin_pause(); }
-					if (stopped) { all_done = true; break; }
-					m_x = lds_ld(m, (long long)L::M_X); m_v = lds_ld(m, (long long)L::M_V); m_x2 = lds_ld(m, (long long)L::M_X2);
-					if constexpr (EXACT) {
-						m_h = lds_ld(m, (long long)L::M_H); pm = lds_ld(m, (long long)L::M_PM); ppri = lds_ld(m, (long long)L::M_PRI); hst0 = lds_ld(m, (long long)L::M_HST0);
-						if (en == a - 1) {                                   // (not a cell of this stripe yet: keep the newest bookkeeping state)
-							ez_max = lds_ld(m, (long long)(L::M_EZ + 0)); ez_max_t = lds_ld(m, (long long)(L::M_EZ + 1)); ez_max_q = lds_ld(m, (long long)(L::M_EZ + 2));
-							ez_mqe = lds_ld(m, (long long)(L::M_EZ + 3)); ez_mqe_t = lds_ld(m, (long long)(L::M_EZ + 4)); ez_mte = lds_ld(m, (long long)(L::M_EZ + 5));
-							ez_mte_q = lds_ld(m, (long long)(L::M_EZ + 6)); ez_score = lds_ld(m, (long long)(L::M_EZ + 7));
-						}
-					} else if (lds_ld(m, (long long)L::M_TL0) >= 0) { in_th0 = lds_ld(m, (long long)L::M_TH0); in_tl0 = lds_ld(m, (long long)L::M_TL0); }
+					if (first_here && st > a && ((st - a) >> 7) == i) { const int o = st - a; smv[i] = sel(ln == (o & 63), (o & 64) ? (int)0xffff0000 : 0x0000ffff, 0); }
+					if (c0 >= st + 16 && c0 + 127 <= en - 15) sfull_bits |= 1 << i;
+					if (c0 >= st + 16 && c0 + 63 < en - 15) hin_bits |= 1 << (2 * i);
+					if (c0 + 64 >= st + 16 && c0 + 127 < en - 15) hin_bits |= 1 << (2 * i + 1);
 				}
-				have_left = left_now;
+				// (hull start strictly inside the stripe: in every row but the one in which it moved there, lane st takes the constants of :147-150)
+				bool moved = st > prev_st;                                     // lane st - 1 was computed in the last row (:141-146): first row of an epoch only
+				prev_st = st;
 
-				int out_th0 = 0, out_tl0 = -1;
-				if constexpr (EXACT) {
-					if (r > 0) {
-						if (have_cells && hm > KSW_NEG_INF && hm >= pm) {
-							// this stripe may hold the row maximum. Its lane priority (the reference's SIMD tie rule, see ksw_dp_packed) is wanted by a new
-							// maximum (hm > ez.max >= the stale copy) or by a z-drop test that can fire (ez.max - hm > zdrop; ez.max <= copy + slack)
-							int my_pri = -1;
-							if (safe || hm > ezl || (zdrop >= 0 && ezl + ez_slack - hm > zdrop)) {
-								WM_KEEP_BRANCH();
-								const int en1 = st0 + (en0 - st0) / 4 * 4;
-								const V<int> g4 = (4 - ((ln + (a - st0)) & 3)) << 20;    // (a, chunk starts: multiples of 4 — the residue is the same in every chunk)
-								V<int> best = -1;
-								static_for_desc<B>([&](auto CC) {
-									constexpr int ci = decltype(CC)::value;
-									if ((ci >> 1) < i_lo || (ci >> 1) > i_hi) return;
-									const V<int> t = ln + (a + 64 * ci);
-									const vbool hit = H[ci] == hm && cast<unsigned>(t - st0) <= (unsigned)(en0 - st0);
-									if (any(hit)) {
-										WM_KEEP_BRANCH();
-										V<int> pri = sel(t < en1, g4, V<int>(0));
-										pri = sel(t == en0, V<int>(5 << 20), pri) | (V<int>(0xfffff) - t);
-										best = vmax(best, sel(hit, pri, V<int>(-1)));
-									}
-								});
-								my_pri = wave_max_i32(best);
-							}
-							if (my_pri >= 0) WM_STRIPE_EVENT(7); else WM_STRIPE_EVENT(8);
-						if (hm > pm) { pm = hm; ppri = my_pri; }
-							else if (my_pri > ppri) ppri = my_pri;
-						}
-					} else if (a == 0) {                                         // row 0: one cell (:346)
-						WM_IF(ln == 0) H[0] = vlo8(Vv[0]) - qe; WM_END
-						pm = readlane(H[0], 0); ppri = (5 << 20) | 0xfffff;
-						h_en0 = pm;
+				for (; r < r_end; ++r) {
+					const int stop_row = lds_ld_acq(ctrl, L::C_STOP);             // (consumed at the end of the row: the load's latency hides behind the cells)
+					const int ezl = EXACT ? lds_ld_acq(ctrl, L::C_EZL) : 0;
+					int st0 = 0, en0 = tlen - 1;
+					if (st0 < r - qlen + 1) st0 = r - qlen + 1;
+					if (en0 > r) en0 = r;
+					if (CLIP) {
+						if (st0 < (r - w + 1) >> 1) st0 = (r - w + 1) >> 1;
+						if (en0 > (r + w) >> 1) en0 = (r + w) >> 1;
+						if (st0 > en0) { end_row = r; all_done = true; break; }
 					}
-					if (r - st0 == qlen - 1 && st0 >= a && st0 < a + SW) hst0 = h_of(st0);
-					if (is_last) {
-						const int max_H = pm, max_t = 0xfffff - (ppri & 0xfffff);
-						if (en0 == tlen - 1) { if (h_en0 > ez_mte) ez_mte = h_en0, ez_mte_q = r - en; }
-						if (r - st0 == qlen - 1) { if (hst0 > ez_mqe) ez_mqe = hst0, ez_mqe_t = st0; }
-						if (max_H > ez_max) {
-							if (ppri < 0) { WM_STRIPE_EVENT(3); lds_st_rel(ctrl, L::C_RESTART, 1); lds_st_rel(ctrl, L::C_STOP, -1); all_done = true; break; }
-							ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
-							lds_st_rel(ctrl, L::C_EZL, ez_max);
-						} else if (zdrop >= 0 && ez_max - max_H > zdrop) {       // (otherwise the test of src/ksw2.h:168 cannot fire whatever max_t is)
-							if (ppri < 0) { WM_STRIPE_EVENT(3); lds_st_rel(ctrl, L::C_RESTART, 1); lds_st_rel(ctrl, L::C_STOP, -1); all_done = true; break; }
-							if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
-								const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
-								if (ez_max - max_H > zdrop + l * e2) {
-									ez_zdropped = 1; my_stop = true; WM_STRIPE_EVENT(6);
-									lds_st_rel(ctrl, L::C_STOP, r);
-									row_done = r; was_last = true; all_done = true;
-									break;
+					WM_EMU_ASSERT(st0 / 16 * 16 == st && (en0 + 16) / 16 * 16 - 1 == en);
+					const int cend = st0 + (en0 - st0) / 16 * 16 + 15;
+					const int sched = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
+
+					// ---- advance the query codes to row r: every lane takes the code of lane t - 1; the stripe's first lane takes query[r - a] ----
+					{
+						const int qi0 = r - a;
+						int newc = 0;
+						if (qi0 >= 0 && qi0 < qlen) {
+							if (qi0 < qb0 || qi0 >= qb0 + 64) {
+								qb0 = qi0;
+								const V<int> qidx = ln + qb0;
+								QB = 0;
+								WM_IF(qidx < qlen) QB = cast<int>(gld(query, qidx)); WM_END
+								loads_land();
+							}
+							newc = readlane(QB, qi0 - qb0);
+						}
+						V<int> rq[NW];
+#pragma unroll
+						for (int wd = 0; wd < NW; ++wd) rq[wd] = ror1(QP[wd]);
+#pragma unroll
+						for (int wd = 0; wd < NW; ++wd) QP[wd] = perm(rq[wd], wd ? rq[wd ? wd - 1 : 0] : V<int>(newc << 24), qsel);
+					}
+
+					// previous-row values of the lane below the stripe: the left neighbour's message, or the constants of :141-151 when that lane was not
+					// computed in the last row (which is also the case "hull start on the stripe's first lane and it did not move").
+					// H of that lane is the one exception: lane en0 reads H[en0 - 1] whether or not it was updated in the last row (:322), i.e. the last
+					// value the left neighbour ever sent (KSW_NEG_INF before the first)
+					int px = tA, pv = (st == 0 ? sched & 0xff : (-qe) & 0xff) << 8, px2 = tA2;
+					if (have_left) { px = m_x; pv = m_v; px2 = m_x2; }
+					const bool is_last = have_cells && en0 < a + SW;                // the band's last lane is here: this wavefront closes the row
+					// Every pair of the stripe runs in every row, in straight-line code: a pair (or a lane) outside the hull computes on whatever its
+					// registers hold and its results are masked off (vm), instead of a web of per-pair branches whose joins copy the register arrays
+					// (the first build: ~900 instructions per row for two pairs)
+					V<int> hmax = KSW_NEG_INF;
+					uint8_t *trow = tbp + (size_t)r * jb.n_col;                    // column of lane t = t - st
+					// first-column / first-row boundary of lane r (:152-155): y, y2, u of that lane are reset before the cells
+					if (en >= r && r >= a && r < a + SW) {
+						WM_KEEP_BRANCH();
+						const int o = r - a;
+						const V<int> bm = sel(ln == (o & 63), (o & 64) ? (int)0xffff0000 : 0x0000ffff, 0);
+						static_for_desc<BP>([&](auto IC) {
+							constexpr int i = decltype(IC)::value;
+							if ((o >> 7) == i) { Y[i] = bfi(bm, rep16(tB), Y[i]); Y2[i] = bfi(bm, rep16(tB2), Y2[i]); U[i] = bfi(bm, tb16(sched), U[i]); }
+						});
+					}
+					// exact maximum: H of lane en0 - 1 in the previous row (lane en0 continues from its left neighbour, :322), read before H moves
+					int hprev = KSW_NEG_INF, h_en0 = KSW_NEG_INF;
+					auto h_of = [&](int t) {
+						const int o = t - a, ci = o >> 6;
+						int hh = 0;
+#pragma unroll
+						for (int k = 0; k < (EXACT ? B : 1); ++k) if (ci == k) hh = readlane(H[k], o & 63);
+						return hh;
+					};
+					if constexpr (EXACT) { if (is_last) { WM_KEEP_BRANCH(); hprev = en0 - 1 < a ? m_h : h_of(en0 - 1); } }
+					const bool inject = first_here && !moved && st > a;
+
+					// rotations by one thread of x, v, x2 (lane t - 1 of the previous row, see ksw_dp_packed); thread 0 is patched from the pair below
+					V<int> rX[BP], rV[BP], rX2[BP];
+#pragma unroll
+					for (int i = 0; i < BP; ++i) { rX[i] = ror1(X[i]); rV[i] = ror1(Vv[i]); rX2[i] = ror1(X2[i]); }
+					static_for_desc<BP>([&](auto IC) {
+						constexpr int i = decltype(IC)::value;
+						constexpr int wd = i >> 1, psel = (i & 1) ? 0x0c030c02 : 0x0c010c00;
+						const int c0 = a + 128 * i;
+						// ---- match / mismatch (/ ambiguous) scores, tie-break tag in the low bits ----
+						const V<int> xq = TP[wd] ^ QP[wd];
+						V<int> sv = pk_mad(pk_minu(perm(xq, xq, psel), one2), rep16(MISt - MCHt), rep16(MCHt));
+						if constexpr (HASN) {
+							const V<int> oq = TP[wd] | QP[wd];
+							const V<int> isn = pk_lshr(perm(oq, oq, psel) & 0x00040004, 2);           // 1 where either code is 4
+							sv = bfi(pk_sub(0, isn), rep16(NNt), sv);
+						}
+						if constexpr (CLIP) {   // the score row is persistent and only [st0, cend] is rewritten
+							if (sfull_bits >> i & 1) S[i] = sv;
+							else {
+								WM_KEEP_BRANCH();
+								const V<int> t_lo = ln + c0, t_hi = ln + (c0 + 64);
+								const V<int> m = sel(t_lo >= st0 && t_lo <= cend, 0x0000ffff, 0) | sel(t_hi >= st0 && t_hi <= cend, (int)0xffff0000, 0);
+								S[i] = bfi(m, sv, S[i]);
+							}
+							sv = S[i];
+						}
+						// ---- the cells ----
+						V<int> x1, v1, x21;
+						if constexpr (i > 0) { x1 = perm(rX[i], rX[i ? i - 1 : 0], rsel); v1 = perm(rV[i], rV[i ? i - 1 : 0], rsel); x21 = perm(rX2[i], rX2[i ? i - 1 : 0], rsel); }
+						else { x1 = perm(rX[0], V<int>(px << 16), rsel); v1 = perm(rV[0], V<int>(pv << 16), rsel); x21 = perm(rX2[0], V<int>(px2 << 16), rsel); }
+						if (inject) {            // (sm_i is zero in every pair but the one that holds the hull start)
+							WM_KEEP_BRANCH(); WM_STRIPE_EVENT(1);
+							x1 = bfi(smv[i], rep16(tA), x1); v1 = bfi(smv[i], rep16(negqe16), v1); x21 = bfi(smv[i], rep16(tA2), x21);
+						}
+						const V<int> ou = U[i];
+						V<int> nu, nv, nx, ny, nx2, ny2, p;
+						ksw_pcell(cc, sv, x1, v1, x21, Y[i], ou, Y2[i], nu, nv, nx, ny, nx2, ny2, p);
+						if (full_bits >> i & 1) {
+							U[i] = nu; Vv[i] = nv; X[i] = nx; Y[i] = ny; X2[i] = nx2; Y2[i] = ny2;
+							gst(trow, ln + (c0 - st), cast<uint8_t>(p));
+							gst(trow, ln + (c0 + 64 - st), cast<uint8_t>(lshr(p, 16)));
+						} else {
+							WM_KEEP_BRANCH();
+							// lanes beyond the hull keep their stale values when the band is clipped (they feed back); lanes below it are dead. An unclipped
+							// band never reads either again. Traceback: column t - st, only lanes of the hull are part of the row
+							if constexpr (CLIP) {
+								const V<int> m = vm[i];
+								U[i] = bfi(m, nu, U[i]); Vv[i] = bfi(m, nv, Vv[i]); X[i] = bfi(m, nx, X[i]); Y[i] = bfi(m, ny, Y[i]);
+								X2[i] = bfi(m, nx2, X2[i]); Y2[i] = bfi(m, ny2, Y2[i]);
+							} else { U[i] = nu; Vv[i] = nv; X[i] = nx; Y[i] = ny; X2[i] = nx2; Y2[i] = ny2; }
+							WM_IF((vm[i] & 0xffff) != 0) gst(trow, ln + (c0 - st), cast<uint8_t>(p)); WM_END
+							WM_IF(lshr(vm[i], 16) != 0) gst(trow, ln + (c0 + 64 - st), cast<uint8_t>(lshr(p, 16))); WM_END
+						}
+						if constexpr (EXACT) {
+							// H += v (:320-345). Lanes outside the band keep their H; lane en0 takes H of its left neighbour + u
+#pragma unroll
+							for (int hf = 1; hf >= 0; --hf) {
+								const int ci = 2 * i + hf;
+								const V<int> v8 = hf ? vhi8(Vv[i]) : vlo8(Vv[i]);
+								V<int> hn = H[ci] + v8;
+								if (hin_bits >> ci & 1) {                       // chunk strictly inside the band: every lane is a plain update
+									H[ci] = hn;
+									hmax = vmax(hmax, hn);
+								} else {
+									WM_KEEP_BRANCH();
+									const int en0x = en0 > 0 ? en0 : -1;
+									const V<int> t = ln + (c0 + 64 * hf);
+									const V<int> u8 = hf ? vhi8(U[i]) : vlo8(U[i]);
+									hn = sel(t == en0x, V<int>(u8 + hprev), hn);
+									const vbool inb = t >= st0 && t <= en0;
+									H[ci] = sel(inb, hn, H[ci]);
+									hmax = vmax(hmax, sel(inb, hn, V<int>(KSW_NEG_INF)));
 								}
 							}
 						}
-						if (r == n_rows - 1 && en0 == tlen - 1) ez_score = h_en0;
-					}
-				} else if constexpr (!CLIP && WM_KSW_EDGE_TRACK) {
-					// approximate max, band never clips: follow the hull's first lane (see ksw_dp_packed). The owner is the stripe that holds st0
-					if (trk) {
-						WM_EMU_ASSERT(st0 >= a && st0 < a + SW);
-						const int d = (r < qlen ? half_of(Vv, st0) : half_of(U, st0)) >> 8;
-						H0 = r ? H0 + d : d - qe;
-						if (r == n_rows - 1) ez_score = H0;
-						const int st0n = r + 1 - qlen + 1 > 0 ? r + 1 - qlen + 1 : 0;       // st0 of the next row
-						if (st0n >= a + SW && r + 1 < n_rows) { WM_STRIPE_EVENT(4); out_th0 = H0; out_tl0 = st0n; trk = false; WM_EMU_ASSERT(pub); }
-					}
-					if (in_tl0 >= 0) { trk = true; H0 = in_th0; }
-				} else {
-					// approximate max along one diagonal-ish track (:359-375): the step of row r reads v of lane L0 and u of lane L0 + 1 of THIS row. The
-					// track never trails the band (after row r: L0 >= st0(r)), so both lanes are in the owner's stripe or L0 is the left neighbour's last
-					// lane, whose v arrives in the left message. When the next step's lane L0 + 1 belongs to the right neighbour and that one computes cells
-					// in the next row, the state goes there in this row's message (as long as it does not, L0 + 1 is beyond the band and the step is ours)
-					if (trk) {
-						if (r > 0) {
-							const int L1 = last_H0_t + 1;
-							const bool in0 = last_H0_t >= st0 && last_H0_t <= en0, in1 = L1 >= st0 && L1 <= en0;
-							int d0 = 0, d1 = 0;
-							if (in0) d0 = last_H0_t >= a ? half_of(Vv, last_H0_t) >> 8 : (int)(short)m_v >> 8;
-							if (L1 >= a && L1 < a + SW) d1 = half_of(U, L1) >> 8;
-							WM_EMU_ASSERT((in0 || (L1 >= a && L1 < a + SW)) && (!in1 || L1 < a + SW) && last_H0_t >= a - 1);
-							if (in0 && in1) {
-								if (d0 > d1) H0 += d0;
-								else H0 += d1, ++last_H0_t;
-							} else if (in0) H0 += d0;
-							else { ++last_H0_t; H0 += d1; }
-						} else { H0 = (half_of(Vv, 0) >> 8) - qe; last_H0_t = 0; }
-						if (r == n_rows - 1 && en0 == tlen - 1) ez_score = H0;
-						if (last_H0_t + 1 >= a + SW && r + 1 < n_rows) {
-							ksw_geo_t gn;
-							if (ksw_geo<CLIP>(r + 1, qlen, tlen, w, gn) && a + SW <= gn.en) { WM_STRIPE_EVENT(5); out_th0 = H0; out_tl0 = last_H0_t; trk = false; WM_EMU_ASSERT(pub); }
-						}
-					}
-					if (in_tl0 >= 0) { trk = true; H0 = in_th0; last_H0_t = in_tl0; }
-				}
+					});
+					if constexpr (EXACT) { if (is_last && en0 == tlen - 1) { WM_KEEP_BRANCH(); h_en0 = h_of(en0); } }
+					moved = false;
 
-				// ---- publish this row for the right neighbour ----
-				if (pub) {
-					while (lds_ld_acq(prog, right_wv) < r - R) { if (lds_ld_acq(ctrl, L::C_STOP) <= r) { stopped = true; break; } WM_STRIPE_SPIN(2, r, a, wv, lds_ld_acq(prog, right_wv)); spin_pause(); }
-					if (stopped) { all_done = true; break; }
-					int *m = ring_out + (r % R) * L::SLOT;
-					WM_IF(ln == 63)
-						lds_st(m, V<int>(L::M_X), lshr(X[BP - 1], 16)); lds_st(m, V<int>(L::M_V), lshr(Vv[BP - 1], 16)); lds_st(m, V<int>(L::M_X2), lshr(X2[BP - 1], 16));
+					// ---- the lane (uniform) of this stripe as (register, half, thread) ----
+					auto half_of = [&](const V<int> (&arr)[BP], int t) { return get_half<BP>(arr, a, t); };
+
+					// ---- this stripe's share of the row's bookkeeping ----
+					int hm = KSW_NEG_INF;
+					// the left message of this row: values for the next row, and the row-wide quantities accumulated so far
+					int pm = KSW_NEG_INF, ppri = -1, hst0 = KSW_NEG_INF;
+					int in_th0 = 0, in_tl0 = -1;
+					bool stopped = false;
+					if (left_now) {
+						const int *m = ring_in + (r % R) * L::SLOT;
+						int o8[8];
+						while (lds_ld_msg(m, o8) != r) { if (lds_ld_acq(ctrl, L::C_STOP) <= r) { stopped = true; break; } WM_STRIPE_SPIN(1, r, a, wv, lds_ld_acq(m, L::M_STAMP)); spin_pause(); }
+						if (stopped) { all_done = true; break; }
+						m_x = o8[0]; m_v = o8[1]; m_x2 = o8[2];
 						if constexpr (EXACT) {
-							lds_st(m, V<int>(L::M_H), H[EXACT ? B - 1 : 0]); lds_st(m, V<int>(L::M_PM), V<int>(pm)); lds_st(m, V<int>(L::M_PRI), V<int>(ppri)); lds_st(m, V<int>(L::M_HST0), V<int>(hst0));
-							if (en == a + SW - 1) {
-								lds_st(m, V<int>(L::M_EZ + 0), V<int>(ez_max)); lds_st(m, V<int>(L::M_EZ + 1), V<int>(ez_max_t)); lds_st(m, V<int>(L::M_EZ + 2), V<int>(ez_max_q));
-								lds_st(m, V<int>(L::M_EZ + 3), V<int>(ez_mqe)); lds_st(m, V<int>(L::M_EZ + 4), V<int>(ez_mqe_t)); lds_st(m, V<int>(L::M_EZ + 5), V<int>(ez_mte));
-								lds_st(m, V<int>(L::M_EZ + 6), V<int>(ez_mte_q)); lds_st(m, V<int>(L::M_EZ + 7), V<int>(ez_score));
+							m_h = o8[3]; pm = o8[4]; ppri = o8[5]; hst0 = o8[6];
+							if (en == a - 1) {                                   // (not a cell of this stripe yet: keep the newest bookkeeping state)
+								ez_max = lds_ld(m, (long long)(L::M_EZ + 0)); ez_max_t = lds_ld(m, (long long)(L::M_EZ + 1)); ez_max_q = lds_ld(m, (long long)(L::M_EZ + 2));
+								ez_mqe = lds_ld(m, (long long)(L::M_EZ + 3)); ez_mqe_t = lds_ld(m, (long long)(L::M_EZ + 4)); ez_mte = lds_ld(m, (long long)(L::M_EZ + 5));
+								ez_mte_q = lds_ld(m, (long long)(L::M_EZ + 6)); ez_score = lds_ld(m, (long long)(L::M_EZ + 7));
 							}
-						} else { lds_st(m, V<int>(L::M_TH0), V<int>(out_th0)); lds_st(m, V<int>(L::M_TL0), V<int>(out_tl0)); }
-					WM_END
-					lds_st_rel(m, L::M_STAMP, r);
+						} else if (o8[5] >= 0) { in_th0 = o8[4]; in_tl0 = o8[5]; }
+					}
+					have_left = left_now;
+					if constexpr (EXACT) { if (r > 0 && have_cells) hm = wave_max_i32(hmax); }
+
+					int out_th0 = 0, out_tl0 = -1;
+					if constexpr (EXACT) {
+						if (r > 0) {
+							if (have_cells && hm > KSW_NEG_INF && hm >= pm) {
+								// this stripe may hold the row maximum. Its lane priority (the reference's SIMD tie rule, see ksw_dp_packed) is wanted by a new
+								// maximum (hm > ez.max >= the stale copy) or by a z-drop test that can fire (ez.max - hm > zdrop; ez.max <= copy + slack)
+								int my_pri = -1;
+								if (safe || hm > ezl || (zdrop >= 0 && ezl + ez_slack - hm > zdrop)) {
+									WM_KEEP_BRANCH();
+									const int en1 = st0 + (en0 - st0) / 4 * 4;
+									const V<int> g4 = (4 - ((ln + (a - st0)) & 3)) << 20;    // (a, chunk starts: multiples of 4 — the residue is the same in every chunk)
+									V<int> best = -1;
+									static_for_desc<B>([&](auto CC) {
+										constexpr int ci = decltype(CC)::value;
+										if ((ci >> 1) < i_lo || (ci >> 1) > i_hi) return;
+										const V<int> t = ln + (a + 64 * ci);
+										const vbool hit = H[ci] == hm && cast<unsigned>(t - st0) <= (unsigned)(en0 - st0);
+										if (any(hit)) {
+											WM_KEEP_BRANCH();
+											V<int> pri = sel(t < en1, g4, V<int>(0));
+											pri = sel(t == en0, V<int>(5 << 20), pri) | (V<int>(0xfffff) - t);
+											best = vmax(best, sel(hit, pri, V<int>(-1)));
+										}
+									});
+									my_pri = wave_max_i32(best);
+								}
+								if (my_pri >= 0) WM_STRIPE_EVENT(7); else WM_STRIPE_EVENT(8);
+								if (hm > pm) { pm = hm; ppri = my_pri; }
+								else if (my_pri > ppri) ppri = my_pri;
+							}
+						} else if (a == 0) {                                         // row 0: one cell (:346)
+							WM_IF(ln == 0) H[0] = vlo8(Vv[0]) - qe; WM_END
+							pm = readlane(H[0], 0); ppri = (5 << 20) | 0xfffff;
+							h_en0 = pm;
+						}
+						if (r - st0 == qlen - 1 && st0 >= a && st0 < a + SW) hst0 = h_of(st0);
+						if (is_last) {
+							const int max_H = pm, max_t = 0xfffff - (ppri & 0xfffff);
+							if (en0 == tlen - 1) { if (h_en0 > ez_mte) ez_mte = h_en0, ez_mte_q = r - en; }
+							if (r - st0 == qlen - 1) { if (hst0 > ez_mqe) ez_mqe = hst0, ez_mqe_t = st0; }
+							if (max_H > ez_max) {
+								if (ppri < 0) { WM_STRIPE_EVENT(3); lds_st_rel(ctrl, L::C_RESTART, 1); lds_st_rel(ctrl, L::C_STOP, -1); all_done = true; break; }
+								ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
+								lds_st_rel(ctrl, L::C_EZL, ez_max);
+							} else if (zdrop >= 0 && ez_max - max_H > zdrop) {       // (otherwise the test of src/ksw2.h:168 cannot fire whatever max_t is)
+								if (ppri < 0) { WM_STRIPE_EVENT(3); lds_st_rel(ctrl, L::C_RESTART, 1); lds_st_rel(ctrl, L::C_STOP, -1); all_done = true; break; }
+								if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
+									const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+									if (ez_max - max_H > zdrop + l * e2) {
+										ez_zdropped = 1; my_stop = true; WM_STRIPE_EVENT(6);
+										lds_st_rel(ctrl, L::C_STOP, r);
+										row_done = r; was_last = true; all_done = true;
+										break;
+									}
+								}
+							}
+							if (r == n_rows - 1 && en0 == tlen - 1) ez_score = h_en0;
+						}
+					} else if constexpr (!CLIP && WM_KSW_EDGE_TRACK) {
+						// approximate max, band never clips: follow the hull's first lane (see ksw_dp_packed). The owner is the stripe that holds st0
+						if (trk) {
+							WM_EMU_ASSERT(st0 >= a && st0 < a + SW);
+							const int d = (r < qlen ? half_of(Vv, st0) : half_of(U, st0)) >> 8;
+							H0 = r ? H0 + d : d - qe;
+							if (r == n_rows - 1) ez_score = H0;
+							const int st0n = r + 1 - qlen + 1 > 0 ? r + 1 - qlen + 1 : 0;       // st0 of the next row
+							if (st0n >= a + SW && r + 1 < n_rows) { WM_STRIPE_EVENT(4); out_th0 = H0; out_tl0 = st0n; trk = false; WM_EMU_ASSERT(pub); }
+						}
+						if (in_tl0 >= 0) { trk = true; H0 = in_th0; }
+					} else {
+						// approximate max along one diagonal-ish track (:359-375): the step of row r reads v of lane L0 and u of lane L0 + 1 of THIS row. The
+						// track never trails the band (after row r: L0 >= st0(r)), so both lanes are in the owner's stripe or L0 is the left neighbour's last
+						// lane, whose v arrives in the left message. When the next step's lane L0 + 1 belongs to the right neighbour and that one computes cells
+						// in the next row, the state goes there in this row's message (as long as it does not, L0 + 1 is beyond the band and the step is ours)
+						if (trk) {
+							if (r > 0) {
+								const int L1 = last_H0_t + 1;
+								const bool in0 = last_H0_t >= st0 && last_H0_t <= en0, in1 = L1 >= st0 && L1 <= en0;
+								int d0 = 0, d1 = 0;
+								if (in0) d0 = last_H0_t >= a ? half_of(Vv, last_H0_t) >> 8 : (int)(short)m_v >> 8;
+								if (L1 >= a && L1 < a + SW) d1 = half_of(U, L1) >> 8;
+								WM_EMU_ASSERT((in0 || (L1 >= a && L1 < a + SW)) && (!in1 || L1 < a + SW) && last_H0_t >= a - 1);
+								if (in0 && in1) {
+									if (d0 > d1) H0 += d0;
+									else H0 += d1, ++last_H0_t;
+								} else if (in0) H0 += d0;
+								else { ++last_H0_t; H0 += d1; }
+							} else { H0 = (half_of(Vv, 0) >> 8) - qe; last_H0_t = 0; }
+							if (r == n_rows - 1 && en0 == tlen - 1) ez_score = H0;
+							if (last_H0_t + 1 >= a + SW && r + 1 < n_rows) {
+								ksw_geo_t gn;
+								if (ksw_geo<CLIP>(r + 1, qlen, tlen, w, gn) && a + SW <= gn.en) { WM_STRIPE_EVENT(5); out_th0 = H0; out_tl0 = last_H0_t; trk = false; WM_EMU_ASSERT(pub); }
+							}
+						}
+						if (in_tl0 >= 0) { trk = true; H0 = in_th0; last_H0_t = in_tl0; }
+					}
+
+					// ---- publish this row for the right neighbour ----
+					if (pub) {
+						while (lds_ld_acq(prog, right_wv) < r - R) { if (lds_ld_acq(ctrl, L::C_STOP) <= r) { stopped = true; break; } WM_STRIPE_SPIN(2, r, a, wv, lds_ld_acq(prog, right_wv)); spin_pause(); }
+						if (stopped) { all_done = true; break; }
+						int *m = ring_out + (r % R) * L::SLOT;
+						WM_IF(ln == 63)
+							lds_st(m, V<int>(L::M_X), lshr(X[BP - 1], 16)); lds_st(m, V<int>(L::M_V), lshr(Vv[BP - 1], 16)); lds_st(m, V<int>(L::M_X2), lshr(X2[BP - 1], 16));
+							if constexpr (EXACT) {
+								lds_st(m, V<int>(L::M_H), H[EXACT ? B - 1 : 0]); lds_st(m, V<int>(L::M_PM), V<int>(pm)); lds_st(m, V<int>(L::M_PRI), V<int>(ppri)); lds_st(m, V<int>(L::M_HST0), V<int>(hst0));
+								if (en == a + SW - 1) {
+									lds_st(m, V<int>(L::M_EZ + 0), V<int>(ez_max)); lds_st(m, V<int>(L::M_EZ + 1), V<int>(ez_max_t)); lds_st(m, V<int>(L::M_EZ + 2), V<int>(ez_max_q));
+									lds_st(m, V<int>(L::M_EZ + 3), V<int>(ez_mqe)); lds_st(m, V<int>(L::M_EZ + 4), V<int>(ez_mqe_t)); lds_st(m, V<int>(L::M_EZ + 5), V<int>(ez_mte));
+									lds_st(m, V<int>(L::M_EZ + 6), V<int>(ez_mte_q)); lds_st(m, V<int>(L::M_EZ + 7), V<int>(ez_score));
+								}
+							} else { lds_st(m, V<int>(L::M_TH0), V<int>(out_th0)); lds_st(m, V<int>(L::M_TL0), V<int>(out_tl0)); }
+						WM_END
+						lds_st_rel(m, L::M_STAMP, r);
+					}
+					lds_st_rel(prog, wv, r - 1);                 // the left ring's messages up to row r - 1 may be overwritten
+					row_done = r; was_last = is_last;
+					if (r >= stop_row) { all_done = true; break; }   // (a z-drop in row stop_row: nothing after it exists)
 				}
-				lds_st_rel(prog, wv, r - 1);                 // the left ring's messages up to row r - 1 may be overwritten
-				row_done = r; was_last = is_last;
-				if (r >= stop_row) { all_done = true; break; }   // (a z-drop in row stop_row: nothing after it exists)
 			}
 		}
 

@@ -222,6 +222,20 @@ WM_DEV int lds_ld_acq(const int *p, long long i)
 	asm volatile("" ::: "memory");
 	return v;
 }
+// a message slot (16-byte aligned): the stamp p[0] first, then the 8 payload ints p[4..11] as two 128-bit loads — three DS instructions issued back
+// to back, executed in that order, ONE wait. If the stamp read is the expected one, the payload — written before the stamp — is too.
+WM_DEV int lds_ld_msg(const int *p, int (&o)[8])
+{
+	typedef int wm_i4 __attribute__((ext_vector_type(4)));
+	typedef __attribute__((address_space(3))) wm_i4 wm_lds_i4;
+	asm volatile("" ::: "memory");
+	const int s = ((const volatile wm_lds_int*)p)[0];
+	const wm_i4 a = *(const volatile wm_lds_i4*)((const wm_lds_int*)p + 4), b = *(const volatile wm_lds_i4*)((const wm_lds_int*)p + 8);
+	asm volatile("" ::: "memory");
+	o[0] = __builtin_amdgcn_readfirstlane(a.x); o[1] = __builtin_amdgcn_readfirstlane(a.y); o[2] = __builtin_amdgcn_readfirstlane(a.z); o[3] = __builtin_amdgcn_readfirstlane(a.w);
+	o[4] = __builtin_amdgcn_readfirstlane(b.x); o[5] = __builtin_amdgcn_readfirstlane(b.y); o[6] = __builtin_amdgcn_readfirstlane(b.z); o[7] = __builtin_amdgcn_readfirstlane(b.w);
+	return __builtin_amdgcn_readfirstlane(s);
+}
 WM_DEV void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 
 } // namespace simt
