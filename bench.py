@@ -40,7 +40,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before HIP initialises (see winnowmap_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")   # before HIP initialises (see winnowmap_amd/__init__.py)
 from winnowmap_amd import gpu, synth  # noqa: E402
 from winnowmap_amd import dist as wmdist  # noqa: E402
 from winnowmap_amd import parity as wmparity  # noqa: E402

@@ -234,7 +234,7 @@ def test_position_jobs_equal_byte_jobs(tmp_path):
 def all_stripes():
     gpu.set_ksw_routing(1, 1, 1)
     yield
-    gpu.set_ksw_routing(-1, int(os.environ.get("WM_KSW_STRIPE_ROWS4", 0)), int(os.environ.get("WM_KSW_STRIPE_ROWS8", 2048)))
+    gpu.set_ksw_routing(-1, int(os.environ.get("WM_KSW_STRIPE_ROWS4", 0)), int(os.environ.get("WM_KSW_STRIPE_ROWS8", 4096)))
 
 
 @pytest.mark.parametrize("preset", [0, 1, 2, 3, 4])

@@ -11,7 +11,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
 B = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(B)

@@ -2,7 +2,7 @@
 import os
 
 # The mapper drives the GPU from many host threads, one HIP stream each; ROCm maps streams onto 4 hardware queues by
-# default, which serialises them. 16 is what an MI355X runs cleanly at once (profiles/r02f_stream_conc.txt: 15.5 kernels in
-# flight with 16 or 20 queues; 24 and more oversubscribe the queue slots and fall back to 4..8). Must be set before the HIP
-# runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# default, which serialises them. 16 or 20 queues run that many kernels at once (profiles/r02f_stream_conc.txt); 24 and more
+# oversubscribe the queue slots. 20 = 6 device contexts + 14 side streams split by the weight of a call (round 4: +14 % over 16,
+# profiles/r04g_sched_sweep.txt). Must be set before the HIP runtime initialises (the library sets the same default itself).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")

@@ -281,9 +281,10 @@ struct wm_ctx_s {
 	hipStream_t stream;
 	hipStream_t kstream[4];                     // own side streams (created on first use): kernel classes of one batch run concurrently
 	// the mapper's contexts draw their side streams from ONE pool instead, sized so that all streams of the mapper fit the hardware queues
-	// (GPU_MAX_HW_QUEUES = 16: more streams than queues share queues and serialise, profiles/r02f_stream_conc.txt)
+	// (GPU_MAX_HW_QUEUES = 20 since round 4 — 6 main streams + 14 side streams; 16 / 24 / 32 measured slower, profiles/r04g_sched_sweep.txt;
+	// more streams than queues share queues and serialise, profiles/r02f_stream_conc.txt)
 	hipStream_t *side_pool; int n_side_pool; std::atomic<unsigned> *side_next;
-	std::vector<hipStream_t> owned_pool; std::atomic<unsigned> owned_next{0};   // (the pool lives in the mapper's first context; the others point at it)
+	std::vector<hipStream_t> owned_pool; std::atomic<unsigned> owned_next[3];   // (the pool lives in the mapper's first context; the others point at it; one cursor per weight class)
 	hipEvent_t kev[5];
 	hipEvent_t cev[WM_KSW_NCLASS][2];           // per-class start/stop (on the stream the class was launched on)
 	double k_ms[WM_KSW_NCLASS]; uint64_t k_cells[WM_KSW_NCLASS], k_launches[WM_KSW_NCLASS];   // accumulated per kernel class
@@ -369,6 +370,11 @@ static hipError_t ctx_sync(wm_ctx_s *c)
 	}
 }
 
+// ROCm maps HIP streams onto 4 hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and reads it when the runtime initialises: a library
+// constructor sets the default the mapper is tuned for (6 contexts + 14 side streams) before any HIP call of this process can have happened
+// through this library; a value given by the user wins. (Python callers get the same default from winnowmap_amd/__init__.py.)
+__attribute__((constructor)) static void wm_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "20", 0); }
+
 extern "C" int wm_device_count(void)
 {
 	int n = 0;
@@ -395,6 +401,7 @@ extern "C" int wm_ctx_create(int device, size_t arena_bytes, wm_ctx_t **out)
 	HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 	for (int i = 0; i < 4; ++i) c->kstream[i] = 0;
 	c->side_pool = 0; c->n_side_pool = 0; c->side_next = 0;
+	for (int i = 0; i < 3; ++i) c->owned_next[i] = 0;
 	for (int i = 0; i < 5; ++i) HIPCHK(hipEventCreateWithFlags(&c->kev[i], hipEventDisableTiming));
 	for (int k = 0; k < WM_KSW_NCLASS; ++k) { HIPCHK(hipEventCreate(&c->cev[k][0])); HIPCHK(hipEventCreate(&c->cev[k][1])); c->k_ms[k] = 0; c->k_cells[k] = c->k_launches[k] = 0; }
 	for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
@@ -467,7 +474,7 @@ static int stripe_min_rows(int bp)
 {
 	if (g_stripe_on.load(std::memory_order_relaxed) < 0) {
 		g_stripe_rows4 = getenv("WM_KSW_STRIPE_ROWS4") ? std::max(0, atoi(getenv("WM_KSW_STRIPE_ROWS4"))) : 0;
-		g_stripe_rows8 = getenv("WM_KSW_STRIPE_ROWS8") ? std::max(0, atoi(getenv("WM_KSW_STRIPE_ROWS8"))) : 2048;
+		g_stripe_rows8 = getenv("WM_KSW_STRIPE_ROWS8") ? std::max(0, atoi(getenv("WM_KSW_STRIPE_ROWS8"))) : 4096;      // (3 000-row extensions are faster on one wavefront, 10 000-row ones on four: profiles/r04c_probe.txt)
 		g_stripe_on = !(getenv("WM_KSW_STRIPE") && atoi(getenv("WM_KSW_STRIPE")) == 0);
 	}
 	return !g_stripe_on.load(std::memory_order_relaxed) ? 0 : bp == 4 ? g_stripe_rows4.load(std::memory_order_relaxed) : bp == 8 ? g_stripe_rows8.load(std::memory_order_relaxed) : 1;   // (bp == 0: are the stripe classes on at all)
@@ -724,9 +731,35 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	if (fan) HIPCHK(hipEventRecord(c->kev[4], c->stream));
 	hipStream_t ks = c->stream;
 	hipStream_t side[4] = {0, 0, 0, 0};          // the side streams of this call: from the mapper's pool, else the context's own
-	const int n_use = c->side_pool ? std::min(n_side, c->n_side_pool) : n_side;
+	// The pool is shared by the contexts, i.e. by concurrent calls: a kernel waits for whatever sits in front of it on its stream. A call of short
+	// alignments must never queue behind a 50-ms launch of another call, so the pool is split by the weight of the call (its longest job, in the
+	// units of the hub's queues: rows x register pairs): light | heavy | huge calls draw from their own part (WM_SIDE_SPLIT=light,heavy; rest = huge;
+	// 0,0 = one pool as before).
+	int pool_lo = 0, pool_n = c->n_side_pool, wclass = 0;
+	if (c->side_pool && c->n_side_pool >= 6) {
+		static const long heavy_units = getenv("WM_KSW_HEAVY_UNITS") ? atol(getenv("WM_KSW_HEAVY_UNITS")) : 8192, huge_units = getenv("WM_KSW_HUGE_UNITS") ? atol(getenv("WM_KSW_HUGE_UNITS")) : 131072;
+		static int split_l = -1, split_h = -1;
+		if (split_l < 0) {
+			int a = (c->n_side_pool * 3 + 3) / 7, h = (c->n_side_pool * 2 + 3) / 7;           // 14 streams: 6 | 4 | 4 (profiles/r04g_sched_sweep.txt); 10: 4 | 3 | 3
+			if (const char *e = getenv("WM_SIDE_SPLIT")) sscanf(e, "%d,%d", &a, &h);
+			split_h = std::max(0, h); split_l = std::max(0, a);
+		}
+		if (split_l > 0 && split_h > 0 && split_l + split_h < c->n_side_pool) {
+			long mx = 0;
+			for (const wm_ksw_djob_t &d : b->jobs) {
+				if (d.klass < 0) continue;
+				long w_ = d.w < 0 ? std::max(d.qlen, d.tlen) : d.w, nn = std::min(d.qlen, d.tlen);
+				if (nn > w_ + 1) nn = w_ + 1;
+				mx = std::max(mx, ((long)d.qlen + d.tlen) * ((nn + 127) / 128 + 1));
+			}
+			wclass = huge_units > 0 && mx > huge_units ? 2 : heavy_units > 0 && mx > heavy_units ? 1 : 0;
+			pool_lo = wclass == 0 ? 0 : wclass == 1 ? split_l : split_l + split_h;
+			pool_n = wclass == 0 ? split_l : wclass == 1 ? split_h : c->n_side_pool - split_l - split_h;
+		}
+	}
+	const int n_use = c->side_pool ? std::min(n_side, pool_n) : n_side;
 	if (fan && n_use > 0) {
-		if (c->side_pool) { const unsigned b0 = c->side_next->fetch_add((unsigned)n_use); for (int i = 0; i < n_use; ++i) side[i] = c->side_pool[(b0 + (unsigned)i) % (unsigned)c->n_side_pool]; }
+		if (c->side_pool) { const unsigned b0 = c->side_next[wclass].fetch_add((unsigned)n_use); for (int i = 0; i < n_use; ++i) side[i] = c->side_pool[pool_lo + (int)((b0 + (unsigned)i) % (unsigned)pool_n)]; }
 		else for (int i = 0; i < n_use; ++i) { if (!c->kstream[i]) HIPCHK(hipStreamCreateWithFlags(&c->kstream[i], hipStreamNonBlocking)); side[i] = c->kstream[i]; }
 	}
 	auto next_stream = [&]() {
@@ -2623,8 +2656,8 @@ extern "C" int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena
 		HIPCHK(hipStreamSynchronize(c0->stream));
 		while ((int)c0->owned_pool.size() > P) { hipStreamDestroy(c0->owned_pool.back()); c0->owned_pool.pop_back(); }
 		while ((int)c0->owned_pool.size() < P) { hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); c0->owned_pool.push_back(st); }
-		c0->side_pool = P > 0 ? c0->owned_pool.data() : 0; c0->n_side_pool = P; c0->side_next = &c0->owned_next;
-		for (wm_ctx_t *w : m->workers) { w->side_pool = c0->side_pool; w->n_side_pool = P; w->side_next = &c0->owned_next; }
+		c0->side_pool = P > 0 ? c0->owned_pool.data() : 0; c0->n_side_pool = P; c0->side_next = c0->owned_next;
+		for (wm_ctx_t *w : m->workers) { w->side_pool = c0->side_pool; w->n_side_pool = P; w->side_next = c0->owned_next; }
 	}
 	// the pinned staging slabs are allocated now, not inside the first mapping call (page-locking a few GB takes a noticeable fraction of a second)
 	{ size_t mark = 0; if (pin_take(m->c, 1, &mark)) pin_release(m->c, mark); }
