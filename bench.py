@@ -194,8 +194,13 @@ def host_report(hs0, hs1, ru0, ru1, elapsed, n_cores):
             "map_wall_s": round(d(hs0["map_wall_s"], hs1["map_wall_s"]), 2), "format_wall_s": round(d(hs0["format_wall_s"], hs1["format_wall_s"]), 2)}
 
 
-def make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1):
-    """The JSON line (without cpu_baseline). ks0/ks1: Mapper.kernel_stats() before/after the timed region."""
+VALU_CEILING = {"lane_ops_per_s": 37.4e12, "wave_instr_per_s": 37.4e12 / 64, "packed_valu_per_128_cells": 53,
+                "gcups": 37.4e12 / 64 / 53 * 128 / 1e9, "source": "tools/ubench/valu_bench.hip on MI355X: profiles/r02_valu_bench.txt (packed 16-bit VALU, all CUs)"}
+
+
+def make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1, union_ms=None):
+    """The JSON line (without cpu_baseline). ks0/ks1: Mapper.kernel_stats() before/after the timed region; union_ms: per class id, the ms with at
+    least one launch of the class running inside the timed region (Mapper.kernel_union)."""
     value = total_bases / elapsed / 1e9
     # dominant kernel = the ksw kernel (instantiation) with the largest summed launch time in the timed region (HIP events on its stream);
     # several job classes can share one kernel (the 16-pair classes all run on ksw_pmulti_kernel<4, 4>)
@@ -210,6 +215,26 @@ def make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1):
     all_ms = sum(v[0] for v in cls.values())
     all_cells = sum(v[1] for v in cls.values())
     classes = {k: {"ms": round(v[0], 3), "cells": v[1], "launches": v[2]} for k, v in cls.items() if v[2] > 0}
+    # launches of one kernel overlap on different streams: `ms` above is summed residency; `union_ms` is the time with at least one launch running
+    if union_ms:
+        un = {}
+        for k, v in union_ms.items():
+            if k in ks1:
+                un[ksw_class_name(k)] = un.get(ksw_class_name(k), 0.0) + v      # (classes sharing a kernel: an upper bound of their union)
+        for k in classes:
+            classes[k]["union_ms"] = round(un.get(k, 0.0), 3)
+            classes[k]["gcups_residency"] = round(classes[k]["cells"] / max(classes[k]["ms"], 1e-9) / 1e6, 2)
+            classes[k]["gcups_union"] = round(classes[k]["cells"] / max(classes[k]["union_ms"], 1e-9) / 1e6, 2) if classes[k]["union_ms"] > 0 else None
+    # instructions per DP cell of each kernel, from separate rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU passes (tools/pmc_insts.py -> profiles/)
+    ipc = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "insts_per_cell.json")) as f:
+            ipc = json.load(f)
+        for k in classes:
+            if k in ipc.get("kernels", {}):
+                classes[k].update({"valu_per_cell": ipc["kernels"][k].get("valu_per_cell"), "salu_per_cell": ipc["kernels"][k].get("salu_per_cell")})
+    except Exception:  # noqa: BLE001
+        ipc = None
     # HBM traffic per DP cell of each kernel, measured in separate rocprofv3 --pmc passes (tools/pmc_ratio.py -> profiles/)
     traffic = None
     pmc = None
@@ -236,7 +261,15 @@ def make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1):
                      "kernel": kname, "algorithmic_bytes": "1 B traceback per DP cell (sequence bytes are < 1 %)",
                      "launches": d_launch, "avg_launch_ms": d_ms / max(1, d_launch), "cells_per_launch": d_cells / max(1, d_launch),
                      "gcups_dominant": d_cells / max(d_ms, 1e-9) / 1e6, "gcups_all_ksw_classes": all_cells / max(all_ms, 1e-9) / 1e6,
-                     "note": "int8 DP is VALU-issue bound (61 packed instructions per 128 cells in the register classes), not HBM bound; launch durations include overlap with other streams"},
+                     # what bounds the kernels is instruction issue, not memory: the measured packed-VALU ceiling of the chip, the DP rate it allows at the
+                     # 53 packed VALU instructions per 128 cells of the lean register kernel, and how far the step and the dominant kernel are from it
+                     "valu_ceiling": VALU_CEILING,
+                     "gcups_step": all_cells / max(elapsed, 1e-9) / 1e9 / max(1, world),
+                     "issue_frac_step": all_cells / max(elapsed, 1e-9) / 1e9 / max(1, world) / VALU_CEILING["gcups"],
+                     "issue_frac_dominant": d_cells / max(d_ms, 1e-9) / 1e6 / VALU_CEILING["gcups"],
+                     "insts_per_cell_source": (ipc or {}).get("source"),
+                     "note": "int8 DP is instruction-issue bound, not HBM bound (frac above is the HBM fraction of the 1 B/cell traceback stream); `ms` of a class is the SUM of its launch "
+                             "durations (launches overlap on different streams: residency), `union_ms` the time with at least one launch running; gcups_step = cells of all classes / wall time of the timed region"},
     }
 
 
@@ -316,7 +349,10 @@ def main():
     # later steps cycle through these (mapping is stateless). Every distinct batch is mapped once before the timed region when there is a warm-up:
     # the library's pinned pools and result buffers grow to the largest batch they have seen, and a batch first seen inside the timed region
     # pays for that growth (0.2545 vs 0.272 Gbp/s, profiles/r03o_*)
-    n_distinct = min(n_steps, int(os.environ.get("WM_BENCH_DISTINCT_BATCHES", 4)), args.warmup if args.warmup > 0 else n_steps)
+    # (the cap by the warm-up count made every timed step a batch the library had already seen. Now up to 4 distinct batches whatever
+    # the warm-up; the JSON line says how many timed steps ran on batches first seen inside the timed region — all batches have the same shape, so
+    # what a first sight costs is the growth of pinned pools / result buffers to this batch's hit count)
+    n_distinct = min(n_steps, int(os.environ.get("WM_BENCH_DISTINCT_BATCHES", 4)))
     reads, _ = synth.make_reads(ref, n_distinct * args.reads_per_step, args.read_len, cfg["seed"] + 1000 * rank, profile=cfg["profile"], sv_frac=cfg["sv_frac"])
     seqs = [synth.codes_to_ascii(r) for r in reads]
     del reads
@@ -369,6 +405,13 @@ def main():
 
     run_steps(mbatches[:args.warmup])
     sync()
+    seen = set(i % n_distinct for i in range(args.warmup))
+    unseen_steps = 0
+    for i in range(args.warmup, n_steps):
+        if i % n_distinct not in seen:
+            unseen_steps += 1
+            seen.add(i % n_distinct)
+    _, dev_t0 = mapper.kernel_union(0.0)
     ks0 = mapper.kernel_stats()
     hs0 = mapper.host_stats()
     thr0 = cgroup_throttle()
@@ -388,7 +431,10 @@ def main():
         total_bases = float(bases)
 
     if rank == 0:
-        out = make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1)
+        union_ms, _ = mapper.kernel_union(dev_t0)
+        out = make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1, union_ms)
+        out["config"]["distinct_batches"] = n_distinct
+        out["config"]["timed_steps_on_batches_first_seen_in_the_timed_region"] = unseen_steps
         if dist is not None:
             out["config"]["rccl_world_size"] = dist.get_world_size()
         out["host"] = host_report(hs0, hs1, ru0, ru1, elapsed, n_cores)
@@ -399,6 +445,32 @@ def main():
         out["host"]["host_bound_note"] = "bases per CPU-second of this rank x its host threads: the rate at which the host glue alone could feed one GPU; with N ranks on one node the usable cores are divided by N"
         thr1 = cgroup_throttle()
         out["host"]["cpu_quota_throttled"] = {"periods": thr1[0] - thr0[0], "seconds": round(thr1[1] - thr0[1], 3)}
+        # what THIS node's host side allows at 8 ranks: all usable cores / the CPU-seconds one base costs — next to 8 x this rank's rate
+        out["host"]["host_bound_gbps_node"] = round(n_cores / max(cpu_per_base, 1e-12) / 1e9, 4)
+        out["host"]["predicted_8rank_gbps"] = round(min(8 * out["value"] / max(1, world), n_cores / max(cpu_per_base, 1e-12) / 1e9), 4)
+        out["host"]["predicted_8rank_note"] = "min(8 x the per-rank rate of this run, usable cores / CPU-s per base): with %d usable cores the host side caps an 8-rank node here; not a measurement" % n_cores
+        if world == 1 and int(os.environ.get("WM_BENCH_FILE", 1)):
+            # the drop-in path: reads.fa -> out.paf through wm_map_file (reader / two mapping lanes / ordered writer, host/wm_pipeline.cpp) on the
+            # mini-batches of the timed region: FASTA parsing and record output inside the clock, as in the reference's mapping phase (src/map.c:1107-1224)
+            try:
+                nb = min(2, len(distinct))
+                rq_f = os.path.join(tmp, "f2f_reads.fa")
+                fn, fs_ = [], []
+                for d_ in distinct[:nb]:
+                    fn += d_[0]; fs_ += d_[1]
+                write_reads_fasta(rq_f, fn, fs_)
+                fbases = sum(len(x) for x in fs_)
+                t_f = time.time()
+                st_f = mapper.map_file(rq_f, os.path.join(tmp, "f2f_out.paf"), int(fbases // nb) + 1)
+                wall_f = time.time() - t_f
+                out["file_to_file"] = {"value": fbases / wall_f / 1e9, "unit": "Gbp/s", "reads": len(fs_), "mini_batches": int(st_f["batches"]), "wall_s": round(wall_f, 3),
+                                       "read_s": round(st_f["t_read"], 3), "map_s": round(st_f["t_map"], 3), "write_s": round(st_f["t_write"], 3),
+                                       "paf_bytes": os.path.getsize(os.path.join(tmp, "f2f_out.paf")),
+                                       "note": "wm_map_file(reads.fa -> out.paf): %d mini-batch(es) of one step each, FASTA parsing and PAF output inside the clock; reported beside `value`, not instead" % nb}
+                os.unlink(rq_f)
+                log("file to file: %d reads, %.2f s = %.4f Gbp/s (read %.2f map %.2f write %.2f s)" % (len(fs_), wall_f, fbases / wall_f / 1e9, st_f["t_read"], st_f["t_map"], st_f["t_write"]))
+            except Exception as e:  # noqa: BLE001
+                log("file-to-file leg error:", repr(e))
         if world == 1 and args.cpu_sample != 0:
             # one full step (the first timed batch) through the REAL reference on this host's cores: CPU baseline + parity
             bn, bs = batches[args.warmup]
@@ -411,8 +483,9 @@ def main():
                     ours, _, _, _ = mapper.map(bn, bs, copy_text=True)
                     with open(ref_paf, "rb") as f:
                         d = wmparity.diff_texts(f.read(), ours, sam=False)
-                    out["parity"] = {"reads": len(bs), "reads_with_hits": d["reads"], "hits": d["hits"], "mismatches": d["mismatches"],
-                                     "compared": "PAF records incl. cg:Z CIGAR and all tags vs winnowmap_ref on the same reads; MAPQ and rl:i masked (reference UB, src/map.c:281)"}
+                    out["parity"] = {"reads": len(bs), "reads_with_hits": d["reads"], "hits": d["hits"], "mismatches": d["mismatches"], "mapq_compared": d["mapq_compared"],
+                                     "compared": "PAF records incl. cg:Z CIGAR and all tags vs winnowmap_ref on the same reads; MAPQ and rl:i masked only for reads of >= 10 000 bases "
+                                                 "(the MCAS path: uninitialised rep_len in the reference, src/map.c:281) — i.e. for every read of this workload; compared below the gate in tests/"}
                     if d["examples"]:
                         out["parity"]["examples"] = d["examples"]
                     log("parity: %d reads, %d hits, %d mismatching reads (%.1fs)" % (len(bs), d["hits"], d["mismatches"], time.time() - t2))

@@ -316,6 +316,9 @@ int wm_mapper_stats(const wm_mapper_t *m, uint64_t *out9);
  * wm_mapper_create: out[3k] = summed launch durations (ms, HIP events on the launching stream), out[3k+1] = DP cells,
  * out[3k+2] = launches. cap = doubles available in out; *n_classes receives the class count. Feeds bench.py's roofline. */
 int wm_mapper_kernel_stats(const wm_mapper_t *m, double *out, int cap, int *n_classes);
+/* Launches of one class overlap on different streams, so the summed durations above are residency. out[k] = ms during which AT LEAST ONE launch of
+ * class k was running (union of the launch intervals on the device clock) after since_ms; *now_ms = the clock now (the next call's since_ms). */
+int wm_mapper_kernel_union(const wm_mapper_t *m, double since_ms, double *out, int cap, double *now_ms);
 /* where the host time of the mapping calls went since wm_mapper_create (seconds, summed over the worker threads; the host replaces
  * kt_for(worker_for), src/map.c:1164): out[0] = CPU time running the per-read glue, out[1] = wall time asleep waiting for device results,
  * out[2..5] = CPU time inside the batched window (sketch → seed → sort → chain, one call) / seed / chain / ksw calls, out[6..9] = their wall time, out[10..13] = number of

@@ -28,7 +28,7 @@ def key(kernel_name):        # "void ksw_dp_kernel<16, true, false>(...)" -> "ks
         return None
     k = m.group(1)
     pm = re.match(r"ksw_pmulti_kernel<(\d+), (\d+)", k)      # the <CLIP, HASN> variants of one geometry are one class in bench.py
-    return "ksw_pmulti_kernel<%s, %s>" % pm.groups() if pm else k              # (spelled like bench.py's class names, spaces included)
+    return "ksw_pmulti_kernel<%s, %s>" % pm.groups() if pm else k              # (spelled like bench.py's class names, spaces included; stripe kernels keep their <BP, NWV, CLIP, HASN>)
 
 
 # the --pmc passes serialise the dispatches: their durations are each kernel's time ALONE on the chip (no sharing with concurrent kernels)
@@ -60,3 +60,31 @@ for k in set(list(fetch) + list(write)):
 m_ = re.search(r'"reads_per_step_per_gpu": (\d+)', open(os.path.join(src, "pmc1.log")).read())
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --steps 1 --warmup 0 --reads-per-step %s (%s), FETCH_SIZE x2 (gfx950), KiB units" % (m_.group(1) if m_ else "?", os.path.basename(src.rstrip("/"))),
            "bytes_per_cell": out}, open("profiles/pmc_bytes_per_cell.json", "w"), indent=1)
+
+# ---- instruction issue per DP cell (third pass): SQ_INSTS_* count wave-instructions, SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_ANY quad-cycles ----
+try:
+    names = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")
+    raw = {n: counters("pmc3", n) for n in names}
+    c3 = classes("pmc3.log")
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for n in names:
+        for kn, v in raw[n].items():
+            per[key(kn)][n] += v
+    kern = {}
+    for k, v in per.items():
+        if not k or k not in c3 or not c3[k]["cells"]:
+            continue
+        cells = c3[k]["cells"]
+        ins = v["SQ_INSTS_VALU"] + v["SQ_INSTS_SALU"] + v["SQ_INSTS_LDS"]
+        kern[k] = {"valu_per_cell": v["SQ_INSTS_VALU"] / cells, "salu_per_cell": v["SQ_INSTS_SALU"] / cells, "valu_per_128_cells": 128 * v["SQ_INSTS_VALU"] / cells,
+                   "salu_per_128_cells": 128 * v["SQ_INSTS_SALU"] / cells, "cycles_per_instruction_per_wave": 4.0 * v["SQ_WAVE_CYCLES"] / max(ins, 1.0),
+                   "wave_cycles_waiting_frac": v["SQ_WAIT_ANY"] / max(v["SQ_WAVE_CYCLES"], 1.0), "wave_cycles_issue_stall_frac": v["SQ_WAIT_INST_ANY"] / max(v["SQ_WAVE_CYCLES"], 1.0),
+                   "wave_cycles_active_frac": v["SQ_ACTIVE_INST_ANY"] / max(v["SQ_WAVE_CYCLES"], 1.0)}
+        print("%-40s VALU %.1f SALU %.1f per 128 cells, %.1f cycles per instruction per wave, waiting %.0f %% stalled %.0f %% issuing %.0f %%" %
+              (k, kern[k]["valu_per_128_cells"], kern[k]["salu_per_128_cells"], kern[k]["cycles_per_instruction_per_wave"], 100 * kern[k]["wave_cycles_waiting_frac"],
+               100 * kern[k]["wave_cycles_issue_stall_frac"], 100 * kern[k]["wave_cycles_active_frac"]))
+    json.dump({"source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY pass of bench.py --steps 1 --warmup 0 "
+                         "--reads-per-step %s (%s): wave-instructions per DP cell; cycle counters are quad-cycles (MI355X_MICROARCH.md)" % (m_.group(1) if m_ else "?", os.path.basename(src.rstrip("/"))),
+               "kernels": kern}, open("profiles/insts_per_cell.json", "w"), indent=1)
+except Exception as e:
+    print("no instruction counter pass:", e)

@@ -11,9 +11,11 @@ mkdir -p $OUT
 if [ "${PMC:-0}" = "1" ]; then
   # HBM traffic (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE, in their own passes, no trace domains)
   # (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950; a reduced batch keeps the serialised counter runs short)
-  ( cd /tmp && WM_BENCH_CPU_SAMPLE=0 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc1 -o bench -- python $ROOT/bench.py --steps 1 --warmup 0 --reads-per-step ${PMC_READS:-1024} > $OUT/pmc1.log 2>&1 )
-  ( cd /tmp && WM_BENCH_CPU_SAMPLE=0 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc2 -o bench -- python $ROOT/bench.py --steps 1 --warmup 0 --reads-per-step ${PMC_READS:-1024} > $OUT/pmc2.log 2>&1 )
-  ( cd $ROOT && python tools/pmc_ratio.py gpurun_out/prof_$TAG > $OUT/pmc_ratio.txt 2>&1; cat $OUT/pmc_ratio.txt; cp profiles/pmc_bytes_per_cell.json $OUT/ )
+  ( cd /tmp && WM_BENCH_CPU_SAMPLE=0 WM_BENCH_FILE=0 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc1 -o bench -- python $ROOT/bench.py --steps 1 --warmup 0 --reads-per-step ${PMC_READS:-1024} > $OUT/pmc1.log 2>&1 )
+  ( cd /tmp && WM_BENCH_CPU_SAMPLE=0 WM_BENCH_FILE=0 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc2 -o bench -- python $ROOT/bench.py --steps 1 --warmup 0 --reads-per-step ${PMC_READS:-1024} > $OUT/pmc2.log 2>&1 )
+  # instruction issue: what bounds the DP kernels: wave-instructions by type, wave cycles (quad-cycles) and where they went
+  ( cd /tmp && WM_BENCH_CPU_SAMPLE=0 WM_BENCH_FILE=0 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc3 -o bench -- python $ROOT/bench.py --steps 1 --warmup 0 --reads-per-step ${PMC_READS:-1024} > $OUT/pmc3.log 2>&1 )
+  ( cd $ROOT && python tools/pmc_ratio.py gpurun_out/prof_$TAG > $OUT/pmc_ratio.txt 2>&1; cat $OUT/pmc_ratio.txt; cp profiles/pmc_bytes_per_cell.json profiles/insts_per_cell.json $OUT/ )
 fi
 python bench.py "$@" > $OUT/bench.json 2> $OUT/bench.log
 grep -v "^W2026" $OUT/bench.log | tail -6; cat $OUT/bench.json

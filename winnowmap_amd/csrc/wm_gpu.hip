@@ -288,6 +288,9 @@ struct wm_ctx_s {
 	hipEvent_t kev[5];
 	hipEvent_t cev[WM_KSW_NCLASS][2];           // per-class start/stop (on the stream the class was launched on)
 	double k_ms[WM_KSW_NCLASS]; uint64_t k_cells[WM_KSW_NCLASS], k_launches[WM_KSW_NCLASS];   // accumulated per kernel class
+	// every launch of a class as an interval on the device's clock (ms since the process-wide base event): launches of one class overlap on
+	// different streams, so their SUMMED durations are residency, not time — the union of the intervals is (wm_mapper_kernel_union)
+	std::vector<std::pair<float, float>> k_iv[WM_KSW_NCLASS];
 	uint8_t *arena;
 	size_t arena_bytes, arena_used;
 	hipEvent_t ev[4];
@@ -374,6 +377,22 @@ static hipError_t ctx_sync(wm_ctx_s *c)
 // constructor sets the default the mapper is tuned for (6 contexts + 14 side streams) before any HIP call of this process can have happened
 // through this library; a value given by the user wins. (Python callers get the same default from winnowmap_amd/__init__.py.)
 __attribute__((constructor)) static void wm_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "20", 0); }
+
+// one recorded event per device: the zero of the interval clock above (hipEventElapsedTime works between events of different streams)
+static hipEvent_t device_base_event(int device)
+{
+	static std::mutex mu;
+	static std::vector<hipEvent_t> ev;
+	std::lock_guard<std::mutex> lk(mu);
+	if ((int)ev.size() <= device) ev.resize(device + 1, (hipEvent_t)0);
+	if (!ev[device]) {
+		hipEvent_t e;
+		if (hipSetDevice(device) != hipSuccess || hipEventCreate(&e) != hipSuccess) return 0;
+		if (hipEventRecord(e, 0) != hipSuccess || hipEventSynchronize(e) != hipSuccess) { hipEventDestroy(e); return 0; }
+		ev[device] = e;
+	}
+	return ev[device];
+}
 
 extern "C" int wm_device_count(void)
 {
@@ -890,7 +909,14 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	for (int k = 0; k < WM_KSW_NCLASS; ++k)
 		if (!b->order[k].empty()) {
 			float ms = 0;
-			if (hipEventElapsedTime(&ms, c->cev[k][0], c->cev[k][1]) == hipSuccess) { c->k_ms[k] += ms; c->k_cells[k] += b->class_cells[k]; c->k_launches[k] += 1; }
+			if (hipEventElapsedTime(&ms, c->cev[k][0], c->cev[k][1]) == hipSuccess) {
+				c->k_ms[k] += ms; c->k_cells[k] += b->class_cells[k]; c->k_launches[k] += 1;
+				float t0 = 0;
+				if (hipEvent_t base = device_base_event(c->device)) if (hipEventElapsedTime(&t0, base, c->cev[k][0]) == hipSuccess) {
+					if (c->k_iv[k].size() > 400000) c->k_iv[k].erase(c->k_iv[k].begin(), c->k_iv[k].begin() + 200000);      // (a file of any size: keep the recent past)
+					c->k_iv[k].push_back(std::make_pair(t0, t0 + ms));
+				}
+			}
 		}
 	if (b->h_err) return set_err(WM_EINTERNAL, "cigar slot overflow in backtrack");
 	return WM_OK;
@@ -2960,6 +2986,36 @@ extern "C" int wm_mapper_kernel_stats(const wm_mapper_t *m, double *out, int cap
 		double ms = m->c->k_ms[k], cells = (double)m->c->k_cells[k], ln = (double)m->c->k_launches[k];
 		for (const wm_ctx_t *w : m->workers) { ms += w->k_ms[k]; cells += (double)w->k_cells[k]; ln += (double)w->k_launches[k]; }
 		out[3 * k] = ms; out[3 * k + 1] = cells; out[3 * k + 2] = ln;
+	}
+	return WM_OK;
+}
+
+// out[k] = milliseconds during which at least one launch of ksw class k was running (union of its launch intervals over all contexts), counting
+// only what lies after `since_ms` on the device clock; returns through *now_ms the current reading of that clock (pass it as since_ms next time)
+extern "C" int wm_mapper_kernel_union(const wm_mapper_t *m, double since_ms, double *out, int cap, double *now_ms_out)
+{
+	if (!m || cap < WM_KSW_NCLASS) return set_err(WM_EINVAL, "need room for %d doubles", WM_KSW_NCLASS);
+	std::vector<const wm_ctx_t*> cs; cs.push_back(m->c); cs.insert(cs.end(), m->workers.begin(), m->workers.end());
+	for (int k = 0; k < WM_KSW_NCLASS; ++k) {
+		std::vector<std::pair<float, float>> iv;
+		for (const wm_ctx_t *c : cs) for (const auto &p : c->k_iv[k]) if (p.second > since_ms) iv.push_back(std::make_pair(std::max(p.first, (float)since_ms), p.second));
+		std::sort(iv.begin(), iv.end());
+		double tot = 0, cur_s = 0, cur_e = -1;
+		for (const auto &p : iv) {
+			if (p.first > cur_e) { if (cur_e > cur_s) tot += cur_e - cur_s; cur_s = p.first; cur_e = p.second; }
+			else if (p.second > cur_e) cur_e = p.second;
+		}
+		if (cur_e > cur_s) tot += cur_e - cur_s;
+		out[k] = tot;
+	}
+	if (now_ms_out) {
+		*now_ms_out = 0;
+		hipEvent_t base = device_base_event(m->c->device), e;
+		if (base && hipEventCreate(&e) == hipSuccess) {
+			float t = 0;
+			if (hipEventRecord(e, m->c->stream) == hipSuccess && hipEventSynchronize(e) == hipSuccess && hipEventElapsedTime(&t, base, e) == hipSuccess) *now_ms_out = t;
+			hipEventDestroy(e);
+		}
 	}
 	return WM_OK;
 }

@@ -428,6 +428,14 @@ class Mapper:
         _chk(lib().wm_mapper_kernel_stats(self._h, out.ctypes.data, len(out), C.byref(n)))
         return {k: (float(out[3 * k]), float(out[3 * k + 1]), int(out[3 * k + 2])) for k in range(n.value)}
 
+    def kernel_union(self, since_ms=0.0):
+        """(dict class -> ms with at least one launch of the class running since `since_ms`, device clock now in ms)"""
+        out = np.zeros(64, np.float64)
+        now = C.c_double()
+        lib().wm_mapper_kernel_union.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        _chk(lib().wm_mapper_kernel_union(self._h, float(since_ms), out.ctypes.data, len(out), C.byref(now)))
+        return {k: float(out[k]) for k in range(44)}, now.value
+
     def host_stats(self):
         """host time accounting since the mapper was created (wm_mapper_host_stats), seconds summed over the worker threads"""
         a = np.zeros(24, np.float64)
