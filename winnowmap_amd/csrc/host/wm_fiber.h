@@ -67,7 +67,10 @@ struct Fiber { FiberCtx ctx; char *stack; std::function<void()> fn; bool done; S
 // so that they do not hold back the heavy ones either.
 // OP_WINDOW: one MCAS window / stage-2 pass, sketch → seed → sort → chain → extraction in one device call (WindowReq). The per-stage operations
 // (OP_SKETCH / OP_SEED / OP_CHAIN) remain for callers that want a single stage.
-enum { OP_SKETCH = 0, OP_SEED = 1, OP_CHAIN = 2, OP_KSW = 3, OP_KSW_HEAVY = 4, OP_KSW_HUGE = 5, OP_WINDOW = 6, OP_N = 7 };
+// OP_WINDOW_BIG: the windows that can carry giant anchor sets — a stage-2 pass (handed-in anchors, or the whole read) — in a queue of their own: a
+// window call lasts as long as its largest job (one 10^5-anchor sort + chain: ~25 ms), and the thousands of 1-kb stage-1 windows of a batch, which
+// finish in one small kernel, would wait for it (round 4 timeline: gpurun_out/r04f).
+enum { OP_SKETCH = 0, OP_SEED = 1, OP_CHAIN = 2, OP_KSW = 3, OP_KSW_HEAVY = 4, OP_KSW_HUGE = 5, OP_WINDOW = 6, OP_WINDOW_BIG = 7, OP_N = 8 };
 inline double thread_cpu_s() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 inline double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -85,9 +88,9 @@ struct Hub {
 	std::mutex mu;
 	std::condition_variable cv;
 	// published requests and the fibers waiting for them (taken whole by a dispatcher)
-	std::vector<SketchReq*> q_sketch; std::vector<SeedReq*> q_seed; std::vector<ChainReq*> q_chain; std::vector<KswReq*> q_ksw, q_kswh, q_kswx; std::vector<WindowReq*> q_window;
+	std::vector<SketchReq*> q_sketch; std::vector<SeedReq*> q_seed; std::vector<ChainReq*> q_chain; std::vector<KswReq*> q_ksw, q_kswh, q_kswx; std::vector<WindowReq*> q_window, q_windowb;
 	std::vector<Fiber*> waiters[OP_N];
-	int inflight = 0, inflight_op[OP_N] = {0, 0, 0, 0, 0, 0, 0};
+	int inflight = 0, inflight_op[OP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
 	int n_workers = 1, n_idle = 0;          // workers of the mapping call; workers asleep with nothing runnable
 	std::vector<HelpTask*> help;            // loops of running batched calls that still have chunks to hand out
 	double cpu_help = 0;                    // CPU seconds idle workers spent inside such loops
@@ -129,27 +132,27 @@ struct Hub {
 		}
 	} par;
 	std::atomic<int64_t> live{0};           // fibers alive + reads not yet admitted, over all workers: 0 = the mapping call is finished
-	uint64_t n_batches[OP_N] = {0, 0, 0, 0, 0, 0, 0}, n_reqs[OP_N] = {0, 0, 0, 0, 0, 0, 0};
+	uint64_t n_batches[OP_N] = {0, 0, 0, 0, 0, 0, 0, 0}, n_reqs[OP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
 	// where the host time goes (seconds, summed over the workers): CPU time running fibers, CPU and wall time inside the batched
 	// calls per operation, wall time asleep waiting for results
-	double cpu_fiber = 0, cpu_op[OP_N] = {0, 0, 0, 0, 0, 0, 0}, wall_op[OP_N] = {0, 0, 0, 0, 0, 0, 0}, wall_idle = 0;
+	double cpu_fiber = 0, cpu_op[OP_N] = {0, 0, 0, 0, 0, 0, 0, 0}, wall_op[OP_N] = {0, 0, 0, 0, 0, 0, 0, 0}, wall_idle = 0;
 	double wall_fiber = 0, wall_lock = 0, wall_total = 0;     // wall time running fibers (>> cpu_fiber: the workers are being descheduled), waiting for the hub mutex, inside run()
-	size_t pending(int op) const { return op == OP_SKETCH ? q_sketch.size() : op == OP_SEED ? q_seed.size() : op == OP_CHAIN ? q_chain.size() : op == OP_KSW ? q_ksw.size() : op == OP_KSW_HEAVY ? q_kswh.size() : op == OP_KSW_HUGE ? q_kswx.size() : q_window.size(); }
+	size_t pending(int op) const { return op == OP_SKETCH ? q_sketch.size() : op == OP_SEED ? q_seed.size() : op == OP_CHAIN ? q_chain.size() : op == OP_KSW ? q_ksw.size() : op == OP_KSW_HEAVY ? q_kswh.size() : op == OP_KSW_HUGE ? q_kswx.size() : op == OP_WINDOW ? q_window.size() : q_windowb.size(); }
 	// scheduling knobs (environment, read once per mapping call): a further concurrent batch of an operation that is already in flight is
 	// issued when at least min_more[op] requests are pending and fewer than max_op[op] batches of it are running
-	size_t min_more[OP_N] = { 4096, 4096, 4096, 24576, 2048, 64, 4096 };
-	int max_op[OP_N] = { 2, 2, 2, 3, 2, 1, 3 };
+	size_t min_more[OP_N] = { 4096, 4096, 4096, 24576, 2048, 64, 4096, 1024 };
+	int max_op[OP_N] = { 2, 2, 2, 3, 2, 1, 3, 2 };
 	// a batch is worth its fixed cost — a kernel launch lasts at least as long as its longest job, and the device runs only so many
 	// kernels at once — when it is large: an operation is issued when min_batch[op] requests are pending or the oldest has waited
 	// max_wait_ms[op], whichever comes first (0 / 0 = at once)
-	size_t min_batch[OP_N] = { 8192, 8192, 8192, 98304, 12288, 256, 8192 };
-	double max_wait_ms[OP_N] = { 15, 15, 15, 30, 60, 100, 15 };
-	double first_pending[OP_N] = { 0, 0, 0, 0, 0, 0, 0 };          // wall_s() when the queue of the operation last became non-empty
+	size_t min_batch[OP_N] = { 8192, 8192, 8192, 98304, 12288, 256, 8192, 2048 };
+	double max_wait_ms[OP_N] = { 15, 15, 15, 30, 60, 100, 15, 30 };
+	double first_pending[OP_N] = { 0, 0, 0, 0, 0, 0, 0, 0 };          // wall_s() when the queue of the operation last became non-empty
 	long heavy_units = 8192;                // rows x 128-lane register pairs above which an alignment goes to the heavy queue (0 = no heavy queue)
 	long huge_units = 131072;               // ... and to the queue of the few very long ones (0 = none)
 	void read_env()
 	{
-		static const char *nm[OP_N] = { "SKETCH", "SEED", "CHAIN", "KSW", "KSWH", "KSWX", "WINDOW" };
+		static const char *nm[OP_N] = { "SKETCH", "SEED", "CHAIN", "KSW", "KSWH", "KSWX", "WINDOW", "WINDOWB" };
 		for (int op = 0; op < OP_N; ++op) {
 			char key[64];
 			snprintf(key, sizeof(key), "WM_%s_MIN_MORE", nm[op]); if (getenv(key)) min_more[op] = (size_t)atol(getenv(key));
@@ -257,7 +260,15 @@ public:
 	void sketch(SketchReq &r) { l_sketch_.push_back(&r); wait(1 << OP_SKETCH); }
 	void seed(SeedReq &r) { l_seed_.push_back(&r); wait(1 << OP_SEED); }
 	void chain(ChainReq &r) { l_chain_.push_back(&r); wait(1 << OP_CHAIN); }
-	void window(WindowReq &r) { l_window_.push_back(&r); wait(1 << OP_WINDOW); }
+	void window(WindowReq &r)
+	{
+		// WM_WINDOW_BIG_LEN=8192 switches the second queue on (stage-1 windows are at most maxPrefixLength long: 8 000 for map-ont). Off by default: measured
+		// neutral (0.242 vs 0.247 Gbp/s, profiles/r04g_sched_sweep.txt) — even a window call of a dozen requests takes 50-90 ms, waiting for a device context
+		static const int big_len = getenv("WM_WINDOW_BIG_LEN") ? atoi(getenv("WM_WINDOW_BIG_LEN")) : -1;
+		const bool big = big_len >= 0 && (!r.pre.empty() || r.len > big_len);
+		(big ? l_windowb_ : l_window_).push_back(&r);
+		wait(1 << (big ? OP_WINDOW_BIG : OP_WINDOW));
+	}
 	void ksw(std::vector<KswReq> &rs)
 	{
 		if (rs.empty()) return;
@@ -330,6 +341,7 @@ private:
 		if (!l_kswh_.empty()) { H.q_kswh.insert(H.q_kswh.end(), l_kswh_.begin(), l_kswh_.end()); l_kswh_.clear(); any = true; }
 		if (!l_kswx_.empty()) { H.q_kswx.insert(H.q_kswx.end(), l_kswx_.begin(), l_kswx_.end()); l_kswx_.clear(); any = true; }
 		if (!l_window_.empty()) { H.q_window.insert(H.q_window.end(), l_window_.begin(), l_window_.end()); l_window_.clear(); any = true; }
+		if (!l_windowb_.empty()) { H.q_windowb.insert(H.q_windowb.end(), l_windowb_.begin(), l_windowb_.end()); l_windowb_.clear(); any = true; }
 		for (int op = 0; op < OP_N; ++op)
 			if (!l_wait_[op].empty()) { H.waiters[op].insert(H.waiters[op].end(), l_wait_[op].begin(), l_wait_[op].end()); l_wait_[op].clear(); }
 		if (any) H.cv.notify_all();          // somebody idle may want to dispatch what was just published
@@ -345,7 +357,7 @@ private:
 		// nothing running anywhere and nobody able to produce more requests: whatever is pending must go now
 		const bool drain = H.inflight == 0 && H.n_idle + 1 >= H.n_workers;
 		int best = -1;
-		static const int stage_order[OP_N] = { OP_KSW_HUGE, OP_KSW_HEAVY, OP_KSW, OP_CHAIN, OP_SEED, OP_SKETCH, OP_WINDOW };
+		static const int stage_order[OP_N] = { OP_KSW_HUGE, OP_KSW_HEAVY, OP_KSW, OP_WINDOW_BIG, OP_CHAIN, OP_SEED, OP_SKETCH, OP_WINDOW };
 		for (int oi = 0; oi < OP_N; ++oi) {                   // later stages first: finishing reads frees their memory and admits new ones
 			const int op = stage_order[oi];
 			const size_t n = H.pending(op);
@@ -367,7 +379,7 @@ private:
 		size_t n = 0;
 		if (op == OP_SKETCH) { a.swap(H.q_sketch); n = a.size(); } else if (op == OP_SEED) { b.swap(H.q_seed); n = b.size(); }
 		else if (op == OP_CHAIN) { c.swap(H.q_chain); n = c.size(); } else if (op == OP_KSW) { d.swap(H.q_ksw); n = d.size(); } else if (op == OP_KSW_HEAVY) { d.swap(H.q_kswh); n = d.size(); }
-		else if (op == OP_KSW_HUGE) { d.swap(H.q_kswx); n = d.size(); } else { wq.swap(H.q_window); n = wq.size(); }
+		else if (op == OP_KSW_HUGE) { d.swap(H.q_kswx); n = d.size(); } else if (op == OP_WINDOW) { wq.swap(H.q_window); n = wq.size(); } else { wq.swap(H.q_windowb); n = wq.size(); }
 		++H.inflight; ++H.inflight_op[op]; ++H.n_batches[op]; H.n_reqs[op] += n;
 		lk.unlock();
 		static const bool trace = getenv("WM_TRACE") != 0;
@@ -379,7 +391,7 @@ private:
 			if (op == OP_SKETCH) H.ops->sketch_batch(H.w, H.k, a);
 			else if (op == OP_SEED) H.ops->seed_batch(b);
 			else if (op == OP_CHAIN) H.ops->chain_batch(c);
-			else if (op == OP_WINDOW) H.ops->window_batch(H.w, H.k, wq);
+			else if (op == OP_WINDOW || op == OP_WINDOW_BIG) H.ops->window_batch(H.w, H.k, wq);
 			else if (H.splice) H.ops->exts2_batch(H.sc, H.noncan, H.junc_bonus, d);
 			else H.ops->ksw_batch(H.sc, d);
 		} catch (const std::exception &e) {          // the waiters below are released in any case (their requests keep their zero-initialised results)
@@ -387,7 +399,7 @@ private:
 		} catch (...) {
 			note_internal_error("exception in a batched device call", __FILE__, __LINE__);
 		}
-		if (trace) fprintf(stderr, "[batch] worker %2d %s n=%zu %.1f ms\n", rank_, op == OP_SKETCH ? "sketch" : op == OP_SEED ? "seed" : op == OP_CHAIN ? "chain" : op == OP_KSW ? "ksw" : op == OP_KSW_HEAVY ? "ksw-heavy" : op == OP_KSW_HUGE ? "ksw-huge" : "window", n,
+		if (trace) fprintf(stderr, "[batch] worker %2d %s n=%zu %.1f ms\n", rank_, op == OP_SKETCH ? "sketch" : op == OP_SEED ? "seed" : op == OP_CHAIN ? "chain" : op == OP_KSW ? "ksw" : op == OP_KSW_HEAVY ? "ksw-heavy" : op == OP_KSW_HUGE ? "ksw-huge" : op == OP_WINDOW_BIG ? "window-big" : "window", n,
 		                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 		tl_par_hook() = prev_hook;
 		const double dc = thread_cpu_s() - c0, dw = wall_s() - w0;
@@ -407,7 +419,7 @@ private:
 	std::vector<Fiber*> pool_;
 	std::vector<char*> slabs_; int slab_left_ = 0;
 	std::vector<Fiber*> inbox_;             // fibers whose results arrived (filled by dispatchers under the hub mutex)
-	std::vector<SketchReq*> l_sketch_; std::vector<SeedReq*> l_seed_; std::vector<ChainReq*> l_chain_; std::vector<KswReq*> l_ksw_, l_kswh_, l_kswx_; std::vector<WindowReq*> l_window_;
+	std::vector<SketchReq*> l_sketch_; std::vector<SeedReq*> l_seed_; std::vector<ChainReq*> l_chain_; std::vector<KswReq*> l_ksw_, l_kswh_, l_kswx_; std::vector<WindowReq*> l_window_, l_windowb_;
 	std::vector<Fiber*> l_wait_[OP_N];
 };
 

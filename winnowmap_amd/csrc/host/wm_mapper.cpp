@@ -278,12 +278,12 @@ void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::v
 	if (stats) {
 		for (int op = 0; op < OP_N; ++op) stats->n_flush += hub.n_batches[op];
 		stats->n_ksw += hub.n_reqs[OP_KSW] + hub.n_reqs[OP_KSW_HEAVY] + hub.n_reqs[OP_KSW_HUGE]; stats->n_chain += hub.n_reqs[OP_CHAIN]; stats->n_seed += hub.n_reqs[OP_SEED];
-		stats->n_sketch += hub.n_reqs[OP_SKETCH] + hub.n_reqs[OP_WINDOW];           // (windows: every window is sketched, seeded and chained in one call)
+		stats->n_sketch += hub.n_reqs[OP_SKETCH] + hub.n_reqs[OP_WINDOW] + hub.n_reqs[OP_WINDOW_BIG];           // (windows: every window is sketched, seeded and chained in one call)
 		if (getenv("WM_TRACE")) { for (auto &e : hub.site_cpu) fprintf(stderr, "[site] %-28s %8.2f s CPU\n", e.first, e.second); }
 		stats->cpu_fiber += hub.cpu_fiber; stats->wall_idle += hub.wall_idle; stats->cpu_help += hub.cpu_help;
 		stats->wall_fiber += hub.wall_fiber; stats->wall_lock += hub.wall_lock; stats->wall_total += hub.wall_total;
 		for (int op = 0; op < OP_N; ++op) {           // (the heavy alignment queues are reported with the ksw operation, the fused window call in the first slot)
-			const int o = op == OP_WINDOW ? 0 : op >= OP_KSW_HEAVY ? OP_KSW : op;
+			const int o = op == OP_WINDOW || op == OP_WINDOW_BIG ? 0 : op >= OP_KSW_HEAVY ? OP_KSW : op;
 			stats->n_batches[o] += hub.n_batches[op]; stats->cpu_op[o] += hub.cpu_op[op]; stats->wall_op[o] += hub.wall_op[op];
 		}
 	}
