@@ -333,12 +333,13 @@ def main():
         log("index: %d minimizers, built in %.1fs (reference sketched on the device in %.2fs)" % (idx.n_minimizers, time.time() - t_i, ist["device_sketch_s"]))
     if dist is not None:
         dev = torch.device("cuda", local)
-        idx = wmdist.broadcast_index(idx if rank == 0 else None, rank, dist, dev)      # RCCL over xGMI, one broadcast per flat array
+        idx, uploaded = wmdist.broadcast_index(idx if rank == 0 else None, rank, dist, dev, ctx)      # RCCL over xGMI, one broadcast per flat array, received straight into the context
         # every rank regenerates the (seeded) reference only to draw its reads from it
         if rank != 0:
             n_contigs = max(1, int(round(args.ref_mb / 10.0)))
             ref = synth.make_reference(n_contigs, int(args.ref_mb * 1e6 / n_contigs), 3, repeat_frac=0.10)
-    idx.upload(ctx)
+    if dist is None or not uploaded:
+        idx.upload(ctx)
     mapper = gpu.Mapper(ctx, idx, cfg["preset"], gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
     if n_threads > 1:
         mapper.set_threads(n_threads, arena)

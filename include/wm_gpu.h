@@ -258,6 +258,16 @@ int wm_map_reads_slot(wm_mapper_t *m, int slot, int n, const char *const *names,
  * orders each mini-batch like src/map.c:1124-1143, maps it and writes PAF/SAM records to out_path ("-" = stdout); reading,
  * mapping and writing overlap. stats (optional, 6 doubles): reads, bases, mini-batches, seconds reading / mapping / writing. */
 int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *out_path, int64_t mini_batch_bases, double *stats);
+/* ---- several GPUs from one C process (reads shard, the index is broadcast, no data-path collective) ----
+ * wm_index_upload_dev: like wm_index_upload, but the five flat arrays (S, hkey, hval, P, bloom bits — sizes and contig table from `idx`) come from DEVICE
+ * memory on src_device: the receive buffers of an RCCL broadcast, or another context's copy; one device-to-device (xGMI peer) copy per array, no host
+ * staging. wm_index_upload_peer: the index that context `src` holds, copied into `dst` (any GPU of the node) — the in-process index broadcast.
+ * wm_map_file_multi: wm_map_file over n mappers (one per GPU, each with its own context / index copy / host threads): mini-batches go round-robin to
+ * 2 lanes per mapper, the ordered writer restores input order, the output equals wm_map_file's. Replaces the role of mm_map_file_frag's pipeline
+ * (src/map.c:1226-1268) for an N-GPU node; the reference has no counterpart (it has one address space). */
+int wm_index_upload_dev(wm_ctx_t *ctx, const wm_index_t *idx, const void *d_S, const void *d_hkey, const void *d_hval, const void *d_P, const void *d_bloom, int src_device);
+int wm_index_upload_peer(wm_ctx_t *dst, const wm_index_t *idx, const wm_ctx_t *src);
+int wm_map_file_multi(wm_mapper_t *const *mappers, int n, const char *reads_path, const char *out_path, int64_t mini_batch_bases, double *stats);
 /* argv of the calling front end: with MM_F_OUT_SAM, wm_map_file starts the file with the @SQ lines and the @PG line carrying this
  * command line, as mm_write_sam_hdr does before mapping (src/format.c:118-139, src/main.c:393). Optional (no CL: field without it). */
 int wm_mapper_set_cmdline(wm_mapper_t *m, int argc, const char *const *argv);

@@ -211,7 +211,10 @@ def test_index_build_on_device_equals_host_build(tmp_path):
         for a, b in zip(ha, da):
             assert np.array_equal(a, b)
         assert st["minimizers"] == host.n_minimizers
-        print("device index build: %.2fs total, device sketch %.3fs, %d minimizers (arena %d MB)" % (time.time() - t0, st["device_sketch_s"], st["minimizers"], arena >> 20))
+        # ... and the TABLE (bucket sort + hash-table fill, src/index.c:200-254) was built on the device too: two radix sorts, run-length encoding, a scan
+        assert st["table_on_device_s"] >= 0, st
+        print("device index build: %.2fs total, device sketch %.3fs, table %.3fs (device part %.3fs), %d minimizers (arena %d MB)" %
+              (time.time() - t0, st["device_sketch_s"], st["table_s"], st["table_on_device_s"], st["minimizers"], arena >> 20))
         dev.upload(c)                                                 # and the context is usable afterwards
         dev.close(); c.close()
     host.close()

@@ -38,7 +38,8 @@ def _worker(rank, world, port, tmp, q):
         kf = os.path.join(tmp, "rep.txt")
         synth.write_kmer_list(kf, km, cnt, 15)
         idx = gpu.Index(fa, kf, k=15, w=50, n_threads=2)
-    idx = wmdist.broadcast_index(idx, rank, dist, dev)
+    idx, on_dev = wmdist.broadcast_index(idx, rank, dist, dev)
+    assert not on_dev               # (gloo on CPU: no context to receive into; the RCCL form is tests/test_e2e_gpu.py::test_index_handed_on_device_to_device)
     sizes, arrs = idx.export_arrays()
     digest = [int(x) for x in sizes] + [int(np.frombuffer(a.tobytes(), np.uint8).astype(np.uint64).sum()) for a in arrs] + [idx.n_minimizers]
     mine = wmdist.shard(37, rank, world)
@@ -84,7 +85,7 @@ def _map_worker(rank, world, port, tmp, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     preset, fa, kf, k, reads = E.make_golden.inputs("ont_short", os.path.join(tmp, "r%d" % rank))   # (seeded: every rank regenerates the same reads)
     idx = gpu.Index(fa, kf, k=k, w=50, n_threads=2) if rank == 0 else None
-    idx = wmdist.broadcast_index(idx, rank, dist, torch.device("cpu"))
+    idx, _ = wmdist.broadcast_index(idx, rank, dist, torch.device("cpu"))
     # the received index drives the HOST mapper of this rank (oracle-backed device ops: no GPU here) on this rank's shard of the reads
     mmi = os.path.join(tmp, "rank%d.mmi" % rank)
     idx.save(mmi)

@@ -195,3 +195,51 @@ def test_small_arena_splits_batches_and_gives_the_same_records():
         m.close(); idx.close(); c.close()
     assert len(out[0][1]) >= 200
     assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
+
+
+def test_index_handed_on_device_to_device_and_the_file_loop_over_two_mappers(ctx):
+    """SURVEY §8(b) / §8(e) from C: the index goes from one device context to another without touching the host (wm_index_upload_peer: one
+    hipMemcpyPeer per flat array — two contexts of this one GPU here, two GPUs on a node), a mapper on each, and wm_map_file_multi fans the
+    mini-batches of a reads file over them (2 lanes per mapper): the file must equal wm_map_file's of one mapper. Then the RCCL form: a 1-rank
+    `nccl` group broadcasts the flat arrays and the context receives them from the broadcast buffers (wm_index_upload_dev, winnowmap_amd/dist.py)."""
+    import os
+    tmp = tempfile.mkdtemp()
+    preset, fa, kf, k, reads = E.make_golden.inputs("ont_short", tmp)
+    reads = [r[:3000 + 211 * i] for i, r in enumerate(reads)] * 3
+    rq = os.path.join(tmp, "reads.fa")
+    with open(rq, "wb") as f:
+        for i, s in enumerate(reads):
+            f.write(b">read%d\n" % i + s + b"\n")
+    idx = gpu.Index(fa, kf, k=k, w=50)
+    idx.upload(ctx)
+    ctx2 = gpu.Context(0, 2 << 30)
+    idx.upload_peer(ctx2, ctx)
+    m1 = gpu.Mapper(ctx, idx, preset, gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG); m1.set_threads(4, 1 << 30)
+    m2 = gpu.Mapper(ctx2, idx, preset, gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG); m2.set_threads(4, 1 << 30)
+    one, two = os.path.join(tmp, "one.paf"), os.path.join(tmp, "two.paf")
+    st1 = m1.map_file(rq, one, 15000)
+    st2 = gpu.map_file_multi([m1, m2], rq, two, 15000)
+    assert st1["reads"] == st2["reads"] == len(reads) and st2["batches"] >= 6
+    a, b = open(one, "rb").read(), open(two, "rb").read()
+    assert a == b and a.count(b"\n") >= len(reads)
+    # the second context alone maps like the first (its index arrived device to device)
+    t1 = m1.map(["q%d" % i for i in range(8)], reads[:8])[0]
+    t2 = m2.map(["q%d" % i for i in range(8)], reads[:8])[0]
+    assert t1 == t2 and len(t1) > 0
+    m1.close(); m2.close()
+    # RCCL: one-rank group, the broadcast buffers feed the context directly
+    import torch
+    import torch.distributed as dist
+    from winnowmap_amd import dist as wmdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(wmdist.free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        ctx3 = gpu.Context(0, 2 << 30)
+        idx_b, on_dev = wmdist.broadcast_index(idx, 0, dist, torch.device("cuda", 0), ctx3)
+        assert on_dev
+        m3 = gpu.Mapper(ctx3, idx_b, preset, gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
+        assert m3.map(["q%d" % i for i in range(8)], reads[:8])[0] == t1
+        m3.close(); ctx3.close()
+    finally:
+        dist.destroy_process_group()
+    ctx2.close(); idx.close()

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <algorithm>
+#include <functional>
 #include <fstream>
 #include <thread>
 #include <atomic>
@@ -294,15 +295,32 @@ void index_table_from_minimizers(Index &ix, std::vector<m128> &all)
 	ix.hkey.assign((size_t)1 << ix.hbits, ~0ULL);
 	ix.hval.assign((size_t)1 << ix.hbits, 0);
 	ix.P.resize(all.size());
-	const uint64_t msk = ((uint64_t)1 << ix.hbits) - 1;
+	// The keys enter the table in the order of (home slot, key). Linear probing then has a closed form — the j-th key lands on
+	// max(home_j, slot of the key before it + 1), a prefix maximum — which is what lets the device build the same table with a sort and a scan
+	// (wm_gpu.hip: index_table_on_device); the few keys that run past the last slot wrap around to the first free slots in the same order.
+	struct Grp { uint64_t home, key, val; };
+	std::vector<Grp> g;
+	g.reserve(nk);
 	for (size_t i = 0; i < all.size();) {
 		size_t j = i;
 		const uint64_t key = all[i].x >> 8;
 		while (j < all.size() && (all[j].x >> 8) == key) { ix.P[j] = all[j].y; ++j; }
-		uint64_t s = Index::slot_of(key, ix.hbits);
-		while (ix.hkey[s] != ~0ULL) s = (s + 1) & msk;
-		ix.hkey[s] = key; ix.hval[s] = (uint64_t)i << 32 | (uint64_t)(j - i);
+		g.push_back(Grp{ Index::slot_of(key, ix.hbits), key, (uint64_t)i << 32 | (uint64_t)(j - i) });
 		i = j;
+	}
+	std::stable_sort(g.begin(), g.end(), [](const Grp &a, const Grp &b) { return a.home < b.home; });      // (g is in key order: stable = ties by key)
+	index_table_insert(ix, g.size(), [&](size_t t, uint64_t *key, uint64_t *val) { *key = g[t].key; *val = g[t].val; return g[t].home; });
+}
+
+// sequential linear probing of n keys given in (home slot, key) order
+void index_table_insert(Index &ix, size_t n, const std::function<uint64_t(size_t, uint64_t*, uint64_t*)> &item)
+{
+	const uint64_t msk = ((uint64_t)1 << ix.hbits) - 1;
+	for (size_t t = 0; t < n; ++t) {
+		uint64_t key, val;
+		uint64_t s = item(t, &key, &val);
+		while (ix.hkey[s] != ~0ULL) s = (s + 1) & msk;
+		ix.hkey[s] = key; ix.hval[s] = val;
 	}
 }
 

@@ -56,6 +56,9 @@ struct Index {
 
 // names/seqs: reference contigs (ASCII). kmer_file: the -W list ("kmer count" lines) or empty.
 // Returns 0, or -1 with err set (e.g. k-mer length mismatch, src/index.c:403-407).
+// keys in (home slot, key) order -> the table by sequential linear probing (the canonical layout; the device build computes the same with a scan and
+// calls this only for the few keys that wrap past the last slot). item(t, &key, &val) returns the home slot of the t-th key.
+void index_table_insert(Index &ix, size_t n, const std::function<uint64_t(size_t, uint64_t*, uint64_t*)> &item);
 int index_build(const IdxOpt &io, const std::vector<std::string> &names, const std::vector<std::string> &seqs,
                 const std::string &kmer_file, int n_threads, Index &out, std::string &err);
 int index_build_from_fasta(const IdxOpt &io, const std::string &fasta, const std::string &kmer_file, int n_threads, Index &out, std::string &err);

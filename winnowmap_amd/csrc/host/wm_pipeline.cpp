@@ -26,12 +26,12 @@ template <class T> struct Slot {
 };
 }
 
-int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_qual, const MapFn &map_fn, FILE *out, FileStats *st, std::string &err)
+int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_qual, const MapFn &map_fn, FILE *out, FileStats *st, std::string &err, int n_lanes_arg)
 {
-	return map_file_id(reads_path, mini_batch_bases, with_qual, [&](std::vector<ReadIn> &b, std::string &t, int lane, uint64_t) { return map_fn(b, t, lane); }, out, st, err);
+	return map_file_id(reads_path, mini_batch_bases, with_qual, [&](std::vector<ReadIn> &b, std::string &t, int lane, uint64_t) { return map_fn(b, t, lane); }, out, st, err, n_lanes_arg);
 }
 
-int map_file_id(const std::string &reads_path, int64_t mini_batch_bases, bool with_qual, const MapFnId &map_fn, FILE *out, FileStats *st, std::string &err)
+int map_file_id(const std::string &reads_path, int64_t mini_batch_bases, bool with_qual, const MapFnId &map_fn, FILE *out, FileStats *st, std::string &err, int n_lanes_arg)
 {
 	FastxReader rd;
 	if (rd.open(reads_path, err) < 0) return -1;
@@ -47,7 +47,7 @@ int map_file_id(const std::string &reads_path, int64_t mini_batch_bases, bool wi
 	std::mutex omu; std::condition_variable ocv;
 	std::map<uint64_t, std::unique_ptr<std::string>> done;
 	const char *le = getenv("WM_MAP_LANES");
-	const int n_lanes = le && atoi(le) == 1 ? 1 : 2;
+	const int n_lanes = n_lanes_arg > 0 ? n_lanes_arg : le && atoi(le) == 1 ? 1 : 2;
 	uint64_t next_out = 0; int lanes_running = n_lanes;                 // (set BEFORE the writer starts: it leaves when no lane is running and nothing is queued)
 	std::thread reader([&]() {
 		uint64_t id = 0;
@@ -104,7 +104,7 @@ int map_file_id(const std::string &reads_path, int64_t mini_batch_bases, bool wi
 			{ std::lock_guard<std::mutex> lk(fs_mu); fs.t_map += now_s() - t0; fs.n_batches += 1; fs.n_reads += b->reads.size(); fs.n_bases += nb; }
 			if (rc.load() == 0) {
 				std::unique_lock<std::mutex> lk(omu);
-				ocv.wait(lk, [&] { return b->id < next_out + 2 || rc.load() != 0; });          // (at most two finished texts wait for the writer)
+				ocv.wait(lk, [&] { return b->id < next_out + (uint64_t)n_lanes || rc.load() != 0; });          // (at most one finished text per lane waits for the writer)
 				done[b->id] = std::move(text);
 				ocv.notify_all();
 			}
@@ -113,10 +113,10 @@ int map_file_id(const std::string &reads_path, int64_t mini_batch_bases, bool wi
 		--lanes_running;
 		ocv.notify_all();
 	};
-	std::thread lane1;
-	if (n_lanes == 2) lane1 = std::thread(lane_fn, 1);
+	std::vector<std::thread> lanes;
+	for (int l = 1; l < n_lanes; ++l) lanes.emplace_back(lane_fn, l);
 	lane_fn(0);
-	if (lane1.joinable()) lane1.join();
+	for (std::thread &t : lanes) t.join();
 	reader.join();
 	writer.join();
 	if (st) *st = fs;

@@ -28,10 +28,12 @@ struct FileStats { uint64_t n_reads = 0, n_bases = 0, n_batches = 0; double t_re
 // one): a mapping call ramps up and drains its pipeline of dependent device calls over several hundred milliseconds, which the other lane's
 // steady state covers. Records are written in input order whatever lane finishes first.
 typedef std::function<int(std::vector<ReadIn> &batch, std::string &text, int lane)> MapFn;
-int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_qual, const MapFn &map_fn, FILE *out, FileStats *st, std::string &err);
+// n_lanes: mini-batches mapped at a time (threads calling map_fn concurrently with lane = 0 .. n_lanes - 1); 0 = the default above (2, WM_MAP_LANES=1: 1).
+// A caller that owns several devices passes two lanes per device (wm_map_file_multi).
+int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_qual, const MapFn &map_fn, FILE *out, FileStats *st, std::string &err, int n_lanes = 0);
 // the same with the ordinal of the mini-batch (0, 1, …: the same reads file read again yields the same mini-batches in the same order)
 typedef std::function<int(std::vector<ReadIn> &batch, std::string &text, int lane, uint64_t batch_id)> MapFnId;
-int map_file_id(const std::string &reads_path, int64_t mini_batch_bases, bool with_qual, const MapFnId &map_fn, FILE *out, FileStats *st, std::string &err);
+int map_file_id(const std::string &reads_path, int64_t mini_batch_bases, bool with_qual, const MapFnId &map_fn, FILE *out, FileStats *st, std::string &err, int n_lanes = 0);
 
 // A reference indexed in several parts (`-I` smaller than the reference, `--split-prefix`; src/main.c:398-429): the reads are mapped against one
 // part after the other (begin_part(j) makes part j current — upload, mapper —, map_part maps one mini-batch against it), the hits of every read

@@ -1473,8 +1473,162 @@ extern "C" int wm_index_upload(wm_ctx_t *c, const wm_index_t *h)
 	return WM_OK;
 }
 
+// The index from DEVICE memory: the five flat arrays of `h` (S, hkey, hval, P, bloom bits; sizes and contig table from h) are taken from device pointers on
+// device src_device — the receive buffers of an RCCL broadcast (winnowmap_amd/dist.py), or another context's copy (wm_index_upload_peer): one
+// hipMemcpyPeer per array, device to device over xGMI, no host staging. SURVEY §8(b): "wm_index_bcast(rank, nranks) next to wm_index_upload".
+extern "C" int wm_index_upload_dev(wm_ctx_t *c, const wm_index_t *h, const void *d_S, const void *d_hkey, const void *d_hval, const void *d_P, const void *d_bloom, int src_device)
+{
+	if (!c || !h || !d_S || !d_hkey || !d_hval || !d_bloom) return set_err(WM_EINVAL, "null argument");
+	HIPCHK(hipSetDevice(c->device));
+	const wm::Index &ix = h->ix;
+	if (!ix.P.empty() && !d_P) return set_err(WM_EINVAL, "null argument");
+	if (ix.bloom.table_bits >= ((uint64_t)1 << 32)) return set_err(WM_EINVAL, "bloom table of %llu bits not supported on device", (unsigned long long)ix.bloom.table_bits);
+	if (src_device != c->device) {
+		int can = 0;
+		if (hipDeviceCanAccessPeer(&can, c->device, src_device) == hipSuccess && can) { const hipError_t e = hipDeviceEnablePeerAccess(src_device, 0); if (e != hipSuccess) (void)hipGetLastError(); }   // (already enabled is fine; hipMemcpyPeer stages through the host otherwise)
+	}
+	if (c->have_index && c->owns_index) { hipFree(c->d_hkey); hipFree(c->d_hval); hipFree(c->d_P); hipFree(c->d_bloom); hipFree(c->d_S); }
+	if (!c->have_index && c->owns_filter && c->d_bloom) { hipFree(c->d_bloom); c->d_bloom = 0; }
+	c->owns_filter = false;
+	c->have_index = false; c->d_S = 0; c->seq_off.clear(); c->seq_len.clear();
+	HIPCHK(hipMalloc((void**)&c->d_hkey, ix.hkey.size() * 8 + 8));
+	HIPCHK(hipMalloc((void**)&c->d_hval, ix.hval.size() * 8 + 8));
+	HIPCHK(hipMalloc((void**)&c->d_P, ix.P.size() * 8 + 8));
+	HIPCHK(hipMalloc((void**)&c->d_bloom, ix.bloom.bits.size() + 8));
+	HIPCHK(hipMalloc((void**)&c->d_S, ix.S.size() * 4 + 8));
+	HIPCHK(hipMemcpyPeer(c->d_S, c->device, d_S, src_device, ix.S.size() * 4));
+	HIPCHK(hipMemcpyPeer(c->d_hkey, c->device, d_hkey, src_device, ix.hkey.size() * 8));
+	HIPCHK(hipMemcpyPeer(c->d_hval, c->device, d_hval, src_device, ix.hval.size() * 8));
+	if (!ix.P.empty()) HIPCHK(hipMemcpyPeer(c->d_P, c->device, d_P, src_device, ix.P.size() * 8));
+	HIPCHK(hipMemcpyPeer(c->d_bloom, c->device, d_bloom, src_device, ix.bloom.bits.size()));
+	HIPCHK(hipDeviceSynchronize());
+	for (const wm::RefSeq &r : ix.seq) { c->seq_off.push_back(r.offset); c->seq_len.push_back(r.len); }
+	c->hbits = ix.hbits;
+	c->skp.w = ix.w; c->skp.k = ix.k; c->skp.table_bits = (uint32_t)ix.bloom.table_bits; c->skp.salt0 = ix.bloom.salt[0]; c->skp.salt1 = ix.bloom.salt[1];
+	c->have_index = true; c->owns_index = true;
+	return WM_OK;
+}
+// the index of context `src` (wm_index_upload / _dev of the same wm_index_t) copied into context `dst`, which may live on another GPU of the node: the
+// one-process form of the index broadcast (a C host that drives N GPUs builds once, uploads once and hands the arrays on over xGMI)
+extern "C" int wm_index_upload_peer(wm_ctx_t *dst, const wm_index_t *h, const wm_ctx_t *src)
+{
+	if (!dst || !h || !src) return set_err(WM_EINVAL, "null argument");
+	if (!src->have_index) return set_err(WM_EINVAL, "the source context holds no index");
+	if (src->hbits != h->ix.hbits || src->seq_len.size() != h->ix.seq.size()) return set_err(WM_EINVAL, "the source context holds a different index");
+	return wm_index_upload_dev(dst, h, src->d_S, src->d_hkey, src->d_hval, src->d_P, src->d_bloom, src->device);
+}
+
 static int sketch_batch_impl(wm_ctx_t *c, int n, const uint8_t *seqs, size_t seqs_bytes, const uint64_t *seq_off, const int32_t *len, const uint8_t *resident,
                              wm128_t *out, size_t out_cap, uint64_t *out_off, int32_t *counts);
+
+// ---- the index TABLE on the device (worker_post + mm_idx_post, src/index.c:200-254): (key, position) records -> P (positions grouped by key, ascending) and
+// the open-addressing table hkey / hval. Two stable LSD radix sorts (by position, then by key) give the reference's order inside a bucket (src/index.c:213,
+// radix_sort_128x by x then the run's positions in y order); run-length encoding gives the distinct keys and their counts; the table layout is the canonical one
+// of host/wm_index.cpp (keys enter in (home slot, key) order), whose linear probing is a prefix maximum: slot_j = j + max_{i <= j}(home_i - i).
+__global__ __launch_bounds__(256) void idx_split_kernel(const wm128_t *__restrict__ a, uint64_t n, uint64_t *__restrict__ x, uint64_t *__restrict__ y)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) { x[i] = a[i].x >> 8; y[i] = a[i].y; }
+}
+__global__ __launch_bounds__(256) void idx_home_kernel(const uint64_t *__restrict__ uniq, uint32_t nk, int hbits, uint32_t *__restrict__ home, uint32_t *__restrict__ idx)
+{
+	const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+	if (j < nk) { home[j] = (uint32_t)((uniq[j] * 0x9E3779B97F4A7C15ULL) >> (64 - hbits)); idx[j] = j; }       // Index::slot_of
+}
+__global__ __launch_bounds__(256) void idx_rel_kernel(const uint32_t *__restrict__ home, uint32_t nk, long long *__restrict__ t)
+{
+	const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+	if (j < nk) t[j] = (long long)home[j] - (long long)j;
+}
+__global__ __launch_bounds__(256) void idx_place_kernel(const long long *__restrict__ m, const uint32_t *__restrict__ idx, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ first,
+                                                         const uint32_t *__restrict__ cnt, uint32_t nk, uint64_t size, uint64_t *__restrict__ hkey, uint64_t *__restrict__ hval,
+                                                         uint32_t *__restrict__ n_over)
+{
+	const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= nk) return;
+	const uint64_t p = (uint64_t)((long long)j + m[j]);
+	if (p < size) { const uint32_t g = idx[j]; hkey[p] = uniq[g]; hval[p] = (uint64_t)first[g] << 32 | cnt[g]; }
+	else atomicAdd(n_over, 1u);              // (runs past the last slot: the tail of the (home, key) order — placed by the host, wrapping around)
+}
+
+// returns WM_OK, 1 = not applicable here (too large for the arena or for 32-bit P offsets: the host builds the table), < 0 = error
+static int index_table_on_device(wm_ctx_t *c, wm::Index &ix, const std::vector<wm::m128> &all, double *t_dev_s)
+{
+	const uint64_t n = all.size();
+	if (n == 0 || n >= ((uint64_t)1 << 32)) return 1;                     // (P is indexed with 32 bits in hval: as the host build)
+	ArenaMark mark(c);
+	const double t0 = now_ms();
+	wm128_t *d_a = (wm128_t*)arena_take(c, n * 16);
+	uint64_t *d_x = (uint64_t*)arena_take(c, n * 8), *d_y = (uint64_t*)arena_take(c, n * 8), *d_x2 = (uint64_t*)arena_take(c, n * 8), *d_y2 = (uint64_t*)arena_take(c, n * 8);
+	uint64_t *d_uniq = (uint64_t*)arena_take(c, n * 8);
+	uint32_t *d_cnt = (uint32_t*)arena_take(c, n * 4), *d_first = (uint32_t*)arena_take(c, n * 4), *d_small = (uint32_t*)arena_take(c, 64);
+	if (!d_a || !d_x || !d_y || !d_x2 || !d_y2 || !d_uniq || !d_cnt || !d_first || !d_small) return 1;            // does not fit the arena: the host builds the table
+#define IX_CHK(call) do { if ((call) != hipSuccess) return set_err(WM_EINTERNAL, "device index table: %s", #call); } while (0)
+	IX_CHK(hipMemcpyAsync(d_a, all.data(), n * 16, hipMemcpyHostToDevice, c->stream));
+	hipLaunchKernelGGL(idx_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_a, n, d_x, d_y);
+	size_t tmp_bytes = 0, need = 0;
+	IX_CHK(rocprim::radix_sort_pairs(nullptr, need, d_y, d_y2, d_x, d_x2, (size_t)n, 0, 64, c->stream)); tmp_bytes = need;
+	IX_CHK(rocprim::radix_sort_pairs(nullptr, need, d_x2, d_x, d_y2, d_y, (size_t)n, 0, 56, c->stream)); tmp_bytes = std::max(tmp_bytes, need);
+	IX_CHK(rocprim::run_length_encode(nullptr, need, d_x, (unsigned int)n, d_uniq, d_cnt, d_small, c->stream)); tmp_bytes = std::max(tmp_bytes, need);
+	IX_CHK(rocprim::exclusive_scan(nullptr, need, d_cnt, d_first, 0u, (size_t)n, rocprim::plus<uint32_t>(), c->stream)); tmp_bytes = std::max(tmp_bytes, need);
+	void *d_tmp = arena_take(c, tmp_bytes + 256);
+	if (!d_tmp) return 1;
+	need = tmp_bytes;
+	IX_CHK(rocprim::radix_sort_pairs(d_tmp, need, d_y, d_y2, d_x, d_x2, (size_t)n, 0, 64, c->stream));            // by position
+	need = tmp_bytes;
+	IX_CHK(rocprim::radix_sort_pairs(d_tmp, need, d_x2, d_x, d_y2, d_y, (size_t)n, 0, 56, c->stream));            // then, stable, by key: (key, position) order
+	need = tmp_bytes;
+	IX_CHK(rocprim::run_length_encode(d_tmp, need, d_x, (unsigned int)n, d_uniq, d_cnt, d_small, c->stream));
+	uint32_t nk = 0;
+	IX_CHK(hipMemcpyAsync(&nk, d_small, 4, hipMemcpyDeviceToHost, c->stream));
+	IX_CHK(ctx_sync(c));
+	need = tmp_bytes;
+	IX_CHK(rocprim::exclusive_scan(d_tmp, need, d_cnt, d_first, 0u, (size_t)nk, rocprim::plus<uint32_t>(), c->stream));
+	ix.scan_n_runs();
+	ix.n_minimizers = n; ix.n_keys = nk;
+	ix.hbits = 4;
+	while (((uint64_t)1 << ix.hbits) < 2 * (uint64_t)nk + 2) ++ix.hbits;
+	const uint64_t size = (uint64_t)1 << ix.hbits;
+	uint64_t *d_hkey = (uint64_t*)arena_take(c, size * 8), *d_hval = (uint64_t*)arena_take(c, size * 8);
+	uint32_t *d_home = (uint32_t*)arena_take(c, (size_t)nk * 4), *d_idx = (uint32_t*)arena_take(c, (size_t)nk * 4), *d_home2 = (uint32_t*)arena_take(c, (size_t)nk * 4), *d_idx2 = (uint32_t*)arena_take(c, (size_t)nk * 4);
+	long long *d_t = (long long*)arena_take(c, (size_t)nk * 8), *d_m = (long long*)arena_take(c, (size_t)nk * 8);
+	size_t need2 = 0, tmp2 = 0;
+	if (!d_hkey || !d_hval || !d_home || !d_idx || !d_home2 || !d_idx2 || !d_t || !d_m) return 1;
+	IX_CHK(rocprim::radix_sort_pairs(nullptr, need2, d_home, d_home2, d_idx, d_idx2, (size_t)nk, 0, ix.hbits, c->stream)); tmp2 = need2;
+	IX_CHK(rocprim::inclusive_scan(nullptr, need2, d_t, d_m, (size_t)nk, rocprim::maximum<long long>(), c->stream)); tmp2 = std::max(tmp2, need2);
+	void *d_tmp2 = tmp2 <= tmp_bytes ? d_tmp : arena_take(c, tmp2 + 256);
+	if (!d_tmp2) return 1;
+	const unsigned gk = (unsigned)((nk + 255) / 256);
+	IX_CHK(hipMemsetAsync(d_hkey, 0xff, size * 8, c->stream));
+	IX_CHK(hipMemsetAsync(d_hval, 0, size * 8, c->stream));
+	IX_CHK(hipMemsetAsync(d_small, 0, 8, c->stream));
+	hipLaunchKernelGGL(idx_home_kernel, dim3(gk), dim3(256), 0, c->stream, d_uniq, nk, ix.hbits, d_home, d_idx);
+	need2 = tmp2;
+	IX_CHK(rocprim::radix_sort_pairs(d_tmp2, need2, d_home, d_home2, d_idx, d_idx2, (size_t)nk, 0, ix.hbits, c->stream));   // stable: ties stay in key order
+	hipLaunchKernelGGL(idx_rel_kernel, dim3(gk), dim3(256), 0, c->stream, d_home2, nk, d_t);
+	need2 = tmp2;
+	IX_CHK(rocprim::inclusive_scan(d_tmp2, need2, d_t, d_m, (size_t)nk, rocprim::maximum<long long>(), c->stream));
+	hipLaunchKernelGGL(idx_place_kernel, dim3(gk), dim3(256), 0, c->stream, d_m, d_idx2, d_uniq, d_first, d_cnt, nk, size, d_hkey, d_hval, d_small);
+	ix.hkey.resize(size); ix.hval.resize(size); ix.P.resize(n);
+	uint32_t n_over = 0;
+	IX_CHK(hipMemcpyAsync(ix.hkey.data(), d_hkey, size * 8, hipMemcpyDeviceToHost, c->stream));
+	IX_CHK(hipMemcpyAsync(ix.hval.data(), d_hval, size * 8, hipMemcpyDeviceToHost, c->stream));
+	IX_CHK(hipMemcpyAsync(ix.P.data(), d_y, n * 8, hipMemcpyDeviceToHost, c->stream));
+	IX_CHK(hipMemcpyAsync(&n_over, d_small, 4, hipMemcpyDeviceToHost, c->stream));
+	IX_CHK(ctx_sync(c));
+	if (n_over) {                             // the last n_over keys of the (home, key) order wrap around: sequential probing from their home slots
+		std::vector<uint32_t> idx2(n_over);
+		std::vector<uint64_t> uq(nk); std::vector<uint32_t> fi(nk), cn(nk);
+		IX_CHK(hipMemcpy(idx2.data(), d_idx2 + (nk - n_over), (size_t)n_over * 4, hipMemcpyDeviceToHost));
+		IX_CHK(hipMemcpy(uq.data(), d_uniq, (size_t)nk * 8, hipMemcpyDeviceToHost));
+		IX_CHK(hipMemcpy(fi.data(), d_first, (size_t)nk * 4, hipMemcpyDeviceToHost));
+		IX_CHK(hipMemcpy(cn.data(), d_cnt, (size_t)nk * 4, hipMemcpyDeviceToHost));
+		wm::index_table_insert(ix, n_over, [&](size_t t, uint64_t *key, uint64_t *val) { const uint32_t g = idx2[t]; *key = uq[g]; *val = (uint64_t)fi[g] << 32 | cn[g]; return wm::Index::slot_of(uq[g], ix.hbits); });
+	}
+#undef IX_CHK
+	if (t_dev_s) *t_dev_s = (now_ms() - t0) * 1e-3;
+	return WM_OK;
+}
 
 extern "C" int wm_index_build_gpu(wm_ctx_t *c, const char *fasta, const char *kmer_file, int k, int w, int n_threads, wm_index_t **out, double *stats)
 {
@@ -1531,8 +1685,13 @@ extern "C" int wm_index_build_gpu(wm_ctx_t *c, const char *fasta, const char *km
 	if (rc) { delete h; return rc; }
 	const double t2 = now_ms();
 	const double n_mini = (double)all.size();
-	wm::index_table_from_minimizers(ix, all);
+	// the table: on the device as well (WM_INDEX_TABLE_HOST=1: the host's sort + probing, A/B); a table that does not fit the arena falls to the host
+	double t_tab_dev = -1;
+	const int trc = getenv("WM_INDEX_TABLE_HOST") ? 1 : index_table_on_device(c, ix, all, &t_tab_dev);
+	if (trc < 0) { delete h; return trc; }
+	if (trc > 0) { t_tab_dev = -1; wm::index_table_from_minimizers(ix, all); }
 	if (stats) { stats[0] = (t1 - t0) * 1e-3; stats[1] = (t2 - t1) * 1e-3; stats[2] = (now_ms() - t2) * 1e-3; stats[3] = n_mini; }
+	c->aux_ms = (float)(t_tab_dev * 1e3);          // (wm_last_aux_ms: the device table build of this call, < 0 = built on the host)
 	*out = h;
 	return WM_OK;
 }
@@ -2856,6 +3015,48 @@ extern "C" int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *o
 		else le.keep(r);
 		return r;
 	}, out, &fs, err);
+	if (out != stdout) fclose(out);
+	if (stats) { stats[0] = (double)fs.n_reads; stats[1] = (double)fs.n_bases; stats[2] = (double)fs.n_batches; stats[3] = fs.t_read; stats[4] = fs.t_map; stats[5] = fs.t_write; }
+	if (rc) return le.code ? set_err(le.code, "%s", le.msg.c_str()) : set_err(WM_EINVAL, "%s", err.c_str());
+	return WM_OK;
+}
+
+// The file loop over N mappers — one per GPU of the node (each with its own context, index copy and host threads: wm_ctx_create(device i),
+// wm_index_upload_peer, wm_mapper_create, wm_mapper_set_threads) — inside ONE process: the C twin of `one rank per GPU`. The reader hands mini-batches
+// to 2 lanes per mapper (lane l -> mapper l % n, result slot l / n), reads shard by mini-batch, nothing is exchanged between the devices, and the
+// ordered writer puts the records back into input order: the output file equals wm_map_file's (and the reference's). The SAM header, if wanted, is
+// written once from the first mapper's index and command line.
+extern "C" int wm_map_file_multi(wm_mapper_t *const *ms, int n, const char *reads_path, const char *out_path, int64_t mini_batch_bases, double *stats)
+{
+	g_err[0] = 0;
+	if (!ms || n < 1 || !reads_path || !out_path) return set_err(WM_EINVAL, "bad argument");
+	for (int i = 0; i < n; ++i) {
+		if (!ms[i]) return set_err(WM_EINVAL, "null mapper");
+		if (ms[i]->mo.flag != ms[0]->mo.flag || ms[i]->idx->ix.seq.size() != ms[0]->idx->ix.seq.size() || ms[i]->idx->ix.hbits != ms[0]->idx->ix.hbits)
+			return set_err(WM_EINVAL, "mapper %d differs from mapper 0 (options or index)", i);
+	}
+	FILE *out = strcmp(out_path, "-") == 0 ? stdout : fopen(out_path, "wb");
+	if (!out) return set_err(WM_EINVAL, "cannot open '%s' for writing", out_path);
+	wm_mapper_t *m0 = ms[0];
+	std::string err;
+	if ((m0->mo.flag & 0x8) && m0->sam_header) {
+		std::string hdr;
+		std::vector<const char*> av;
+		for (const std::string &a : m0->cmdline) av.push_back(a.c_str());
+		wm::write_sam_header(hdr, m0->idx->ix, (int)av.size(), av.data());
+		if (fwrite(hdr.data(), 1, hdr.size(), out) != hdr.size()) { if (out != stdout) fclose(out); return set_err(WM_EINVAL, "write error on '%s'", out_path); }
+	}
+	wm::FileStats fs;
+	const bool with_qual = (m0->mo.flag & 0x8) != 0;
+	LaneError le;
+	const int rc = wm::map_file(reads_path, mini_batch_bases, with_qual, [&](std::vector<wm::ReadIn> &batch, std::string &text, int lane) {
+		wm_mapper_t *m = ms[lane % n];
+		const int slot = lane / n;
+		const int r = map_reads_impl(m, batch, now_ms(), slot);
+		if (r == 0) text.swap(m->res[slot].text);
+		else le.keep(r);
+		return r;
+	}, out, &fs, err, 2 * n);
 	if (out != stdout) fclose(out);
 	if (stats) { stats[0] = (double)fs.n_reads; stats[1] = (double)fs.n_bases; stats[2] = (double)fs.n_batches; stats[3] = fs.t_read; stats[4] = fs.t_map; stats[5] = fs.t_write; }
 	if (rc) return le.code ? set_err(le.code, "%s", le.msg.c_str()) : set_err(WM_EINVAL, "%s", err.c_str());

@@ -13,9 +13,12 @@ def export_lengths(sizes):
     return [s[0], s[1], s[1], s[2], s[3], 2 * s[4], s[5]]
 
 
-def broadcast_index(idx, rank, dist, device):
+def broadcast_index(idx, rank, dist, device, ctx=None):
     """rank 0 passes its gpu.Index, the others None; every rank returns an Index with identical content.
-    One broadcast for the 9-entry size header, then one per flat array (bytes)."""
+    One broadcast for the 9-entry size header, then one per flat array (bytes). With `ctx` (a gpu.Context on `device`, RCCL): the five arrays the
+    kernels use go from the broadcast's receive buffers straight into the context (wm_index_upload_dev: device to device, no second trip through
+    host memory) and the function returns (index, True); the host copy of the index (contig table, packed bases and occurrence counts for the
+    host-side glue) is filled from one device-to-host copy per array. Without `ctx` (gloo on CPU): (index, False), the caller uploads."""
     import torch
     from . import gpu
     if rank == 0:
@@ -25,7 +28,8 @@ def broadcast_index(idx, rank, dist, device):
         st = torch.zeros(9, dtype=torch.int64, device=device)
     dist.broadcast(st, 0)
     sizes_b = st.cpu().numpy().astype(np.uint64)
-    recv = []
+    on_device = ctx is not None and getattr(device, "type", "cpu") == "cuda"
+    recv, bufs = [], []
     for i, (m, dt) in enumerate(zip(export_lengths(sizes_b), _EXPORT_DTYPES)):
         nbytes = max(m, 1) * np.dtype(dt).itemsize
         if rank == 0:
@@ -33,8 +37,14 @@ def broadcast_index(idx, rank, dist, device):
         else:
             t = torch.empty(nbytes, dtype=torch.uint8, device=device)
         dist.broadcast(t, 0)
-        recv.append(t.cpu().numpy().view(dt))
-    return idx if rank == 0 else gpu.Index.from_arrays(sizes_b, recv)
+        bufs.append(t)
+        if rank != 0:
+            recv.append(t.cpu().numpy().view(dt))
+    out = idx if rank == 0 else gpu.Index.from_arrays(sizes_b, recv)
+    if on_device:
+        torch.cuda.synchronize(device)
+        out.upload_dev(ctx, [b.data_ptr() for b in bufs[:5]], device.index if device.index is not None else torch.cuda.current_device())
+    return out, on_device
 
 
 def shard(n, rank, world):

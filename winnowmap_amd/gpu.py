@@ -270,6 +270,16 @@ def build_index_parts(fasta, kmer_file, k, w, batch_bases, n_threads=8):
     return [Index(_handle=C.c_void_p(arr[i])) for i in range(n.value)]
 
 
+def map_file_multi(mappers, reads_path, out_path, mini_batch_bases=0):
+    """wm_map_file_multi: the file loop over several mappers (one per GPU), two lanes each, records in input order"""
+    L = lib()
+    L.wm_map_file_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_char_p, C.c_int64, C.c_void_p]
+    arr = (C.c_void_p * len(mappers))(*[m._h for m in mappers])
+    st = np.zeros(6, np.float64)
+    _chk(L.wm_map_file_multi(arr, len(mappers), os.fsencode(reads_path), os.fsencode(out_path), mini_batch_bases, st.ctypes.data))
+    return dict(zip(("reads", "bases", "batches", "t_read", "t_map", "t_write"), (float(x) for x in st)))
+
+
 def map_file_split(ctx, parts, opt, n_threads, reads_path, out_path, mini_batch_bases=0):
     """wm_map_file_split: the reads against every index part in turn, hits merged like `--split-prefix` (mm_split_merge)"""
     L = lib()
@@ -301,7 +311,10 @@ class Index:
         h = C.c_void_p()
         st = np.zeros(4, np.float64)
         _chk(L.wm_index_build_gpu(ctx._h, os.fsencode(fasta), os.fsencode(kmer_file) if kmer_file else None, k, w, n_threads, C.byref(h), st.ctypes.data))
-        return Index(_handle=h), {"read_pack_s": float(st[0]), "device_sketch_s": float(st[1]), "table_s": float(st[2]), "minimizers": int(st[3])}
+        L.wm_last_aux_ms.restype = C.c_float
+        L.wm_last_aux_ms.argtypes = [C.c_void_p]
+        return Index(_handle=h), {"read_pack_s": float(st[0]), "device_sketch_s": float(st[1]), "table_s": float(st[2]), "minimizers": int(st[3]),
+                                  "table_on_device_s": float(L.wm_last_aux_ms(ctx._h)) * 1e-3}       # (< 0: the table was built by the host)
 
     def read_junc_bed(self, path):
         """--junc-bed: annotated introns for splice mode's junction bonus (wm_index_read_junc_bed = mm_idx_bed_read, src/index.c:756)"""
@@ -346,6 +359,18 @@ class Index:
 
     def upload(self, ctx):
         _chk(lib().wm_index_upload(ctx._h, self._h))
+
+    def upload_dev(self, ctx, d_ptrs, src_device):
+        """wm_index_upload_dev: the flat arrays S, hkey, hval, P, bloom from DEVICE pointers (e.g. the receive buffers of the RCCL broadcast) on src_device"""
+        L = lib()
+        L.wm_index_upload_dev.argtypes = [C.c_void_p, C.c_void_p] + [C.c_void_p] * 5 + [C.c_int]
+        _chk(L.wm_index_upload_dev(ctx._h, self._h, *[C.c_void_p(int(p)) for p in d_ptrs], int(src_device)))
+
+    def upload_peer(self, dst_ctx, src_ctx):
+        """wm_index_upload_peer: the copy context `src_ctx` holds goes to `dst_ctx` (any GPU of the node), device to device"""
+        L = lib()
+        L.wm_index_upload_peer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(L.wm_index_upload_peer(dst_ctx._h, self._h, src_ctx._h))
 
     @property
     def n_minimizers(self):
