@@ -227,19 +227,33 @@ def test_index_handed_on_device_to_device_and_the_file_loop_over_two_mappers(ctx
     t2 = m2.map(["q%d" % i for i in range(8)], reads[:8])[0]
     assert t1 == t2 and len(t1) > 0
     m1.close(); m2.close()
-    # RCCL: one-rank group, the broadcast buffers feed the context directly
-    import torch
-    import torch.distributed as dist
-    from winnowmap_amd import dist as wmdist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(wmdist.free_port())
-    dist.init_process_group("nccl", rank=0, world_size=1)
-    try:
-        ctx3 = gpu.Context(0, 2 << 30)
-        idx_b, on_dev = wmdist.broadcast_index(idx, 0, dist, torch.device("cuda", 0), ctx3)
-        assert on_dev
-        m3 = gpu.Mapper(ctx3, idx_b, preset, gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
-        assert m3.map(["q%d" % i for i in range(8)], reads[:8])[0] == t1
-        m3.close(); ctx3.close()
-    finally:
-        dist.destroy_process_group()
+    # RCCL: one-rank group, the broadcast buffers feed the context directly. In a process of its own with torch imported FIRST: torch brings its own HIP
+    # runtime, and a process that has already initialised the system's through libwmgpu.so leaves torch without a device (bench.py imports torch first too)
+    import subprocess
+    import sys
+    np.save(os.path.join(tmp, "t1.npy"), np.frombuffer(t1, np.uint8))
+    script = """
+import os, sys, tempfile
+import torch, torch.distributed as dist
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import e2e_common as E
+from winnowmap_amd import gpu, dist as wmdist
+tmp = %r
+preset, fa, kf, k, reads = E.make_golden.inputs("ont_short", tempfile.mkdtemp())
+reads = [r[:3000 + 211 * i] for i, r in enumerate(reads)]
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(wmdist.free_port())
+dist.init_process_group("nccl", rank=0, world_size=1)
+idx = gpu.Index(fa, kf, k=k, w=50)
+ctx3 = gpu.Context(0, 2 << 30)
+idx_b, on_dev = wmdist.broadcast_index(idx, 0, dist, torch.device("cuda", 0), ctx3)
+assert on_dev
+m3 = gpu.Mapper(ctx3, idx_b, preset, gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
+t3 = m3.map(["q%%d" %% i for i in range(8)], reads[:8])[0]
+assert np.array_equal(np.frombuffer(t3, np.uint8), np.load(os.path.join(tmp, "t1.npy"))), "records differ"
+m3.close(); ctx3.close(); dist.destroy_process_group()
+print("RCCL-received index maps identically")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), tmp)
+    p = subprocess.run([sys.executable, "-c", script], capture_output=True, timeout=300)
+    assert p.returncode == 0 and b"maps identically" in p.stdout, p.stderr.decode(errors="replace")[-1500:]
     ctx2.close(); idx.close()
