@@ -252,7 +252,7 @@ def make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1, un
         "config": {"workload": "BASELINE config %d: %d x %d bp %s reads per step per GPU vs %.0f Mb synthetic reference (10%% repeats), -W repetitive_k15.txt -x %s, CIGAR on"
                                % (args.config, args.reads_per_step, args.read_len, CONFIGS[args.config]["label"], args.ref_mb, CONFIGS[args.config]["preset"]),
                    "reads_per_step_per_gpu": args.reads_per_step, "read_len": args.read_len, "ref_mb": args.ref_mb, "host_threads": n_threads,
-                   "reads_per_s": total_bases / args.read_len / elapsed, "hits": hits, "parallelism": "reads sharded over %d rank(s), index broadcast" % world, "mini_batches_in_flight": 2 if int(os.environ.get("WM_BENCH_PIPELINE", 1)) else 1,
+                   "reads_per_s": total_bases / args.read_len / elapsed, "hits": hits, "parallelism": "reads sharded over %d rank(s), index broadcast" % world, "mini_batches_in_flight": max(1, min(4, int(os.environ.get("WM_BENCH_SLOTS", 2)))) if int(os.environ.get("WM_BENCH_PIPELINE", 1)) else 1,
                    # which kernel variants ran (tools/r03_first_run.sh A/Bs them): build-time defines and run-time switches
                    "variants": {"kernel_defines": gpu.build_defines(),
                                 **{k: os.environ[k] for k in ("WM_KSW_PMULTI", "WM_KSW_COOP_BT", "WM_SEED_DEVICE_SORT", "WM_CONTEXTS") if k in os.environ}}},
@@ -374,7 +374,7 @@ def main():
     # phases of one hide behind the steady state of the other. Every step is one mini-batch, mapped completely inside the timed region; the
     # steps of a slot run in order. WM_BENCH_PIPELINE=0: one step at a time (A/B).
     import threading
-    n_slots = 2 if int(os.environ.get("WM_BENCH_PIPELINE", 1)) else 1
+    n_slots = max(1, min(4, int(os.environ.get("WM_BENCH_SLOTS", 2)))) if int(os.environ.get("WM_BENCH_PIPELINE", 1)) else 1
 
     def run_steps(step_batches):
         """maps the given mini-batches on n_slots lanes (each lane takes the next unmapped step, like wm_map_file's lanes); returns (hits, bases)"""
@@ -494,6 +494,8 @@ def main():
                 log("cpu baseline / parity error:", repr(e))
                 out.setdefault("cpu_baseline", None)
         print(json.dumps(out), flush=True)
+    if os.environ.get("WM_PROF"):
+        mapper.close()              # (prints the host glue's time per named region to stderr)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

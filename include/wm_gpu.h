@@ -245,10 +245,11 @@ int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena_bytes_per_
  * returned for tests; hit_first[i] = index of read i's first hit, hit_first[n] = total. */
 int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, const char *const *seqs, const int32_t *lens,
                  const char **text, size_t *text_len, const int32_t **hits, const uint32_t **cigars, const int64_t **hit_first);
-/* wm_map_reads with its own result buffers (slot 0 or 1; wm_map_reads = slot 0): calls with different slots may run CONCURRENTLY from two host
- * threads on one mapper. They share the device contexts; each keeps the codes of its mini-batch in its own slab. A mapping call spends its first
- * and last few hundred milliseconds filling and draining its pipeline of dependent device calls: with two mini-batches in flight those phases of one
- * hide behind the steady state of the other (bench.py maps consecutive steps on alternating slots). Results are valid until the next call on that slot. */
+#define WM_MAX_SLOTS 4
+/* wm_map_reads with its own result buffers (slot 0 .. WM_MAX_SLOTS - 1; wm_map_reads = slot 0): calls with different slots may run CONCURRENTLY from
+ * different host threads on one mapper. They share the device contexts; each keeps the codes of its mini-batch in its own slab. A mapping call spends its first
+ * and last few hundred milliseconds filling and draining its pipeline of dependent device calls: with several mini-batches in flight those phases of one
+ * hide behind the steady state of the others (bench.py maps consecutive steps on WM_BENCH_SLOTS slots, wm_map_file on WM_MAP_LANES lanes; default 2). Results are valid until the next call on that slot. */
 int wm_map_reads_slot(wm_mapper_t *m, int slot, int n, const char *const *names, const char *const *seqs, const int32_t *lens,
                       const char **text, size_t *text_len, const int32_t **hits, const uint32_t **cigars, const int64_t **hit_first);
 /* counters of the last wm_map_reads call: [0] super-steps, [1] ksw jobs, [2] chain jobs, [3] seed jobs,

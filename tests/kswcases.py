@@ -98,3 +98,66 @@ def make_splice_cases(seed, n, max_exon=120, max_intron=400):
         out.append(dict(q=q, t=t, a=sc[0], b=sc[1], q_=sc[2], e=sc[3], q2=sc[4], noncan=sc[5], junc_bonus=sc[6],
                         zdrop=[200, 50, -1, 400][it % 4], flag=flag, junc=jn))
     return out
+
+
+def stripe_cases(seed, n, max_len):
+    """approximate-maximum, exact and z-dropping jobs of any length (make_cases only has tiny approximate-maximum jobs): related prefix + unrelated
+    tail, long indels, N bases, every band"""
+    from winnowmap_amd import synth
+    rng = np.random.default_rng(seed)
+    out = []
+    for ci in range(n):
+        tl = int(rng.integers(1, max_len))
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        kind = int(rng.integers(0, 6))
+        if kind == 0:
+            q = rng.integers(0, 4, int(rng.integers(1, max_len))).astype(np.uint8)
+        elif kind == 1:
+            k = int(rng.integers(1, tl + 1))
+            q = np.concatenate([synth.mutate_codes(t[:k], rng, 0.03, 0.03, 0.04), rng.integers(0, 4, int(rng.integers(1, max_len))).astype(np.uint8)])
+        elif kind == 2:
+            k = int(rng.integers(0, tl + 1)); g = int(rng.integers(1, 200))
+            q = synth.mutate_codes(t, rng, 0.02, 0.02, 0.02)
+            q = np.concatenate([q[:k], rng.integers(0, 4, g).astype(np.uint8), q[k:]]) if rng.integers(0, 2) else np.concatenate([q[:k], q[min(len(q), k + g):]])
+        else:
+            q = synth.mutate_codes(t, rng, 0.03, 0.03, 0.04)
+        if len(q) == 0:
+            q = np.array([1], np.uint8)
+        if rng.integers(0, 8) == 0:
+            q[rng.integers(0, len(q))] = 4
+        if rng.integers(0, 8) == 0:
+            t[rng.integers(0, len(t))] = 4
+        out.append(dict(q=q, t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1,
+                        w=int(rng.choice([751, 3001, 50, 10, 200, -1, 5, 100, 127, 128, 129, 30, 1501])), zdrop=int(rng.choice([400, 200, 25, 50, -1, 100])),
+                        end_bonus=int(rng.choice([-1, 10, 0])), flag=int(rng.choice([0x08, 0x08, 0x00, 0x40, 0xC2, 0x42, 0x80, 0x0A, 0x88]))))
+    return out
+
+
+def stripe_edge_cases(seed, n, max_len):
+    """lengths around the stripe boundaries (multiples of 128), unequal lengths, every small band: the ends of a job as the stripe-pipelined kernel sees
+    them (a band that runs empty before the next stripe starts, stripes that are never reached, the band's last lane right below a stripe)"""
+    from winnowmap_amd import synth
+    rng = np.random.default_rng(seed)
+    out = []
+    for ci in range(n):
+        base = int(rng.choice([0, 128, 256, 384, 512, 640])) if rng.integers(0, 2) else 0
+        tl = max(1, min(max_len, base + int(rng.integers(-20, 140))))
+        ql = max(1, int(rng.choice([tl + int(rng.integers(-150, 150)), int(rng.integers(1, max_len)), tl])))
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        if rng.integers(0, 3) == 0:
+            q = rng.integers(0, 4, ql).astype(np.uint8)
+        else:
+            q = synth.mutate_codes(t, rng, 0.03, 0.03, 0.04)
+            q = np.concatenate([q, rng.integers(0, 4, max(0, ql - len(q))).astype(np.uint8)])[:ql]
+        if len(q) == 0:
+            q = np.array([1], np.uint8)
+        if rng.integers(0, 10) == 0:
+            q[rng.integers(0, len(q))] = 4
+        if rng.integers(0, 10) == 0:
+            t[rng.integers(0, len(t))] = 4
+        pr = PRESETS[int(rng.integers(0, len(PRESETS)))]
+        out.append(dict(q=q, t=t, a=pr[0], b=pr[1], q_=pr[2], e=pr[3], q2=pr[4], e2=pr[5],
+                        w=int(rng.choice([1, 2, 5, 10, 15, 16, 17, 30, 31, 32, 33, 50, 63, 64, 65, 100, 111, 112, 113, 127, 128, 200, 751, -1])),
+                        zdrop=int(rng.choice([400, 200, 25, 50, -1, 100])), end_bonus=int(rng.choice([-1, 10, 0])),
+                        flag=int(rng.choice([0x08, 0x08, 0x00, 0x40, 0xC2, 0x42, 0x80, 0x0A, 0x88]))))
+    return out

@@ -5,7 +5,6 @@
 #include "ksw_kernel.h"              // winnowmap_amd/csrc
 #include "ksw_packed_kernel.h"
 #include "ksw_packed_multi_kernel.h"
-#include "ksw_stripe_kernel.h"
 #include "ksw_exts2_kernel.h"
 #include "ksw_plan.h"
 #include "sketch_kernel.h"
@@ -62,35 +61,6 @@ template <int BP, int NWV> static void run_pmulti(int variant, const wm_ksw_scor
 	pthread_barrier_destroy(&bar);
 }
 
-// the stripe-pipelined kernel: NWV emulated wavefronts (one host thread each) that talk through the LDS rings, no barrier in the row loop
-template <int BP, int NWV> static void run_stripe(int variant, const wm_ksw_score_t &sc, const wm_ksw_djob_t &jb, const uint8_t *seqs, uint8_t *tb, wm_ksw_dres_t *res)
-{
-	const bool exact = variant & 4, clip = variant & 2, hasn = variant & 1;
-	std::vector<int> lds(wmk::ksw_stripe_lds<BP, NWV>::INTS, 0x5a5a5a5a);
-	pthread_barrier_t bar;
-	pthread_barrier_init(&bar, 0, NWV);
-	simt::block_barrier() = &bar;
-	std::vector<std::thread> th;
-	for (int w = 0; w < NWV; ++w)
-		th.emplace_back([&, w]() {
-			simt::wave_slot() = w; simt::exec_mask() = ~0ull;
-			if (exact) {
-				if (clip && hasn) wmk::ksw_dp_stripe<BP, NWV, true, true, true>(sc, jb, seqs, tb, lds.data(), res);
-				else if (clip) wmk::ksw_dp_stripe<BP, NWV, true, false, true>(sc, jb, seqs, tb, lds.data(), res);
-				else if (hasn) wmk::ksw_dp_stripe<BP, NWV, false, true, true>(sc, jb, seqs, tb, lds.data(), res);
-				else wmk::ksw_dp_stripe<BP, NWV, false, false, true>(sc, jb, seqs, tb, lds.data(), res);
-			} else {
-				if (clip && hasn) wmk::ksw_dp_stripe<BP, NWV, true, true, false>(sc, jb, seqs, tb, lds.data(), res);
-				else if (clip) wmk::ksw_dp_stripe<BP, NWV, true, false, false>(sc, jb, seqs, tb, lds.data(), res);
-				else if (hasn) wmk::ksw_dp_stripe<BP, NWV, false, true, false>(sc, jb, seqs, tb, lds.data(), res);
-				else wmk::ksw_dp_stripe<BP, NWV, false, false, false>(sc, jb, seqs, tb, lds.data(), res);
-			}
-		});
-	for (auto &t : th) t.join();
-	simt::block_barrier() = 0;
-	pthread_barrier_destroy(&bar);
-}
-
 static int g_coop_backtrack = 0;
 extern "C" {
 
@@ -110,8 +80,6 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 	jb.q_off = 0; jb.t_off = qlen; jb.qlen = qlen; jb.tlen = tlen; jb.w = w; jb.zdrop = zdrop; jb.end_bonus = end_bonus; jb.flag = flag;
 	bool emu_blk3_small = false, emu_blk_lds = false, emu_bp2 = false;
 	int emu_pmulti = 0;      // 200 + geometry * 10 + (CLIP * 2 + HASN): the packed multi-wave kernel; geometry 0 = <1,2> (256 lanes), 1 = <2,3> (768), 2 = <4,4> (2048), 3 = <8,4> (4096), 4 = <4,8> (4096) and 5 = <8,8> (8192): the product's WM_KSW_PMULTI geometries
-	int emu_stripe = 0;      // 300 + geometry * 10 + (CLIP * 2 + HASN): the stripe-pipelined kernel; geometry 0 = <1,2>, 1 = <1,3>, 2 = <2,3>, 3 = <2,4>, 4 = <4,4>, 5 = <4,8>, 6 = <8,8>, 7 = <1,4>
-	if (force_klass >= 300 && force_klass < 380) { emu_stripe = 1 + (force_klass - 300) / 10; force_klass = WM_KSW_P4 + (force_klass - 300) % 10; }
 	if (force_klass >= 200 && force_klass < 260) { emu_pmulti = 1 + (force_klass - 200) / 10; force_klass = WM_KSW_P4 + (force_klass - 200) % 10; }
 	// force_klass: -1 = choose like the product host; 0..23 = that register class (window and CLIP / HASN bits as given, EXACT always follows
 	// the job's flag); 100 + (CLIP*2 + HASN) = the 2-pair window (256 lanes: many re-bases and pair boundaries on small inputs; tests only);
@@ -121,7 +89,7 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 	if (force_klass == 125) { emu_blk_lds = true; force_klass = WM_KSW_BLOCK2; }
 	if (force_klass == 126) { emu_blk3_small = true; force_klass = WM_KSW_BLOCK3; }
 	int n_col, klass = wm_ksw_classify(qlen, tlen, w, wm_ksw_has_n(query, qlen) | wm_ksw_has_n(target, tlen), flag, &n_col);
-	if (force_klass >= 0 && !emu_pmulti && !emu_stripe) {
+	if (force_klass >= 0 && !emu_pmulti) {
 		if (force_klass < WM_KSW_BLOCK) {
 			if (klass >= WM_KSW_BLOCK || (force_klass & ~7) < (klass & ~7)) return -1;      // window too small for this job
 			if ((klass & 3) & ~(force_klass & 3)) return -1;                               // the job needs CLIP / HASN and the forced variant lacks it
@@ -142,35 +110,13 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 		if (need & ~(force_klass & 3)) return -1;
 		klass = (force_klass & 3) | ((flag & 0x08) ? 0 : 4);
 	}
-	if (emu_stripe) {
-		static const int max_ncol[8] = { 128, 2 * 128, 2 * 256, 3 * 256, 3 * 512, 7 * 512, 7 * 1024, 3 * 128 };
-		n_col = wm_ksw_ncol(qlen, tlen, w);
-		if (n_col > max_ncol[emu_stripe - 1]) return -1;
-		const int has_n = wm_ksw_has_n(query, qlen) | wm_ksw_has_n(target, tlen);
-		int ww = w < 0 ? (tlen > qlen ? tlen : qlen) : w;
-		const int need = (!(ww >= qlen && ww >= tlen) ? 2 : 0) | (has_n ? 1 : 0);
-		if (need & ~(force_klass & 3)) return -1;
-		klass = (force_klass & 3) | ((flag & 0x08) ? 0 : 4);
-	}
 	*klass_out = klass;
 	if (emu_blk3_small && n_col + 16 > 128 * WM_KSW_BLK_MAXC) return -1;
 	jb.n_col = n_col; jb.tb_off = 0; jb.klass = klass;
 	std::vector<uint8_t> tb((size_t)(qlen + tlen - 1) * n_col + 64, 0xEE);
 	wm_ksw_dres_t res;
 	memset(&res, 0, sizeof(res));
-	if (emu_stripe) {
-		const int variant = klass & 7;
-		switch (emu_stripe) {
-		case 1: run_stripe<1, 2>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
-		case 2: run_stripe<1, 3>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
-		case 3: run_stripe<2, 3>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
-		case 4: run_stripe<2, 4>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
-		case 5: run_stripe<4, 4>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
-		case 6: run_stripe<4, 8>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
-		case 7: run_stripe<8, 8>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
-		default: run_stripe<1, 4>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
-		}
-	} else if (emu_pmulti) {
+	if (emu_pmulti) {
 		const int variant = (klass & 4) | ((klass & 2) || (klass & 1) ? 2 : 0) | (klass & 1);      // (jobs with an N run on the CLIP instantiation, as in the product)
 		if (emu_pmulti == 1) run_pmulti<1, 2>(variant, sc, jb, seqs.data(), tb.data(), &res);
 		else if (emu_pmulti == 2) run_pmulti<2, 3>(variant, sc, jb, seqs.data(), tb.data(), &res);

@@ -315,3 +315,77 @@ def test_wave_cooperative_backtrack_equals_the_single_thread_walk(emu):
             assert np.array_equal(cig, o["cigar"]), (klass, len(c["q"]), len(c["t"]), hex(c["flag"]), c["w"], W.cigar_str(cig)[:80], W.cigar_str(o["cigar"])[:80])
     finally:
         emu.emu_set_coop_backtrack(0)
+
+
+# ---- the stripe-pipelined ksw kernel (ksw_stripe_kernel.h): a library of its own, with event counters and a watchdog on the polling loops ----
+STRIPE_EVENTS = {"stripe_switch": 0, "inject": 1, "ez_handover_at_activation": 2, "restart": 3, "edge_trk_handover": 4, "trk_handover": 5, "zdrop": 6,
+                 "pri_eval": 7, "pri_skipped": 8}
+
+
+def _load_stripe(defines=()):
+    E = C.CDLL(build.build_emu_stripe(defines))
+    E.emu_stripe_extd2.argtypes = [C.c_int, W.u8p, C.c_int, W.u8p, W.i8p] + [C.c_int] * 9 + [W.i32p, W.u32p, C.c_int, C.POINTER(C.c_int)]
+    E.emu_ksw_extd2 = E.emu_stripe_extd2
+    return E
+
+
+def _stripe_events(E):
+    ev = (C.c_long * 16)()
+    E.emu_stripe_events(ev)
+    return {k: int(ev[i]) for k, i in STRIPE_EVENTS.items()}
+
+
+def _stripe_run(E, cases, forces):
+    n_run = collections.Counter()
+    for c in cases:
+        o = None
+        for force in forces:
+            n, ez, cig, klass = emu_ksw(E, c, force)
+            if n < 0:
+                continue            # the job does not fit this geometry, or needs CLIP / HASN and the variant lacks it
+            if o is None:
+                o = W.o_ksw_extd2(c["q"], c["t"], mat=W.simple_mat(c["a"], c["b"], 1), q=c["q_"], e=c["e"], q2=c["q2"], e2=c["e2"],
+                                  w=c["w"], zdrop=c["zdrop"], end_bonus=c["end_bonus"], flag=c["flag"])
+            n_run[(force - 300) // 10] += 1
+            assert [int(x) for x in ez] == [o[k] for k in W.EZ_FIELDS], (force, klass, len(c["q"]), len(c["t"]), c["w"], hex(c["flag"]), c["zdrop"])
+            assert np.array_equal(cig, o["cigar"]), (force, klass, len(c["q"]), len(c["t"]), c["w"], hex(c["flag"]), c["zdrop"])
+    return n_run
+
+
+def test_stripe_pipelined_ksw_kernel_matches_oracle():
+    """ksw_dp_stripe: wavefronts own fixed 128*BP-lane target stripes cyclically and hand (H, E, F, prefix maximum, bookkeeping state, the approximate
+    maximum's track) to the right neighbour through row-stamped LDS messages. Small geometries (<1,2> = 2 waves x 128 lanes ... <2,3>) put stripe
+    switches, hand-overs and ring wrap-arounds on small random cases of every flag / band / scoring combination; the product's geometries (<2,4>,
+    <4,8>, <8,8>) run on natively wide bands. The host's thread scheduler supplies the interleavings; every rare path must have run."""
+    E = _load_stripe()
+    small = [300 + g * 10 + v for g in (0, 1, 7, 2) for v in (0, 2, 3)]
+    n_run = _stripe_run(E, kswcases.stripe_edge_cases(3, 260, 700), small)
+    n_run += _stripe_run(E, kswcases.stripe_cases(5, 60, 700), small)
+    n_run += _stripe_run(E, kswcases.make_cases(9, 60, max_len=500), small)
+    from winnowmap_amd import synth
+    rng = np.random.default_rng(23)
+    wide = []
+    for tl, fl, w, zd in ((900, 0x08, -1, 400), (1500, 0x40, 700, 200), (1900, 0x00, -1, 400), (3300, 0x88, 1500, 400), (5200, 0x00, 2600, 100), (2500, 0x0A, -1, -1)):
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        q = synth.mutate_codes(t, rng, 0.03, 0.03, 0.03)
+        if fl == 0x0A:
+            q[len(q) // 2] = 4
+        wide.append(dict(q=q, t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=w, zdrop=zd, end_bonus=-1, flag=fl))
+    n_run += _stripe_run(E, wide, [300 + g * 10 + v for g in (3, 4, 5, 6) for v in (2, 3)])
+    ev = _stripe_events(E)
+    assert n_run[0] > 100 and n_run[1] > 150 and n_run[7] > 150 and n_run[2] > 200 and n_run[3] >= 2 and n_run[4] >= 4 and n_run[5] >= 8 and n_run[6] >= 10, n_run
+    for k in ("stripe_switch", "inject", "ez_handover_at_activation", "edge_trk_handover", "trk_handover", "zdrop", "pri_eval", "pri_skipped"):
+        assert ev[k] > 0, ev
+    assert ev["restart"] == 0, ev              # with the real margin the safe-mode repeat is (provably) never needed
+
+
+def test_stripe_kernel_repeat_in_safe_mode():
+    """the exact-maximum path skips the priority evaluation of a row whose prefix maximum cannot reach ez.max minus a margin; should a later stripe
+    need a skipped priority after all, the job repeats with every priority evaluated. The real margin makes that unreachable; a useless margin
+    (WM_STRIPE_TEST_SLACK) forces it, and the results must not change."""
+    E = _load_stripe(("WM_STRIPE_TEST_SLACK=-100000",))
+    forces = [300 + g * 10 + v for g in (0, 1, 7, 2) for v in (2, 3)]
+    exact = [c for c in kswcases.stripe_edge_cases(4, 260, 700) + kswcases.stripe_cases(6, 40, 700) if not (c["flag"] & 0x08)]
+    n_run = _stripe_run(E, exact, forces)
+    ev = _stripe_events(E)
+    assert sum(n_run.values()) > 300 and ev["restart"] > 20, (n_run, ev)

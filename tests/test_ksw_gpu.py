@@ -244,41 +244,8 @@ def test_stripe_kernels_random_cases_all_flags(ctx, all_stripes, preset):
     assert not bad, bad[:3]
 
 
-def stripe_cases(seed, n, max_len):
-    """approximate-maximum, exact and z-dropping jobs of any length (make_cases only has tiny approximate-maximum jobs): related prefix + unrelated
-    tail, long indels, N bases, every band"""
-    from winnowmap_amd import synth
-    rng = np.random.default_rng(seed)
-    out = []
-    for ci in range(n):
-        tl = int(rng.integers(1, max_len))
-        t = rng.integers(0, 4, tl).astype(np.uint8)
-        kind = int(rng.integers(0, 6))
-        if kind == 0:
-            q = rng.integers(0, 4, int(rng.integers(1, max_len))).astype(np.uint8)
-        elif kind == 1:
-            k = int(rng.integers(1, tl + 1))
-            q = np.concatenate([synth.mutate_codes(t[:k], rng, 0.03, 0.03, 0.04), rng.integers(0, 4, int(rng.integers(1, max_len))).astype(np.uint8)])
-        elif kind == 2:
-            k = int(rng.integers(0, tl + 1)); g = int(rng.integers(1, 200))
-            q = synth.mutate_codes(t, rng, 0.02, 0.02, 0.02)
-            q = np.concatenate([q[:k], rng.integers(0, 4, g).astype(np.uint8), q[k:]]) if rng.integers(0, 2) else np.concatenate([q[:k], q[min(len(q), k + g):]])
-        else:
-            q = synth.mutate_codes(t, rng, 0.03, 0.03, 0.04)
-        if len(q) == 0:
-            q = np.array([1], np.uint8)
-        if rng.integers(0, 8) == 0:
-            q[rng.integers(0, len(q))] = 4
-        if rng.integers(0, 8) == 0:
-            t[rng.integers(0, len(t))] = 4
-        out.append(dict(q=q, t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1,
-                        w=int(rng.choice([751, 3001, 50, 10, 200, -1, 5, 100, 127, 128, 129, 30, 1501])), zdrop=int(rng.choice([400, 200, 25, 50, -1, 100])),
-                        end_bonus=int(rng.choice([-1, 10, 0])), flag=int(rng.choice([0x08, 0x08, 0x00, 0x40, 0xC2, 0x42, 0x80, 0x0A, 0x88]))))
-    return out
-
-
 def test_stripe_kernels_long_jobs_every_band(ctx, all_stripes):
-    bad = _run_group(ctx, stripe_cases(11, 300, 2600))
+    bad = _run_group(ctx, kswcases.stripe_cases(11, 300, 2600))
     assert not bad, bad[:3]
 
 

@@ -105,6 +105,22 @@ def build_emu(defines=()):
     return out
 
 
+def build_emu_stripe(defines=()):
+    """tests/simt_emu/libwm_emu_stripe[_<defines>].so: the stripe-pipelined ksw kernel alone on the emulator, with its event counters and the
+    polling watchdog (tests/simt_emu/emu_stripe.cpp). ("WM_STRIPE_TEST_SLACK=...",) builds the variant whose bookkeeping margin is useless, so that
+    the repeat-in-safe-mode path runs."""
+    emu = os.path.join(ROOT, "tests", "simt_emu")
+    tag = "".join("_" + "".join(ch if ch.isalnum() else "_" for ch in d) for d in defines)
+    out = os.path.join(emu, "libwm_emu_stripe%s.so" % tag)
+    srcs = [os.path.join(emu, f) for f in ("emu_stripe.cpp", "simt.h")] + \
+           [os.path.join(CSRC, f) for f in ("ksw_stripe_kernel.h", "ksw_packed_kernel.h", "ksw_kernel.h", "ksw_plan.h")]
+    with _Lock(out):
+        if _newer(out, srcs):
+            _run_to(out, lambda o: ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wno-unknown-pragmas"] +
+                    ["-D" + d for d in defines] + ["-I" + emu, "-I" + CSRC, "-o", o, os.path.join(emu, "emu_stripe.cpp")])
+    return out
+
+
 def build_harness():
     """tests/host_harness/libwm_harness.so: the product HOST mapper driven by oracle-backed device ops (tests only)."""
     hd = os.path.join(ROOT, "tests", "host_harness")
@@ -122,4 +138,5 @@ if __name__ == "__main__":
     build_gpu(force="--force" in sys.argv, verbose=True)
     build_oracle()
     build_emu()
+    build_emu_stripe()
     build_harness()

@@ -284,6 +284,7 @@ static void append_cigar(Reg &r, const std::vector<uint32_t> &c)
 
 static int test_zdrop(const MapOpt &opt, const uint8_t *qseq, const uint8_t *tseq, const std::vector<uint32_t> &cigar, const int8_t *mat)
 {   // mm_test_zdrop + update_max_zdrop, src/align.c:32-89
+	WM_PROF("align.test_zdrop");
 	int32_t score = 0, max = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
 	int pos[2][2] = {{-1, -1}, {-1, -1}};
 	auto upd = [&](int32_t sc, int ii, int jj) {

@@ -23,7 +23,7 @@ struct MapStats {
 // Maps reads[i] → out[i] (out is resized). The caller chooses the batch (the reference uses ≤ 1 Gbase mini-batches).
 // n_threads > 1: the host glue of the reads runs on that many threads (a SchedTeam); device batches span the whole team.
 // on_read_done (optional): called by the worker that finishes read i (out[i] is final) — e.g. to format its records while the others are still mapped.
-// slot (0 or 1): two calls with different slots may run concurrently on one DeviceOps (DeviceOps::load_reads).
+// slot (0 .. WM_MAX_SLOTS - 1): calls with different slots may run concurrently on one DeviceOps (DeviceOps::load_reads).
 void map_batch(const Index &idx, const MapOpt &opt, DeviceOps *ops, const std::vector<ReadIn> &reads, std::vector<ReadOut> &out, MapStats *stats = 0, int n_threads = 1,
                const std::function<void(size_t)> *on_read_done = 0, int slot = 0);
 

@@ -26,6 +26,13 @@ template <class T> struct Slot {
 };
 }
 
+int default_lanes()
+{
+	const char *le = getenv("WM_MAP_LANES");                                 // mini-batches in flight per mapper: 1 .. 4, default 2
+	const int n = le ? atoi(le) : 2;
+	return n < 1 ? 1 : n > 4 ? 4 : n;
+}
+
 int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_qual, const MapFn &map_fn, FILE *out, FileStats *st, std::string &err, int n_lanes_arg)
 {
 	return map_file_id(reads_path, mini_batch_bases, with_qual, [&](std::vector<ReadIn> &b, std::string &t, int lane, uint64_t) { return map_fn(b, t, lane); }, out, st, err, n_lanes_arg);
@@ -46,8 +53,7 @@ int map_file_id(const std::string &reads_path, int64_t mini_batch_bases, bool wi
 	// finished mini-batches wait here for their turn: the file lists them in input order
 	std::mutex omu; std::condition_variable ocv;
 	std::map<uint64_t, std::unique_ptr<std::string>> done;
-	const char *le = getenv("WM_MAP_LANES");
-	const int n_lanes = n_lanes_arg > 0 ? n_lanes_arg : le && atoi(le) == 1 ? 1 : 2;
+	const int n_lanes = n_lanes_arg > 0 ? n_lanes_arg : default_lanes();
 	uint64_t next_out = 0; int lanes_running = n_lanes;                 // (set BEFORE the writer starts: it leaves when no lane is running and nothing is queued)
 	std::thread reader([&]() {
 		uint64_t id = 0;

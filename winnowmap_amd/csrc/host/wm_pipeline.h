@@ -28,8 +28,9 @@ struct FileStats { uint64_t n_reads = 0, n_bases = 0, n_batches = 0; double t_re
 // one): a mapping call ramps up and drains its pipeline of dependent device calls over several hundred milliseconds, which the other lane's
 // steady state covers. Records are written in input order whatever lane finishes first.
 typedef std::function<int(std::vector<ReadIn> &batch, std::string &text, int lane)> MapFn;
-// n_lanes: mini-batches mapped at a time (threads calling map_fn concurrently with lane = 0 .. n_lanes - 1); 0 = the default above (2, WM_MAP_LANES=1: 1).
+// n_lanes: mini-batches mapped at a time (threads calling map_fn concurrently with lane = 0 .. n_lanes - 1); 0 = default_lanes().
 // A caller that owns several devices passes two lanes per device (wm_map_file_multi).
+int default_lanes();        // WM_MAP_LANES (1 .. 4), default 2
 int map_file(const std::string &reads_path, int64_t mini_batch_bases, bool with_qual, const MapFn &map_fn, FILE *out, FileStats *st, std::string &err, int n_lanes = 0);
 // the same with the ordinal of the mini-batch (0, 1, …: the same reads file read again yields the same mini-batches in the same order)
 typedef std::function<int(std::vector<ReadIn> &batch, std::string &text, int lane, uint64_t batch_id)> MapFnId;

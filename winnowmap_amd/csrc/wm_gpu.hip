@@ -2621,26 +2621,26 @@ struct GpuOps {                          // the device contexts of a mapper, sha
 	void init(const std::vector<wm_ctx_t*> &cs) { ctxs.resize(cs.size()); for (size_t i = 0; i < cs.size(); ++i) { ctxs[i].c = cs[i]; free_.push_back((int)i); } }
 	int max_inflight() const { return (int)ctxs.size(); }
 	bool waits_asleep() const { return getenv("WM_SPIN_SYNC") == 0; }
-	// The read codes of a mini-batch go to the device once. Two mini-batches can be in flight (two concurrent mapping calls, slots 0 and 1): one
-	// allocation of two slabs, owned by the first context and aliased by the others (one device); a call's offsets start at slot * slab.
+	// The read codes of a mini-batch go to the device once. Up to WM_MAX_SLOTS mini-batches can be in flight (concurrent mapping calls, one slot each): one
+	// allocation of WM_MAX_SLOTS slabs, owned by the first context and aliased by the others (one device); a call's offsets start at slot * slab.
 	std::mutex reads_mu;
 	size_t slab = 0;
-	bool slot_busy[2] = { false, false };
+	bool slot_busy[WM_MAX_SLOTS] = { false };
 	bool load_reads(const uint8_t *codes, size_t n, int slot, int64_t *base, std::string &err)
 	{
 		*base = 0;
 		const bool off = getenv("WM_NO_RESIDENT") != 0;            // A/B switch: per-request staging as before
-		if (off || ctxs.empty() || slot < 0 || slot > 1) return false;
+		if (off || ctxs.empty() || slot < 0 || slot >= WM_MAX_SLOTS) return false;
 		wm_ctx_t *c0 = ctxs[0].c;
 		std::lock_guard<std::mutex> lk(reads_mu);
 		if (hipSetDevice(c0->device) != hipSuccess) return false;
 		if (n + 64 > slab || !c0->d_reads || !c0->owns_reads) {
-			if (slot_busy[1 - slot]) return false;                  // the other mini-batch lives in the allocation: this one is served from its host views
+			for (int o = 0; o < WM_MAX_SLOTS; ++o) if (o != slot && slot_busy[o]) return false;      // another mini-batch lives in the allocation: this one is served from its host views
 			if (c0->d_reads && c0->owns_reads) hipFree(c0->d_reads);
 			c0->d_reads = 0; c0->owns_reads = false; slab = 0;
 			const size_t want = (n + n / 8 + (1 << 20) + 255) & ~(size_t)255;
-			if (hipMalloc((void**)&c0->d_reads, 2 * want) != hipSuccess) { (void)hipGetLastError(); c0->d_reads = 0; return false; }
-			c0->owns_reads = true; c0->reads_cap = 2 * want; c0->reads_bytes = 2 * want; slab = want;
+			if (hipMalloc((void**)&c0->d_reads, WM_MAX_SLOTS * want) != hipSuccess) { (void)hipGetLastError(); c0->d_reads = 0; return false; }
+			c0->owns_reads = true; c0->reads_cap = WM_MAX_SLOTS * want; c0->reads_bytes = WM_MAX_SLOTS * want; slab = want;
 			for (size_t i = 1; i < ctxs.size(); ++i) {
 				wm_ctx_t *c = ctxs[i].c;
 				if (c->owns_reads && c->d_reads) hipFree(c->d_reads);
@@ -2653,7 +2653,7 @@ struct GpuOps {                          // the device contexts of a mapper, sha
 		*base = (int64_t)((size_t)slot * slab);
 		return true;
 	}
-	void release_reads(int slot) { std::lock_guard<std::mutex> lk(reads_mu); if (slot >= 0 && slot <= 1) slot_busy[slot] = false; }
+	void release_reads(int slot) { std::lock_guard<std::mutex> lk(reads_mu); if (slot >= 0 && slot < WM_MAX_SLOTS) slot_busy[slot] = false; }
 	// One batched call on a free context. A context belongs to exactly one call while it is out of the free list, so whatever the call leaves in
 	// the context's `error` is ITS error: it moves into the sink of the mapping call that issued the batch before the context is handed back
 	// (two mapping calls share the contexts, wm_map_reads_slot). A mapping call that has failed issues nothing more.
@@ -2719,7 +2719,7 @@ struct wm_mapper_s {
 	int n_threads = 1;
 	wm::IdxOpt io; wm::MapOpt mo;
 	// results of the last mapping call per slot (wm_map_reads = slot 0; wm_map_reads_slot: two calls may run concurrently)
-	struct Result { std::string text; std::vector<int32_t> hits; std::vector<uint32_t> cigars; std::vector<int64_t> first; } res[2];
+	struct Result { std::string text; std::vector<int32_t> hits; std::vector<uint32_t> cigars; std::vector<int64_t> first; } res[WM_MAX_SLOTS];
 	uint64_t stats[9];
 	double host_stats[24] = {0};
 	std::mutex stats_mu;
@@ -2807,7 +2807,13 @@ extern "C" int wm_mapper_create_opt(wm_ctx_t *c, const wm_index_t *idx, const wm
 }
 extern "C" int wm_mapper_set_sam_header(wm_mapper_t *m, int on) { if (!m) return set_err(WM_EINVAL, "null mapper"); m->sam_header = on != 0; return WM_OK; }
 
-extern "C" void wm_mapper_destroy(wm_mapper_t *m) { if (m) { for (wm_ctx_t *w : m->workers) wm_ctx_destroy(w); delete m; } }
+extern "C" void wm_mapper_destroy(wm_mapper_t *m)
+{
+	if (!m) return;
+	if (wm::prof_on()) wm::prof_report(stderr);                // WM_PROF=1: the host glue's time per named region (accumulated over the process)
+	for (wm_ctx_t *w : m->workers) wm_ctx_destroy(w);
+	delete m;
+}
 
 // Host parallelism: n_threads worker threads run the host glue of the reads (fibers, wm_fiber.h) and take turns issuing the batched
 // device calls; C device contexts (own HIP stream + arena + pinned slab each; WM_CONTEXTS, default 4) let C batches be in flight at once.
@@ -2874,7 +2880,7 @@ extern "C" int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, con
 extern "C" int wm_map_reads_slot(wm_mapper_t *m, int slot, int n, const char *const *names, const char *const *seqs, const int32_t *lens,
                                  const char **text, size_t *text_len, const int32_t **hits, const uint32_t **cigars, const int64_t **hit_first)
 {
-	if (!m || slot < 0 || slot > 1) return set_err(WM_EINVAL, "slot must be 0 or 1");
+	if (!m || slot < 0 || slot >= WM_MAX_SLOTS) return set_err(WM_EINVAL, "slot must be 0 .. WM_MAX_SLOTS - 1");
 	const double tm0 = now_ms();
 	std::vector<wm::ReadIn> reads(n);
 	wm::parallel_for(m->n_threads, (size_t)n, [&](size_t i) { reads[i].name = names[i]; reads[i].seq.assign(seqs[i], lens[i]); });
@@ -3010,7 +3016,7 @@ extern "C" int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *o
 	const bool with_qual = (m->mo.flag & 0x8) != 0;                    // SAM output prints QUAL
 	LaneError le;
 	const int rc = wm::map_file(reads_path, mini_batch_bases, with_qual, [&](std::vector<wm::ReadIn> &batch, std::string &text, int lane) {
-		const int r = map_reads_impl(m, batch, now_ms(), lane);             // (two mini-batches in flight: lane = result slot = slab of resident read codes)
+		const int r = map_reads_impl(m, batch, now_ms(), lane);             // (WM_MAP_LANES mini-batches in flight, default 2: lane = result slot = slab of resident read codes)
 		if (r == 0) text.swap(m->res[lane].text);
 		else le.keep(r);
 		return r;
@@ -3023,7 +3029,7 @@ extern "C" int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *o
 
 // The file loop over N mappers — one per GPU of the node (each with its own context, index copy and host threads: wm_ctx_create(device i),
 // wm_index_upload_peer, wm_mapper_create, wm_mapper_set_threads) — inside ONE process: the C twin of `one rank per GPU`. The reader hands mini-batches
-// to 2 lanes per mapper (lane l -> mapper l % n, result slot l / n), reads shard by mini-batch, nothing is exchanged between the devices, and the
+// to WM_MAP_LANES (default 2) lanes per mapper (lane l -> mapper l % n, result slot l / n), reads shard by mini-batch, nothing is exchanged between the devices, and the
 // ordered writer puts the records back into input order: the output file equals wm_map_file's (and the reference's). The SAM header, if wanted, is
 // written once from the first mapper's index and command line.
 extern "C" int wm_map_file_multi(wm_mapper_t *const *ms, int n, const char *reads_path, const char *out_path, int64_t mini_batch_bases, double *stats)
@@ -3056,7 +3062,7 @@ extern "C" int wm_map_file_multi(wm_mapper_t *const *ms, int n, const char *read
 		if (r == 0) text.swap(m->res[slot].text);
 		else le.keep(r);
 		return r;
-	}, out, &fs, err, 2 * n);
+	}, out, &fs, err, wm::default_lanes() * n);
 	if (out != stdout) fclose(out);
 	if (stats) { stats[0] = (double)fs.n_reads; stats[1] = (double)fs.n_bases; stats[2] = (double)fs.n_batches; stats[3] = fs.t_read; stats[4] = fs.t_map; stats[5] = fs.t_write; }
 	if (rc) return le.code ? set_err(le.code, "%s", le.msg.c_str()) : set_err(WM_EINVAL, "%s", err.c_str());

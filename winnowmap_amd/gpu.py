@@ -417,7 +417,7 @@ class Mapper:
         """names: list of str/bytes; seqs: list of bytes (ASCII) — or names = the tuple Mapper.marshal() returned. Returns
         (text, hits[n_hits,16], cigars, first[n+1]).
         copy_text=False returns the text LENGTH instead of a Python copy of the records (they stay in the library's buffer).
-        slot (0 or 1): calls on different slots may run concurrently from two threads (wm_map_reads_slot; ctypes releases the GIL)."""
+        slot (0 .. WM_MAX_SLOTS - 1 = 3): calls on different slots may run concurrently from different threads (wm_map_reads_slot; ctypes releases the GIL)."""
         L = lib()
         n, nm, sq, lens, _keep = names if seqs is None else Mapper.marshal(names, seqs)
         text, tlen = C.c_char_p(), C.c_size_t()
