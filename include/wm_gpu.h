@@ -101,6 +101,15 @@ typedef struct {
 int wm_reads_upload(wm_ctx_t *ctx, const uint8_t *codes, size_t n);
 int wm_ksw_batch_pos(wm_ctx_t *ctx, const wm_ksw_score_t *sc, int n_jobs, const wm_ksw_pos_t *jobs,
                      wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used);
+/* The same call, which also runs the scan of mm_test_zdrop + update_max_zdrop (src/align.c:32-66) on the device over the finished alignment of every
+ * job whose flag carries WM_KSW_F_ZDWALK (the gap fills, src/align.c:736; forward jobs only): zd[i] = the largest z-drop along the CIGAR
+ * (max - score - |di - dj| * e with the caller's q / e) and the target / query span between its maximum and its end — pos[0][0..1], pos[1][0..1] of
+ * src/align.c:51; {0, -1, -1, -1, -1} for the other jobs. What is left for the host of mm_test_zdrop is the verdict (the inversion test by ksw_ll_i16 on
+ * the few alignments whose drop exceeds zdrop_inv, src/align.c:68-89). The walk is one function for the host and the device: csrc/cigar_walk.h. */
+#define WM_KSW_F_ZDWALK 0x10000
+typedef struct { int32_t max_zdrop, t0, t1, q0, q1; } wm_zd_t;
+int wm_ksw_batch_pos_zd(wm_ctx_t *ctx, const wm_ksw_score_t *sc, int n_jobs, const wm_ksw_pos_t *jobs,
+                        wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used, wm_zd_t *zd);
 
 /* ksw_ll_qinit + ksw_ll_i16 (src/ksw2.h:82-83, src/ksw2_ll_sse.c:32-147): local alignment SCORE of query vs target with affine gaps
  * (16-bit striped lanes in the reference; ties and the striped layout's end coordinates are reproduced: *qe may be as low as -7 … see

@@ -432,4 +432,11 @@ int h_map_file_split(const char *fasta, const char *kmer_file, int k, int w, int
 	return n_parts;
 }
 
+// the host's compile of the CIGAR walks the device also runs (winnowmap_amd/csrc/cigar_walk.h)
+void h_zdrop_walk(const uint8_t *q, const uint8_t *t, const uint32_t *cigar, int n_cigar, int match, int mismatch, int ambi, int gq, int ge, int32_t *out5)
+{
+	wm_zd_t z;
+	wm_zdrop_walk(q, t, cigar, n_cigar, match, mismatch, ambi, gq, ge, &z);
+	out5[0] = z.max_zdrop; out5[1] = z.t0; out5[2] = z.t1; out5[3] = z.q0; out5[4] = z.q1;
+}
 } // extern "C"

@@ -220,6 +220,33 @@ def test_position_jobs_equal_byte_jobs(tmp_path):
     for k in r0.dtype.names:
         assert np.array_equal(r0[k], r1[k]), k
     assert np.array_equal(p0, p1)
+    # the z-drop scan of mm_test_zdrop (src/align.c:32-66) on the device over the finished CIGARs (wm_ksw_batch_pos_zd, ksw_zdwalk_kernel) against the
+    # host's compile of the same walk (csrc/cigar_walk.h through tests/host_harness; the host's verdicts are pinned to the reference by
+    # tests/test_host_diff_fuzz.py): flagged forward jobs carry their scan, everything else the neutral value; alignments and CIGARs are unchanged
+    import ctypes as C
+    from winnowmap_amd import build
+    H = C.CDLL(build.build_harness())
+    H.h_zdrop_walk.argtypes = [W.u8p, W.u8p, W.u32p, C.c_int] + [C.c_int] * 5 + [W.i32p]
+    posz = pos.copy()
+    fwd = (pos["step"] == 1) & ((pos["flag"] & 0x80) == 0)
+    want = fwd & (np.arange(n) % 5 != 0)
+    posz["flag"] = np.where(want, pos["flag"] | gpu.KSW_F_ZDWALK, pos["flag"])
+    r2, p2, zd = c.ksw_batch_pos_zd(sc, posz)
+    for k in r0.dtype.names:
+        assert np.array_equal(r0[k], r2[k]), k
+    assert np.array_equal(p0, p2)
+    n_drop = 0
+    for i in range(n):
+        if not want[i]:
+            assert list(zd[i]) == [0, -1, -1, -1, -1], i
+            continue
+        q, t, _ = pairs[i]
+        cig = np.ascontiguousarray(p2[r2["cig_off"][i]:r2["cig_off"][i] + r2["n_cigar"][i]])
+        exp = np.zeros(5, np.int32)
+        H.h_zdrop_walk(np.ascontiguousarray(q), np.ascontiguousarray(t), cig if len(cig) else np.zeros(1, np.uint32), len(cig), 2, -4, -1, 4, 2, exp)
+        assert list(zd[i]) == list(exp), (i, list(zd[i]), list(exp))
+        n_drop += int(exp[0] > 0)
+    assert int(want.sum()) > 100 and n_drop > 50, (int(want.sum()), n_drop)
     # positions outside the resident data are refused, not read
     bad = pos[:1].copy()
     bad["t_pos"] = 59990; bad["tlen"] = 100; bad["step"] = 1

@@ -33,3 +33,5 @@ for f in sorted(glob.glob(os.path.join(out, "bench_*.json"))):
     except Exception as e:
         print(f, "unreadable:", e)
 PY
+# host glue per named region (WM_PROF=1)
+( WM_PROF=1 WM_BENCH_FILE=0 WM_BENCH_CPU_SAMPLE=0 timeout 150 python bench.py --steps 4 --warmup 2 --reads-per-step 16384 > $OUT/bench_prof.json 2> $OUT/bench_prof.log ); grep "\[prof\]" $OUT/bench_prof.log | sort -k3 -n -r | head -30

@@ -1,5 +1,6 @@
 // wm_align.cpp — see wm_align.h.
 #include "wm_align.h"
+#include "../cigar_walk.h"
 #include <math.h>
 #include <algorithm>
 #include <list>
@@ -259,20 +260,6 @@ static void fix_bad_ends_splice(const MapOpt &opt, const Index &mi, const Reg &r
 	}
 }
 
-static inline uint32_t match_run(const uint8_t *t, const uint8_t *q, uint32_t n)
-{
-	uint32_t l = 0;
-	while (l + 8 <= n) {
-		uint64_t a, b;
-		memcpy(&a, t + l, 8); memcpy(&b, q + l, 8);
-		const uint64_t bad = (a ^ b) | (a & 0xFCFCFCFCFCFCFCFCULL);
-		if (bad) return l + (uint32_t)(__builtin_ctzll(bad) >> 3);
-		l += 8;
-	}
-	while (l < n && t[l] == q[l] && t[l] < 4) ++l;
-	return l;
-}
-
 static void append_cigar(Reg &r, const std::vector<uint32_t> &c)
 {   // mm_append_cigar, src/align.c:288-311
 	if (c.empty()) return;
@@ -282,50 +269,29 @@ static void append_cigar(Reg &r, const std::vector<uint32_t> &c)
 	r.cigar.insert(r.cigar.end(), c.begin() + from, c.end());
 }
 
+static bool zdwalk_on_host() { static const bool h = getenv("WM_ZDWALK_HOST") != 0; return h; }      // A/B switch: the host walks the fills' CIGARs as before
+
+// the verdict of mm_test_zdrop (src/align.c:68-89) given the scan's result (wm_zdrop_walk, cigar_walk.h — run by the device over the CIGAR pool of the
+// ksw call, or here): 2 = a candidate inversion (the local alignment of the reverse-complemented query stretch scores high enough), 1 = z-drop
+static int zdrop_verdict(const MapOpt &opt, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, const wm_zd_t &z)
+{
+	const int q_len = z.q1 - z.q0, t_len = z.t1 - z.t0;
+	if (!(opt.flag & (F_SPLICE | F_SR | F_FOR_ONLY | F_REV_ONLY)) && z.max_zdrop > opt.zdrop_inv && q_len < opt.max_gap && t_len < opt.max_gap) {
+		std::vector<uint8_t> q2(q_len > 0 ? q_len : 0);
+		for (int x = 0; x < q_len; ++x) { const int c = qseq[z.q1 - x - 1]; q2[x] = c >= 4 ? 4 : 3 - c; }
+		int q_off, t_off;
+		const int sc = ll_i16(q_len, q2.data(), t_len, tseq + z.t0, mat, opt.q, opt.e, &q_off, &t_off);
+		if (sc >= opt.min_chain_score * opt.a && sc >= opt.min_dp_max) return 2;
+	}
+	return z.max_zdrop > opt.zdrop ? 1 : 0;
+}
+
 static int test_zdrop(const MapOpt &opt, const uint8_t *qseq, const uint8_t *tseq, const std::vector<uint32_t> &cigar, const int8_t *mat)
 {   // mm_test_zdrop + update_max_zdrop, src/align.c:32-89
 	WM_PROF("align.test_zdrop");
-	int32_t score = 0, max = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
-	int pos[2][2] = {{-1, -1}, {-1, -1}};
-	auto upd = [&](int32_t sc, int ii, int jj) {
-		if (sc < max) {
-			const int li = ii - max_i, lj = jj - max_j, diff = li > lj ? li - lj : lj - li;
-			const int z = max - sc - diff * opt.e;
-			if (z > max_zdrop) { max_zdrop = z; pos[0][0] = max_i; pos[0][1] = ii; pos[1][0] = max_j; pos[1][1] = jj; }
-		} else max = sc, max_i = ii, max_j = jj;
-	};
-	for (uint32_t c : cigar) {
-		const uint32_t op = c & 0xf, len = c >> 4;
-		if (op == 0) {
-			// (a run of matches only raises the score: inside a dip the drop z = max - score - diff * e shrinks, so nothing can be recorded
-			// there, and above the old maximum the last base of the run is where max_i / max_j end up — one update per run is exact)
-			const int match_sc = mat[0];
-			for (uint32_t l = 0; l < len;) {
-				const uint32_t run = match_sc > 0 ? match_run(tseq + i + l, qseq + j + l, len - l) : 0;
-				if (run) {
-					score += (int32_t)run * match_sc; l += run;
-					if (score >= max) max = score, max_i = i + (int)l - 1, max_j = j + (int)l - 1;
-					continue;
-				}
-				score += mat[tseq[i + l] * 5 + qseq[j + l]]; upd(score, i + l, j + l);
-				++l;
-			}
-			i += len, j += len;
-		} else if (op == 1 || op == 2 || op == 3) {
-			score -= opt.q + opt.e * len;
-			if (op == 1) j += len; else i += len;
-			upd(score, i, j);
-		}
-	}
-	const int q_len = pos[1][1] - pos[1][0], t_len = pos[0][1] - pos[0][0];
-	if (!(opt.flag & (F_SPLICE | F_SR | F_FOR_ONLY | F_REV_ONLY)) && max_zdrop > opt.zdrop_inv && q_len < opt.max_gap && t_len < opt.max_gap) {
-		std::vector<uint8_t> q2(q_len > 0 ? q_len : 0);
-		for (int x = 0; x < q_len; ++x) { const int c = qseq[pos[1][1] - x - 1]; q2[x] = c >= 4 ? 4 : 3 - c; }
-		int q_off, t_off;
-		const int sc = ll_i16(q_len, q2.data(), t_len, tseq + pos[0][0], mat, opt.q, opt.e, &q_off, &t_off);
-		if (sc >= opt.min_chain_score * opt.a && sc >= opt.min_dp_max) return 2;
-	}
-	return max_zdrop > opt.zdrop ? 1 : 0;
+	wm_zd_t z;
+	wm_zdrop_walk(qseq, tseq, cigar.data(), (int)cigar.size(), mat[0], mat[1], mat[24], opt.q, opt.e, &z);
+	return zdrop_verdict(opt, qseq, tseq, mat, z);
 }
 
 static void fix_cigar(Reg &r, const uint8_t *qseq, const uint8_t *tseq, int *qshift, int *tshift)
@@ -392,42 +358,10 @@ static void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const
 	int qshift, tshift;
 	fix_cigar(r, qseq, tseq, &qshift, &tshift);
 	qseq += qshift, tseq += tshift;
-	int32_t s = 0, max = 0, toff = 0, qoff = 0;
-	r.blen = r.mlen = 0;
-	for (uint32_t c : r.cigar) {
-		const uint32_t op = c & 0xf, len = c >> 4;
-		if (op == 0) {
-			int n_ambi = 0, n_diff = 0;
-			const int match_sc = mat[0];
-			for (uint32_t l = 0; l < len;) {
-				const uint32_t run = match_sc > 0 ? match_run(tseq + toff + l, qseq + qoff + l, len - l) : 0;
-				if (run) { s += (int32_t)run * match_sc; max = max > s ? max : s; l += run; continue; }   // (s only grows along the run)
-				const int cq = qseq[qoff + l], ct = tseq[toff + l];
-				if (ct > 3 || cq > 3) ++n_ambi;
-				else if (ct != cq) ++n_diff;
-				s += mat[ct * 5 + cq];
-				if (s < 0) s = 0; else max = max > s ? max : s;
-				++l;
-			}
-			r.blen += len - n_ambi, r.mlen += len - (n_ambi + n_diff), r.n_ambi += n_ambi;
-			toff += len, qoff += len;
-		} else if (op == 1) {
-			int n_ambi = 0;
-			for (uint32_t l = 0; l < len; ++l) if (qseq[qoff + l] > 3) ++n_ambi;
-			r.blen += len - n_ambi, r.n_ambi += n_ambi;
-			s -= q + e * len;
-			if (s < 0) s = 0;
-			qoff += len;
-		} else if (op == 2) {
-			int n_ambi = 0;
-			for (uint32_t l = 0; l < len; ++l) if (tseq[toff + l] > 3) ++n_ambi;
-			r.blen += len - n_ambi, r.n_ambi += n_ambi;
-			s -= q + e * len;
-			if (s < 0) s = 0;
-			toff += len;
-		} else if (op == 3) toff += len;
-	}
-	r.dp_max = max;
+	wm_extra_t x;
+	wm_extra_walk(qseq, tseq, r.cigar.data(), (int)r.cigar.size(), mat[0], mat[1], mat[24], q, e, &x);
+	r.blen = x.blen; r.mlen = x.mlen; r.n_ambi += x.n_ambi; r.dp_max = x.dp_max;
+	const int32_t qoff = x.qoff, toff = x.toff; (void)qoff; (void)toff;
 	WM_INVARIANT(qoff == r.qe - r.qs && toff == r.re - r.rs);
 }
 
@@ -566,6 +500,7 @@ static void plan_reg(const AlnEnv &E, RegAln &A, m128 *a, std::vector<KswReq> &j
 			if (a[as1 + i].y & SEED_LONG_JOIN) f.bw1 = qe - qs > re - rs ? qe - qs : re - rs;
 			KswReq j = make_job(E, A.rev, qs, qe, rid, rs, re, tb, rs0, A.t_has_n, false);
 			j.w = f.bw1; j.end_bonus = -1; j.zdrop = opt.zdrop; j.flag = extra_flag | EZ_APPROX_MAX;
+			j.want_zd = !zdwalk_on_host();                                // judge_reg tests this alignment's z-drop (src/align.c:736)
 			attach_junc(E, j, rid, rs, re, false);
 			f.job = (int)jobs.size(); jobs.push_back(std::move(j));
 			A.fills.push_back(f);
@@ -590,11 +525,12 @@ static void judge_reg(const AlnEnv &E, RegAln &A, const std::vector<KswReq> &job
 	for (size_t k = 0; k < A.fills.size(); ++k) {
 		Fill &f = A.fills[k];
 		const KswReq &j = jobs[f.job];
-		const int code = test_zdrop(*E.opt, j.qp, j.tp, j.cigar, E.mat);      // (fills are never reversed)
+		// (fills are never reversed) the scan comes back with the alignment when the device ran it (ksw_zdwalk_kernel), else the host walks the CIGAR
+		const int code = j.has_zd ? zdrop_verdict(*E.opt, j.qp, j.tp, E.mat, j.zd) : test_zdrop(*E.opt, j.qp, j.tp, j.cigar, E.mat);
 		A.redo_code[k] = code;
 		if (code != 0) {
 			KswReq d = j;                                                      // same operands, exact maximum this time
-			d.cigar.clear(); d.w = f.bw1; d.end_bonus = -1; d.zdrop = code == 2 ? E.opt->zdrop_inv : E.opt->zdrop; d.flag = j.flag & ~EZ_APPROX_MAX;      // (keeps the splice bits)
+			d.cigar.clear(); d.want_zd = d.has_zd = false; d.w = f.bw1; d.end_bonus = -1; d.zdrop = code == 2 ? E.opt->zdrop_inv : E.opt->zdrop; d.flag = j.flag & ~EZ_APPROX_MAX;      // (keeps the splice bits)
 			f.redo_job = (int)redo.size(); redo.push_back(std::move(d));
 		}
 	}

@@ -4,6 +4,7 @@
 // nothing in the product constructs anything but GpuOps.
 #pragma once
 #include "wm_core.h"
+#include "../cigar_walk.h"
 
 namespace wm {
 
@@ -63,6 +64,10 @@ struct KswReq {                    // ksw_extd2_sse (src/ksw2.h:60)
 	// splice mode with a junction annotation (--junc-bed): the bits of mm_idx_bed_junc (src/index.c:768-803) for the target range, in the
 	// order the target is presented (reversed for the left extension, src/align.c:693-696); empty = no annotation
 	std::vector<uint8_t> junc;
+	// want_zd: the mapper will judge this alignment's z-drop (mm_test_zdrop, src/align.c:32-89) — a device implementation may return the scan with the
+	// alignment (has_zd + zd, see cigar_walk.h); without it the host walks the CIGAR itself
+	bool want_zd = false, has_zd = false;
+	wm_zd_t zd = { 0, -1, -1, -1, -1 };
 	wm_ksw_result_t ez = {};       // out
 	std::vector<uint32_t> cigar;   // out
 	int qlen() const { return ql; }

@@ -49,6 +49,7 @@ static inline double now_ms() { return std::chrono::duration<double, std::milli>
 #include "ksw_stripe_kernel.h"
 #include "ksw_exts2_kernel.h"
 #include "ksw_plan.h"
+#include "cigar_walk.h"
 #include "sketch_kernel.h"
 #include "seedchain_kernel.h"
 #include "window_kernel.h"
@@ -262,6 +263,22 @@ __global__ __launch_bounds__(64) void ksw_gather_kernel(const wm_ksw_djob_t *__r
 	}
 }
 
+// mm_test_zdrop's scan (src/align.c:32-66) over the finished alignments of the jobs that ask for it (WM_KSW_F_ZDWALK: the gap fills, whose z-drop the
+// mapper judges after every first pass, src/align.c:736): one thread per job walks the job's ops in the dense pool and its operands in the batch's
+// slab — the same function body the host compiles (cigar_walk.h). sc: the scores as the CALLER gave them (q, e not swapped).
+__global__ __launch_bounds__(64) void ksw_zdwalk_kernel(int n, wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const wm_ksw_dres_t *__restrict__ res,
+                                                         const uint32_t *__restrict__ off, const uint32_t *__restrict__ pool, const uint8_t *__restrict__ seqs,
+                                                         wm_zd_t *__restrict__ zd)
+{
+	WM_SETPRIO(3);
+	const int j = blockIdx.x * 64 + threadIdx.x;
+	if (j >= n) return;
+	wm_zd_t z = { 0, -1, -1, -1, -1 };
+	if ((jobs[j].flag & WM_KSW_F_ZDWALK) && !(jobs[j].flag & KSW_F_REV_CIGAR))
+		wm_zdrop_walk(seqs + jobs[j].q_off, seqs + jobs[j].t_off, pool + off[j], res[j].n_cigar, sc.match, sc.mismatch, sc.sc_ambi, sc.q, sc.e, &z);
+	zd[j] = z;
+}
+
 // ======================================================================================================
 // host
 // ======================================================================================================
@@ -330,7 +347,8 @@ static void pin_release(wm_ctx_s *c, size_t mark) { c->pin_used = mark; }
 
 struct wm_ksw_dev_batch_s {
 	int n_jobs;
-	wm_ksw_score_t sc;
+	wm_ksw_score_t sc, sc_in;                   // sc: the cheaper gap piece first (src/ksw2_extd2_sse.c:70); sc_in: as the caller gave them
+	wm_zd_t *d_zd = 0;                          // z-drop scans of the jobs flagged WM_KSW_F_ZDWALK (0: no job asked)
 	std::vector<wm_ksw_djob_t> jobs;            // host copy
 	std::vector<int> order[WM_KSW_NCLASS];      // job indices per class, largest first
 	std::vector<int> ord;                       // the classes' orders back to back (what the device sees)
@@ -531,7 +549,7 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 	if (pos && !c->d_reads) return set_err(WM_EINVAL, "position jobs need wm_reads_upload on this context");
 	HIPCHK(hipSetDevice(c->device));
 	wm_ksw_dev_batch_t *b = new wm_ksw_dev_batch_t();
-	b->n_jobs = n_jobs; b->sc = sc; b->cells = b->tb_bytes = 0; b->dp_ms = b->bt_ms = 0; b->total_ops = 0; b->h_err = 0;
+	b->n_jobs = n_jobs; b->sc = sc; b->sc_in = *sc_in; b->cells = b->tb_bytes = 0; b->dp_ms = b->bt_ms = 0; b->total_ops = 0; b->h_err = 0;
 	memset(b->class_cells, 0, sizeof(b->class_cells));
 	b->arena_mark = c->arena_used;
 	b->jobs.resize(n_jobs);
@@ -647,6 +665,9 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 	b->d_off = (uint32_t*)arena_take(c, nj * 4 + 64);
 	b->d_total = (uint32_t*)arena_take(c, 64);
 	b->d_err = (int*)arena_take(c, 64);
+	bool any_zd = false;
+	for (int i = 0; i < n_jobs && !any_zd; ++i) any_zd = (b->jobs[i].flag & WM_KSW_F_ZDWALK) != 0;
+	b->d_zd = any_zd ? (wm_zd_t*)arena_take(c, nj * sizeof(wm_zd_t)) : 0;
 	b->d_seqs = (uint8_t*)arena_take(c, slab_bytes + 64);
 	b->slab_bytes = slab_bytes;
 	wm_ksw_dsrc_t *d_src = pos ? (wm_ksw_dsrc_t*)arena_take(c, nj * sizeof(wm_ksw_dsrc_t)) : 0;
@@ -666,7 +687,7 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 		b->d_b3off = (uint64_t*)arena_take(c, b->b3off.size() * 8 + 64);
 		if (!b->d_b3state || !b->d_b3off) b->d_tb = 0;
 	}
-	if (!b->d_jobs || !b->d_order || !b->d_res || !b->d_off || !b->d_total || !b->d_err || !b->d_seqs || (pos && !d_src) || !b->d_cig || !b->d_pool || !b->d_tb) {
+	if (!b->d_jobs || !b->d_order || !b->d_res || !b->d_off || !b->d_total || !b->d_err || !b->d_seqs || (any_zd && !b->d_zd) || (pos && !d_src) || !b->d_cig || !b->d_pool || !b->d_tb) {
 		c->arena_used = b->arena_mark;
 		delete b;
 		return set_err(WM_ENOMEM, "batch needs %.1f MB of traceback + buffers; arena is %.1f MB", (tb_off + cig_off * 8 + slab_bytes) / 1048576.0, c->arena_bytes / 1048576.0);
@@ -893,6 +914,7 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, b->d_jobs, b->d_tb, b->d_res, b->d_cig, b->d_err);
 	hipLaunchKernelGGL(ksw_scan_kernel, dim3(1), dim3(1024), 0, c->stream, n, b->d_res, b->d_off, b->d_total);
 	hipLaunchKernelGGL(ksw_gather_kernel, dim3(n), dim3(64), 0, c->stream, b->d_jobs, b->d_res, b->d_off, b->d_cig, b->d_pool, (uint32_t)b->pool_cap);
+	if (b->d_zd) hipLaunchKernelGGL(ksw_zdwalk_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, b->sc_in, b->d_jobs, b->d_res, b->d_off, b->d_pool, b->d_seqs, b->d_zd);
 	HIPCHK(hipEventRecord(c->ev[2], c->stream));
 	HIPCHK(hipGetLastError());
 	int *h_small = c->pin_small ? c->pin_small : &b->h_err;            // [0] error flag, [1] total ops
@@ -962,8 +984,22 @@ extern "C" void wm_ksw_dev_free(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	delete b;
 }
 
+// the z-drop scans of a run batch (jobs flagged WM_KSW_F_ZDWALK; the others: no drop)
+static int ksw_fetch_zd(wm_ctx_t *c, wm_ksw_dev_batch_t *b, wm_zd_t *out)
+{
+	const int n = b->n_jobs;
+	if (!b->d_zd) { for (int i = 0; i < n; ++i) out[i] = wm_zd_t{ 0, -1, -1, -1, -1 }; return WM_OK; }
+	if (n == 0) return WM_OK;
+	HIPCHK(hipSetDevice(c->device));
+	UBuf<wm_zd_t> z(n, c);
+	HIPCHK(hipMemcpyAsync(z.data(), b->d_zd, (size_t)n * sizeof(wm_zd_t), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(ctx_sync(c));
+	memcpy(out, z.data(), (size_t)n * sizeof(wm_zd_t));
+	return WM_OK;
+}
+
 static int ksw_batch_impl(wm_ctx_t *c, const wm_ksw_score_t *sc, int n_jobs, const wm_ksw_job_t *jobs, const uint8_t *seqs, size_t seqs_bytes, const wm_ksw_pos_t *pos,
-                          wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used)
+                          wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used, wm_zd_t *zd = 0)
 {
 	// process in chunks whose traceback (and operands) fit the arena
 	if (!c) return set_err(WM_EINVAL, "null context");
@@ -990,6 +1026,7 @@ static int ksw_batch_impl(wm_ctx_t *c, const wm_ksw_score_t *sc, int n_jobs, con
 		const double tc = now_ms();
 		size_t u = 0;
 		if (!rc) rc = wm_ksw_dev_fetch(c, b, results + i0, cigar_pool + used, cigar_cap - used, &u);
+		if (!rc && zd) rc = ksw_fetch_zd(c, b, zd + i0);
 		c->acc_cells += b->cells; c->t_prep += tb_ - ta; c->t_run += tc - tb_; c->t_fetch += now_ms() - tc; kms += b->dp_ms + b->bt_ms;
 		wm_ksw_dev_free(c, b);
 		if (rc) { if (cigar_used) *cigar_used = used + u; return rc; }
@@ -1014,6 +1051,13 @@ extern "C" int wm_ksw_batch_pos(wm_ctx_t *c, const wm_ksw_score_t *sc, int n_job
 {
 	if (n_jobs > 0 && !jobs) return set_err(WM_EINVAL, "null jobs");
 	return ksw_batch_impl(c, sc, n_jobs, 0, 0, 0, jobs, results, cigar_pool, cigar_cap, cigar_used);
+}
+
+extern "C" int wm_ksw_batch_pos_zd(wm_ctx_t *c, const wm_ksw_score_t *sc, int n_jobs, const wm_ksw_pos_t *jobs,
+                                   wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used, wm_zd_t *zd)
+{
+	if (n_jobs > 0 && (!jobs || !zd)) return set_err(WM_EINVAL, "null jobs / zd");
+	return ksw_batch_impl(c, sc, n_jobs, 0, 0, 0, jobs, results, cigar_pool, cigar_cap, cigar_used, zd);
 }
 
 extern "C" int wm_ksw_extd2(wm_ctx_t *c, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
@@ -2524,6 +2568,7 @@ struct GpuOpsCtx {
 		for (int i = 0; i < n && all_res; ++i) all_res = reqs[i]->resident();
 		for (int i = 0; i < n; ++i) cap += (size_t)reqs[i]->ql + reqs[i]->tl + 2;
 		std::vector<wm_ksw_result_t> res(n);
+		std::vector<wm_zd_t> zd;
 		UBuf<uint32_t> pool(cap, c);
 		size_t used = 0;
 		c->acc_cells = 0; c->t_prep = c->t_run = c->t_fetch = 0;
@@ -2535,10 +2580,15 @@ struct GpuOpsCtx {
 				const wm::KswReq &r = *reqs[i];
 				wm_ksw_pos_t &j = jobs[i];
 				j.qwin_off = r.qwin_off; j.qwin_len = r.qwin_len; j.q_pos = r.q_pos; j.rid = r.rid; j.t_pos = r.t_pos; j.qlen = r.ql; j.tlen = r.tl;
-				j.w = r.w; j.zdrop = r.zdrop; j.end_bonus = r.end_bonus; j.flag = r.flag; j.step = (int8_t)r.step; j.has_n = r.has_n; memset(j.pad, 0, sizeof(j.pad));
+				j.w = r.w; j.zdrop = r.zdrop; j.end_bonus = r.end_bonus; j.flag = r.flag | (r.want_zd && r.step == 1 ? WM_KSW_F_ZDWALK : 0); j.step = (int8_t)r.step; j.has_n = r.has_n; memset(j.pad, 0, sizeof(j.pad));
 			});
 			t1 = now_ms();
-			if (wm_ksw_batch_pos(c, &sc, n, jobs.data(), res.data(), pool.data(), cap, &used)) { fail("ksw"); return; }
+			bool any_zd = false;
+			for (int i = 0; i < n && !any_zd; ++i) any_zd = reqs[i]->want_zd && reqs[i]->step == 1;
+			if (any_zd) {           // the z-drop scans of the gap fills come back with the alignments (ksw_zdwalk_kernel)
+				zd.resize(n);
+				if (wm_ksw_batch_pos_zd(c, &sc, n, jobs.data(), res.data(), pool.data(), cap, &used, zd.data())) { fail("ksw"); return; }
+			} else if (wm_ksw_batch_pos(c, &sc, n, jobs.data(), res.data(), pool.data(), cap, &used)) { fail("ksw"); return; }
 		} else {                // host views -> one byte slab
 			std::vector<wm_ksw_job_t> jobs(n);
 			size_t tot = 0;
@@ -2562,6 +2612,8 @@ struct GpuOpsCtx {
 		wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
 			reqs[i]->ez = res[i];
 			reqs[i]->cigar.assign(pool.begin() + res[i].cig_off, pool.begin() + res[i].cig_off + res[i].n_cigar);
+			reqs[i]->has_zd = !zd.empty() && reqs[i]->want_zd && reqs[i]->step == 1;
+			if (reqs[i]->has_zd) reqs[i]->zd = zd[i];
 		});
 		t_pack += t1 - t0; t_unpack += now_ms() - t2; t_prep += c->t_prep; t_run += c->t_run; t_fetch += c->t_fetch;
 	}

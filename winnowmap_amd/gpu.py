@@ -23,6 +23,7 @@ KSW_RES_DTYPE = np.dtype([("max", np.int32), ("zdropped", np.int32), ("max_q", n
                           ("mqe", np.int32), ("mqe_t", np.int32), ("mte", np.int32), ("mte_q", np.int32),
                           ("score", np.int32), ("reach_end", np.int32), ("n_cigar", np.int32), ("cig_off", np.uint32)])
 
+KSW_F_ZDWALK = 0x10000        # wm_ksw_batch_pos_zd: run the z-drop scan on this job's alignment
 KSW_POS_DTYPE = np.dtype([("qwin_off", np.int64), ("qwin_len", np.int32), ("q_pos", np.int32), ("rid", np.int32), ("t_pos", np.int32),
                           ("qlen", np.int32), ("tlen", np.int32), ("w", np.int32), ("zdrop", np.int32), ("end_bonus", np.int32), ("flag", np.int32),
                           ("step", np.int8), ("has_n", np.int8), ("pad", np.int8, (6,))])      # wm_ksw_pos_t
@@ -121,6 +122,19 @@ class Context:
         lib().wm_ksw_batch_pos.argtypes = [C.c_void_p, C.POINTER(KswScore), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _chk(lib().wm_ksw_batch_pos(self._h, C.byref(score), len(jobs), jobs.ctypes.data, res.ctypes.data, pool.ctypes.data, cap, C.byref(used)))
         return res, pool[:used.value]
+
+    def ksw_batch_pos_zd(self, score, jobs):
+        """wm_ksw_batch_pos_zd: as ksw_batch_pos, plus the z-drop scan (mm_test_zdrop's walk, src/align.c:32-66) of every job whose flag carries
+        KSW_F_ZDWALK, run on the device over the finished CIGARs -> (results, pool, zd[n, 5] = max_zdrop, t0, t1, q0, q1)"""
+        jobs = np.ascontiguousarray(jobs, KSW_POS_DTYPE)
+        res = np.zeros(len(jobs), KSW_RES_DTYPE)
+        cap = int((np.maximum(jobs["qlen"], 0).astype(np.int64) + np.maximum(jobs["tlen"], 0) + 2).sum()) + 16
+        pool = np.zeros(cap, np.uint32)
+        zd = np.zeros((len(jobs), 5), np.int32)
+        used = C.c_size_t(0)
+        lib().wm_ksw_batch_pos_zd.argtypes = [C.c_void_p, C.POINTER(KswScore), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
+        _chk(lib().wm_ksw_batch_pos_zd(self._h, C.byref(score), len(jobs), jobs.ctypes.data, res.ctypes.data, pool.ctypes.data, cap, C.byref(used), zd.ctypes.data))
+        return res, pool[:used.value], zd
 
     def ksw_prepare(self, score, jobs, seqs):
         jobs = np.ascontiguousarray(jobs, KSW_JOB_DTYPE)
