@@ -246,7 +246,7 @@ def test_position_jobs_equal_byte_jobs(tmp_path):
         H.h_zdrop_walk(np.ascontiguousarray(q), np.ascontiguousarray(t), cig if len(cig) else np.zeros(1, np.uint32), len(cig), 2, -4, -1, 4, 2, exp)
         assert list(zd[i]) == list(exp), (i, list(zd[i]), list(exp))
         n_drop += int(exp[0] > 0)
-    assert int(want.sum()) > 100 and n_drop > 50, (int(want.sum()), n_drop)
+    assert int(want.sum()) >= 100 and n_drop >= 30, (int(want.sum()), n_drop)
     # positions outside the resident data are refused, not read
     bad = pos[:1].copy()
     bad["t_pos"] = 59990; bad["tlen"] = 100; bad["step"] = 1

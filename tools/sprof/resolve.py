@@ -1,0 +1,50 @@
+"""python tools/sprof/resolve.py sprof.txt [top_n]: self time per function from the samples of tools/sprof/libsprof.so, using `nm` on the modules that
+exist on this machine (the repo's libraries travel to the GPU box unchanged, so their offsets resolve here)."""
+import bisect, collections, os, subprocess, sys
+
+def symtab(path):
+    try:
+        out = subprocess.run(["nm", "-C", "--defined-only", "-n", path], capture_output=True, text=True).stdout
+        if not out.strip():
+            out = subprocess.run(["nm", "-C", "-D", "--defined-only", "-n", path], capture_output=True, text=True).stdout
+    except Exception:
+        return [], []
+    addrs, names = [], []
+    for l in out.splitlines():
+        p = l.split(" ", 2)
+        if len(p) == 3 and p[1] in "tTwW":
+            addrs.append(int(p[0], 16)); names.append(p[2])
+    return addrs, names
+
+def main():
+    f = sys.argv[1]; top = int(sys.argv[2]) if len(sys.argv) > 2 else 45
+    per_mod = collections.Counter(); per_fn = collections.Counter(); tabs = {}; total = 0
+    for l in open(f):
+        if l.startswith("#"):
+            continue
+        path, off, n = l.rsplit(" ", 2)
+        off = int(off, 16); n = int(n); total += n
+        mod = os.path.basename(path)
+        per_mod[mod] += n
+        local = path if os.path.exists(path) else None
+        if local is None:
+            for cand in ("winnowmap_amd/" + mod, "oracle/_ref/" + mod):
+                if os.path.exists(cand):
+                    local = cand
+        if local is None:
+            per_fn[(mod, "?")] += n; continue
+        if local not in tabs:
+            tabs[local] = symtab(local)
+        a, names = tabs[local]
+        i = bisect.bisect_right(a, off) - 1
+        per_fn[(mod, names[i] if i >= 0 else "?")] += n
+    print("total samples %d = %.1f CPU-s" % (total, total / 1e3))
+    print("-- by module")
+    for m, n in per_mod.most_common(12):
+        print("  %6.2f %%  %8.1f s  %s" % (100.0 * n / total, n / 1e3, m))
+    print("-- by function (self time)")
+    for (m, fn), n in per_fn.most_common(top):
+        print("  %6.2f %%  %8.1f s  %-22s %s" % (100.0 * n / total, n / 1e3, m, fn[:150]))
+
+if __name__ == "__main__":
+    main()
