@@ -3,6 +3,7 @@
 // context's stream, measures kernel time with HIP events on that stream, and gathers results.
 // There is no CPU compute path in this file: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <malloc.h>
 #include <string.h>
 #include <cstring>
 #include <rocprim/rocprim.hpp>          // device radix sort + run-length encode for the k-mer counter (wm_write_repetitive_kmers_gpu)
@@ -395,6 +396,21 @@ static hipError_t ctx_sync(wm_ctx_s *c)
 // constructor sets the default the mapper is tuned for (6 contexts + 14 side streams) before any HIP call of this process can have happened
 // through this library; a value given by the user wins. (Python callers get the same default from winnowmap_amd/__init__.py.)
 __attribute__((constructor)) static void wm_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "20", 0); }
+
+// The mapping calls allocate and free their per-call tables (tens of MB per batched call, from 16+ worker threads) at a rate at which glibc's defaults
+// turn into system calls: a worker's malloc arena grows in 128-KB steps (one mprotect each), gives the memory back as soon as it is free, deletes and
+// re-creates its 64-MB heaps, and serves anything above the mmap threshold by mmap / munmap. The sampling profile of a bench run had 58 % of the
+// host's CPU samples inside mprotect (profiles/r04l_host_sampling_profile.txt) — with the address-space lock held, i.e. with every other thread's page
+// faults waiting. Keep the memory instead: grow in 64-MB steps, never trim, allocate up to 32 MB from the arenas: -15 % host CPU, +9 % throughput in one
+// GPU call (profiles/r04m_malloc_tuning.txt). Process-wide, like GPU_MAX_HW_QUEUES; WM_MALLOPT=0 or any MALLOC_* tunable of the caller's own wins.
+__attribute__((constructor)) static void wm_default_malloc()
+{
+	const char *off = getenv("WM_MALLOPT");
+	if (off && atoi(off) == 0) return;
+	if (!getenv("MALLOC_TOP_PAD_")) mallopt(M_TOP_PAD, 64 << 20);
+	if (!getenv("MALLOC_TRIM_THRESHOLD_")) mallopt(M_TRIM_THRESHOLD, 0x7fffffff);
+	if (!getenv("MALLOC_MMAP_THRESHOLD_")) mallopt(M_MMAP_THRESHOLD, 32 << 20);
+}
 
 // one recorded event per device: the zero of the interval clock above (hipEventElapsedTime works between events of different streams)
 static hipEvent_t device_base_event(int device)
