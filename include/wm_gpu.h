@@ -159,8 +159,10 @@ int wm_ksw_extd2(wm_ctx_t *ctx, int qlen, const uint8_t *query, int tlen, const 
 typedef struct wm_index_s wm_index_t;
 int wm_index_build(const char *fasta, const char *kmer_file, int k, int w, int n_threads, wm_index_t **out);
 /* The same index with the expensive part — mm_sketch over the whole reference (src/index.c:289-358; serial in the reference, ~31 Mb/s) — on the
- * device: one wavefront per contig runs the window-minimum chain kernel (sketch_coop) on the contig's codes, the host packs the bases,
- * builds the bloom filter before and the key table after (src/index.c:200-252). Bit-identical to wm_index_build (tests/test_aux_gpu.py).
+ * device: one wavefront per contig runs the window-minimum chain kernel (sketch_coop) on the contig's codes, the host packs the bases and
+ * builds the bloom filter before; the key table (src/index.c:200-252: per-bucket sort + hash fill) is built on the device as well — radix sort of
+ * the minimizers, run-length encode, sort by home slot, linear probing as a prefix maximum (index_table_on_device) — with the host's builder as the
+ * fall-back when the arena is too small for the sort. Bit-identical to wm_index_build (tests/test_aux_gpu.py).
  * Needs odd k (every preset); contigs are sketched in groups that fit the context's arena (~26 B per base). stats (optional, 4 doubles):
  * seconds reading + packing, sketching on the device (incl. transfers), building the table; minimizers. */
 int wm_index_build_gpu(wm_ctx_t *ctx, const char *fasta, const char *kmer_file, int k, int w, int n_threads, wm_index_t **out, double *stats);
