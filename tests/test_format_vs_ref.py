@@ -201,6 +201,7 @@ def test_file_pipeline_is_race_free_over_many_runs():
     for it in range(40):
         outp = os.path.join(tmp, "o%d.paf" % it)
         st = np.zeros(6, np.float64)
+        os.environ["WM_MAP_LANES"] = str([2, 2, 1, 3, 4][it % 5])          # mini-batches in flight: the default, one at a time, and the most the library allows
         assert H.h_map_file(h, preset.encode(), 0x4 | 0x20, rq.encode(), outp.encode(), 3000, 2, st.ctypes.data) == 0
         assert st[0] == 24 and st[2] >= 8
         txt = open(outp, "rb").read()
@@ -208,3 +209,4 @@ def test_file_pipeline_is_race_free_over_many_runs():
             first = txt
             assert txt.count(b"\n") >= 20
         assert txt == first, it
+    os.environ.pop("WM_MAP_LANES", None)

@@ -11,6 +11,9 @@
 #include <atomic>
 #include <map>
 #include <stdlib.h>
+#include <stddef.h>
+#include <string.h>
+#include <unistd.h>
 
 namespace wm {
 
@@ -132,6 +135,82 @@ int map_file_id(const std::string &reads_path, int64_t mini_batch_bases, bool wi
 	return ret;
 }
 
+namespace {
+// hits of one index part on disk: blobs of (n reads; per read rep_len, frag_gap, n regs; per reg the fixed fields + CIGAR), keyed by mini-batch
+struct HitSpill {
+	int fd = -1; uint64_t end = 0; std::string error;
+	std::mutex mu; std::map<uint64_t, std::pair<uint64_t, uint64_t>> at;      // mini-batch -> (offset, bytes)
+	~HitSpill() { if (fd >= 0) close(fd); }
+	bool open(std::string &err)
+	{
+		const char *td = getenv("TMPDIR");
+		std::string path = std::string(td && td[0] ? td : "/tmp") + "/wm_split_XXXXXX";
+		fd = mkstemp(&path[0]);
+		if (fd < 0) { err = "cannot create a temporary file for the hits of an index part in " + path; return false; }
+		unlink(path.c_str());                                               // anonymous: gone with the descriptor, whatever happens
+		return true;
+	}
+	static void w32(std::string &b, uint32_t v) { b.append((const char*)&v, 4); }
+	bool put(uint64_t id, const std::vector<ReadOut> &o)
+	{
+		const size_t fixed = offsetof(Reg, cigar);
+		std::string b;
+		w32(b, (uint32_t)o.size());
+		for (const ReadOut &r : o) {
+			w32(b, (uint32_t)r.rep_len); w32(b, (uint32_t)r.frag_gap); w32(b, (uint32_t)r.regs.size());
+			for (const Reg &g : r.regs) {
+				b.append((const char*)&g, fixed);
+				w32(b, (uint32_t)g.cigar.size());
+				b.append((const char*)g.cigar.data(), g.cigar.size() * 4);
+			}
+		}
+		std::lock_guard<std::mutex> lk(mu);
+		size_t done = 0;
+		while (done < b.size()) {
+			const ssize_t k = pwrite(fd, b.data() + done, b.size() - done, (off_t)(end + done));
+			if (k <= 0) { error = "write error on the temporary file of an index part's hits"; return false; }
+			done += (size_t)k;
+		}
+		at[id] = std::make_pair(end, (uint64_t)b.size());
+		end += b.size();
+		return true;
+	}
+	bool get(uint64_t id, std::vector<ReadOut> &o)
+	{
+		std::pair<uint64_t, uint64_t> w;
+		{ std::lock_guard<std::mutex> lk(mu); auto it = at.find(id); if (it == at.end()) return false; w = it->second; }
+		std::string b(w.second, '\0');
+		size_t done = 0;
+		while (done < b.size()) {
+			const ssize_t k = pread(fd, &b[done], b.size() - done, (off_t)(w.first + done));
+			if (k <= 0) return false;
+			done += (size_t)k;
+		}
+		const size_t fixed = offsetof(Reg, cigar);
+		size_t p = 0;
+		auto r32 = [&](uint32_t &v) { if (p + 4 > b.size()) return false; memcpy(&v, &b[p], 4); p += 4; return true; };
+		uint32_t n;
+		if (!r32(n)) return false;
+		o.assign(n, ReadOut());
+		for (ReadOut &r : o) {
+			uint32_t rl, fg, nr;
+			if (!r32(rl) || !r32(fg) || !r32(nr)) return false;
+			r.rep_len = (int)rl; r.frag_gap = (int)fg; r.regs.resize(nr);
+			for (Reg &g : r.regs) {
+				uint32_t nc;
+				if (p + fixed > b.size()) return false;
+				memcpy((void*)&g, &b[p], fixed); p += fixed;
+				if (!r32(nc) || p + (size_t)nc * 4 > b.size()) return false;
+				g.cigar.resize(nc);
+				if (nc) memcpy(g.cigar.data(), &b[p], (size_t)nc * 4);
+				p += (size_t)nc * 4;
+			}
+		}
+		return p == b.size();
+	}
+};
+}
+
 int map_file_split(const std::string &reads_path, int64_t mini_batch_bases, const MapOpt &opt, int k, const Index &dict, const std::vector<SplitPart> &parts,
                    const std::function<int(int part)> &begin_part,
                    const std::function<int(int part, std::vector<ReadIn> &batch, std::vector<ReadOut> &out, int lane)> &map_part,
@@ -140,9 +219,11 @@ int map_file_split(const std::string &reads_path, int64_t mini_batch_bases, cons
 	if (opt.flag & (F_OUT_CS | F_OUT_MD)) { err = "--cs or --MD doesn't work with a reference indexed in parts"; return -1; }      // src/options.c:139-141
 	const int n_parts = (int)parts.size();
 	const bool with_qual = (opt.flag & F_OUT_SAM) != 0;
-	// hits[part][mini-batch] = one ReadOut per read of the mini-batch, in the order the pipeline hands the reads over
-	std::vector<std::map<uint64_t, std::vector<ReadOut>>> hits(n_parts);
-	std::mutex hm;
+	// The hits of one index part — one ReadOut per read, CIGARs included — go to an anonymous temporary file per part, one blob per mini-batch, as the
+	// reference spills them to <prefix>.NNNN.tmp (src/map.c:1174-1190, read back in merge_hits, src/map.c:1050-1105): this flow exists for references too big for one index, and reads x parts hits
+	// do not belong in RAM. In memory: where each blob lies. $TMPDIR, else /tmp.
+	std::vector<HitSpill> spill(n_parts);
+	for (int j = 0; j < n_parts; ++j) if (!spill[j].open(err)) return -1;
 	FileStats fs_all;
 	for (int j = 0; j < n_parts; ++j) {
 		if (begin_part(j)) { err = "cannot set up index part " + std::to_string(j); return -1; }
@@ -151,11 +232,9 @@ int map_file_split(const std::string &reads_path, int64_t mini_batch_bases, cons
 			std::vector<ReadOut> o;
 			const int r = map_part(j, batch, o, lane);
 			if (r) return r;
-			std::lock_guard<std::mutex> lk(hm);
-			hits[j][id] = std::move(o);
-			return 0;
+			return spill[j].put(id, o) ? 0 : -1;
 		}, 0, &fs, err);
-		if (rc) return rc;
+		if (rc) { if (err.empty() || err == "mapping failed") err = spill[j].error.empty() ? err : spill[j].error; return rc; }
 		fs_all.t_read += fs.t_read; fs_all.t_map += fs.t_map;
 	}
 	std::vector<int> rid_shift(n_parts, 0);
@@ -163,12 +242,13 @@ int map_file_split(const std::string &reads_path, int64_t mini_batch_bases, cons
 	// the merge pass (merge_hits, src/map.c:1050-1105)
 	FileStats fs;
 	const int rc = map_file_id(reads_path, mini_batch_bases, with_qual, [&](std::vector<ReadIn> &batch, std::string &text, int, uint64_t id) {
+		std::vector<std::vector<ReadOut>> ph(n_parts);                    // this mini-batch's hits, part by part
+		for (int j = 0; j < n_parts; ++j)
+			if (!spill[j].get(id, ph[j]) || ph[j].size() != batch.size()) return -1;
 		for (size_t i = 0; i < batch.size(); ++i) {
 			ReadOut m;
 			for (int j = 0; j < n_parts; ++j) {
-				auto it = hits[j].find(id);
-				if (it == hits[j].end() || it->second.size() != batch.size()) return -1;
-				ReadOut &p = it->second[i];
+				ReadOut &p = ph[j][i];
 				if (p.rep_len > m.rep_len) m.rep_len = p.rep_len;
 				if (j == 0) m.frag_gap = p.frag_gap;
 				for (Reg &r : p.regs) { r.rid += rid_shift[j]; m.regs.push_back(std::move(r)); }

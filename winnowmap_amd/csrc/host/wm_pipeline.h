@@ -40,8 +40,8 @@ int map_file_id(const std::string &reads_path, int64_t mini_batch_bases, bool wi
 // part after the other (begin_part(j) makes part j current — upload, mapper —, map_part maps one mini-batch against it), the hits of every read
 // are kept, and a last pass over the reads merges them exactly like mm_split_merge / merge_hits (src/map.c:1050-1105): part order, contig ids
 // shifted by the parts before, mm_hit_sort, mm_set_parent, mm_select_sub, mm_set_sam_pri, mm_set_mapq with the largest rep_len. `dict` = the
-// contigs of all parts in order (names and lengths only). The reference spills the per-part hits to <prefix>.NNNN.tmp files; here they stay in
-// memory. --cs / --MD are refused like the reference does (src/options.c:139-141).
+// contigs of all parts in order (names and lengths only). The reference spills the per-part hits to <prefix>.NNNN.tmp files (src/map.c:1174-1190); here each part has an
+// anonymous temporary file under $TMPDIR (one blob per mini-batch), so that memory holds one mini-batch's hits per lane, not reads x parts. --cs / --MD are refused like the reference does (src/options.c:139-141).
 struct SplitPart { int n_seq; };
 int map_file_split(const std::string &reads_path, int64_t mini_batch_bases, const MapOpt &opt, int k, const Index &dict, const std::vector<SplitPart> &parts,
                    const std::function<int(int part)> &begin_part,
