@@ -2681,7 +2681,7 @@ struct GpuOpsCtx {
 // The product's DeviceOps: a pool of device contexts. Every batched call borrows a free context (its own HIP stream, arena and pinned
 // slab), so up to max_inflight() batches — of the same or of different operations — are on the device at once, issued by different
 // host threads (wm_fiber.h).
-struct GpuOps {                          // the device contexts of a mapper, shared by its (at most two concurrent) mapping calls: see CallOps
+struct GpuOps {                          // the device contexts of a mapper, shared by its (at most WM_MAX_SLOTS concurrent) mapping calls: see CallOps
 	std::vector<GpuOpsCtx> ctxs;
 	std::vector<int> free_;
 	std::mutex mu;
