@@ -111,6 +111,11 @@ typedef struct { int32_t max_zdrop, t0, t1, q0, q1; } wm_zd_t;
 int wm_ksw_batch_pos_zd(wm_ctx_t *ctx, const wm_ksw_score_t *sc, int n_jobs, const wm_ksw_pos_t *jobs,
                         wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used, wm_zd_t *zd);
 
+/* diagnostics: per-phase cycle table of the stripe-pipelined wide-hull kernel; only in a library built with WM_KERNEL_DEFINES="WM_STRIPE_TIMING=1"
+ * (WM_EINVAL otherwise). out16: cycles summed over wavefronts in scan / epoch set-up / cells / wait-left / bookkeeping / wait-right / publish, then rows,
+ * epochs, total cycles, wavefronts. */
+int wm_debug_stripe_timing(uint64_t *out16, int reset);
+
 /* ksw_ll_qinit + ksw_ll_i16 (src/ksw2.h:82-83, src/ksw2_ll_sse.c:32-147): local alignment SCORE of query vs target with affine gaps
  * (16-bit striped lanes in the reference; ties and the striped layout's end coordinates are reproduced: *qe may be as low as -7 … see
  * host/wm_align.cpp). m = 5, mat = 5x5. Runs on the HOST (the mapper needs it twice per inversion candidate / boundary exon only);

@@ -7,6 +7,7 @@ from winnowmap_amd import gpu
 import kswcases
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+TIMING = "WM_STRIPE_TIMING" in gpu.build_defines()     # diagnostic variant: per-phase cycles of the stripe-pipelined kernel (ksw_stripe_kernel.h)
 NOSTORE = "WM_KSW_NOSTORE" in gpu.build_defines()      # timing-only variant: the traceback is never written, the backtrack may fail on what it finds
 
 
@@ -58,6 +59,8 @@ for name, L, njob, flag in (("p16_1500x", 1500, 256, 0x40), ("p16_1500a", 1500, 
     jobs, seqs = gpu.pack_jobs(cases)
     b = ctx.ksw_prepare(sc, jobs, seqs)
     run(b)
+    if TIMING:
+        gpu.stripe_timing(reset=True)
     best = None
     for rep in range(2):
         t1 = time.time(); run(b); wall = time.time() - t1
@@ -66,4 +69,12 @@ for name, L, njob, flag in (("p16_1500x", 1500, 256, 0x40), ("p16_1500a", 1500, 
             best = dict(s, wall_ms=wall * 1e3)
     print("%-11s jobs=%d cells=%.3e dp=%.2f ms bt=%.2f ms wall=%.2f ms  -> %.1f GCUPS (dp), %.2f us per row" %
           (name, njob, best["cells"], best["dp_ms"], best["bt_ms"], best["wall_ms"], best["cells"] / best["dp_ms"] / 1e6, best["dp_ms"] * 1e3 / (2 * L)), flush=True)
+    if TIMING:          # where a stripe wavefront's cycles go (WM_STRIPE_TIMING build): per ACTIVE row of a wavefront, and as shares of its time in the kernel
+        t = gpu.stripe_timing(reset=True)
+        rows = max(1, t["rows"])
+        print("            stripe timing: %d wavefronts, %d active wavefront-rows (%.1f per job-row), %d epochs; cycles per active row: cells %.0f  wait_left %.0f  book %.0f  "
+              "wait_right %.0f  publish %.0f  epoch set-up %.0f  scan/idle %.0f | share of kernel time: cells %.0f %%  waits %.0f %%  book %.0f %%  publish %.0f %%  scan/idle %.0f %%" %
+              (t["waves"], t["rows"], t["rows"] / (2.0 * 2 * L * njob), t["epochs"], t["cells"] / rows, t["wait_left"] / rows, t["book"] / rows, t["wait_right"] / rows, t["publish"] / rows,
+               t["epoch"] / rows, t["scan"] / rows, 100.0 * t["cells"] / max(1, t["total"]), 100.0 * (t["wait_left"] + t["wait_right"]) / max(1, t["total"]),
+               100.0 * t["book"] / max(1, t["total"]), 100.0 * t["publish"] / max(1, t["total"]), 100.0 * t["scan"] / max(1, t["total"])), flush=True)
     b.free()

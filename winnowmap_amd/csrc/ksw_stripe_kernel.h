@@ -32,6 +32,25 @@
 #ifndef WM_STRIPE_EVENT
 #define WM_STRIPE_EVENT(k) ((void)0)      // test hook (tests/simt_emu): counts how often the rare paths run
 #endif
+// Diagnostic build (WM_KERNEL_DEFINES="WM_STRIPE_TIMING=1", a variant library: winnowmap_amd/build.py): every wavefront accumulates the shader-clock
+// cycles (s_memtime) it spends in each phase of the row loop and adds them to a device-global table at the end of the job; wm_debug_stripe_timing
+// reads the table (tools/ksw_probe.py prints it per shape). Empty in every other build: the shipped kernels do not change.
+#if defined(WM_STRIPE_TIMING) && defined(__HIPCC__)
+__device__ unsigned long long g_wm_stripe_timing[16];
+#endif
+#if defined(WM_STRIPE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#define WM_ST_DECL() unsigned long long st_acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; unsigned long long st_t = __builtin_amdgcn_s_memtime(); const unsigned long long st_t0 = st_t
+#define WM_ST_LAP(k) do { const unsigned long long st_n = __builtin_amdgcn_s_memtime(); st_acc[k] += st_n - st_t; st_t = st_n; } while (0)
+#define WM_ST_COUNT(k) (++st_acc[k])
+#define WM_ST_FLUSH() do { st_acc[9] = __builtin_amdgcn_s_memtime() - st_t0; \
+		if (__lane_id() == 0) { for (int k_ = 0; k_ < 10; ++k_) atomicAdd(&g_wm_stripe_timing[k_], st_acc[k_]); atomicAdd(&g_wm_stripe_timing[10], 1ull); } } while (0)
+#else
+#define WM_ST_DECL() ((void)0)
+#define WM_ST_LAP(k) ((void)0)
+#define WM_ST_COUNT(k) ((void)0)
+#define WM_ST_FLUSH() ((void)0)
+#endif
+enum { WM_ST_SCAN = 0, WM_ST_EPOCH = 1, WM_ST_CELLS = 2, WM_ST_WAIT_LEFT = 3, WM_ST_BOOK = 4, WM_ST_WAIT_RIGHT = 5, WM_ST_PUBLISH = 6, WM_ST_ROWS = 7, WM_ST_EPOCHS = 8, WM_ST_TOTAL = 9 };
 
 namespace wmk {
 
@@ -104,6 +123,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 	int *ring_out = lds + wv * (R * L::SLOT), *ring_in = lds + ((wv + NWV - 1) % NWV) * (R * L::SLOT);
 	int *prog = lds + L::PROG, *ctrl = lds + L::CTRL;
 	const int right_wv = (wv + 1) % NWV;
+	WM_ST_DECL();
 
 	for (int safe = 0; safe < 2; ++safe) {
 		// ---- the workgroup's LDS state: no message yet, nobody has consumed anything, nothing stops ----
@@ -205,6 +225,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 			// ~900 instructions per row for two pairs, profiles/r04b: a lone wavefront issues one instruction per ~4.4 cycles.)
 			bool leave = false;
 			while (!all_done && !leave) {
+				WM_ST_LAP(WM_ST_SCAN); WM_ST_COUNT(WM_ST_EPOCHS);               // (activation scan, first message, register set-up — or the tail of the last row)
 				if (r >= n_rows) { all_done = true; break; }
 				if (!ksw_geo<CLIP>(r, qlen, tlen, w, g)) { end_row = r; all_done = true; break; }
 				const int st = g.st, en = g.en;
@@ -253,7 +274,9 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 				bool moved = st > prev_st;                                     // lane st - 1 was computed in the last row (:141-146): first row of an epoch only
 				prev_st = st;
 
+				WM_ST_LAP(WM_ST_EPOCH);
 				for (; r < r_end; ++r) {
+					WM_ST_COUNT(WM_ST_ROWS);
 					const int stop_row = lds_ld_acq(ctrl, L::C_STOP);             // (consumed at the end of the row: the load's latency hides behind the cells)
 					const int ezl = EXACT ? lds_ld_acq(ctrl, L::C_EZL) : 0;
 					int st0 = 0, en0 = tlen - 1;
@@ -401,6 +424,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 					});
 					if constexpr (EXACT) { if (is_last && en0 == tlen - 1) { WM_KEEP_BRANCH(); h_en0 = h_of(en0); } }
 					moved = false;
+					WM_ST_LAP(WM_ST_CELLS);
 
 					// ---- the lane (uniform) of this stripe as (register, half, thread) ----
 					auto half_of = [&](const V<int> (&arr)[BP], int t) { return get_half<BP>(arr, a, t); };
@@ -427,6 +451,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 						} else if (o8[5] >= 0) { in_th0 = o8[4]; in_tl0 = o8[5]; }
 					}
 					have_left = left_now;
+					WM_ST_LAP(WM_ST_WAIT_LEFT);
 					if constexpr (EXACT) { if (r > 0 && have_cells) hm = wave_max_i32(hmax); }
 
 					int out_th0 = 0, out_tl0 = -1;
@@ -527,9 +552,11 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 					}
 
 					// ---- publish this row for the right neighbour ----
+					WM_ST_LAP(WM_ST_BOOK);
 					if (pub) {
 						while (lds_ld_acq(prog, right_wv) < r - R) { if (lds_ld_acq(ctrl, L::C_STOP) <= r) { stopped = true; break; } WM_STRIPE_SPIN(2, r, a, wv, lds_ld_acq(prog, right_wv)); spin_pause(); }
 						if (stopped) { all_done = true; break; }
+						WM_ST_LAP(WM_ST_WAIT_RIGHT);
 						int *m = ring_out + (r % R) * L::SLOT;
 						WM_IF(ln == 63)
 							lds_st(m, V<int>(L::M_X), lshr(X[BP - 1], 16)); lds_st(m, V<int>(L::M_V), lshr(Vv[BP - 1], 16)); lds_st(m, V<int>(L::M_X2), lshr(X2[BP - 1], 16));
@@ -546,6 +573,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 					}
 					lds_st_rel(prog, wv, r - 1);                 // the left ring's messages up to row r - 1 may be overwritten
 					row_done = r; was_last = is_last;
+					WM_ST_LAP(WM_ST_PUBLISH);
 					if (r >= stop_row) { all_done = true; break; }   // (a z-drop in row stop_row: nothing after it exists)
 				}
 			}
@@ -555,6 +583,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 		// (a wavefront that has left the row loop reads no message any more: its left neighbour may still be publishing — e.g. the band runs empty a
 		// few rows before the stripe this wavefront was waiting for is reached — and must not wait for it)
 		lds_st_rel(prog, wv, BIG);
+		WM_ST_LAP(WM_ST_SCAN);
 		block_sync_lds();
 		const int stop_row = lds_ld_acq(ctrl, L::C_STOP), restart = lds_ld_acq(ctrl, L::C_RESTART);
 		if (restart) { block_sync_lds(); continue; }
@@ -577,6 +606,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 		}
 		break;
 	}
+	WM_ST_FLUSH();
 }
 
 } // namespace wmk

@@ -1076,6 +1076,23 @@ extern "C" int wm_ksw_batch_pos_zd(wm_ctx_t *c, const wm_ksw_score_t *sc, int n_
 	return ksw_batch_impl(c, sc, n_jobs, 0, 0, 0, jobs, results, cigar_pool, cigar_cap, cigar_used, zd);
 }
 
+// diagnostic: the per-phase cycle table of the stripe-pipelined kernel (a library built with WM_KERNEL_DEFINES="WM_STRIPE_TIMING=1"; ksw_stripe_kernel.h).
+// out[0..6] = shader-clock cycles summed over all wavefronts: scan / epoch set-up / cells / waiting for the left message / bookkeeping / waiting for the
+// right neighbour's progress / publishing; out[7] rows, out[8] epochs, out[9] cycles inside the kernel, out[10] wavefronts. reset: clear afterwards.
+extern "C" int wm_debug_stripe_timing(uint64_t *out16, int reset)
+{
+#ifdef WM_STRIPE_TIMING
+	unsigned long long h[16];
+	if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wm_stripe_timing), sizeof(h)) != hipSuccess) return set_err(WM_EINTERNAL, "hipMemcpyFromSymbol: %s", hipGetErrorString(hipGetLastError()));
+	for (int i = 0; i < 16; ++i) out16[i] = h[i];
+	if (reset) { memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_wm_stripe_timing), h, sizeof(h)) != hipSuccess) return set_err(WM_EINTERNAL, "hipMemcpyToSymbol failed"); }
+	return WM_OK;
+#else
+	(void)out16; (void)reset;
+	return set_err(WM_EINVAL, "this library was not built with WM_STRIPE_TIMING");
+#endif
+}
+
 extern "C" int wm_ksw_extd2(wm_ctx_t *c, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                             int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, wm_ksw_result_t *ez, uint32_t **cigar_out)
 {

@@ -183,6 +183,18 @@ def build_defines():
     return lib().wm_build_defines().decode()
 
 
+STRIPE_TIMING_FIELDS = ("scan", "epoch", "cells", "wait_left", "book", "wait_right", "publish", "rows", "epochs", "total", "waves")
+
+
+def stripe_timing(reset=True):
+    """per-phase shader-clock cycles of the stripe-pipelined ksw kernel, summed over wavefronts since the last reset (wm_debug_stripe_timing; only in a
+    library built with WM_KERNEL_DEFINES="WM_STRIPE_TIMING=1", WmError otherwise)"""
+    out = np.zeros(16, np.uint64)
+    lib().wm_debug_stripe_timing.argtypes = [C.c_void_p, C.c_int]
+    _chk(lib().wm_debug_stripe_timing(out.ctypes.data, 1 if reset else 0))
+    return {k: int(out[i]) for i, k in enumerate(STRIPE_TIMING_FIELDS)}
+
+
 def pack_jobs(pairs, w=751, zdrop=400, end_bonus=-1, flag=0):
     """pairs: list of (query codes, target codes[, dict overrides]). Returns (jobs, seqs)."""
     jobs = np.zeros(len(pairs), KSW_JOB_DTYPE)
