@@ -158,7 +158,7 @@ def ksw_class_name(k):
     spelled as rocprofv3 prints the instantiation ksw_dpp_kernel<BP, CLIP, HASN, EXACT> (jobs with an N run on the CLIP instantiation)"""
     if k >= 28:                                                    # stripe classes: WM_KSW_STRIPE + geometry * 4 + CLIP * 2 + HASN
         g, v = (k - 28) >> 2, (k - 28) & 3
-        return "ksw_stripe_kernel<%s, %s, %s>" % (("2, 4", "2, 8", "4, 8", "8, 8")[g], str(bool(v & 2) or bool(v & 1)).lower(), str(bool(v & 1)).lower())
+        return "ksw_stripe_kernel<%s, %s, %s>" % (("2, 4", "2, 8", "4, 8", "8, 8", "1, 16", "2, 16")[g], str(bool(v & 2) or bool(v & 1)).lower(), str(bool(v & 1)).lower())
     if k >= 24:
         return KSW_WIDE_CLASSES[k]
     if k >= 16 and int(os.environ.get("WM_KSW_PMULTI", 2)) >= 2:       # the 16-pair classes run on 4 wavefronts per alignment (library default)

@@ -4,7 +4,8 @@
 // assert that they did), WM_STRIPE_SPIN is a watchdog on every polling loop (a protocol deadlock aborts with the place instead of hanging the suite).
 // A library of its own (winnowmap_amd/build.py build_emu_stripe) so that the big emulator driver does not pay for its 64 instantiations.
 //   emu_stripe_extd2(..., force): 300 + geometry * 10 + (CLIP * 2 + HASN); geometry 0 = <BP 1, 2 waves>, 1 = <1,3>, 2 = <2,3>, 3 = <2,4>, 4 = <4,4>,
-//   5 = <4,8>, 6 = <8,8>, 7 = <1,4>; <2,4>, <2,8>(not here: same code as <2,4> with more waves), <4,8>, <8,8> are the product's geometries.
+//   5 = <4,8>, 6 = <8,8>, 7 = <1,4>, 8 = <1,16>, 9 = <2,16>; <2,4>, <2,8> (not here: same code as <2,4> with more waves), <4,8>, <8,8> and the
+//   opt-in <1,16>, <2,16> are the product's geometries.
 #include <atomic>
 static std::atomic<long> g_ev[16];
 #define WM_STRIPE_EVENT(k) (++g_ev[k])
@@ -62,9 +63,9 @@ int emu_stripe_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *ta
 	wm_ksw_djob_t jb;
 	memset(&jb, 0, sizeof(jb));
 	jb.q_off = 0; jb.t_off = qlen; jb.qlen = qlen; jb.tlen = tlen; jb.w = w; jb.zdrop = zdrop; jb.end_bonus = end_bonus; jb.flag = flag;
-	if (force_klass < 300) return -1;
+	if (force_klass < 300 || force_klass >= 400) return -1;
 	const int emu_stripe = 1 + (force_klass - 300) / 10; force_klass = (force_klass - 300) % 10;
-	static const int max_ncol[8] = { 128, 2 * 128, 2 * 256, 3 * 256, 3 * 512, 7 * 512, 7 * 1024, 3 * 128 };
+	static const int max_ncol[10] = { 128, 2 * 128, 2 * 256, 3 * 256, 3 * 512, 7 * 512, 7 * 1024, 3 * 128, 15 * 128, 15 * 256 };
 	int n_col = wm_ksw_ncol(qlen, tlen, w);
 	if (n_col > max_ncol[emu_stripe - 1]) return -1;
 	const int has_n = wm_ksw_has_n(query, qlen) | wm_ksw_has_n(target, tlen);
@@ -86,7 +87,9 @@ int emu_stripe_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *ta
 	case 5: run_stripe<4, 4>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
 	case 6: run_stripe<4, 8>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
 	case 7: run_stripe<8, 8>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
-	default: run_stripe<1, 4>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
+	case 8: run_stripe<1, 4>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
+	case 9: run_stripe<1, 16>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
+	default: run_stripe<2, 16>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
 	}
 	int n = 0;
 	if (res.bt_i >= 0) {

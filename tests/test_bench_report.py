@@ -17,7 +17,7 @@ def _bench():
 def test_report_has_contract_keys_for_any_dominant_class():
     B = _bench()
     args = argparse.Namespace(steps=3, warmup=1, reads_per_step=16384, read_len=15000, ref_mb=250.0, config=2)
-    n_classes = 44                     # WM_KSW_NCLASS (winnowmap_amd/csrc/ksw_plan.h): what Mapper.kernel_stats() returns
+    n_classes = 52                     # WM_KSW_NCLASS (winnowmap_amd/csrc/ksw_plan.h): what Mapper.kernel_stats() returns
     zero = {k: (0.0, 0.0, 0) for k in range(n_classes)}
     assert B.ksw_class_name(0) == "ksw_dpp_kernel<4, false, false, false>" and B.ksw_class_name(14) == "ksw_dpp_kernel<8, true, false, true>"
     assert B.ksw_class_name(21) == "ksw_pmulti_kernel<4, 4>" and B.ksw_class_name(24) == "ksw_pmulti_kernel<4, 8>"

@@ -379,6 +379,26 @@ def test_stripe_pipelined_ksw_kernel_matches_oracle():
     assert ev["restart"] == 0, ev              # with the real margin the safe-mode repeat is (provably) never needed
 
 
+def test_stripe_sixteen_wavefront_geometries_match_oracle():
+    """<1,16> and <2,16> (opt-in routing, wm_ksw_set_routing(2, ...)): the same kernel with one / two lane pairs per wavefront and sixteen wavefronts —
+    small random cases (most stripes never reached, rings of 16) and hulls of 900 .. 3 700 lanes"""
+    E = _load_stripe()
+    forces = [300 + g * 10 + v for g in (8, 9) for v in (0, 2, 3)]
+    n_run = _stripe_run(E, kswcases.stripe_edge_cases(13, 120, 700), forces)
+    n_run += _stripe_run(E, kswcases.stripe_cases(15, 30, 1800), forces)
+    from winnowmap_amd import synth
+    rng = np.random.default_rng(29)
+    wide = []
+    for tl, fl, w, zd in ((950, 0x08, -1, 400), (1800, 0x40, 900, 200), (1850, 0x00, -1, 400), (2400, 0x88, 1200, 400), (3700, 0x00, -1, 100), (3000, 0x0A, -1, -1)):
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        q = synth.mutate_codes(t, rng, 0.03, 0.03, 0.03)
+        if fl == 0x0A:
+            q[len(q) // 2] = 4
+        wide.append(dict(q=q, t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=w, zdrop=zd, end_bonus=-1, flag=fl))
+    n_run += _stripe_run(E, wide, [300 + g * 10 + v for g in (8, 9) for v in (2, 3)])
+    assert n_run[8] > 150 and n_run[9] > 150, n_run
+
+
 def test_stripe_kernel_repeat_in_safe_mode():
     """the exact-maximum path skips the priority evaluation of a row whose prefix maximum cannot reach ez.max minus a margin; should a later stripe
     need a skipped priority after all, the job repeats with every priority evaluated. The real margin makes that unreachable; a useless margin

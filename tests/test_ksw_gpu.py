@@ -257,11 +257,24 @@ def test_position_jobs_equal_byte_jobs(tmp_path):
 
 # ---- the stripe-pipelined multi-wave kernels (csrc/ksw_stripe_kernel.h): every job of the suites above once more with the routing thresholds at
 # one row, so that each runs on NWV wavefronts that hand rows to each other through LDS (geometry by traceback pitch), and natively wide hulls ----
-@pytest.fixture()
-def all_stripes():
-    gpu.set_ksw_routing(1, 1, 1)
+def _default_routing():
+    on = 0 if os.environ.get("WM_KSW_STRIPE") == "0" else 2 if int(os.environ.get("WM_KSW_STRIPE16", 0)) > 0 else 1
+    gpu.set_ksw_routing(on, int(os.environ.get("WM_KSW_STRIPE_ROWS4", 0)), int(os.environ.get("WM_KSW_STRIPE_ROWS8", 4096)))
+
+
+# on = 1: the default geometries (<2,4> <2,8> <4,8> <8,8>); on = 2: the sixteen-wavefront geometries (<1,16> <2,16>) wherever they fit
+@pytest.fixture(params=[1, 2], ids=["nwv4_8", "nwv16"])
+def all_stripes(request):
+    gpu.set_ksw_routing(request.param, 1, 1)
     yield
-    gpu.set_ksw_routing(-1, int(os.environ.get("WM_KSW_STRIPE_ROWS4", 0)), int(os.environ.get("WM_KSW_STRIPE_ROWS8", 4096)))
+    _default_routing()
+
+
+@pytest.fixture(params=[1, 2], ids=["nwv4_8", "nwv16"])
+def stripe_geometries(request):
+    gpu.set_ksw_routing(request.param, -1, -1)
+    yield
+    _default_routing()
 
 
 @pytest.mark.parametrize("preset", [0, 1, 2, 3, 4])
@@ -276,8 +289,9 @@ def test_stripe_kernels_long_jobs_every_band(ctx, all_stripes):
     assert not bad, bad[:3]
 
 
-def test_stripe_kernels_wide_hulls(ctx):
-    """hulls of 1 100 .. 7 000 lanes: geometries <2,8>, <4,8>, <8,8> by default routing (exact + z-drop, approximate maximum, unbanded, an N)"""
+def test_stripe_kernels_wide_hulls(ctx, stripe_geometries):
+    """hulls of 1 100 .. 7 000 lanes: geometries <2,8>, <4,8>, <8,8> by default routing — <1,16>, <2,16>, <8,8> with the sixteen-wavefront geometries
+    (exact + z-drop, approximate maximum, unbanded, an N)"""
     from winnowmap_amd import synth
     rng = np.random.default_rng(21)
     cases = []

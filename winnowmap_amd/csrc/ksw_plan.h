@@ -8,15 +8,17 @@ enum {            // register classes (ksw_dp_packed<BP,...>): klass = window*8 
 	                  // 1008 / 2032 lanes); 24, 25 = multi-wave LDS kernels; 26 = multi-wave kernel with its state in global scratch; 27 = single-wave generic kernel
 	WM_KSW_P4 = 0, WM_KSW_P8 = 8, WM_KSW_P16 = 16, WM_KSW_BLOCK = 24, WM_KSW_BLOCK2 = 25, WM_KSW_BLOCK3 = 26, WM_KSW_GENERIC = 27,
 	// stripe-pipelined multi-wave kernels (ksw_stripe_kernel.h): klass = WM_KSW_STRIPE + geometry * 4 + CLIP * 2 + HASN (a job with an N runs on the
-	// CLIP instantiation: 1 is unused); geometry 0..3 = <BP, NWV> of <2,4> <2,8> <4,8> <8,8>: traceback pitch n_col up to 768 / 1792 / 3584 / 7168
-	WM_KSW_STRIPE = 28, WM_KSW_NCLASS = 44
+	// CLIP instantiation: 1 is unused); geometry 0..3 = <BP, NWV> of <2,4> <2,8> <4,8> <8,8>: traceback pitch n_col up to 768 / 1792 / 3584 / 7168;
+	// geometry 4, 5 = <1,16> <2,16> (up to 1920 / 3840 lanes): half the pairs per wavefront for the same hull — the cells of a row are the largest
+	// share of a stripe wavefront's row time (profiles/r04q_stripe_timing.txt). Opt-in (wide16 of wm_ksw_route) until the bench has judged them.
+	WM_KSW_STRIPE = 28, WM_KSW_NCLASS = 52
 };
-static const int wm_ksw_stripe_max_ncol[4] = { 3 * 256, 7 * 256, 7 * 512, 7 * 1024 };      // ksw_stripe_lds<BP, NWV>::MAX_NCOL
+static const int wm_ksw_stripe_max_ncol[6] = { 3 * 256, 7 * 256, 7 * 512, 7 * 1024, 15 * 128, 15 * 256 };      // ksw_stripe_lds<BP, NWV>::MAX_NCOL
 // Which jobs leave their register / barrier class for a stripe class: every hull wider than the one-wave window of 8 pairs (the former 16-pair and
 // BLOCK / BLOCK2 classes: one DP row cost 2.5 us there whatever the hull), and LONG alignments of the 4- and 8-pair classes — one alignment on
 // one wavefront is one dependent chain of qlen + tlen rows, and the longest chain of a launch is the launch's duration (min_rows4 / min_rows8:
 // rows from which the chain is split over four wavefronts; 0 = never).
-static inline int wm_ksw_route(int klass, int n_col, int qlen, int tlen, int w, int has_n, int min_rows4, int min_rows8)
+static inline int wm_ksw_route(int klass, int n_col, int qlen, int tlen, int w, int has_n, int min_rows4, int min_rows8, int wide16 = 0)
 {
 	if (klass < 0 || klass >= WM_KSW_BLOCK3) return klass;
 	const int n_rows = qlen + tlen - 1;
@@ -25,6 +27,10 @@ static inline int wm_ksw_route(int klass, int n_col, int qlen, int tlen, int w, 
 	if (klass < WM_KSW_P8) { if (!min_rows4 || n_rows < min_rows4) return klass; geom = 0; }
 	else if (klass < WM_KSW_P16) { if (!min_rows8 || n_rows < min_rows8) return klass; geom = n_col <= wm_ksw_stripe_max_ncol[0] ? 0 : 1; }
 	else geom = n_col <= wm_ksw_stripe_max_ncol[1] ? 1 : n_col <= wm_ksw_stripe_max_ncol[2] ? 2 : n_col <= wm_ksw_stripe_max_ncol[3] ? 3 : -1;
+	if (wide16 && geom >= 0) {                               // sixteen wavefronts: one pair each up to 1920 lanes, two up to 3840
+		if (n_col <= wm_ksw_stripe_max_ncol[4]) geom = 4;
+		else if (n_col <= wm_ksw_stripe_max_ncol[5]) geom = 5;
+	}
 	if (geom < 0) return klass;                              // (7169..8176 lanes: stays on ksw_dp_pmulti<8,8>)
 	const int clip = !(w >= qlen && w >= tlen) || has_n;
 	return WM_KSW_STRIPE + geom * 4 + clip * 2 + (has_n ? 1 : 0);

@@ -522,12 +522,13 @@ template <int BP> static void launch_dpp(int variant, int n, hipStream_t s, cons
 
 // WM_KSW_STRIPE_ROWS4 / WM_KSW_STRIPE_ROWS8: alignments of the 4- / 8-pair register classes with at least this many DP rows run on four wavefronts
 // (ksw_plan.h: wm_ksw_route); 0 = never. WM_KSW_STRIPE=0: no stripe classes at all (the round-3 kernels; A/B). wm_ksw_set_routing overrides.
-static std::atomic<int> g_stripe_on(-1), g_stripe_rows4(-1), g_stripe_rows8(-1);
+static std::atomic<int> g_stripe_on(-1), g_stripe_rows4(-1), g_stripe_rows8(-1), g_stripe_wide16(0);
 static int stripe_min_rows(int bp)
 {
 	if (g_stripe_on.load(std::memory_order_relaxed) < 0) {
 		g_stripe_rows4 = getenv("WM_KSW_STRIPE_ROWS4") ? std::max(0, atoi(getenv("WM_KSW_STRIPE_ROWS4"))) : 0;
 		g_stripe_rows8 = getenv("WM_KSW_STRIPE_ROWS8") ? std::max(0, atoi(getenv("WM_KSW_STRIPE_ROWS8"))) : 4096;      // (3 000-row extensions are faster on one wavefront, 10 000-row ones on four: profiles/r04c_probe.txt)
+		g_stripe_wide16 = getenv("WM_KSW_STRIPE16") && atoi(getenv("WM_KSW_STRIPE16")) > 0;      // <1,16> / <2,16> instead of <2,4> / <2,8> / <4,8> (opt-in)
 		g_stripe_on = !(getenv("WM_KSW_STRIPE") && atoi(getenv("WM_KSW_STRIPE")) == 0);
 	}
 	return !g_stripe_on.load(std::memory_order_relaxed) ? 0 : bp == 4 ? g_stripe_rows4.load(std::memory_order_relaxed) : bp == 8 ? g_stripe_rows8.load(std::memory_order_relaxed) : 1;   // (bp == 0: are the stripe classes on at all)
@@ -535,7 +536,7 @@ static int stripe_min_rows(int bp)
 extern "C" void wm_ksw_set_routing(int on, int rows4, int rows8)
 {
 	stripe_min_rows(0);
-	if (on >= 0) g_stripe_on = on != 0;
+	if (on >= 0) { g_stripe_on = on != 0; g_stripe_wide16 = on >= 2; }      // (on = 2: with the sixteen-wavefront geometries)
 	if (rows4 >= 0) g_stripe_rows4 = rows4;
 	if (rows8 >= 0) g_stripe_rows8 = rows8;
 }
@@ -634,7 +635,7 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 		d.q_off = pos ? q_off : (uint32_t)(q_off - slab_lo); d.t_off = pos ? t_off : (uint32_t)(t_off - slab_lo);
 		int n_col;
 		d.klass = wm_ksw_classify(qlen, tlen, w, has_n, flag, &n_col);
-		if (stripe_min_rows(0)) d.klass = wm_ksw_route(d.klass, n_col, qlen, tlen, w, has_n, stripe_min_rows(4), stripe_min_rows(8));
+		if (stripe_min_rows(0)) d.klass = wm_ksw_route(d.klass, n_col, qlen, tlen, w, has_n, stripe_min_rows(4), stripe_min_rows(8), g_stripe_wide16.load(std::memory_order_relaxed));
 		d.n_col = n_col;
 		cells[i] = wm_ksw_cells(qlen, tlen, w, &bands[i]);
 	});
@@ -889,6 +890,8 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 			case 0: launch_stripe<2, 4>(var, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
 			case 1: launch_stripe<2, 8>(var, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
 			case 2: launch_stripe<4, 8>(var, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
+			case 4: launch_stripe<1, 16>(var, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
+			case 5: launch_stripe<2, 16>(var, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
 			default: launch_stripe<8, 8>(var, nk, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res); break;
 			}
 			continue;

@@ -485,7 +485,7 @@ class Mapper:
         now = C.c_double()
         lib().wm_mapper_kernel_union.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
         _chk(lib().wm_mapper_kernel_union(self._h, float(since_ms), out.ctypes.data, len(out), C.byref(now)))
-        return {k: float(out[k]) for k in range(44)}, now.value
+        return {k: float(out[k]) for k in range(52)}, now.value      # (WM_KSW_NCLASS)
 
     def host_stats(self):
         """host time accounting since the mapper was created (wm_mapper_host_stats), seconds summed over the worker threads"""
