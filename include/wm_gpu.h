@@ -148,8 +148,8 @@ void wm_ksw_dev_free(wm_ctx_t *ctx, wm_ksw_dev_batch_t *b);
 /* Kernel routing knob (process-wide; results never depend on it): alignments of the 4-pair / 8-pair one-wavefront classes (traceback pitch <= 496 /
  * <= 1008 lanes) with at least rows4 / rows8 DP rows (qlen + tlen - 1) run on the stripe-pipelined multi-wave kernel (csrc/ksw_stripe_kernel.h), like
  * every wider hull does. 0 = never, < 0 = leave that threshold as it is; on = 0 switches the stripe classes off altogether (the barrier-per-row
- * kernels of round 3), 2 = on with the sixteen-wavefront geometries (<1,16> / <2,16>: one / two lane pairs per wavefront for hulls up to 1920 / 3840
- * lanes; WM_KSW_STRIPE16=1), < 0 = leave. Defaults: WM_KSW_STRIPE_ROWS4 / WM_KSW_STRIPE_ROWS8 / WM_KSW_STRIPE from the environment. Not part of the
+ * kernels of round 3), 2 = on with the sixteen-wavefront geometries (<2,16>: two lane pairs per wavefront for hulls of 1793..3840 lanes instead of
+ * four; <1,16> for the long jobs of the one-wavefront classes; environment: WM_KSW_STRIPE16 = 1 | 2 | 3, bits in that order), < 0 = leave. Defaults: WM_KSW_STRIPE_ROWS4 / WM_KSW_STRIPE_ROWS8 / WM_KSW_STRIPE from the environment. Not part of the
  * reference's interface: tests force every job through every kernel with it, tools/ tune the thresholds. */
 void wm_ksw_set_routing(int on, int rows4, int rows8);
 

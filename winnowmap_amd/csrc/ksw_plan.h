@@ -10,7 +10,7 @@ enum {            // register classes (ksw_dp_packed<BP,...>): klass = window*8 
 	// stripe-pipelined multi-wave kernels (ksw_stripe_kernel.h): klass = WM_KSW_STRIPE + geometry * 4 + CLIP * 2 + HASN (a job with an N runs on the
 	// CLIP instantiation: 1 is unused); geometry 0..3 = <BP, NWV> of <2,4> <2,8> <4,8> <8,8>: traceback pitch n_col up to 768 / 1792 / 3584 / 7168;
 	// geometry 4, 5 = <1,16> <2,16> (up to 1920 / 3840 lanes): half the pairs per wavefront for the same hull — the cells of a row are the largest
-	// share of a stripe wavefront's row time (profiles/r04q_stripe_timing.txt). Opt-in (wide16 of wm_ksw_route) until the bench has judged them.
+	// share of a stripe wavefront's row time (profiles/r04q_stripe_timing.txt). Opt-in (wide16 of wm_ksw_route) until a bench A/B has judged them.
 	WM_KSW_STRIPE = 28, WM_KSW_NCLASS = 52
 };
 static const int wm_ksw_stripe_max_ncol[6] = { 3 * 256, 7 * 256, 7 * 512, 7 * 1024, 15 * 128, 15 * 256 };      // ksw_stripe_lds<BP, NWV>::MAX_NCOL
@@ -27,10 +27,11 @@ static inline int wm_ksw_route(int klass, int n_col, int qlen, int tlen, int w, 
 	if (klass < WM_KSW_P8) { if (!min_rows4 || n_rows < min_rows4) return klass; geom = 0; }
 	else if (klass < WM_KSW_P16) { if (!min_rows8 || n_rows < min_rows8) return klass; geom = n_col <= wm_ksw_stripe_max_ncol[0] ? 0 : 1; }
 	else geom = n_col <= wm_ksw_stripe_max_ncol[1] ? 1 : n_col <= wm_ksw_stripe_max_ncol[2] ? 2 : n_col <= wm_ksw_stripe_max_ncol[3] ? 3 : -1;
-	if (wide16 && geom >= 0) {                               // sixteen wavefronts: one pair each up to 1920 lanes, two up to 3840
-		if (n_col <= wm_ksw_stripe_max_ncol[4]) geom = 4;
-		else if (n_col <= wm_ksw_stripe_max_ncol[5]) geom = 5;
-	}
+	// sixteen wavefronts (opt-in, bits of wide16; isolated probe, profiles/r04q_stripe_timing.txt): bit 0 = <2,16> for the hulls <4,8> serves (1793..3584
+	// lanes, and up to 3840): 2.03 vs 2.54 us per row exact, 1.56 vs 1.93 approximate; bit 1 = <1,16> for the long jobs of the one-wavefront classes
+	// (hull <= 1008 lanes): 1.88 vs 2.04 / 1.29 vs 1.45. Hulls of 1009..1792 lanes stay on <2,8>: one pair per wavefront was slower there (3.47 vs 2.38).
+	if ((wide16 & 1) && geom >= 0 && n_col > wm_ksw_stripe_max_ncol[1] && n_col <= wm_ksw_stripe_max_ncol[5]) geom = 5;
+	if ((wide16 & 2) && geom >= 0 && klass < WM_KSW_P16) geom = 4;
 	if (geom < 0) return klass;                              // (7169..8176 lanes: stays on ksw_dp_pmulti<8,8>)
 	const int clip = !(w >= qlen && w >= tlen) || has_n;
 	return WM_KSW_STRIPE + geom * 4 + clip * 2 + (has_n ? 1 : 0);

@@ -528,7 +528,7 @@ static int stripe_min_rows(int bp)
 	if (g_stripe_on.load(std::memory_order_relaxed) < 0) {
 		g_stripe_rows4 = getenv("WM_KSW_STRIPE_ROWS4") ? std::max(0, atoi(getenv("WM_KSW_STRIPE_ROWS4"))) : 0;
 		g_stripe_rows8 = getenv("WM_KSW_STRIPE_ROWS8") ? std::max(0, atoi(getenv("WM_KSW_STRIPE_ROWS8"))) : 4096;      // (3 000-row extensions are faster on one wavefront, 10 000-row ones on four: profiles/r04c_probe.txt)
-		g_stripe_wide16 = getenv("WM_KSW_STRIPE16") && atoi(getenv("WM_KSW_STRIPE16")) > 0;      // <1,16> / <2,16> instead of <2,4> / <2,8> / <4,8> (opt-in)
+		g_stripe_wide16 = getenv("WM_KSW_STRIPE16") ? atoi(getenv("WM_KSW_STRIPE16")) & 3 : 0;      // opt-in, bits: 1 = <2,16> instead of <4,8>, 2 = <1,16> for long narrow jobs (ksw_plan.h)
 		g_stripe_on = !(getenv("WM_KSW_STRIPE") && atoi(getenv("WM_KSW_STRIPE")) == 0);
 	}
 	return !g_stripe_on.load(std::memory_order_relaxed) ? 0 : bp == 4 ? g_stripe_rows4.load(std::memory_order_relaxed) : bp == 8 ? g_stripe_rows8.load(std::memory_order_relaxed) : 1;   // (bp == 0: are the stripe classes on at all)
@@ -536,7 +536,7 @@ static int stripe_min_rows(int bp)
 extern "C" void wm_ksw_set_routing(int on, int rows4, int rows8)
 {
 	stripe_min_rows(0);
-	if (on >= 0) { g_stripe_on = on != 0; g_stripe_wide16 = on >= 2; }      // (on = 2: with the sixteen-wavefront geometries)
+	if (on >= 0) { g_stripe_on = on != 0; g_stripe_wide16 = on >= 2 ? 3 : 0; }      // (on = 2: with both sixteen-wavefront geometries)
 	if (rows4 >= 0) g_stripe_rows4 = rows4;
 	if (rows8 >= 0) g_stripe_rows8 = rows8;
 }
