@@ -118,3 +118,19 @@ def test_exported_ksw_ll_i16_equals_the_references():
         qe, te = C.c_int(), C.c_int()
         s = L.wm_ksw_ll_i16(len(q), q, len(t), t, mat, go, ge, C.byref(qe), C.byref(te))
         assert (s, qe.value, te.value) == W.r_ksw_ll(q, t, mat, go, ge), it
+
+
+def test_round4_entry_points_refuse_bad_arguments_without_touching_a_device(lib):
+    """argument checks of the entry points added in round 4 run before any device call: they must answer WM_EINVAL (-2) with a message, on any box"""
+    lib.wm_map_file_multi.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int64, C.c_void_p]
+    assert lib.wm_map_file_multi(None, 0, b"reads.fa", b"-", 0, None) == -2 and lib.wm_last_error()
+    lib.wm_debug_stripe_timing.argtypes = [C.c_void_p, C.c_int]
+    out = np.zeros(16, np.uint64)
+    assert lib.wm_debug_stripe_timing(out.ctypes.data, 0) == -2          # the shipped library is not the WM_STRIPE_TIMING variant
+    assert b"WM_STRIPE_TIMING" in lib.wm_last_error()
+    lib.wm_ksw_batch_pos_zd.argtypes = [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p, C.c_void_p]
+    assert lib.wm_ksw_batch_pos_zd(None, None, 3, None, None, None, 0, None, None) == -2
+    lib.wm_ksw_set_routing(-1, -1, -1)                                    # (leaves everything as it is; must not need a device)
+    lib.wm_set_cmdline.argtypes = [C.c_int, C.c_void_p]
+    lib.wm_set_cmdline(-1, None)
+    lib.wm_set_cmdline(0, None)
