@@ -354,9 +354,21 @@ def main():
     # the warm-up; the JSON line says how many timed steps ran on batches first seen inside the timed region — all batches have the same shape, so
     # what a first sight costs is the growth of pinned pools / result buffers to this batch's hit count)
     n_distinct = min(n_steps, int(os.environ.get("WM_BENCH_DISTINCT_BATCHES", 4)))
-    reads, _ = synth.make_reads(ref, n_distinct * args.reads_per_step, args.read_len, cfg["seed"] + 1000 * rank, profile=cfg["profile"], sv_frac=cfg["sv_frac"])
-    seqs = [synth.codes_to_ascii(r) for r in reads]
-    del reads
+    # WM_BENCH_CACHE=<dir>: A/B runs of one GPU call share the generated reads (same seeds = same reads; only the generation time is saved)
+    cache = os.environ.get("WM_BENCH_CACHE")
+    cpath = os.path.join(cache, "reads_c%d_r%d_n%d_l%d_m%d.npz" % (args.config, rank, n_distinct * args.reads_per_step, args.read_len, int(args.ref_mb))) if cache else None
+    if cpath and os.path.exists(cpath):
+        z = np.load(cpath)
+        blob, ends = z["blob"].tobytes(), z["ends"]
+        seqs = [blob[(ends[i - 1] if i else 0):ends[i]] for i in range(len(ends))]
+        del blob
+    else:
+        reads, _ = synth.make_reads(ref, n_distinct * args.reads_per_step, args.read_len, cfg["seed"] + 1000 * rank, profile=cfg["profile"], sv_frac=cfg["sv_frac"])
+        seqs = [synth.codes_to_ascii(r) for r in reads]
+        del reads
+        if cpath:
+            os.makedirs(cache, exist_ok=True)
+            np.savez(cpath, blob=np.frombuffer(b"".join(seqs), np.uint8), ends=np.cumsum([len(x) for x in seqs]))
     names = [("r%d_%d" % (rank, i)).encode() for i in range(len(seqs))]
     distinct = [(names[i * args.reads_per_step:(i + 1) * args.reads_per_step], seqs[i * args.reads_per_step:(i + 1) * args.reads_per_step]) for i in range(n_distinct)]
     marshalled = [gpu.Mapper.marshal(*d) for d in distinct]       # the C argument arrays of wm_map_reads, built once (not the mapper's work)
@@ -417,6 +429,9 @@ def main():
     hs0 = mapper.host_stats()
     thr0 = cgroup_throttle()
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    if os.environ.get("SPROF_MARK"):        # tools/sprof: keep only the samples of the timed region and what follows it
+        import signal
+        os.kill(os.getpid(), signal.SIGUSR2)
     t_start = time.time()
     hits, bases = run_steps(mbatches[args.warmup:])
     sync()

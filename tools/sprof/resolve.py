@@ -19,6 +19,13 @@ def symtab(path):
 def main():
     f = sys.argv[1]; top = int(sys.argv[2]) if len(sys.argv) > 2 else 45
     per_mod = collections.Counter(); per_fn = collections.Counter(); tabs = {}; total = 0
+    hints = collections.defaultdict(list); main_exe = None
+    for l in open(f):
+        if l.startswith("#sym "):
+            _, path, off, name = l.split()
+            hints[os.path.basename(path)].append((int(off, 16), name + " [resolved]"))
+        elif l.startswith("#main "):
+            main_exe = l.split(" ", 1)[1].strip()
     for l in open(f):
         if l.startswith("#"):
             continue
@@ -27,6 +34,8 @@ def main():
         mod = os.path.basename(path)
         per_mod[mod] += n
         local = path if os.path.exists(path) else None
+        if path == "[main]" and main_exe and os.path.exists(main_exe):
+            local = main_exe
         if local is None:
             for cand in ("winnowmap_amd/" + mod, "oracle/_ref/" + mod):
                 if os.path.exists(cand):
@@ -34,7 +43,9 @@ def main():
         if local is None:
             per_fn[(mod, "?")] += n; continue
         if local not in tabs:
-            tabs[local] = symtab(local)
+            a_, n_ = symtab(local)
+            merged = sorted(list(zip(a_, n_)) + hints.get(mod, []))
+            tabs[local] = ([x[0] for x in merged], [x[1] for x in merged])
         a, names = tabs[local]
         i = bisect.bisect_right(a, off) - 1
         per_fn[(mod, names[i] if i >= 0 else "?")] += n

@@ -27,6 +27,7 @@ void on_prof(int, siginfo_t *, void *uc_)
 	const size_t i = g_n.fetch_add(1, std::memory_order_relaxed);
 	if (i < CAP) g_pc[i] = (void*)uc->uc_mcontext.gregs[REG_RIP];
 }
+void on_mark(int) { g_n.store(0, std::memory_order_relaxed); }      // SIGUSR2 (raise(SIGUSR2) in the profiled program): forget what was sampled so far
 struct Mod { uintptr_t lo, hi, base; std::string path; };
 std::vector<Mod> g_mods;
 int on_phdr(struct dl_phdr_info *info, size_t, void *)
@@ -60,7 +61,18 @@ void finish()
 		for (const Mod &m : g_mods) if (pc >= m.lo && pc < m.hi) { hit = &m; break; }
 		if (hit) ++cnt[std::make_pair(hit->path, pc - hit->base)]; else ++cnt[std::make_pair(std::string("[unknown]"), pc)];
 	}
-	fprintf(f, "# samples %zu (1 ms of process CPU time each)\n", n);
+	fprintf(f, "# samples %zu (one per tick of process CPU time: 1 ms asked, the kernel's HZ decides)\n", n);
+	{   // the resolved addresses of libc's IFUNC routines (memcpy and friends live under local symbols that nm -D does not list: without these
+		// hints their samples are booked on whatever exported symbol happens to precede them)
+		static const char *names[] = { "memcpy", "memmove", "memset", "memcmp", "memchr", "strlen", "strcmp", "strchr", "malloc", "free", "realloc", "calloc", "mprotect", "madvise", "brk", "sbrk", "mmap", "munmap", 0 };
+		for (int i = 0; names[i]; ++i) {
+			const uintptr_t a = (uintptr_t)dlsym(RTLD_DEFAULT, names[i]);
+			if (!a) continue;
+			for (const Mod &m : g_mods) if (a >= m.lo && a < m.hi) { fprintf(f, "#sym %s %zx %s\n", m.path.c_str(), (size_t)(a - m.base), names[i]); break; }
+		}
+		char exe[4096]; const ssize_t k = readlink("/proc/self/exe", exe, sizeof(exe) - 1);
+		if (k > 0) { exe[k] = 0; fprintf(f, "#main %s\n", exe); }
+	}
 	for (const auto &kv : cnt) fprintf(f, "%s %zx %zu\n", kv.first.first.c_str(), (size_t)kv.first.second, kv.second);
 	fclose(f);
 }
@@ -71,6 +83,9 @@ __attribute__((constructor)) void start()
 	struct sigaction sa; memset(&sa, 0, sizeof(sa));
 	sa.sa_sigaction = on_prof; sa.sa_flags = SA_SIGINFO | SA_RESTART;
 	sigaction(SIGPROF, &sa, 0);
+	struct sigaction sm; memset(&sm, 0, sizeof(sm));
+	sm.sa_handler = on_mark; sm.sa_flags = SA_RESTART;
+	sigaction(SIGUSR2, &sm, 0);
 	struct itimerval it; it.it_interval.tv_sec = 0; it.it_interval.tv_usec = 1000; it.it_value = it.it_interval;
 	setitimer(ITIMER_PROF, &it, 0);
 	atexit(finish);

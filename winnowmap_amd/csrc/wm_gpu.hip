@@ -428,6 +428,32 @@ static hipEvent_t device_base_event(int device)
 	return ev[device];
 }
 
+// WM_CU_SPLIT=N (experiment, default 0 = off): the latency-bound alignment classes (the side streams of heavy / huge ksw calls: stripe kernels, long exact
+// extensions) get N compute units of their own and everything else — the contexts' main streams and the light calls' side streams — the other 256 - N, so
+// that a serial chain of a few hundred wavefronts never shares a SIMD with eight throughput wavefronts (VERDICT r4 item 2 iii). Mask bit i is compute unit
+// i / 8 of XCD i % 8 (the driver deals the bits round-robin over the XCDs), so [0, N) takes N / 8 units of every XCD. Masked streams are created
+// without hipStreamNonBlocking by the runtime (they synchronise with the NULL stream): nothing on the mapping path uses the NULL stream.
+static int cu_split() { static const int v = getenv("WM_CU_SPLIT") ? std::max(0, std::min(248, atoi(getenv("WM_CU_SPLIT")) / 8 * 8)) : 0; return v; }
+static hipError_t make_stream(hipStream_t *st, int cu_lo, int cu_hi)
+{
+	int n_cu = 0;
+	hipDeviceProp_t prop;
+	int dev = 0;
+	if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+	if (cu_lo <= 0 && (cu_hi < 0 || cu_hi >= n_cu || n_cu <= 0)) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+	if (cu_hi < 0 || cu_hi > n_cu) cu_hi = n_cu;
+	std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
+	for (int i = cu_lo; i < cu_hi; ++i) mask[(size_t)i >> 5] |= 1u << (i & 31);
+	return hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
+}
+// how the mapper's side-stream pool of P streams is divided among light | heavy | huge ksw calls (WM_SIDE_SPLIT=light,heavy; the rest = huge)
+static void side_split(int P, int *light, int *heavy)
+{
+	int a = (P * 3 + 3) / 7, h = (P * 2 + 3) / 7;           // 14 streams: 6 | 4 | 4 (profiles/r04g_sched_sweep.txt); 10: 4 | 3 | 3
+	if (const char *e = getenv("WM_SIDE_SPLIT")) sscanf(e, "%d,%d", &a, &h);
+	*light = std::max(0, a); *heavy = std::max(0, h);
+}
+
 extern "C" int wm_device_count(void)
 {
 	int n = 0;
@@ -784,7 +810,7 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	int n_nonempty = 0, used_mask = 0, rr = 0;
 	for (int k = 0; k < WM_KSW_NCLASS; ++k) n_nonempty += !b->order[k].empty();
 	static const int n_side = std::max(0, std::min(4, getenv("WM_SIDE_STREAMS") ? atoi(getenv("WM_SIDE_STREAMS")) : 3));   // contexts x (1 + side streams) should not exceed the hardware queues
-	const bool fan = n_nonempty > 1 && !trace_k && n_side > 0;
+	bool fan = n_nonempty > 1 && !trace_k && n_side > 0;
 	if (fan) HIPCHK(hipEventRecord(c->kev[4], c->stream));
 	hipStream_t ks = c->stream;
 	hipStream_t side[4] = {0, 0, 0, 0};          // the side streams of this call: from the mapper's pool, else the context's own
@@ -796,11 +822,7 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	if (c->side_pool && c->n_side_pool >= 6) {
 		static const long heavy_units = getenv("WM_KSW_HEAVY_UNITS") ? atol(getenv("WM_KSW_HEAVY_UNITS")) : 8192, huge_units = getenv("WM_KSW_HUGE_UNITS") ? atol(getenv("WM_KSW_HUGE_UNITS")) : 131072;
 		static int split_l = -1, split_h = -1;
-		if (split_l < 0) {
-			int a = (c->n_side_pool * 3 + 3) / 7, h = (c->n_side_pool * 2 + 3) / 7;           // 14 streams: 6 | 4 | 4 (profiles/r04g_sched_sweep.txt); 10: 4 | 3 | 3
-			if (const char *e = getenv("WM_SIDE_SPLIT")) sscanf(e, "%d,%d", &a, &h);
-			split_h = std::max(0, h); split_l = std::max(0, a);
-		}
+		if (split_l < 0) { int a, h; side_split(c->n_side_pool, &a, &h); split_h = h; split_l = a; }
 		if (split_l > 0 && split_h > 0 && split_l + split_h < c->n_side_pool) {
 			long mx = 0;
 			for (const wm_ksw_djob_t &d : b->jobs) {
@@ -815,6 +837,7 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		}
 	}
 	const int n_use = c->side_pool ? std::min(n_side, pool_n) : n_side;
+	if (!fan && cu_split() > 0 && wclass > 0 && c->side_pool && n_use > 0 && !trace_k) { fan = true; HIPCHK(hipEventRecord(c->kev[4], c->stream)); }   // (even a single class: the main stream runs on the other CUs)
 	if (fan && n_use > 0) {
 		if (c->side_pool) { const unsigned b0 = c->side_next[wclass].fetch_add((unsigned)n_use); for (int i = 0; i < n_use; ++i) side[i] = c->side_pool[pool_lo + (int)((b0 + (unsigned)i) % (unsigned)pool_n)]; }
 		else for (int i = 0; i < n_use; ++i) { if (!c->kstream[i]) HIPCHK(hipStreamCreateWithFlags(&c->kstream[i], hipStreamNonBlocking)); side[i] = c->kstream[i]; }
@@ -2712,6 +2735,8 @@ struct GpuOps {                          // the device contexts of a mapper, sha
 	// The read codes of a mini-batch go to the device once. Up to WM_MAX_SLOTS mini-batches can be in flight (concurrent mapping calls, one slot each): one
 	// allocation of WM_MAX_SLOTS slabs, owned by the first context and aliased by the others (one device); a call's offsets start at slot * slab.
 	std::mutex reads_mu;
+	hipStream_t up_stream = 0;                  // uploads of the mini-batches' read codes
+	~GpuOps() { if (up_stream) hipStreamDestroy(up_stream); }
 	size_t slab = 0;
 	bool slot_busy[WM_MAX_SLOTS] = { false };
 	bool load_reads(const uint8_t *codes, size_t n, int slot, int64_t *base, std::string &err)
@@ -2735,7 +2760,10 @@ struct GpuOps {                          // the device contexts of a mapper, sha
 				c->d_reads = c0->d_reads; c->reads_bytes = c0->reads_bytes; c->reads_cap = 0; c->owns_reads = false;
 			}
 		}
-		if (n && hipMemcpy(c0->d_reads + (size_t)slot * slab, codes, n, hipMemcpyHostToDevice) != hipSuccess) { err = std::string("reads upload: ") + hipGetErrorString(hipGetLastError()); return false; }
+		// (a stream of its own, not the NULL stream: a NULL-stream copy waits for every blocking stream of the device and makes them wait for it)
+		if (!up_stream && hipStreamCreateWithFlags(&up_stream, hipStreamNonBlocking) != hipSuccess) { up_stream = 0; (void)hipGetLastError(); }
+		if (n && (up_stream ? (hipMemcpyAsync(c0->d_reads + (size_t)slot * slab, codes, n, hipMemcpyHostToDevice, up_stream) != hipSuccess || hipStreamSynchronize(up_stream) != hipSuccess)
+		                    : hipMemcpy(c0->d_reads + (size_t)slot * slab, codes, n, hipMemcpyHostToDevice) != hipSuccess)) { err = std::string("reads upload: ") + hipGetErrorString(hipGetLastError()); return false; }
 		for (GpuOpsCtx &x : ctxs) x.resident = true;
 		slot_busy[slot] = true;
 		*base = (int64_t)((size_t)slot * slab);
@@ -2933,8 +2961,22 @@ extern "C" int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena
 		if (C == 1) P = 0;                                   // a single context keeps its own side streams
 		wm_ctx_t *c0 = m->c;                                  // (the pool lives and dies with the mapper's first context)
 		HIPCHK(hipStreamSynchronize(c0->stream));
+		const int split = cu_split();
+		if (split > 0) {                                      // (experiment: every stream of the mapper is re-made with its half of the chip)
+			for (hipStream_t st : c0->owned_pool) hipStreamDestroy(st);
+			c0->owned_pool.clear();
+			std::vector<wm_ctx_t*> all; all.push_back(c0); all.insert(all.end(), m->workers.begin(), m->workers.end());
+			for (wm_ctx_t *x : all) { HIPCHK(hipStreamSynchronize(x->stream)); HIPCHK(hipStreamDestroy(x->stream)); HIPCHK(make_stream(&x->stream, split, -1)); }
+		}
+		int sp_l = 0, sp_h = 0;
+		side_split(P, &sp_l, &sp_h);
 		while ((int)c0->owned_pool.size() > P) { hipStreamDestroy(c0->owned_pool.back()); c0->owned_pool.pop_back(); }
-		while ((int)c0->owned_pool.size() < P) { hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); c0->owned_pool.push_back(st); }
+		while ((int)c0->owned_pool.size() < P) {
+			hipStream_t st;
+			const bool latency_side = split > 0 && (int)c0->owned_pool.size() >= sp_l;        // heavy | huge part of the pool
+			HIPCHK(split > 0 ? (latency_side ? make_stream(&st, 0, split) : make_stream(&st, split, -1)) : hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+			c0->owned_pool.push_back(st);
+		}
 		c0->side_pool = P > 0 ? c0->owned_pool.data() : 0; c0->n_side_pool = P; c0->side_next = c0->owned_next;
 		for (wm_ctx_t *w : m->workers) { w->side_pool = c0->side_pool; w->n_side_pool = P; w->side_next = c0->owned_next; }
 	}
