@@ -232,6 +232,20 @@ int h_parallel_tasks_selftest(int n_threads, int n)
 	if (n >= 2 && hook.chunk_seen != 1) return -3;          // coarse tasks ask the hook for chunks of one
 	return tl_par_chunk() == 0 ? 0 : -4;
 }
+// the vectorised host routines against their portable specifications (wm_align.cpp): ksw_ll_i16 and the scan of mm_update_extra
+int h_extra_walk_both(const uint8_t *q, const uint8_t *t, const uint32_t *cigar, int n_cigar, int match, int mismatch, int ambi, int gq, int ge, int32_t *fast6, int32_t *generic6)
+{
+	wm::extra_walk_both(q, t, cigar, n_cigar, match, mismatch, ambi, gq, ge, fast6, generic6);
+	return 0;
+}
+int h_ll_i16_portable(int qlen, const uint8_t *q, int tlen, const uint8_t *t, const int8_t *mat, int gapo, int gape, int *qe, int *te)
+{
+#if defined(__SSE2__)
+	return ll_i16_portable(qlen, q, tlen, t, mat, gapo, gape, qe, te);
+#else
+	return ll_i16(qlen, q, tlen, t, mat, gapo, gape, qe, te);
+#endif
+}
 int h_ll_i16(int qlen, const uint8_t *q, int tlen, const uint8_t *t, const int8_t *mat, int gapo, int gape, int *qe, int *te) { return ll_i16(qlen, q, tlen, t, mat, gapo, gape, qe, te); }
 
 int64_t h_chain_extract(int64_t n, const uint64_t *ax, const uint64_t *ay, const int32_t *f, const int32_t *p, const int32_t *v, int min_cnt, int min_sc,

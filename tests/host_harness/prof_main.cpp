@@ -9,6 +9,7 @@
 #include <unordered_map>
 #include <sys/resource.h>
 #include <signal.h>
+#include <malloc.h>
 
 static inline uint64_t mix64(uint64_t h, uint64_t v) { h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); h *= 0xff51afd7ed558ccdull; return h ^ (h >> 29); }
 static uint64_t hash_bytes(const void *p, size_t n, uint64_t h)
@@ -93,6 +94,7 @@ static double cpu_now() { rusage ru; getrusage(RUSAGE_SELF, &ru); return ru.ru_u
 
 int main(int argc, char **argv)
 {
+	if (!getenv("NO_MALLOPT")) { mallopt(M_TOP_PAD, 64 << 20); mallopt(M_TRIM_THRESHOLD, 0x7fffffff); mallopt(M_MMAP_THRESHOLD, 32 << 20); }   // (what libwmgpu.so sets for the product)
 	if (argc < 4) { fprintf(stderr, "usage: prof_main ref.fa rep.txt reads.fa [n_reads] [preset]   (env: THREADS, REPLAYS, LATENCY_MS, FORMAT=1)\n"); return 1; }
 	Harness *h = (Harness*)h_index_build(argv[1], argv[2], 15, 50, 8);
 	std::vector<std::string> names, seqs; std::string err;
@@ -121,6 +123,7 @@ int main(int argc, char **argv)
 		fprintf(stderr, "per read: %.1f chains (largest window %zu), %.0f chained anchors, %.0f CIGAR ops returned by the alignments\n", (double)nu / n, big, (double)na / n, (double)nc / n);
 	}
 	rp.replay = true;
+	if (prof_on()) { std::lock_guard<std::mutex> g(prof_mutex()); for (ProfSlot &sl : prof_slots()) sl.ms = 0, sl.n = 0; }      // (region timers: the replays only)
 	rp.latency_ms = getenv("LATENCY_MS") ? atof(getenv("LATENCY_MS")) : 0;
 	const bool do_format = getenv("FORMAT") && atoi(getenv("FORMAT"));
 	const int n_replays = getenv("REPLAYS") ? atoi(getenv("REPLAYS")) : 3;

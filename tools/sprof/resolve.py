@@ -26,6 +26,11 @@ def main():
             hints[os.path.basename(path)].append((int(off, 16), name + " [resolved]"))
         elif l.startswith("#main "):
             main_exe = l.split(" ", 1)[1].strip()
+    stk = []
+    for l in open(f):
+        if l.startswith("#stk "):
+            _, n, rest = l.rstrip("\n").split(" ", 2)
+            stk.append((int(n), [x.rsplit(" ", 1) for x in rest.split(" | ")]))
     for l in open(f):
         if l.startswith("#"):
             continue
@@ -56,6 +61,37 @@ def main():
     print("-- by function (self time)")
     for (m, fn), n in per_fn.most_common(top):
         print("  %6.2f %%  %8.1f s  %-22s %s" % (100.0 * n / total, n / 1e3, m, fn[:150]))
+
+    # callers: for the hottest leaf functions, the code addresses found on the stack above the sample (nearest symbols; not an unwound call chain)
+    if stk:
+        def sym(path, off):
+            mod = os.path.basename(path)
+            local = path if os.path.exists(path) else None
+            if path == "[main]" and main_exe and os.path.exists(main_exe):
+                local = main_exe
+            if local is None:
+                for cand in ("winnowmap_amd/" + mod, "oracle/_ref/" + mod):
+                    if os.path.exists(cand):
+                        local = cand
+            if local is None:
+                return mod + ":?"
+            if local not in tabs:
+                a_, n_ = symtab(local)
+                merged = sorted(list(zip(a_, n_)) + hints.get(mod, []))
+                tabs[local] = ([x[0] for x in merged], [x[1] for x in merged])
+            a, names = tabs[local]
+            i = bisect.bisect_right(a, int(off, 16)) - 1
+            return mod.split(".")[0] + ":" + (names[i][:60] if i >= 0 else "?")
+        leaf = collections.defaultdict(collections.Counter); leaf_tot = collections.Counter()
+        for n, chain in stk:
+            names = [sym(p_, o_) for p_, o_ in chain]
+            leaf_tot[names[0]] += n
+            leaf[names[0]][" <- ".join(names[1:5])] += n
+        print("-- stack words above the hottest leaves (nearest symbols)")
+        for lf, n in leaf_tot.most_common(8):
+            print("  %s  (%d samples)" % (lf, n))
+            for ch, m in leaf[lf].most_common(6):
+                print("      %5d  %s" % (m, ch))
 
 if __name__ == "__main__":
     main()

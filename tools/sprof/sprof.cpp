@@ -18,14 +18,20 @@
 #include <map>
 
 namespace {
-const size_t CAP = 4u << 20;
+const size_t CAP = 1u << 20;
+const int NSTK = 40;                     // stack words kept per sample: finish() keeps those that point into code = the callers, without unwind tables
 void **g_pc = 0;
+void **g_stk = 0;
 std::atomic<size_t> g_n(0);
 void on_prof(int, siginfo_t *, void *uc_)
 {
 	ucontext_t *uc = (ucontext_t*)uc_;
 	const size_t i = g_n.fetch_add(1, std::memory_order_relaxed);
-	if (i < CAP) g_pc[i] = (void*)uc->uc_mcontext.gregs[REG_RIP];
+	if (i < CAP) {
+		g_pc[i] = (void*)uc->uc_mcontext.gregs[REG_RIP];
+		void **sp = (void**)uc->uc_mcontext.gregs[REG_RSP];
+		for (int k = 0; k < NSTK; ++k) g_stk[i * NSTK + k] = sp[k];          // (the interrupted thread's own stack: mapped well beyond 40 words above rsp)
+	}
 }
 void on_mark(int) { g_n.store(0, std::memory_order_relaxed); }      // SIGUSR2 (raise(SIGUSR2) in the profiled program): forget what was sampled so far
 struct Mod { uintptr_t lo, hi, base; std::string path; };
@@ -74,12 +80,26 @@ void finish()
 		if (k > 0) { exe[k] = 0; fprintf(f, "#main %s\n", exe); }
 	}
 	for (const auto &kv : cnt) fprintf(f, "%s %zx %zu\n", kv.first.first.c_str(), (size_t)kv.first.second, kv.second);
+	// caller chains ("#stk <module> <offset> | <module> <offset> ..."): per sample the pc and the first stack words that point into executable code
+	std::map<std::string, size_t> chains;
+	for (size_t i = 0; i < n; ++i) {
+		std::string key;
+		char buf[4200];
+		int kept = 0;
+		for (int k = -1; k < NSTK && kept < 6; ++k) {
+			const uintptr_t v = k < 0 ? (uintptr_t)g_pc[i] : (uintptr_t)g_stk[i * NSTK + k];
+			for (const Mod &m : g_mods) if (v >= m.lo && v < m.hi) { snprintf(buf, sizeof(buf), "%s%s %zx", kept ? " | " : "", m.path.c_str(), (size_t)(v - m.base)); key += buf; ++kept; break; }
+		}
+		++chains[key];
+	}
+	for (const auto &kv : chains) fprintf(f, "#stk %zu %s\n", kv.second, kv.first.c_str());
 	fclose(f);
 }
 __attribute__((constructor)) void start()
 {
 	if (getenv("SPROF_OFF")) return;
 	g_pc = (void**)calloc(CAP, sizeof(void*));
+	g_stk = (void**)calloc(CAP * NSTK, sizeof(void*));
 	struct sigaction sa; memset(&sa, 0, sizeof(sa));
 	sa.sa_sigaction = on_prof; sa.sa_flags = SA_SIGINFO | SA_RESTART;
 	sigaction(SIGPROF, &sa, 0);

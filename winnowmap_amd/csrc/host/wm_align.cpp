@@ -4,11 +4,17 @@
 #include <math.h>
 #include <algorithm>
 #include <list>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
+#include <memory>
+#include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
 
 namespace wm {
 
+enum { WM_WALK_PAD = 16 };           // readable bytes behind every sequence extra_walk_fast walks
 enum { EZ_RIGHT = 0x02, EZ_APPROX_MAX = 0x08, EZ_EXTZ_ONLY = 0x40, EZ_REV_CIGAR = 0x80, EZ_SPLICE_FOR = 0x100, EZ_SPLICE_REV = 0x200, EZ_SPLICE_FLANK = 0x400 };   // src/ksw2.h:8-20
 
 static void gen_simple_mat(int8_t *mat, int a, int b, int sc_ambi)
@@ -26,7 +32,69 @@ namespace {
 inline int16_t sat_add(int a, int b) { const int s = a + b; return (int16_t)(s > 32767 ? 32767 : s < -32768 ? -32768 : s); }
 inline int16_t usub(int16_t a, int16_t b) { const uint16_t x = (uint16_t)a, y = (uint16_t)b; return (int16_t)(x > y ? x - y : 0); }
 }
+#if defined(__SSE2__)
+// the same machine on real 8 x int16 vectors (the host is x86-64 wherever the library runs today); the portable lane-by-lane form below is its
+// specification and what other hosts compile
 int ll_i16(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int gapo, int gape, int *qe, int *te)
+{
+	const int V = 8, slen = (qlen + V - 1) / V, n = slen * V;
+	if (slen <= 0) { *qe = *te = -1; return 0; }
+	std::vector<__m128i> buf((size_t)9 * slen + 1);
+	__m128i *profile = buf.data(), *Hprev = profile + (size_t)5 * slen, *Hcur = Hprev + slen, *E = Hcur + slen, *Hbest = E + slen;
+	{
+		int16_t *pr = (int16_t*)profile;
+		for (int a = 0; a < 5; ++a)
+			for (int j = 0; j < slen; ++j)
+				for (int l = 0; l < V; ++l) {
+					const int pos = j + l * slen;
+					pr[((size_t)a * slen + j) * V + l] = pos < qlen ? mat[a * 5 + query[pos]] : 0;
+				}
+	}
+	const __m128i zero = _mm_setzero_si128(), open_ext = _mm_set1_epi16((int16_t)(gapo + gape)), ext = _mm_set1_epi16((int16_t)gape);
+	for (int j = 0; j < slen; ++j) Hprev[j] = Hcur[j] = E[j] = Hbest[j] = zero;
+	int gmax = 0;
+	*qe = *te = -1;
+	for (int i = 0; i < tlen; ++i) {
+		const __m128i *S = profile + (size_t)target[i] * slen;
+		__m128i h = _mm_slli_si128(Hprev[slen - 1], 2), f = zero, best = zero;
+		for (int j = 0; j < slen; ++j) {
+			const __m128i e = E[j];
+			__m128i v = _mm_adds_epi16(h, S[j]);
+			v = _mm_max_epi16(v, e); v = _mm_max_epi16(v, f);
+			best = _mm_max_epi16(best, v);
+			Hcur[j] = v;
+			v = _mm_subs_epu16(v, open_ext);
+			E[j] = _mm_max_epi16(_mm_subs_epu16(e, ext), v);
+			f = _mm_max_epi16(_mm_subs_epu16(f, ext), v);
+			h = Hprev[j];
+		}
+		bool settled = false;
+		for (int k = 0; k < V && !settled; ++k) {              // lazy-F correction rounds
+			f = _mm_slli_si128(f, 2);
+			for (int j = 0; j < slen && !settled; ++j) {
+				__m128i v = _mm_max_epi16(Hcur[j], f);
+				Hcur[j] = v;
+				v = _mm_subs_epu16(v, open_ext);
+				f = _mm_subs_epu16(f, ext);
+				if (!_mm_movemask_epi8(_mm_cmpgt_epi16(f, v))) settled = true;
+			}
+		}
+		int16_t b8[8];
+		_mm_storeu_si128((__m128i*)b8, best);
+		int imax = b8[0];
+		for (int l = 1; l < V; ++l) imax = imax > b8[l] ? imax : b8[l];
+		if (imax >= gmax) { gmax = imax; *te = i; memcpy(Hbest, Hcur, (size_t)slen * sizeof(__m128i)); }
+		std::swap(Hprev, Hcur);
+	}
+	const int16_t *hb = (const int16_t*)Hbest;
+	for (int i = 0; i < n; ++i)
+		if ((int)(uint16_t)hb[i] == gmax) *qe = i / V + i % V * slen;
+	return gmax;
+}
+int ll_i16_portable(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int gapo, int gape, int *qe, int *te)
+#else
+int ll_i16(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int gapo, int gape, int *qe, int *te)
+#endif
 {
 	const int V = 8, slen = (qlen + V - 1) / V, n = slen * V;
 	std::vector<int16_t> profile((size_t)5 * n), Hprev(n, 0), Hcur(n, 0), E(n, 0), Hbest(n, 0);
@@ -351,6 +419,67 @@ static void fix_cigar(Reg &r, const uint8_t *qseq, const uint8_t *tseq, int *qsh
 	}
 }
 
+// wm_extra_walk (cigar_walk.h) with the match stretches compared 16 bases per step. An ONT alignment alternates M runs of a dozen bases with short
+// indels, so the eight-byte run finder of the generic walk spends its time in its byte tail; here one M run is usually one masked 16-byte
+// compare. Both sequences must be readable WM_WALK_PAD bytes beyond the aligned stretch (ref_codes and the two-strand buffer pad for it).
+// mm_update_extra was 15 % of the host's CPU samples in a bench run (gpurun_out/r05a/sprof_report.txt).
+#if defined(__SSE2__)
+static void extra_walk_fast(const uint8_t *qseq, const uint8_t *tseq, const uint32_t *cigar, int n_cigar, int match, int mismatch, int ambi, int q, int e, wm_extra_t *out)
+{
+	int32_t s = 0, max = 0, toff = 0, qoff = 0, blen = 0, mlen = 0, n_ambi_all = 0;
+	const __m128i three = _mm_set1_epi8(3);
+	for (int k = 0; k < n_cigar; ++k) {
+		const uint32_t op = cigar[k] & 0xf, len = cigar[k] >> 4;
+		if (op == 0) {
+			int n_ambi = 0, n_diff = 0;
+			const uint8_t *tp = tseq + toff, *qp = qseq + qoff;
+			for (uint32_t l0 = 0; l0 < len; l0 += 16) {
+				const uint32_t m = len - l0 < 16 ? len - l0 : 16;
+				const __m128i a = _mm_loadu_si128((const __m128i*)(tp + l0)), b = _mm_loadu_si128((const __m128i*)(qp + l0));
+				// a base is "plain" when both codes are equal and below 4 (codes are 0..4: x > 3 <=> x == 4)
+				const __m128i plain = _mm_andnot_si128(_mm_cmpgt_epi8(_mm_or_si128(a, b), three), _mm_cmpeq_epi8(a, b));
+				uint32_t bad = (uint32_t)(~_mm_movemask_epi8(plain)) & ((1u << m) - 1u);
+				uint32_t done = 0;
+				while (bad) {
+					const uint32_t p = (uint32_t)__builtin_ctz(bad);
+					bad &= bad - 1;
+					if (p > done) { s += (int32_t)(p - done) * match; max = max > s ? max : s; }
+					const int ct = tp[l0 + p], cq = qp[l0 + p];
+					if (ct > 3 || cq > 3) { ++n_ambi; s += ambi; }
+					else { ++n_diff; s += mismatch; }
+					if (s < 0) s = 0; else max = max > s ? max : s;
+					done = p + 1;
+				}
+				if (m > done) { s += (int32_t)(m - done) * match; max = max > s ? max : s; }
+			}
+			blen += (int32_t)len - n_ambi; mlen += (int32_t)len - (n_ambi + n_diff); n_ambi_all += n_ambi;
+			toff += len; qoff += len;
+		} else if (op == 1 || op == 2) {
+			const uint8_t *p = op == 1 ? qseq + qoff : tseq + toff;
+			int n_ambi = 0;
+			for (uint32_t l = 0; l < len; ++l) n_ambi += p[l] > 3;
+			blen += (int32_t)len - n_ambi; n_ambi_all += n_ambi;
+			s -= q + e * (int32_t)len;
+			if (s < 0) s = 0;
+			if (op == 1) qoff += len; else toff += len;
+		} else if (op == 3) toff += len;
+	}
+	out->dp_max = max; out->mlen = mlen; out->blen = blen; out->n_ambi = n_ambi_all; out->qoff = qoff; out->toff = toff;
+}
+#endif
+// test hook (tests/host_harness): the fast walk against the generic one
+void extra_walk_both(const uint8_t *qseq, const uint8_t *tseq, const uint32_t *cigar, int n_cigar, int match, int mismatch, int ambi, int q, int e, int32_t *fast6, int32_t *generic6)
+{
+	wm_extra_t a, b;
+	wm_extra_walk(qseq, tseq, cigar, n_cigar, match, mismatch, ambi, q, e, &b);
+#if defined(__SSE2__)
+	if (match > 0) extra_walk_fast(qseq, tseq, cigar, n_cigar, match, mismatch, ambi, q, e, &a); else a = b;
+#else
+	a = b;
+#endif
+	memcpy(fast6, &a, sizeof(a)); memcpy(generic6, &b, sizeof(b));
+}
+
 static void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int q, int e)
 {
 	WM_PROF("align.update_extra");   // mm_update_extra, src/align.c:240-286 (no =/X rewriting: MM_F_EQX is applied at output time if requested)
@@ -359,6 +488,10 @@ static void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const
 	fix_cigar(r, qseq, tseq, &qshift, &tshift);
 	qseq += qshift, tseq += tshift;
 	wm_extra_t x;
+#if defined(__SSE2__)
+	if (mat[0] > 0) extra_walk_fast(qseq, tseq, r.cigar.data(), (int)r.cigar.size(), mat[0], mat[1], mat[24], q, e, &x);
+	else
+#endif
 	wm_extra_walk(qseq, tseq, r.cigar.data(), (int)r.cigar.size(), mat[0], mat[1], mat[24], q, e, &x);
 	r.blen = x.blen; r.mlen = x.mlen; r.n_ambi += x.n_ambi; r.dp_max = x.dp_max;
 	const int32_t qoff = x.qoff, toff = x.toff; (void)qoff; (void)toff;
@@ -386,7 +519,7 @@ struct RegAln {
 static inline std::vector<uint8_t> ref_codes(const Index &idx, int rid, int st, int en)
 {
 	WM_PROF("align.ref_codes");
-	std::vector<uint8_t> t(en > st ? en - st : 0);
+	std::vector<uint8_t> t((en > st ? en - st : 0) + WM_WALK_PAD, 4);      // (+ padding: extra_walk_fast loads 16 bases at a time)
 	if (en > st) idx.getseq(rid, st, en, t.data());
 	return t;
 }
@@ -621,7 +754,7 @@ static bool align_inv(Scheduler &sch, const AlnEnv &E, const Reg &r1, const Reg 
 	if (tl < opt.min_chain_score || tl > opt.max_gap) return false;
 	std::vector<uint8_t> tseq = ref_codes(*E.idx, r1.rid, r1.re, r2.rs);
 	const uint8_t *qsrc = r1.rev ? &E.qseq0[0][r2.qe] : &E.qseq0[1][E.qlen - r2.qs];
-	std::vector<uint8_t> qr(ql), tr(tseq.rbegin(), tseq.rend());
+	std::vector<uint8_t> qr(ql), tr(tseq.rend() - tl, tseq.rend());      // (tseq carries padding behind its tl bases)
 	for (int i = 0; i < ql; ++i) qr[i] = qsrc[ql - 1 - i];
 	int q_off, t_off;
 	const int score = ll_i16(ql, qr.data(), tl, tr.data(), E.mat, opt.q, opt.e, &q_off, &t_off);
@@ -656,9 +789,20 @@ void align_skeleton(Scheduler &sch, const MapOpt &opt, const Index &idx, int qle
 	E.opt = &opt; E.idx = &idx; E.qlen = qlen; E.q_dev_off = q_dev_off; E.q_has_n = false;
 	// both strands in ONE buffer, reverse complement right behind the forward strand, exactly like the reference's
 	// qseq0 (src/align.c:871-877): mm_align1_inv may step a few bases in front of a strand (see align_inv)
-	std::vector<uint8_t> both((size_t)2 * qlen + 8, 4);
-	uint8_t *fw = both.data() + 8, *rc = fw + qlen;
-	for (int i = 0; i < qlen; ++i) { fw[i] = qcodes[i]; rc[qlen - 1 - i] = qcodes[i] < 4 ? 3 - qcodes[i] : 4; E.q_has_n |= qcodes[i] >= 4; }
+	// (three flat loops the compiler vectorises — a copy, a reversed complement, an OR-reduction — instead of one byte loop with two branches:
+	// that loop was 10 % of the host glue's CPU samples, tests/host_harness/prof.sh)
+	std::unique_ptr<uint8_t[]> both(new uint8_t[(size_t)2 * qlen + 8 + WM_WALK_PAD]);
+	memset(both.get(), 4, 8);
+	memset(both.get() + 8 + (size_t)2 * qlen, 4, WM_WALK_PAD);
+	uint8_t *fw = both.get() + 8, *rc = fw + qlen;
+	memcpy(fw, qcodes, (size_t)qlen);
+	{
+		const uint8_t *last = qcodes + qlen - 1;
+		unsigned any_n = 0;
+		for (int i = 0; i < qlen; ++i) { const uint8_t c = last[-i]; rc[i] = (uint8_t)(c < 4 ? 3 ^ c : 4); }      // (3 - c == 3 ^ c for c in 0..3)
+		for (int i = 0; i < qlen; ++i) any_n |= qcodes[i];
+		E.q_has_n = (any_n & 0xfc) != 0;
+	}
 	E.qseq0[0] = fw; E.qseq0[1] = rc;
 	gen_simple_mat(E.mat, opt.a, opt.b, opt.sc_ambi);
 	const int n_a = squeeze_a(regs, a);

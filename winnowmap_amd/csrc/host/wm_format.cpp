@@ -2,7 +2,17 @@
 #include <stdio.h>
 namespace wm {
 
-static void put_int(std::string &s, long long v) { char b[24]; int n = snprintf(b, sizeof(b), "%lld", v); s.append(b, n); }
+// decimal digits without printf: a record of a 15-kb read carries ~5 000 integers (one per CIGAR operation), and snprintf("%lld") for each of them was
+// a tenth of the host's CPU samples in a bench run (gpurun_out/r05a/sprof_report.txt: libc's vfprintf internals)
+static inline void put_int(std::string &s, long long v)
+{
+	char b[24];
+	int n = 24;
+	unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+	do { b[--n] = (char)('0' + u % 10); u /= 10; } while (u);
+	if (v < 0) b[--n] = '-';
+	s.append(b + n, (size_t)(24 - n));
+}
 
 void write_sam_header(std::string &s, const Index &idx, int argc, const char *const *argv)
 {
@@ -126,6 +136,7 @@ static void write_paf(std::string &s, const Index &idx, const ReadIn &t, const R
 	if (rep_len >= 0) { s += "\trl:i:"; put_int(s, rep_len); }
 	if (r->has_p && (flag & F_OUT_CG)) {
 		s += "\tcg:Z:";
+		s.reserve(s.size() + r->cigar.size() * 4 + 64);
 		for (uint32_t c : r->cigar) { put_int(s, c >> 4); s += "MIDNSHP=XB"[c & 0xf]; }
 	}
 	if (r->has_p && (flag & (F_OUT_CS | F_OUT_MD))) write_cs_or_md(s, idx, t, *r, flag);

@@ -85,9 +85,20 @@ void split_reg(Reg &r, Reg &r2, int n, int qlen, const m128 *a)
 	r.split |= 1; r2.split |= 2;
 }
 
-void set_parent(float mask_level, int mask_len, std::vector<Reg> &r, int sub_diff, int hard_mask_level)
+// The chain-level bookkeeping below (set_parent, select_sub, sync_regs) runs on every chain the chaining kernel returns — thousands per read in
+// repeats, nearly all of them dropped by select_sub — so it is written once over the element type: Reg, or the slim ChainRec that
+// gen_regs_select uses before any Reg is built.
+namespace {
+struct ChainRec {                       // the fields of a Reg that mm_set_parent / mm_select_sub / mm_sync_regs read or write, for a chain without an alignment
+	int32_t id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, n_sub;
+	uint32_t hash, rev, inv, sam_pri;
+	static constexpr bool has_p = false;
+	static constexpr int32_t dp_max = 0;
+	int32_t dp_max2;
+};
+
+template <class R> void set_parent_impl(float mask_level, int mask_len, std::vector<R> &r, int sub_diff, int hard_mask_level)
 {
-	WM_PROF("hit.set_parent");
 	const int n = (int)r.size();
 	if (n <= 0) return;
 	for (int i = 0; i < n; ++i) r[i].id = i;
@@ -96,7 +107,7 @@ void set_parent(float mask_level, int mask_len, std::vector<Reg> &r, int sub_dif
 	pri.push_back(0);
 	r[0].parent = 0;
 	for (int i = 1; i < n; ++i) {
-		Reg &ri = r[i];
+		R &ri = r[i];
 		const int si = ri.qs, ei = ri.qe;
 		int uncov = 0;
 		bool secondary = false;
@@ -123,7 +134,7 @@ void set_parent(float mask_level, int mask_len, std::vector<Reg> &r, int sub_dif
 		}
 		if (overlaps) {
 			for (int p : pri) {
-				Reg &rp = r[p];
+				R &rp = r[p];
 				const int sj = rp.qs, ej = rp.qe;
 				if (ej <= si || sj >= ei) continue;
 				const int mn = ej - sj < ei - si ? ej - sj : ei - si;
@@ -149,6 +160,59 @@ void set_parent(float mask_level, int mask_len, std::vector<Reg> &r, int sub_dif
 	}
 }
 
+template <class R> int set_sam_pri_impl(std::vector<R> &r)
+{
+	int n_pri = 0;
+	for (R &x : r) {
+		if (x.id == x.parent) { ++n_pri; x.sam_pri = (n_pri == 1); }
+		else x.sam_pri = 0;
+	}
+	return n_pri;
+}
+
+template <class R> void sync_regs_impl(std::vector<R> &r)
+{
+	const int n = (int)r.size();
+	if (n <= 0) return;
+	int max_id = -1;
+	for (const R &x : r) max_id = max_id > x.id ? max_id : x.id;
+	std::vector<int> where(max_id + 1 > 0 ? max_id + 1 : 0, -1);
+	for (int i = 0; i < n; ++i) if (r[i].id >= 0) where[r[i].id] = i;
+	for (int i = 0; i < n; ++i) {
+		R &x = r[i];
+		x.id = i;
+		if (x.parent == PARENT_TMP_PRI) x.parent = i;
+		else if (x.parent >= 0 && where[x.parent] >= 0) x.parent = where[x.parent];
+		else x.parent = PARENT_UNSET;
+	}
+	set_sam_pri_impl(r);
+}
+
+template <class R> void select_sub_impl(float pri_ratio, int min_diff, int best_n, std::vector<R> &r)
+{
+	if (!(pri_ratio > 0.0f) || r.empty()) return;
+	const int n = (int)r.size();
+	int k = 0, n_2nd = 0;
+	for (int i = 0; i < n; ++i) {
+		const int p = r[i].parent;
+		bool keep = false;
+		if (p == i || r[i].inv) keep = true;
+		else if ((r[i].score >= r[p].score * pri_ratio || r[i].score + min_diff >= r[p].score) && n_2nd < best_n) {
+			// NB: r[p] may already have been overwritten by compaction in the reference too (p < i, r[k++]=r[i])
+			if (!(r[i].qs == r[p].qs && r[i].qe == r[p].qe && r[i].rid == r[p].rid && r[i].rs == r[p].rs && r[i].re == r[p].re)) { keep = true; ++n_2nd; }
+		}
+		if (keep) { if (k != i) r[k] = r[i]; ++k; }
+	}
+	if (k != n) { r.resize(k); sync_regs_impl(r); }
+}
+} // namespace
+
+void set_parent(float mask_level, int mask_len, std::vector<Reg> &r, int sub_diff, int hard_mask_level)
+{
+	WM_PROF("hit.set_parent");
+	set_parent_impl(mask_level, mask_len, r, sub_diff, hard_mask_level);
+}
+
 void hit_sort(std::vector<Reg> &r)
 {
 	WM_PROF("hit.hit_sort");
@@ -170,51 +234,62 @@ void hit_sort(std::vector<Reg> &r)
 	r.swap(t);
 }
 
-int set_sam_pri(std::vector<Reg> &r)
-{
-	int n_pri = 0;
-	for (Reg &x : r) {
-		if (x.id == x.parent) { ++n_pri; x.sam_pri = (n_pri == 1); }
-		else x.sam_pri = 0;
-	}
-	return n_pri;
-}
+int set_sam_pri(std::vector<Reg> &r) { return set_sam_pri_impl(r); }
 
-void sync_regs(std::vector<Reg> &r)
-{
-	const int n = (int)r.size();
-	if (n <= 0) return;
-	int max_id = -1;
-	for (const Reg &x : r) max_id = max_id > x.id ? max_id : x.id;
-	std::vector<int> where(max_id + 1 > 0 ? max_id + 1 : 0, -1);
-	for (int i = 0; i < n; ++i) if (r[i].id >= 0) where[r[i].id] = i;
-	for (int i = 0; i < n; ++i) {
-		Reg &x = r[i];
-		x.id = i;
-		if (x.parent == PARENT_TMP_PRI) x.parent = i;
-		else if (x.parent >= 0 && where[x.parent] >= 0) x.parent = where[x.parent];
-		else x.parent = PARENT_UNSET;
-	}
-	set_sam_pri(r);
-}
+void sync_regs(std::vector<Reg> &r) { sync_regs_impl(r); }
 
 void select_sub(float pri_ratio, int min_diff, int best_n, std::vector<Reg> &r)
 {
 	WM_PROF("hit.select_sub");
-	if (!(pri_ratio > 0.0f) || r.empty()) return;
-	const int n = (int)r.size();
-	int k = 0, n_2nd = 0;
-	for (int i = 0; i < n; ++i) {
-		const int p = r[i].parent;
-		bool keep = false;
-		if (p == i || r[i].inv) keep = true;
-		else if ((r[i].score >= r[p].score * pri_ratio || r[i].score + min_diff >= r[p].score) && n_2nd < best_n) {
-			// NB: r[p] may already have been overwritten by compaction in the reference too (p < i, r[k++]=r[i])
-			if (!(r[i].qs == r[p].qs && r[i].qe == r[p].qe && r[i].rid == r[p].rid && r[i].rs == r[p].rs && r[i].re == r[p].re)) { keep = true; ++n_2nd; }
-		}
-		if (keep) { if (k != i) r[k] = r[i]; ++k; }
+	select_sub_impl(pri_ratio, min_diff, best_n, r);
+}
+
+// gen_regs + set_parent + select_sub (src/map.c:256-262 after mm_gen_regs, :375) with the same result, for the usual case that most chains are dropped:
+// the three steps run on ChainRec (64 bytes, coordinates only) and a Reg — with its fuzzy lengths, a walk over the chain's anchors — is built for
+// the survivors alone. A stage-1 window in a repeat returns thousands of chains of which select_sub keeps a handful: building and ordering full
+// Regs for all of them was a third of the host glue's CPU time (tests/host_harness/prof.sh).
+std::vector<Reg> gen_regs_select(uint32_t hash, int qlen, int n_u, const uint64_t *u, const m128 *a, float mask_level, int mask_len, int sub_diff, int hard_mask_level,
+                                 float pri_ratio, int min_diff, int best_n)
+{
+	WM_PROF("hit.gen_regs_select");
+	std::vector<Reg> regs;
+	if (n_u == 0) return regs;
+	std::vector<m128> z(n_u);
+	for (int i = 0, k = 0; i < n_u; ++i) {
+		const uint32_t h = (uint32_t)hash64_full((hash64_full(a[k].x) + hash64_full(a[k].y)) ^ hash);
+		z[i].x = u[i] ^ h;
+		z[i].y = (uint64_t)k << 32 | (uint32_t)(int32_t)u[i];
+		k += (int32_t)u[i];
 	}
-	if (k != n) { r.resize(k); sync_regs(r); }
+	radix_sort_128x(z.data(), z.data() + n_u);
+	std::vector<ChainRec> c;
+	c.reserve(n_u);
+	for (int i = 0; i < n_u; ++i) {                         // descending score (the reference reverses the sorted array, src/hit.c:75-77)
+		const m128 &zi = z[n_u - 1 - i];
+		ChainRec x;
+		x.id = i; x.parent = PARENT_UNSET; x.score = (int32_t)(zi.x >> 32); x.hash = (uint32_t)zi.x; x.cnt = (int32_t)zi.y; x.as = (int32_t)(zi.y >> 32);
+		x.subsc = 0; x.n_sub = 0; x.inv = 0; x.sam_pri = 0; x.dp_max2 = 0;
+		const m128 &first = a[x.as], &last = a[x.as + x.cnt - 1];            // mm_reg_set_coor without the lengths (reg_set_coor above)
+		const int32_t span0 = a_span(first);
+		x.rev = (uint32_t)(first.x >> 63);
+		x.rid = (int32_t)(first.x << 1 >> 33);
+		x.rs = a_rpos(first) + 1 > span0 ? a_rpos(first) + 1 - span0 : 0;
+		x.re = a_rpos(last) + 1;
+		if (!x.rev) { x.qs = a_qpos(first) + 1 - span0; x.qe = a_qpos(last) + 1; }
+		else { x.qs = qlen - (a_qpos(last) + 1); x.qe = qlen - (a_qpos(first) + 1 - span0); }
+		c.push_back(x);
+	}
+	set_parent_impl(mask_level, mask_len, c, sub_diff, hard_mask_level);
+	select_sub_impl(pri_ratio, min_diff, best_n, c);
+	regs.resize(c.size());
+	for (size_t i = 0; i < c.size(); ++i) {
+		const ChainRec &x = c[i];
+		Reg &r = regs[i];
+		r.id = x.id; r.parent = x.parent; r.score = r.score0 = x.score; r.hash = x.hash; r.cnt = x.cnt; r.as = x.as;
+		r.subsc = x.subsc; r.n_sub = x.n_sub; r.sam_pri = x.sam_pri; r.div = -1.0f;
+		reg_set_coor(r, qlen, a);
+	}
+	return regs;
 }
 
 void filter_regs(const MapOpt &opt, int qlen, std::vector<Reg> &r)

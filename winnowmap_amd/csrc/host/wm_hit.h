@@ -7,6 +7,9 @@ namespace wm {
 
 void reg_set_coor(Reg &r, int32_t qlen, const m128 *a);                                   // mm_reg_set_coor  src/hit.c:23
 std::vector<Reg> gen_regs(uint32_t hash, int qlen, int n_u, const uint64_t *u, const m128 *a);   // mm_gen_regs      :52
+// mm_gen_regs + mm_set_parent + mm_select_sub in one step (identical result; Regs are built for the chains select_sub keeps only)
+std::vector<Reg> gen_regs_select(uint32_t hash, int qlen, int n_u, const uint64_t *u, const m128 *a, float mask_level, int mask_len, int sub_diff, int hard_mask_level,
+                                 float pri_ratio, int min_diff, int best_n);
 void split_reg(Reg &r, Reg &r2, int n, int qlen, const m128 *a);                          // mm_split_reg     :106
 void set_parent(float mask_level, int mask_len, std::vector<Reg> &r, int sub_diff, int hard_mask_level);   // mm_set_parent :125
 void hit_sort(std::vector<Reg> &r);                                                        // mm_hit_sort      :188

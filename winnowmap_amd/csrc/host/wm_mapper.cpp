@@ -52,13 +52,12 @@ void window_and_align(Scheduler &sch, const Index &idx, const MapOpt &o, float g
 	const int rep_len = *rep_len_io;
 	out.a = std::move(wr.a);
 	out.rep_len = rep_len;
-	out.regs = gen_regs(hash, qlen, (int)wr.u.size(), wr.u.data(), out.a.data());
-	// chain_post (src/map.c:256-265)
+	// mm_gen_regs, then chain_post (src/map.c:256-265): set_parent + select_sub fused with the region generation (wm_hit.h)
 	if (!(o.flag & F_ALL_CHAINS)) {
-		set_parent(o.mask_level, o.mask_len, out.regs, o.a * 2 + o.b, (o.flag & F_HARD_MLEVEL) != 0);
-		select_sub(o.pri_ratio, idx.k * 2, o.best_n, out.regs);
+		out.regs = gen_regs_select(hash, qlen, (int)wr.u.size(), wr.u.data(), out.a.data(), o.mask_level, o.mask_len, o.a * 2 + o.b, (o.flag & F_HARD_MLEVEL) != 0,
+		                           o.pri_ratio, idx.k * 2, o.best_n);
 		if (!(o.flag & (F_SPLICE | F_SR | F_NO_LJOIN))) join_long(o, qlen, out.regs, out.a.data());
-	}
+	} else out.regs = gen_regs(hash, qlen, (int)wr.u.size(), wr.u.data(), out.a.data());
 	// align_regs (src/map.c:267-277)
 	if (o.flag & F_CIGAR) {
 		align_skeleton(sch, o, idx, qlen, codes, dev_off, out.regs, out.a.data());

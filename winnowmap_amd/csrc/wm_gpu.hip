@@ -598,7 +598,7 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 	b->jobs.resize(n_jobs);
 	// where the operands go in the device slab: position jobs are laid out back to back; byte jobs keep their offsets, rebased to the
 	// lowest one so that only [lo, hi) of the caller's buffer travels
-	std::vector<wm_ksw_dsrc_t> dsrc(pos ? n_jobs : 0);
+	UBuf<wm_ksw_dsrc_t> dsrc(pos ? n_jobs : 0, c);             // (pinned: uploaded as it is)
 	size_t slab_lo = 0, slab_bytes = 0;
 	int bad0 = -1;
 	if (pos) {
@@ -738,8 +738,14 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 	b->ord.clear();
 	b->ord.reserve(nj);
 	for (int k = 0; k < WM_KSW_NCLASS; ++k) b->ord.insert(b->ord.end(), b->order[k].begin(), b->order[k].end());
-	HIPCHK(hipMemcpyAsync(b->d_jobs, b->jobs.data(), n_jobs * sizeof(wm_ksw_djob_t), hipMemcpyHostToDevice, c->stream));
-	if (!b->ord.empty()) HIPCHK(hipMemcpyAsync(b->d_order, b->ord.data(), b->ord.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+	// the job table and the launch order travel through the context's pinned slab: an asynchronous copy out of pageable memory makes the runtime pin
+	// the pages for the duration of the copy (or bounce them through its own staging buffer, waiting in between) — driver calls per batched call
+	UBuf<wm_ksw_djob_t> pj(n_jobs, c);
+	UBuf<int> po(b->ord.size(), c);
+	if (n_jobs) memcpy(pj.data(), b->jobs.data(), (size_t)n_jobs * sizeof(wm_ksw_djob_t));
+	if (!b->ord.empty()) memcpy(po.data(), b->ord.data(), b->ord.size() * sizeof(int));
+	HIPCHK(hipMemcpyAsync(b->d_jobs, pj.data(), n_jobs * sizeof(wm_ksw_djob_t), hipMemcpyHostToDevice, c->stream));
+	if (!b->ord.empty()) HIPCHK(hipMemcpyAsync(b->d_order, po.data(), b->ord.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
 	if (pos) {
 		if (n_jobs > 0) {
 			HIPCHK(hipMemcpyAsync(d_src, dsrc.data(), (size_t)n_jobs * sizeof(wm_ksw_dsrc_t), hipMemcpyHostToDevice, c->stream));
@@ -848,6 +854,8 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		ks = side[si];
 		if (!(used_mask >> si & 1)) { hipStreamWaitEvent(ks, c->kev[4], 0); used_mask |= 1 << si; }
 	};
+	// WM_KSW_CLASS_EVENTS=0: no start / stop events around the classes' launches (wm_mapper_kernel_stats then reports nothing; A/B of what the events cost)
+	static const bool class_events = !(getenv("WM_KSW_CLASS_EVENTS") && atoi(getenv("WM_KSW_CLASS_EVENTS")) == 0);
 	int offs[WM_KSW_NCLASS + 1];
 	offs[0] = 0;
 	for (int k = 0; k < WM_KSW_NCLASS; ++k) offs[k + 1] = offs[k] + (int)b->order[k].size();
@@ -863,8 +871,8 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		off = offs[k];
 		next_stream();
 		const double tk0 = trace_k ? now_ms() : 0;
-		hipEventRecord(c->cev[k][0], ks);
-		struct Done { decltype(class_done) &f; int k; double t; hipEvent_t e; hipStream_t s; ~Done() { hipEventRecord(e, s); f(k, t); } } done_guard{ class_done, k, tk0, c->cev[k][1], ks };
+		if (class_events) hipEventRecord(c->cev[k][0], ks);
+		struct Done { decltype(class_done) &f; int k; double t; hipEvent_t e; hipStream_t s; bool on; ~Done() { if (on) hipEventRecord(e, s); f(k, t); } } done_guard{ class_done, k, tk0, c->cev[k][1], ks, class_events };
 		if (k == WM_KSW_BLOCK || k == WM_KSW_BLOCK2 || k == WM_KSW_BLOCK3) {
 			const size_t fixed = (size_t)WM_KSW_BLK_PUB * 4;
 			if (k == WM_KSW_BLOCK || k == WM_KSW_BLOCK2) {
@@ -970,7 +978,7 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	HIPCHK(hipEventElapsedTime(&b->dp_ms, c->ev[0], c->ev[1]));
 	HIPCHK(hipEventElapsedTime(&b->bt_ms, c->ev[1], c->ev[2]));
 	c->last_ms = b->dp_ms + b->bt_ms;
-	for (int k = 0; k < WM_KSW_NCLASS; ++k)
+	for (int k = 0; k < WM_KSW_NCLASS && class_events; ++k)
 		if (!b->order[k].empty()) {
 			float ms = 0;
 			if (hipEventElapsedTime(&ms, c->cev[k][0], c->cev[k][1]) == hipSuccess) {
