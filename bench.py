@@ -340,6 +340,7 @@ def main():
             ref = synth.make_reference(n_contigs, int(args.ref_mb * 1e6 / n_contigs), 3, repeat_frac=0.10)
     if dist is None or not uploaded:
         idx.upload(ctx)
+    os.environ.setdefault("WM_READ_SLABS", str(max(1, min(4, int(os.environ.get("WM_BENCH_SLOTS", 2))))))      # resident read slabs = mini-batches in flight (below)
     mapper = gpu.Mapper(ctx, idx, cfg["preset"], gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
     if n_threads > 1:
         mapper.set_threads(n_threads, arena)

@@ -148,8 +148,10 @@ void wm_ksw_dev_free(wm_ctx_t *ctx, wm_ksw_dev_batch_t *b);
 /* Kernel routing knob (process-wide; results never depend on it): alignments of the 4-pair / 8-pair one-wavefront classes (traceback pitch <= 496 /
  * <= 1008 lanes) with at least rows4 / rows8 DP rows (qlen + tlen - 1) run on the stripe-pipelined multi-wave kernel (csrc/ksw_stripe_kernel.h), like
  * every wider hull does. 0 = never, < 0 = leave that threshold as it is; on = 0 switches the stripe classes off altogether (the barrier-per-row
- * kernels of round 3), 2 = on with the sixteen-wavefront geometries (<2,16>: two lane pairs per wavefront for hulls of 1793..3840 lanes instead of
- * four; <1,16> for the long jobs of the one-wavefront classes; environment: WM_KSW_STRIPE16 = 1 | 2 | 3, bits in that order), < 0 = leave. Defaults: WM_KSW_STRIPE_ROWS4 / WM_KSW_STRIPE_ROWS8 / WM_KSW_STRIPE from the environment. Not part of the
+ * kernels of round 3), 1 = on with the default geometries (since round 5: <2,16> — two lane pairs per wavefront, sixteen wavefronts — for hulls of
+ * 1793..3840 lanes instead of <4,8>), 2 = both sixteen-wavefront geometries (also <1,16> for the long jobs of the one-wavefront classes), 3 = none of
+ * them (the round-4 routing); environment: WM_KSW_STRIPE16 = 0 | 1 | 2 | 3, bits in that order; < 0 = leave. Defaults: WM_KSW_STRIPE_ROWS4 /
+ * WM_KSW_STRIPE_ROWS8 / WM_KSW_STRIPE / WM_KSW_STRIPE16 from the environment. Not part of the
  * reference's interface: tests force every job through every kernel with it, tools/ tune the thresholds. */
 void wm_ksw_set_routing(int on, int rows4, int rows8);
 
@@ -246,6 +248,14 @@ int wm_window_batch(wm_ctx_t *ctx, int n, const wm_window_job_t *jobs, const uin
 float wm_last_aux_ms(const wm_ctx_t *ctx);
 
 /* ---- the mapper: replacement of kt_for(worker_for) (src/map.c:1164) ---------------------------------- */
+/* PROCESS-WIDE SETTINGS the library makes for the mapper (both are defaults: a value the caller has set wins; WM_NO_PROCESS_DEFAULTS=1 switches both off):
+ *  - at load time: GPU_MAX_HW_QUEUES=20 in the environment, unless it is set (the HIP runtime reads it once, when it initialises: a mapper runs 6 device
+ *    contexts + 14 side streams and HIP's default of 4 hardware queues would serialise them);
+ *  - when the first mapper is created: glibc's allocator is told to grow its arenas in 64-MB steps, never to trim them and to serve up to 32 MB from
+ *    them (mallopt; WM_MALLOPT=0 or the caller's own MALLOC_TOP_PAD_ / MALLOC_TRIM_THRESHOLD_ / MALLOC_MMAP_THRESHOLD_ win): the mapping calls allocate
+ *    and free their per-call tables from dozens of threads, which with the defaults is one mprotect / brk per table (profiles/r04l, r04m). The
+ *    process's resident memory after a mapping call therefore stays at its high-water mark.
+ * A program that uses only the batched operations above is not touched by the second. */
 typedef struct wm_mapper_s wm_mapper_t;
 /* preset: NULL/"" or "map-ont" | "map-pb" | "map-pb-clr" | "asm5" | "asm10" | "asm20" (mm_set_opt, src/options.c:89);
  * flag: mm_mapopt_t::flag bits to OR in (MM_F_CIGAR 0x4, MM_F_OUT_SAM 0x8, MM_F_OUT_CG 0x20, ...). */
@@ -344,6 +354,7 @@ int wm_mapper_stats(const wm_mapper_t *m, uint64_t *out9);
  * wm_mapper_create: out[3k] = summed launch durations (ms, HIP events on the launching stream), out[3k+1] = DP cells,
  * out[3k+2] = launches. cap = doubles available in out; *n_classes receives the class count. Feeds bench.py's roofline. */
 int wm_mapper_kernel_stats(const wm_mapper_t *m, double *out, int cap, int *n_classes);
+int wm_ksw_n_classes(void);      /* the class count (what out of wm_mapper_kernel_stats / _union must hold) */
 /* Launches of one class overlap on different streams, so the summed durations above are residency. out[k] = ms during which AT LEAST ONE launch of
  * class k was running (union of the launch intervals on the device clock) after since_ms; *now_ms = the clock now (the next call's since_ms). */
 int wm_mapper_kernel_union(const wm_mapper_t *m, double since_ms, double *out, int cap, double *now_ms);

@@ -305,6 +305,7 @@ int h_map(void *hv, const char *preset, int64_t flag_extra, const char *seq, int
 	MapStats st;
 	map_batch(h->idx, mo, &ops, reads, out, &st);
 	note_pos(ops);
+	if (!st.internal_error.empty()) { fprintf(stderr, "[harness] %s\n", st.internal_error.c_str()); return -5; }      // a violated invariant of the host mapper (it used to be dropped here)
 	if (ops.n_pos_bad.load()) return -3;
 	if (stats_out) { stats_out[0] = st.n_flush; stats_out[1] = st.n_ksw; stats_out[2] = st.n_chain; stats_out[3] = st.n_sketch; }
 	int64_t nc = 0;

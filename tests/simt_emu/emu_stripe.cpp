@@ -92,6 +92,7 @@ int emu_stripe_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *ta
 	default: run_stripe<2, 16>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
 	}
 	int n = 0;
+	if (res.bt_i == KSW_BT_WATCHDOG) return -4;              // the kernel's own watchdog gave up (WM_STRIPE_SPIN_BUDGET): what ksw_backtrack_kernel turns into the batch's error
 	if (res.bt_i >= 0) {
 		n = wmk::ksw_backtrack_thread(jb, tb.data(), res.bt_i, res.bt_j, cigar_out, cigar_cap);
 		if (n < 0) return -3;

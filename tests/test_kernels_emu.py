@@ -409,3 +409,25 @@ def test_stripe_kernel_repeat_in_safe_mode():
     n_run = _stripe_run(E, exact, forces)
     ev = _stripe_events(E)
     assert sum(n_run.values()) > 300 and ev["restart"] > 20, (n_run, ev)
+
+
+def test_stripe_kernel_watchdog_gives_up_instead_of_hanging():
+    """the kernel's polling loops have a budget; a wavefront that exceeds it stops the workgroup and the job comes back flagged (bt_i =
+    KSW_BT_WATCHDOG -> emu_stripe_extd2 returns -4; on the device the traceback kernel raises the batch's error and wm_ksw_dev_run returns WM_EINTERNAL).
+    A budget of a few polls expires in almost every job on the emulator (a neighbour is a host thread away); jobs that are not flagged are correct."""
+    E = _load_stripe(("WM_STRIPE_SPIN_BUDGET=3",))
+    cases = [c for c in kswcases.stripe_cases(21, 24, 700)]
+    n_flagged = n_ok = 0
+    for c in cases:
+        for force in (300 + 1 * 10 + 3, 300 + 3 * 10 + 3):                 # <1,3> and <2,4>, CLIP + HASN instantiations (serve every job)
+            n, ez, cig, klass = emu_ksw(E, c, force)
+            if n == -4:
+                n_flagged += 1
+                continue
+            if n < 0:
+                continue
+            o = W.o_ksw_extd2(c["q"], c["t"], mat=W.simple_mat(c["a"], c["b"], 1), q=c["q_"], e=c["e"], q2=c["q2"], e2=c["e2"],
+                              w=c["w"], zdrop=c["zdrop"], end_bonus=c["end_bonus"], flag=c["flag"])
+            assert [int(x) for x in ez] == [o[k] for k in W.EZ_FIELDS] and np.array_equal(cig, o["cigar"])
+            n_ok += 1
+    assert n_flagged > 5, (n_flagged, n_ok)

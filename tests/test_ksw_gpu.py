@@ -258,19 +258,21 @@ def test_position_jobs_equal_byte_jobs(tmp_path):
 # ---- the stripe-pipelined multi-wave kernels (csrc/ksw_stripe_kernel.h): every job of the suites above once more with the routing thresholds at
 # one row, so that each runs on NWV wavefronts that hand rows to each other through LDS (geometry by traceback pitch), and natively wide hulls ----
 def _default_routing():
-    on = 0 if os.environ.get("WM_KSW_STRIPE") == "0" else 2 if int(os.environ.get("WM_KSW_STRIPE16", 0)) > 0 else 1
+    w16 = int(os.environ.get("WM_KSW_STRIPE16", 1)) & 3
+    on = 0 if os.environ.get("WM_KSW_STRIPE") == "0" else 3 if w16 == 0 else 2 if w16 >= 2 else 1
     gpu.set_ksw_routing(on, int(os.environ.get("WM_KSW_STRIPE_ROWS4", 0)), int(os.environ.get("WM_KSW_STRIPE_ROWS8", 4096)))
 
 
-# on = 1: the default geometries (<2,4> <2,8> <4,8> <8,8>); on = 2: the sixteen-wavefront geometries (<1,16> <2,16>) wherever they fit
-@pytest.fixture(params=[1, 2], ids=["nwv4_8", "nwv16"])
+# on = 3: the geometries of four / eight wavefronts (<2,4> <2,8> <4,8> <8,8>); on = 2: the sixteen-wavefront geometries (<1,16> <2,16>) wherever they fit;
+# on = 1: the default routing (<2,16> for hulls of 1793..3840 lanes, else as 3)
+@pytest.fixture(params=[3, 2], ids=["nwv4_8", "nwv16"])
 def all_stripes(request):
     gpu.set_ksw_routing(request.param, 1, 1)
     yield
     _default_routing()
 
 
-@pytest.fixture(params=[1, 2], ids=["nwv4_8", "nwv16"])
+@pytest.fixture(params=[3, 2, 1], ids=["nwv4_8", "nwv16", "default"])
 def stripe_geometries(request):
     gpu.set_ksw_routing(request.param, -1, -1)
     yield

@@ -90,10 +90,11 @@ def config4(args):
     with open(ref_paf, "rb") as f:
         d = parity.diff_texts(f.read(), ours, sam=False)
     far = sum(1 for l in ours.split(b"\n") if l.startswith(b"r") and l.split(b"\t")[0] in (b"r%d" % j for j in range(8)) and l.split(b"\t")[5] == b"chr%d" % (n_ctg - 1))
+    n_mini = int(idx.n_minimizers)
     m.close(); idx.close(); ctx.close()
     return {"record": "BASELINE config 4 reference at size, one MI355X", "reference_gbase": total / 1e9, "contigs": n_ctg, "reads": len(seqs), "read_len": 15000,
             "kmer_list": {"where": "device", "k": 15, "kmers": int(n_k), "seconds": round(t_w, 1)},
-            "index": {"where": "device (sketch + table)", "minimizers": int(idx.n_minimizers) if hasattr(idx, "n_minimizers") else None, "seconds": round(t_idx, 1), "stats": ist},
+            "index": {"where": "device (sketch + table)", "minimizers": n_mini, "seconds": round(t_idx, 1), "stats": ist},
             "map_seconds": round(t_map, 1), "reference_binary_seconds": round(t_ref, 1), "records_of_reads_from_beyond_2^31_bases": far,
             "parity": {"reads_with_hits": d["reads"], "hits": d["hits"], "mismatches": d["mismatches"], "examples": d.get("examples", [])[:3],
                        "compared": "PAF incl. cg:Z vs winnowmap_ref -t 16 -W -cx map-ont on the same files (MAPQ / rl:i masked for reads >= 10 kb, parity.py)"}}
@@ -141,10 +142,11 @@ def config5(args):
     with open(ref_paf, "rb") as f:
         d = parity.diff_texts(f.read(), ours, sam=False)
     ks = m.kernel_stats()
+    n_mini = int(idx.n_minimizers)
     m.close(); idx.close(); ctx.close()
     wide = {k: v for k, v in ks.items() if v[2] > 0}
     return {"record": "BASELINE config 5 contig size, one MI355X", "reference_mb": total / 1e6, "contigs": len(seqs), "contig_mb": args.contig_mb, "preset": "asm20 (k 19, w 50: src/options.c:112-115 leaves w at its default)",
-            "index": {"where": "device", "minimizers": int(idx.n_minimizers), "seconds": round(t_idx, 1)}, "map_seconds": round(t_map, 1), "gbps": sum(len(s) for s in seqs) / t_map / 1e9,
+            "index": {"where": "device", "minimizers": n_mini, "seconds": round(t_idx, 1)}, "map_seconds": round(t_map, 1), "gbps": sum(len(s) for s in seqs) / t_map / 1e9,
             "reference_binary_seconds": round(t_ref, 1),
             "ksw_classes_used": {str(k): {"ms": round(v[0], 1), "cells": v[1], "launches": v[2]} for k, v in wide.items()},
             "parity": {"reads_with_hits": d["reads"], "hits": d["hits"], "mismatches": d["mismatches"], "examples": d.get("examples", [])[:3],

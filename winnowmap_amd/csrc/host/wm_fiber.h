@@ -145,8 +145,10 @@ struct Hub {
 	// a batch is worth its fixed cost — a kernel launch lasts at least as long as its longest job, and the device runs only so many
 	// kernels at once — when it is large: an operation is issued when min_batch[op] requests are pending or the oldest has waited
 	// max_wait_ms[op], whichever comes first (0 / 0 = at once)
-	size_t min_batch[OP_N] = { 8192, 8192, 8192, 98304, 12288, 256, 8192, 2048 };
-	double max_wait_ms[OP_N] = { 15, 15, 15, 30, 60, 100, 15, 30 };
+	// (the huge queue: 512 jobs / 250 ms since round 5 — a launch of stripe-pipelined jobs lasts as long as its longest job whatever their number, so
+	// fewer, fuller launches: +3..9 % on config 2 together with the sixteen-wavefront routing, profiles/r05_sched.txt; before: 256 / 100 ms)
+	size_t min_batch[OP_N] = { 8192, 8192, 8192, 98304, 12288, 512, 8192, 2048 };
+	double max_wait_ms[OP_N] = { 15, 15, 15, 30, 60, 250, 15, 30 };
 	double first_pending[OP_N] = { 0, 0, 0, 0, 0, 0, 0, 0 };          // wall_s() when the queue of the operation last became non-empty
 	long heavy_units = 8192;                // rows x 128-lane register pairs above which an alignment goes to the heavy queue (0 = no heavy queue)
 	long huge_units = 131072;               // ... and to the queue of the few very long ones (0 = none)

@@ -241,10 +241,14 @@ int map_file_split(const std::string &reads_path, int64_t mini_batch_bases, cons
 	for (int j = 1; j < n_parts; ++j) rid_shift[j] = rid_shift[j - 1] + parts[j - 1].n_seq;
 	// the merge pass (merge_hits, src/map.c:1050-1105)
 	FileStats fs;
+	std::string merge_err;
 	const int rc = map_file_id(reads_path, mini_batch_bases, with_qual, [&](std::vector<ReadIn> &batch, std::string &text, int, uint64_t id) {
 		std::vector<std::vector<ReadOut>> ph(n_parts);                    // this mini-batch's hits, part by part
 		for (int j = 0; j < n_parts; ++j)
-			if (!spill[j].get(id, ph[j]) || ph[j].size() != batch.size()) return -1;
+			if (!spill[j].get(id, ph[j]) || ph[j].size() != batch.size()) {
+				if (merge_err.empty()) merge_err = !spill[j].error.empty() ? spill[j].error : "the hits of index part " + std::to_string(j) + " for mini-batch " + std::to_string(id) + " could not be read back from their temporary file";
+				return -1;
+			}
 		for (size_t i = 0; i < batch.size(); ++i) {
 			ReadOut m;
 			for (int j = 0; j < n_parts; ++j) {
@@ -266,6 +270,7 @@ int map_file_split(const std::string &reads_path, int64_t mini_batch_bases, cons
 		}
 		return 0;
 	}, out, &fs, err);
+	if (rc && !merge_err.empty() && (err.empty() || err == "mapping failed")) err = merge_err;
 	if (st) { *st = fs; st->t_map += fs_all.t_map; st->t_read += fs_all.t_read; }
 	return rc;
 }

@@ -34,6 +34,7 @@ namespace wmk {
 using namespace simt;
 
 #define KSW_NEG_INF (-0x40000000)
+#define KSW_BT_WATCHDOG (-3)          // wm_ksw_dres_t::bt_i of a job whose stripe kernel gave up waiting (ksw_stripe_kernel.h: WM_STRIPE_SPIN_BUDGET)
 #define KSW_F_RIGHT 0x02
 #define KSW_F_APPROX_MAX 0x08
 #define KSW_F_EXTZ_ONLY 0x40

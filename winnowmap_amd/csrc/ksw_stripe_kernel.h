@@ -29,6 +29,13 @@
 #ifndef WM_STRIPE_SPIN
 #define WM_STRIPE_SPIN(where, r, a, wv, extra) ((void)0)      // test hook: a watchdog for the polling loops
 #endif
+// Every cross-wavefront polling loop has a budget: a wavefront that has polled WM_STRIPE_SPIN_BUDGET times since it started (each poll
+// is an LDS load + s_sleep: ~10^2 cycles, so the default is seconds — legitimate waits are a few rows of a neighbour, microseconds) declares the
+// protocol broken: it raises C_RESTART = 2 and the stop word, everybody leaves, the job's result carries bt_i = KSW_BT_WATCHDOG, the traceback kernel
+// turns that into the batch's error flag and wm_ksw_dev_run returns WM_EINTERNAL instead of hanging the mapping call.
+#ifndef WM_STRIPE_SPIN_BUDGET
+#define WM_STRIPE_SPIN_BUDGET (1 << 25)
+#endif
 #ifndef WM_STRIPE_EVENT
 #define WM_STRIPE_EVENT(k) ((void)0)      // test hook (tests/simt_emu): counts how often the rare paths run
 #endif
@@ -123,6 +130,8 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 	int *ring_out = lds + wv * (R * L::SLOT), *ring_in = lds + ((wv + NWV - 1) % NWV) * (R * L::SLOT);
 	int *prog = lds + L::PROG, *ctrl = lds + L::CTRL;
 	const int right_wv = (wv + 1) % NWV;
+	int spins = 0;                                                   // polls of this wavefront so far (all loops, both passes)
+	auto give_up = [&]() { lds_st_rel(ctrl, L::C_RESTART, 2); lds_st_rel(ctrl, L::C_STOP, -1); };      // (the loop that called it sees the stop word at its next poll)
 	WM_ST_DECL();
 
 	for (int safe = 0; safe < 2; ++safe) {
@@ -203,7 +212,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 					if (a > 0 && gp.st <= a - 1 && a - 1 <= gp.en) {      // lane a - 1 was computed in row r - 1: take its message
 						const int *m = ring_in + ((r - 1) % R) * L::SLOT;
 						bool gone = false;
-						while (lds_ld_acq(m, L::M_STAMP) != r - 1) { if (lds_ld_acq(ctrl, L::C_STOP) < r) { gone = true; break; } WM_STRIPE_SPIN(0, r, a, wv, lds_ld_acq(m, L::M_STAMP)); spin_pause(); }
+						while (lds_ld_acq(m, L::M_STAMP) != r - 1) { if (lds_ld_acq(ctrl, L::C_STOP) < r) { gone = true; break; } WM_STRIPE_SPIN(0, r, a, wv, lds_ld_acq(m, L::M_STAMP)); if (++spins > WM_STRIPE_SPIN_BUDGET) give_up(); spin_pause(); }
 						if (gone) { all_done = true; break; }
 						m_x = lds_ld(m, (long long)L::M_X); m_v = lds_ld(m, (long long)L::M_V); m_x2 = lds_ld(m, (long long)L::M_X2); m_h = lds_ld(m, (long long)L::M_H);
 						have_left = true;
@@ -438,7 +447,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 					if (left_now) {
 						const int *m = ring_in + (r % R) * L::SLOT;
 						int o8[8];
-						while (lds_ld_msg(m, o8) != r) { if (lds_ld_acq(ctrl, L::C_STOP) <= r) { stopped = true; break; } WM_STRIPE_SPIN(1, r, a, wv, lds_ld_acq(m, L::M_STAMP)); spin_pause(); }
+						while (lds_ld_msg(m, o8) != r) { if (lds_ld_acq(ctrl, L::C_STOP) <= r) { stopped = true; break; } WM_STRIPE_SPIN(1, r, a, wv, lds_ld_acq(m, L::M_STAMP)); if (++spins > WM_STRIPE_SPIN_BUDGET) give_up(); spin_pause(); }
 						if (stopped) { all_done = true; break; }
 						m_x = o8[0]; m_v = o8[1]; m_x2 = o8[2];
 						if constexpr (EXACT) {
@@ -554,7 +563,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 					// ---- publish this row for the right neighbour ----
 					WM_ST_LAP(WM_ST_BOOK);
 					if (pub) {
-						while (lds_ld_acq(prog, right_wv) < r - R) { if (lds_ld_acq(ctrl, L::C_STOP) <= r) { stopped = true; break; } WM_STRIPE_SPIN(2, r, a, wv, lds_ld_acq(prog, right_wv)); spin_pause(); }
+						while (lds_ld_acq(prog, right_wv) < r - R) { if (lds_ld_acq(ctrl, L::C_STOP) <= r) { stopped = true; break; } WM_STRIPE_SPIN(2, r, a, wv, lds_ld_acq(prog, right_wv)); if (++spins > WM_STRIPE_SPIN_BUDGET) give_up(); spin_pause(); }
 						if (stopped) { all_done = true; break; }
 						WM_ST_LAP(WM_ST_WAIT_RIGHT);
 						int *m = ring_out + (r % R) * L::SLOT;
@@ -586,6 +595,17 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 		WM_ST_LAP(WM_ST_SCAN);
 		block_sync_lds();
 		const int stop_row = lds_ld_acq(ctrl, L::C_STOP), restart = lds_ld_acq(ctrl, L::C_RESTART);
+		if (restart == 2) {                                          // the watchdog: no result; the batch fails loudly (see WM_STRIPE_SPIN_BUDGET)
+			if (wv == 0) {
+				WM_IF(ln == 0)
+					wm_ksw_dres_t o;
+					o.max = 0; o.zdropped = 0; o.max_q = o.max_t = o.mqe_t = o.mte_q = -1; o.mqe = o.mte = o.score = KSW_NEG_INF;
+					o.reach_end = 0; o.n_cigar = 0; o.bt_i = KSW_BT_WATCHDOG; o.bt_j = -1;
+					*res = o;
+				WM_END
+			}
+			break;
+		}
 		if (restart) { block_sync_lds(); continue; }
 		bool writer;
 		if (EXACT) writer = stop_row != BIG ? my_stop : (was_last && row_done == end_row - 1);

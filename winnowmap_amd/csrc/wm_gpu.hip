@@ -18,6 +18,7 @@
 #include <thread>
 #include <chrono>
 #include <atomic>
+#include <mutex>
 #include <unistd.h>
 #include "host/wm_core.h"
 // large staging buffers: no value-initialisation (a std::vector would memset hundreds of MB per batch). When a context is
@@ -206,9 +207,10 @@ __global__ __launch_bounds__(64) void ksw_backtrack_kernel(int n, const wm_ksw_d
 	if (j >= n) return;
 	wm_ksw_dres_t r = res[j];
 	int nc = 0;
+	if (r.bt_i == KSW_BT_WATCHDOG) atomicMax(err, 2);
 	if (r.bt_i >= 0) {
 		nc = wmk::ksw_backtrack_thread(jobs[j], tb, r.bt_i, r.bt_j, cig_scratch + jobs[j].cig_off, jobs[j].cig_cap);
-		if (nc < 0) { atomicExch(err, 1); nc = 0; }
+		if (nc < 0) { atomicMax(err, 1); nc = 0; }
 	}
 	res[j].n_cigar = nc;
 }
@@ -222,9 +224,10 @@ __global__ __launch_bounds__(64) void ksw_backtrack_coop_kernel(int n, const wm_
 	const int j = blockIdx.x;
 	const int bt_i = res[j].bt_i, bt_j = res[j].bt_j;
 	int nc = 0;
+	if (bt_i == KSW_BT_WATCHDOG && threadIdx.x == 0) atomicMax(err, 2);
 	if (bt_i >= 0) {
 		nc = wmk::ksw_backtrack_wave(jobs[j], tb, bt_i, bt_j, cig_scratch + jobs[j].cig_off, jobs[j].cig_cap, tile);
-		if (nc < 0) { if (threadIdx.x == 0) atomicExch(err, 1); nc = 0; }
+		if (nc < 0) { if (threadIdx.x == 0) atomicMax(err, 1); nc = 0; }
 	}
 	if (threadIdx.x == 0) res[j].n_cigar = nc;
 }
@@ -309,6 +312,7 @@ struct wm_ctx_s {
 	// every launch of a class as an interval on the device's clock (ms since the process-wide base event): launches of one class overlap on
 	// different streams, so their SUMMED durations are residency, not time — the union of the intervals is (wm_mapper_kernel_union)
 	std::vector<std::pair<float, float>> k_iv[WM_KSW_NCLASS];
+	std::mutex iv_mu;                           // k_iv: appended by the batched call that holds the context, read by wm_mapper_kernel_union from any thread
 	uint8_t *arena;
 	size_t arena_bytes, arena_used;
 	hipEvent_t ev[4];
@@ -395,7 +399,9 @@ static hipError_t ctx_sync(wm_ctx_s *c)
 // ROCm maps HIP streams onto 4 hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and reads it when the runtime initialises: a library
 // constructor sets the default the mapper is tuned for (6 contexts + 14 side streams) before any HIP call of this process can have happened
 // through this library; a value given by the user wins. (Python callers get the same default from winnowmap_amd/__init__.py.)
-__attribute__((constructor)) static void wm_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "20", 0); }
+// (this is the one setting that has to happen at load time — the HIP runtime reads the variable when it initialises. WM_NO_PROCESS_DEFAULTS=1
+// leaves the process alone; include/wm_gpu.h documents both process-wide settings.)
+__attribute__((constructor)) static void wm_default_hw_queues() { if (!getenv("WM_NO_PROCESS_DEFAULTS")) setenv("GPU_MAX_HW_QUEUES", "20", 0); }
 
 // The mapping calls allocate and free their per-call tables (tens of MB per batched call, from 16+ worker threads) at a rate at which glibc's defaults
 // turn into system calls: a worker's malloc arena grows in 128-KB steps (one mprotect each), gives the memory back as soon as it is free, deletes and
@@ -403,13 +409,18 @@ __attribute__((constructor)) static void wm_default_hw_queues() { setenv("GPU_MA
 // host's CPU samples inside mprotect (profiles/r04l_host_sampling_profile.txt) — with the address-space lock held, i.e. with every other thread's page
 // faults waiting. Keep the memory instead: grow in 64-MB steps, never trim, allocate up to 32 MB from the arenas: -15 % host CPU, +9 % throughput in one
 // GPU call (profiles/r04m_malloc_tuning.txt). Process-wide, like GPU_MAX_HW_QUEUES; WM_MALLOPT=0 or any MALLOC_* tunable of the caller's own wins.
-__attribute__((constructor)) static void wm_default_malloc()
+// Applied when the first mapper of the process is created (not at load time: a program that only links the library for its batched operations keeps
+// glibc's defaults — ADVICE r4); WM_MALLOPT=0 / WM_NO_PROCESS_DEFAULTS=1 switch it off.
+static void wm_default_malloc()
 {
-	const char *off = getenv("WM_MALLOPT");
-	if (off && atoi(off) == 0) return;
-	if (!getenv("MALLOC_TOP_PAD_")) mallopt(M_TOP_PAD, 64 << 20);
-	if (!getenv("MALLOC_TRIM_THRESHOLD_")) mallopt(M_TRIM_THRESHOLD, 0x7fffffff);
-	if (!getenv("MALLOC_MMAP_THRESHOLD_")) mallopt(M_MMAP_THRESHOLD, 32 << 20);
+	static std::once_flag once;
+	std::call_once(once, [] {
+		const char *off = getenv("WM_MALLOPT");
+		if ((off && atoi(off) == 0) || getenv("WM_NO_PROCESS_DEFAULTS")) return;
+		if (!getenv("MALLOC_TOP_PAD_")) mallopt(M_TOP_PAD, 64 << 20);
+		if (!getenv("MALLOC_TRIM_THRESHOLD_")) mallopt(M_TRIM_THRESHOLD, 0x7fffffff);
+		if (!getenv("MALLOC_MMAP_THRESHOLD_")) mallopt(M_MMAP_THRESHOLD, 32 << 20);
+	});
 }
 
 // one recorded event per device: the zero of the interval clock above (hipEventElapsedTime works between events of different streams)
@@ -554,7 +565,7 @@ static int stripe_min_rows(int bp)
 	if (g_stripe_on.load(std::memory_order_relaxed) < 0) {
 		g_stripe_rows4 = getenv("WM_KSW_STRIPE_ROWS4") ? std::max(0, atoi(getenv("WM_KSW_STRIPE_ROWS4"))) : 0;
 		g_stripe_rows8 = getenv("WM_KSW_STRIPE_ROWS8") ? std::max(0, atoi(getenv("WM_KSW_STRIPE_ROWS8"))) : 4096;      // (3 000-row extensions are faster on one wavefront, 10 000-row ones on four: profiles/r04c_probe.txt)
-		g_stripe_wide16 = getenv("WM_KSW_STRIPE16") ? atoi(getenv("WM_KSW_STRIPE16")) & 3 : 0;      // opt-in, bits: 1 = <2,16> instead of <4,8>, 2 = <1,16> for long narrow jobs (ksw_plan.h)
+		g_stripe_wide16 = getenv("WM_KSW_STRIPE16") ? atoi(getenv("WM_KSW_STRIPE16")) & 3 : 1;      // bits: 1 = <2,16> instead of <4,8> (default since round 5: profiles/r05_sched.txt), 2 = <1,16> for long narrow jobs (measured worse; ksw_plan.h)
 		g_stripe_on = !(getenv("WM_KSW_STRIPE") && atoi(getenv("WM_KSW_STRIPE")) == 0);
 	}
 	return !g_stripe_on.load(std::memory_order_relaxed) ? 0 : bp == 4 ? g_stripe_rows4.load(std::memory_order_relaxed) : bp == 8 ? g_stripe_rows8.load(std::memory_order_relaxed) : 1;   // (bp == 0: are the stripe classes on at all)
@@ -562,7 +573,7 @@ static int stripe_min_rows(int bp)
 extern "C" void wm_ksw_set_routing(int on, int rows4, int rows8)
 {
 	stripe_min_rows(0);
-	if (on >= 0) { g_stripe_on = on != 0; g_stripe_wide16 = on >= 2 ? 3 : 0; }      // (on = 2: with both sixteen-wavefront geometries)
+	if (on >= 0) { g_stripe_on = on != 0; g_stripe_wide16 = on == 2 ? 3 : on == 3 ? 0 : 1; }      // (1: the default routing, <2,16> for the 1793..3840-lane hulls; 2: both sixteen-wavefront geometries; 3: none of them)
 	if (rows4 >= 0) g_stripe_rows4 = rows4;
 	if (rows8 >= 0) g_stripe_rows8 = rows8;
 }
@@ -985,11 +996,13 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 				c->k_ms[k] += ms; c->k_cells[k] += b->class_cells[k]; c->k_launches[k] += 1;
 				float t0 = 0;
 				if (hipEvent_t base = device_base_event(c->device)) if (hipEventElapsedTime(&t0, base, c->cev[k][0]) == hipSuccess) {
-					if (c->k_iv[k].size() > 400000) c->k_iv[k].erase(c->k_iv[k].begin(), c->k_iv[k].begin() + 200000);      // (a file of any size: keep the recent past)
+					std::lock_guard<std::mutex> lk(c->iv_mu);
+					if (c->k_iv[k].size() > 100000) c->k_iv[k].erase(c->k_iv[k].begin(), c->k_iv[k].begin() + 50000);      // (a file of any size: keep the recent past)
 					c->k_iv[k].push_back(std::make_pair(t0, t0 + ms));
 				}
 			}
 		}
+	if (b->h_err == 2) return set_err(WM_EINTERNAL, "a stripe-pipelined alignment kernel gave up waiting for a neighbouring wavefront (watchdog, ksw_stripe_kernel.h); WM_KSW_STRIPE=0 routes around it");
 	if (b->h_err) return set_err(WM_EINTERNAL, "cigar slot overflow in backtrack");
 	return WM_OK;
 }
@@ -1164,6 +1177,7 @@ __global__ __launch_bounds__(64) void ksw_exts2_backtrack_kernel(wm_ksw_score_t 
 	if (j >= n) return;
 	wm_ksw_dres_t r = res[j];
 	int nc = 0;
+	if (r.bt_i == KSW_BT_WATCHDOG) atomicMax(err, 2);
 	if (r.bt_i >= 0) {
 		nc = wmk::ksw_exts2_backtrack_thread(sc, jobs[j], tb, r.bt_i, r.bt_j, cig_scratch + jobs[j].cig_off, jobs[j].cig_cap);
 		if (nc < 0) { atomicExch(err, 1); nc = 0; }
@@ -1562,22 +1576,27 @@ extern "C" int wm_index_upload(wm_ctx_t *c, const wm_index_t *h)
 	HIPCHK(hipSetDevice(c->device));
 	const wm::Index &ix = h->ix;
 	if (ix.bloom.table_bits >= ((uint64_t)1 << 32)) return set_err(WM_EINVAL, "bloom table of %llu bits not supported on device", (unsigned long long)ix.bloom.table_bits);
+	// (new arrays first; the old index goes only when the new one is complete — as wm_index_upload_dev)
+	uint64_t *n_hkey = 0, *n_hval = 0, *n_P = 0; uint8_t *n_bloom = 0; uint32_t *n_S = 0;
+	auto drop = [&]() { hipFree(n_hkey); hipFree(n_hval); hipFree(n_P); hipFree(n_bloom); hipFree(n_S); (void)hipGetLastError(); };
+#define UP_CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { drop(); return set_err(e_ == hipErrorOutOfMemory ? WM_ENOMEM : WM_ENODEV, "%s failed: %s", #x, hipGetErrorString(e_)); } } while (0)
+	UP_CHK(hipMalloc((void**)&n_hkey, ix.hkey.size() * 8 + 8));
+	UP_CHK(hipMalloc((void**)&n_hval, ix.hval.size() * 8 + 8));
+	UP_CHK(hipMalloc((void**)&n_P, ix.P.size() * 8 + 8));
+	UP_CHK(hipMalloc((void**)&n_bloom, ix.bloom.bits.size() + 8));
+	UP_CHK(hipMalloc((void**)&n_S, ix.S.size() * 4 + 8));
+	UP_CHK(hipMemcpy(n_S, ix.S.data(), ix.S.size() * 4, hipMemcpyHostToDevice));
+	UP_CHK(hipMemcpy(n_hkey, ix.hkey.data(), ix.hkey.size() * 8, hipMemcpyHostToDevice));
+	UP_CHK(hipMemcpy(n_hval, ix.hval.data(), ix.hval.size() * 8, hipMemcpyHostToDevice));
+	if (!ix.P.empty()) UP_CHK(hipMemcpy(n_P, ix.P.data(), ix.P.size() * 8, hipMemcpyHostToDevice));
+	UP_CHK(hipMemcpy(n_bloom, ix.bloom.bits.data(), ix.bloom.bits.size(), hipMemcpyHostToDevice));
+#undef UP_CHK
 	if (c->have_index && c->owns_index) { hipFree(c->d_hkey); hipFree(c->d_hval); hipFree(c->d_P); hipFree(c->d_bloom); hipFree(c->d_S); }
-	if (!c->have_index && c->owns_filter && c->d_bloom) { hipFree(c->d_bloom); c->d_bloom = 0; }
+	if (!c->have_index && c->owns_filter && c->d_bloom) hipFree(c->d_bloom);
 	c->owns_filter = false;
-	c->have_index = false; c->d_S = 0; c->seq_off.clear(); c->seq_len.clear();
-	HIPCHK(hipMalloc((void**)&c->d_hkey, ix.hkey.size() * 8 + 8));
-	HIPCHK(hipMalloc((void**)&c->d_hval, ix.hval.size() * 8 + 8));
-	HIPCHK(hipMalloc((void**)&c->d_P, ix.P.size() * 8 + 8));
-	HIPCHK(hipMalloc((void**)&c->d_bloom, ix.bloom.bits.size() + 8));
-	HIPCHK(hipMalloc((void**)&c->d_S, ix.S.size() * 4 + 8));
-	HIPCHK(hipMemcpy(c->d_S, ix.S.data(), ix.S.size() * 4, hipMemcpyHostToDevice));
+	c->d_hkey = n_hkey; c->d_hval = n_hval; c->d_P = n_P; c->d_bloom = n_bloom; c->d_S = n_S;
 	c->seq_off.clear(); c->seq_len.clear();
 	for (const wm::RefSeq &r : ix.seq) { c->seq_off.push_back(r.offset); c->seq_len.push_back(r.len); }
-	HIPCHK(hipMemcpy(c->d_hkey, ix.hkey.data(), ix.hkey.size() * 8, hipMemcpyHostToDevice));
-	HIPCHK(hipMemcpy(c->d_hval, ix.hval.data(), ix.hval.size() * 8, hipMemcpyHostToDevice));
-	if (!ix.P.empty()) HIPCHK(hipMemcpy(c->d_P, ix.P.data(), ix.P.size() * 8, hipMemcpyHostToDevice));
-	HIPCHK(hipMemcpy(c->d_bloom, ix.bloom.bits.data(), ix.bloom.bits.size(), hipMemcpyHostToDevice));
 	c->hbits = ix.hbits;
 	c->skp.w = ix.w; c->skp.k = ix.k; c->skp.table_bits = (uint32_t)ix.bloom.table_bits; c->skp.salt0 = ix.bloom.salt[0]; c->skp.salt1 = ix.bloom.salt[1];
 	c->have_index = true; c->owns_index = true;
@@ -1598,21 +1617,28 @@ extern "C" int wm_index_upload_dev(wm_ctx_t *c, const wm_index_t *h, const void 
 		int can = 0;
 		if (hipDeviceCanAccessPeer(&can, c->device, src_device) == hipSuccess && can) { const hipError_t e = hipDeviceEnablePeerAccess(src_device, 0); if (e != hipSuccess) (void)hipGetLastError(); }   // (already enabled is fine; hipMemcpyPeer stages through the host otherwise)
 	}
+	// new arrays first, the context's old index is released only when all of them are there and filled (a failed allocation used to leave
+	// the context without any index, and the arrays already allocated leaked)
+	uint64_t *n_hkey = 0, *n_hval = 0, *n_P = 0; uint8_t *n_bloom = 0; uint32_t *n_S = 0;
+	auto drop = [&]() { hipFree(n_hkey); hipFree(n_hval); hipFree(n_P); hipFree(n_bloom); hipFree(n_S); (void)hipGetLastError(); };
+#define UP_CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { drop(); return set_err(e_ == hipErrorOutOfMemory ? WM_ENOMEM : WM_ENODEV, "%s failed: %s", #x, hipGetErrorString(e_)); } } while (0)
+	UP_CHK(hipMalloc((void**)&n_hkey, ix.hkey.size() * 8 + 8));
+	UP_CHK(hipMalloc((void**)&n_hval, ix.hval.size() * 8 + 8));
+	UP_CHK(hipMalloc((void**)&n_P, ix.P.size() * 8 + 8));
+	UP_CHK(hipMalloc((void**)&n_bloom, ix.bloom.bits.size() + 8));
+	UP_CHK(hipMalloc((void**)&n_S, ix.S.size() * 4 + 8));
+	UP_CHK(hipMemcpyPeer(n_S, c->device, d_S, src_device, ix.S.size() * 4));
+	UP_CHK(hipMemcpyPeer(n_hkey, c->device, d_hkey, src_device, ix.hkey.size() * 8));
+	UP_CHK(hipMemcpyPeer(n_hval, c->device, d_hval, src_device, ix.hval.size() * 8));
+	if (!ix.P.empty()) UP_CHK(hipMemcpyPeer(n_P, c->device, d_P, src_device, ix.P.size() * 8));
+	UP_CHK(hipMemcpyPeer(n_bloom, c->device, d_bloom, src_device, ix.bloom.bits.size()));
+	UP_CHK(hipDeviceSynchronize());
+#undef UP_CHK
 	if (c->have_index && c->owns_index) { hipFree(c->d_hkey); hipFree(c->d_hval); hipFree(c->d_P); hipFree(c->d_bloom); hipFree(c->d_S); }
-	if (!c->have_index && c->owns_filter && c->d_bloom) { hipFree(c->d_bloom); c->d_bloom = 0; }
+	if (!c->have_index && c->owns_filter && c->d_bloom) hipFree(c->d_bloom);
 	c->owns_filter = false;
-	c->have_index = false; c->d_S = 0; c->seq_off.clear(); c->seq_len.clear();
-	HIPCHK(hipMalloc((void**)&c->d_hkey, ix.hkey.size() * 8 + 8));
-	HIPCHK(hipMalloc((void**)&c->d_hval, ix.hval.size() * 8 + 8));
-	HIPCHK(hipMalloc((void**)&c->d_P, ix.P.size() * 8 + 8));
-	HIPCHK(hipMalloc((void**)&c->d_bloom, ix.bloom.bits.size() + 8));
-	HIPCHK(hipMalloc((void**)&c->d_S, ix.S.size() * 4 + 8));
-	HIPCHK(hipMemcpyPeer(c->d_S, c->device, d_S, src_device, ix.S.size() * 4));
-	HIPCHK(hipMemcpyPeer(c->d_hkey, c->device, d_hkey, src_device, ix.hkey.size() * 8));
-	HIPCHK(hipMemcpyPeer(c->d_hval, c->device, d_hval, src_device, ix.hval.size() * 8));
-	if (!ix.P.empty()) HIPCHK(hipMemcpyPeer(c->d_P, c->device, d_P, src_device, ix.P.size() * 8));
-	HIPCHK(hipMemcpyPeer(c->d_bloom, c->device, d_bloom, src_device, ix.bloom.bits.size()));
-	HIPCHK(hipDeviceSynchronize());
+	c->d_hkey = n_hkey; c->d_hval = n_hval; c->d_P = n_P; c->d_bloom = n_bloom; c->d_S = n_S;
+	c->seq_off.clear(); c->seq_len.clear();
 	for (const wm::RefSeq &r : ix.seq) { c->seq_off.push_back(r.offset); c->seq_len.push_back(r.len); }
 	c->hbits = ix.hbits;
 	c->skp.w = ix.w; c->skp.k = ix.k; c->skp.table_bits = (uint32_t)ix.bloom.table_bits; c->skp.salt0 = ix.bloom.salt[0]; c->skp.salt1 = ix.bloom.salt[1];
@@ -1625,6 +1651,7 @@ extern "C" int wm_index_upload_peer(wm_ctx_t *dst, const wm_index_t *h, const wm
 {
 	if (!dst || !h || !src) return set_err(WM_EINVAL, "null argument");
 	if (!src->have_index) return set_err(WM_EINVAL, "the source context holds no index");
+	if (dst == src) return set_err(WM_EINVAL, "source and destination are the same context");
 	if (src->hbits != h->ix.hbits || src->seq_len.size() != h->ix.seq.size()) return set_err(WM_EINVAL, "the source context holds a different index");
 	return wm_index_upload_dev(dst, h, src->d_S, src->d_hkey, src->d_hval, src->d_P, src->d_bloom, src->device);
 }
@@ -2746,6 +2773,7 @@ struct GpuOps {                          // the device contexts of a mapper, sha
 	hipStream_t up_stream = 0;                  // uploads of the mini-batches' read codes
 	~GpuOps() { if (up_stream) hipStreamDestroy(up_stream); }
 	size_t slab = 0;
+	int n_slabs = 0;
 	bool slot_busy[WM_MAX_SLOTS] = { false };
 	bool load_reads(const uint8_t *codes, size_t n, int slot, int64_t *base, std::string &err)
 	{
@@ -2755,13 +2783,17 @@ struct GpuOps {                          // the device contexts of a mapper, sha
 		wm_ctx_t *c0 = ctxs[0].c;
 		std::lock_guard<std::mutex> lk(reads_mu);
 		if (hipSetDevice(c0->device) != hipSuccess) return false;
-		if (n + 64 > slab || !c0->d_reads || !c0->owns_reads) {
+		if (n + 64 > slab || slot >= n_slabs || !c0->d_reads || !c0->owns_reads) {
 			for (int o = 0; o < WM_MAX_SLOTS; ++o) if (o != slot && slot_busy[o]) return false;      // another mini-batch lives in the allocation: this one is served from its host views
 			if (c0->d_reads && c0->owns_reads) hipFree(c0->d_reads);
 			c0->d_reads = 0; c0->owns_reads = false; slab = 0;
 			const size_t want = (n + n / 8 + (1 << 20) + 255) & ~(size_t)255;
-			if (hipMalloc((void**)&c0->d_reads, WM_MAX_SLOTS * want) != hipSuccess) { (void)hipGetLastError(); c0->d_reads = 0; return false; }
-			c0->owns_reads = true; c0->reads_cap = WM_MAX_SLOTS * want; c0->reads_bytes = WM_MAX_SLOTS * want; slab = want;
+			// slabs for the mini-batches that can be in flight: WM_READ_SLABS, else the lanes of wm_map_file (WM_MAP_LANES), at least 2 (four were
+			// allocated whatever the caller used — 4.5 GB for 1-Gbase mini-batches); a call on a slot beyond them is served from its host views
+			n_slabs = std::max(2, std::min((int)WM_MAX_SLOTS, getenv("WM_READ_SLABS") ? atoi(getenv("WM_READ_SLABS")) : getenv("WM_MAP_LANES") ? atoi(getenv("WM_MAP_LANES")) : 2));
+			if (slot >= n_slabs) n_slabs = slot + 1;
+			if (hipMalloc((void**)&c0->d_reads, (size_t)n_slabs * want) != hipSuccess) { (void)hipGetLastError(); c0->d_reads = 0; return false; }
+			c0->owns_reads = true; c0->reads_cap = (size_t)n_slabs * want; c0->reads_bytes = (size_t)n_slabs * want; slab = want;
 			for (size_t i = 1; i < ctxs.size(); ++i) {
 				wm_ctx_t *c = ctxs[i].c;
 				if (c->owns_reads && c->d_reads) hipFree(c->d_reads);
@@ -2867,6 +2899,7 @@ extern "C" int wm_mapper_create(wm_ctx_t *c, const wm_index_t *idx, const char *
 	if (!c || !idx) return set_err(WM_EINVAL, "null argument");
 	if (!c->have_index) return set_err(WM_EINVAL, "wm_index_upload has not been called on this context");
 	if (mapper_index_ok(idx)) return WM_EINVAL;
+	wm_default_malloc();
 	wm_mapper_t *m = new wm_mapper_t();
 	m->c = c; m->idx = idx;
 	wm::set_preset(0, m->io, m->mo);
@@ -2917,6 +2950,7 @@ extern "C" int wm_mapper_create_opt(wm_ctx_t *c, const wm_index_t *idx, const wm
 	if (!c || !idx || !opt) return set_err(WM_EINVAL, "null argument");
 	if (!c->have_index) return set_err(WM_EINVAL, "wm_index_upload has not been called on this context");
 	if (mapper_index_ok(idx)) return WM_EINVAL;
+	wm_default_malloc();
 	wm_mapper_t *m = new wm_mapper_t();
 	m->c = c; m->idx = idx;
 	wm::set_preset(0, m->io, m->mo);
@@ -3320,6 +3354,7 @@ extern "C" int wm_ksw_ll_i16(int qlen, const uint8_t *query, int tlen, const uin
 	return sc;
 }
 
+extern "C" int wm_ksw_n_classes(void) { return WM_KSW_NCLASS; }      // kernel classes wm_mapper_kernel_stats / _union report on (ksw_plan.h)
 extern "C" int wm_mapper_stats(const wm_mapper_t *m, uint64_t *out9) { memcpy(out9, m->stats, sizeof(m->stats)); return WM_OK; }
 // per ksw kernel class (ksw_plan.h) since the mapper was created: out[3*k] = summed launch durations in ms (HIP events on the
 // launching stream), out[3*k+1] = DP cells, out[3*k+2] = launches; n_classes receives WM_KSW_NCLASS
@@ -3343,7 +3378,10 @@ extern "C" int wm_mapper_kernel_union(const wm_mapper_t *m, double since_ms, dou
 	std::vector<const wm_ctx_t*> cs; cs.push_back(m->c); cs.insert(cs.end(), m->workers.begin(), m->workers.end());
 	for (int k = 0; k < WM_KSW_NCLASS; ++k) {
 		std::vector<std::pair<float, float>> iv;
-		for (const wm_ctx_t *c : cs) for (const auto &p : c->k_iv[k]) if (p.second > since_ms) iv.push_back(std::make_pair(std::max(p.first, (float)since_ms), p.second));
+		for (const wm_ctx_t *c : cs) {
+			std::lock_guard<std::mutex> lk(const_cast<wm_ctx_t*>(c)->iv_mu);
+			for (const auto &p : c->k_iv[k]) if (p.second > since_ms) iv.push_back(std::make_pair(std::max(p.first, (float)since_ms), p.second));
+		}
 		std::sort(iv.begin(), iv.end());
 		double tot = 0, cur_s = 0, cur_e = -1;
 		for (const auto &p : iv) {

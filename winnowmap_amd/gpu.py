@@ -400,6 +400,8 @@ class Index:
 
     @property
     def n_minimizers(self):
+        if not self._h:
+            raise RuntimeError("the index has been closed")
         return int(lib().wm_index_n_minimizers(self._h))
 
     def names(self):
@@ -481,11 +483,12 @@ class Mapper:
 
     def kernel_union(self, since_ms=0.0):
         """(dict class -> ms with at least one launch of the class running since `since_ms`, device clock now in ms)"""
-        out = np.zeros(64, np.float64)
+        ncl = int(lib().wm_ksw_n_classes())
+        out = np.zeros(max(64, ncl), np.float64)
         now = C.c_double()
         lib().wm_mapper_kernel_union.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
         _chk(lib().wm_mapper_kernel_union(self._h, float(since_ms), out.ctypes.data, len(out), C.byref(now)))
-        return {k: float(out[k]) for k in range(52)}, now.value      # (WM_KSW_NCLASS)
+        return {k: float(out[k]) for k in range(ncl)}, now.value
 
     def host_stats(self):
         """host time accounting since the mapper was created (wm_mapper_host_stats), seconds summed over the worker threads"""
