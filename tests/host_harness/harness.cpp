@@ -447,6 +447,30 @@ int h_map_file_split(const char *fasta, const char *kmer_file, int k, int w, int
 	return n_parts;
 }
 
+// the mapper's own mm_test_zdrop (scan + verdict incl. the inversion test) and mm_update_extra (mm_fix_cigar + the vector scan), for
+// tests/test_walks_vs_ref.py: compared with the reference's static functions (oracle/ref_align_shim.cpp)
+int h_test_zdrop(int64_t flag, int zdrop, int zdrop_inv, int q, int e, int max_gap, int min_chain_score, int a, int min_dp_max,
+                 const uint8_t *qseq, const uint8_t *tseq, const uint32_t *cigar, int n_cigar, const int8_t *mat)
+{
+	MapOpt o;
+	o.flag = flag; o.zdrop = zdrop; o.zdrop_inv = zdrop_inv; o.q = q; o.e = e; o.max_gap = max_gap; o.min_chain_score = min_chain_score; o.a = a; o.min_dp_max = min_dp_max;
+	std::vector<uint32_t> cg(cigar, cigar + n_cigar);
+	return test_zdrop(o, qseq, tseq, cg, mat);
+}
+int h_update_extra(int rev, int qs, int qe, int rs, int re, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int q, int e,
+                   const uint32_t *cigar, int n_cigar, int32_t *out6, uint32_t *cigar_out, int cap, int *n_out)
+{
+	Reg r;
+	r.rev = rev; r.qs = qs; r.qe = qe; r.rs = rs; r.re = re; r.has_p = true;
+	r.cigar.assign(cigar, cigar + n_cigar);
+	update_extra(r, qseq, tseq, mat, q, e);
+	out6[0] = r.blen; out6[1] = r.mlen; out6[2] = (int32_t)r.n_ambi; out6[3] = r.dp_max; out6[4] = rev ? r.qe : r.qs; out6[5] = r.rs;
+	*n_out = (int)r.cigar.size();
+	for (size_t i = 0; i < r.cigar.size() && (int)i < cap; ++i) cigar_out[i] = r.cigar[i];
+	std::string ie;
+	return take_internal_error(ie) ? -5 : 0;
+}
+
 // the host's compile of the CIGAR walks the device also runs (winnowmap_amd/csrc/cigar_walk.h)
 void h_zdrop_walk(const uint8_t *q, const uint8_t *t, const uint32_t *cigar, int n_cigar, int match, int mismatch, int ambi, int gq, int ge, int32_t *out5)
 {
