@@ -2247,9 +2247,13 @@ __global__ __launch_bounds__(64) void win_sort_kernel(const wm_win_job_t *__rest
 
 // anchor sets beyond the LDS classes: a whole workgroup sorts (win_bigsort_block: stable, exact whenever the keys are distinct); if two keys tie the
 // job falls back to the literal replay of the reference's permutation by one wavefront (win_sort_wave<true>) on the untouched input
+// tie_list != 0 (round 5): a job whose keys tie is not replayed here — one lane walking the permutation through global memory costs ~1.5 us per anchor and
+// digit level (14 s for the 10^6 anchors of a 5-Mb contig's stage-2 pass, profiles/r05_config5.txt) — but handed to the HOST, where the same serial
+// algorithm runs a thousand times faster (window_launch: the ranges of the listed jobs travel down, are sorted by host/wm_core.cpp's radix_sort_128x,
+// travel back, and win_plan_list_kernel finishes the job). Entry i of the list (8 ints from tie_list + 8 + 8 i): job, round, a_off lo / hi, n, n_pre.
 template <int NWV>
 __global__ __launch_bounds__(64 * NWV) void win_bigsort_kernel(const wm_win_job_t *__restrict__ jobs, const wm_win_res_t *res, wm128_t *anchors, wm128_t *buf0, wm128_t *buf1,
-                                                               wm_chain_job_t *cj, int *lists, int *counts, int n_jobs, int lo)
+                                                               wm_chain_job_t *cj, int *lists, int *counts, int n_jobs, int lo, int *tie_list)
 {
 	WM_SETPRIO(2);
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2268,6 +2272,13 @@ __global__ __launch_bounds__(64 * NWV) void win_bigsort_kernel(const wm_win_job_
 			const int m = round == 0 ? n - n_pre : n;
 			int tie = 0;
 			const int cur = wmk::win_bigsort_block(NWV, rng, buf0 + r.a_off, buf1 + r.a_off, m, big, &tie);
+			if (tie && tie_list) {                 // (uniform over the workgroup) the host finishes this job: this round and what follows it
+				if (threadIdx.x == 0) {
+					int *e = tie_list + 8 + 8 * atomicAdd(tie_list, 1);
+					e[0] = j; e[1] = round; e[2] = (int)(uint32_t)((uint64_t)r.a_off & 0xffffffffu); e[3] = (int)(uint32_t)((uint64_t)r.a_off >> 32); e[4] = n; e[5] = n_pre;
+				}
+				return;
+			}
 			if (tie) { if (wv == 0) wmk::win_sort_wave<true>(rng, m, ws); }
 			else if (cur >= 0) {
 				const uint64_t *src = (const uint64_t*)((cur ? buf1 : buf0) + r.a_off);
@@ -2279,6 +2290,16 @@ __global__ __launch_bounds__(64 * NWV) void win_bigsort_kernel(const wm_win_job_
 		}
 	}
 	if (wv == 0) wmk::win_plan_wave(jb, j, r.a_off, n, a, cj, lists, counts, n_jobs);
+}
+
+// the jobs the host sorted (win_bigsort_kernel's tie list): their fill is planned here
+__global__ __launch_bounds__(64) void win_plan_list_kernel(const wm_win_job_t *__restrict__ jobs, const wm_win_res_t *res, const wm128_t *anchors, wm_chain_job_t *cj, int *lists, int *counts,
+                                                           int n_jobs, const int *tie_list)
+{
+	if ((int)blockIdx.x >= tie_list[0]) return;
+	const int j = tie_list[8 + 8 * blockIdx.x];
+	const wm_win_res_t r = res[j];
+	wmk::win_plan_wave(jobs[j], j, r.a_off, r.n_a, anchors + r.a_off, cj, lists, counts, n_jobs);
 }
 
 // the fills of seedchain_kernel.h over a device-side job list (block b serves list[b]; blocks beyond *count leave)
@@ -2380,6 +2401,9 @@ static int window_launch(wm_ctx_t *c, int n, const wm_window_job_t *jobs, const 
 	D.d_res = (wm_win_res_t*)arena_take(c, (size_t)n * sizeof(wm_win_res_t) + 64);
 	wm_chain_job_t *d_cj = (wm_chain_job_t*)arena_take(c, (size_t)n * sizeof(wm_chain_job_t) + 64);
 	int *d_lists = (int*)arena_take(c, (size_t)n * 4 * 4 + 64);
+	static const bool ties_on_host = !(getenv("WM_WINDOW_TIES_HOST") && atoi(getenv("WM_WINDOW_TIES_HOST")) == 0);      // (0: the literal replay on the device, as until round 4; A/B)
+	int *d_tie = ties_on_host ? (int*)arena_take(c, (size_t)(8 + 8 * (size_t)n) * 4) : 0;
+	if (ties_on_host && !d_tie) return set_err(WM_ENOMEM, "window batch does not fit the arena");
 	uint64_t *d_ctr = (uint64_t*)arena_take(c, 64);          // [0] anchors used, [1] chains in the result pool, [2] anchors in the result pool, [3] worst err (int), [4..5] the four class counts (ints)
 	if (!d_jobs || !d_sj || !d_ord || !d_seqs || !d_pre || !d_so || !d_sx || !d_sy || !d_sl || !d_mini || !d_mcnt || !d_occ || !d_emit || !d_first || !D.d_res || !d_cj || !d_lists || !d_ctr)
 		return set_err(WM_ENOMEM, "window batch does not fit the arena");
@@ -2406,6 +2430,7 @@ static int window_launch(wm_ctx_t *c, int n, const wm_window_job_t *jobs, const 
 	HIPCHK(hipMemcpyAsync(d_sj, sj.data(), (size_t)n * sizeof(wm_sketch_job_t), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipMemsetAsync(D.d_res, 0, (size_t)n * sizeof(wm_win_res_t), c->stream));
 	HIPCHK(hipMemsetAsync(d_ctr, 0, 64, c->stream));
+	if (d_tie) HIPCHK(hipMemsetAsync(d_tie, 0, 32, c->stream));
 	HIPCHK(hipEventRecord(c->ev[0], c->stream));
 	hipLaunchKernelGGL(sketch_coop_kernel, dim3(n), dim3(64), 0, c->stream, c->skp, d_sj, d_ord, d_seqs, c->d_bloom, d_so, d_sx, d_sy, d_sl, d_mini, d_mcnt);
 	wm_index_view_t ix = { c->d_hkey, c->d_hval, c->d_P, c->hbits, 0 };
@@ -2420,7 +2445,44 @@ static int window_launch(wm_ctx_t *c, int n, const wm_window_job_t *jobs, const 
 	{
 		constexpr int NWV = 8;
 		const size_t big_bytes = (size_t)((WIN_BIG_INTS(NWV) + 3) & ~3) * 4 + ws_bytes;
-		hipLaunchKernelGGL(win_bigsort_kernel<NWV>, dim3(n), dim3(64 * NWV), big_bytes, c->stream, d_jobs, D.d_res, d_a, d_b, d_w, d_cj, d_lists, d_counts, n, kLarge);
+		hipLaunchKernelGGL(win_bigsort_kernel<NWV>, dim3(n), dim3(64 * NWV), big_bytes, c->stream, d_jobs, D.d_res, d_a, d_b, d_w, d_cj, d_lists, d_counts, n, kLarge, d_tie);
+	}
+	if (d_tie) {
+		// large anchor sets whose keys tie: the exact order of equal keys is the reference's unstable sort's (src/ksort.h:101-151), a serial algorithm —
+		// serial work belongs on the host. One small read-back per window call; the ranges travel only when there are such jobs.
+		int *h_cnt = c->pin_small ? c->pin_small + 16 : 0;
+		int cnt_pageable = 0;
+		HIPCHK(hipMemcpyAsync(h_cnt ? h_cnt : &cnt_pageable, d_tie, 4, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(ctx_sync(c));
+		const int n_tie = h_cnt ? *h_cnt : cnt_pageable;
+		if (n_tie > 0) {
+			UBuf<int> tl((size_t)8 * n_tie, c);
+			HIPCHK(hipMemcpyAsync(tl.data(), d_tie + 8, (size_t)8 * n_tie * 4, hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(ctx_sync(c));
+			std::vector<uint64_t> off((size_t)n_tie + 1, 0);
+			for (int i = 0; i < n_tie; ++i) off[i + 1] = off[i] + (uint64_t)tl[8 * i + 4];
+			UBuf<wm128_t> ha((size_t)off[n_tie] + 1, c);
+			for (int i = 0; i < n_tie; ++i) {
+				const uint64_t a_off = (uint64_t)(uint32_t)tl[8 * i + 2] | (uint64_t)(uint32_t)tl[8 * i + 3] << 32;
+				HIPCHK(hipMemcpyAsync(ha.data() + off[i], d_a + a_off, (size_t)tl[8 * i + 4] * 16, hipMemcpyDeviceToHost, c->stream));
+			}
+			HIPCHK(ctx_sync(c));
+			{
+				WM_SITE("window.tie_sort");
+				wm::parallel_for(c->host_threads, (size_t)n_tie, [&](size_t i) {
+					wm::m128 *a0 = (wm::m128*)(ha.data() + off[i]);
+					const int nn = tl[8 * i + 4], round = tl[8 * i + 1], n_pre = std::min(tl[8 * i + 5], nn);
+					if (round == 0) wm::radix_sort_128x(a0 + n_pre, a0 + nn);                    // the seeded anchors (src/map.c:252) ...
+					if (round == 1 || n_pre > 0) wm::radix_sort_128x(a0, a0 + nn);               // ... then the union with the handed-in ones (:833)
+				});
+			}
+			for (int i = 0; i < n_tie; ++i) {
+				const uint64_t a_off = (uint64_t)(uint32_t)tl[8 * i + 2] | (uint64_t)(uint32_t)tl[8 * i + 3] << 32;
+				HIPCHK(hipMemcpyAsync(d_a + a_off, ha.data() + off[i], (size_t)tl[8 * i + 4] * 16, hipMemcpyHostToDevice, c->stream));
+			}
+			hipLaunchKernelGGL(win_plan_list_kernel, dim3(n_tie), dim3(64), 0, c->stream, d_jobs, D.d_res, d_a, d_cj, d_lists, d_counts, n, d_tie);
+			HIPCHK(ctx_sync(c));                 // (the staging buffers above are released at the end of this block)
+		}
 	}
 	{   // the fill, per class list: 0 dense (8 waves, W 4096) | 1 large sparse (1 wave, W 1024) | 2 n <= 1024 | 3 n <= 256
 		HIPCHK(hipFuncSetAttribute((const void*)win_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
