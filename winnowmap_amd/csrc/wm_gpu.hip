@@ -439,24 +439,6 @@ static hipEvent_t device_base_event(int device)
 	return ev[device];
 }
 
-// WM_CU_SPLIT=N (experiment, default 0 = off): the latency-bound alignment classes (the side streams of heavy / huge ksw calls: stripe kernels, long exact
-// extensions) get N compute units of their own and everything else — the contexts' main streams and the light calls' side streams — the other 256 - N, so
-// that a serial chain of a few hundred wavefronts never shares a SIMD with eight throughput wavefronts (VERDICT r4 item 2 iii). Mask bit i is compute unit
-// i / 8 of XCD i % 8 (the driver deals the bits round-robin over the XCDs), so [0, N) takes N / 8 units of every XCD. Masked streams are created
-// without hipStreamNonBlocking by the runtime (they synchronise with the NULL stream): nothing on the mapping path uses the NULL stream.
-static int cu_split() { static const int v = getenv("WM_CU_SPLIT") ? std::max(0, std::min(248, atoi(getenv("WM_CU_SPLIT")) / 8 * 8)) : 0; return v; }
-static hipError_t make_stream(hipStream_t *st, int cu_lo, int cu_hi)
-{
-	int n_cu = 0;
-	hipDeviceProp_t prop;
-	int dev = 0;
-	if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-	if (cu_lo <= 0 && (cu_hi < 0 || cu_hi >= n_cu || n_cu <= 0)) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-	if (cu_hi < 0 || cu_hi > n_cu) cu_hi = n_cu;
-	std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
-	for (int i = cu_lo; i < cu_hi; ++i) mask[(size_t)i >> 5] |= 1u << (i & 31);
-	return hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
-}
 // how the mapper's side-stream pool of P streams is divided among light | heavy | huge ksw calls (WM_SIDE_SPLIT=light,heavy; the rest = huge)
 static void side_split(int P, int *light, int *heavy)
 {
@@ -827,7 +809,7 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	int n_nonempty = 0, used_mask = 0, rr = 0;
 	for (int k = 0; k < WM_KSW_NCLASS; ++k) n_nonempty += !b->order[k].empty();
 	static const int n_side = std::max(0, std::min(4, getenv("WM_SIDE_STREAMS") ? atoi(getenv("WM_SIDE_STREAMS")) : 3));   // contexts x (1 + side streams) should not exceed the hardware queues
-	bool fan = n_nonempty > 1 && !trace_k && n_side > 0;
+	const bool fan = n_nonempty > 1 && !trace_k && n_side > 0;
 	if (fan) HIPCHK(hipEventRecord(c->kev[4], c->stream));
 	hipStream_t ks = c->stream;
 	hipStream_t side[4] = {0, 0, 0, 0};          // the side streams of this call: from the mapper's pool, else the context's own
@@ -854,7 +836,6 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		}
 	}
 	const int n_use = c->side_pool ? std::min(n_side, pool_n) : n_side;
-	if (!fan && cu_split() > 0 && wclass > 0 && c->side_pool && n_use > 0 && !trace_k) { fan = true; HIPCHK(hipEventRecord(c->kev[4], c->stream)); }   // (even a single class: the main stream runs on the other CUs)
 	if (fan && n_use > 0) {
 		if (c->side_pool) { const unsigned b0 = c->side_next[wclass].fetch_add((unsigned)n_use); for (int i = 0; i < n_use; ++i) side[i] = c->side_pool[pool_lo + (int)((b0 + (unsigned)i) % (unsigned)pool_n)]; }
 		else for (int i = 0; i < n_use; ++i) { if (!c->kstream[i]) HIPCHK(hipStreamCreateWithFlags(&c->kstream[i], hipStreamNonBlocking)); side[i] = c->kstream[i]; }
@@ -3065,22 +3046,11 @@ extern "C" int wm_mapper_set_threads(wm_mapper_t *m, int n_threads, size_t arena
 		if (C == 1) P = 0;                                   // a single context keeps its own side streams
 		wm_ctx_t *c0 = m->c;                                  // (the pool lives and dies with the mapper's first context)
 		HIPCHK(hipStreamSynchronize(c0->stream));
-		const int split = cu_split();
-		if (split > 0) {                                      // (experiment: every stream of the mapper is re-made with its half of the chip)
-			for (hipStream_t st : c0->owned_pool) hipStreamDestroy(st);
-			c0->owned_pool.clear();
-			std::vector<wm_ctx_t*> all; all.push_back(c0); all.insert(all.end(), m->workers.begin(), m->workers.end());
-			for (wm_ctx_t *x : all) { HIPCHK(hipStreamSynchronize(x->stream)); HIPCHK(hipStreamDestroy(x->stream)); HIPCHK(make_stream(&x->stream, split, -1)); }
-		}
-		int sp_l = 0, sp_h = 0;
-		side_split(P, &sp_l, &sp_h);
+		// (compute units of their own for the heavy / huge calls' side streams — hipExtStreamCreateWithCUMask, VERDICT r4 item 2 iii — were measured in round 5:
+		// 0.075 / 0.118 / 0.174 Gbp/s with 32 / 64 / 96 CUs against 0.257 without; profiles/r05_sched.txt. The few hundred latency-bound wavefronts of a
+		// stripe launch need the whole chip's SIMDs.)
 		while ((int)c0->owned_pool.size() > P) { hipStreamDestroy(c0->owned_pool.back()); c0->owned_pool.pop_back(); }
-		while ((int)c0->owned_pool.size() < P) {
-			hipStream_t st;
-			const bool latency_side = split > 0 && (int)c0->owned_pool.size() >= sp_l;        // heavy | huge part of the pool
-			HIPCHK(split > 0 ? (latency_side ? make_stream(&st, 0, split) : make_stream(&st, split, -1)) : hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-			c0->owned_pool.push_back(st);
-		}
+		while ((int)c0->owned_pool.size() < P) { hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); c0->owned_pool.push_back(st); }
 		c0->side_pool = P > 0 ? c0->owned_pool.data() : 0; c0->n_side_pool = P; c0->side_next = c0->owned_next;
 		for (wm_ctx_t *w : m->workers) { w->side_pool = c0->side_pool; w->n_side_pool = P; w->side_next = c0->owned_next; }
 	}
