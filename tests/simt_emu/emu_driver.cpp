@@ -250,6 +250,45 @@ int emu_sketch_coop(int n, const uint8_t *seqs, const uint64_t *offs, const int3
 	return 0;
 }
 
+// the same cut into chunks of `chunk` positions, one emulated wavefront per chunk (the sketch_long_* kernels of wm_gpu.hip: phase 1 per chunk, the first
+// sync position of every chunk, phase 2 from sync to sync, the chunks' minimizers concatenated). poison != 0: every chunk's phase 1 runs on a scratch of
+// its own that holds garbage outside the chunk, so that nothing depends on what a neighbour computed earlier than the protocol says.
+int emu_sketch_chunked(int n, const uint8_t *seqs, const uint64_t *offs, const int32_t *lens, int w, int k, uint32_t table_bits, uint32_t salt0, uint32_t salt1,
+                       const uint8_t *bloom_bits, uint64_t *ox, uint64_t *oy, const uint64_t *out_offs, const int32_t *caps, int32_t *counts, int chunk, int32_t *n_absorbed)
+{
+	uint64_t tot = 0;
+	wm_sketch_params_t P = { w, k, table_bits, salt0, salt1 };
+	for (int i = 0; i < n; ++i) tot = std::max<uint64_t>(tot, out_offs[i] + caps[i]);
+	std::vector<wm128_t> out(tot + 1);
+	int absorbed = 0;
+	for (int i = 0; i < n; ++i) {
+		const int L = lens[i] > 0 ? lens[i] : 0;
+		std::vector<double> so((size_t)L + 1, -7.0); std::vector<uint64_t> sx((size_t)L + 1, 0xdeadbeefULL); std::vector<uint32_t> sy((size_t)L + 1, 0xabcdu), sl((size_t)L + 1, 0u);
+		const int n_ch = L > 0 ? (L + chunk - 1) / chunk : 1;
+		simt::exec_mask() = ~0ull;
+		for (int c = n_ch - 1; c >= 0; --c) {                 // (any order: phase 1 of a chunk depends on the sequence alone)
+			const int b = c * chunk, e = std::min(L, b + chunk);
+			wmk::sketch_p1_range(P, (long long)offs[i], L, seqs, bloom_bits, so.data(), sx.data(), sy.data(), sl.data(), b, e);
+		}
+		std::vector<int> sync(n_ch, -1);
+		for (int c = 1; c < n_ch; ++c) { sync[c] = wmk::sketch_find_sync(w, so.data(), c * chunk, std::min(L, (c + 1) * chunk)); absorbed += sync[c] < 0; }
+		int total = 0;
+		for (int c = 0; c < n_ch; ++c) {
+			if (c > 0 && sync[c] < 0) continue;
+			int t_stop = -1;
+			for (int d = c + 1; d < n_ch && t_stop < 0; ++d) t_stop = sync[d];
+			std::vector<wm128_t> tmp((size_t)chunk * 4 + 64);
+			const int cnt = wmk::sketch_p2_range(P, L, so.data(), sx.data(), sy.data(), sl.data(), c == 0 ? 0 : sync[c], c != 0, t_stop, tmp.data(), (int)tmp.size());
+			if (cnt > (int)tmp.size()) return -1;
+			for (int j = 0; j < cnt; ++j) { if (total < caps[i]) out[out_offs[i] + total] = tmp[j]; ++total; }
+		}
+		counts[i] = total;
+	}
+	if (n_absorbed) *n_absorbed = absorbed;
+	for (uint64_t i = 0; i < tot; ++i) ox[i] = out[i].x, oy[i] = out[i].y;
+	return 0;
+}
+
 // seed lookup on a flat index given as arrays
 int emu_seed(const uint64_t *hkey, const uint64_t *hval, const uint64_t *P, int hbits, const uint64_t *mx, const uint64_t *my, int n_mini, int qlen,
              int max_occ, int flag, uint64_t *ax, uint64_t *ay, int cap, int32_t *res_out)

@@ -150,6 +150,47 @@ def test_sketch_kernel_emulated_matches_oracle(emu, small_index, kernel, w, k):
         assert np.array_equal(ox[int(ooffs[i]):int(ooffs[i]) + n], ex) and np.array_equal(oy[int(ooffs[i]):int(ooffs[i]) + n], ey)
 
 
+@pytest.mark.parametrize("w,k,chunk", [(50, 15, 64), (50, 15, 257), (50, 19, 1000), (10, 15, 100), (100, 21, 333), (5, 11, 64), (200, 27, 512)])
+def test_sketch_in_chunks_matches_oracle(emu, small_index, w, k, chunk):
+    """sketch_p1_range / sketch_find_sync / sketch_p2_range (sketch_kernel.h): a sequence cut into chunks, one wavefront per chunk, as the sketch_long_*
+    kernels run contigs and long reads. Chunks far shorter than in the product (64 .. 1 000 positions against 16 384) put a boundary into every
+    kind of stretch: N runs, masked reads, homopolymers and short tandem repeats (equal orders: no sync position, the chunk is absorbed), sequence ends."""
+    S = small_index
+    emu.emu_sketch_chunked.argtypes = list(emu.emu_sketch.argtypes) + [C.c_int, C.POINTER(C.c_int32)]
+    rng = np.random.default_rng(40 + chunk)
+    seqs = [r.copy() for r in S["reads"][:2]]
+    m = S["reads"][1].copy(); m[1000:6000] = 4; m[9000:9049] = 4; m[9100:9151] = 4; m[12000:12014] = 4; m[12100:12115] = 4
+    seqs += [m, np.full(300, 4, np.uint8), np.concatenate([np.full(70, 4, np.uint8), S["reads"][2][:500], np.full(3, 4, np.uint8), S["reads"][2][500:520]])]
+    for ln_ in (1, 14, 15, 16, 63, 64, 65, 66, 79, 113, 128, 129, chunk - 1, chunk, chunk + 1, 2 * chunk, 2 * chunk + k):
+        seqs.append(S["reads"][3][100:100 + ln_].copy())
+    for it in range(16):                      # low-complexity / periodic sequences (ties over whole chunks), some with N; and such stretches inside random sequence
+        L, unit = int(rng.integers(100, 4000)), int(rng.integers(1, 13))
+        s = np.tile(rng.integers(0, 4, unit), L // unit + 1)[:L].astype(np.uint8)
+        if it % 2:
+            s = S["synth"].mutate_codes(s, rng, 0.01, 0, 0)
+        for _ in range(int(rng.integers(0, 3))):
+            s[int(rng.integers(0, len(s)))] = 4
+        if it % 4 == 0:
+            s = np.concatenate([S["reads"][4][:int(rng.integers(50, 900))], s, S["reads"][4][2000:2000 + int(rng.integers(50, 900))]])
+        seqs.append(s)
+    seqs.append(np.zeros(3 * chunk + 17, np.uint8))                    # one homopolymer across several chunks
+    lens = np.array([len(s) for s in seqs], np.int32)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    caps = (lens + 1).astype(np.int32)
+    ooffs = np.concatenate([[0], np.cumsum(caps)[:-1]]).astype(np.uint64)
+    ox = np.zeros(int(caps.sum()), np.uint64); oy = np.zeros(int(caps.sum()), np.uint64); counts = np.zeros(len(seqs), np.int32)
+    absorbed = C.c_int32()
+    rc = emu.emu_sketch_chunked(len(seqs), np.concatenate(seqs), offs, lens, w, k, S["tb"], S["salts"][0], S["salts"][1], C.cast(S["bloom_bits"], C.c_void_p), ox, oy, ooffs, caps, counts,
+                                chunk, C.byref(absorbed))
+    assert rc == 0
+    for i, s in enumerate(seqs):
+        ex, ey = W.o_sketch(bytes(s), w, k, rid=0, bloom=S["bloom"])
+        n = counts[i]
+        assert n == len(ex), (i, len(s), n, len(ex))
+        assert np.array_equal(ox[int(ooffs[i]):int(ooffs[i]) + n], ex) and np.array_equal(oy[int(ooffs[i]):int(ooffs[i]) + n], ey), (i, len(s))
+    assert absorbed.value > 0          # chunks without a sync position occurred (N runs, homopolymers)
+
+
 def _expected_anchors(S, mx, my, qlen, max_occ=5000):
     """collect_seed_hits restated in numpy/python on the product index (src/map.c:97-130,222-254)"""
     H, h = S["H"], S["h"]

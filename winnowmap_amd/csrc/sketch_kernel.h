@@ -177,18 +177,40 @@ WM_DEV void sketch_wave(const wm_sketch_params_t P, const wm_sketch_job_t *jobs,
 // position the current minimum is flushed (:208-214).
 // Slot 0 is always empty for k >= 2 (l = 1 < k), which makes "m = 0, empty" the state after step 0.
 // ------------------------------------------------------------------------------------------------------------------------------
-WM_DEV void sketch_coop(const wm_sketch_params_t P, const wm_sketch_job_t jb, const uint8_t *seqs, const uint8_t *bloom_bits,
-                        double *so, uint64_t *sx, uint32_t *sy, uint32_t *sl, wm128_t *out, int *count_out)
+// ---- the two phases over a RANGE of the sequence (round 5): a long sequence — a contig of the reference at index time, a 5-Mb query contig, the
+// stage-2 pass of a long read — is cut into chunks and every chunk gets a wavefront of its own (sketch_long_* kernels, wm_gpu.hip) instead of one
+// wavefront walking 10^6..10^8 positions (a 125-Mb contig: 34 s). Phase 1 is positional, so a chunk only has to know where the last ambiguous base
+// before it lies (as far as the comparisons with w + k can see). Phase 2's state after step t is (m, order[m]); a chunk may start wherever that state
+// is KNOWN without the history: at a position t whose order is strictly smaller than every order of the w - 1 positions before it (and is a real
+// k-mer) the automaton holds m = t after step t whatever happened before — a smaller order replaces any minimum (:180-190), and if the minimum is
+// being overwritten in that very step the rescan of (t - w, t] finds t as its only smallest slot (:199-204). sketch_find_sync finds the first such
+// position of a chunk; the wavefront of the chunk before runs up to and including the event of that step (it emits the minimum that t replaces) and
+// stops, the chunk's own wavefront starts from (m = t) without emitting. A chunk without such a position (a long low-complexity stretch) is simply
+// absorbed by its predecessor. The chunks' minimizers concatenate to the sequence's.
+
+// phase 1 for positions [begin, end) of a sequence of n codes at seqs + soff
+WM_DEV void sketch_p1_range(const wm_sketch_params_t P, long long soff, int n, const uint8_t *seqs, const uint8_t *bloom_bits,
+                            double *so, uint64_t *sx, uint32_t *sy, uint32_t *sl, int begin, int end)
 {
-	const int w = P.w, k = P.k, n = jb.len;
+	const int w = P.w, k = P.k;
 	const uint64_t mask = (1ULL << 2 * k) - 1;
 	const V<int> ln = lane();
-	const long long soff = (long long)jb.seq_off;
-	// ---- phase 1 ----
-	int last_n = -1;                                 // position of the last ambiguous base seen so far
-	for (int t0 = 0; t0 < n; t0 += 64) {
+	// position of the last ambiguous base before `begin`, as far back as l = i - last_n is ever compared with (w + k): beyond that any value does
+	int last_n = -1;
+	if (begin > 0) {
+		const int lo = begin - (w + k + 2) > 0 ? begin - (w + k + 2) : 0;
+		last_n = lo - 1;                                       // (nothing ambiguous in [lo, begin): l >= w + k + 2 at `begin`, or exact when lo == 0)
+		for (int t0 = lo; t0 < begin; t0 += 64) {
+			const V<int> i = ln + t0;
+			V<int> hit = -1;
+			WM_IF(i < begin) WM_IF(cast<int>(gld(seqs, cast<long long>(i) + soff)) >= 4) hit = i; WM_END WM_END
+			const int mx = readlane(wave_scan_max(hit), 63);
+			last_n = mx > last_n ? mx : last_n;
+		}
+	}
+	for (int t0 = begin; t0 < end; t0 += 64) {
 		const V<int> i = ln + t0;
-		const vbool in = i < n;
+		const vbool in = i < end;
 		V<int> c = 4;
 		WM_IF(in) c = cast<int>(gld(seqs, cast<long long>(i) + soff)); WM_END
 		const V<int> lastN = vmax(wave_scan_max(sel(in && c >= 4, i, V<int>(-1))), last_n);
@@ -220,12 +242,42 @@ WM_DEV void sketch_coop(const wm_sketch_params_t P, const wm_sketch_job_t jb, co
 			gst(so, i, co); gst(sx, i, cx); gst(sy, i, cy); gst(sl, i, cast<uint32_t>(l));
 		WM_END
 	}
-	mem_sync();                                      // phase 2 reads what other lanes of this wave wrote (same CU: a workgroup-scope fence; no L2 write-back per job)
-	// ---- phase 2 ----
-	int m = 0, n_out = 0;
-	double om = 2.0;
-	bool m_set = false;                              // the current minimum is a real k-mer
-	const long long ooff = (long long)jb.out_off;
+}
+
+// the first position t of [from, to) that holds a real k-mer whose order is strictly smaller than the orders of the (up to) w - 1 positions before it
+// (uniform; -1: none). so: phase-1 orders of the whole sequence (positions < from are read: they belong to the chunk before, written by phase 1)
+WM_DEV int sketch_find_sync(int w, const double *so, int from, int to)
+{
+	const V<int> ln = lane();
+	for (int t0 = from; t0 < to; t0 += 64) {
+		const V<int> t = ln + t0;
+		const vbool in = t < to;
+		V<double> o = 2.0;
+		WM_IF(in) o = gld(so, t); WM_END
+		vbool ok = in && o < 2.0;
+		for (int j = 1; j < w && any(ok); ++j) {
+			WM_IF(ok)
+				const V<int> q = t - j;
+				WM_IF(q >= 0) ok = o < gld(so, q); WM_END
+			WM_END
+		}
+		const uint64_t bm = ballot(ok);
+		if (bm) return t0 + __builtin_ctzll(bm);
+	}
+	return -1;
+}
+
+// phase 2 from the state (m0, set0) — (0, false) at the start of a sequence, (t, true) at a sync position t — up to and including the event after
+// which the minimum is t_stop (-1: to the end of the sequence, where the last minimum is flushed, :208-214). Minimizers go to out[0 .. cap); returns
+// how many the reference emits over the stretch (may exceed cap).
+WM_DEV int sketch_p2_range(const wm_sketch_params_t P, int n, const double *so, const uint64_t *sx, const uint32_t *sy, const uint32_t *sl,
+                           int m0, bool set0, int t_stop, wm128_t *out, int cap)
+{
+	const int w = P.w, k = P.k;
+	const V<int> ln = lane();
+	int m = m0, n_out = 0;
+	double om = set0 ? gld(so, (long long)m0) : 2.0;
+	bool m_set = set0;                               // the current minimum is a real k-mer
 	for (;;) {
 		int found = -1;
 		for (int b = m + 1; b <= m + w && b < n && found < 0; b += 64) {
@@ -238,22 +290,23 @@ WM_DEV void sketch_coop(const wm_sketch_params_t P, const wm_sketch_job_t jb, co
 		}
 		if (found >= 0) {                            // a strictly smaller order arrives at step `found` (:180-190)
 			if (m_set && (int)gld(sl, (long long)found) >= w + k) {
-				WM_IF(ln == 0 && n_out < jb.cap)
-					gst((uint64_t*)out, V<long long>((ooff + n_out) * 2), V<uint64_t>(gld(sx, (long long)m)));
-					gst((uint64_t*)out, V<long long>((ooff + n_out) * 2 + 1), V<uint64_t>((uint64_t)gld(sy, (long long)m)));
+				WM_IF(ln == 0 && n_out < cap)
+					gst((uint64_t*)out, V<long long>((long long)n_out * 2), V<uint64_t>(gld(sx, (long long)m)));
+					gst((uint64_t*)out, V<long long>((long long)n_out * 2 + 1), V<uint64_t>((uint64_t)gld(sy, (long long)m)));
 				WM_END
 				++n_out;
 			}
 			m = found; om = gld(so, (long long)m); m_set = true;
+			if (m == t_stop) return n_out;           // the next chunk starts from here
 			continue;
 		}
 		if (m + w > n - 1) break;                    // the minimum is never overwritten: flushed below
 		{
 			const int t = m + w;                     // slot m is overwritten at step m + w (:191-205)
 			if (m_set && (int)gld(sl, (long long)t) >= w + k - 1) {
-				WM_IF(ln == 0 && n_out < jb.cap)
-					gst((uint64_t*)out, V<long long>((ooff + n_out) * 2), V<uint64_t>(gld(sx, (long long)m)));
-					gst((uint64_t*)out, V<long long>((ooff + n_out) * 2 + 1), V<uint64_t>((uint64_t)gld(sy, (long long)m)));
+				WM_IF(ln == 0 && n_out < cap)
+					gst((uint64_t*)out, V<long long>((long long)n_out * 2), V<uint64_t>(gld(sx, (long long)m)));
+					gst((uint64_t*)out, V<long long>((long long)n_out * 2 + 1), V<uint64_t>((uint64_t)gld(sy, (long long)m)));
 				WM_END
 				++n_out;
 			}
@@ -276,16 +329,28 @@ WM_DEV void sketch_coop(const wm_sketch_params_t P, const wm_sketch_job_t jb, co
 				if (v <= best) { best = v; best_t = b + p; }   // (a later block wins ties)
 			}
 			m = best_t; om = best; m_set = om < 2.0;
+			if (m == t_stop) return n_out;
 		}
 	}
+	WM_EMU_ASSERT(t_stop < 0);                       // (a sync position ahead is always reached: see the header)
 	if (m_set) {                                     // flush (:208-214)
-		WM_IF(ln == 0 && n_out < jb.cap)
-			gst((uint64_t*)out, V<long long>((ooff + n_out) * 2), V<uint64_t>(gld(sx, (long long)m)));
-			gst((uint64_t*)out, V<long long>((ooff + n_out) * 2 + 1), V<uint64_t>((uint64_t)gld(sy, (long long)m)));
+		WM_IF(ln == 0 && n_out < cap)
+			gst((uint64_t*)out, V<long long>((long long)n_out * 2), V<uint64_t>(gld(sx, (long long)m)));
+			gst((uint64_t*)out, V<long long>((long long)n_out * 2 + 1), V<uint64_t>((uint64_t)gld(sy, (long long)m)));
 		WM_END
 		++n_out;
 	}
-	WM_IF(ln == 0) gst(count_out, V<long long>(0), V<int>(n_out)); WM_END
+	return n_out;
+}
+
+WM_DEV void sketch_coop(const wm_sketch_params_t P, const wm_sketch_job_t jb, const uint8_t *seqs, const uint8_t *bloom_bits,
+                        double *so, uint64_t *sx, uint32_t *sy, uint32_t *sl, wm128_t *out, int *count_out)
+{
+	const int n = jb.len;
+	sketch_p1_range(P, (long long)jb.seq_off, n, seqs, bloom_bits, so, sx, sy, sl, 0, n);
+	mem_sync();                                      // phase 2 reads what other lanes of this wave wrote (same CU: a workgroup-scope fence; no L2 write-back per job)
+	const int n_out = sketch_p2_range(P, n, so, sx, sy, sl, 0, false, -1, out + jb.out_off, jb.cap);
+	WM_IF(lane() == 0) gst(count_out, V<long long>(0), V<int>(n_out)); WM_END
 }
 
 } // namespace wmk

@@ -1281,12 +1281,67 @@ __global__ __launch_bounds__(64) void sketch_kernel(wm_sketch_params_t P, const 
 
 // one wavefront per sequence (sketch_coop, odd k): order[] lists the jobs longest first; so / sx / sy / sl = per-position scratch
 __global__ __launch_bounds__(64) void sketch_coop_kernel(wm_sketch_params_t P, const wm_sketch_job_t *jobs, const int *order, const uint8_t *seqs, const uint8_t *bloom,
-                                                          double *so, uint64_t *sx, uint32_t *sy, uint32_t *sl, wm128_t *out, int *counts)
+                                                          double *so, uint64_t *sx, uint32_t *sy, uint32_t *sl, wm128_t *out, int *counts, int long_thr)
 {
 	WM_SETPRIO(2);
 	const int j = order[blockIdx.x];
 	const wm_sketch_job_t jb = jobs[j];
+	if (long_thr > 0 && jb.len >= long_thr) return;           // sketched chunk by chunk (sketch_long_* kernels)
 	wmk::sketch_coop(P, jb, seqs, bloom, so + jb.scratch_off, sx + jb.scratch_off, sy + jb.scratch_off, sl + jb.scratch_off, out, counts + j);
+}
+
+// ---- long sequences (contigs of the reference at index time, query contigs, stage-2 passes of very long reads): one wavefront per CHUNK of the
+// sequence instead of one per sequence (sketch_kernel.h: sketch_p1_range / sketch_find_sync / sketch_p2_range explain why that is exact). Four launches:
+// phase 1 of every chunk | the first sync position of every chunk | phase 2 from sync to sync into chunk-local slots | per job: the chunks' minimizers
+// concatenated into the job's output slot. sketch_coop_kernel leaves these jobs alone (long_thr).
+struct wm_sk_chunk_t { int32_t job, begin, end, first; uint64_t out_off; int32_t cap, pad; };
+__global__ __launch_bounds__(64) void sketch_long_p1_kernel(wm_sketch_params_t P, const wm_sketch_job_t *jobs, const wm_sk_chunk_t *chunks, const uint8_t *seqs, const uint8_t *bloom,
+                                                             double *so, uint64_t *sx, uint32_t *sy, uint32_t *sl)
+{
+	const wm_sk_chunk_t ch = chunks[blockIdx.x];
+	const wm_sketch_job_t jb = jobs[ch.job];
+	wmk::sketch_p1_range(P, (long long)jb.seq_off, jb.len, seqs, bloom, so + jb.scratch_off, sx + jb.scratch_off, sy + jb.scratch_off, sl + jb.scratch_off, ch.begin, ch.end);
+}
+__global__ __launch_bounds__(64) void sketch_long_sync_kernel(wm_sketch_params_t P, const wm_sketch_job_t *jobs, const wm_sk_chunk_t *chunks, const double *so, int *sync)
+{
+	const wm_sk_chunk_t ch = chunks[blockIdx.x];
+	const int t = ch.first ? 0 : wmk::sketch_find_sync(P.w, so + jobs[ch.job].scratch_off, ch.begin, ch.end);
+	if (threadIdx.x == 0) sync[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(64) void sketch_long_p2_kernel(wm_sketch_params_t P, const wm_sketch_job_t *jobs, const wm_sk_chunk_t *chunks, int n_chunks, const double *so, const uint64_t *sx,
+                                                             const uint32_t *sy, const uint32_t *sl, const int *sync, wm128_t *cout, int *ccount)
+{
+	WM_SETPRIO(2);
+	const int b = blockIdx.x;
+	const wm_sk_chunk_t ch = chunks[b];
+	int n = 0;
+	if (ch.first || sync[b] >= 0) {                           // (a chunk without a sync position is covered by the wavefront of the chunk before it)
+		int t_stop = -1;
+		for (int d = b + 1; d < n_chunks && chunks[d].job == ch.job && t_stop < 0; ++d) t_stop = sync[d];
+		const wm_sketch_job_t jb = jobs[ch.job];
+		n = wmk::sketch_p2_range(P, jb.len, so + jb.scratch_off, sx + jb.scratch_off, sy + jb.scratch_off, sl + jb.scratch_off, ch.first ? 0 : sync[b], !ch.first, t_stop, cout + ch.out_off, ch.cap);
+	}
+	if (threadIdx.x == 0) ccount[b] = n;
+}
+// long_jobs[3 i ..]: job, its first chunk, its chunk count
+__global__ __launch_bounds__(64) void sketch_long_gather_kernel(const wm_sketch_job_t *jobs, const int *long_jobs, const wm_sk_chunk_t *chunks, const wm128_t *cout, const int *ccount,
+                                                                 wm128_t *out, int *counts)
+{
+	const int j = long_jobs[3 * blockIdx.x], c0 = long_jobs[3 * blockIdx.x + 1], nc = long_jobs[3 * blockIdx.x + 2];
+	const wm_sketch_job_t jb = jobs[j];
+	long long total = 0;
+	bool over = false;
+	for (int c = c0; c < c0 + nc; ++c) {
+		const int m = ccount[c];
+		if (m > chunks[c].cap) over = true;
+		if (!over && total + m <= jb.cap) {
+			const uint64_t *src = (const uint64_t*)(cout + chunks[c].out_off);
+			uint64_t *dst = (uint64_t*)(out + jb.out_off + total);
+			for (int i = threadIdx.x; i < 2 * m; i += 64) dst[i] = src[i];
+		}
+		total += m;
+	}
+	if (threadIdx.x == 0) counts[j] = over || total > jb.cap ? jb.cap + 1 : (int)total;      // (more than the slot holds: the caller repeats the job with a full-size slot)
 }
 
 __global__ __launch_bounds__(64) void seed_kernel(wm_index_view_t ix, const wm_seed_job_t *jobs, const wm128_t *mini, wm128_t *anchors,
@@ -1780,10 +1835,10 @@ extern "C" int wm_index_build_gpu(wm_ctx_t *c, const char *fasta, const char *km
 	std::vector<wm::m128> all;
 	int rc = WM_OK;
 	const size_t budget = (size_t)(c->arena_bytes * 0.85);
-	for (size_t g0 = 0; g0 < seqs.size() && rc == WM_OK;) {             // groups of contigs that fit the arena: 1 B codes + 24 B scratch + 2 B output per base
+	for (size_t g0 = 0; g0 < seqs.size() && rc == WM_OK;) {             // groups of contigs that fit the arena: 1 B codes + 24 B scratch + 2 B output + 4 B chunk-local output (+ tables) per base
 		size_t g1 = g0, bases = 0;
-		while (g1 < seqs.size() && (g1 == g0 || (bases + seqs[g1].size()) * 28 + 4096 * (g1 - g0 + 1) <= budget)) { bases += seqs[g1].size(); ++g1; }
-		if (bases * 28 > budget) { rc = set_err(WM_ENOMEM, "contig %zu (%zu bases) needs %.1f GB of arena for the device sketch", g0, seqs[g0].size(), seqs[g0].size() * 28 / 1073741824.0); break; }
+		while (g1 < seqs.size() && (g1 == g0 || (bases + seqs[g1].size()) * 34 + 4096 * (g1 - g0 + 1) <= budget)) { bases += seqs[g1].size(); ++g1; }
+		if (bases * 34 > budget) { rc = set_err(WM_ENOMEM, "contig %zu (%zu bases) needs %.1f GB of arena for the device sketch", g0, seqs[g0].size(), seqs[g0].size() * 34 / 1073741824.0); break; }
 		const int n = (int)(g1 - g0);
 		std::vector<uint64_t> off(n), ooff(n);
 		std::vector<int32_t> len(n), cnt(n);
@@ -1841,6 +1896,78 @@ extern "C" int wm_sketch_batch(wm_ctx_t *c, int n, const uint8_t *seqs, size_t s
 {
 	return sketch_batch_impl(c, n, seqs, seqs_bytes, seq_off, len, 0, out, out_cap, out_off, counts);
 }
+// The one-wavefront-per-sequence sketch of `n` jobs (h_jobs = the host copy of d_jobs) and, for sequences of WM_SKETCH_LONG (65 536) codes and more, the
+// chunked form: WM_SKETCH_CHUNK (16 384) positions per wavefront. allow_long = false (a repeat with full-size slots): everything on one wavefront each.
+// Everything is queued on the context's stream; with long jobs the call waits once (its chunk tables are staged in the pinned slab).
+static int sketch_long_thr(bool allow_long, int *chunk_out)
+{
+	static const int long_env = getenv("WM_SKETCH_LONG") ? atoi(getenv("WM_SKETCH_LONG")) : 65536;
+	static const int chunk = std::max(1024, getenv("WM_SKETCH_CHUNK") ? atoi(getenv("WM_SKETCH_CHUNK")) : 16384);
+	*chunk_out = chunk;
+	return allow_long && long_env > 0 ? std::max(long_env, 2 * chunk) : 0;
+}
+// device bytes sketch_launch needs on top of the caller's buffers (chunk tables + chunk-local output slots): a caller that hands the rest of the arena to
+// something else (window_launch: the anchor pool) reserves them first and passes the block in
+static size_t sketch_long_bytes(int n, const wm_sketch_job_t *h_jobs, bool allow_long)
+{
+	int chunk = 0;
+	const int long_thr = sketch_long_thr(allow_long, &chunk);
+	size_t bytes = 0;
+	if (long_thr > 0)
+		for (int i = 0; i < n; ++i)
+			if (h_jobs[i].len >= long_thr) {
+				const size_t k = ((size_t)h_jobs[i].len + chunk - 1) / chunk;
+				bytes += k * (sizeof(wm_sk_chunk_t) + 8 + ((size_t)chunk / 4 + 64 + 1) * sizeof(wm128_t)) + 12 + 1024;
+			}
+	return bytes ? bytes + 4096 : 0;
+}
+static int sketch_launch(wm_ctx_t *c, int n, const wm_sketch_job_t *h_jobs, const wm_sketch_job_t *d_jobs, const int *d_ord, const uint8_t *d_seqs,
+                         double *d_so, uint64_t *d_sx, uint32_t *d_sy, uint32_t *d_sl, wm128_t *d_out, int *d_cnt, bool allow_long, uint8_t *mem = 0, size_t mem_bytes = 0)
+{
+	int chunk = 0;
+	const int long_thr = sketch_long_thr(allow_long, &chunk);
+	size_t mem_used = 0;
+	auto take = [&](size_t bytes) -> void* {                   // from the caller's block if there is one, else from the arena
+		if (!mem) return arena_take(c, bytes);
+		const size_t a = (mem_used + 255) & ~(size_t)255;
+		if (a + bytes > mem_bytes) return (void*)0;
+		mem_used = a + bytes;
+		return mem + a;
+	};
+	std::vector<int> lj;                                       // job, first chunk, chunks
+	size_t n_ch = 0;
+	if (long_thr > 0)
+		for (int i = 0; i < n; ++i)
+			if (h_jobs[i].len >= long_thr) { const int k = (h_jobs[i].len + chunk - 1) / chunk; lj.push_back(i); lj.push_back((int)n_ch); lj.push_back(k); n_ch += (size_t)k; }
+	hipLaunchKernelGGL(sketch_coop_kernel, dim3(n), dim3(64), 0, c->stream, c->skp, d_jobs, d_ord, d_seqs, c->d_bloom, d_so, d_sx, d_sy, d_sl, d_out, d_cnt, long_thr);
+	if (lj.empty()) return WM_OK;
+	UBuf<wm_sk_chunk_t> ch(n_ch, c);
+	UBuf<int> plj(lj.size(), c);
+	memcpy(plj.data(), lj.data(), lj.size() * sizeof(int));
+	uint64_t co = 0;
+	for (size_t q = 0; q < lj.size(); q += 3) {
+		const int i = lj[q], c0 = lj[q + 1], k = lj[q + 2];
+		for (int t = 0; t < k; ++t) {
+			wm_sk_chunk_t &x = ch[(size_t)c0 + t];
+			x.job = i; x.begin = t * chunk; x.end = std::min(h_jobs[i].len, (t + 1) * chunk); x.first = t == 0; x.pad = 0;
+			x.cap = (x.end - x.begin) / 4 + 64;                   // (a chunk's wavefront also covers the chunks it absorbs: twice the job slot's density; beyond that the job is repeated)
+			x.out_off = co; co += (uint64_t)x.cap;
+		}
+	}
+	wm_sk_chunk_t *d_ch = (wm_sk_chunk_t*)take(n_ch * sizeof(wm_sk_chunk_t));
+	int *d_lj = (int*)take(lj.size() * 4 + 64), *d_sync = (int*)take(n_ch * 4 + 64), *d_cc = (int*)take(n_ch * 4 + 64);
+	wm128_t *d_cout = (wm128_t*)take((co + 1) * sizeof(wm128_t));
+	if (!d_ch || !d_lj || !d_sync || !d_cc || !d_cout) return set_err(WM_ENOMEM, "sketch batch does not fit the arena");
+	HIPCHK(hipMemcpyAsync(d_ch, ch.data(), n_ch * sizeof(wm_sk_chunk_t), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(d_lj, plj.data(), lj.size() * 4, hipMemcpyHostToDevice, c->stream));
+	hipLaunchKernelGGL(sketch_long_p1_kernel, dim3((unsigned)n_ch), dim3(64), 0, c->stream, c->skp, d_jobs, d_ch, d_seqs, c->d_bloom, d_so, d_sx, d_sy, d_sl);
+	hipLaunchKernelGGL(sketch_long_sync_kernel, dim3((unsigned)n_ch), dim3(64), 0, c->stream, c->skp, d_jobs, d_ch, d_so, d_sync);
+	hipLaunchKernelGGL(sketch_long_p2_kernel, dim3((unsigned)n_ch), dim3(64), 0, c->stream, c->skp, d_jobs, d_ch, (int)n_ch, d_so, d_sx, d_sy, d_sl, d_sync, d_cout, d_cc);
+	hipLaunchKernelGGL(sketch_long_gather_kernel, dim3((unsigned)(lj.size() / 3)), dim3(64), 0, c->stream, d_jobs, d_lj, d_ch, d_cout, d_cc, d_out, d_cnt);
+	HIPCHK(ctx_sync(c));                 // (the staged tables above are read by the copies until here)
+	return WM_OK;
+}
+
 static int sketch_batch_impl(wm_ctx_t *c, int n, const uint8_t *seqs, size_t seqs_bytes, const uint64_t *seq_off, const int32_t *len, const uint8_t *resident,
                              wm128_t *out, size_t out_cap, uint64_t *out_off, int32_t *counts)
 try {
@@ -1896,7 +2023,7 @@ try {
 			std::sort(ord.begin(), ord.end(), [&](int a, int b) { return jb[a].len != jb[b].len ? jb[a].len > jb[b].len : a < b; });     // longest first
 			HIPCHK(hipMemcpyAsync(d_ord, ord.data(), ord.size() * 4, hipMemcpyHostToDevice, c->stream));
 			HIPCHK(hipEventRecord(c->ev[0], c->stream));
-			hipLaunchKernelGGL(sketch_coop_kernel, dim3((int)jb.size()), dim3(64), 0, c->stream, c->skp, d_jobs, d_ord, d_seqs, c->d_bloom, d_so, d_sx, d_sy, d_sl, d_out, d_cnt);
+			if (const int rc = sketch_launch(c, (int)jb.size(), jb.data(), d_jobs, d_ord, d_seqs, d_so, d_sx, d_sy, d_sl, d_out, d_cnt, round == 0)) return rc;
 		} else {
 			HIPCHK(hipEventRecord(c->ev[0], c->stream));
 			hipLaunchKernelGGL(sketch_kernel, dim3(((int)jb.size() + 63) / 64), dim3(64), lds, c->stream, c->skp, d_jobs, (int)jb.size(), d_seqs, c->d_bloom, d_out, d_cnt);
@@ -2390,6 +2517,9 @@ static int window_launch(wm_ctx_t *c, int n, const wm_window_job_t *jobs, const 
 		return set_err(WM_ENOMEM, "window batch does not fit the arena");
 	int *d_counts = (int*)(d_ctr + 4);
 	D.d_ctr = d_ctr;
+	const size_t long_bytes = sketch_long_bytes(n, sj.data(), !slot_full);       // chunked sketch of long sequences: its tables come before the pool takes the rest
+	uint8_t *d_long = long_bytes ? (uint8_t*)arena_take(c, long_bytes) : 0;
+	if (long_bytes && !d_long) return set_err(WM_ENOMEM, "window batch does not fit the arena");
 	// the rest of the arena is the anchor pool: 72 B per anchor (anchors 16, f|p|v|t 16, z/u 8, b 16, w 16) + the two dense result pools (24)
 	const size_t left = c->arena_bytes - ((c->arena_used + 255) & ~(size_t)255);
 	const uint64_t cap = left > 4096 ? (left - 4096) / 96 : 0;
@@ -2413,7 +2543,7 @@ static int window_launch(wm_ctx_t *c, int n, const wm_window_job_t *jobs, const 
 	HIPCHK(hipMemsetAsync(d_ctr, 0, 64, c->stream));
 	if (d_tie) HIPCHK(hipMemsetAsync(d_tie, 0, 32, c->stream));
 	HIPCHK(hipEventRecord(c->ev[0], c->stream));
-	hipLaunchKernelGGL(sketch_coop_kernel, dim3(n), dim3(64), 0, c->stream, c->skp, d_sj, d_ord, d_seqs, c->d_bloom, d_so, d_sx, d_sy, d_sl, d_mini, d_mcnt);
+	if (const int rc = sketch_launch(c, n, sj.data(), d_sj, d_ord, d_seqs, d_so, d_sx, d_sy, d_sl, d_mini, d_mcnt, !slot_full, d_long, long_bytes)) return rc;
 	wm_index_view_t ix = { c->d_hkey, c->d_hval, c->d_P, c->hbits, 0 };
 	hipLaunchKernelGGL(win_seed_kernel, dim3(n), dim3(64), 0, c->stream, ix, d_jobs, d_sj, d_mcnt, d_mini, d_pre, d_occ, d_first, d_emit, d_a, d_ctr, cap, D.d_res, (int*)(d_ctr + 3));
 	const size_t ws_bytes = (size_t)wmk::WIN_WS_PAD * 4;
