@@ -267,6 +267,10 @@ def make_report(args, world, n_threads, elapsed, total_bases, hits, ks0, ks1, un
                      "gcups_step": all_cells / max(elapsed, 1e-9) / 1e9 / max(1, world),
                      "issue_frac_step": all_cells / max(elapsed, 1e-9) / 1e9 / max(1, world) / VALU_CEILING["gcups"],
                      "issue_frac_dominant": d_cells / max(d_ms, 1e-9) / 1e6 / VALU_CEILING["gcups"],
+                     # the dominant kernel's MEASURED instruction mix next to the 53 packed VALU per 128 cells the ceiling assumes: the distance of
+                     # issue_frac_dominant from 1 is partly instruction count (this ratio) and partly latency (a lone wavefront per SIMD issues one per ~10 cycles)
+                     "dominant_valu_salu_per_128_cells": ([round(128 * classes[kname]["valu_per_cell"], 1), round(128 * classes[kname]["salu_per_cell"], 1)]
+                                                          if classes.get(kname, {}).get("valu_per_cell") is not None and classes[kname].get("salu_per_cell") is not None else None),
                      "insts_per_cell_source": (ipc or {}).get("source"),
                      "note": "int8 DP is instruction-issue bound, not HBM bound (frac above is the HBM fraction of the 1 B/cell traceback stream); `ms` of a class is the SUM of its launch "
                              "durations (launches overlap on different streams: residency), `union_ms` the time with at least one launch running; gcups_step = cells of all classes / wall time of the timed region"},

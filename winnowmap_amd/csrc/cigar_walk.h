@@ -1,6 +1,6 @@
 // cigar_walk.h — the walks over a finished alignment's CIGAR that the reference runs on the host after every alignment, written ONCE for
 // the host and the device: one function body, compiled by hipcc into the kernels that run them over the CIGAR pool a ksw call already holds
-// in HBM (wm_gpu.hip: ksw_zdwalk_kernel, cigar_extra_kernel) and by g++ into the host mapper (host/wm_align.cpp: the same results for device
+// in HBM (wm_gpu.hip: ksw_zdwalk_kernel runs wm_zdrop_walk; wm_extra_walk has no kernel — mm_update_extra needs the region's final CIGAR, which exists on the host only) and by g++ into the host mapper (host/wm_align.cpp: the same results for device
 // operations that do not supply them, e.g. the oracle-backed ones of tests/host_harness). Sequences are 0..4 codes, one byte per base; CIGAR
 // ops are BAM-encoded (len << 4 | op), in output order.
 //   wm_zdrop_walk   = the scan of mm_test_zdrop + update_max_zdrop (src/align.c:32-66): the largest z-drop along the alignment and where it spans
