@@ -212,8 +212,11 @@ def test_index_handed_on_device_to_device_and_the_file_loop_over_two_mappers(ctx
             f.write(b">read%d\n" % i + s + b"\n")
     idx = gpu.Index(fa, kf, k=k, w=50)
     idx.upload(ctx)
-    ctx2 = gpu.Context(0, 2 << 30)
+    n_dev = int(gpu.lib().wm_device_count())
+    ctx2 = gpu.Context(1 if n_dev > 1 else 0, 2 << 30)          # the second GPU of the node when there is one (hipMemcpyPeer across devices), else a second context of this one
     idx.upload_peer(ctx2, ctx)
+    with pytest.raises(gpu.WmError):                            # source == destination used to free the arrays it then copied from
+        idx.upload_peer(ctx, ctx)
     m1 = gpu.Mapper(ctx, idx, preset, gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG); m1.set_threads(4, 1 << 30)
     m2 = gpu.Mapper(ctx2, idx, preset, gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG); m2.set_threads(4, 1 << 30)
     one, two = os.path.join(tmp, "one.paf"), os.path.join(tmp, "two.paf")
