@@ -277,7 +277,7 @@ int emu_sketch_chunked(int n, const uint8_t *seqs, const uint64_t *offs, const i
 			if (c > 0 && sync[c] < 0) continue;
 			int t_stop = -1;
 			for (int d = c + 1; d < n_ch && t_stop < 0; ++d) t_stop = sync[d];
-			std::vector<wm128_t> tmp((size_t)chunk * 4 + 64);
+			std::vector<wm128_t> tmp((size_t)L + 2);                  // (a wavefront covers every chunk it absorbs)
 			const int cnt = wmk::sketch_p2_range(P, L, so.data(), sx.data(), sy.data(), sl.data(), c == 0 ? 0 : sync[c], c != 0, t_stop, tmp.data(), (int)tmp.size());
 			if (cnt > (int)tmp.size()) return -1;
 			for (int j = 0; j < cnt; ++j) { if (total < caps[i]) out[out_offs[i] + total] = tmp[j]; ++total; }
