@@ -341,10 +341,27 @@ int wm_mapper_create_opt(wm_ctx_t *ctx, const wm_index_t *idx, const wm_mapopt_t
  * mapped against one part after the other with the hits merged at the end (`--split-prefix`: mm_split_merge / merge_hits, src/map.c:1050-1105,
  * 1278-1321): contig ids shifted by the parts before, mm_hit_sort, mm_set_parent, mm_select_sub, mm_set_sam_pri, mm_set_mapq with the largest
  * rep_len. The output file equals `winnowmap -I … --split-prefix …`'s (the reference keeps the per-part hits in <prefix>.NNNN.tmp files; here they
- * stay in host memory). Every part is an index of its own: destroy each with wm_index_destroy. */
+ * go to anonymous temporary files under $TMPDIR). Every part is an index of its own: destroy each with wm_index_destroy. */
 int wm_index_build_parts(const char *fasta, const char *kmer_file, int k, int w, int n_threads, uint64_t batch_bases, wm_index_t **out, int cap, int *n_parts);
 int wm_map_file_split(wm_ctx_t *ctx, int n_parts, wm_index_t *const *parts, const wm_mapopt_t *opt, int n_threads, const char *reads_path, const char *out_path,
                       int64_t mini_batch_bases, double *stats);
+/* The same flow ONE PART AT A TIME, the way the reference's main runs it (src/main.c:398-429: mm_idx_reader_read builds a part, mm_map_file maps every
+ * read against it, mm_idx_destroy, next part; mm_split_merge at the end) — host memory and the device hold one index part at a time:
+ *   wm_split_begin      starts a run over `reads_path` (k, w: what every part must have been built with)
+ *   wm_split_add_part   uploads the part to the run's context, maps the whole reads file against it and spills the hits to an anonymous temporary
+ *                       file under $TMPDIR (the reference's <prefix>.NNNN.tmp, src/map.c:1174-1190); the part may be destroyed when it returns
+ *   wm_split_finish     SAM header over the contigs of all parts (src/map.c:1304-1306), the merge pass, the output file; frees the run (also on error)
+ *   wm_split_abort      frees a run that is not finished
+ * wm_map_file_split above is these three over parts the caller already holds; wm_map_file_split_fasta reads the reference FASTA part by part
+ * (mm_idx_gen's rule, src/index.c:289-300,383) and builds each part when its turn comes — on the host, or with on_device != 0 on the GPU
+ * (wm_index_build_gpu's sketch + table kernels) — so a reference of any size needs the memory of ONE part. *n_parts receives the number of parts. */
+typedef struct wm_split_s wm_split_t;
+int wm_split_begin(wm_ctx_t *ctx, const wm_mapopt_t *opt, int k, int w, int n_threads, const char *reads_path, int64_t mini_batch_bases, wm_split_t **out);
+int wm_split_add_part(wm_split_t *s, wm_index_t *part);
+int wm_split_finish(wm_split_t *s, const char *out_path, double *stats);
+void wm_split_abort(wm_split_t *s);
+int wm_map_file_split_fasta(wm_ctx_t *ctx, const char *fasta, const char *kmer_file, int k, int w, int build_threads, uint64_t batch_bases, int on_device,
+                            const wm_mapopt_t *opt, int n_threads, const char *reads_path, const char *out_path, int64_t mini_batch_bases, double *stats, int *n_parts);
 
 /* wm_map_file prints the SAM header itself when MM_F_OUT_SAM is set; a front end that has already printed it (the reference's main does,
  * src/main.c:393) turns that off */

@@ -8,13 +8,15 @@
 //     src/index.c:515 → wm_index_load), the -W list through opt->kmer_freq_filename (the reference does not persist its bloom filter);
 //   * every field of mm_mapopt_t goes into wm_mapopt_t (same names), so presets AND individual command-line options carry over;
 //   * records are written by wm_map_file to stdout exactly where the reference writes them (the SAM header was printed by main already);
-//   * --split-prefix (a reference indexed in parts): mm_split_merge is wrapped as well and runs wm_map_file_split over the parts main presented.
+//   * --split-prefix (a reference indexed in parts): every (part, reads file) call maps and spills at once (wm_split_add_part); the wrapped mm_split_merge
+//     runs the merge passes (wm_split_finish). One index part in memory at a time, as in the reference's own main.
 // WM_BACKEND=cpu in the environment runs the reference's own mm_map_file instead (A/B inside one binary).
 // tests/test_binding_gpu.py diffs `winnowmap_wm ...` against `winnowmap_ref ...`.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <string>
 #include <unistd.h>
 #include "minimap.h"
 #include "../include/wm_gpu.h"
@@ -65,10 +67,15 @@ int take_index(const mm_idx_t *mi, const mm_mapopt_t *opt, wm_index_t **out)
 	return rc ? -1 : 0;
 }
 
-// --split-prefix (a reference indexed in parts, src/main.c:365-429): main calls mm_map_file once per index part and mm_split_merge at the end. Bound:
-// every part's index is taken over when main presents it (nothing is mapped yet, no <prefix>.NNNN.tmp is written), and the wrapped mm_split_merge
-// runs the library's twin of the whole flow, wm_map_file_split, over the parts.
-struct SplitState { std::vector<wm_index_t*> parts; std::vector<int> seen; int n_threads = 1; } g_split;       // seen: mm_idx_t::index, the part's ordinal
+// --split-prefix (a reference indexed in parts, src/main.c:365-429): main calls mm_map_file once per (index part, reads file) and mm_split_merge at the
+// end. Bound one part at a time, like main itself holds them: the part main presents is taken over, the reads file is mapped against it at once and the
+// hits are spilled by the library (wm_split_add_part — its twin of <prefix>.NNNN.tmp); the part is dropped when main presents the next one. The wrapped
+// mm_split_merge runs the merge passes (wm_split_finish), one per reads file.
+struct SplitState {
+	wm_ctx_t *ctx = 0; wm_index_t *part = 0; int part_no = -1;
+	std::vector<std::string> files; std::vector<wm_split_t*> runs;
+	void drop() { for (wm_split_t *r : runs) if (r) wm_split_abort(r); runs.clear(); files.clear(); if (part) wm_index_destroy(part); part = 0; part_no = -1; if (ctx) wm_ctx_destroy(ctx); ctx = 0; }
+} g_split;
 
 int open_backend(const mm_idx_t *mi, const mm_mapopt_t *opt, int n_threads)
 {
@@ -106,13 +113,23 @@ extern "C" int __wrap_mm_map_file(const mm_idx_t *idx, const char *fn, const mm_
 		fprintf(stderr, "[wm_gpu] short-read / fragment modes are outside the library's path (single-segment long reads): using the CPU path\n");
 		return __real_mm_map_file(idx, fn, opt, n_threads);
 	}
-	if (opt->split_prefix) {                                             // one call per (index part, reads file): keep the part, map in mm_split_merge
-		if (g_split.seen.empty() || g_split.seen.back() != idx->index) {
-			wm_index_t *part = 0;
-			if (take_index(idx, opt, &part)) { fprintf(stderr, "[wm_gpu] %s\n", wm_last_error()); return -1; }
-			g_split.parts.push_back(part); g_split.seen.push_back(idx->index);
+	if (opt->split_prefix) {                                             // one call per (index part, reads file)
+		if (!g_split.ctx && wm_ctx_create(0, 0, &g_split.ctx)) { fprintf(stderr, "[wm_gpu] %s\n", wm_last_error()); return -1; }
+		if (g_split.part_no != idx->index) {                             // main has moved on to the next part: the one before is done with
+			if (g_split.part) wm_index_destroy(g_split.part);
+			g_split.part = 0; g_split.part_no = idx->index;
+			if (take_index(idx, opt, &g_split.part)) { fprintf(stderr, "[wm_gpu] %s\n", wm_last_error()); return -1; }
 		}
-		g_split.n_threads = n_threads;
+		size_t f = 0;
+		while (f < g_split.files.size() && g_split.files[f] != fn) ++f;
+		if (f == g_split.files.size()) {
+			wm_mapopt_t wo;
+			copy_opt(opt, &wo);
+			wm_split_t *run = 0;
+			if (wm_split_begin(g_split.ctx, &wo, idx->k, idx->w, n_threads > 1 ? n_threads : 1, fn, opt->mini_batch_size, &run)) { fprintf(stderr, "[wm_gpu] %s\n", wm_last_error()); return -1; }
+			g_split.files.push_back(fn); g_split.runs.push_back(run);
+		}
+		if (wm_split_add_part(g_split.runs[f], g_split.part)) { fprintf(stderr, "[wm_gpu] %s\n", wm_last_error()); return -1; }
 		return 0;
 	}
 	if (g_be.for_idx != idx && open_backend(idx, opt, n_threads)) {
@@ -130,23 +147,21 @@ extern "C" int __wrap_mm_map_file(const mm_idx_t *idx, const char *fn, const mm_
 extern "C" int __wrap_mm_split_merge(int n_segs, const char **fn, const mm_mapopt_t *opt, int n_split_idx)
 {
 	const char *be = getenv("WM_BACKEND");
-	if ((be && strcmp(be, "cpu") == 0) || g_split.parts.empty()) return __real_mm_split_merge(n_segs, fn, opt, n_split_idx);
-	wm_ctx_t *ctx = 0;
-	if (wm_ctx_create(0, 0, &ctx)) { fprintf(stderr, "[wm_gpu] %s\n", wm_last_error()); return -1; }
-	wm_mapopt_t wo;
-	copy_opt(opt, &wo);
+	if ((be && strcmp(be, "cpu") == 0) || g_split.runs.empty()) return __real_mm_split_merge(n_segs, fn, opt, n_split_idx);
 	wm_set_cmdline(-1, 0);                                               // main has printed the @PG line (mm_write_sam_hdr(0, ...), src/main.c:395)
 	fflush(stdout);
 	int rc = 0;
 	for (int i = 0; i < n_segs && !rc; ++i) {                            // (single-segment reads: one merged pass per reads file)
+		size_t f = 0;
+		while (f < g_split.files.size() && g_split.files[f] != fn[i]) ++f;
+		if (f == g_split.files.size() || !g_split.runs[f]) { fprintf(stderr, "[wm_gpu] %s was not mapped against the index parts\n", fn[i]); rc = -1; break; }
 		double st[6];
-		rc = wm_map_file_split(ctx, (int)g_split.parts.size(), g_split.parts.data(), &wo, g_split.n_threads > 1 ? g_split.n_threads : 1, fn[i], "-", opt->mini_batch_size, st);
+		rc = wm_split_finish(g_split.runs[f], "-", st);                  // (frees the run, also on error)
+		g_split.runs[f] = 0;
 		if (rc) fprintf(stderr, "[wm_gpu] %s\n", wm_last_error());
 	}
-	for (wm_index_t *p : g_split.parts) wm_index_destroy(p);
-	g_split.parts.clear(); g_split.seen.clear();
-	wm_ctx_destroy(ctx);
+	g_split.drop();
 	return rc ? -1 : 0;
 }
 
-__attribute__((destructor)) static void wm_binding_fini() { g_be.close(); }
+__attribute__((destructor)) static void wm_binding_fini() { g_split.drop(); g_be.close(); }

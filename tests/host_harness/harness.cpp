@@ -421,27 +421,41 @@ int h_map_file_split(const char *fasta, const char *kmer_file, int k, int w, int
 	if (preset && preset[0] && set_preset(preset, io, mo) < 0) return -1;
 	io.k = k; io.w = w;
 	mo.flag |= flag_extra; mo.flag &= ~g_flag_clear;
-	std::vector<Index> parts;
 	std::string err;
-	const int n_parts = index_build_parts_from_fasta(io, fasta, kmer_file ? kmer_file : "", n_threads, (uint64_t)batch_bases, parts, err);
-	if (n_parts < 0) { fprintf(stderr, "h_map_file_split: %s\n", err.c_str()); return -2; }
 	std::vector<uint64_t> kms;
 	if (kmer_file && kmer_file[0]) { std::ifstream in(kmer_file); std::string km; uint64_t f; while (in >> km >> f) kms.push_back(wmo_encode_kmer(km.c_str(), (int)km.size())); }
 	wmo_bloom_t *bloom = wmo_bloom_new(kms.size());
 	for (uint64_t x : kms) wmo_bloom_insert(bloom, x);
-	Index dict; dict.k = k; dict.w = w;
-	std::vector<SplitPart> sp;
-	for (const Index &p : parts) { for (const RefSeq &r : p.seq) dict.seq.push_back(r); sp.push_back(SplitPart{ (int)p.seq.size() }); }
+	// one part at a time (src/main.c:398-429): the next part is read and built when its turn comes, mapped, spilled and destroyed
+	IndexPartReader rd;
+	if (rd.open(fasta, err) < 0) { fprintf(stderr, "h_map_file_split: %s\n", err.c_str()); return -2; }
+	SplitRun run(reads_path, mini_batch_bases, mo, k, w);
+	std::vector<std::string> names, seqs;
+	std::vector<size_t> part_seqs;
+	int n_parts = 0;
+	while (rd.next((uint64_t)batch_bases, names, seqs) > 0) {
+		Index part;
+		if (index_build(io, names, seqs, kmer_file ? kmer_file : "", n_threads, part, err) < 0) { fprintf(stderr, "h_map_file_split: %s\n", err.c_str()); return -2; }
+		std::vector<std::string>().swap(seqs);
+		MapOpt cur = mo;
+		mapopt_update(cur, part);
+		OracleOps ops; ops.idx = &part; ops.bloom = bloom; ops.opt = &cur;
+		const int rc = run.add_part(part.seq, [&](std::vector<ReadIn> &batch, std::vector<ReadOut> &o, int lane) -> int { map_batch(part, cur, &ops, batch, o, 0, n_threads, 0, lane); return 0; }, err);
+		if (rc) { fprintf(stderr, "h_map_file_split: %s\n", err.c_str()); return -4; }
+		part_seqs.push_back(part.seq.size());
+		++n_parts;
+	}
+	{   // the parts formed one at a time are the parts the all-at-once builder forms
+		std::vector<Index> all;
+		const int n2 = index_build_parts_from_fasta(io, fasta, kmer_file ? kmer_file : "", n_threads, (uint64_t)batch_bases, all, err);
+		if (n2 != n_parts) { fprintf(stderr, "h_map_file_split: %d parts one at a time, %d at once\n", n_parts, n2); return -5; }
+		for (int j = 0; j < n2; ++j) if (all[j].seq.size() != part_seqs[j]) { fprintf(stderr, "h_map_file_split: part %d differs\n", j); return -5; }
+	}
 	FILE *out = fopen(out_path, "wb");
 	if (!out) return -3;
-	if (mo.flag & 0x8) { std::string hdr; write_sam_header(hdr, dict, 0, 0); fwrite(hdr.data(), 1, hdr.size(), out); }
-	std::unique_ptr<OracleOps> ops;
-	MapOpt cur = mo;
+	if (mo.flag & 0x8) { std::string hdr; write_sam_header(hdr, run.dict(), 0, 0); fwrite(hdr.data(), 1, hdr.size(), out); }
 	FileStats fs;
-	const int rc = map_file_split(reads_path, mini_batch_bases, mo, k, dict, sp,
-		[&](int j) -> int { cur = mo; mapopt_update(cur, parts[j]); ops.reset(new OracleOps()); ops->idx = &parts[j]; ops->bloom = bloom; ops->opt = &cur; return 0; },
-		[&](int j, std::vector<ReadIn> &batch, std::vector<ReadOut> &o, int lane) -> int { map_batch(parts[j], cur, ops.get(), batch, o, 0, n_threads, 0, lane); return 0; },
-		out, &fs, err);
+	const int rc = run.finish(out, &fs, err);
 	fclose(out);
 	if (rc) { fprintf(stderr, "h_map_file_split: %s\n", err.c_str()); return -4; }
 	return n_parts;

@@ -226,6 +226,12 @@ inline int lds_ld_msg(const int *p, int (&o)[8])
 	for (int i = 0; i < 8; ++i) o[i] = __atomic_load_n(p + 4 + i, __ATOMIC_SEQ_CST);
 	return s;
 }
+// split-phase forms (csrc/simt.h): the emulator takes the snapshot where the load is issued
+inline int lds_ld_issue(const int *p, long long i) { return __atomic_load_n(p + i, __ATOMIC_SEQ_CST); }
+inline int lds_uniform(int raw) { return raw; }
+struct lds_msg_raw { int s; int o[8]; };
+inline void lds_ld_msg_issue(const int *p, lds_msg_raw &m) { m.s = lds_ld_msg(p, m.o); }
+inline int lds_msg_take(const lds_msg_raw &m, int (&o)[8]) { for (int i = 0; i < 8; ++i) o[i] = m.o[i]; return m.s; }
 inline void spin_pause() { sched_yield(); }
 inline int lds_ld(const int *p, long long i) { return p[i]; }
 template <class I> void lds_st(int *p, const V<I> &idx, const V<int> &v) { gst(p, idx, v); }

@@ -306,8 +306,26 @@ def test_reference_indexed_in_parts_matches_split_prefix_of_the_reference_cli():
     assert st["reads"] == len(reads)
     d = parity.diff_texts(want, open(outp, "rb").read(), sam=False)
     assert d["reads"] >= 100 and d["hits"] >= 110 and d["mismatches"] == 0 and d["mapq_compared"] >= 26, d
+    ours = open(outp, "rb").read()
+    # one part in memory at a time (src/main.c:398-429): the parts built when their turn comes — on the host, then on the device — and a run fed part by part
+    for on_dev in (False, True):
+        out2 = os.path.join(tmp, "lazy%d.paf" % on_dev)
+        st2 = gpu.map_file_split_fasta(ctx, fa, kf, 15, 50, 350000, opt, 8, rq, out2, on_device=on_dev)
+        assert st2["parts"] == 3 and st2["reads"] == len(reads)
+        assert open(out2, "rb").read() == ours, "on_device=%s" % on_dev
+    run = gpu.SplitRun(ctx, opt, 15, 50, 8, rq)
     for p in parts:
-        p.close()
+        run.add_part(p)
+        p.close()                       # (a part is done with when add_part returns)
+    out3 = os.path.join(tmp, "fed.paf")
+    run.finish(out3)
+    assert open(out3, "rb").read() == ours
+    with pytest.raises(gpu.WmError):    # a part built with another k is refused
+        r2 = gpu.SplitRun(ctx, opt, 15, 50, 8, rq)
+        try:
+            r2.add_part(gpu.Index(fa, kf, 17, 50))
+        finally:
+            r2.abort()
     ctx.close()
     # the same through the reference's own CLI bound to the library: main presents the parts, the wrapped mm_split_merge runs wm_map_file_split
     # (oracle/wm_binding.cpp); PAF and SAM (header: @PG from main, then the @SQ lines of every part)

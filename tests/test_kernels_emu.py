@@ -360,7 +360,7 @@ def test_wave_cooperative_backtrack_equals_the_single_thread_walk(emu):
 
 # ---- the stripe-pipelined ksw kernel (ksw_stripe_kernel.h): a library of its own, with event counters and a watchdog on the polling loops ----
 STRIPE_EVENTS = {"stripe_switch": 0, "inject": 1, "ez_handover_at_activation": 2, "restart": 3, "edge_trk_handover": 4, "trk_handover": 5, "zdrop": 6,
-                 "pri_eval": 7, "pri_skipped": 8}
+                 "pri_eval": 7, "pri_skipped": 8, "early_message_hit": 9}
 
 
 def _load_stripe(defines=()):
@@ -450,6 +450,16 @@ def test_stripe_kernel_repeat_in_safe_mode():
     n_run = _stripe_run(E, exact, forces)
     ev = _stripe_events(E)
     assert sum(n_run.values()) > 300 and ev["restart"] > 20, (n_run, ev)
+
+
+def test_stripe_kernel_with_the_left_message_loaded_before_the_cells():
+    """WM_STRIPE_EARLY_MSG=1 (a build switch, off by default: ksw_stripe_kernel.h): the message of a row is read before the row's cells and used after
+    them; when it was not there yet the polling loop takes over. Same results; both outcomes of the early read must have occurred."""
+    E = _load_stripe(("WM_STRIPE_EARLY_MSG=1",))
+    forces = [300 + g * 10 + v for g in (0, 1, 7, 2, 9) for v in (0, 2, 3)]
+    n_run = _stripe_run(E, kswcases.stripe_edge_cases(31, 120, 700) + kswcases.stripe_cases(33, 30, 700), forces)
+    ev = _stripe_events(E)
+    assert sum(n_run.values()) > 800 and ev["early_message_hit"] > 1000 and ev["restart"] == 0, (n_run, ev)
 
 
 def test_stripe_kernel_watchdog_gives_up_instead_of_hanging():

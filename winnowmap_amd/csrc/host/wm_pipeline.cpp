@@ -211,42 +211,65 @@ struct HitSpill {
 };
 }
 
-int map_file_split(const std::string &reads_path, int64_t mini_batch_bases, const MapOpt &opt, int k, const Index &dict, const std::vector<SplitPart> &parts,
-                   const std::function<int(int part)> &begin_part,
-                   const std::function<int(int part, std::vector<ReadIn> &batch, std::vector<ReadOut> &out, int lane)> &map_part,
-                   FILE *out, FileStats *st, std::string &err)
+// ---- a reference indexed in parts, one part at a time ----
+struct SplitRun::Impl {
+	std::string reads_path; int64_t mini_batch_bases; MapOpt opt; int k; bool with_qual;
+	std::vector<std::unique_ptr<HitSpill>> spill;
+	std::vector<int> n_seq;
+	Index dict;
+	FileStats fs_all;
+};
+SplitRun::SplitRun(const std::string &reads_path, int64_t mini_batch_bases, const MapOpt &opt, int k, int w) : p_(new Impl())
 {
-	if (opt.flag & (F_OUT_CS | F_OUT_MD)) { err = "--cs or --MD doesn't work with a reference indexed in parts"; return -1; }      // src/options.c:139-141
-	const int n_parts = (int)parts.size();
-	const bool with_qual = (opt.flag & F_OUT_SAM) != 0;
+	p_->reads_path = reads_path; p_->mini_batch_bases = mini_batch_bases; p_->opt = opt; p_->k = k; p_->with_qual = (opt.flag & F_OUT_SAM) != 0;
+	p_->dict.k = k; p_->dict.w = w;
+}
+SplitRun::~SplitRun() { delete p_; }
+const Index &SplitRun::dict() const { return p_->dict; }
+int SplitRun::n_parts() const { return (int)p_->spill.size(); }
+
+int SplitRun::add_part(const std::vector<RefSeq> &contigs, const std::function<int(std::vector<ReadIn> &batch, std::vector<ReadOut> &out, int lane)> &map_part, std::string &err)
+{
+	if (p_->opt.flag & (F_OUT_CS | F_OUT_MD)) { err = "--cs or --MD doesn't work with a reference indexed in parts"; return -1; }      // src/options.c:139-141
 	// The hits of one index part — one ReadOut per read, CIGARs included — go to an anonymous temporary file per part, one blob per mini-batch, as the
 	// reference spills them to <prefix>.NNNN.tmp (src/map.c:1174-1190, read back in merge_hits, src/map.c:1050-1105): this flow exists for references too big for one index, and reads x parts hits
 	// do not belong in RAM. In memory: where each blob lies. $TMPDIR, else /tmp.
-	std::vector<HitSpill> spill(n_parts);
-	for (int j = 0; j < n_parts; ++j) if (!spill[j].open(err)) return -1;
-	FileStats fs_all;
-	for (int j = 0; j < n_parts; ++j) {
-		if (begin_part(j)) { err = "cannot set up index part " + std::to_string(j); return -1; }
-		FileStats fs;
-		const int rc = map_file_id(reads_path, mini_batch_bases, with_qual, [&](std::vector<ReadIn> &batch, std::string &, int lane, uint64_t id) {
-			std::vector<ReadOut> o;
-			const int r = map_part(j, batch, o, lane);
-			if (r) return r;
-			return spill[j].put(id, o) ? 0 : -1;
-		}, 0, &fs, err);
-		if (rc) { if (err.empty() || err == "mapping failed") err = spill[j].error.empty() ? err : spill[j].error; return rc; }
-		fs_all.t_read += fs.t_read; fs_all.t_map += fs.t_map;
-	}
-	std::vector<int> rid_shift(n_parts, 0);
-	for (int j = 1; j < n_parts; ++j) rid_shift[j] = rid_shift[j - 1] + parts[j - 1].n_seq;
-	// the merge pass (merge_hits, src/map.c:1050-1105)
+	std::unique_ptr<HitSpill> sp(new HitSpill());
+	if (!sp->open(err)) return -1;
+	HitSpill &spill = *sp;
+	const int j = (int)p_->spill.size();
+	FileStats fs;
+	const int rc = map_file_id(p_->reads_path, p_->mini_batch_bases, p_->with_qual, [&](std::vector<ReadIn> &batch, std::string &, int lane, uint64_t id) {
+		std::vector<ReadOut> o;
+		const int r = map_part(batch, o, lane);
+		if (r) return r;
+		return spill.put(id, o) ? 0 : -1;
+	}, 0, &fs, err);
+	if (rc) { if (err.empty() || err == "mapping failed") err = spill.error.empty() ? err : spill.error; return rc; }
+	(void)j;
+	p_->fs_all.t_read += fs.t_read; p_->fs_all.t_map += fs.t_map;
+	for (const RefSeq &r : contigs) p_->dict.seq.push_back(r);
+	p_->n_seq.push_back((int)contigs.size());
+	p_->spill.push_back(std::move(sp));
+	return 0;
+}
+
+// the merge pass (merge_hits, src/map.c:1050-1105)
+int SplitRun::finish(FILE *out, FileStats *st, std::string &err)
+{
+	const int n_parts = (int)p_->spill.size();
+	const MapOpt &opt = p_->opt;
+	const int k = p_->k;
+	std::vector<std::unique_ptr<HitSpill>> &spill = p_->spill;
+	std::vector<int> rid_shift(n_parts > 0 ? n_parts : 1, 0);
+	for (int j = 1; j < n_parts; ++j) rid_shift[j] = rid_shift[j - 1] + p_->n_seq[j - 1];
 	FileStats fs;
 	std::string merge_err;
-	const int rc = map_file_id(reads_path, mini_batch_bases, with_qual, [&](std::vector<ReadIn> &batch, std::string &text, int, uint64_t id) {
+	const int rc = map_file_id(p_->reads_path, p_->mini_batch_bases, p_->with_qual, [&](std::vector<ReadIn> &batch, std::string &text, int, uint64_t id) {
 		std::vector<std::vector<ReadOut>> ph(n_parts);                    // this mini-batch's hits, part by part
 		for (int j = 0; j < n_parts; ++j)
-			if (!spill[j].get(id, ph[j]) || ph[j].size() != batch.size()) {
-				if (merge_err.empty()) merge_err = !spill[j].error.empty() ? spill[j].error : "the hits of index part " + std::to_string(j) + " for mini-batch " + std::to_string(id) + " could not be read back from their temporary file";
+			if (!spill[j]->get(id, ph[j]) || ph[j].size() != batch.size()) {
+				if (merge_err.empty()) merge_err = !spill[j]->error.empty() ? spill[j]->error : "the hits of index part " + std::to_string(j) + " for mini-batch " + std::to_string(id) + " could not be read back from their temporary file";
 				return -1;
 			}
 		for (size_t i = 0; i < batch.size(); ++i) {
@@ -266,13 +289,55 @@ int map_file_split(const std::string &reads_path, int64_t mini_batch_bases, cons
 			}
 			set_mapq(m.regs, opt.min_chain_score, opt.a, m.rep_len, (opt.flag & F_SR) != 0);
 			m.rep_len = 0;               // merge_hits keeps the merged rep_len in a local (src/map.c:1067) and never stores s->rep_len[k]: the records carry rl:i:0
-			write_read(text, dict, batch[i], m, opt.flag);
+			write_read(text, p_->dict, batch[i], m, opt.flag);
 		}
 		return 0;
 	}, out, &fs, err);
 	if (rc && !merge_err.empty() && (err.empty() || err == "mapping failed")) err = merge_err;
-	if (st) { *st = fs; st->t_map += fs_all.t_map; st->t_read += fs_all.t_read; }
+	if (st) { *st = fs; st->t_map += p_->fs_all.t_map; st->t_read += p_->fs_all.t_read; }
 	return rc;
+}
+
+int map_file_split(const std::string &reads_path, int64_t mini_batch_bases, const MapOpt &opt, int k, const Index &dict, const std::vector<SplitPart> &parts,
+                   const std::function<int(int part)> &begin_part,
+                   const std::function<int(int part, std::vector<ReadIn> &batch, std::vector<ReadOut> &out, int lane)> &map_part,
+                   FILE *out, FileStats *st, std::string &err)
+{
+	if (opt.flag & (F_OUT_CS | F_OUT_MD)) { err = "--cs or --MD doesn't work with a reference indexed in parts"; return -1; }      // src/options.c:139-141
+	SplitRun run(reads_path, mini_batch_bases, opt, k, dict.w);
+	size_t at = 0;
+	for (int j = 0; j < (int)parts.size(); ++j) {
+		if (begin_part(j)) { err = "cannot set up index part " + std::to_string(j); return -1; }
+		std::vector<RefSeq> contigs(dict.seq.begin() + at, dict.seq.begin() + at + parts[j].n_seq);
+		at += parts[j].n_seq;
+		const int rc = run.add_part(contigs, [&](std::vector<ReadIn> &batch, std::vector<ReadOut> &o, int lane) { return map_part(j, batch, o, lane); }, err);
+		if (rc) return rc;
+	}
+	return run.finish(out, st, err);
+}
+
+// ---- the parts of a reference FASTA, built when their turn comes (mm_idx_reader_read, src/index.c:655-676 with mm_idx_gen's reading rule, :289-300) ----
+struct IndexPartReader::Impl { FastxReader rd; bool open = false, eof = false; };
+IndexPartReader::IndexPartReader() : p_(new Impl()) {}
+IndexPartReader::~IndexPartReader() { delete p_; }
+int IndexPartReader::open(const std::string &fasta, std::string &err)
+{
+	if (p_->rd.open(fasta, err) < 0) return -1;
+	p_->open = true; p_->eof = false;
+	return 0;
+}
+int IndexPartReader::next(uint64_t batch_bases, std::vector<std::string> &names, std::vector<std::string> &seqs)
+{
+	names.clear(); seqs.clear();
+	if (!p_->open || p_->eof) return 0;
+	const uint64_t mini = batch_bases < 50000000ULL ? batch_bases : 50000000ULL;      // mm_idx_gen: min(mini_batch_size, batch_size), src/index.c:383
+	uint64_t sum = 0;
+	while (sum <= batch_bases) {                                        // step 0 of the reference's pipeline: another mini-batch unless sum_len > batch_size (:295)
+		std::vector<ReadIn> chunk;
+		if (p_->rd.next_batch((int64_t)mini, false, chunk) == 0) { p_->eof = true; break; }      // mm_bseq_read: sequences until the chunk reaches `mini` bases
+		for (ReadIn &r : chunk) { sum += r.seq.size(); names.push_back(std::move(r.name)); seqs.push_back(std::move(r.seq)); }
+	}
+	return (int)seqs.size();
 }
 
 } // namespace wm

@@ -42,6 +42,35 @@ int map_file_id(const std::string &reads_path, int64_t mini_batch_bases, bool wi
 // shifted by the parts before, mm_hit_sort, mm_set_parent, mm_select_sub, mm_set_sam_pri, mm_set_mapq with the largest rep_len. `dict` = the
 // contigs of all parts in order (names and lengths only). The reference spills the per-part hits to <prefix>.NNNN.tmp files (src/map.c:1174-1190); here each part has an
 // anonymous temporary file under $TMPDIR (one blob per mini-batch), so that memory holds one mini-batch's hits per lane, not reads x parts. --cs / --MD are refused like the reference does (src/options.c:139-141).
+// The flow ONE PART AT A TIME, as the reference's main runs it (src/main.c:398-429: read / build a part, map every read against it, destroy it, next):
+// add_part maps the whole reads file against the part the caller has made current (contigs = its names and lengths) and spills the hits; the part
+// may be destroyed afterwards. finish is the merge pass; dict() = the contigs of every part so far (what the SAM header lists).
+class SplitRun {
+public:
+	SplitRun(const std::string &reads_path, int64_t mini_batch_bases, const MapOpt &opt, int k, int w);
+	~SplitRun();
+	SplitRun(const SplitRun&) = delete; SplitRun &operator=(const SplitRun&) = delete;
+	int add_part(const std::vector<RefSeq> &contigs, const std::function<int(std::vector<ReadIn> &batch, std::vector<ReadOut> &out, int lane)> &map_part, std::string &err);
+	int finish(FILE *out, FileStats *st, std::string &err);
+	const Index &dict() const;
+	int n_parts() const;
+private:
+	struct Impl;
+	Impl *p_;
+};
+// the sequences of the next index part of a reference FASTA (mm_idx_gen's reading rule with batch_size = batch_bases, src/index.c:289-300,383): 0 = no more
+class IndexPartReader {
+public:
+	IndexPartReader();
+	~IndexPartReader();
+	IndexPartReader(const IndexPartReader&) = delete; IndexPartReader &operator=(const IndexPartReader&) = delete;
+	int open(const std::string &fasta, std::string &err);
+	int next(uint64_t batch_bases, std::vector<std::string> &names, std::vector<std::string> &seqs);
+private:
+	struct Impl;
+	Impl *p_;
+};
+// (every part given up front: the form of rounds 3-4, kept for callers that hold the parts anyway)
 struct SplitPart { int n_seq; };
 int map_file_split(const std::string &reads_path, int64_t mini_batch_bases, const MapOpt &opt, int k, const Index &dict, const std::vector<SplitPart> &parts,
                    const std::function<int(int part)> &begin_part,

@@ -36,6 +36,15 @@
 #ifndef WM_STRIPE_SPIN_BUDGET
 #define WM_STRIPE_SPIN_BUDGET (1 << 25)
 #endif
+// WM_STRIPE_EARLY_MSG=1 (build define, A/B): the left neighbour's message of a row is loaded BEFORE the row's cells and consumed after them, so that its LDS
+// round trip hides behind the cells (in the steady state the neighbour is a row or more ahead). Measured in round 5 (profiles/r05_stripe_split_phase.txt):
+// the isolated wide-hull probe gains 3-9 % per row (blk_3000x 2.00 -> 1.83 us), but the nine registers the message occupies across the cells take
+// <2,16> from 104 to 128 VGPRs — four such wavefronts then fill a SIMD's register file and no bulk wavefront shares the CU — and the mapper lost 2-3 %
+// (0.2996 / 0.3032 -> 0.2941 / 0.2898 Gbp/s at 32 768 reads per step). Off by default; the stop word, the stale ez.max and the back-pressure word
+// are split-phase / cached in every build (two registers).
+#ifndef WM_STRIPE_EARLY_MSG
+#define WM_STRIPE_EARLY_MSG 0
+#endif
 #ifndef WM_STRIPE_EVENT
 #define WM_STRIPE_EVENT(k) ((void)0)      // test hook (tests/simt_emu): counts how often the rare paths run
 #endif
@@ -96,6 +105,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 	typedef ksw_stripe_lds<BP, NWV> L;
 	constexpr int SW = L::SW, B = 2 * BP, NW = (B + 3) / 4, R = L::R;
 	constexpr int BIG = 0x7fffffff;
+	constexpr bool EARLY_MSG = WM_STRIPE_EARLY_MSG && BP <= 4;
 	const int qlen = jb.qlen, tlen = jb.tlen, flag = jb.flag, zdrop = jb.zdrop;
 	const int w = jb.w < 0 ? (tlen > qlen ? tlen : qlen) : jb.w;
 	const bool right = (flag & KSW_F_RIGHT) != 0;
@@ -157,6 +167,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 		int end_row = n_rows;                   // first row that does not exist (n_rows, or the first row with an empty band)
 		int r = 0, s = wv;
 		bool all_done = false;
+		int right_seen = -1;                    // lower bound of the right neighbour's progress word (it only grows during a pass): re-read when it no longer suffices
 
 		while (!all_done) {
 			// ================= find the first row that touches stripe s =================
@@ -286,8 +297,13 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 				WM_ST_LAP(WM_ST_EPOCH);
 				for (; r < r_end; ++r) {
 					WM_ST_COUNT(WM_ST_ROWS);
-					const int stop_row = lds_ld_acq(ctrl, L::C_STOP);             // (consumed at the end of the row: the load's latency hides behind the cells)
-					const int ezl = EXACT ? lds_ld_acq(ctrl, L::C_EZL) : 0;
+					// split-phase loads (simt.h): issued here, waited for where the values are used — the stop word at the end of the row, the stale ez.max
+					// in the bookkeeping, the left neighbour's message after the cells. In the steady state that neighbour is a row or more ahead, so the
+					// message is already there and its LDS round trip hides behind the cells; if it is not, the polling loop below takes over.
+					const int stop_raw = lds_ld_issue(ctrl, L::C_STOP);
+					const int ezl_raw = EXACT ? lds_ld_issue(ctrl, L::C_EZL) : 0;
+					lds_msg_raw early;
+					if (EARLY_MSG && left_now) lds_ld_msg_issue(ring_in + (r % R) * L::SLOT, early);
 					int st0 = 0, en0 = tlen - 1;
 					if (st0 < r - qlen + 1) st0 = r - qlen + 1;
 					if (en0 > r) en0 = r;
@@ -447,7 +463,13 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 					if (left_now) {
 						const int *m = ring_in + (r % R) * L::SLOT;
 						int o8[8];
-						while (lds_ld_msg(m, o8) != r) { if (lds_ld_acq(ctrl, L::C_STOP) <= r) { stopped = true; break; } WM_STRIPE_SPIN(1, r, a, wv, lds_ld_acq(m, L::M_STAMP)); if (++spins > WM_STRIPE_SPIN_BUDGET) give_up(); spin_pause(); }
+						int stamp = EARLY_MSG ? lds_msg_take(early, o8) : lds_ld_msg(m, o8);
+						if (stamp == r) WM_STRIPE_EVENT(9);
+						while (stamp != r) {
+							if (lds_ld_acq(ctrl, L::C_STOP) <= r) { stopped = true; break; }
+							WM_STRIPE_SPIN(1, r, a, wv, lds_ld_acq(m, L::M_STAMP)); if (++spins > WM_STRIPE_SPIN_BUDGET) give_up(); spin_pause();
+							stamp = lds_ld_msg(m, o8);
+						}
 						if (stopped) { all_done = true; break; }
 						m_x = o8[0]; m_v = o8[1]; m_x2 = o8[2];
 						if constexpr (EXACT) {
@@ -461,6 +483,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 					}
 					have_left = left_now;
 					WM_ST_LAP(WM_ST_WAIT_LEFT);
+					const int ezl = EXACT ? lds_uniform(ezl_raw) : 0;
 					if constexpr (EXACT) { if (r > 0 && have_cells) hm = wave_max_i32(hmax); }
 
 					int out_th0 = 0, out_tl0 = -1;
@@ -563,7 +586,11 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 					// ---- publish this row for the right neighbour ----
 					WM_ST_LAP(WM_ST_BOOK);
 					if (pub) {
-						while (lds_ld_acq(prog, right_wv) < r - R) { if (lds_ld_acq(ctrl, L::C_STOP) <= r) { stopped = true; break; } WM_STRIPE_SPIN(2, r, a, wv, lds_ld_acq(prog, right_wv)); if (++spins > WM_STRIPE_SPIN_BUDGET) give_up(); spin_pause(); }
+						while (right_seen < r - R) {                               // (slot r % R still holds row r - R until the right neighbour has consumed it)
+							right_seen = lds_ld_acq(prog, right_wv);
+							if (right_seen >= r - R) break;
+							if (lds_ld_acq(ctrl, L::C_STOP) <= r) { stopped = true; break; } WM_STRIPE_SPIN(2, r, a, wv, right_seen); if (++spins > WM_STRIPE_SPIN_BUDGET) give_up(); spin_pause();
+						}
 						if (stopped) { all_done = true; break; }
 						WM_ST_LAP(WM_ST_WAIT_RIGHT);
 						int *m = ring_out + (r % R) * L::SLOT;
@@ -583,7 +610,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 					lds_st_rel(prog, wv, r - 1);                 // the left ring's messages up to row r - 1 may be overwritten
 					row_done = r; was_last = is_last;
 					WM_ST_LAP(WM_ST_PUBLISH);
-					if (r >= stop_row) { all_done = true; break; }   // (a z-drop in row stop_row: nothing after it exists)
+					if (r >= lds_uniform(stop_raw)) { all_done = true; break; }   // (a z-drop in row stop_row: nothing after it exists)
 				}
 			}
 		}

@@ -236,6 +236,32 @@ WM_DEV int lds_ld_msg(const int *p, int (&o)[8])
 	o[4] = __builtin_amdgcn_readfirstlane(b.x); o[5] = __builtin_amdgcn_readfirstlane(b.y); o[6] = __builtin_amdgcn_readfirstlane(b.z); o[7] = __builtin_amdgcn_readfirstlane(b.w);
 	return __builtin_amdgcn_readfirstlane(s);
 }
+// Split-phase forms: the DS instructions are issued where lds_*_issue stands, the wait (s_waitcnt) lands where the value is first USED — lds_uniform /
+// lds_msg_take — so an LDS round trip hides behind whatever is computed in between. The value is the one LDS held when the load was issued.
+WM_DEV int lds_ld_issue(const int *p, long long i)
+{
+	asm volatile("" ::: "memory");
+	const int v = ((const volatile wm_lds_int*)p)[i];
+	asm volatile("" ::: "memory");
+	return v;                                   // (per-lane copy of a uniform word: lds_uniform makes it scalar)
+}
+WM_DEV int lds_uniform(int raw) { return __builtin_amdgcn_readfirstlane(raw); }
+struct lds_msg_raw { int s; int a __attribute__((ext_vector_type(4))); int b __attribute__((ext_vector_type(4))); };
+WM_DEV void lds_ld_msg_issue(const int *p, lds_msg_raw &m)
+{
+	typedef int wm_i4 __attribute__((ext_vector_type(4)));
+	typedef __attribute__((address_space(3))) wm_i4 wm_lds_i4;
+	asm volatile("" ::: "memory");
+	m.s = ((const volatile wm_lds_int*)p)[0];
+	m.a = *(const volatile wm_lds_i4*)((const wm_lds_int*)p + 4); m.b = *(const volatile wm_lds_i4*)((const wm_lds_int*)p + 8);
+	asm volatile("" ::: "memory");
+}
+WM_DEV int lds_msg_take(const lds_msg_raw &m, int (&o)[8])
+{
+	o[0] = __builtin_amdgcn_readfirstlane(m.a.x); o[1] = __builtin_amdgcn_readfirstlane(m.a.y); o[2] = __builtin_amdgcn_readfirstlane(m.a.z); o[3] = __builtin_amdgcn_readfirstlane(m.a.w);
+	o[4] = __builtin_amdgcn_readfirstlane(m.b.x); o[5] = __builtin_amdgcn_readfirstlane(m.b.y); o[6] = __builtin_amdgcn_readfirstlane(m.b.z); o[7] = __builtin_amdgcn_readfirstlane(m.b.w);
+	return __builtin_amdgcn_readfirstlane(m.s);
+}
 WM_DEV void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 
 } // namespace simt

@@ -67,6 +67,9 @@ static inline double now_ms() { return std::chrono::duration<double, std::milli>
 #ifndef WM_PRIO
 #define WM_PRIO 1
 #endif
+#ifndef WM_STRIPE_PRIO
+#define WM_STRIPE_PRIO 2      // the stripe-pipelined classes: a few hundred wavefronts per launch, each a chain of dependent rows (3: above the exact / clipped register classes, for A/B)
+#endif
 #if WM_PRIO
 #define WM_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #else
@@ -165,7 +168,7 @@ template <int BP, int NWV, bool CLIP, bool HASN>
 __global__ __launch_bounds__(64 * NWV) void ksw_stripe_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
                                                                const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res)
 {
-	WM_SETPRIO(2);
+	WM_SETPRIO(WM_STRIPE_PRIO);
 	__shared__ int lds[wmk::ksw_stripe_lds<BP, NWV>::INTS];
 	const int j = order[blockIdx.x];
 	const wm_ksw_djob_t jb = jobs[j];
@@ -1804,6 +1807,8 @@ static int index_table_on_device(wm_ctx_t *c, wm::Index &ix, const std::vector<w
 	return WM_OK;
 }
 
+static int wm_index_build_seqs_dev(wm_ctx_t *c, const wm::IdxOpt &io, std::vector<std::string> &names, std::vector<std::string> &seqs, const std::string &kmer_file, int n_threads,
+                                   wm_index_t **out, double *stats = 0, bool replace_ok = true, double t0 = -1);
 extern "C" int wm_index_build_gpu(wm_ctx_t *c, const char *fasta, const char *kmer_file, int k, int w, int n_threads, wm_index_t **out, double *stats)
 {
 	*out = 0;
@@ -1811,13 +1816,27 @@ extern "C" int wm_index_build_gpu(wm_ctx_t *c, const char *fasta, const char *km
 	wm::IdxOpt io; io.k = k; io.w = w;
 	wm::MapOpt mo; std::string err;
 	if (wm::check_opt(io, mo, err) < 0) return set_err(WM_EINVAL, "%s", err.c_str());
-	if (!(k & 1) || k < 2) return set_err(WM_EINVAL, "the device index build needs an odd k (got %d): use wm_index_build", k);
-	if (c->have_index) return set_err(WM_EINVAL, "the context already holds an index: build on a fresh context, then wm_index_upload");
-	HIPCHK(hipSetDevice(c->device));
 	const double t0 = now_ms();
 	std::vector<std::string> names, seqs;
 	if (wm::read_fastx(fasta, names, seqs, 0, 0, err) < 0) return set_err(WM_EINVAL, "%s", err.c_str());
 	if (seqs.empty()) return set_err(WM_EINVAL, "no sequences in %s", fasta);
+	return wm_index_build_seqs_dev(c, io, names, seqs, kmer_file ? kmer_file : "", n_threads, out, stats, false, t0);
+}
+// the same from sequences in memory. replace_ok: the context may hold an uploaded index that no mapper is using (wm_map_file_split_fasta between two
+// parts): its filter and sketch parameters are put back when the build is done.
+static int wm_index_build_seqs_dev(wm_ctx_t *c, const wm::IdxOpt &io, std::vector<std::string> &names, std::vector<std::string> &seqs, const std::string &kmer_file_s, int n_threads,
+                                   wm_index_t **out, double *stats, bool replace_ok, double t0)
+{
+	*out = 0;
+	const int k = io.k, w = io.w;
+	const char *kmer_file = kmer_file_s.c_str();
+	std::string err;
+	if (!(k & 1) || k < 2) return set_err(WM_EINVAL, "the device index build needs an odd k (got %d): use wm_index_build", k);
+	if (c->have_index && !replace_ok) return set_err(WM_EINVAL, "the context already holds an index: build on a fresh context, then wm_index_upload");
+	HIPCHK(hipSetDevice(c->device));
+	if (t0 < 0) t0 = now_ms();
+	struct Keep { wm_ctx_t *c; uint8_t *bloom; bool owns; wm_sketch_params_t skp; ~Keep() { c->d_bloom = bloom; c->owns_filter = owns; c->skp = skp; } } keep{ c, c->d_bloom, c->owns_filter, c->skp };
+	if (c->have_index) { c->d_bloom = 0; c->owns_filter = false; }      // (the resident index's filter: untouched, back in place on return)
 	wm_index_t *h = new wm_index_t();
 	wm::Index &ix = h->ix;
 	if (wm::index_begin(io, names, seqs, kmer_file ? kmer_file : "", n_threads, ix, err) < 0) { delete h; return set_err(WM_EINVAL, "%s", err.c_str()); }
@@ -1856,6 +1875,7 @@ extern "C" int wm_index_build_gpu(wm_ctx_t *c, const char *fasta, const char *km
 	}
 	c->d_bloom = 0;
 	hipFree(d_bloom);
+	if (!c->have_index) { keep.bloom = 0; keep.owns = false; keep.skp = c->skp; }      // (as before on a fresh context: no filter left behind)
 	if (rc) { delete h; return rc; }
 	const double t2 = now_ms();
 	const double n_mini = (double)all.size();
@@ -3438,25 +3458,51 @@ static int map_reads_raw(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, std::ve
 	return WM_OK;
 }
 
-extern "C" int wm_map_file_split(wm_ctx_t *c, int n_parts, wm_index_t *const *parts, const wm_mapopt_t *opt, int n_threads, const char *reads_path, const char *out_path,
-                                 int64_t mini_batch_bases, double *stats)
+// One part at a time (src/main.c:398-429: the reference's main holds one mm_idx_t, maps every read against it, destroys it, reads the next): wm_split_begin,
+// wm_split_add_part per part — upload, mapper, the whole reads file against it, hits spilled; the part may be destroyed on return —, wm_split_finish = header + merge.
+struct wm_split_s {
+	wm_ctx_t *c; wm_mapopt_t copt; wm::MapOpt mo; int n_threads; int k, w;
+	wm::SplitRun *run;
+};
+extern "C" int wm_split_begin(wm_ctx_t *c, const wm_mapopt_t *opt, int k, int w, int n_threads, const char *reads_path, int64_t mini_batch_bases, wm_split_t **out)
 {
 	g_err[0] = 0;
-	if (!c || n_parts < 1 || !parts || !opt || !reads_path || !out_path) return set_err(WM_EINVAL, "bad argument");
+	if (!c || !opt || !reads_path || !out) return set_err(WM_EINVAL, "bad argument");
+	*out = 0;
 	wm::MapOpt mo; wm::IdxOpt io;
 	wm::set_preset(0, io, mo);
 	mapopt_from_c(opt, mo);
-	wm::Index dict;                                                    // names and lengths of every contig, part after part (mm_split_merge_prep)
-	std::vector<wm::SplitPart> sp;
-	for (int j = 0; j < n_parts; ++j) {
-		if (!parts[j]) return set_err(WM_EINVAL, "null index part");
-		if (j == 0) { dict.k = parts[j]->ix.k; dict.w = parts[j]->ix.w; }
-		for (const wm::RefSeq &r : parts[j]->ix.seq) dict.seq.push_back(r);
-		sp.push_back(wm::SplitPart{ (int)parts[j]->ix.seq.size() });
-	}
+	if (mo.flag & (wm::F_OUT_CS | wm::F_OUT_MD)) return set_err(WM_EINVAL, "--cs or --MD doesn't work with a reference indexed in parts");      // src/options.c:139-141
+	wm_split_t *s = new wm_split_t();
+	s->c = c; s->copt = *opt; s->mo = mo; s->n_threads = n_threads > 1 ? n_threads : 1; s->k = k; s->w = w;
+	s->run = new wm::SplitRun(reads_path, mini_batch_bases, mo, k, w);
+	*out = s;
+	return WM_OK;
+}
+extern "C" void wm_split_abort(wm_split_t *s) { if (s) { delete s->run; delete s; } }
+extern "C" int wm_split_add_part(wm_split_t *s, wm_index_t *part)
+{
+	g_err[0] = 0;
+	if (!s || !part) return set_err(WM_EINVAL, "null argument");
+	if (part->ix.k != s->k || part->ix.w != s->w) return set_err(WM_EINVAL, "index part built with k = %d, w = %d; the run was started for k = %d, w = %d", part->ix.k, part->ix.w, s->k, s->w);
+	wm_mapper_t *m = 0;
+	if (wm_index_upload(s->c, part)) return WM_EINVAL;
+	if (wm_mapper_create_opt(s->c, part, &s->copt, &m)) return WM_EINVAL;
+	if (wm_mapper_set_threads(m, s->n_threads, 0)) { wm_mapper_destroy(m); return WM_EINVAL; }
+	LaneError le;
+	std::string err;
+	const int rc = s->run->add_part(part->ix.seq, [&](std::vector<wm::ReadIn> &batch, std::vector<wm::ReadOut> &o, int lane) -> int { const int r = map_reads_raw(m, batch, o, lane); if (r) le.keep(r); return r; }, err);
+	wm_mapper_destroy(m);
+	if (rc) return le.code ? set_err(le.code, "%s", le.msg.c_str()) : set_err(WM_EINVAL, "%s", err.c_str());
+	return WM_OK;
+}
+extern "C" int wm_split_finish(wm_split_t *s, const char *out_path, double *stats)
+{
+	g_err[0] = 0;
+	if (!s || !out_path) { wm_split_abort(s); return set_err(WM_EINVAL, "bad argument"); }
 	FILE *out = strcmp(out_path, "-") == 0 ? stdout : fopen(out_path, "wb");
-	if (!out) return set_err(WM_EINVAL, "cannot open '%s' for writing", out_path);
-	if (mo.flag & 0x8) {
+	if (!out) { wm_split_abort(s); return set_err(WM_EINVAL, "cannot open '%s' for writing", out_path); }
+	if (s->mo.flag & 0x8) {
 		// SAM: the reference's main prints @PG (with CL:) when it sees the first of several parts (mm_write_sam_hdr(0, ...), src/main.c:395); the merge
 		// pass then lists every part's contigs (src/map.c:1304-1306) — @PG first, @SQ after it
 		std::string hdr, sq;
@@ -3465,29 +3511,69 @@ extern "C" int wm_map_file_split(wm_ctx_t *c, int n_parts, wm_index_t *const *pa
 		bool with_pg;
 		{ std::lock_guard<std::mutex> lk(g_cmdline_mu); for (const std::string &a : g_cmdline) av.push_back(a.c_str()); with_pg = g_split_pg; }
 		if (with_pg) wm::write_sam_header(hdr, none, (int)av.size(), av.data());
-		wm::write_sam_header(sq, dict, 0, 0);
+		wm::write_sam_header(sq, s->run->dict(), 0, 0);
 		hdr += sq.substr(0, sq.rfind("@PG"));
-		if (fwrite(hdr.data(), 1, hdr.size(), out) != hdr.size()) { if (out != stdout) fclose(out); return set_err(WM_EINVAL, "write error on '%s'", out_path); }
+		if (fwrite(hdr.data(), 1, hdr.size(), out) != hdr.size()) { if (out != stdout) fclose(out); wm_split_abort(s); return set_err(WM_EINVAL, "write error on '%s'", out_path); }
 	}
-	wm_mapper_t *m = 0;
 	wm::FileStats fs;
 	std::string err;
-	LaneError le;
-	const int rc = wm::map_file_split(reads_path, mini_batch_bases, mo, dict.k, dict, sp,
-		[&](int j) -> int {
-			if (m) { wm_mapper_destroy(m); m = 0; }
-			if (wm_index_upload(c, parts[j])) return -1;
-			if (wm_mapper_create_opt(c, parts[j], opt, &m)) return -1;
-			if (wm_mapper_set_threads(m, n_threads > 1 ? n_threads : 1, 0)) return -1;
-			return 0;
-		},
-		[&](int, std::vector<wm::ReadIn> &batch, std::vector<wm::ReadOut> &o, int lane) -> int { const int r = map_reads_raw(m, batch, o, lane); if (r) le.keep(r); return r; },
-		out, &fs, err);
-	if (m) wm_mapper_destroy(m);
+	const int rc = s->run->finish(out, &fs, err);
 	if (out != stdout) fclose(out);
 	if (stats) { stats[0] = (double)fs.n_reads; stats[1] = (double)fs.n_bases; stats[2] = (double)fs.n_batches; stats[3] = fs.t_read; stats[4] = fs.t_map; stats[5] = fs.t_write; }
-	if (rc) return le.code ? set_err(le.code, "%s", le.msg.c_str()) : g_err[0] ? WM_EINVAL : set_err(WM_EINVAL, "%s", err.c_str());
+	wm_split_abort(s);
+	if (rc) return set_err(WM_EINVAL, "%s", err.c_str());
 	return WM_OK;
+}
+
+// every part given up front (rounds 3-4; the parts stay the caller's)
+extern "C" int wm_map_file_split(wm_ctx_t *c, int n_parts, wm_index_t *const *parts, const wm_mapopt_t *opt, int n_threads, const char *reads_path, const char *out_path,
+                                 int64_t mini_batch_bases, double *stats)
+{
+	g_err[0] = 0;
+	if (!c || n_parts < 1 || !parts || !opt || !reads_path || !out_path) return set_err(WM_EINVAL, "bad argument");
+	for (int j = 0; j < n_parts; ++j) if (!parts[j]) return set_err(WM_EINVAL, "null index part");
+	wm_split_t *s = 0;
+	int rc = wm_split_begin(c, opt, parts[0]->ix.k, parts[0]->ix.w, n_threads, reads_path, mini_batch_bases, &s);
+	if (rc) return rc;
+	for (int j = 0; j < n_parts; ++j)
+		if ((rc = wm_split_add_part(s, parts[j])) != WM_OK) { wm_split_abort(s); return rc; }
+	return wm_split_finish(s, out_path, stats);
+}
+
+// the reference FASTA indexed part by part AS THE RUN GOES: one part in host memory (and one on the device) at a time, like `winnowmap -I <batch_bases>
+// --split-prefix` (src/main.c:417-419). on_device: the part's minimizers are sketched and its table built on the GPU (wm_index_build_dev's path).
+extern "C" int wm_map_file_split_fasta(wm_ctx_t *c, const char *fasta, const char *kmer_file, int k, int w, int build_threads, uint64_t batch_bases, int on_device,
+                                       const wm_mapopt_t *opt, int n_threads, const char *reads_path, const char *out_path, int64_t mini_batch_bases, double *stats, int *n_parts)
+{
+	g_err[0] = 0;
+	if (!c || !fasta || !opt || !reads_path || !out_path || batch_bases == 0) return set_err(WM_EINVAL, "bad argument");
+	if (n_parts) *n_parts = 0;
+	wm::IdxOpt io; io.k = k; io.w = w;
+	{ wm::MapOpt mo; std::string e; if (wm::check_opt(io, mo, e) < 0) return set_err(WM_EINVAL, "%s", e.c_str()); }
+	wm::IndexPartReader rd;
+	std::string err;
+	if (rd.open(fasta, err) < 0) return set_err(WM_EINVAL, "%s", err.c_str());
+	wm_split_t *s = 0;
+	int rc = wm_split_begin(c, opt, k, w, n_threads, reads_path, mini_batch_bases, &s);
+	if (rc) return rc;
+	std::vector<std::string> names, seqs;
+	int n = 0;
+	while (rd.next(batch_bases, names, seqs) > 0) {
+		wm_index_t *part = 0;
+		if (on_device) rc = wm_index_build_seqs_dev(c, io, names, seqs, kmer_file ? kmer_file : "", build_threads, &part);
+		else {
+			part = new wm_index_t();
+			if (wm::index_build(io, names, seqs, kmer_file ? kmer_file : "", build_threads, part->ix, err) < 0) { delete part; part = 0; rc = set_err(WM_EINVAL, "%s", err.c_str()); }
+		}
+		std::vector<std::string>().swap(seqs);
+		if (rc == WM_OK) rc = wm_split_add_part(s, part);
+		if (part) wm_index_destroy(part);
+		if (rc) { wm_split_abort(s); return rc; }
+		++n;
+	}
+	if (n == 0) { wm_split_abort(s); return set_err(WM_EINVAL, "no sequences in %s", fasta); }
+	if (n_parts) *n_parts = n;
+	return wm_split_finish(s, out_path, stats);
 }
 
 extern "C" int wm_index_read_junc_bed(wm_index_t *idx, const char *path)

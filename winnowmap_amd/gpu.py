@@ -316,6 +316,48 @@ def map_file_split(ctx, parts, opt, n_threads, reads_path, out_path, mini_batch_
     return dict(zip(("reads", "bases", "batches", "t_read", "t_map", "t_write"), (float(x) for x in st)))
 
 
+def map_file_split_fasta(ctx, fasta, kmer_file, k, w, batch_bases, opt, n_threads, reads_path, out_path, on_device=False, build_threads=8, mini_batch_bases=0):
+    """wm_map_file_split_fasta: like `winnowmap -I <batch_bases> --split-prefix`, one index part in memory at a time (built when its turn comes)"""
+    L = lib()
+    L.wm_map_file_split_fasta.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.POINTER(MapOpt), C.c_int,
+                                          C.c_char_p, C.c_char_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int)]
+    st = np.zeros(6, np.float64)
+    n = C.c_int()
+    _chk(L.wm_map_file_split_fasta(ctx._h, os.fsencode(fasta), os.fsencode(kmer_file) if kmer_file else None, k, w, build_threads, batch_bases, 1 if on_device else 0,
+                                   C.byref(opt), n_threads, os.fsencode(reads_path), os.fsencode(out_path), mini_batch_bases, st.ctypes.data, C.byref(n)))
+    d = dict(zip(("reads", "bases", "batches", "t_read", "t_map", "t_write"), (float(x) for x in st)))
+    d["parts"] = n.value
+    return d
+
+
+class SplitRun:
+    """wm_split_begin / wm_split_add_part / wm_split_finish: a reference indexed in parts, one part at a time (src/main.c:398-429)"""
+
+    def __init__(self, ctx, opt, k, w, n_threads, reads_path, mini_batch_bases=0):
+        L = lib()
+        L.wm_split_begin.argtypes = [C.c_void_p, C.POINTER(MapOpt), C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int64, C.POINTER(C.c_void_p)]
+        L.wm_split_add_part.argtypes = [C.c_void_p, C.c_void_p]
+        L.wm_split_finish.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+        L.wm_split_abort.argtypes = [C.c_void_p]
+        L.wm_split_abort.restype = None
+        self._h = C.c_void_p()
+        _chk(L.wm_split_begin(ctx._h, C.byref(opt), k, w, n_threads, os.fsencode(reads_path), mini_batch_bases, C.byref(self._h)))
+
+    def add_part(self, idx):
+        _chk(lib().wm_split_add_part(self._h, idx._h))
+
+    def finish(self, out_path):
+        st = np.zeros(6, np.float64)
+        h, self._h = self._h, None
+        _chk(lib().wm_split_finish(h, os.fsencode(out_path), st.ctypes.data))
+        return dict(zip(("reads", "bases", "batches", "t_read", "t_map", "t_write"), (float(x) for x in st)))
+
+    def abort(self):
+        if self._h:
+            lib().wm_split_abort(self._h)
+            self._h = None
+
+
 class Index:
     """Reference index (host build, mm_idx_gen semantics); `upload(ctx)` copies the flat arrays to HBM."""
 
