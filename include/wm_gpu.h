@@ -292,7 +292,9 @@ int wm_map_file(wm_mapper_t *m, const char *reads_path, const char *out_path, in
  * staging. wm_index_upload_peer: the index that context `src` holds, copied into `dst` (any GPU of the node) — the in-process index broadcast.
  * wm_map_file_multi: wm_map_file over n mappers (one per GPU, each with its own context / index copy / host threads): mini-batches go round-robin to
  * 2 lanes per mapper, the ordered writer restores input order, the output equals wm_map_file's. Replaces the role of mm_map_file_frag's pipeline
- * (src/map.c:1226-1268) for an N-GPU node; the reference has no counterpart (it has one address space). */
+ * (src/map.c:1226-1268) for an N-GPU node; the reference has no counterpart (it has one address space). With n > 1 the 2n mapping calls in flight share the
+ * host: each gets usable cores / 2n worker threads for the duration of the loop (never more than its mapper's own count, at least 2; usable = the affinity
+ * mask cut by the cgroup CPU quota; WM_MULTI_THREADS=<per call> overrides, 0 = the mappers' own counts). */
 int wm_index_upload_dev(wm_ctx_t *ctx, const wm_index_t *idx, const void *d_S, const void *d_hkey, const void *d_hval, const void *d_P, const void *d_bloom, int src_device);
 int wm_index_upload_peer(wm_ctx_t *dst, const wm_index_t *idx, const wm_ctx_t *src);
 int wm_map_file_multi(wm_mapper_t *const *mappers, int n, const char *reads_path, const char *out_path, int64_t mini_batch_bases, double *stats);

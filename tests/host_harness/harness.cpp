@@ -485,6 +485,8 @@ int h_update_extra(int rev, int qs, int qe, int rs, int re, const uint8_t *qseq,
 	return take_internal_error(ie) ? -5 : 0;
 }
 
+int h_usable_cores(void) { return usable_cores(); }
+
 // the host's compile of the CIGAR walks the device also runs (winnowmap_amd/csrc/cigar_walk.h)
 void h_zdrop_walk(const uint8_t *q, const uint8_t *t, const uint32_t *cigar, int n_cigar, int match, int mismatch, int ambi, int gq, int ge, int32_t *out5)
 {

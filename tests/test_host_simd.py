@@ -71,3 +71,10 @@ def test_ksw_ll_i16_on_vectors_equals_the_lane_by_lane_form(H):
             s = f(len(q), q, len(t), t, mat, go, ge, C.byref(qe), C.byref(te))
             r.append((s, qe.value, te.value))
         assert r[0] == r[1], (it, r)
+
+
+def test_usable_cores_follow_affinity_and_cgroup_quota():
+    """wm::usable_cores (what wm_map_file_multi divides among its mapping calls) = the Python launcher's count (winnowmap_amd/dist.py)"""
+    from winnowmap_amd import dist
+    H = C.CDLL(build.build_harness())
+    assert H.h_usable_cores() == dist.available_cores() >= 1

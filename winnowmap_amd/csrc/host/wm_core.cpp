@@ -1,5 +1,10 @@
 // wm_core.cpp — options/presets, exact-permutation sorts, small hashes (see wm_core.h for citations).
 #include "wm_core.h"
+#include <sched.h>
+#include <unistd.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
 #include <mutex>
 #include <string.h>
 #include <string>
@@ -206,6 +211,27 @@ uint32_t x31_hash_string(const char *s)
 
 std::vector<ProfSlot> &prof_slots() { static std::vector<ProfSlot> v; return v; }
 std::mutex &prof_mutex() { static std::mutex m; return m; }
+int usable_cores()
+{
+	int n = 0;
+	cpu_set_t set;
+	if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+	if (n < 1) { const long c = sysconf(_SC_NPROCESSORS_ONLN); n = c > 0 ? (int)c : 1; }
+	double quota = 0;
+	if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota|max> <period>"
+		char q[64]; double per = 0;
+		if (fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) quota = atof(q) / per;
+		fclose(f);
+	} else {
+		double qv = -1, per = 0;
+		if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lf", &qv) != 1) qv = -1; fclose(g); }
+		if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lf", &per) != 1) per = 0; fclose(g); }
+		if (qv > 0 && per > 0) quota = qv / per;
+	}
+	if (quota > 0 && quota < n) n = (int)quota > 0 ? (int)quota : 1;      // (whole cores, like winnowmap_amd/dist.py: available_cores)
+	return n;
+}
+
 int prof_region(const char *name)
 {
 	std::lock_guard<std::mutex> g(prof_mutex());

@@ -164,6 +164,8 @@ struct ProfScope {
 	explicit ProfScope(int id_) : id(id_) { if (id >= 0) t0 = std::chrono::steady_clock::now(); }
 	~ProfScope() { if (id >= 0) { const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); std::lock_guard<std::mutex> g(prof_mutex()); prof_slots()[id].ms += ms; prof_slots()[id].n += 1; } }
 };
+// host cores this process may use: the affinity mask, cut by the cgroup CPU quota (cpu.max, or cfs_quota_us / cfs_period_us) when there is one
+int usable_cores();
 int prof_region(const char *name);
 void prof_report(FILE *f);
 #define WM_PROF(name) static const int wm_prof_id = wm::prof_on() ? wm::prof_region(name) : -1; wm::ProfScope wm_prof_scope(wm_prof_id)   /* one per block */

@@ -3066,6 +3066,8 @@ struct wm_mapper_s {
 	wm_ctx_t *c; const wm_index_t *idx;
 	std::vector<wm_ctx_t*> workers;        // extra contexts (own stream + arena slice) for groups 1..G-1
 	int n_threads = 1;
+	int n_threads_cap = 0;                 // > 0: a file loop over several mappers has divided the host's cores among its mapping calls (wm_map_file_multi)
+	int call_threads() const { return n_threads_cap > 0 && n_threads_cap < n_threads ? n_threads_cap : n_threads; }
 	wm::IdxOpt io; wm::MapOpt mo;
 	// results of the last mapping call per slot (wm_map_reads = slot 0; wm_map_reads_slot: two calls may run concurrently)
 	struct Result { std::string text; std::vector<int32_t> hits; std::vector<uint32_t> cigars; std::vector<int64_t> first; } res[WM_MAX_SLOTS];
@@ -3272,7 +3274,7 @@ static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double
 	std::vector<std::string> texts(n);
 	const std::function<void(size_t)> fmt = [&](size_t i) { wm::write_read(texts[i], m->idx->ix, reads[i], out[i], m->mo.flag); };
 	CallOps call(ops);                       // this call's view of the shared contexts: its failed batches fail this call, nobody else's
-	wm::map_batch(m->idx->ix, m->mo, &call, reads, out, &st, m->n_threads, &fmt, slot);
+	wm::map_batch(m->idx->ix, m->mo, &call, reads, out, &st, m->call_threads(), &fmt, slot);
 	if (!call.err.msg.empty()) return set_err(WM_ENODEV, "%s", call.err.msg.c_str());
 	if (!st.internal_error.empty()) return set_err(WM_EINTERNAL, "%s", st.internal_error.c_str());
 	{ std::string ie; if (wm::take_internal_error(ie)) return set_err(WM_EINTERNAL, "%s", ie.c_str()); }      // (recorded by a thread outside any call's team)
@@ -3313,7 +3315,7 @@ static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double
 	m->stats[0] = st.n_flush; m->stats[1] = st.n_ksw; m->stats[2] = st.n_chain; m->stats[3] = st.n_seed; m->stats[4] = st.n_sketch;
 	m->host_stats[0] += st.cpu_fiber; m->host_stats[1] += st.wall_idle;
 	for (int op = 0; op < 4; ++op) { m->host_stats[2 + op] += st.cpu_op[op]; m->host_stats[6 + op] += st.wall_op[op]; m->host_stats[10 + op] += (double)st.n_batches[op]; }
-	m->host_stats[14] += (tm2 - tm1) * 1e-3; m->host_stats[15] += (now_ms() - tm2) * 1e-3; m->host_stats[16] = m->n_threads; m->host_stats[17] += st.cpu_help;
+	m->host_stats[14] += (tm2 - tm1) * 1e-3; m->host_stats[15] += (now_ms() - tm2) * 1e-3; m->host_stats[16] = m->call_threads(); m->host_stats[17] += st.cpu_help;
 	m->host_stats[18] += st.wall_fiber; m->host_stats[19] += st.wall_lock; m->host_stats[20] += st.wall_total;
 	if (trace_m) fprintf(stderr, "[host] fibers cpu %.2f s | idle wall %.2f s | batched calls cpu/wall/n: sketch %.2f/%.2f/%llu seed %.2f/%.2f/%llu chain %.2f/%.2f/%llu ksw %.2f/%.2f/%llu\n", st.cpu_fiber, st.wall_idle,
 	                     st.cpu_op[0], st.wall_op[0], (unsigned long long)st.n_batches[0], st.cpu_op[1], st.wall_op[1], (unsigned long long)st.n_batches[1],
@@ -3409,6 +3411,17 @@ extern "C" int wm_map_file_multi(wm_mapper_t *const *ms, int n, const char *read
 	wm::FileStats fs;
 	const bool with_qual = (m0->mo.flag & 0x8) != 0;
 	LaneError le;
+	// n mappers x lanes mapping calls run at once, each with its mapper's worker threads: on a host whose usable cores (affinity, cgroup quota) are fewer
+	// than that product the calls are given an equal share each for the duration of the loop (eight mappers of sixteen threads under a 16-CPU quota were
+	// 256 runnable threads: the collapse of profiles/r04j). WM_MULTI_THREADS=<n> sets the share per call, 0 leaves the mappers' own counts.
+	{
+		const int lanes = wm::default_lanes() * n;
+		int share = wm::usable_cores() / lanes;
+		if (getenv("WM_MULTI_THREADS")) share = atoi(getenv("WM_MULTI_THREADS"));
+		else if (share < 2) share = 2;
+		for (int i = 0; i < n; ++i) ms[i]->n_threads_cap = n > 1 ? share : 0;
+	}
+	struct Uncap { wm_mapper_t *const *ms; int n; ~Uncap() { for (int i = 0; i < n; ++i) ms[i]->n_threads_cap = 0; } } uncap{ ms, n };
 	const int rc = wm::map_file(reads_path, mini_batch_bases, with_qual, [&](std::vector<wm::ReadIn> &batch, std::string &text, int lane) {
 		wm_mapper_t *m = ms[lane % n];
 		const int slot = lane / n;
