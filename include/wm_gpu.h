@@ -98,6 +98,8 @@ typedef struct {
 	int32_t w, zdrop, end_bonus, flag;
 	int8_t step, has_n, pad[6];
 } wm_ksw_pos_t;
+/* codes: the 0..4 codes (seq_nt4_table) of the mini-batch's reads back to back; they are packed on the host to 2 bits per base + 1 ambiguity bit per base
+ * (0.375 B per base across PCIe and in HBM) — offsets into them stay BASE indices. */
 int wm_reads_upload(wm_ctx_t *ctx, const uint8_t *codes, size_t n);
 int wm_ksw_batch_pos(wm_ctx_t *ctx, const wm_ksw_score_t *sc, int n_jobs, const wm_ksw_pos_t *jobs,
                      wm_ksw_result_t *results, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used);
@@ -174,6 +176,13 @@ int wm_index_build(const char *fasta, const char *kmer_file, int k, int w, int n
  * Needs odd k (every preset); contigs are sketched in groups that fit the context's arena (~26 B per base). stats (optional, 4 doubles):
  * seconds reading + packing, sketching on the device (incl. transfers), building the table; minimizers. */
 int wm_index_build_gpu(wm_ctx_t *ctx, const char *fasta, const char *kmer_file, int k, int w, int n_threads, wm_index_t **out, double *stats);
+/* Both with the index flags of mm_idxopt_t::flag (src/minimap.h:41-43). Known here: MM_I_HPC = 1, the CLI's -H — minimizers over the homopolymer-
+ * compressed sequence (src/sketch.c:152-163: a run of one base is one step, a minimizer sits on the last base of its last run and carries the summed length
+ * of its k runs as span); a mapper on such an index sketches its reads the same way (the device sketch compacts every sequence into its runs first, needs
+ * an odd k) and anchors are moved to the start of their runs before alignment (mm_adjust_minier, src/align.c:352-361). An index loaded from a file carries
+ * its flag in the header. */
+int wm_index_build_flag(const char *fasta, const char *kmer_file, int k, int w, int idx_flag, int n_threads, wm_index_t **out);
+int wm_index_build_gpu_flag(wm_ctx_t *ctx, const char *fasta, const char *kmer_file, int k, int w, int idx_flag, int n_threads, wm_index_t **out, double *stats);
 void wm_index_destroy(wm_index_t *idx);
 /* The reference's index file ("MMI\2": winnowmap -d, mm_idx_dump / mm_idx_load, src/index.c:515-608). Files written here load in
  * the reference and vice versa. The reference does not store its bloom filter; wm_index_save appends it as a trailer the reference

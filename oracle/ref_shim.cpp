@@ -17,11 +17,13 @@
 extern "C" {
 
 // ---- index (src/index.c:634,660 mm_idx_reader_open/read → mm_idx_gen :378) ----
-void *refshim_idx_build(const char *fasta, const char *kmer_file, int k, int w, int n_threads)
+void *refshim_idx_build_flag(const char *fasta, const char *kmer_file, int k, int w, int idx_flag, int n_threads);
+void *refshim_idx_build(const char *fasta, const char *kmer_file, int k, int w, int n_threads) { return refshim_idx_build_flag(fasta, kmer_file, k, w, 0, n_threads); }
+void *refshim_idx_build_flag(const char *fasta, const char *kmer_file, int k, int w, int idx_flag, int n_threads)      // idx_flag: MM_I_HPC = 1 (the CLI's -H)
 {
 	mm_idxopt_t io;
 	mm_idxopt_init(&io);
-	io.k = k, io.w = w;
+	io.k = k, io.w = w; io.flag |= idx_flag;
 	mm_verbose = 1;
 	mm_idx_reader_t *r = mm_idx_reader_open(fasta, &io, 0);
 	if (!r) return 0;

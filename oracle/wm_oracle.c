@@ -125,16 +125,20 @@ uint64_t wmo_encode_kmer(const char *s, int k)
 }
 
 /* ------------------------------------------------------------------------------------------------
- * mm_sketch, non-HPC (src/sketch.c:128-219). Weighted robust winnowing; see SURVEY.md Appendix D.
+ * mm_sketch (src/sketch.c:128-219). Weighted robust winnowing; see SURVEY.md Appendix D.
+ * is_hpc (homopolymer compression, :152-163): a run of one unambiguous base is ONE step of the automaton — a k-mer is made of k consecutive runs, its
+ * position is the LAST base of its last run (:159), its span (the low byte of x) the summed length of those runs (:161-162, a queue of the last k run
+ * lengths that an ambiguous base empties, :175); k-mers that span 256 bases or more are not used (:168).
  * ---------------------------------------------------------------------------------------------- */
 #define EMPTY64 UINT64_MAX
-int64_t wmo_sketch(const char *seq, int len, int w, int k, uint32_t rid, const wmo_bloom_t *f,
-                   uint64_t *ox, uint64_t *oy, int64_t cap)
+static int64_t sketch_impl(const char *seq, int len, int w, int k, uint32_t rid, const wmo_bloom_t *f, int is_hpc,
+                           uint64_t *ox, uint64_t *oy, int64_t cap)
 {
 	const uint64_t mask = (1ULL << 2 * k) - 1, top = 2 * (uint64_t)(k - 1);
 	uint64_t fw = 0, rc = 0, ring_x[256], ring_y[256], best_x = EMPTY64, best_y = EMPTY64;
 	double ring_o[256], best_o = 2.0;
 	int i, j, run = 0, slot = 0, best_slot = 0;
+	int rl[32], rl_n = 0, rl_head = 0, span = 0;            /* HPC: lengths of the last (up to) k runs since the last ambiguous base, and their sum */
 	int64_t n_out = 0;
 	assert(len > 0 && w > 0 && w < 256 && k > 0 && k <= 28);
 	for (j = 0; j < w; ++j) ring_x[j] = ring_y[j] = EMPTY64, ring_o[j] = 2.0;
@@ -145,17 +149,24 @@ int64_t wmo_sketch(const char *seq, int len, int w, int k, uint32_t rid, const w
 		double co = 2.0;
 		if (c < 4) {
 			int strand;
+			if (is_hpc) {                             /* the whole run is this step; i moves to its last base (:153-159) */
+				int n = 1;
+				while (i + n < len && nt4((uint8_t)seq[i + n]) == c) ++n;
+				i += n - 1;
+				rl[(rl_head + rl_n++) & 31] = n; span += n;
+				if (rl_n > k) { span -= rl[rl_head & 31]; ++rl_head; --rl_n; }
+			}
 			fw = (fw << 2 | (uint64_t)c) & mask;
 			rc = rc >> 2 | (3ULL ^ (uint64_t)c) << top;
 			if (fw == rc) continue;                 /* palindrome: the whole step is skipped (:166) */
 			strand = fw < rc ? 0 : 1;
-			if (++run >= k) {
+			if (++run >= k && (!is_hpc || span < 256)) {
 				uint64_t km = strand ? rc : fw;
-				cx = wmo_hash64(km, mask) << 8 | (uint64_t)k;
+				cx = wmo_hash64(km, mask) << 8 | (uint64_t)(is_hpc ? span : k);
 				cy = (uint64_t)rid << 32 | (uint32_t)i << 1 | (uint64_t)strand;
 				co = wmo_order(km, wmo_bloom_contains(f, km));
 			}
-		} else run = 0;
+		} else run = 0, rl_n = rl_head = 0, span = 0;
 		ring_x[slot] = cx, ring_y[slot] = cy, ring_o[slot] = co;
 		if (co < best_o) {                           /* strictly smaller: older of equal orders stays (:180) */
 			if (run >= w + k && best_x != EMPTY64) EMIT();
@@ -173,6 +184,14 @@ int64_t wmo_sketch(const char *seq, int len, int w, int k, uint32_t rid, const w
 	if (best_x != EMPTY64) EMIT();
 #undef EMIT
 	return n_out;
+}
+int64_t wmo_sketch(const char *seq, int len, int w, int k, uint32_t rid, const wmo_bloom_t *f, uint64_t *ox, uint64_t *oy, int64_t cap)
+{
+	return sketch_impl(seq, len, w, k, rid, f, 0, ox, oy, cap);
+}
+int64_t wmo_sketch_hpc(const char *seq, int len, int w, int k, uint32_t rid, const wmo_bloom_t *f, uint64_t *ox, uint64_t *oy, int64_t cap)
+{
+	return sketch_impl(seq, len, w, k, rid, f, 1, ox, oy, cap);
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -13,6 +13,7 @@
 #include "../../winnowmap_amd/csrc/host/wm_format.cpp"
 #include "../../winnowmap_amd/csrc/host/wm_pipeline.cpp"
 #include "../../oracle/wm_oracle.h"
+#include "../../winnowmap_amd/csrc/reads2bit.h"
 #include <fstream>
 
 using namespace wm;
@@ -22,14 +23,22 @@ struct OracleOps : DeviceOps {
 	int max_inflight() const override { return 64; }             // stateless CPU calls: any number may run at once
 	// "resident" data like the device implementation keeps it: the batch's read codes (and the index's packed reference). Requests are
 	// served from their host views; the resident positions they carry are decoded as well and must give the same bytes.
-	const uint8_t *rd = 0; size_t rd_n = 0;
+	// (kept the way the device keeps them: 2 bits per base + an ambiguity bitmap, packed by the product's wm_pack_codes — csrc/reads2bit.h)
+	std::vector<uint64_t> rd_pk, rd_nm; size_t rd_n = 0;
 	std::atomic<long> n_pos_checked{0}, n_pos_bad{0};
-	bool load_reads(const uint8_t *codes, size_t n, int, int64_t *base) override { rd = codes; rd_n = n; *base = 0; return true; }
+	bool load_reads(const uint8_t *codes, size_t n, int, int64_t *base) override
+	{
+		rd_pk.assign(wm_pk_words(n), ~0ULL); rd_nm.assign(wm_nm_words(n), ~0ULL);
+		wm_pack_codes(codes, n, rd_pk.data(), rd_nm.data());
+		rd_n = n; *base = 0;
+		return true;
+	}
+	uint8_t rd_at(int64_t p) const { return (uint8_t)wm_rd_code(rd_pk.data(), rd_nm.data(), (uint64_t)p); }
 	uint8_t two_strand(const KswReq &r, int64_t p) const
 	{   // KswReq: [0,L) forward strand, [L,2L) reverse complement, negative = N padding
 		const int64_t L = r.qwin_len;
 		if (p < 0 || p >= 2 * L) return 4;
-		const uint8_t c = p < L ? rd[r.qwin_off + p] : rd[r.qwin_off + (2 * L - 1 - p)];
+		const uint8_t c = p < L ? rd_at(r.qwin_off + p) : rd_at(r.qwin_off + (2 * L - 1 - p));
 		return p < L ? c : (c < 4 ? 3 - c : 4);
 	}
 	void check_positions(const KswReq &r, const std::vector<uint8_t> &q, const std::vector<uint8_t> &t)
@@ -49,9 +58,9 @@ struct OracleOps : DeviceOps {
 	void sketch_batch(int w, int k, std::vector<SketchReq*> &reqs) override
 	{
 		for (SketchReq *r : reqs) {
-			if (r->dev_off >= 0) { ++n_pos_checked; if ((size_t)r->dev_off + r->len > rd_n || memcmp(rd + r->dev_off, r->seq, r->len) != 0) ++n_pos_bad; }
+			if (r->dev_off >= 0) { ++n_pos_checked; bool bad = (size_t)r->dev_off + r->len > rd_n; for (int64_t t = 0; !bad && t < r->len; ++t) bad = rd_at(r->dev_off + t) != r->seq[t]; if (bad) ++n_pos_bad; }
 			std::vector<uint64_t> x(r->len + 8), y(r->len + 8);
-			int64_t n = wmo_sketch((const char*)r->seq, r->len, w, k, 0, bloom, x.data(), y.data(), r->len + 8);
+			int64_t n = (idx->flag & 1 ? wmo_sketch_hpc : wmo_sketch)((const char*)r->seq, r->len, w, k, 0, bloom, x.data(), y.data(), r->len + 8);
 			r->mini.resize(n);
 			for (int64_t i = 0; i < n; ++i) r->mini[i].x = x[i], r->mini[i].y = y[i];
 		}
@@ -171,10 +180,12 @@ static void note_pos(const OracleOps &o) { g_pos_checked += o.n_pos_checked.load
 
 extern "C" {
 
-void *h_index_build(const char *fasta, const char *kmer_file, int k, int w, int n_threads)
+void *h_index_build_flag(const char *fasta, const char *kmer_file, int k, int w, int idx_flag, int n_threads);
+void *h_index_build(const char *fasta, const char *kmer_file, int k, int w, int n_threads) { return h_index_build_flag(fasta, kmer_file, k, w, 0, n_threads); }
+void *h_index_build_flag(const char *fasta, const char *kmer_file, int k, int w, int idx_flag, int n_threads)      // idx_flag 1 = MM_I_HPC (-H)
 {
 	Harness *h = new Harness();
-	IdxOpt io; io.k = k; io.w = w;
+	IdxOpt io; io.k = k; io.w = w; io.flag = idx_flag;
 	std::string err;
 	if (index_build_from_fasta(io, fasta, kmer_file ? kmer_file : "", n_threads, h->idx, err) < 0) { fprintf(stderr, "h_index_build: %s\n", err.c_str()); delete h; return 0; }
 	std::vector<uint64_t> kms;
@@ -196,7 +207,7 @@ int h_index_get(void *hv, uint64_t minier, uint64_t *out, int cap)
 int64_t h_sketch(void *hv, const char *seq, int len, int w, int k, uint32_t rid, uint64_t *ox, uint64_t *oy, int64_t cap)
 {
 	std::vector<m128> v;
-	sketch(seq, len, w, k, rid, &((Harness*)hv)->idx.bloom, v);
+	sketch(seq, len, w, k, rid, &((Harness*)hv)->idx.bloom, v, (((Harness*)hv)->idx.flag & 1) != 0);
 	for (size_t i = 0; i < v.size() && (int64_t)i < cap; ++i) ox[i] = v[i].x, oy[i] = v[i].y;
 	return (int64_t)v.size();
 }
@@ -486,6 +497,10 @@ int h_update_extra(int rev, int qs, int qe, int rs, int re, const uint8_t *qseq,
 }
 
 int h_usable_cores(void) { return usable_cores(); }
+// the product's host packer of the resident reads (csrc/reads2bit.h)
+void h_pack_codes(const uint8_t *codes, size_t n, uint64_t *pk, uint64_t *nm) { wm_pack_codes(codes, n, pk, nm); }
+size_t h_pk_words(size_t n) { return wm_pk_words(n); }
+size_t h_nm_words(size_t n) { return wm_nm_words(n); }
 
 // the host's compile of the CIGAR walks the device also runs (winnowmap_amd/csrc/cigar_walk.h)
 void h_zdrop_walk(const uint8_t *q, const uint8_t *t, const uint32_t *cigar, int n_cigar, int match, int mismatch, int ambi, int gq, int ge, int32_t *out5)

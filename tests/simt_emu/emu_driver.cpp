@@ -211,20 +211,40 @@ int emu_ksw_exts2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 	return n;
 }
 
+// emu_set_packed(1): the sketch entry points below hand the sequences over as the mapper's resident reads do — 2 bits per base + an ambiguity bitmap
+// (reads2bit.h: wm_pack_codes on the host, rd2_* in the kernels), the job offsets flagged WM_RD_PACKED_BIT — instead of bytes
+static int g_packed = 0, g_hpc = 0;
+void emu_set_packed(int on) { g_packed = on; }
+void emu_set_hpc(int on) { g_hpc = on; }            // emu_sketch_coop with homopolymer compression (wm_sketch_params_t::hpc)
+namespace {
+struct PackedSeqs {
+	std::vector<uint64_t> pk, nm;
+	PackedSeqs(int n, const uint8_t *seqs, const uint64_t *offs, const int32_t *lens)
+	{
+		size_t tot = 0;
+		for (int i = 0; i < n; ++i) if (lens[i] > 0) tot = std::max<size_t>(tot, (size_t)offs[i] + (size_t)lens[i]);
+		pk.assign(wm_pk_words(tot), 0x5555555555555555ULL); nm.assign(wm_nm_words(tot), ~0ULL);      // (garbage first: the packer writes every word)
+		if (g_packed) wm_pack_codes(seqs, tot, pk.data(), nm.data());
+	}
+	uint64_t off(uint64_t o) const { return g_packed ? (o | WM_RD_PACKED_BIT) : o; }
+};
+}
+
 // mm_sketch through the emulated sketch kernel: n sequences (codes) packed in seqs; returns per-sequence counts and minimizers
 int emu_sketch(int n, const uint8_t *seqs, const uint64_t *offs, const int32_t *lens, int w, int k, uint32_t table_bits, uint32_t salt0, uint32_t salt1,
                const uint8_t *bloom_bits, uint64_t *ox, uint64_t *oy, const uint64_t *out_offs, const int32_t *caps, int32_t *counts)
 {
 	std::vector<wm_sketch_job_t> jobs(n);
 	uint64_t tot = 0;
-	for (int i = 0; i < n; ++i) { jobs[i].seq_off = offs[i]; jobs[i].len = lens[i]; jobs[i].out_off = out_offs[i]; jobs[i].cap = caps[i]; jobs[i].scratch_off = 0; tot = std::max<uint64_t>(tot, out_offs[i] + caps[i]); }
+	const PackedSeqs ps(n, seqs, offs, lens);
+	for (int i = 0; i < n; ++i) { jobs[i].seq_off = ps.off(offs[i]); jobs[i].len = lens[i]; jobs[i].out_off = out_offs[i]; jobs[i].cap = caps[i]; jobs[i].scratch_off = 0; tot = std::max<uint64_t>(tot, out_offs[i] + caps[i]); }
 	std::vector<wm128_t> out(tot + 1);
 	wm_sketch_params_t P = { w, k, table_bits, salt0, salt1 };
 	std::vector<double> ro((size_t)w * 64);
 	std::vector<uint32_t> ry((size_t)w * 64);
 	for (int wv = 0; wv * 64 < n; ++wv) {
 		simt::exec_mask() = ~0ull;
-		wmk::sketch_wave(P, jobs.data(), n, wv, seqs, bloom_bits, ro.data(), ry.data(), out.data(), counts);
+		wmk::sketch_wave(P, jobs.data(), n, wv, g_packed ? 0 : seqs, ps.pk.data(), ps.nm.data(), bloom_bits, ro.data(), ry.data(), out.data(), counts);
 	}
 	for (uint64_t i = 0; i < tot; ++i) ox[i] = out[i].x, oy[i] = out[i].y;
 	return 0;
@@ -238,13 +258,16 @@ int emu_sketch_coop(int n, const uint8_t *seqs, const uint64_t *offs, const int3
 	wm_sketch_params_t P = { w, k, table_bits, salt0, salt1 };
 	for (int i = 0; i < n; ++i) tot = std::max<uint64_t>(tot, out_offs[i] + caps[i]);
 	std::vector<wm128_t> out(tot + 1);
+	const PackedSeqs ps(n, seqs, offs, lens);
 	for (int i = 0; i < n; ++i) {
 		wm_sketch_job_t jb;
-		jb.seq_off = offs[i]; jb.len = lens[i]; jb.out_off = out_offs[i]; jb.cap = caps[i]; jb.scratch_off = 0;
+		jb.seq_off = ps.off(offs[i]); jb.len = lens[i]; jb.out_off = out_offs[i]; jb.cap = caps[i]; jb.scratch_off = 0;
 		const size_t L = (size_t)(lens[i] > 0 ? lens[i] : 0) + 1;
-		std::vector<double> so(L); std::vector<uint64_t> sx(L); std::vector<uint32_t> sy(L), sl(L);
+		std::vector<double> so(L); std::vector<uint64_t> sx(L); std::vector<uint32_t> sy(L), sl(L), he(L, 0xdeadbeefu);
+		std::vector<uint8_t> hc(L, 9);
 		simt::exec_mask() = ~0ull;
-		wmk::sketch_coop(P, jb, seqs, bloom_bits, so.data(), sx.data(), sy.data(), sl.data(), out.data(), counts + i);
+		P.hpc = g_hpc;
+		wmk::sketch_coop(P, jb, g_packed ? 0 : seqs, ps.pk.data(), ps.nm.data(), bloom_bits, so.data(), sx.data(), sy.data(), sl.data(), out.data(), counts + i, hc.data(), he.data());
 	}
 	for (uint64_t i = 0; i < tot; ++i) ox[i] = out[i].x, oy[i] = out[i].y;
 	return 0;
@@ -261,6 +284,7 @@ int emu_sketch_chunked(int n, const uint8_t *seqs, const uint64_t *offs, const i
 	for (int i = 0; i < n; ++i) tot = std::max<uint64_t>(tot, out_offs[i] + caps[i]);
 	std::vector<wm128_t> out(tot + 1);
 	int absorbed = 0;
+	const PackedSeqs ps(n, seqs, offs, lens);
 	for (int i = 0; i < n; ++i) {
 		const int L = lens[i] > 0 ? lens[i] : 0;
 		std::vector<double> so((size_t)L + 1, -7.0); std::vector<uint64_t> sx((size_t)L + 1, 0xdeadbeefULL); std::vector<uint32_t> sy((size_t)L + 1, 0xabcdu), sl((size_t)L + 1, 0u);
@@ -268,7 +292,7 @@ int emu_sketch_chunked(int n, const uint8_t *seqs, const uint64_t *offs, const i
 		simt::exec_mask() = ~0ull;
 		for (int c = n_ch - 1; c >= 0; --c) {                 // (any order: phase 1 of a chunk depends on the sequence alone)
 			const int b = c * chunk, e = std::min(L, b + chunk);
-			wmk::sketch_p1_range(P, (long long)offs[i], L, seqs, bloom_bits, so.data(), sx.data(), sy.data(), sl.data(), b, e);
+			wmk::sketch_p1_range(P, (long long)ps.off(offs[i]), L, g_packed ? 0 : seqs, ps.pk.data(), ps.nm.data(), bloom_bits, so.data(), sx.data(), sy.data(), sl.data(), b, e);
 		}
 		std::vector<int> sync(n_ch, -1);
 		for (int c = 1; c < n_ch; ++c) { sync[c] = wmk::sketch_find_sync(w, so.data(), c * chunk, std::min(L, (c + 1) * chunk)); absorbed += sync[c] < 0; }

@@ -276,6 +276,68 @@ def test_splice_mode_with_a_junction_annotation_matches_the_reference_library():
 
 
 @need_ref
+def test_homopolymer_compressed_index_maps_like_the_reference_with_H():
+    """`-H` (MM_I_HPC; src/sketch.c:152-163, mm_adjust_minier's HPC branch src/align.c:352-361): minimizers over the homopolymer-compressed sequence on both
+    sides. A reference with long homopolymer runs planted, reads with run-length errors on top of the ONT profile, long reads (MCAS) and short ones (MAPQ
+    compared); the index built on the host and on the device must be the same index; PAF + CIGAR against `winnowmap_ref -H`, then the reference's own CLI
+    bound to the library (`winnowmap_wm -H`: the index travels as an .mmi file with the flag in its header)."""
+    tmp = tempfile.mkdtemp()
+    rng = np.random.default_rng(91)
+    ref = synth.make_reference(2, 400000, 90, repeat_frac=0.05)
+    for c in ref:                                          # homopolymer runs of 5 .. 300 bases every few kb
+        for p in range(1500, len(c) - 2000, 3000):
+            n = int(rng.choice([5, 9, 20, 60, 300]))
+            c[p:p + n] = int(rng.integers(0, 4))
+    fa = os.path.join(tmp, "ref.fa")
+    synth.write_fasta(fa, ref, prefix="chr")
+    km, cnt = synth.repetitive_kmers(ref, 15)
+    kf = os.path.join(tmp, "rep.txt")
+    synth.write_kmer_list(kf, km, cnt, 15)
+    reads, _ = synth.make_reads(ref, 60, 12000, 92, profile="ont", sv_frac=0.1)
+    reads += synth.make_reads(ref, 60, 3000, 93, profile="ont")[0]
+
+    def hp_errors(r):                                      # lengthen / shorten runs, the error HPC was invented for
+        out = []
+        i = 0
+        while i < len(r):
+            j = i + 1
+            while j < len(r) and r[j] == r[i]:
+                j += 1
+            n = j - i
+            if n >= 3 and rng.random() < 0.3:
+                n = max(1, n + int(rng.integers(-2, 3)))
+            out.append(np.full(n, r[i], np.uint8))
+            i = j
+        return np.concatenate(out)
+
+    reads = [hp_errors(r) for r in reads]
+    rq = os.path.join(tmp, "reads.fa")
+    _write_reads(rq, reads)
+    args = ["-t", "4", "-H", "-W", kf, "-cx", "map-ont", fa, rq]
+    want = _run(REF_BIN, args)
+    ctx = gpu.Context(0, 8 << 30)
+    ih = gpu.Index(fa, kf, 15, 50, hpc=True)
+    idv, _ = gpu.Index.build_on_device(ctx, fa, kf, 15, 50, hpc=True)
+    a, b = os.path.join(tmp, "h.mmi"), os.path.join(tmp, "d.mmi")
+    ih.save(a); idv.save(b)
+    assert open(a, "rb").read() == open(b, "rb").read() and ih.n_minimizers > 1000
+    i0 = gpu.Index(fa, kf, 15, 50)
+    assert ih.n_minimizers != i0.n_minimizers                     # (it is another index than the plain one)
+    i0.close()
+    idv.upload(ctx)
+    m = gpu.Mapper(ctx, idv, "map-ont", gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
+    m.set_threads(8, 2 << 30)
+    seqs = [synth.codes_to_ascii(r) for r in reads]
+    ours, hits, _, _ = m.map([b"r%d" % i for i in range(len(seqs))], seqs)
+    d = parity.diff_texts(want, ours, sam=False)
+    assert d["reads"] >= 100 and d["hits"] >= 100 and d["mismatches"] == 0 and d["mapq_compared"] >= 50, d
+    m.close(); ih.close(); idv.close(); ctx.close()
+    if os.path.exists(WM_BIN):
+        d = parity.diff_texts(want, _run(WM_BIN, args), sam=False)
+        assert d["reads"] >= 100 and d["mismatches"] == 0, d
+
+
+@need_ref
 def test_reference_indexed_in_parts_matches_split_prefix_of_the_reference_cli():
     """wm_index_build_parts + wm_map_file_split against `winnowmap_ref -t 1 -I 350k --split-prefix …` (mm_split_merge, src/map.c:1050-1105):
     six 200-kb contigs = three index parts, a 30-kb duplication across two parts, 120 reads; the merged records must be the reference's."""

@@ -78,3 +78,30 @@ def test_usable_cores_follow_affinity_and_cgroup_quota():
     from winnowmap_amd import dist
     H = C.CDLL(build.build_harness())
     assert H.h_usable_cores() == dist.available_cores() >= 1
+
+
+def test_read_codes_pack_to_two_bits_and_an_ambiguity_bitmap():
+    """wm_pack_codes (csrc/reads2bit.h): base p = bits 2 * (p & 31) of pk[p >> 5], ambiguous iff bit p & 63 of nm[p >> 6] (its code bits 0); tail bits and
+    the slack words zero. Every length around the 32- / 64-base word boundaries, N at random places, runs of N, all-N."""
+    H = C.CDLL(build.build_harness())
+    H.h_pk_words.restype = H.h_nm_words.restype = C.c_size_t
+    H.h_pk_words.argtypes = H.h_nm_words.argtypes = [C.c_size_t]
+    H.h_pack_codes.argtypes = [W.u8p, C.c_size_t, W.u64p, W.u64p]
+    rng = np.random.default_rng(5)
+    for n in [0, 1, 7, 8, 9, 31, 32, 33, 63, 64, 65, 127, 128, 129, 1000, 4096, 4097, 100003]:
+        for kind in range(3):
+            codes = rng.integers(0, 4, n).astype(np.uint8)
+            if kind == 1 and n:
+                codes[rng.integers(0, n, max(1, n // 9))] = 4
+                codes[n // 3:n // 3 + 70] = 4
+            if kind == 2:
+                codes[:] = 4
+            pkw, nmw = H.h_pk_words(n), H.h_nm_words(n)
+            pk = np.full(pkw, 0xAAAAAAAAAAAAAAAA, np.uint64); nm = np.full(nmw, 0xFFFFFFFFFFFFFFFF, np.uint64)
+            H.h_pack_codes(np.ascontiguousarray(codes), n, pk, nm)
+            want_pk = np.zeros(pkw, np.uint64); want_nm = np.zeros(nmw, np.uint64)
+            p = np.arange(n, dtype=np.uint64)
+            c2 = np.where(codes >= 4, 0, codes).astype(np.uint64)
+            np.bitwise_or.at(want_pk, (p >> np.uint64(5)).astype(np.int64), c2 << (np.uint64(2) * (p & np.uint64(31))))
+            np.bitwise_or.at(want_nm, (p >> np.uint64(6)).astype(np.int64), (codes >= 4).astype(np.uint64) << (p & np.uint64(63)))
+            assert np.array_equal(pk, want_pk) and np.array_equal(nm, want_nm), (n, kind)

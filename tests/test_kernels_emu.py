@@ -118,9 +118,12 @@ def small_index():
 
 
 @pytest.mark.parametrize("kernel,w,k", [("lane", 50, 15), ("coop", 50, 15), ("coop", 50, 19), ("coop", 100, 21), ("coop", 10, 15), ("coop", 5, 11), ("coop", 200, 27), ("lane", 20, 14)])
-def test_sketch_kernel_emulated_matches_oracle(emu, small_index, kernel, w, k):
-    """both sketch kernels: one lane per sequence (sketch_wave, any k) and one wavefront per sequence (sketch_coop, odd k)"""
+@pytest.mark.parametrize("packed", [0, 1])
+def test_sketch_kernel_emulated_matches_oracle(emu, small_index, kernel, w, k, packed):
+    """both sketch kernels: one lane per sequence (sketch_wave, any k) and one wavefront per sequence (sketch_coop, odd k); sequences as bytes, and as the
+    mapper's resident reads are laid out in HBM (packed = 1: 2 bits per base + ambiguity bitmap, csrc/reads2bit.h — the k-mer of a position is one 64-bit window)"""
     S = small_index
+    emu.emu_set_packed(packed)
     rng = np.random.default_rng(4)
     seqs = [r[st:st + 2000].copy() for r in S["reads"][:3] for st in range(0, 14000, 4000)]
     # masked reads as stage 2 sketches them (mapped stretches replaced by N, src/map.c:786-846), N runs of every length around w and k
@@ -142,7 +145,10 @@ def test_sketch_kernel_emulated_matches_oracle(emu, small_index, kernel, w, k):
     ooffs = np.concatenate([[0], np.cumsum(caps)[:-1]]).astype(np.uint64)
     ox = np.zeros(int(caps.sum()), np.uint64); oy = np.zeros(int(caps.sum()), np.uint64); counts = np.zeros(len(seqs), np.int32)
     fn = emu.emu_sketch if kernel == "lane" else emu.emu_sketch_coop
-    fn(len(seqs), np.concatenate(seqs), offs, lens, w, k, S["tb"], S["salts"][0], S["salts"][1], C.cast(S["bloom_bits"], C.c_void_p), ox, oy, ooffs, caps, counts)
+    try:
+        fn(len(seqs), np.concatenate(seqs), offs, lens, w, k, S["tb"], S["salts"][0], S["salts"][1], C.cast(S["bloom_bits"], C.c_void_p), ox, oy, ooffs, caps, counts)
+    finally:
+        emu.emu_set_packed(0)
     for i, s in enumerate(seqs):
         ex, ey = W.o_sketch(bytes(s), w, k, rid=0, bloom=S["bloom"])
         n = counts[i]
@@ -150,8 +156,51 @@ def test_sketch_kernel_emulated_matches_oracle(emu, small_index, kernel, w, k):
         assert np.array_equal(ox[int(ooffs[i]):int(ooffs[i]) + n], ex) and np.array_equal(oy[int(ooffs[i]):int(ooffs[i]) + n], ey)
 
 
+@pytest.mark.parametrize("w,k,packed", [(50, 15, 0), (50, 15, 1), (10, 19, 1), (5, 11, 0), (100, 21, 1)])
+def test_sketch_with_homopolymer_compression_matches_oracle(emu, small_index, w, k, packed):
+    """MM_I_HPC (-H, src/sketch.c:152-163) in sketch_coop: the sequence is compacted into its runs (sketch_hpc_steps), the two phases run over the runs;
+    a minimizer sits on the last base of its last run and carries the summed length of its k runs as span (none at 256 and beyond). Sequences with long
+    runs, runs next to N and at both ends; bytes and packed reads. The oracle's HPC branch is pinned to the reference's mm_sketch (tests/test_oracle_vs_ref.py)."""
+    S = small_index
+    rng = np.random.default_rng(50 + k)
+    seqs = [r[:6000].copy() for r in S["reads"][:3]]
+    for it in range(20):
+        L = int(rng.integers(20, 1500))
+        runs = rng.integers(1, 7, L)
+        runs[rng.integers(0, L, max(1, L // 40))] = rng.integers(15, 330, max(1, L // 40))
+        base = rng.integers(0, 4, L)
+        base[1:] = np.where(base[1:] == base[:-1], (base[1:] + 1) & 3, base[1:])
+        s = np.repeat(base, runs).astype(np.uint8)
+        for _ in range(int(rng.integers(0, 4))):
+            p = int(rng.integers(0, len(s)))
+            s[p:p + int(rng.integers(1, 4))] = 4
+        seqs.append(s)
+    seqs += [np.zeros(700, np.uint8), np.full(90, 4, np.uint8), np.array([2], np.uint8), np.array([1, 1, 1, 4, 4, 0, 0], np.uint8)]
+    for ln_ in (63, 64, 65, 128, 129):
+        seqs.append(S["reads"][3][200:200 + ln_].copy())
+    lens = np.array([len(s) for s in seqs], np.int32)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    caps = (lens + 1).astype(np.int32)
+    ooffs = np.concatenate([[0], np.cumsum(caps)[:-1]]).astype(np.uint64)
+    ox = np.zeros(int(caps.sum()), np.uint64); oy = np.zeros(int(caps.sum()), np.uint64); counts = np.zeros(len(seqs), np.int32)
+    emu.emu_set_packed(packed); emu.emu_set_hpc(1)
+    try:
+        emu.emu_sketch_coop(len(seqs), np.concatenate(seqs), offs, lens, w, k, S["tb"], S["salts"][0], S["salts"][1], C.cast(S["bloom_bits"], C.c_void_p), ox, oy, ooffs, caps, counts)
+    finally:
+        emu.emu_set_packed(0); emu.emu_set_hpc(0)
+    n_span = 0
+    for i, s in enumerate(seqs):
+        ex, ey = W.o_sketch(bytes(s), w, k, rid=0, bloom=S["bloom"], hpc=True)
+        n = counts[i]
+        assert n == len(ex), (i, len(s), n, len(ex))
+        assert np.array_equal(ox[int(ooffs[i]):int(ooffs[i]) + n], ex) and np.array_equal(oy[int(ooffs[i]):int(ooffs[i]) + n], ey), i
+        n_span += int(np.count_nonzero((ex & np.uint64(0xff)) != np.uint64(k)))
+    assert n_span > 100
+
+
 @pytest.mark.parametrize("w,k,chunk", [(50, 15, 64), (50, 15, 257), (50, 19, 1000), (10, 15, 100), (100, 21, 333), (5, 11, 64), (200, 27, 512)])
-def test_sketch_in_chunks_matches_oracle(emu, small_index, w, k, chunk):
+@pytest.mark.parametrize("packed", [0, 1])
+def test_sketch_in_chunks_matches_oracle(emu, small_index, w, k, chunk, packed):
     """sketch_p1_range / sketch_find_sync / sketch_p2_range (sketch_kernel.h): a sequence cut into chunks, one wavefront per chunk, as the sketch_long_*
     kernels run contigs and long reads. Chunks far shorter than in the product (64 .. 1 000 positions against 16 384) put a boundary into every
     kind of stretch: N runs, masked reads, homopolymers and short tandem repeats (equal orders: no sync position, the chunk is absorbed), sequence ends."""
@@ -180,8 +229,12 @@ def test_sketch_in_chunks_matches_oracle(emu, small_index, w, k, chunk):
     ooffs = np.concatenate([[0], np.cumsum(caps)[:-1]]).astype(np.uint64)
     ox = np.zeros(int(caps.sum()), np.uint64); oy = np.zeros(int(caps.sum()), np.uint64); counts = np.zeros(len(seqs), np.int32)
     absorbed = C.c_int32()
-    rc = emu.emu_sketch_chunked(len(seqs), np.concatenate(seqs), offs, lens, w, k, S["tb"], S["salts"][0], S["salts"][1], C.cast(S["bloom_bits"], C.c_void_p), ox, oy, ooffs, caps, counts,
-                                chunk, C.byref(absorbed))
+    emu.emu_set_packed(packed)
+    try:
+        rc = emu.emu_sketch_chunked(len(seqs), np.concatenate(seqs), offs, lens, w, k, S["tb"], S["salts"][0], S["salts"][1], C.cast(S["bloom_bits"], C.c_void_p), ox, oy, ooffs, caps, counts,
+                                    chunk, C.byref(absorbed))
+    finally:
+        emu.emu_set_packed(0)
     assert rc == 0
     for i, s in enumerate(seqs):
         ex, ey = W.o_sketch(bytes(s), w, k, rid=0, bloom=S["bloom"])

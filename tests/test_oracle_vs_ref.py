@@ -143,6 +143,26 @@ def test_bloom_and_sketch_vs_reference(ref_index):
             ox, oy = W.o_sketch(s, w, k, rid=3, bloom=f)
             rx, ry = W.r_sketch(mi, s, w, k, rid=3)
             assert np.array_equal(ox, rx) and np.array_equal(oy, ry)
+    # homopolymer compression (-H, src/sketch.c:152-163): runs of every length incl. beyond the 255-base span limit, runs next to N, at the sequence ends
+    for it in range(30):
+        L = int(rng.integers(200, 3000))
+        runs = rng.integers(1, 9, L)
+        runs[rng.integers(0, L, L // 50)] = rng.integers(20, 400, L // 50)
+        base = rng.integers(0, 4, L)
+        base[1:] = np.where(base[1:] == base[:-1], (base[1:] + 1) & 3, base[1:])
+        a = bytearray(synth.codes_to_ascii(np.repeat(base, runs).astype(np.uint8)))
+        for _ in range(int(rng.integers(0, 5))):
+            p = int(rng.integers(0, len(a) - 3))
+            a[p:p + int(rng.integers(1, 4))] = b"N"
+        seqs.append(bytes(a))
+    n_hpc = 0
+    for s in seqs:
+        for w, k in ((50, 15), (10, 19), (5, 7), (10, 14)):
+            ox, oy = W.o_sketch(s, w, k, rid=3, bloom=f, hpc=True)
+            rx, ry = W.r_sketch(mi, s, w, k, rid=3, hpc=True)
+            assert np.array_equal(ox, rx) and np.array_equal(oy, ry)
+            n_hpc += int(np.count_nonzero((ox & np.uint64(0xff)) != np.uint64(k)))
+    assert n_hpc > 1000                        # spans other than k occurred
 
 
 def ref_anchors(mi, seq, w, k, mid_occ=5000):

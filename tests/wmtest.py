@@ -73,6 +73,8 @@ def oracle():
         L.wmo_encode_kmer.argtypes = [C.c_char_p, C.c_int]
         L.wmo_sketch.restype = C.c_int64
         L.wmo_sketch.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, u64p, u64p, C.c_int64]
+        L.wmo_sketch_hpc.restype = C.c_int64
+        L.wmo_sketch_hpc.argtypes = L.wmo_sketch.argtypes
         L.wmo_radix_sort_128x.argtypes = [C.c_void_p, C.c_void_p]
         L.wmo_radix_sort_64.argtypes = [C.c_void_p, C.c_void_p]
         L.wmo_chain_dp.restype = C.c_int64
@@ -104,14 +106,14 @@ def o_bloom_view(f):
     return int(s.table_bits), (int(s.salt[0]), int(s.salt[1])), bits
 
 
-def o_sketch(seq, w, k, rid=0, bloom=None):
+def o_sketch(seq, w, k, rid=0, bloom=None, hpc=False):
     L = oracle()
     if isinstance(seq, str):
         seq = seq.encode()
     cap = len(seq) + 8
     ox = np.zeros(cap, np.uint64)
     oy = np.zeros(cap, np.uint64)
-    n = L.wmo_sketch(seq, len(seq), w, k, rid, bloom, ox, oy, cap)
+    n = (L.wmo_sketch_hpc if hpc else L.wmo_sketch)(seq, len(seq), w, k, rid, bloom, ox, oy, cap)
     return ox[:n].copy(), oy[:n].copy()
 
 
@@ -228,14 +230,14 @@ def ref():
     return _ref
 
 
-def r_sketch(mi, seq, w, k, rid=0):
+def r_sketch(mi, seq, w, k, rid=0, hpc=False):
     L = ref()
     if isinstance(seq, str):
         seq = seq.encode()
     cap = len(seq) + 8
     ox = np.zeros(cap, np.uint64)
     oy = np.zeros(cap, np.uint64)
-    n = L.refshim_sketch(mi, seq, len(seq), w, k, rid, 0, ox, oy, cap)
+    n = L.refshim_sketch(mi, seq, len(seq), w, k, rid, 1 if hpc else 0, ox, oy, cap)
     return ox[:n].copy(), oy[:n].copy()
 
 

@@ -8,20 +8,23 @@ import numpy as np
 import wmtest as W
 from winnowmap_amd import build, synth
 
-CASES = [("map-ont", 15, 50, "ont", True), ("map-pb", 15, 50, "hifi", True), ("map-ont", 15, 50, "ont", False), ("asm20", 19, 50, "hifi", False),
-         ("splice", 15, 25, None, False), ("map-pb-clr", 15, 50, "ont", False)]
+# (preset, k, w, read profile, -W list, -H: homopolymer-compressed index, src/sketch.c:152-163 + mm_adjust_minier's HPC branch)
+CASES = [("map-ont", 15, 50, "ont", True, 0), ("map-pb", 15, 50, "hifi", True, 0), ("map-ont", 15, 50, "ont", False, 0), ("asm20", 19, 50, "hifi", False, 0),
+         ("splice", 15, 25, None, False, 0), ("map-pb-clr", 15, 50, "ont", False, 0), ("map-ont", 15, 50, "ont", True, 1), ("map-pb", 19, 10, "hifi", False, 1)]
 
 
 def run(s0, ns, verbose=True):
     """-> (reads compared, mismatching reads, reads whose MAPQ was part of the comparison)"""
     H = C.CDLL(build.build_harness())
-    H.h_index_build.restype = C.c_void_p
-    H.h_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+    H.h_index_build_flag.restype = C.c_void_p
+    H.h_index_build_flag.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
     H.h_map.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_int, C.c_char_p, W.i32p, C.c_int, W.u32p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]
     R = W.ref()
+    R.refshim_idx_build_flag.restype = C.c_void_p
+    R.refshim_idx_build_flag.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
     reads_total = bad = with_mapq = 0
     for seed in range(s0, s0 + ns):
-        preset, k, w, prof, use_w = CASES[seed % len(CASES)]
+        preset, k, w, prof, use_w, hpc = CASES[seed % len(CASES)]
         rng = np.random.default_rng(seed)
         tmp = tempfile.mkdtemp()
         ref = synth.make_reference(int(rng.integers(1, 4)), int(rng.integers(150000, 400000)), seed, repeat_frac=float(rng.choice([0.0, 0.05, 0.15])))
@@ -46,8 +49,8 @@ def run(s0, ns, verbose=True):
             km, cnt = synth.repetitive_kmers(ref, k)
             synth.write_kmer_list(tmp + "/rep.txt", km, cnt, k)
             kf = (tmp + "/rep.txt").encode()
-        h = H.h_index_build(fa.encode(), kf, k, w, 4)
-        mi = R.refshim_idx_build(fa.encode(), kf, k, w, 4)
+        h = H.h_index_build_flag(fa.encode(), kf, k, w, hpc, 4)
+        mi = R.refshim_idx_build_flag(fa.encode(), kf, k, w, hpc, 4)
         opt = R.refshim_mapopt(preset.encode(), 0x4 | 0x20, mi)
         for i, r in enumerate(reads):
             s = synth.codes_to_ascii(r)

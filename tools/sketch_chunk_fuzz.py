@@ -68,7 +68,9 @@ def main():
         ooffs = np.concatenate([[0], np.cumsum(caps)[:-1]]).astype(np.uint64)
         ox = np.zeros(int(caps.sum()), np.uint64); oy = np.zeros(int(caps.sum()), np.uint64); counts = np.zeros(len(seqs), np.int32)
         ab = C.c_int32()
+        E.emu_set_packed(seed & 1)                   # every other seed: the sequences as 2 bits per base + ambiguity bitmap (csrc/reads2bit.h)
         rc = E.emu_sketch_chunked(len(seqs), np.concatenate(seqs), offs, lens, w, k, tb, salts[0], salts[1], bits.ctypes.data, ox, oy, ooffs, caps, counts, chunk, C.byref(ab))
+        E.emu_set_packed(0)
         assert rc == 0
         for i, s in enumerate(seqs):
             ex, ey = W.o_sketch(bytes(s), w, k, rid=0, bloom=bloom["obj"] if bloom else None)

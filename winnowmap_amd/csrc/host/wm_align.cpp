@@ -186,10 +186,28 @@ static void attach_junc(const AlnEnv &E, KswReq &j, int32_t rid, int32_t rs, int
 	if (reversed) std::reverse(j.junc.begin(), j.junc.end());
 }
 
-static inline void adjust_minier(const Index &idx, const m128 &a, int32_t *r, int32_t *q)
-{   // mm_adjust_minier, non-HPC branch (src/align.c:362-363)
-	*r = (int32_t)a.x - (idx.k >> 1);
-	*q = (int32_t)a.y - (idx.k >> 1);
+static inline void adjust_minier(const Index &idx, const uint8_t *const qseq0[2], const m128 &a, int32_t *r, int32_t *q)
+{   // mm_adjust_minier (src/align.c:350-365)
+	if (idx.flag & 1) {
+		// homopolymer-compressed index (MM_I_HPC): an anchor sits on the LAST base of a run on either side — step back to the run's first base
+		// (mm_get_hplen_back on the packed reference, src/align.c:340-348; the query strand by hand, :353-358)
+		const uint8_t *qseq = qseq0[a.x >> 63];
+		int i, c;
+		*q = (int32_t)a.y;
+		for (i = *q - 1, c = qseq[*q]; i > 0; --i)
+			if (qseq[i] != c) break;
+		*q = i + 1;
+		const uint32_t rid = (uint32_t)(a.x << 1 >> 33), x = (uint32_t)(int32_t)a.x;
+		const int64_t off0 = (int64_t)idx.seq[rid].offset, off = off0 + x;
+		const int ct = (int)(idx.S[off >> 3] >> ((off & 7) << 2) & 0xf);
+		int64_t t;
+		for (t = off - 1; t >= off0; --t)
+			if ((int)(idx.S[t >> 3] >> ((t & 7) << 2) & 0xf) != ct) break;
+		*r = (int32_t)a.x + 1 - (int)(off - t);
+	} else {
+		*r = (int32_t)a.x - (idx.k >> 1);
+		*q = (int32_t)a.y - (idx.k >> 1);
+	}
 }
 
 static std::vector<int> collect_long_gaps(int as1, int cnt1, const m128 *a, int min_gap)
@@ -549,8 +567,8 @@ static void plan_reg(const AlnEnv &E, RegAln &A, m128 *a, std::vector<KswReq> &j
 	}
 	filter_bad_seeds(A.as1, A.cnt1, a, 10, 40, opt.max_gap >> 1, 10);
 	filter_bad_seeds_alt(A.as1, A.cnt1, a, 30, opt.max_gap >> 1);
-	adjust_minier(mi, a[A.as1], &A.rs, &A.qs);
-	adjust_minier(mi, a[A.as1 + A.cnt1 - 1], &A.re, &A.qe);
+	adjust_minier(mi, E.qseq0, a[A.as1], &A.rs, &A.qs);
+	adjust_minier(mi, E.qseq0, a[A.as1 + A.cnt1 - 1], &A.re, &A.qe);
 	const int32_t as1 = A.as1, cnt1 = A.cnt1, rid = A.rid;
 	int32_t rs = A.rs, qs = A.qs, re = A.re, qe = A.qe, rs0, qs0, re0, qe0, rs1, qs1, re1, qe1, l, i;
 	const int32_t ref_len = (int32_t)mi.seq[rid].len;
@@ -627,7 +645,7 @@ static void plan_reg(const AlnEnv &E, RegAln &A, m128 *a, std::vector<KswReq> &j
 	}
 	for (i = 1; i < cnt1; ++i) {                                       // gap filling (:709-765), first pass
 		if ((a[as1 + i].y & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1) continue;
-		adjust_minier(mi, a[as1 + i], &re, &qe);
+		adjust_minier(mi, E.qseq0, a[as1 + i], &re, &qe);
 		if (i == cnt1 - 1 || (a[as1 + i].y & SEED_LONG_JOIN) || (qe - qs >= opt.min_ksw_len && re - rs >= opt.min_ksw_len)) {
 			Fill f; f.idx = i; f.qs = qs; f.qe = qe; f.rs = rs; f.re = re; f.bw1 = A.bw; f.redo_job = -1;
 			if (a[as1 + i].y & SEED_LONG_JOIN) f.bw1 = qe - qs > re - rs ? qe - qs : re - rs;

@@ -97,7 +97,8 @@ struct Winnower {
 		for (int j = 0; j < w; ++j) ring_x[j] = ring_y[j] = NONE, ring_o[j] = 2.0;
 	}
 	void emit() { m128 m = { min_x, min_y }; out.push_back(m); }
-	void push(uint32_t rid, uint32_t pos, int c)
+	// span: what the low byte of x carries — k, or with homopolymer compression the length of the k runs that make the k-mer (then only < 256 counts)
+	void push(uint32_t rid, uint32_t pos, int c, int span)
 	{
 		uint64_t x = NONE, y = NONE;
 		double o = 2.0;
@@ -106,9 +107,9 @@ struct Winnower {
 			rev = rev >> 2 | (3ULL ^ (uint64_t)c) << top_shift;
 			if (fwd == rev) return;                            // strand-ambiguous k-mer: nothing happens at all
 			const int strand = fwd < rev ? 0 : 1;
-			if (++run >= k) {
+			if (++run >= k && span < 256) {
 				const uint64_t km = strand ? rev : fwd;
-				x = hash64_masked(km, mask) << 8 | (uint64_t)k;
+				x = hash64_masked(km, mask) << 8 | (uint64_t)span;
 				y = (uint64_t)rid << 32 | (uint64_t)pos << 1 | (uint64_t)strand;
 				o = minimizer_order(km, bloom && bloom->contains(km));
 			}
@@ -131,10 +132,27 @@ struct Winnower {
 };
 }
 
-void sketch(const char *seq, int len, int w, int k, uint32_t rid, const Bloom *bloom, std::vector<m128> &out)
+void sketch(const char *seq, int len, int w, int k, uint32_t rid, const Bloom *bloom, std::vector<m128> &out, bool hpc)
 {
 	Winnower wn(w, k, bloom, out);
-	for (int i = 0; i < len; ++i) wn.push(rid, (uint32_t)i, nt4_table[(uint8_t)seq[i]]);
+	if (!hpc) {
+		for (int i = 0; i < len; ++i) wn.push(rid, (uint32_t)i, nt4_table[(uint8_t)seq[i]], k);
+	} else {
+		// homopolymer compression (src/sketch.c:152-163): a run of one base is one step, at the position of its last base; the span is the summed length
+		// of the last k runs since the last ambiguous base
+		int rl[32], n_rl = 0, head = 0, span = 0;
+		for (int i = 0; i < len; ++i) {
+			const int c = nt4_table[(uint8_t)seq[i]];
+			if (c < 4) {
+				int n = 1;
+				while (i + n < len && nt4_table[(uint8_t)seq[i + n]] == c) ++n;
+				i += n - 1;
+				rl[(head + n_rl++) & 31] = n; span += n;
+				if (n_rl > k) { span -= rl[head & 31]; ++head; --n_rl; }
+			} else n_rl = head = 0, span = 0;
+			wn.push(rid, (uint32_t)i, c, span);
+		}
+	}
 	wn.finish();
 }
 
@@ -262,7 +280,7 @@ int index_build(const IdxOpt &io, const std::vector<std::string> &names, const s
 	auto work = [&]() {
 		for (size_t i; (i = next.fetch_add(1)) < seqs.size();) {
 			const std::string &s = seqs[i];
-			if (!s.empty()) sketch(s.data(), (int)s.size(), io.w, io.k, (uint32_t)i, &ix.bloom, per[i]);
+			if (!s.empty()) sketch(s.data(), (int)s.size(), io.w, io.k, (uint32_t)i, &ix.bloom, per[i], (io.flag & 1) != 0);
 		}
 	};
 	{

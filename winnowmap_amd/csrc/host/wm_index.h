@@ -20,8 +20,8 @@ struct Bloom {                              // ext/bloom/bloom_filter.hpp as con
 uint64_t encode_kmer(const char *s, int k);                    // encodeKmer, src/index.c:362-376
 double minimizer_order(uint64_t kmer, bool down_weighted);     // applyWeight, src/sketch.c:70-89
 
-// mm_sketch (src/sketch.c:128-219), non-HPC. Appends to out.
-void sketch(const char *seq, int len, int w, int k, uint32_t rid, const Bloom *bloom, std::vector<m128> &out);
+// mm_sketch (src/sketch.c:128-219). Appends to out.
+void sketch(const char *seq, int len, int w, int k, uint32_t rid, const Bloom *bloom, std::vector<m128> &out, bool hpc = false);      // hpc: MM_I_HPC, src/sketch.c:152-163
 
 struct RefSeq { std::string name; uint64_t offset; uint32_t len; };
 

@@ -1,4 +1,5 @@
-// sketch_kernel.h — weighted robust-winnowing minimizers (mm_sketch, src/sketch.c:128-219, non-HPC) on gfx950.
+// sketch_kernel.h — weighted robust-winnowing minimizers (mm_sketch, src/sketch.c:128-219) on gfx950. Homopolymer compression (:152-163) in the
+// one-wavefront-per-sequence kernel only (sketch_coop: sketch_hpc_steps compacts the sequence into its runs, the two phases then run over the runs).
 //
 // Mapping: ONE LANE per (sub)sequence — stage 1 of Winnowmap2 sketches ~9 windows per read, so a mini-batch holds
 // 10^4..10^6 independent sequences and the machine fills with thread-level parallelism; the winnowing automaton
@@ -14,6 +15,7 @@
 #error "include simt.h before sketch_kernel.h"
 #endif
 #include "wm_internal.h"
+#include "reads2bit.h"
 
 namespace wmk {
 using namespace simt;
@@ -46,7 +48,16 @@ WM_DEV V<uint32_t> sk_bloom_hash(V<uint64_t> key, uint32_t salt)
 // jobs[j]: sequence of 0..4 codes at seqs+seq_off (len bytes); minimizers go to out[out_off .. out_off+cap) and
 // counts[j] receives how many the reference would emit (may exceed cap: the host then retries with a larger slot).
 // ring_o / ring_y: w*64 entries each (LDS, or global scratch for very large w).
-WM_DEV void sketch_wave(const wm_sketch_params_t P, const wm_sketch_job_t *jobs, int n_jobs, int wave_id, const uint8_t *seqs,
+// a sequence's 0..4 code: byte i of the staged bytes at seqs + soff, or base i of the resident packed reads when soff carries WM_RD_PACKED_BIT (per lane)
+WM_DEV V<int> sk_code(const uint8_t *seqs, const uint64_t *pk, const uint64_t *nm, V<long long> soff, V<long long> i)
+{
+	V<int> c = 0;
+	const vbool packed = (soff & (long long)WM_RD_PACKED_BIT) != 0LL;
+	WM_IF(packed) c = rd2_code(pk, nm, (soff & (long long)(WM_RD_PACKED_BIT - 1)) + i); WM_ELSE c = cast<int>(gld(seqs, soff + i)); WM_END
+	return c;
+}
+
+WM_DEV void sketch_wave(const wm_sketch_params_t P, const wm_sketch_job_t *jobs, int n_jobs, int wave_id, const uint8_t *seqs, const uint64_t *pk, const uint64_t *nm,
                         const uint8_t *bloom_bits, double *ring_o, uint32_t *ring_y, wm128_t *out, int *counts)
 {
 	const int w = P.w, k = P.k;
@@ -74,7 +85,7 @@ WM_DEV void sketch_wave(const wm_sketch_params_t P, const wm_sketch_job_t *jobs,
 
 	for (int i = 0; i < max_len; ++i) {
 		WM_IF(have && len > i)
-			V<int> c = cast<int>(gld(seqs, soff + (long long)i));
+			V<int> c = sk_code(seqs, pk, nm, soff, V<long long>((long long)i));
 			V<double> co = 2.0;
 			V<int> cy = -1;
 			vbool skip = c < 0;                // false
@@ -109,7 +120,7 @@ WM_DEV void sketch_wave(const wm_sketch_params_t P, const wm_sketch_job_t *jobs,
 					V<int> pos = min_y >> 1, strand = min_y & 1;
 					V<uint64_t> f2 = (uint64_t)0, r2 = (uint64_t)0;
 					for (int t = 0; t < k; ++t) {
-						V<uint64_t> cc = cast<uint64_t>(gld(seqs, soff + cast<long long>(pos - (k - 1) + t)));
+						V<uint64_t> cc = cast<uint64_t>(sk_code(seqs, pk, nm, soff, cast<long long>(pos - (k - 1) + t)));
 						f2 = ((f2 << 2) | cc) & mask;
 						r2 = (r2 >> 2) | ((cc ^ (uint64_t)3) << (int)top);
 					}
@@ -145,7 +156,7 @@ WM_DEV void sketch_wave(const wm_sketch_params_t P, const wm_sketch_job_t *jobs,
 		V<int> pos = min_y >> 1, strand = min_y & 1;
 		V<uint64_t> f2 = (uint64_t)0, r2 = (uint64_t)0;
 		for (int t = 0; t < k; ++t) {
-			V<uint64_t> cc = cast<uint64_t>(gld(seqs, soff + cast<long long>(pos - (k - 1) + t)));
+			V<uint64_t> cc = cast<uint64_t>(sk_code(seqs, pk, nm, soff, cast<long long>(pos - (k - 1) + t)));
 			f2 = ((f2 << 2) | cc) & mask;
 			r2 = (r2 >> 2) | ((cc ^ (uint64_t)3) << (int)top);
 		}
@@ -188,9 +199,13 @@ WM_DEV void sketch_wave(const wm_sketch_params_t P, const wm_sketch_job_t *jobs,
 // stops, the chunk's own wavefront starts from (m = t) without emitting. A chunk without such a position (a long low-complexity stretch) is simply
 // absorbed by its predecessor. The chunks' minimizers concatenate to the sequence's.
 
-// phase 1 for positions [begin, end) of a sequence of n codes at seqs + soff
-WM_DEV void sketch_p1_range(const wm_sketch_params_t P, long long soff, int n, const uint8_t *seqs, const uint8_t *bloom_bits,
-                            double *so, uint64_t *sx, uint32_t *sy, uint32_t *sl, int begin, int end)
+// phase 1 for positions [begin, end) of a sequence of n codes: bytes at seqs + soff, or (PACKED) bases soff .. of the resident packed reads (reads2bit.h),
+// where the k bases that end at a position are one shifted 64-bit window instead of k byte loads
+// HPC: the "sequence" is the list of the automaton's steps (sketch_hpc_steps: seqs[s] = the code of step s, he[s] = the position of its last base):
+// a k-mer's position is he[s], its span he[s] - he[s - k] — the k runs are contiguous — and k-mers that span 256 bases or more are not used (:168)
+template <bool PACKED, bool HPC = false>
+WM_DEV void sketch_p1_range_t(const wm_sketch_params_t P, long long soff, int n, const uint8_t *seqs, const uint64_t *pk, const uint64_t *nm, const uint8_t *bloom_bits,
+                              double *so, uint64_t *sx, uint32_t *sy, uint32_t *sl, int begin, int end, const uint32_t *he = 0)
 {
 	const int w = P.w, k = P.k;
 	const uint64_t mask = (1ULL << 2 * k) - 1;
@@ -203,7 +218,11 @@ WM_DEV void sketch_p1_range(const wm_sketch_params_t P, long long soff, int n, c
 		for (int t0 = lo; t0 < begin; t0 += 64) {
 			const V<int> i = ln + t0;
 			V<int> hit = -1;
-			WM_IF(i < begin) WM_IF(cast<int>(gld(seqs, cast<long long>(i) + soff)) >= 4) hit = i; WM_END WM_END
+			WM_IF(i < begin)
+				vbool amb = false;
+				if constexpr (PACKED) amb = rd2_is_n(nm, cast<long long>(i) + soff); else amb = cast<int>(gld(seqs, cast<long long>(i) + soff)) >= 4;
+				WM_IF(amb) hit = i; WM_END
+			WM_END
 			const int mx = readlane(wave_scan_max(hit), 63);
 			last_n = mx > last_n ? mx : last_n;
 		}
@@ -211,21 +230,39 @@ WM_DEV void sketch_p1_range(const wm_sketch_params_t P, long long soff, int n, c
 	for (int t0 = begin; t0 < end; t0 += 64) {
 		const V<int> i = ln + t0;
 		const vbool in = i < end;
-		V<int> c = 4;
-		WM_IF(in) c = cast<int>(gld(seqs, cast<long long>(i) + soff)); WM_END
-		const V<int> lastN = vmax(wave_scan_max(sel(in && c >= 4, i, V<int>(-1))), last_n);
+		vbool amb = false;
+		WM_IF(in)
+			if constexpr (PACKED) amb = rd2_is_n(nm, cast<long long>(i) + soff); else amb = cast<int>(gld(seqs, cast<long long>(i) + soff)) >= 4;
+		WM_END
+		const V<int> lastN = vmax(wave_scan_max(sel(in && amb, i, V<int>(-1))), last_n);
 		const V<int> l = i - lastN;                  // unambiguous bases ending here (0 on an N)
 		last_n = readlane(lastN, 63);
-		const vbool valid = in && l >= k;
+		vbool valid = in && l >= k;
+		V<int> span = k, epos = i;
+		if constexpr (HPC) {
+			WM_IF(valid)
+				epos = cast<int>(gld(he, i));
+				V<int> before = -1;
+				WM_IF(i >= k) before = cast<int>(gld(he, i - k)); WM_END
+				span = epos - before;
+			WM_END
+			valid = valid && span < 256;
+		}
 		V<double> co = 2.0;
 		V<uint64_t> cx = ~(uint64_t)0;
 		V<uint32_t> cy = 0xffffffffu;
 		WM_IF(valid)
 			V<uint64_t> f = (uint64_t)0, g = (uint64_t)0;
-			for (int j = 0; j < k; ++j) {            // base j steps back: digit j of the forward k-mer, digit k-1-j of the reverse complement
-				const V<uint64_t> cj = cast<uint64_t>(gld(seqs, cast<long long>(i - j) + soff));
-				f = f | (cj << (2 * j));
-				g = g | ((cj ^ (uint64_t)3) << (2 * (k - 1 - j)));
+			if constexpr (PACKED) {                  // the window of the k bases i-k+1 .. i, earliest base in the low bits: its complement IS the reverse-complement k-mer
+				const V<uint64_t> win = rd2_window(pk, cast<long long>(i - (k - 1)) + soff);
+				g = ~win & mask;
+				f = rd2_rev(win) >> (64 - 2 * k);
+			} else {
+				for (int j = 0; j < k; ++j) {        // base j steps back: digit j of the forward k-mer, digit k-1-j of the reverse complement
+					const V<uint64_t> cj = cast<uint64_t>(gld(seqs, cast<long long>(i - j) + soff));
+					f = f | (cj << (2 * j));
+					g = g | ((cj ^ (uint64_t)3) << (2 * (k - 1 - j)));
+				}
 			}
 			const V<int> strand = sel(f < g, 0, 1);
 			const V<uint64_t> km = sel(strand == 1, g, f);
@@ -235,13 +272,21 @@ WM_DEV void sketch_p1_range(const wm_sketch_params_t P, long long soff, int n, c
 			const V<double> x = cast<double>(sk_fmix64(km)) * 1.0 / 18446744073709551616.0;
 			const V<double> x2 = x * x, x4 = x2 * x2;
 			co = sel(down, -1.0 * (x4 * x4), -1.0 * x);
-			cx = (sk_hash64(km, mask) << 8) | (uint64_t)k;
-			cy = cast<uint32_t>((i << 1) | strand);
+			cx = (sk_hash64(km, mask) << 8) | cast<uint64_t>(span);
+			cy = cast<uint32_t>((epos << 1) | strand);
 		WM_END
 		WM_IF(in)
 			gst(so, i, co); gst(sx, i, cx); gst(sy, i, cy); gst(sl, i, cast<uint32_t>(l));
 		WM_END
 	}
+}
+
+// soff: a byte offset into seqs, or WM_RD_PACKED_BIT | base index into the resident packed reads (uniform per call)
+WM_DEV void sketch_p1_range(const wm_sketch_params_t P, long long soff, int n, const uint8_t *seqs, const uint64_t *pk, const uint64_t *nm, const uint8_t *bloom_bits,
+                            double *so, uint64_t *sx, uint32_t *sy, uint32_t *sl, int begin, int end)
+{
+	if (soff & (long long)WM_RD_PACKED_BIT) sketch_p1_range_t<true>(P, soff & (long long)(WM_RD_PACKED_BIT - 1), n, seqs, pk, nm, bloom_bits, so, sx, sy, sl, begin, end);
+	else sketch_p1_range_t<false>(P, soff, n, seqs, pk, nm, bloom_bits, so, sx, sy, sl, begin, end);
 }
 
 // the first position t of [from, to) that holds a real k-mer whose order is strictly smaller than the orders of the (up to) w - 1 positions before it
@@ -343,11 +388,44 @@ WM_DEV int sketch_p2_range(const wm_sketch_params_t P, int n, const double *so, 
 	return n_out;
 }
 
-WM_DEV void sketch_coop(const wm_sketch_params_t P, const wm_sketch_job_t jb, const uint8_t *seqs, const uint8_t *bloom_bits,
-                        double *so, uint64_t *sx, uint32_t *sy, uint32_t *sl, wm128_t *out, int *count_out)
+// homopolymer compression (src/sketch.c:152-163) as a compaction: the STEPS of the reference's automaton in order — every run of one unambiguous base, every
+// ambiguous base on its own (:175) — hc[s] = the step's code, he[s] = the position of its last base (where :159 leaves i). Returns the number of steps.
+WM_DEV int sketch_hpc_steps(long long soff, int n, const uint8_t *seqs, const uint64_t *pk, const uint64_t *nm, uint8_t *hc, uint32_t *he)
 {
+	const V<int> ln = lane();
+	int S = 0;
+	for (int t0 = 0; t0 < n; t0 += 64) {
+		const V<int> i = ln + t0;
+		const vbool in = i < n;
+		V<int> c = 4, cn = 5;
+		WM_IF(in)
+			c = sk_code(seqs, pk, nm, V<long long>(soff), cast<long long>(i));
+			WM_IF(i + 1 < n) cn = sk_code(seqs, pk, nm, V<long long>(soff), cast<long long>(i + 1)); WM_END
+		WM_END
+		const vbool last = in && (c >= 4 || cn != c);
+		const uint64_t bm = ballot(last);
+		const V<int> at = mbcnt(bm) + S;
+		WM_IF(last) gst(hc, at, cast<uint8_t>(c)); gst(he, at, cast<uint32_t>(i)); WM_END
+		S += popc64(bm);
+	}
+	return S;
+}
+
+// hc / he: scratch of jb.len entries each for the compacted sequence (P.hpc only)
+WM_DEV void sketch_coop(const wm_sketch_params_t P, const wm_sketch_job_t jb, const uint8_t *seqs, const uint64_t *pk, const uint64_t *nm, const uint8_t *bloom_bits,
+                        double *so, uint64_t *sx, uint32_t *sy, uint32_t *sl, wm128_t *out, int *count_out, uint8_t *hc = 0, uint32_t *he = 0)
+{
+	if (P.hpc) {
+		const int S = sketch_hpc_steps((long long)jb.seq_off, jb.len, seqs, pk, nm, hc, he);
+		mem_sync();
+		sketch_p1_range_t<false, true>(P, 0, S, hc, pk, nm, bloom_bits, so, sx, sy, sl, 0, S, he);
+		mem_sync();
+		const int n_hpc = sketch_p2_range(P, S, so, sx, sy, sl, 0, false, -1, out + jb.out_off, jb.cap);
+		WM_IF(lane() == 0) gst(count_out, V<long long>(0), V<int>(n_hpc)); WM_END
+		return;
+	}
 	const int n = jb.len;
-	sketch_p1_range(P, (long long)jb.seq_off, n, seqs, bloom_bits, so, sx, sy, sl, 0, n);
+	sketch_p1_range(P, (long long)jb.seq_off, n, seqs, pk, nm, bloom_bits, so, sx, sy, sl, 0, n);
 	mem_sync();                                      // phase 2 reads what other lanes of this wave wrote (same CU: a workgroup-scope fence; no L2 write-back per job)
 	const int n_out = sketch_p2_range(P, n, so, sx, sy, sl, 0, false, -1, out + jb.out_off, jb.cap);
 	WM_IF(lane() == 0) gst(count_out, V<long long>(0), V<int>(n_out)); WM_END

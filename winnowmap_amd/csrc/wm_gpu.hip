@@ -52,6 +52,7 @@ static inline double now_ms() { return std::chrono::duration<double, std::milli>
 #include "ksw_exts2_kernel.h"
 #include "ksw_plan.h"
 #include "cigar_walk.h"
+#include "reads2bit.h"
 #include "sketch_kernel.h"
 #include "seedchain_kernel.h"
 #include "window_kernel.h"
@@ -179,7 +180,8 @@ __global__ __launch_bounds__(64 * NWV) void ksw_stripe_kernel(wm_ksw_score_t sc,
 // operands of position jobs (wm_ksw_batch_pos): expand query and target of job blockIdx.x into the batch's sequence slab. Query = two-strand
 // space of a (sub)read of the resident read codes (src/align.c:871-877), target = 4-bit packed reference (mm_idx_getseq, src/index.c:161-171).
 __global__ __launch_bounds__(64) void ksw_expand_kernel(const wm_ksw_djob_t *__restrict__ jobs, const wm_ksw_dsrc_t *__restrict__ src,
-                                                         const uint8_t *__restrict__ reads, const uint32_t *__restrict__ S, uint8_t *__restrict__ seqs)
+                                                         const uint64_t *__restrict__ reads_pk, const uint64_t *__restrict__ reads_nm, const uint32_t *__restrict__ S,
+                                                         uint8_t *__restrict__ seqs)
 {
 	WM_SETPRIO(1);
 	const int j = blockIdx.x;
@@ -191,8 +193,8 @@ __global__ __launch_bounds__(64) void ksw_expand_kernel(const wm_ksw_djob_t *__r
 	for (int i = threadIdx.x; i < jb.qlen; i += 64) {
 		const int64_t p = (int64_t)sr.q_pos + (int64_t)i * sr.step;
 		uint8_t c = 4;
-		if (p >= 0 && p < L) c = reads[sr.qwin_off + p];
-		else if (p >= L && p < 2 * L) { c = reads[sr.qwin_off + (2 * L - 1 - p)]; c = c < 4 ? 3 - c : 4; }
+		if (p >= 0 && p < L) c = (uint8_t)wmk::rd2_code(reads_pk, reads_nm, (long long)(sr.qwin_off + p));
+		else if (p >= L && p < 2 * L) { c = (uint8_t)wmk::rd2_code(reads_pk, reads_nm, (long long)(sr.qwin_off + (2 * L - 1 - p))); c = c < 4 ? 3 - c : 4; }
 		q[i] = c;
 	}
 	for (int i = threadIdx.x; i < jb.tlen; i += 64) {
@@ -327,7 +329,9 @@ struct wm_ctx_s {
 	uint8_t *d_bloom;
 	uint32_t *d_S;                              // packed reference (4 bits per base), for position jobs
 	std::vector<uint64_t> seq_off; std::vector<uint32_t> seq_len;       // contig table of the uploaded index (bounds of position jobs)
-	uint8_t *d_reads; size_t reads_bytes, reads_cap; bool owns_reads;   // 0..4 codes of the current mini-batch (wm_reads_upload)
+	// the read codes of the current mini-batch(es), resident: 2 bits per base in d_reads, the ambiguity bitmap in d_reads_nm (reads2bit.h; one allocation);
+	// reads_bytes = bases a job may address, reads_cap = bases the allocation holds (wm_reads_upload / GpuOps::load_reads)
+	uint64_t *d_reads, *d_reads_nm; size_t reads_bytes, reads_cap; bool owns_reads;
 	int hbits;
 	wm_sketch_params_t skp;
 	bool have_index, owns_index;
@@ -485,7 +489,7 @@ extern "C" int wm_ctx_create(int device, size_t arena_bytes, wm_ctx_t **out)
 	c->owns_filter = false;
 	c->pin_small = 0;
 	if (hipHostMalloc((void**)&c->pin_small, 256, hipHostMallocDefault) != hipSuccess) { c->pin_small = 0; (void)hipGetLastError(); }
-	c->d_S = 0; c->d_reads = 0; c->reads_bytes = c->reads_cap = 0; c->owns_reads = false;
+	c->d_S = 0; c->d_reads = 0; c->d_reads_nm = 0; c->reads_bytes = c->reads_cap = 0; c->owns_reads = false;
 	*out = c;
 	return WM_OK;
 }
@@ -745,7 +749,7 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 	if (pos) {
 		if (n_jobs > 0) {
 			HIPCHK(hipMemcpyAsync(d_src, dsrc.data(), (size_t)n_jobs * sizeof(wm_ksw_dsrc_t), hipMemcpyHostToDevice, c->stream));
-			hipLaunchKernelGGL(ksw_expand_kernel, dim3(n_jobs), dim3(64), 0, c->stream, b->d_jobs, d_src, c->d_reads, c->d_S, b->d_seqs);
+			hipLaunchKernelGGL(ksw_expand_kernel, dim3(n_jobs), dim3(64), 0, c->stream, b->d_jobs, d_src, c->d_reads, c->d_reads_nm, c->d_S, b->d_seqs);
 		}
 	} else if (slab_bytes) HIPCHK(hipMemcpyAsync(b->d_seqs, seqs + slab_lo, slab_bytes, hipMemcpyHostToDevice, c->stream));
 	if (!b->goff.empty()) HIPCHK(hipMemcpyAsync(b->d_goff, b->goff.data(), b->goff.size() * 8, hipMemcpyHostToDevice, c->stream));
@@ -761,20 +765,34 @@ extern "C" int wm_ksw_dev_prepare(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int 
 	return ksw_prepare_impl(c, sc_in, n_jobs, jobs, seqs, seqs_bytes, 0, out);
 }
 
+// the allocation that holds `cap` bases of resident reads: pk words first, then the bitmap
+static int reads_alloc(wm_ctx_t *c, size_t cap)
+{
+	const size_t pkw = cap / 32 + 2, nmw = cap / 64 + 2;
+	c->d_reads = 0; c->d_reads_nm = 0; c->reads_cap = 0;
+	if (hipMalloc((void**)&c->d_reads, (pkw + nmw) * 8) != hipSuccess) { (void)hipGetLastError(); c->d_reads = 0; return set_err(WM_ENOMEM, "cannot allocate %zu bytes for the resident reads", (pkw + nmw) * 8); }
+	c->d_reads_nm = c->d_reads + pkw;
+	c->reads_cap = cap;
+	return WM_OK;
+}
 extern "C" int wm_reads_upload(wm_ctx_t *c, const uint8_t *codes, size_t n)
 {
 	if (!c || (n && !codes)) return set_err(WM_EINVAL, "null argument");
 	HIPCHK(hipSetDevice(c->device));
-	if (!c->owns_reads) { c->d_reads = 0; c->reads_cap = 0; }
-	if (n + 64 > c->reads_cap) {
+	if (!c->owns_reads) { c->d_reads = 0; c->d_reads_nm = 0; c->reads_cap = 0; }
+	if (n + 256 > c->reads_cap) {
 		if (c->d_reads) HIPCHK(hipFree(c->d_reads));
-		c->d_reads = 0; c->reads_cap = 0;
-		const size_t cap = n + n / 8 + (1 << 20);
-		HIPCHK(hipMalloc((void**)&c->d_reads, cap));
-		c->reads_cap = cap;
+		c->d_reads = 0; c->d_reads_nm = 0; c->reads_cap = 0;
+		const size_t cap = (n + n / 8 + (1 << 20) + 255) & ~(size_t)255;
+		const int rc = reads_alloc(c, cap);
+		if (rc) return rc;
 	}
 	c->owns_reads = true;
-	if (n) HIPCHK(hipMemcpy(c->d_reads, codes, n, hipMemcpyHostToDevice));
+	// packed on the host (reads2bit.h: 2 bits per base + 1 ambiguity bit), 0.375 B per base across PCIe and in HBM
+	std::vector<uint64_t> pk(wm_pk_words(n)), nm(wm_nm_words(n));
+	wm_pack_codes(codes, n, pk.data(), nm.data());
+	HIPCHK(hipMemcpy(c->d_reads, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(c->d_reads_nm, nm.data(), nm.size() * 8, hipMemcpyHostToDevice));
 	c->reads_bytes = n;
 	return WM_OK;
 }
@@ -1273,24 +1291,27 @@ catch (const std::bad_alloc &) { return set_err(WM_ENOMEM, "out of host memory")
 
 struct wm_index_s { wm::Index ix; };
 
-__global__ __launch_bounds__(64) void sketch_kernel(wm_sketch_params_t P, const wm_sketch_job_t *jobs, int n_jobs, const uint8_t *seqs,
+// (seqs: the call's staged bytes; rpk / rnm: the resident packed reads, for jobs whose seq_off carries WM_RD_PACKED_BIT — reads2bit.h)
+__global__ __launch_bounds__(64) void sketch_kernel(wm_sketch_params_t P, const wm_sketch_job_t *jobs, int n_jobs, const uint8_t *seqs, const uint64_t *rpk, const uint64_t *rnm,
                                                      const uint8_t *bloom, wm128_t *out, int *counts)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	double *ring_o = (double*)smem;
 	uint32_t *ring_y = (uint32_t*)(smem + (size_t)P.w * 64 * sizeof(double));
-	wmk::sketch_wave(P, jobs, n_jobs, blockIdx.x, seqs, bloom, ring_o, ring_y, out, counts);
+	wmk::sketch_wave(P, jobs, n_jobs, blockIdx.x, seqs, rpk, rnm, bloom, ring_o, ring_y, out, counts);
 }
 
 // one wavefront per sequence (sketch_coop, odd k): order[] lists the jobs longest first; so / sx / sy / sl = per-position scratch
-__global__ __launch_bounds__(64) void sketch_coop_kernel(wm_sketch_params_t P, const wm_sketch_job_t *jobs, const int *order, const uint8_t *seqs, const uint8_t *bloom,
-                                                          double *so, uint64_t *sx, uint32_t *sy, uint32_t *sl, wm128_t *out, int *counts, int long_thr)
+__global__ __launch_bounds__(64) void sketch_coop_kernel(wm_sketch_params_t P, const wm_sketch_job_t *jobs, const int *order, const uint8_t *seqs, const uint64_t *rpk, const uint64_t *rnm,
+                                                          const uint8_t *bloom, double *so, uint64_t *sx, uint32_t *sy, uint32_t *sl, wm128_t *out, int *counts, int long_thr,
+                                                          uint8_t *hc, uint32_t *he)
 {
 	WM_SETPRIO(2);
 	const int j = order[blockIdx.x];
 	const wm_sketch_job_t jb = jobs[j];
 	if (long_thr > 0 && jb.len >= long_thr) return;           // sketched chunk by chunk (sketch_long_* kernels)
-	wmk::sketch_coop(P, jb, seqs, bloom, so + jb.scratch_off, sx + jb.scratch_off, sy + jb.scratch_off, sl + jb.scratch_off, out, counts + j);
+	wmk::sketch_coop(P, jb, seqs, rpk, rnm, bloom, so + jb.scratch_off, sx + jb.scratch_off, sy + jb.scratch_off, sl + jb.scratch_off, out, counts + j,
+	                 hc ? hc + jb.scratch_off : 0, he ? he + jb.scratch_off : 0);        // (P.hpc: the job's compacted sequence)
 }
 
 // ---- long sequences (contigs of the reference at index time, query contigs, stage-2 passes of very long reads): one wavefront per CHUNK of the
@@ -1298,12 +1319,12 @@ __global__ __launch_bounds__(64) void sketch_coop_kernel(wm_sketch_params_t P, c
 // phase 1 of every chunk | the first sync position of every chunk | phase 2 from sync to sync into chunk-local slots | per job: the chunks' minimizers
 // concatenated into the job's output slot. sketch_coop_kernel leaves these jobs alone (long_thr).
 struct wm_sk_chunk_t { int32_t job, begin, end, first; uint64_t out_off; int32_t cap, pad; };
-__global__ __launch_bounds__(64) void sketch_long_p1_kernel(wm_sketch_params_t P, const wm_sketch_job_t *jobs, const wm_sk_chunk_t *chunks, const uint8_t *seqs, const uint8_t *bloom,
-                                                             double *so, uint64_t *sx, uint32_t *sy, uint32_t *sl)
+__global__ __launch_bounds__(64) void sketch_long_p1_kernel(wm_sketch_params_t P, const wm_sketch_job_t *jobs, const wm_sk_chunk_t *chunks, const uint8_t *seqs, const uint64_t *rpk,
+                                                             const uint64_t *rnm, const uint8_t *bloom, double *so, uint64_t *sx, uint32_t *sy, uint32_t *sl)
 {
 	const wm_sk_chunk_t ch = chunks[blockIdx.x];
 	const wm_sketch_job_t jb = jobs[ch.job];
-	wmk::sketch_p1_range(P, (long long)jb.seq_off, jb.len, seqs, bloom, so + jb.scratch_off, sx + jb.scratch_off, sy + jb.scratch_off, sl + jb.scratch_off, ch.begin, ch.end);
+	wmk::sketch_p1_range(P, (long long)jb.seq_off, jb.len, seqs, rpk, rnm, bloom, so + jb.scratch_off, sx + jb.scratch_off, sy + jb.scratch_off, sl + jb.scratch_off, ch.begin, ch.end);
 }
 __global__ __launch_bounds__(64) void sketch_long_sync_kernel(wm_sketch_params_t P, const wm_sketch_job_t *jobs, const wm_sk_chunk_t *chunks, const double *so, int *sync)
 {
@@ -1404,8 +1425,13 @@ extern "C" float wm_last_aux_ms(const wm_ctx_t *c) { return c ? c->aux_ms : 0.f;
 
 extern "C" int wm_index_build(const char *fasta, const char *kmer_file, int k, int w, int n_threads, wm_index_t **out)
 {
+	return wm_index_build_flag(fasta, kmer_file, k, w, 0, n_threads, out);
+}
+extern "C" int wm_index_build_flag(const char *fasta, const char *kmer_file, int k, int w, int idx_flag, int n_threads, wm_index_t **out)
+{
 	*out = 0;
-	wm::IdxOpt io; io.k = k; io.w = w;
+	if (idx_flag & ~1) return set_err(WM_EINVAL, "index flag %d: only MM_I_HPC (1) is known here", idx_flag);
+	wm::IdxOpt io; io.k = k; io.w = w; io.flag = idx_flag;
 	wm::MapOpt mo; std::string err;
 	if (wm::check_opt(io, mo, err) < 0) return set_err(WM_EINVAL, "%s", err.c_str());
 	wm_index_t *h = new wm_index_t();
@@ -1637,7 +1663,7 @@ extern "C" int wm_index_upload(wm_ctx_t *c, const wm_index_t *h)
 	c->seq_off.clear(); c->seq_len.clear();
 	for (const wm::RefSeq &r : ix.seq) { c->seq_off.push_back(r.offset); c->seq_len.push_back(r.len); }
 	c->hbits = ix.hbits;
-	c->skp.w = ix.w; c->skp.k = ix.k; c->skp.table_bits = (uint32_t)ix.bloom.table_bits; c->skp.salt0 = ix.bloom.salt[0]; c->skp.salt1 = ix.bloom.salt[1];
+	c->skp.w = ix.w; c->skp.k = ix.k; c->skp.table_bits = (uint32_t)ix.bloom.table_bits; c->skp.salt0 = ix.bloom.salt[0]; c->skp.salt1 = ix.bloom.salt[1]; c->skp.hpc = ix.flag & 1;
 	c->have_index = true; c->owns_index = true;
 	return WM_OK;
 }
@@ -1680,7 +1706,7 @@ extern "C" int wm_index_upload_dev(wm_ctx_t *c, const wm_index_t *h, const void 
 	c->seq_off.clear(); c->seq_len.clear();
 	for (const wm::RefSeq &r : ix.seq) { c->seq_off.push_back(r.offset); c->seq_len.push_back(r.len); }
 	c->hbits = ix.hbits;
-	c->skp.w = ix.w; c->skp.k = ix.k; c->skp.table_bits = (uint32_t)ix.bloom.table_bits; c->skp.salt0 = ix.bloom.salt[0]; c->skp.salt1 = ix.bloom.salt[1];
+	c->skp.w = ix.w; c->skp.k = ix.k; c->skp.table_bits = (uint32_t)ix.bloom.table_bits; c->skp.salt0 = ix.bloom.salt[0]; c->skp.salt1 = ix.bloom.salt[1]; c->skp.hpc = ix.flag & 1;
 	c->have_index = true; c->owns_index = true;
 	return WM_OK;
 }
@@ -1811,9 +1837,14 @@ static int wm_index_build_seqs_dev(wm_ctx_t *c, const wm::IdxOpt &io, std::vecto
                                    wm_index_t **out, double *stats = 0, bool replace_ok = true, double t0 = -1);
 extern "C" int wm_index_build_gpu(wm_ctx_t *c, const char *fasta, const char *kmer_file, int k, int w, int n_threads, wm_index_t **out, double *stats)
 {
+	return wm_index_build_gpu_flag(c, fasta, kmer_file, k, w, 0, n_threads, out, stats);
+}
+extern "C" int wm_index_build_gpu_flag(wm_ctx_t *c, const char *fasta, const char *kmer_file, int k, int w, int idx_flag, int n_threads, wm_index_t **out, double *stats)
+{
 	*out = 0;
 	if (!c) return set_err(WM_EINVAL, "null context");
-	wm::IdxOpt io; io.k = k; io.w = w;
+	if (idx_flag & ~1) return set_err(WM_EINVAL, "index flag %d: only MM_I_HPC (1) is known here", idx_flag);
+	wm::IdxOpt io; io.k = k; io.w = w; io.flag = idx_flag;
 	wm::MapOpt mo; std::string err;
 	if (wm::check_opt(io, mo, err) < 0) return set_err(WM_EINVAL, "%s", err.c_str());
 	const double t0 = now_ms();
@@ -1850,7 +1881,7 @@ static int wm_index_build_seqs_dev(wm_ctx_t *c, const wm::IdxOpt &io, std::vecto
 	if (c->owns_filter && c->d_bloom) hipFree(c->d_bloom);
 	c->owns_filter = false;
 	c->d_bloom = d_bloom;
-	c->skp.w = w; c->skp.k = k; c->skp.table_bits = (uint32_t)ix.bloom.table_bits; c->skp.salt0 = ix.bloom.salt[0]; c->skp.salt1 = ix.bloom.salt[1];
+	c->skp.w = w; c->skp.k = k; c->skp.table_bits = (uint32_t)ix.bloom.table_bits; c->skp.salt0 = ix.bloom.salt[0]; c->skp.salt1 = ix.bloom.salt[1]; c->skp.hpc = io.flag & 1;
 	std::vector<wm::m128> all;
 	int rc = WM_OK;
 	const size_t budget = (size_t)(c->arena_bytes * 0.85);
@@ -1906,7 +1937,7 @@ extern "C" int wm_sketch_set_filter(wm_ctx_t *c, const uint8_t *bits, size_t n_b
 	if (c->d_bloom) { hipFree(c->d_bloom); c->d_bloom = 0; }
 	HIPCHK(hipMalloc((void**)&c->d_bloom, n_bytes + 8));
 	HIPCHK(hipMemcpy(c->d_bloom, bits, n_bytes, hipMemcpyHostToDevice));
-	c->skp.w = w; c->skp.k = k; c->skp.table_bits = (uint32_t)table_bits; c->skp.salt0 = salt0; c->skp.salt1 = salt1;
+	c->skp.w = w; c->skp.k = k; c->skp.table_bits = (uint32_t)table_bits; c->skp.salt0 = salt0; c->skp.salt1 = salt1; c->skp.hpc = 0;
 	c->owns_filter = true;
 	return WM_OK;
 }
@@ -1919,8 +1950,9 @@ extern "C" int wm_sketch_batch(wm_ctx_t *c, int n, const uint8_t *seqs, size_t s
 // The one-wavefront-per-sequence sketch of `n` jobs (h_jobs = the host copy of d_jobs) and, for sequences of WM_SKETCH_LONG (65 536) codes and more, the
 // chunked form: WM_SKETCH_CHUNK (16 384) positions per wavefront. allow_long = false (a repeat with full-size slots): everything on one wavefront each.
 // Everything is queued on the context's stream; with long jobs the call waits once (its chunk tables are staged in the pinned slab).
-static int sketch_long_thr(bool allow_long, int *chunk_out)
+static int sketch_long_thr(bool allow_long, int *chunk_out, bool hpc = false)
 {
+	if (hpc) { *chunk_out = 16384; return 0; }                 // homopolymer compression: every sequence on one wavefront (the chunks would have to be cut in run space)
 	static const int long_env = getenv("WM_SKETCH_LONG") ? atoi(getenv("WM_SKETCH_LONG")) : 65536;
 	static const int chunk = std::max(1024, getenv("WM_SKETCH_CHUNK") ? atoi(getenv("WM_SKETCH_CHUNK")) : 16384);
 	*chunk_out = chunk;
@@ -1928,11 +1960,16 @@ static int sketch_long_thr(bool allow_long, int *chunk_out)
 }
 // device bytes sketch_launch needs on top of the caller's buffers (chunk tables + chunk-local output slots): a caller that hands the rest of the arena to
 // something else (window_launch: the anchor pool) reserves them first and passes the block in
-static size_t sketch_long_bytes(int n, const wm_sketch_job_t *h_jobs, bool allow_long)
+static size_t sketch_long_bytes(int n, const wm_sketch_job_t *h_jobs, bool allow_long, bool hpc = false)
 {
 	int chunk = 0;
-	const int long_thr = sketch_long_thr(allow_long, &chunk);
+	const int long_thr = sketch_long_thr(allow_long, &chunk, hpc);
 	size_t bytes = 0;
+	if (hpc) {                                                  // the compacted sequences: a code and an end position per base at most
+		uint64_t slots = 0;
+		for (int i = 0; i < n; ++i) if (h_jobs[i].len > 0) slots = std::max<uint64_t>(slots, h_jobs[i].scratch_off + (uint64_t)h_jobs[i].len);
+		return (size_t)(slots + 1) * 5 + 4096;
+	}
 	if (long_thr > 0)
 		for (int i = 0; i < n; ++i)
 			if (h_jobs[i].len >= long_thr) {
@@ -1945,7 +1982,8 @@ static int sketch_launch(wm_ctx_t *c, int n, const wm_sketch_job_t *h_jobs, cons
                          double *d_so, uint64_t *d_sx, uint32_t *d_sy, uint32_t *d_sl, wm128_t *d_out, int *d_cnt, bool allow_long, uint8_t *mem = 0, size_t mem_bytes = 0)
 {
 	int chunk = 0;
-	const int long_thr = sketch_long_thr(allow_long, &chunk);
+	const bool hpc = c->skp.hpc != 0;
+	const int long_thr = sketch_long_thr(allow_long, &chunk, hpc);
 	size_t mem_used = 0;
 	auto take = [&](size_t bytes) -> void* {                   // from the caller's block if there is one, else from the arena
 		if (!mem) return arena_take(c, bytes);
@@ -1959,7 +1997,15 @@ static int sketch_launch(wm_ctx_t *c, int n, const wm_sketch_job_t *h_jobs, cons
 	if (long_thr > 0)
 		for (int i = 0; i < n; ++i)
 			if (h_jobs[i].len >= long_thr) { const int k = (h_jobs[i].len + chunk - 1) / chunk; lj.push_back(i); lj.push_back((int)n_ch); lj.push_back(k); n_ch += (size_t)k; }
-	hipLaunchKernelGGL(sketch_coop_kernel, dim3(n), dim3(64), 0, c->stream, c->skp, d_jobs, d_ord, d_seqs, c->d_bloom, d_so, d_sx, d_sy, d_sl, d_out, d_cnt, long_thr);
+	uint8_t *d_hc = 0; uint32_t *d_he = 0;
+	if (hpc) {
+		uint64_t slots = 0;
+		for (int i = 0; i < n; ++i) if (h_jobs[i].len > 0) slots = std::max<uint64_t>(slots, h_jobs[i].scratch_off + (uint64_t)h_jobs[i].len);
+		d_he = (uint32_t*)take((size_t)(slots + 1) * 4); d_hc = (uint8_t*)take((size_t)slots + 1);
+		if (!d_he || !d_hc) return set_err(WM_ENOMEM, "sketch batch does not fit the arena (homopolymer-compressed copies)");
+	}
+	hipLaunchKernelGGL(sketch_coop_kernel, dim3(n), dim3(64), 0, c->stream, c->skp, d_jobs, d_ord, d_seqs, c->d_reads, c->d_reads_nm, c->d_bloom, d_so, d_sx, d_sy, d_sl, d_out, d_cnt, long_thr,
+	                   d_hc, d_he);
 	if (lj.empty()) return WM_OK;
 	UBuf<wm_sk_chunk_t> ch(n_ch, c);
 	UBuf<int> plj(lj.size(), c);
@@ -1980,7 +2026,7 @@ static int sketch_launch(wm_ctx_t *c, int n, const wm_sketch_job_t *h_jobs, cons
 	if (!d_ch || !d_lj || !d_sync || !d_cc || !d_cout) return set_err(WM_ENOMEM, "sketch batch does not fit the arena");
 	HIPCHK(hipMemcpyAsync(d_ch, ch.data(), n_ch * sizeof(wm_sk_chunk_t), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipMemcpyAsync(d_lj, plj.data(), lj.size() * 4, hipMemcpyHostToDevice, c->stream));
-	hipLaunchKernelGGL(sketch_long_p1_kernel, dim3((unsigned)n_ch), dim3(64), 0, c->stream, c->skp, d_jobs, d_ch, d_seqs, c->d_bloom, d_so, d_sx, d_sy, d_sl);
+	hipLaunchKernelGGL(sketch_long_p1_kernel, dim3((unsigned)n_ch), dim3(64), 0, c->stream, c->skp, d_jobs, d_ch, d_seqs, c->d_reads, c->d_reads_nm, c->d_bloom, d_so, d_sx, d_sy, d_sl);
 	hipLaunchKernelGGL(sketch_long_sync_kernel, dim3((unsigned)n_ch), dim3(64), 0, c->stream, c->skp, d_jobs, d_ch, d_so, d_sync);
 	hipLaunchKernelGGL(sketch_long_p2_kernel, dim3((unsigned)n_ch), dim3(64), 0, c->stream, c->skp, d_jobs, d_ch, (int)n_ch, d_so, d_sx, d_sy, d_sl, d_sync, d_cout, d_cc);
 	hipLaunchKernelGGL(sketch_long_gather_kernel, dim3((unsigned)(lj.size() / 3)), dim3(64), 0, c->stream, d_jobs, d_lj, d_ch, d_cout, d_cc, d_out, d_cnt);
@@ -2010,18 +2056,17 @@ try {
 		uint64_t tot = 0;
 		wm_sketch_job_t *d_jobs = (wm_sketch_job_t*)arena_take(c, jb.size() * sizeof(wm_sketch_job_t));
 		uint8_t *d_seqs = (uint8_t*)arena_take(c, seqs_bytes + 64);
-		// one base pointer for the kernel (the staged slab); resident sequences are addressed relative to it
-		const uint64_t res_delta = resident && d_seqs ? (uint64_t)((uintptr_t)c->d_reads - (uintptr_t)d_seqs) : 0;
 		// odd k (every preset): one wavefront per sequence walking the chain of window minima (sketch_coop); even k: the palindrome rule
 		// of src/sketch.c:166 makes the slot stream data dependent -> the one-lane-per-sequence automaton (sketch_wave). WM_SKETCH_LANE=1 forces the latter.
 		static const bool force_lane = getenv("WM_SKETCH_LANE") != 0;
 		const bool coop = (c->skp.k & 1) && c->skp.k >= 2 && !force_lane;
+		if (c->skp.hpc && !coop) return set_err(WM_EINVAL, "homopolymer compression on the device needs an odd k (got %d)", c->skp.k);
 		uint64_t slots = 0;
 		for (size_t t = 0; t < todo.size(); ++t) {
 			const int i = todo[t];
 			const bool res = resident && resident[i];
 			if (res ? (seq_off[i] + (uint64_t)len[i] > c->reads_bytes || !c->d_reads) : (seq_off[i] + (uint64_t)len[i] > seqs_bytes)) return set_err(WM_EINVAL, "sequence %d outside its buffer", i);
-			jb[t].seq_off = res ? res_delta + seq_off[i] : seq_off[i]; jb[t].len = len[i];
+			jb[t].seq_off = res ? (WM_RD_PACKED_BIT | seq_off[i]) : seq_off[i]; jb[t].len = len[i];      // (resident: a base index into the packed reads, reads2bit.h)
 			jb[t].cap = round == 0 ? len[i] / 8 + 16 : len[i] + 1;
 			jb[t].out_off = tot; tot += jb[t].cap;
 			jb[t].scratch_off = slots; slots += (uint64_t)(len[i] > 0 ? len[i] : 0);
@@ -2046,7 +2091,7 @@ try {
 			if (const int rc = sketch_launch(c, (int)jb.size(), jb.data(), d_jobs, d_ord, d_seqs, d_so, d_sx, d_sy, d_sl, d_out, d_cnt, round == 0)) return rc;
 		} else {
 			HIPCHK(hipEventRecord(c->ev[0], c->stream));
-			hipLaunchKernelGGL(sketch_kernel, dim3(((int)jb.size() + 63) / 64), dim3(64), lds, c->stream, c->skp, d_jobs, (int)jb.size(), d_seqs, c->d_bloom, d_out, d_cnt);
+			hipLaunchKernelGGL(sketch_kernel, dim3(((int)jb.size() + 63) / 64), dim3(64), lds, c->stream, c->skp, d_jobs, (int)jb.size(), d_seqs, c->d_reads, c->d_reads_nm, c->d_bloom, d_out, d_cnt);
 		}
 		HIPCHK(hipEventRecord(c->ev[1], c->stream));
 		UBuf<int> cnt(jb.size() + 1, c);
@@ -2537,7 +2582,7 @@ static int window_launch(wm_ctx_t *c, int n, const wm_window_job_t *jobs, const 
 		return set_err(WM_ENOMEM, "window batch does not fit the arena");
 	int *d_counts = (int*)(d_ctr + 4);
 	D.d_ctr = d_ctr;
-	const size_t long_bytes = sketch_long_bytes(n, sj.data(), !slot_full);       // chunked sketch of long sequences: its tables come before the pool takes the rest
+	const size_t long_bytes = sketch_long_bytes(n, sj.data(), !slot_full, c->skp.hpc != 0);       // chunked sketch of long sequences: its tables come before the pool takes the rest
 	uint8_t *d_long = long_bytes ? (uint8_t*)arena_take(c, long_bytes) : 0;
 	if (long_bytes && !d_long) return set_err(WM_ENOMEM, "window batch does not fit the arena");
 	// the rest of the arena is the anchor pool: 72 B per anchor (anchors 16, f|p|v|t 16, z/u 8, b 16, w 16) + the two dense result pools (24)
@@ -2555,9 +2600,8 @@ static int window_launch(wm_ctx_t *c, int n, const wm_window_job_t *jobs, const 
 	HIPCHK(hipMemcpyAsync(d_ord, ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
 	if (stage_hi) HIPCHK(hipMemcpyAsync(d_seqs, seqs, stage_hi, hipMemcpyHostToDevice, c->stream));
 	if (pre_hi) HIPCHK(hipMemcpyAsync(d_pre, pre, pre_hi * sizeof(wm128_t), hipMemcpyHostToDevice, c->stream));
-	// sequences are addressed relative to the staged slab (one base pointer for the sketch kernel): resident ones through the pointer difference
-	const uint64_t res_delta = c->d_reads ? (uint64_t)((uintptr_t)c->d_reads - (uintptr_t)d_seqs) : 0;
-	for (int i = 0; i < n; ++i) if (sj[i].len > 0) sj[i].seq_off = jobs[i].seq_off >= 0 ? res_delta + (uint64_t)jobs[i].seq_off : jobs[i].stage_off;
+	// staged sequences: byte offsets into d_seqs; resident ones: base indices into the packed reads, flagged (reads2bit.h)
+	for (int i = 0; i < n; ++i) if (sj[i].len > 0) sj[i].seq_off = jobs[i].seq_off >= 0 ? (WM_RD_PACKED_BIT | (uint64_t)jobs[i].seq_off) : jobs[i].stage_off;
 	HIPCHK(hipMemcpyAsync(d_sj, sj.data(), (size_t)n * sizeof(wm_sketch_job_t), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipMemsetAsync(D.d_res, 0, (size_t)n * sizeof(wm_win_res_t), c->stream));
 	HIPCHK(hipMemsetAsync(d_ctr, 0, 64, c->stream));
@@ -2964,7 +3008,12 @@ struct GpuOps {                          // the device contexts of a mapper, sha
 	// allocation of WM_MAX_SLOTS slabs, owned by the first context and aliased by the others (one device); a call's offsets start at slot * slab.
 	std::mutex reads_mu;
 	hipStream_t up_stream = 0;                  // uploads of the mini-batches' read codes
-	~GpuOps() { if (up_stream) hipStreamDestroy(up_stream); }
+	uint64_t *stage[WM_MAX_SLOTS] = { 0 }; size_t stage_words[WM_MAX_SLOTS] = { 0 }; bool stage_pinned[WM_MAX_SLOTS] = { false };      // host staging of the packed codes, per slot
+	~GpuOps()
+	{
+		if (up_stream) hipStreamDestroy(up_stream);
+		for (int i = 0; i < WM_MAX_SLOTS; ++i) if (stage[i]) { if (stage_pinned[i]) hipHostFree(stage[i]); else free(stage[i]); }
+	}
 	size_t slab = 0;
 	int n_slabs = 0;
 	bool slot_busy[WM_MAX_SLOTS] = { false };
@@ -2976,7 +3025,7 @@ struct GpuOps {                          // the device contexts of a mapper, sha
 		wm_ctx_t *c0 = ctxs[0].c;
 		std::lock_guard<std::mutex> lk(reads_mu);
 		if (hipSetDevice(c0->device) != hipSuccess) return false;
-		if (n + 64 > slab || slot >= n_slabs || !c0->d_reads || !c0->owns_reads) {
+		if (n + 256 > slab || slot >= n_slabs || !c0->d_reads || !c0->owns_reads) {
 			for (int o = 0; o < WM_MAX_SLOTS; ++o) if (o != slot && slot_busy[o]) return false;      // another mini-batch lives in the allocation: this one is served from its host views
 			if (c0->d_reads && c0->owns_reads) hipFree(c0->d_reads);
 			c0->d_reads = 0; c0->owns_reads = false; slab = 0;
@@ -2985,18 +3034,43 @@ struct GpuOps {                          // the device contexts of a mapper, sha
 			// allocated whatever the caller used — 4.5 GB for 1-Gbase mini-batches); a call on a slot beyond them is served from its host views
 			n_slabs = std::max(2, std::min((int)WM_MAX_SLOTS, getenv("WM_READ_SLABS") ? atoi(getenv("WM_READ_SLABS")) : getenv("WM_MAP_LANES") ? atoi(getenv("WM_MAP_LANES")) : 2));
 			if (slot >= n_slabs) n_slabs = slot + 1;
-			if (hipMalloc((void**)&c0->d_reads, (size_t)n_slabs * want) != hipSuccess) { (void)hipGetLastError(); c0->d_reads = 0; return false; }
-			c0->owns_reads = true; c0->reads_cap = (size_t)n_slabs * want; c0->reads_bytes = (size_t)n_slabs * want; slab = want;
+			if (reads_alloc(c0, (size_t)n_slabs * want) != WM_OK) return false;              // (bases: 2 bits + 1 ambiguity bit each, reads2bit.h)
+			c0->owns_reads = true; c0->reads_bytes = (size_t)n_slabs * want; slab = want;
 			for (size_t i = 1; i < ctxs.size(); ++i) {
 				wm_ctx_t *c = ctxs[i].c;
 				if (c->owns_reads && c->d_reads) hipFree(c->d_reads);
-				c->d_reads = c0->d_reads; c->reads_bytes = c0->reads_bytes; c->reads_cap = 0; c->owns_reads = false;
+				c->d_reads = c0->d_reads; c->d_reads_nm = c0->d_reads_nm; c->reads_bytes = c0->reads_bytes; c->reads_cap = 0; c->owns_reads = false;
 			}
+		}
+		// the mini-batch's codes are packed on the host — 2 bits per base + 1 ambiguity bit, 0.375 B per base across PCIe instead of one byte — into this slot's
+		// pinned staging buffer, by a few threads over disjoint 64-base-aligned ranges (slab is a multiple of 256 bases: the slot's words are its own)
+		const size_t pkw = wm_pk_words(n), nmw = wm_nm_words(n);
+		if (stage_words[slot] < pkw + nmw) {
+			if (stage[slot]) { if (stage_pinned[slot]) hipHostFree(stage[slot]); else free(stage[slot]); }
+			stage[slot] = 0; stage_words[slot] = 0;
+			const size_t want_w = pkw + nmw + (pkw + nmw) / 8 + 1024;
+			stage_pinned[slot] = hipHostMalloc((void**)&stage[slot], want_w * 8, hipHostMallocDefault) == hipSuccess;
+			if (!stage_pinned[slot]) { (void)hipGetLastError(); stage[slot] = (uint64_t*)malloc(want_w * 8); }
+			if (!stage[slot]) { err = "no host memory for the packed reads"; return false; }
+			stage_words[slot] = want_w;
+		}
+		uint64_t *h_pk = stage[slot], *h_nm = stage[slot] + pkw;
+		{
+			const size_t CH = (size_t)1 << 22;                     // bases per range (a multiple of 64)
+			const size_t n_ch = (n + CH - 1) / CH;
+			const int nt = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(8, (size_t)wm::usable_cores()), n_ch));
+			wm::parallel_for(nt, n_ch, [&](size_t ci) { const size_t at = ci * CH, len = std::min(CH, n - at); wm_pack_blocks(codes + at, len, h_pk + at / 32, h_nm + at / 64); });
+			for (size_t i = 2 * ((n + 63) / 64); i < pkw; ++i) h_pk[i] = 0;
+			for (size_t i = (n + 63) / 64; i < nmw; ++i) h_nm[i] = 0;
 		}
 		// (a stream of its own, not the NULL stream: a NULL-stream copy waits for every blocking stream of the device and makes them wait for it)
 		if (!up_stream && hipStreamCreateWithFlags(&up_stream, hipStreamNonBlocking) != hipSuccess) { up_stream = 0; (void)hipGetLastError(); }
-		if (n && (up_stream ? (hipMemcpyAsync(c0->d_reads + (size_t)slot * slab, codes, n, hipMemcpyHostToDevice, up_stream) != hipSuccess || hipStreamSynchronize(up_stream) != hipSuccess)
-		                    : hipMemcpy(c0->d_reads + (size_t)slot * slab, codes, n, hipMemcpyHostToDevice) != hipSuccess)) { err = std::string("reads upload: ") + hipGetErrorString(hipGetLastError()); return false; }
+		uint64_t *d_pk = c0->d_reads + (size_t)slot * slab / 32, *d_nm = c0->d_reads_nm + (size_t)slot * slab / 64;
+		if (n && (up_stream ? (hipMemcpyAsync(d_pk, h_pk, pkw * 8, hipMemcpyHostToDevice, up_stream) != hipSuccess || hipMemcpyAsync(d_nm, h_nm, nmw * 8, hipMemcpyHostToDevice, up_stream) != hipSuccess ||
+		                       hipStreamSynchronize(up_stream) != hipSuccess)
+		                    : (hipMemcpy(d_pk, h_pk, pkw * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_nm, h_nm, nmw * 8, hipMemcpyHostToDevice) != hipSuccess))) {
+			err = std::string("reads upload: ") + hipGetErrorString(hipGetLastError()); return false;
+		}
 		for (GpuOpsCtx &x : ctxs) x.resident = true;
 		slot_busy[slot] = true;
 		*base = (int64_t)((size_t)slot * slab);
@@ -3079,12 +3153,12 @@ struct wm_mapper_s {
 	std::vector<std::string> cmdline;      // argv of the front end, for the @PG line of SAM files (wm_mapper_set_cmdline)
 };
 
-// what the mapper's device path cannot serve is refused when the mapper is made, not in the middle of a mapping call: an index built with
-// homopolymer compression (MM_I_HPC = 1, -H: src/sketch.c:152-163 is not implemented by the device sketch — silently sketching the reads without it
-// would seed nothing) and even k (the fused window call sketches with sketch_coop, which relies on k-mer != reverse complement, src/sketch.c:189)
+// what the mapper's device path cannot serve is refused when the mapper is made, not in the middle of a mapping call: an even k (the fused
+// window call sketches with sketch_coop, which relies on k-mer != reverse complement, src/sketch.c:189). An index built with homopolymer compression
+// (MM_I_HPC, -H) is served since round 5: sketch_coop compacts every sequence into its runs first (src/sketch.c:152-163), mm_adjust_minier's HPC branch
+// (src/align.c:352-361) runs on the host.
 static int mapper_index_ok(const wm_index_t *idx)
 {
-	if (idx->ix.flag & 1) return set_err(WM_EINVAL, "the index was built with homopolymer compression (-H, MM_I_HPC): not supported by the device path");
 	if (!(idx->ix.k & 1)) return set_err(WM_EINVAL, "k = %d: the mapper's device path needs an odd k (every preset of the reference has one)", idx->ix.k);
 	return WM_OK;
 }

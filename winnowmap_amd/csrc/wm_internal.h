@@ -41,6 +41,7 @@ typedef struct {
 	int32_t w, k;
 	uint32_t table_bits;  // bloom geometry (0 bits never happens: the reference always allocates >= 14384)
 	uint32_t salt0, salt1;
+	int32_t hpc;          // homopolymer compression (MM_I_HPC, src/sketch.c:152-163): sketch_coop compacts a sequence into its runs first
 } wm_sketch_params_t;
 
 // ---- seed lookup (collect_matches + expansion of collect_seed_hits, src/map.c:97-130, 222-251) ----

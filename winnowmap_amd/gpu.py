@@ -361,24 +361,25 @@ class SplitRun:
 class Index:
     """Reference index (host build, mm_idx_gen semantics); `upload(ctx)` copies the flat arrays to HBM."""
 
-    def __init__(self, fasta=None, kmer_file=None, k=15, w=50, n_threads=8, _handle=None):
+    def __init__(self, fasta=None, kmer_file=None, k=15, w=50, n_threads=8, _handle=None, hpc=False):
         L = lib()
         _bind_map(L)
         self._h = C.c_void_p()
         if _handle is not None:
             self._h = _handle
             return
-        _chk(L.wm_index_build(os.fsencode(fasta), os.fsencode(kmer_file) if kmer_file else None, k, w, n_threads, C.byref(self._h)))
+        L.wm_index_build_flag.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        _chk(L.wm_index_build_flag(os.fsencode(fasta), os.fsencode(kmer_file) if kmer_file else None, k, w, 1 if hpc else 0, n_threads, C.byref(self._h)))      # hpc: MM_I_HPC (-H)
 
     @staticmethod
-    def build_on_device(ctx, fasta, kmer_file=None, k=15, w=50, n_threads=8):
-        """wm_index_build_gpu: the reference is sketched on the device (one wavefront per contig). Returns (Index, stats dict)."""
+    def build_on_device(ctx, fasta, kmer_file=None, k=15, w=50, n_threads=8, hpc=False):
+        """wm_index_build_gpu[_flag]: the reference is sketched on the device (one wavefront per contig). Returns (Index, stats dict)."""
         L = lib()
         _bind_map(L)
-        L.wm_index_build_gpu.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]
+        L.wm_index_build_gpu_flag.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]
         h = C.c_void_p()
         st = np.zeros(4, np.float64)
-        _chk(L.wm_index_build_gpu(ctx._h, os.fsencode(fasta), os.fsencode(kmer_file) if kmer_file else None, k, w, n_threads, C.byref(h), st.ctypes.data))
+        _chk(L.wm_index_build_gpu_flag(ctx._h, os.fsencode(fasta), os.fsencode(kmer_file) if kmer_file else None, k, w, 1 if hpc else 0, n_threads, C.byref(h), st.ctypes.data))
         L.wm_last_aux_ms.restype = C.c_float
         L.wm_last_aux_ms.argtypes = [C.c_void_p]
         return Index(_handle=h), {"read_pack_s": float(st[0]), "device_sketch_s": float(st[1]), "table_s": float(st[2]), "minimizers": int(st[3]),
