@@ -24,16 +24,20 @@ struct OracleOps : DeviceOps {
 	// "resident" data like the device implementation keeps it: the batch's read codes (and the index's packed reference). Requests are
 	// served from their host views; the resident positions they carry are decoded as well and must give the same bytes.
 	// (kept the way the device keeps them: 2 bits per base + an ambiguity bitmap, packed by the product's wm_pack_codes — csrc/reads2bit.h)
-	std::vector<uint64_t> rd_pk, rd_nm; size_t rd_n = 0;
+	// One slab per slot, like the device's (two mapping calls may be in flight on one ops object: wm_map_file's lanes); a call's offsets start at slot * SLAB.
+	static constexpr int64_t SLAB = (int64_t)1 << 40;
+	std::vector<uint64_t> rd_pk[4], rd_nm[4]; size_t rd_n[4] = { 0, 0, 0, 0 };
 	std::atomic<long> n_pos_checked{0}, n_pos_bad{0};
-	bool load_reads(const uint8_t *codes, size_t n, int, int64_t *base) override
+	bool load_reads(const uint8_t *codes, size_t n, int slot, int64_t *base) override
 	{
-		rd_pk.assign(wm_pk_words(n), ~0ULL); rd_nm.assign(wm_nm_words(n), ~0ULL);
-		wm_pack_codes(codes, n, rd_pk.data(), rd_nm.data());
-		rd_n = n; *base = 0;
+		if (slot < 0 || slot >= 4) { *base = 0; return false; }
+		rd_pk[slot].assign(wm_pk_words(n), ~0ULL); rd_nm[slot].assign(wm_nm_words(n), ~0ULL);
+		wm_pack_codes(codes, n, rd_pk[slot].data(), rd_nm[slot].data());
+		rd_n[slot] = n; *base = (int64_t)slot * SLAB;
 		return true;
 	}
-	uint8_t rd_at(int64_t p) const { return (uint8_t)wm_rd_code(rd_pk.data(), rd_nm.data(), (uint64_t)p); }
+	bool rd_in(int64_t p, int64_t len) const { const int64_t sl = p / SLAB, o = p % SLAB; return p >= 0 && sl < 4 && (size_t)(o + len) <= rd_n[sl]; }
+	uint8_t rd_at(int64_t p) const { const int64_t sl = p / SLAB; return (uint8_t)wm_rd_code(rd_pk[sl].data(), rd_nm[sl].data(), (uint64_t)(p % SLAB)); }
 	uint8_t two_strand(const KswReq &r, int64_t p) const
 	{   // KswReq: [0,L) forward strand, [L,2L) reverse complement, negative = N padding
 		const int64_t L = r.qwin_len;
@@ -58,7 +62,7 @@ struct OracleOps : DeviceOps {
 	void sketch_batch(int w, int k, std::vector<SketchReq*> &reqs) override
 	{
 		for (SketchReq *r : reqs) {
-			if (r->dev_off >= 0) { ++n_pos_checked; bool bad = (size_t)r->dev_off + r->len > rd_n; for (int64_t t = 0; !bad && t < r->len; ++t) bad = rd_at(r->dev_off + t) != r->seq[t]; if (bad) ++n_pos_bad; }
+			if (r->dev_off >= 0) { ++n_pos_checked; bool bad = !rd_in(r->dev_off, r->len); for (int64_t t = 0; !bad && t < r->len; ++t) bad = rd_at(r->dev_off + t) != r->seq[t]; if (bad) ++n_pos_bad; }
 			std::vector<uint64_t> x(r->len + 8), y(r->len + 8);
 			int64_t n = (idx->flag & 1 ? wmo_sketch_hpc : wmo_sketch)((const char*)r->seq, r->len, w, k, 0, bloom, x.data(), y.data(), r->len + 8);
 			r->mini.resize(n);

@@ -237,7 +237,6 @@ int SplitRun::add_part(const std::vector<RefSeq> &contigs, const std::function<i
 	std::unique_ptr<HitSpill> sp(new HitSpill());
 	if (!sp->open(err)) return -1;
 	HitSpill &spill = *sp;
-	const int j = (int)p_->spill.size();
 	FileStats fs;
 	const int rc = map_file_id(p_->reads_path, p_->mini_batch_bases, p_->with_qual, [&](std::vector<ReadIn> &batch, std::string &, int lane, uint64_t id) {
 		std::vector<ReadOut> o;
@@ -246,7 +245,6 @@ int SplitRun::add_part(const std::vector<RefSeq> &contigs, const std::function<i
 		return spill.put(id, o) ? 0 : -1;
 	}, 0, &fs, err);
 	if (rc) { if (err.empty() || err == "mapping failed") err = spill.error.empty() ? err : spill.error; return rc; }
-	(void)j;
 	p_->fs_all.t_read += fs.t_read; p_->fs_all.t_map += fs.t_map;
 	for (const RefSeq &r : contigs) p_->dict.seq.push_back(r);
 	p_->n_seq.push_back((int)contigs.size());

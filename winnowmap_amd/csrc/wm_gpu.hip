@@ -1887,8 +1887,9 @@ static int wm_index_build_seqs_dev(wm_ctx_t *c, const wm::IdxOpt &io, std::vecto
 	const size_t budget = (size_t)(c->arena_bytes * 0.85);
 	for (size_t g0 = 0; g0 < seqs.size() && rc == WM_OK;) {             // groups of contigs that fit the arena: 1 B codes + 24 B scratch + 2 B output + 4 B chunk-local output (+ tables) per base
 		size_t g1 = g0, bases = 0;
-		while (g1 < seqs.size() && (g1 == g0 || (bases + seqs[g1].size()) * 34 + 4096 * (g1 - g0 + 1) <= budget)) { bases += seqs[g1].size(); ++g1; }
-		if (bases * 34 > budget) { rc = set_err(WM_ENOMEM, "contig %zu (%zu bases) needs %.1f GB of arena for the device sketch", g0, seqs[g0].size(), seqs[g0].size() * 34 / 1073741824.0); break; }
+		const size_t per_base = 34 + ((io.flag & 1) ? 5 : 0);             // (+ the homopolymer-compressed copy: a code and an end position per base)
+		while (g1 < seqs.size() && (g1 == g0 || (bases + seqs[g1].size()) * per_base + 4096 * (g1 - g0 + 1) <= budget)) { bases += seqs[g1].size(); ++g1; }
+		if (bases * per_base > budget) { rc = set_err(WM_ENOMEM, "contig %zu (%zu bases) needs %.1f GB of arena for the device sketch", g0, seqs[g0].size(), seqs[g0].size() * per_base / 1073741824.0); break; }
 		const int n = (int)(g1 - g0);
 		std::vector<uint64_t> off(n), ooff(n);
 		std::vector<int32_t> len(n), cnt(n);
@@ -3573,9 +3574,10 @@ extern "C" int wm_split_add_part(wm_split_t *s, wm_index_t *part)
 	if (!s || !part) return set_err(WM_EINVAL, "null argument");
 	if (part->ix.k != s->k || part->ix.w != s->w) return set_err(WM_EINVAL, "index part built with k = %d, w = %d; the run was started for k = %d, w = %d", part->ix.k, part->ix.w, s->k, s->w);
 	wm_mapper_t *m = 0;
-	if (wm_index_upload(s->c, part)) return WM_EINVAL;
-	if (wm_mapper_create_opt(s->c, part, &s->copt, &m)) return WM_EINVAL;
-	if (wm_mapper_set_threads(m, s->n_threads, 0)) { wm_mapper_destroy(m); return WM_EINVAL; }
+	int rc0;
+	if ((rc0 = wm_index_upload(s->c, part)) != WM_OK) return rc0;                       // (the message is the failing call's)
+	if ((rc0 = wm_mapper_create_opt(s->c, part, &s->copt, &m)) != WM_OK) return rc0;
+	if ((rc0 = wm_mapper_set_threads(m, s->n_threads, 0)) != WM_OK) { wm_mapper_destroy(m); return rc0; }
 	LaneError le;
 	std::string err;
 	const int rc = s->run->add_part(part->ix.seq, [&](std::vector<wm::ReadIn> &batch, std::vector<wm::ReadOut> &o, int lane) -> int { const int r = map_reads_raw(m, batch, o, lane); if (r) le.keep(r); return r; }, err);
