@@ -23,12 +23,19 @@ CASES = {
     "ont_short": ("map-ont", 33, 1, 300000, 0.0, 34, 16, 6000, "ont", 0.0, False),
     "hifi": ("map-pb", 35, 2, 300000, 0.1, 36, 10, 20000, "hifi", 0.2, True),
     "asm20": ("asm20", 37, 1, 600000, 0.05, 38, 3, 80000, "hifi", 0.3, False),
+    "ont_hpc": ("map-ont", 41, 1, 300000, 0.05, 42, 14, 9000, "ont", 0.15, True),      # -H: homopolymer-compressed index (IDX_FLAG), runs planted in the reference
 }
+IDX_FLAG = {"ont_hpc": 1}      # mm_idxopt_t::flag of the case's index (MM_I_HPC = 1, the CLI's -H); 0 where absent
 
 
 def inputs(name, tmpdir):
     preset, rs, nc, cl, rf, qs, nr, rl, prof, sv, use_w = CASES[name]
     ref = synth.make_reference(nc, cl, rs, repeat_frac=rf)
+    if IDX_FLAG.get(name, 0) & 1:               # homopolymer runs of 4 .. 280 bases every 2.5 kb: what -H is about
+        rng = np.random.default_rng(rs + 1000)
+        for c in ref:
+            for p in range(1200, len(c) - 1500, 2500):
+                c[p:p + int(rng.choice([4, 8, 17, 40, 280]))] = int(rng.integers(0, 4))
     fa = os.path.join(tmpdir, name + ".fa")
     synth.write_fasta(fa, ref)
     k = 19 if preset.startswith("asm") else 15
@@ -43,10 +50,12 @@ def inputs(name, tmpdir):
 
 def main():
     R = W.ref()
+    R.refshim_idx_build_flag.restype = C.c_void_p
+    R.refshim_idx_build_flag.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
     tmp = tempfile.mkdtemp()
-    for name in CASES:
+    for name in (sys.argv[1:] or CASES):          # (python make_golden.py [case ...]: only the named fixtures are rewritten)
         preset, fa, kf, k, reads = inputs(name, tmp)
-        mi = R.refshim_idx_build(fa.encode(), (kf or "").encode(), k, 50, 4)
+        mi = R.refshim_idx_build_flag(fa.encode(), (kf or "").encode(), k, 50, IDX_FLAG.get(name, 0), 4)
         opt = R.refshim_mapopt(preset.encode(), 0x4 | 0x20, mi)
         hits, cigs, first = [], [], [0]
         for i, s in enumerate(reads):

@@ -20,7 +20,7 @@ def ctx():
 def test_mapper_matches_reference_golden(ctx, name):
     tmp = tempfile.mkdtemp()
     preset, fa, kf, k, reads = E.make_golden.inputs(name, tmp)
-    idx = gpu.Index(fa, kf, k=k, w=50, n_threads=8)
+    idx = gpu.Index(fa, kf, k=k, w=50, n_threads=8, hpc=bool(E.make_golden.IDX_FLAG.get(name, 0) & 1))      # (ont_hpc: the CLI's -H)
     idx.upload(ctx)
     m = gpu.Mapper(ctx, idx, preset, gpu.MM_F_CIGAR | gpu.MM_F_OUT_CG)
     text, hits, cigars, first = m.map(["read%d" % i for i in range(len(reads))], reads)
