@@ -180,7 +180,8 @@ int wm_index_build_gpu(wm_ctx_t *ctx, const char *fasta, const char *kmer_file, 
  * compressed sequence (src/sketch.c:152-163: a run of one base is one step, a minimizer sits on the last base of its last run and carries the summed length
  * of its k runs as span); a mapper on such an index sketches its reads the same way (the device sketch compacts every sequence into its runs first, needs
  * an odd k) and anchors are moved to the start of their runs before alignment (mm_adjust_minier, src/align.c:352-361). An index loaded from a file carries
- * its flag in the header. */
+ * its flag in the header. With -H the device build keeps every contig on ONE wavefront (the chunked sketch cuts in base space, the runs would have to be cut in
+ * run space): for references with contigs of tens of Mb the host build (parallel per contig) is the faster of the two. */
 int wm_index_build_flag(const char *fasta, const char *kmer_file, int k, int w, int idx_flag, int n_threads, wm_index_t **out);
 int wm_index_build_gpu_flag(wm_ctx_t *ctx, const char *fasta, const char *kmer_file, int k, int w, int idx_flag, int n_threads, wm_index_t **out, double *stats);
 void wm_index_destroy(wm_index_t *idx);
