@@ -503,10 +503,11 @@ def main():
                     t2 = time.time()
                     ours, _, _, _ = mapper.map(bn, bs, copy_text=True)
                     with open(ref_paf, "rb") as f:
-                        d = wmparity.diff_texts(f.read(), ours, sam=False)
+                        d = wmparity.diff_texts(f.read(), ours, sam=False, defined=wmparity.defined_names(bn, mapper.rep_len_defined()))
                     out["parity"] = {"reads": len(bs), "reads_with_hits": d["reads"], "hits": d["hits"], "mismatches": d["mismatches"], "mapq_compared": d["mapq_compared"],
-                                     "compared": "PAF records incl. cg:Z CIGAR and all tags vs winnowmap_ref on the same reads; MAPQ and rl:i masked only for reads of >= 10 000 bases "
-                                                 "(the MCAS path: uninitialised rep_len in the reference, src/map.c:281) — i.e. for every read of this workload; compared below the gate in tests/"}
+                                     "compared": "PAF records incl. cg:Z CIGAR and all tags vs winnowmap_ref on the same reads; MAPQ and rl:i are compared wherever the reference assigns rep_len "
+                                                 "(reads below 10 000 bases; above: the stage-2 rescan, src/map.c:808-813, and the fallback, :859-861) and masked on the pure two-stage "
+                                                 "path, where its rep_len is an uninitialised stack word (src/map.c:281,933)"}
                     if d["examples"]:
                         out["parity"]["examples"] = d["examples"]
                     log("parity: %d reads, %d hits, %d mismatching reads (%.1fs)" % (len(bs), d["hits"], d["mismatches"], time.time() - t2))

@@ -289,6 +289,11 @@ int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, const char *co
  * hide behind the steady state of the others (bench.py maps consecutive steps on WM_BENCH_SLOTS slots, wm_map_file on WM_MAP_LANES lanes; default 2). Results are valid until the next call on that slot. */
 int wm_map_reads_slot(wm_mapper_t *m, int slot, int n, const char *const *names, const char *const *seqs, const int32_t *lens,
                       const char **text, size_t *text_len, const int32_t **hits, const uint32_t **cigars, const int64_t **hit_first);
+/* Per read of the slot's last wm_map_reads[_slot] call: flags[i] = 1 when the mapper assigned rep_len where the reference assigns it before mm_set_mapq
+ * reads it (src/map.c:933) — the rescan of the stretches stage 1 left unmapped (src/map.c:808-813), the fallback to plain mapping (:859-861; every read below
+ * SVawareMinReadLength and all of splice mode) — and 0 on the pure two-stage path, where the reference's rep_len is an uninitialised stack word (src/map.c:281)
+ * and its own MAPQ / rl:i differ from run to run (we use rep_len = 0 there). Lets a parity check compare MAPQ on exactly the reads where it is defined. */
+int wm_map_reads_rep_len_defined(const wm_mapper_t *m, int slot, const uint8_t **flags, size_t *n);
 /* counters of the last wm_map_reads call: [0] super-steps, [1] ksw jobs, [2] chain jobs, [3] seed jobs,
  * [4] sketch jobs, [5] DP cells, [6] ksw kernel us, [7] aux kernel us, [8] read bases */
 /* The file-level loop: replacement of mm_map_file / mm_map_file_frag (src/map.c:1226-1268, src/minimap.h:372-374) for

@@ -303,6 +303,8 @@ void *h_index_load_mmi(const char *path, const char *kmer_file)
 
 // same output layout as refshim_map (oracle/ref_shim.cpp)
 static int64_t g_max_sw_mat = 0, g_flag_clear = 0;
+static thread_local int g_last_rl_defined = 1;
+int h_last_rep_len_defined() { return g_last_rl_defined; }        // of the last h_map call on this thread: did the mapper ASSIGN rep_len where the reference does (src/map.c:808-813, 859-861)
 void h_set_flag_clear(int64_t bits) { g_flag_clear = bits; }     // option bits the h_map* calls that follow clear after the preset (e.g. -uf clears MM_F_SPLICE_REV)
 int h_map(void *hv, const char *preset, int64_t flag_extra, const char *seq, int len, const char *name,
           int32_t *hit_out, int hit_cap, uint32_t *cig_out, int64_t cig_cap, int64_t *n_cig_total, uint64_t *stats_out)
@@ -325,6 +327,7 @@ int h_map(void *hv, const char *preset, int64_t flag_extra, const char *seq, int
 	if (stats_out) { stats_out[0] = st.n_flush; stats_out[1] = st.n_ksw; stats_out[2] = st.n_chain; stats_out[3] = st.n_sketch; }
 	int64_t nc = 0;
 	const std::vector<Reg> &regs = out[0].regs;
+	g_last_rl_defined = out[0].rep_len_defined ? 1 : 0;
 	for (size_t i = 0; i < regs.size() && (int)i < hit_cap; ++i) {
 		const Reg &r = regs[i];
 		int32_t *o = hit_out + 16 * i;

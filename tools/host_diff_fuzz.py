@@ -59,7 +59,7 @@ def run(s0, ns, verbose=True):
             rh = np.zeros(16 * 512, np.int32); rc = np.zeros(8000000, np.uint32); rnc = C.c_int64()
             rn = R.refshim_map(mi, opt, s, len(s), b"q", rh, 512, rc, len(rc), C.byref(rnc))
             a = ho[:16 * max(n, 0)].reshape(-1, 16).copy(); b = rh[:16 * max(rn, 0)].reshape(-1, 16).copy()
-            if preset != "splice" and len(s) >= 10000:          # MCAS path: the reference's MAPQ comes from an uninitialised rep_len (src/map.c:281)
+            if preset != "splice" and len(s) >= 10000 and not H.h_last_rep_len_defined():          # pure MCAS path: the reference's MAPQ comes from an uninitialised rep_len (src/map.c:281); with a rescan (:808-813) or the fallback (:859-861) it is assigned and compared
                 a[:, 6] = 0; b[:, 6] = 0
             else:
                 with_mapq += 1

@@ -150,7 +150,7 @@ void stage2(Scheduler &sch, const Index &idx, const MapOpt &opt, ReadTask &T)
 		o3 = opt;
 		window_and_align(sch, idx, o3, opt.chain_gap_scale, T.codes, T.dev_off, true, T.codes, T.dev_off, L, hash, std::vector<m128>(), &rep_len, S, &frag_gap);
 	} else                                                             // the collected anchors cover the read: chain them as they are
-		window_and_align(sch, idx, o3, opt.chain_gap_scale, 0, -1, false, T.codes, T.dev_off, L, hash, std::move(a), &rep_len, S, &frag_gap);
+		window_and_align(sch, idx, o3, opt.chain_gap_scale, 0, -1, false, T.codes, T.dev_off, L, hash, std::move(a), &rep_len, S, &frag_gap), T.out->rep_len_defined = false;
 	T.out->regs = std::move(S.regs);
 	T.out->rep_len = rep_len;
 	T.out->frag_gap = frag_gap;

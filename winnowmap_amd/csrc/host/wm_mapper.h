@@ -10,7 +10,13 @@
 namespace wm {
 
 struct ReadIn { std::string name, seq, qual, comment; };        // mm_bseq1_t, src/bseq.h
-struct ReadOut { std::vector<Reg> regs; int rep_len = 0, frag_gap = 0; };
+struct ReadOut {
+	std::vector<Reg> regs; int rep_len = 0, frag_gap = 0;
+	// the reference ASSIGNS rep_len before mm_set_mapq reads it (src/map.c:933) only where it re-collects seeds for the whole read: the rescan of the
+	// stretches stage 1 left unmapped (:808-813) and the fallback (:859-861). On the pure-MCAS path (collected anchors cover the read) its rep_len is an
+	// uninitialised stack word (:281) and MAPQ / rl:i are not reproducible by the reference itself; there this flag is false and we use 0.
+	bool rep_len_defined = true;
+};
 
 struct MapStats {
 	uint64_t n_flush = 0, n_ksw = 0, n_chain = 0, n_seed = 0, n_sketch = 0;

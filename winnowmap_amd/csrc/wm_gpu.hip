@@ -3145,7 +3145,7 @@ struct wm_mapper_s {
 	int call_threads() const { return n_threads_cap > 0 && n_threads_cap < n_threads ? n_threads_cap : n_threads; }
 	wm::IdxOpt io; wm::MapOpt mo;
 	// results of the last mapping call per slot (wm_map_reads = slot 0; wm_map_reads_slot: two calls may run concurrently)
-	struct Result { std::string text; std::vector<int32_t> hits; std::vector<uint32_t> cigars; std::vector<int64_t> first; } res[WM_MAX_SLOTS];
+	struct Result { std::string text; std::vector<int32_t> hits; std::vector<uint32_t> cigars; std::vector<int64_t> first; std::vector<uint8_t> rl_defined; } res[WM_MAX_SLOTS];
 	uint64_t stats[9];
 	double host_stats[24] = {0};
 	std::mutex stats_mu;
@@ -3326,6 +3326,16 @@ extern "C" int wm_map_reads_slot(wm_mapper_t *m, int slot, int n, const char *co
 	return WM_OK;
 }
 
+// per read of the slot's last mapping call: 1 = the mapper assigned rep_len where the reference assigns it (src/map.c:808-813 rescan, :859-861 fallback),
+// 0 = the pure-MCAS path, where the reference feeds mm_set_mapq an uninitialised word (src/map.c:281,933) and MAPQ / rl:i are not comparable
+extern "C" int wm_map_reads_rep_len_defined(const wm_mapper_t *m, int slot, const uint8_t **flags, size_t *n)
+{
+	if (!m || slot < 0 || slot >= WM_MAX_SLOTS || !flags) return set_err(WM_EINVAL, "bad argument");
+	*flags = m->res[slot].rl_defined.data();
+	if (n) *n = m->res[slot].rl_defined.size();
+	return WM_OK;
+}
+
 // maps `reads` in the given order; results land in m->text / hits / cigars / first / stats
 static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double tm0, int slot)
 {
@@ -3366,7 +3376,9 @@ static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double
 	// output records (formatted above, per read), laid out in input order
 	std::vector<size_t> toff(n + 1, 0), coff(n + 1, 0);
 	R.first.assign(n + 1, 0);
+	R.rl_defined.resize(n);
 	for (int i = 0; i < n; ++i) {
+		R.rl_defined[i] = out[i].rep_len_defined ? 1 : 0;
 		toff[i + 1] = toff[i] + texts[i].size();
 		R.first[i + 1] = R.first[i] + (int64_t)out[i].regs.size();
 		size_t nc = 0;

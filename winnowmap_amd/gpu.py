@@ -503,6 +503,14 @@ class Mapper:
         ca = np.ctypeslib.as_array(C.cast(cig, C.POINTER(C.c_uint32)), shape=(nc,)).copy() if nc else np.zeros(0, np.uint32)
         return C.string_at(text, tlen.value), ha, ca, fa
 
+    def rep_len_defined(self, slot=0):
+        """uint8 per read of the slot's last map() call: 1 where rep_len (hence MAPQ and rl:i) is defined by the reference itself (wm_map_reads_rep_len_defined)"""
+        L = lib()
+        L.wm_map_reads_rep_len_defined.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        p, n = C.c_void_p(), C.c_size_t()
+        _chk(L.wm_map_reads_rep_len_defined(self._h, slot, C.byref(p), C.byref(n)))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint8)
+
     def stats(self):
         a = np.zeros(9, np.uint64)
         lib().wm_mapper_stats(self._h, a.ctypes.data)

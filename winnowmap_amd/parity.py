@@ -3,7 +3,10 @@ at-scale GPU tests). Compared: every column and tag. MAPQ, `rl:i` and the MAPQ f
 reference maps through its two-stage MCAS procedure — reads of at least `mcas_gate` bases (mm_mapopt_t::SVawareMinReadLength,
 10 000 by default) outside splice mode: there `mm_set_mapq` (/root/reference/src/hit.c:463-508) is fed an uninitialised `rep_len`
 (src/map.c:281, never assigned on that path, read at :933), so the reference does not reproduce the two fields itself. Below the
-gate (src/map.c:859-861 sets rep_len) and in splice mode every field is compared. The @PG header line is never compared. Records
+gate (src/map.c:859-861 sets rep_len) and in splice mode every field is compared. Round 6: ABOVE the gate the reference still assigns rep_len
+for the reads whose stage-1 pass left stretches unmapped (the rescan, src/map.c:808-813) or found nothing (the fallback, :859-861); the mapper
+reports those reads (wm_map_reads_rep_len_defined) and `defined` = their names makes MAPQ / rl:i part of the comparison for them too.
+The @PG header line is never compared. Records
 are grouped by read name, so the two texts may list the reads in different orders (the reference prints a mini-batch longest read
 first, src/map.c:1124-1143); inside a read the order of the records must agree."""
 
@@ -35,14 +38,15 @@ def record_query_len(f, sam):
         return None
 
 
-def mask_record(line, sam, mcas_gate=MCAS_GATE):
+def mask_record(line, sam, mcas_gate=MCAS_GATE, defined=None):
     """One output line with the non-reproducible fields removed; None for header lines that are not compared.
-    mcas_gate: reads at least this long have MAPQ / rl:i masked; None: nothing is masked (splice mode, or MCAS switched off)."""
+    mcas_gate: reads at least this long have MAPQ / rl:i masked; None: nothing is masked (splice mode, or MCAS switched off).
+    defined: names (bytes) of reads at or above the gate whose rep_len the reference assigns: not masked either."""
     if sam and line.startswith(b"@"):
         return None
     f = line.rstrip(b"\n").split(b"\t")
     qlen = record_query_len(f, sam)
-    if mcas_gate is None or (qlen is not None and qlen < mcas_gate):
+    if mcas_gate is None or (qlen is not None and qlen < mcas_gate) or (defined is not None and f[0] in defined):
         return b"\t".join(f)
     if sam:
         if len(f) > 4:
@@ -59,12 +63,12 @@ def mask_record(line, sam, mcas_gate=MCAS_GATE):
     return b"\t".join(out)
 
 
-def group_by_read(text, sam=False, mcas_gate=MCAS_GATE):
+def group_by_read(text, sam=False, mcas_gate=MCAS_GATE, defined=None):
     g = {}
     for line in text.split(b"\n"):
         if not line:
             continue
-        m = mask_record(line, sam, mcas_gate)
+        m = mask_record(line, sam, mcas_gate, defined)
         if m is None:
             continue
         name = m[:m.index(b"\t")] if b"\t" in m else m
@@ -72,11 +76,16 @@ def group_by_read(text, sam=False, mcas_gate=MCAS_GATE):
     return g
 
 
-def diff_texts(ref_text, our_text, sam=False, max_examples=3, mcas_gate=MCAS_GATE):
+def defined_names(names, flags):
+    """the `defined` argument of diff_texts from the read names of a Mapper.map() call and Mapper.rep_len_defined()"""
+    return {(n if isinstance(n, bytes) else n.encode()) for n, f in zip(names, flags) if f}
+
+
+def diff_texts(ref_text, our_text, sam=False, max_examples=3, mcas_gate=MCAS_GATE, defined=None):
     """-> dict(reads, hits, mismatches, mapq_compared, examples): `mismatches` counts reads whose record lists differ in any way;
     `mapq_compared` = records of the reference whose MAPQ (and rl:i) took part in the comparison."""
-    a = group_by_read(ref_text, sam, mcas_gate)
-    b = group_by_read(our_text, sam, mcas_gate)
+    a = group_by_read(ref_text, sam, mcas_gate, defined)
+    b = group_by_read(our_text, sam, mcas_gate, defined)
     mism = 0
     hits = 0
     with_mapq = 0
