@@ -259,8 +259,9 @@ float wm_last_aux_ms(const wm_ctx_t *ctx);
 
 /* ---- the mapper: replacement of kt_for(worker_for) (src/map.c:1164) ---------------------------------- */
 /* PROCESS-WIDE SETTINGS the library makes for the mapper (both are defaults: a value the caller has set wins; WM_NO_PROCESS_DEFAULTS=1 switches both off):
- *  - at load time: GPU_MAX_HW_QUEUES=20 in the environment, unless it is set (the HIP runtime reads it once, when it initialises: a mapper runs 6 device
- *    contexts + 14 side streams and HIP's default of 4 hardware queues would serialise them);
+ *  - by the first wm_ctx_create / wm_device_count of the process (NOT at load time any more: loading the library changes nothing): GPU_MAX_HW_QUEUES=20 in
+ *    the environment, unless it is set — the HIP runtime reads it once, when it initialises, and a mapper runs 6 device contexts + 14 side streams that
+ *    HIP's default of 4 hardware queues would serialise. A host program that has made HIP calls of its own before (torch, say) keeps whatever it had;
  *  - when the first mapper is created: glibc's allocator is told to grow its arenas in 64-MB steps, never to trim them and to serve up to 32 MB from
  *    them (mallopt; WM_MALLOPT=0 or the caller's own MALLOC_TOP_PAD_ / MALLOC_TRIM_THRESHOLD_ / MALLOC_MMAP_THRESHOLD_ win): the mapping calls allocate
  *    and free their per-call tables from dozens of threads, which with the defaults is one mprotect / brk per table (profiles/r04l, r04m). The
@@ -289,6 +290,10 @@ int wm_map_reads(wm_mapper_t *m, int n, const char *const *names, const char *co
  * hide behind the steady state of the others (bench.py maps consecutive steps on WM_BENCH_SLOTS slots, wm_map_file on WM_MAP_LANES lanes; default 2). Results are valid until the next call on that slot. */
 int wm_map_reads_slot(wm_mapper_t *m, int slot, int n, const char *const *names, const char *const *seqs, const int32_t *lens,
                       const char **text, size_t *text_len, const int32_t **hits, const uint32_t **cigars, const int64_t **hit_first);
+/* The number of mini-batches the caller keeps in flight (slots 0 .. n - 1 of wm_map_reads_slot): the allocation of resident read codes is made with that
+ * many slabs (default: the lanes of wm_map_file, WM_MAP_LANES / WM_READ_SLABS, at least 2). A mini-batch on a slot without a slab is still mapped, from host
+ * views of its operands (slower; the library says so once on stderr). */
+int wm_mapper_set_slots(wm_mapper_t *m, int n);
 /* Per read of the slot's last wm_map_reads[_slot] call: flags[i] = 1 when the mapper assigned rep_len where the reference assigns it before mm_set_mapq
  * reads it (src/map.c:933) — the rescan of the stretches stage 1 left unmapped (src/map.c:808-813), the fallback to plain mapping (:859-861; every read below
  * SVawareMinReadLength and all of splice mode) — and 0 on the pure two-stage path, where the reference's rep_len is an uninitialised stack word (src/map.c:281)

@@ -29,7 +29,7 @@
 #ifndef WM_STRIPE_SPIN
 #define WM_STRIPE_SPIN(where, r, a, wv, extra) ((void)0)      // test hook: a watchdog for the polling loops
 #endif
-// Every cross-wavefront polling loop has a budget: a wavefront that has polled WM_STRIPE_SPIN_BUDGET times since it started (each poll
+// Every cross-wavefront polling loop has a budget: a wavefront that has polled WM_STRIPE_SPIN_BUDGET times in ONE wait (each poll
 // is an LDS load + s_sleep: ~10^2 cycles, so the default is seconds — legitimate waits are a few rows of a neighbour, microseconds) declares the
 // protocol broken: it raises C_RESTART = 2 and the stop word, everybody leaves, the job's result carries bt_i = KSW_BT_WATCHDOG, the traceback kernel
 // turns that into the batch's error flag and wm_ksw_dev_run returns WM_EINTERNAL instead of hanging the mapping call.
@@ -140,7 +140,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 	int *ring_out = lds + wv * (R * L::SLOT), *ring_in = lds + ((wv + NWV - 1) % NWV) * (R * L::SLOT);
 	int *prog = lds + L::PROG, *ctrl = lds + L::CTRL;
 	const int right_wv = (wv + 1) % NWV;
-	int spins = 0;                                                   // polls of this wavefront so far (all loops, both passes)
+	int spins = 0;                                                   // polls of the wait this wavefront is in (reset on entry to each polling loop: the budget bounds ONE wait, not the job — ADVICE r5)
 	auto give_up = [&]() { lds_st_rel(ctrl, L::C_RESTART, 2); lds_st_rel(ctrl, L::C_STOP, -1); };      // (the loop that called it sees the stop word at its next poll)
 	WM_ST_DECL();
 
@@ -223,6 +223,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 					if (a > 0 && gp.st <= a - 1 && a - 1 <= gp.en) {      // lane a - 1 was computed in row r - 1: take its message
 						const int *m = ring_in + ((r - 1) % R) * L::SLOT;
 						bool gone = false;
+						spins = 0;
 						while (lds_ld_acq(m, L::M_STAMP) != r - 1) { if (lds_ld_acq(ctrl, L::C_STOP) < r) { gone = true; break; } WM_STRIPE_SPIN(0, r, a, wv, lds_ld_acq(m, L::M_STAMP)); if (++spins > WM_STRIPE_SPIN_BUDGET) give_up(); spin_pause(); }
 						if (gone) { all_done = true; break; }
 						m_x = lds_ld(m, (long long)L::M_X); m_v = lds_ld(m, (long long)L::M_V); m_x2 = lds_ld(m, (long long)L::M_X2); m_h = lds_ld(m, (long long)L::M_H);
@@ -465,6 +466,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 						int o8[8];
 						int stamp = EARLY_MSG ? lds_msg_take(early, o8) : lds_ld_msg(m, o8);
 						if (stamp == r) WM_STRIPE_EVENT(9);
+						spins = 0;
 						while (stamp != r) {
 							if (lds_ld_acq(ctrl, L::C_STOP) <= r) { stopped = true; break; }
 							WM_STRIPE_SPIN(1, r, a, wv, lds_ld_acq(m, L::M_STAMP)); if (++spins > WM_STRIPE_SPIN_BUDGET) give_up(); spin_pause();
@@ -586,6 +588,7 @@ WM_DEV void ksw_dp_stripe(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const
 					// ---- publish this row for the right neighbour ----
 					WM_ST_LAP(WM_ST_BOOK);
 					if (pub) {
+						spins = 0;
 						while (right_seen < r - R) {                               // (slot r % R still holds row r - R until the right neighbour has consumed it)
 							right_seen = lds_ld_acq(prog, right_wv);
 							if (right_seen >= r - R) break;

@@ -32,7 +32,8 @@ static inline void wm_pack_blocks(const uint8_t *codes, size_t n, uint64_t *pk, 
 		for (int g = 0; g < 8; ++g) {
 			uint64_t x;
 			memcpy(&x, src + 8 * g, 8);
-			const uint64_t amb = (x >> 2) & 0x0101010101010101ULL;           // bit 0 of byte i: base i is 4 (or 5..7: not produced by seq_nt4_table)
+			const uint64_t hi6 = x & 0xfcfcfcfcfcfcfcfcULL;                  // any of bits 2..7 set: the code is >= 4 (wm_reads_upload accepts arbitrary bytes)
+			const uint64_t amb = ((hi6 | hi6 >> 1 | hi6 >> 2 | hi6 >> 3 | hi6 >> 4 | hi6 >> 5) >> 2) & 0x0101010101010101ULL;   // bit 0 of byte i: base i is ambiguous
 			m |= ((amb * 0x0102040810204080ULL) >> 56) << (8 * g);          // the eight flags gathered into one byte, base 8g + i -> bit 8g + i
 			x &= 0x0303030303030303ULL & ~(amb * 3);                         // an ambiguous base packs as 0
 			const uint64_t y = x | x >> 6 | x >> 12 | x >> 18;               // bytes 0 and 4 of y: bases 0-3 and 4-7, two bits each

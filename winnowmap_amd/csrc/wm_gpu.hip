@@ -408,7 +408,14 @@ static hipError_t ctx_sync(wm_ctx_s *c)
 // through this library; a value given by the user wins. (Python callers get the same default from winnowmap_amd/__init__.py.)
 // (this is the one setting that has to happen at load time — the HIP runtime reads the variable when it initialises. WM_NO_PROCESS_DEFAULTS=1
 // leaves the process alone; include/wm_gpu.h documents both process-wide settings.)
-__attribute__((constructor)) static void wm_default_hw_queues() { if (!getenv("WM_NO_PROCESS_DEFAULTS")) setenv("GPU_MAX_HW_QUEUES", "20", 0); }
+// Round 6: no library constructor any more — loading the library changes nothing in the process. The default is set by the first
+// wm_ctx_create / wm_device_count of the process, immediately before this library's first HIP call; if the host program has already initialised the HIP
+// runtime by then (it read the variable at that moment), the setting is simply too late and the program's own environment rules.
+static void wm_default_hw_queues()
+{
+	static std::once_flag once;
+	std::call_once(once, [] { if (!getenv("WM_NO_PROCESS_DEFAULTS")) setenv("GPU_MAX_HW_QUEUES", "20", 0); });
+}
 
 // The mapping calls allocate and free their per-call tables (tens of MB per batched call, from 16+ worker threads) at a rate at which glibc's defaults
 // turn into system calls: a worker's malloc arena grows in 128-KB steps (one mprotect each), gives the memory back as soon as it is free, deletes and
@@ -456,6 +463,7 @@ static void side_split(int P, int *light, int *heavy)
 
 extern "C" int wm_device_count(void)
 {
+	wm_default_hw_queues();
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
 	return n;
@@ -465,6 +473,7 @@ extern "C" int wm_ctx_create(int device, size_t arena_bytes, wm_ctx_t **out)
 {
 	int n = 0;
 	*out = 0;
+	wm_default_hw_queues();
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return set_err(WM_ENODEV, "no HIP device visible (libwmgpu has no CPU fallback)");
 	if (device < 0 || device >= n) return set_err(WM_EINVAL, "device %d out of range (%d visible)", device, n);
 	HIPCHK(hipSetDevice(device));
@@ -1182,7 +1191,7 @@ __global__ __launch_bounds__(64) void ksw_exts2_backtrack_kernel(wm_ksw_score_t 
 	if (r.bt_i == KSW_BT_WATCHDOG) atomicMax(err, 2);
 	if (r.bt_i >= 0) {
 		nc = wmk::ksw_exts2_backtrack_thread(sc, jobs[j], tb, r.bt_i, r.bt_j, cig_scratch + jobs[j].cig_off, jobs[j].cig_cap);
-		if (nc < 0) { atomicExch(err, 1); nc = 0; }
+		if (nc < 0) { atomicMax(err, 1); nc = 0; }
 	}
 	res[j].n_cigar = nc;
 }
@@ -3017,6 +3026,7 @@ struct GpuOps {                          // the device contexts of a mapper, sha
 	}
 	size_t slab = 0;
 	int n_slabs = 0;
+	std::atomic<int> slots_hint{0};             // mini-batches the caller keeps in flight: wm_mapper_set_slots, the lanes of wm_map_file[_multi], or the highest slot seen + 1
 	bool slot_busy[WM_MAX_SLOTS] = { false };
 	bool load_reads(const uint8_t *codes, size_t n, int slot, int64_t *base, std::string &err)
 	{
@@ -3026,14 +3036,20 @@ struct GpuOps {                          // the device contexts of a mapper, sha
 		wm_ctx_t *c0 = ctxs[0].c;
 		std::lock_guard<std::mutex> lk(reads_mu);
 		if (hipSetDevice(c0->device) != hipSuccess) return false;
+		if (slot + 1 > slots_hint.load()) slots_hint = slot + 1;
 		if (n + 256 > slab || slot >= n_slabs || !c0->d_reads || !c0->owns_reads) {
-			for (int o = 0; o < WM_MAX_SLOTS; ++o) if (o != slot && slot_busy[o]) return false;      // another mini-batch lives in the allocation: this one is served from its host views
+			for (int o = 0; o < WM_MAX_SLOTS; ++o) if (o != slot && slot_busy[o]) {      // another mini-batch lives in the allocation: this one is served from its host views
+				static std::atomic<bool> told(false);
+				if (!told.exchange(true)) fprintf(stderr, "[wmgpu] mini-batch on slot %d is served from host views (no resident slab: %d slab(s) of %zu bases, another slot busy); "
+				                                  "tell the mapper how many mini-batches are in flight (wm_mapper_set_slots / WM_READ_SLABS)\n", slot, n_slabs, slab);
+				return false;
+			}
 			if (c0->d_reads && c0->owns_reads) hipFree(c0->d_reads);
 			c0->d_reads = 0; c0->owns_reads = false; slab = 0;
 			const size_t want = (n + n / 8 + (1 << 20) + 255) & ~(size_t)255;
 			// slabs for the mini-batches that can be in flight: WM_READ_SLABS, else the lanes of wm_map_file (WM_MAP_LANES), at least 2 (four were
 			// allocated whatever the caller used — 4.5 GB for 1-Gbase mini-batches); a call on a slot beyond them is served from its host views
-			n_slabs = std::max(2, std::min((int)WM_MAX_SLOTS, getenv("WM_READ_SLABS") ? atoi(getenv("WM_READ_SLABS")) : getenv("WM_MAP_LANES") ? atoi(getenv("WM_MAP_LANES")) : 2));
+			n_slabs = std::max(2, std::min((int)WM_MAX_SLOTS, getenv("WM_READ_SLABS") ? atoi(getenv("WM_READ_SLABS")) : std::max(slots_hint.load(), getenv("WM_MAP_LANES") ? atoi(getenv("WM_MAP_LANES")) : 2)));
 			if (slot >= n_slabs) n_slabs = slot + 1;
 			if (reads_alloc(c0, (size_t)n_slabs * want) != WM_OK) return false;              // (bases: 2 bits + 1 ambiguity bit each, reads2bit.h)
 			c0->owns_reads = true; c0->reads_bytes = (size_t)n_slabs * want; slab = want;
@@ -3150,6 +3166,7 @@ struct wm_mapper_s {
 	double host_stats[24] = {0};
 	std::mutex stats_mu;
 	std::unique_ptr<GpuOps> ops;           // the device contexts as a pool shared by the mapping calls (created on first use, rebuilt by wm_mapper_set_threads)
+	int slots_hint = 0;                    // wm_mapper_set_slots
 	bool sam_header = true;                // wm_map_file writes the @SQ / @PG lines (wm_mapper_set_sam_header)
 	std::vector<std::string> cmdline;      // argv of the front end, for the @PG line of SAM files (wm_mapper_set_cmdline)
 };
@@ -3326,6 +3343,28 @@ extern "C" int wm_map_reads_slot(wm_mapper_t *m, int slot, int n, const char *co
 	return WM_OK;
 }
 
+// the device contexts of a mapper as the pool its mapping calls share (caller holds m->stats_mu)
+static void ensure_ops(wm_mapper_t *m)
+{
+	if (m->ops) return;
+	m->ops.reset(new GpuOps());
+	std::vector<wm_ctx_t*> cs; cs.push_back(m->c); cs.insert(cs.end(), m->workers.begin(), m->workers.end());
+	m->ops->init(cs);
+	m->ops->slots_hint = m->slots_hint;
+}
+
+// how many mini-batches the caller keeps in flight on this mapper (wm_map_reads_slot on slots 0 .. n - 1): the resident-reads allocation gets that many slabs
+// the next time it is (re)made (a caller of slots 2..3 was silently served from host views)
+extern "C" int wm_mapper_set_slots(wm_mapper_t *m, int n)
+{
+	if (!m || n < 1 || n > WM_MAX_SLOTS) return set_err(WM_EINVAL, "slots must be 1 .. WM_MAX_SLOTS");
+	std::lock_guard<std::mutex> lk(m->stats_mu);
+	if (n > m->slots_hint) m->slots_hint = n;
+	ensure_ops(m);
+	if (n > m->ops->slots_hint.load()) m->ops->slots_hint = n;
+	return WM_OK;
+}
+
 // per read of the slot's last mapping call: 1 = the mapper assigned rep_len where the reference assigns it (src/map.c:808-813 rescan, :859-861 fallback),
 // 0 = the pure-MCAS path, where the reference feeds mm_set_mapq an uninitialised word (src/map.c:281,933) and MAPQ / rl:i are not comparable
 extern "C" int wm_map_reads_rep_len_defined(const wm_mapper_t *m, int slot, const uint8_t **flags, size_t *n)
@@ -3348,7 +3387,7 @@ static int map_reads_impl(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, double
 	const double tm1 = now_ms();
 	{
 		std::lock_guard<std::mutex> lk(m->stats_mu);
-		if (!m->ops) { m->ops.reset(new GpuOps()); std::vector<wm_ctx_t*> cs; cs.push_back(m->c); cs.insert(cs.end(), m->workers.begin(), m->workers.end()); m->ops->init(cs); }
+		ensure_ops(m);
 	}
 	GpuOps &ops = *m->ops;
 	uint64_t cells0 = 0; double ksw_us0 = 0, aux_us0 = 0;
@@ -3545,7 +3584,7 @@ static int map_reads_raw(wm_mapper_t *m, std::vector<wm::ReadIn> &reads, std::ve
 {
 	{
 		std::lock_guard<std::mutex> lk(m->stats_mu);
-		if (!m->ops) { m->ops.reset(new GpuOps()); std::vector<wm_ctx_t*> cs; cs.push_back(m->c); cs.insert(cs.end(), m->workers.begin(), m->workers.end()); m->ops->init(cs); }
+		ensure_ops(m);
 	}
 	GpuOps &ops = *m->ops;
 	wm::MapStats st;
