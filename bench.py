@@ -156,6 +156,9 @@ KSW_WIDE_CLASSES = {24: "ksw_pmulti_kernel<4, 8>", 25: "ksw_pmulti_kernel<8, 8>"
 def ksw_class_name(k):
     """kernel name of a ksw class id (winnowmap_amd/csrc/ksw_plan.h: window*8 + EXACT*4 + CLIP*2 + HASN; 24.. = the wide-hull kernels);
     spelled as rocprofv3 prints the instantiation ksw_dpp_kernel<BP, CLIP, HASN, EXACT> (jobs with an N run on the CLIP instantiation)"""
+    if k >= 52:                                                    # chained-workgroup classes: WM_KSW_CHAIN + geometry * 4 + CLIP * 2 + HASN
+        g, v = (k - 52) >> 2, (k - 52) & 3
+        return "ksw_chain_kernel<%s, %s, %s>" % ((2, 4)[g], str(bool(v & 2) or bool(v & 1)).lower(), str(bool(v & 1)).lower())
     if k >= 28:                                                    # stripe classes: WM_KSW_STRIPE + geometry * 4 + CLIP * 2 + HASN
         g, v = (k - 28) >> 2, (k - 28) & 3
         return "ksw_stripe_kernel<%s, %s, %s>" % (("2, 4", "2, 8", "4, 8", "8, 8", "1, 16", "2, 16")[g], str(bool(v & 2) or bool(v & 1)).lower(), str(bool(v & 1)).lower())

@@ -156,6 +156,12 @@ void wm_ksw_dev_free(wm_ctx_t *ctx, wm_ksw_dev_batch_t *b);
  * WM_KSW_STRIPE_ROWS8 / WM_KSW_STRIPE / WM_KSW_STRIPE16 from the environment. Not part of the
  * reference's interface: tests force every job through every kernel with it, tools/ tune the thresholds. */
 void wm_ksw_set_routing(int on, int rows4, int rows8);
+/* The same kind of knob for the chained-workgroup kernels (csrc/ksw_chain_kernel.h, round 6: one alignment over several compute units, every wavefront a
+ * workgroup of its own, row messages through HBM — any hull width; ksw_extd2_sse's row loop src/ksw2_extd2_sse.c:123-376 is what every wavefront runs on its
+ * stripe). mode bits: 1 = every job the stripe classes and the old wide-hull kernels would serve (default), 2 = also exact extensions of the 8-pair
+ * one-wavefront classes with at least min_rows_exact rows, 4 = every job (tests); 0 = none (the round-5 routing). bp = 2 | 4 register pairs per wavefront
+ * (256- / 512-lane stripes). < 0 / 0 = leave. Environment defaults: WM_KSW_CHAIN (1), WM_KSW_CHAIN_ROWS (2048), WM_KSW_CHAIN_BP (2). Results never depend on it. */
+void wm_ksw_set_chain_routing(int mode, int min_rows_exact, int bp);
 
 /* Scalar drop-in with the reference's exact signature minus the kalloc handle (src/ksw2.h:60-61):
  * one alignment through the same kernels; cigar is malloc'd into *cigar_out (caller frees). */

@@ -345,9 +345,9 @@ int emu_chain_fill(int64_t n, const uint64_t *ax, const uint64_t *ay, int max_di
 	std::vector<uint64_t> sx(W), sy(W);
 	simt::exec_mask() = ~0ull;
 	if (max_iter >> 24) {              // test hook: bits 24.. of max_iter = number of cooperating waves (chain_block)
-		const int NWV = max_iter >> 24;
-		jb.max_iter &= 0xffffff;
-		std::vector<int> pub(NWV * 69 + 16);
+		const int NWV = max_iter >> 24, KT = (max_iter >> 20) & 15;      // bits 20..23: tiles per wavefront and step (chain_block_wide); 0 = chain_block
+		jb.max_iter &= 0xfffff;
+		std::vector<int> pub(NWV * (KT ? KT : 1) * 69 + 16);
 		pthread_barrier_t bar;
 		pthread_barrier_init(&bar, 0, NWV);
 		simt::block_barrier() = &bar;
@@ -355,7 +355,11 @@ int emu_chain_fill(int64_t n, const uint64_t *ax, const uint64_t *ay, int max_di
 		for (int w = 0; w < NWV; ++w)
 			th.emplace_back([&, w]() {
 				simt::wave_slot() = w; simt::exec_mask() = ~0ull;
-				wmk::chain_block(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
+				if (KT == 0) wmk::chain_block(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
+				else if (KT == 1) wmk::chain_block_wide<1>(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
+				else if (KT == 2) wmk::chain_block_wide<2>(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
+				else if (KT == 3) wmk::chain_block_wide<3>(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
+				else wmk::chain_block_wide<5>(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
 			});
 		for (auto &t : th) t.join();
 		simt::block_barrier() = 0;

@@ -18,6 +18,8 @@
 #define WM_KEEP_BRANCH() ((void)0)
 #define WM_EMU_ASSERT(x) do { if (!(x)) { fprintf(stderr, "EMU ASSERT %s:%d: %s\n", __FILE__, __LINE__, #x); abort(); } } while (0)
 
+typedef unsigned long long wm_mbox_t;      // a mailbox word of the chained-workgroup kernels: {value, stamp}, one 64-bit atomic (below)
+
 namespace simt {
 constexpr int WAVE = 64;
 inline uint64_t &exec_mask() { static thread_local uint64_t m = ~0ull; return m; }
@@ -233,6 +235,15 @@ struct lds_msg_raw { int s; int o[8]; };
 inline void lds_ld_msg_issue(const int *p, lds_msg_raw &m) { m.s = lds_ld_msg(p, m.o); }
 inline int lds_msg_take(const lds_msg_raw &m, int (&o)[8]) { for (int i = 0; i < 8; ++i) o[i] = m.o[i]; return m.s; }
 inline void spin_pause() { sched_yield(); }
+// cross-workgroup mailbox words (csrc/simt.h): 64-bit {value, stamp}, one atomic each
+inline V<long long> mbox_pack(const V<int> &val, int stamp) { V<long long> r; for (int i = 0; i < WAVE; ++i) r.v[i] = (long long)(((unsigned long long)(unsigned)stamp << 32) | (unsigned)val.v[i]); return r; }
+inline V<int> mbox_val(const V<long long> &w) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = (int)(unsigned)(unsigned long long)w.v[i]; return r; }
+inline V<int> mbox_stamp(const V<long long> &w) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = (int)(unsigned)((unsigned long long)w.v[i] >> 32); return r; }
+inline V<long long> mbox_ld(const wm_mbox_t *p, const V<int> &idx) { V<long long> r(0); for (int i = 0; i < WAVE; ++i) if (on(i)) r.v[i] = (long long)__atomic_load_n(p + idx.v[i], __ATOMIC_SEQ_CST); return r; }
+inline void mbox_st(wm_mbox_t *p, const V<int> &idx, const V<long long> &v) { for (int i = 0; i < WAVE; ++i) if (on(i)) __atomic_store_n(p + idx.v[i], (wm_mbox_t)v.v[i], __ATOMIC_SEQ_CST); }
+inline int mbox_ld_word(const int *p, int i) { return __atomic_load_n(p + i, __ATOMIC_SEQ_CST); }
+inline void mbox_st_word(int *p, int i, int v) { if (exec_mask()) __atomic_store_n(p + i, v, __ATOMIC_SEQ_CST); }
+template <int L> V<int> wrlane(const V<int> &acc, int v) { static_assert(L >= 0 && L < WAVE, "lane"); V<int> r = acc; r.v[L] = v; return r; }
 inline int lds_ld(const int *p, long long i) { return p[i]; }
 template <class I> void lds_st(int *p, const V<I> &idx, const V<int> &v) { gst(p, idx, v); }
 template <class I> void lds_st(int *p, const V<I> &idx, int v) { gst(p, idx, v); }

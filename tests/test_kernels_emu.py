@@ -294,15 +294,54 @@ def test_seed_and_chain_kernels_emulated_match_oracle(emu, small_index):
         avg = H.h_avg_qspan(n, sy)
         prm = [dict(max_dist_x=5000, min_dist_x=1000, max_dist_y=5000, bw=500), dict(max_dist_x=16000, min_dist_x=1000, max_dist_y=16000, bw=2000)][wi % 2]
         ou, obx, oby = W.o_chain_dp(sx, sy, **prm)
-        # (window, waves): single wave in-window; single wave with a 128-anchor window (wrap + global fallback); 4 and 8 cooperating waves
-        for win, nwv in ((0, 0), (128, 0), (128, 4), (0, 8)):
+        # (window, waves, tiles per wave and step): single wave in-window; single wave with a 128-anchor window (wrap + global fallback); 4 and 8 cooperating
+        # waves (chain_block); chain_block_wide with 2 x 2, 4 x 3 and 16 x 5 tiles per step
+        for win, nwv, kt in ((0, 0, 0), (128, 0, 0), (128, 4, 0), (0, 8, 0), (128, 2, 2), (0, 4, 3), (0, 16, 5)):
             fa = np.zeros(n, np.int32); pa = np.zeros(n, np.int32); va = np.zeros(n, np.int32)
-            emu.emu_chain_fill(n, sx, sy, prm["max_dist_x"], prm["min_dist_x"], prm["max_dist_y"], prm["bw"], 25 | (win << 16), 5000 | (nwv << 24), avg, 1.0, fa, pa, va)
+            emu.emu_chain_fill(n, sx, sy, prm["max_dist_x"], prm["min_dist_x"], prm["max_dist_y"], prm["bw"], 25 | (win << 16), 5000 | (nwv << 24) | (kt << 20), avg, 1.0, fa, pa, va)
             u = np.zeros(n, np.uint64); bx = np.zeros(n, np.uint64); by = np.zeros(n, np.uint64); nu = C.c_int()
             nv = H.h_chain_extract(n, sx, sy, fa, pa, va, 3, 40, C.byref(nu), u, bx, by)
-            assert np.array_equal(u[:nu.value], ou) and np.array_equal(bx[:nv], obx) and np.array_equal(by[:nv], oby), (wi, n, win, nwv)
+            assert np.array_equal(u[:nu.value], ou) and np.array_equal(bx[:nv], obx) and np.array_equal(by[:nv], oby), (wi, n, win, nwv, kt)
             n_chain += 1
-    assert n_chain >= 24
+    assert n_chain >= 40
+
+
+def _satellite_anchors(seed, n_mini, copies, period=171, max_iter_hint=0):
+    """anchors of a query that crosses a tandem array: every query minimizer hits `copies` neighbouring copies of the monomer (dense, long predecessor scans)"""
+    rng = np.random.default_rng(seed)
+    qpos = np.cumsum(rng.integers(5, 40, n_mini)).astype(np.int64) + 100
+    xs, ys = [], []
+    for q in qpos:
+        for k in rng.choice(np.arange(-copies, copies + 1), size=int(rng.integers(max(1, copies // 2), 2 * copies + 1)), replace=False):
+            r = 1_000_000 + int(q) + int(k) * period + int(rng.integers(-2, 3))
+            xs.append(r); ys.append((15 << 32) | int(q))
+    return W.o_radix_sort_128x(np.array(xs, np.uint64), np.array(ys, np.uint64))
+
+
+def test_chain_fill_over_the_whole_predecessor_window_matches_oracle(emu):
+    """chain_block_wide (seedchain_kernel.h): every wavefront scores KT tiles of the predecessor window per step — on satellite-like anchor sets (hundreds of
+    predecessors per anchor, marks everywhere, max_skip breaks in the middle of a window, max_iter clipping the window) against the oracle's mm_chain_dp fill
+    (f and p through the chains they give). Geometries from 2 x 2 tiles per step (many steps per anchor, the carried automaton state) to 16 x 5 (one step)."""
+    H = C.CDLL(build.build_harness())
+    H.h_chain_extract.restype = C.c_int64
+    H.h_chain_extract.argtypes = [C.c_int64, W.u64p, W.u64p, W.i32p, W.i32p, W.i32p, C.c_int, C.c_int, C.POINTER(C.c_int), W.u64p, W.u64p, W.u64p]
+    H.h_avg_qspan.restype = C.c_float
+    H.h_avg_qspan.argtypes = [C.c_int64, W.u64p]
+    n_run = 0
+    for seed, n_mini, copies, max_iter, max_skip in ((1, 60, 12, 5000, 25), (2, 40, 30, 5000, 25), (3, 50, 20, 300, 25), (4, 30, 40, 5000, 3), (5, 25, 60, 700, 40)):
+        sx, sy = _satellite_anchors(seed, n_mini, copies)
+        n = len(sx)
+        avg = H.h_avg_qspan(n, sy)
+        prm = dict(max_dist_x=16000, min_dist_x=1000, max_dist_y=16000, bw=2000)
+        ou, obx, oby = W.o_chain_dp(sx, sy, max_skip=max_skip, max_iter=max_iter, **prm)
+        for win, nwv, kt in ((0, 8, 0), (128, 2, 2), (256, 4, 1), (0, 4, 3), (0, 16, 5), (512, 16, 5)):
+            fa = np.zeros(n, np.int32); pa = np.zeros(n, np.int32); va = np.zeros(n, np.int32)
+            emu.emu_chain_fill(n, sx, sy, prm["max_dist_x"], prm["min_dist_x"], prm["max_dist_y"], prm["bw"], max_skip | (win << 16), max_iter | (nwv << 24) | (kt << 20), avg, 1.0, fa, pa, va)
+            u = np.zeros(n, np.uint64); bx = np.zeros(n, np.uint64); by = np.zeros(n, np.uint64); nu = C.c_int()
+            nv = H.h_chain_extract(n, sx, sy, fa, pa, va, 3, 40, C.byref(nu), u, bx, by)
+            assert np.array_equal(u[:nu.value], ou) and np.array_equal(bx[:nv], obx) and np.array_equal(by[:nv], oby), (seed, n, win, nwv, kt)
+            n_run += 1
+    assert n_run == 30
 
 
 def test_packed_multiwave_ksw_kernel_matches_oracle(emu_v):
@@ -535,3 +574,38 @@ def test_stripe_kernel_watchdog_gives_up_instead_of_hanging():
             assert [int(x) for x in ez] == [o[k] for k in W.EZ_FIELDS] and np.array_equal(cig, o["cigar"])
             n_ok += 1
     assert n_flagged > 5, (n_flagged, n_ok)
+
+
+# ---- the chained-workgroup ksw kernel (ksw_chain_kernel.h): every wavefront a workgroup of its own, row messages through a mailbox in global memory ----
+CHAIN_EVENTS = {"stripe_switch": 0, "inject": 1, "ez_handover_at_activation": 2, "edge_trk_handover": 4, "trk_handover": 5, "zdrop": 6}
+
+
+def _load_chain(defines=()):
+    E = C.CDLL(build.build_emu_chain(defines))
+    E.emu_chain_extd2.argtypes = [C.c_int, W.u8p, C.c_int, W.u8p, W.i8p] + [C.c_int] * 9 + [W.i32p, W.u32p, C.c_int, C.POINTER(C.c_int)]
+    E.emu_ksw_extd2 = E.emu_chain_extd2
+    return E
+
+
+def _chain_events(E):
+    ev = (C.c_long * 16)()
+    E.emu_chain_events(ev)
+    return {k: int(ev[i]) for k, i in CHAIN_EVENTS.items()}
+
+
+def _chain_run(E, cases, forces):
+    n_run = collections.Counter()
+    for c in cases:
+        o = None
+        for force in forces:
+            n, ez, cig, klass = emu_ksw(E, c, force)
+            if n < 0:
+                assert n == -1, (n, force, len(c["q"]), len(c["t"]), c["w"], hex(c["flag"]))      # -1: needs CLIP / HASN and the variant lacks it; anything else is a failure
+                continue
+            if o is None:
+                o = W.o_ksw_extd2(c["q"], c["t"], mat=W.simple_mat(c["a"], c["b"], 1), q=c["q_"], e=c["e"], q2=c["q2"], e2=c["e2"],
+                                  w=c["w"], zdrop=c["zdrop"], end_bonus=c["end_bonus"], flag=c["flag"])
+            n_run[(force - 400) // 10] += 1
+            assert [int(x) for x in ez] == [o[k] for k in W.EZ_FIELDS], (force, klass, len(c["q"]), len(c["t"]), c["w"], hex(c["flag"]), c["zdrop"])
+            assert np.array_equal(cig, o["cigar"]), (force, klass, len(c["q"]), len(c["t"]), c["w"], hex(c["flag"]), c["zdrop"])
+    return n_run

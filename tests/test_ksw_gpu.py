@@ -16,6 +16,19 @@ def ctx():
     c.close()
 
 
+def _default_chain_routing():
+    gpu.set_ksw_chain_routing(int(os.environ.get("WM_KSW_CHAIN", 1)) & 7, int(os.environ.get("WM_KSW_CHAIN_ROWS", 2048)), 4 if os.environ.get("WM_KSW_CHAIN_BP") == "4" else 2)
+
+
+@pytest.fixture(autouse=True)
+def chain_routing_off_unless_asked():
+    """the chained-workgroup kernels (round 6) take every wide or long job by default; the tests of the older kernels below switch them off so that those
+    kernels still run, the chain tests at the end of the file choose their own mode"""
+    gpu.set_ksw_chain_routing(0, -1, -1)
+    yield
+    _default_chain_routing()
+
+
 def _run_group(ctx, cases):
     """cases share one scoring preset (the C-ABI takes one score set per batch)."""
     c0 = cases[0]
@@ -323,3 +336,80 @@ def test_stripe_kernels_wide_hulls(ctx, stripe_geometries):
         cases.append(dict(q=q, t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=w, zdrop=zd, end_bonus=-1, flag=flag))
     bad = _run_group(ctx, cases)
     assert not bad, bad[:3]
+
+
+# ---- the chained-workgroup kernels (csrc/ksw_chain_kernel.h): every wavefront of an alignment a workgroup of its own, row messages through a mailbox in
+# HBM, tickets instead of block indices. mode 4 sends EVERY job there (two wavefronts for a tiny job), the default mode the wide and long ones ----
+@pytest.fixture(params=[2, 4], ids=["bp2", "bp4"])
+def all_chained(request):
+    gpu.set_ksw_chain_routing(4, 1, request.param)
+    yield
+    _default_chain_routing()
+
+
+@pytest.mark.parametrize("preset", [0, 1, 2, 3, 4])
+def test_chain_kernels_random_cases_all_flags(ctx, all_chained, preset):
+    cases = kswcases.make_cases(500 + preset, 240, max_len=900, preset=preset)
+    bad = _run_group(ctx, cases)
+    assert not bad, bad[:3]
+
+
+def test_chain_kernels_long_jobs_every_band(ctx, all_chained):
+    bad = _run_group(ctx, kswcases.stripe_cases(17, 300, 2600))                # (stripe_edge_cases draw a scoring preset per case: emulator tests only)
+    assert not bad, bad[:3]
+
+
+@pytest.mark.parametrize("bp", [2, 4])
+def test_chain_kernels_wide_hulls_incl_beyond_the_stripe_kernels_reach(ctx, bp):
+    """hulls of 1 100 .. 12 000 lanes with the default routing (mode 1): what the stripe classes served, and beyond 7 168 lanes what only ksw_pmulti_kernel<8,8>,
+    ksw_block_kernel and ksw_generic_kernel could (exact + z-drop, approximate maximum, unbanded, an N)"""
+    from winnowmap_amd import synth
+    gpu.set_ksw_chain_routing(1, -1, bp)
+    try:
+        rng = np.random.default_rng(23)
+        cases = []
+        for it, (L, w, flag, zd) in enumerate(((1300, 3001, 0x40, 400), (1700, 1501, 0x08, 400), (2500, -1, 0x08, 400), (3300, 3001, 0x40, 200), (3300, 3001, 0x00, 400),
+                                              (5200, -1, 0x08, 400), (6800, -1, 0x40, 400), (2100, 1200, 0xC2, 100), (4000, 2500, 0x42, 400),
+                                              (7600, -1, 0x08, 400), (9100, -1, 0x40, 400), (12000, -1, 0x08, 400), (8200, 8000, 0x42, 300))):
+            t = rng.integers(0, 4, L).astype(np.uint8)
+            q = synth.mutate_codes(t, rng, 0.03, 0.03, 0.04)
+            if it % 3 == 1:
+                q = np.concatenate([q[:L // 2], rng.integers(0, 4, L // 3).astype(np.uint8)])      # runs off: z-drop
+            if it == 4:
+                t[L // 2] = 4
+            cases.append(dict(q=q, t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=w, zdrop=zd, end_bonus=-1, flag=flag))
+        bad = _run_group(ctx, cases)
+        assert not bad, bad[:3]
+    finally:
+        _default_chain_routing()
+
+
+def test_chain_kernels_a_launch_larger_than_the_chip(ctx):
+    """900 wide jobs in one call = ~9 000 single-wavefront workgroups of one class, several times what the chip holds at once: tickets are taken in start
+    order, consumers start after their producers have run into back-pressure, and every job must still come out right (checked against the oracle on a
+    sample, against the one-wavefront-per-job result for all: results never depend on the routing)"""
+    from winnowmap_amd import synth
+    rng = np.random.default_rng(29)
+    cases = []
+    for it in range(900):
+        L = int(rng.integers(1100, 2600))
+        t = rng.integers(0, 4, L).astype(np.uint8)
+        q = synth.mutate_codes(t, rng, 0.04, 0.03, 0.04)
+        if it % 7 == 3:
+            q = np.concatenate([q[:L // 3], rng.integers(0, 4, L // 2).astype(np.uint8)])
+        cases.append(dict(q=q, t=t, a=2, b=4, q_=4, e=2, q2=24, e2=1, w=[3001, -1, 1501][it % 3], zdrop=[400, 200][it % 2], end_bonus=-1, flag=[0x40, 0x08, 0x00, 0x42][it % 4]))
+    sc = gpu.KswScore(2, -4, -1, 4, 2, 24, 1)
+    jobs, seqs = gpu.pack_jobs([(c["q"], c["t"], dict(w=c["w"], zdrop=c["zdrop"], end_bonus=c["end_bonus"], flag=c["flag"])) for c in cases])
+    gpu.set_ksw_chain_routing(1, -1, 2)
+    try:
+        res, pool = ctx.ksw_batch(sc, jobs, seqs)
+    finally:
+        gpu.set_ksw_chain_routing(0, -1, -1)
+    res0, pool0 = ctx.ksw_batch(sc, jobs, seqs)              # the stripe / register kernels
+    for i in range(len(cases)):
+        assert all(int(res[i][k]) == int(res0[i][k]) for k in W.EZ_FIELDS), (i, res[i], res0[i])
+        assert np.array_equal(pool[res[i]["cig_off"]:res[i]["cig_off"] + res[i]["n_cigar"]], pool0[res0[i]["cig_off"]:res0[i]["cig_off"] + res0[i]["n_cigar"]]), i
+    for i in range(0, len(cases), 60):
+        c = cases[i]
+        o = W.o_ksw_extd2(c["q"], c["t"], mat=W.simple_mat(2, 4, 1), q=4, e=2, q2=24, e2=1, w=c["w"], zdrop=c["zdrop"], end_bonus=-1, flag=c["flag"])
+        assert all(int(res[i][k]) == o[k] for k in W.EZ_FIELDS), (i, res[i], o)

@@ -121,6 +121,21 @@ def build_emu_stripe(defines=()):
     return out
 
 
+def build_emu_chain(defines=()):
+    """tests/simt_emu/libwm_emu_chain[_<defines>].so: the chained-workgroup ksw kernel (ksw_chain_kernel.h) on the emulator, one host thread per wavefront,
+    the mailbox in plain memory (tests/simt_emu/emu_chain.cpp)."""
+    emu = os.path.join(ROOT, "tests", "simt_emu")
+    tag = "".join("_" + "".join(ch if ch.isalnum() else "_" for ch in d) for d in defines)
+    out = os.path.join(emu, "libwm_emu_chain%s.so" % tag)
+    srcs = [os.path.join(emu, f) for f in ("emu_chain.cpp", "simt.h")] + \
+           [os.path.join(CSRC, f) for f in ("ksw_chain_kernel.h", "ksw_stripe_kernel.h", "ksw_packed_kernel.h", "ksw_kernel.h", "ksw_plan.h")]
+    with _Lock(out):
+        if _newer(out, srcs):
+            _run_to(out, lambda o: ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wno-unknown-pragmas"] +
+                    ["-D" + d for d in defines] + ["-I" + emu, "-I" + CSRC, "-o", o, os.path.join(emu, "emu_chain.cpp")])
+    return out
+
+
 def build_harness():
     """tests/host_harness/libwm_harness.so: the product HOST mapper driven by oracle-backed device ops (tests only)."""
     hd = os.path.join(ROOT, "tests", "host_harness")
@@ -139,4 +154,5 @@ if __name__ == "__main__":
     build_oracle()
     build_emu()
     build_emu_stripe()
+    build_emu_chain()
     build_harness()

@@ -11,8 +11,30 @@ enum {            // register classes (ksw_dp_packed<BP,...>): klass = window*8 
 	// CLIP instantiation: 1 is unused); geometry 0..3 = <BP, NWV> of <2,4> <2,8> <4,8> <8,8>: traceback pitch n_col up to 768 / 1792 / 3584 / 7168;
 	// geometry 4, 5 = <1,16> <2,16> (up to 1920 / 3840 lanes): half the pairs per wavefront for the same hull — the cells of a row are the largest
 	// share of a stripe wavefront's row time (profiles/r04q_stripe_timing.txt). Opt-in (wide16 of wm_ksw_route) until a bench A/B has judged them.
-	WM_KSW_STRIPE = 28, WM_KSW_NCLASS = 52
+	WM_KSW_STRIPE = 28,
+	// chained-workgroup kernels (ksw_chain_kernel.h, round 6): klass = WM_KSW_CHAIN + geometry * 4 + CLIP * 2 + HASN, geometry 0 / 1 = 2 / 4 register pairs per
+	// wavefront (256 / 512-lane stripes); ANY hull width and length — every wavefront of a job is a workgroup of its own
+	WM_KSW_CHAIN = 52, WM_KSW_NCLASS = 60
 };
+static const int wm_ksw_chain_bp[2] = { 2, 4 };
+// Which jobs run on the chained-workgroup kernels. mode bit 0: everything the stripe classes and the old wide-hull kernels (BLOCK2 = ksw_dp_pmulti<8,8>,
+// BLOCK3 = ksw_dp_block, GENERIC) serve — hulls wider than one wavefront's window, and the long jobs of the 4- / 8-pair register classes that wm_ksw_route
+// sends to a stripe class; bit 1: exact extensions (z-drop, exact maximum) of the 8-pair register classes from `min_rows_exact` rows on — one wavefront per
+// alignment is one dependent chain of qlen + tlen rows of up to 8 pairs, and a launch lasts as long as its longest chain; bit 2: every job (tests).
+// geom: wm_ksw_chain_bp index.
+static inline int wm_ksw_route_chain(int klass, int qlen, int tlen, int w, int has_n, int flag, int mode, int min_rows_exact, int geom)
+{
+	if (klass < 0 || !mode) return klass;
+	bool go = false;
+	if (mode & 1) go = klass >= WM_KSW_P16;                       // (16-pair register classes, BLOCK.., GENERIC, every stripe class)
+	if (!go && (mode & 2) && klass >= WM_KSW_P8 && klass < WM_KSW_P16 && (klass & 4) && qlen + tlen - 1 >= min_rows_exact) go = true;
+	if (mode & 4) go = true;                                      // (tests: every job)
+	if (!go || klass >= WM_KSW_CHAIN) return klass;
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	const int clip = !(w >= qlen && w >= tlen) || has_n;
+	(void)flag;
+	return WM_KSW_CHAIN + geom * 4 + clip * 2 + (has_n ? 1 : 0);
+}
 static const int wm_ksw_stripe_max_ncol[6] = { 3 * 256, 7 * 256, 7 * 512, 7 * 1024, 15 * 128, 15 * 256 };      // ksw_stripe_lds<BP, NWV>::MAX_NCOL
 // Which jobs leave their register / barrier class for a stripe class: every hull wider than the one-wave window of 8 pairs (the former 16-pair and
 // BLOCK / BLOCK2 classes: one DP row cost 2.5 us there whatever the hull), and LONG alignments of the 4- and 8-pair classes — one alignment on

@@ -469,4 +469,179 @@ WM_DEV void chain_block(const wm_chain_job_t jb, const wm128_t *anchor_pool, int
 		}
 }
 
+// ------------------------------------------------------------------------------------------------------
+// chain_block_wide (round 6): chain_block with the WHOLE predecessor window of an anchor scored in one step. chain_block's step is NWV tiles (512
+// predecessors with eight wavefronts) behind three workgroup barriers; an anchor inside a satellite array scans up to max_iter = 5000 predecessors
+// (src/chain.c:51-55), i.e. ten steps = thirty barriers per anchor, and a 5-Mb contig across such an array is ~10^6 anchors in ONE job: 14 s on one
+// workgroup (profiles/r05_satellite_contig_kernels.txt). Nothing in a scan forces that order: the marks of every scored predecessor may be scattered
+// before any t[j] is read (they only flow from larger to smaller j, and marks behind the break are never looked at), the running maximum before a tile
+// is the maximum of the tiles in front of it — a prefix over per-tile maxima — and only the n_skip / break automaton (src/chain.c:79-86) is sequential,
+// over the few improvement / marked lanes. So here every wavefront scores KT tiles (tile u = k * NWV + wv: a short scan still spreads over all
+// wavefronts), one barrier, every wavefront reads its marks and turns the per-tile maxima (lanes = tiles) into the running maximum before its tiles with
+// one wave scan, publishes the improvement / marked ballots, one barrier, and the automaton runs over the tiles that have events (found with one
+// ballot over the published masks). NWV * KT tiles per step: 16 x 5 = 5 120 predecessors — a whole max_iter window — for the same three barriers.
+// pub: NT * 69 ints (tile maxima | I lo,hi,M lo,hi per tile | 64 scores per tile, written only by tiles that have an improvement), NT = NWV * KT <= 128.
+// ------------------------------------------------------------------------------------------------------
+template <int KT>
+WM_DEV void chain_block_wide(const wm_chain_job_t jb, const wm128_t *anchor_pool, int NWV, int W, uint64_t *sx, uint64_t *sy, int *sf, int *sp, int *st_,
+                             int *pub, int *gf, int *gp, int *gt)
+{
+	const V<int> ln = lane();
+	const int wv = wave_in_block();
+	const uint64_t *a = (const uint64_t*)(anchor_pool + jb.a_off);
+	const int n = jb.n;
+	const long long wm = (long long)W - 1;
+	const bool wraps = n > W;
+	const int NT = NWV * KT;
+	WM_EMU_ASSERT(NT <= 128);
+	int *pub_tmax = pub, *pub_mask = pub + NT, *pub_sc = pub + NT * 5;      // tile max | I lo,hi,M lo,hi per tile | 64 scores per tile
+	const V<int> NEG = -0x7fffffff - 1;
+	if (wraps)
+		for (int i0 = wv * 64; i0 < n; i0 += 64 * NWV) WM_IF(ln + i0 < n) cst(gt, cast<long long>(ln) + (long long)i0, V<int>(0)); WM_END
+	long long st = 0;
+	for (int i = 0; i < n; ++i) {
+		if ((i & 63) == 0) {
+			block_sync_lds();
+			if (wv == 0) {
+				if (wraps && i > 0) chain_flush_tile((long long)i - 64, (long long)i, wm, sf, sp, gf, gp);
+				const V<long long> k = cast<long long>(ln) + (long long)i;
+				WM_IF(k < (long long)n)
+					gst(sx, k & wm, gld(a, k * 2LL)); gst(sy, k & wm, gld(a, k * 2LL + 1LL)); gst(st_, k & wm, V<int>(0));
+				WM_END
+			}
+			block_sync_lds();
+		}
+		const long long lo = (long long)(i & ~63) + 64 - W;
+		const uint64_t ri = gld(sx, (long long)i & wm), yi = gld(sy, (long long)i & wm);
+		const int qi = (int)(uint32_t)yi, span = (int)(yi >> 32 & 0xff);
+		int max_f = span, n_skip = 0;
+		long long max_j = -1;
+		st = chain_advance_st(st, i, ri, (uint64_t)jb.max_dist_x, -1, lo, wm, sx, a);
+		if (i - st > jb.max_iter) st = chain_advance_st(st, i, ri, (uint64_t)jb.min_dist_x, jb.max_iter, lo, wm, sx, a);
+		bool stop = false;
+		for (long long hi0 = (long long)i - 1; hi0 >= st && !stop; hi0 -= 64LL * NT) {
+			// tiles of this step that hold predecessors at all: 0 .. nt - 1
+			const long long span_j = hi0 - st + 1;
+			const int nt = span_j >= 64LL * NT ? NT : (int)((span_j + 63) >> 6);
+			V<int> sc[KT], pmx[KT];
+			vbool valid[KT];
+			bool any_far = false;
+			// ---- phase A: score, scatter the marks, publish the tile maxima ----
+#pragma unroll
+			for (int k = 0; k < KT; ++k) {
+				const int u = k * NWV + wv;
+				sc[k] = 0; pmx[k] = NEG;
+				valid[k] = ln < 0;                                                              // false
+				if (u >= nt) continue;
+				const long long hi = hi0 - 64LL * u;
+				const V<long long> j = V<long long>(hi) - cast<long long>(ln);
+				const vbool in = j >= st, res = j >= lo;
+				V<int> pj = -1, fj = 0;
+				V<uint64_t> xj = (uint64_t)0, yj = (uint64_t)0;
+				if (hi - 63 >= lo) {                                                            // whole tile resident (the common case)
+					WM_IF(in) xj = gld(sx, j & wm); yj = gld(sy, j & wm); fj = gld(sf, j & wm); pj = gld(sp, j & wm); WM_END
+				} else {
+					WM_IF(in && res) xj = gld(sx, j & wm); yj = gld(sy, j & wm); fj = gld(sf, j & wm); pj = gld(sp, j & wm); WM_END
+					WM_IF(in && !res) xj = gld(a, j * 2LL); yj = gld(a, j * 2LL + 1LL); fj = cld(gf, j); pj = cld(gp, j); WM_END
+				}
+				WM_IF(in)
+					vbool ok = in;
+					chain_score(jb, ri, qi, span, xj, yj, fj, sc[k], ok);
+					valid[k] = ok;
+				WM_END
+				const V<long long> pjl = cast<long long>(pj);
+				WM_IF(valid[k] && pj >= 0 && pjl >= lo) gst(st_, pjl & wm, V<int>(i)); WM_END
+				if (st < lo) {
+					const vbool far_mark = valid[k] && pj >= 0 && pjl < lo && pjl >= st;
+					WM_IF(far_mark) cst(gt, pjl, V<int>(i)); WM_END
+					any_far = any_far || any(far_mark);
+				}
+				pmx[k] = wave_scan_max(sel(valid[k], sc[k], NEG));                              // inclusive prefix maximum inside the tile (lane 0 = first visited)
+				WM_IF(ln == 63) gst(pub_tmax, V<int>(u), pmx[k]); WM_END
+			}
+			if (any_far) mem_sync();
+			block_sync_lds();                                                                   // marks + tile maxima visible
+			// ---- phase B: the running maximum before each tile (lanes = tiles), improvement / marked ballots ----
+			V<int> t0 = NEG, t1 = NEG;
+			WM_IF(ln < nt) t0 = gld(pub_tmax, ln); WM_END
+			if (nt > 64) { WM_IF(ln + 64 < nt) t1 = gld(pub_tmax, ln + 64); WM_END }
+			const V<int> s0 = wave_scan_max(t0);
+			const int top0 = readlane(s0, 63);
+			V<int> s1 = NEG;
+			if (nt > 64) s1 = vmax(wave_scan_max(t1), V<int>(top0));
+#pragma unroll
+			for (int k = 0; k < KT; ++k) {
+				const int u = k * NWV + wv;
+				if (u >= nt) continue;
+				const long long hi = hi0 - 64LL * u;
+				const V<long long> j = V<long long>(hi) - cast<long long>(ln);
+				V<int> tj = 0;
+				if (hi - 63 >= lo) { WM_IF(valid[k]) tj = gld(st_, j & wm); WM_END }
+				else {
+					const vbool res = j >= lo;
+					WM_IF(valid[k] && res) tj = gld(st_, j & wm); WM_END
+					WM_IF(valid[k] && !res) tj = cld(gt, j); WM_END
+				}
+				int run_before = max_f;
+				if (u > 0) { const int tb = u - 1 < 64 ? readlane(s0, u - 1) : readlane(s1, u - 1 - 64); run_before = tb > run_before ? tb : run_before; }
+				const V<int> before = vmax(shr1(pmx[k], NEG), V<int>(run_before));
+				const uint64_t I = ballot(valid[k] && sc[k] > before);
+				const uint64_t M = ballot(valid[k] && tj == i) & ~I;
+				WM_IF(ln == 0)
+					gst(pub_mask, V<int>(u * 4), V<int>((int)(uint32_t)I)); gst(pub_mask, V<int>(u * 4 + 1), V<int>((int)(uint32_t)(I >> 32)));
+					gst(pub_mask, V<int>(u * 4 + 2), V<int>((int)(uint32_t)M)); gst(pub_mask, V<int>(u * 4 + 3), V<int>((int)(uint32_t)(M >> 32)));
+				WM_END
+				if (I) gst(pub_sc, ln + u * 64, sc[k]);                                         // (only a tile with an improvement is ever asked for a score)
+			}
+			block_sync_lds();                                                                   // ballots + scores visible
+			// ---- phase C: the automaton over the tiles that have events (every wavefront replays it: all agree without a broadcast) ----
+			{
+				vbool has0 = ln < 0, has1 = ln < 0;
+				WM_IF(ln < nt) has0 = (gld(pub_mask, ln * 4) | gld(pub_mask, ln * 4 + 1) | gld(pub_mask, ln * 4 + 2) | gld(pub_mask, ln * 4 + 3)) != 0; WM_END
+				if (nt > 64) { WM_IF(ln + 64 < nt) has1 = (gld(pub_mask, (ln + 64) * 4) | gld(pub_mask, (ln + 64) * 4 + 1) | gld(pub_mask, (ln + 64) * 4 + 2) | gld(pub_mask, (ln + 64) * 4 + 3)) != 0; WM_END }
+				uint64_t ev_t[2] = { ballot(has0 && ln < nt), nt > 64 ? ballot(has1 && ln + 64 < nt) : 0 };
+				for (int half = 0; half < 2 && !stop; ++half) {
+					uint64_t evt = ev_t[half];
+					while (evt && !stop) {
+						const int u = __builtin_ctzll(evt) + 64 * half;
+						evt &= evt - 1;
+						const long long hw = hi0 - 64LL * u;
+						const uint64_t Iw = (uint64_t)(uint32_t)gld(pub_mask, (long long)u * 4) | (uint64_t)(uint32_t)gld(pub_mask, (long long)u * 4 + 1) << 32;
+						const uint64_t Mw = (uint64_t)(uint32_t)gld(pub_mask, (long long)u * 4 + 2) | (uint64_t)(uint32_t)gld(pub_mask, (long long)u * 4 + 3) << 32;
+						int brk = 64;
+						uint64_t ev = Iw | Mw;
+						while (ev) {
+							const int l = __builtin_ctzll(ev);
+							ev &= ev - 1;
+							if (Iw >> l & 1) { if (n_skip > 0) --n_skip; }
+							else if (++n_skip > jb.max_skip) { brk = l; break; }
+						}
+						const uint64_t Ib = brk < 64 ? Iw & (((uint64_t)1 << brk) - 1) : Iw;
+						if (Ib) {
+							const int l = 63 - __builtin_clzll(Ib);
+							max_f = gld(pub_sc, (long long)u * 64 + l);
+							max_j = hw - l;
+						}
+						if (brk < 64) stop = true;
+					}
+				}
+			}
+			block_sync_lds();                                                                   // pub area may be overwritten by the next step
+		}
+		if (wv == 0) {
+			WM_IF(ln == 0)
+				const V<long long> ii = (long long)i;
+				gst(sf, ii & wm, V<int>(max_f)); gst(sp, ii & wm, V<int>((int)max_j));
+			WM_END
+		}
+		block_sync_lds();
+	}
+	if (wraps) { if (wv == 0) chain_flush_tile((long long)((n - 1) & ~63), (long long)n, wm, sf, sp, gf, gp); }
+	else
+		for (int i0 = wv * 64; i0 < n; i0 += 64 * NWV) {
+			const V<long long> k = cast<long long>(ln) + (long long)i0;
+			WM_IF(k < (long long)n) gst(gf, k, gld(sf, k)); gst(gp, k, gld(sp, k)); WM_END
+		}
+}
+
 } // namespace wmk

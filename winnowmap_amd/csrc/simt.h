@@ -16,6 +16,8 @@
 #define WM_END }
 #define WM_EMU_ASSERT(x) ((void)0)
 
+typedef unsigned long long wm_mbox_t;      // a mailbox word of the chained-workgroup kernels: {value, stamp}, one 64-bit atomic (below)
+
 namespace simt {
 
 template <class T> using V = T;
@@ -263,5 +265,30 @@ WM_DEV int lds_msg_take(const lds_msg_raw &m, int (&o)[8])
 	return __builtin_amdgcn_readfirstlane(m.s);
 }
 WM_DEV void spin_pause() { __builtin_amdgcn_s_sleep(1); }
+
+// ---- cross-WORKGROUP hand-over through global memory (ksw_chain_kernel.h) --------------------------------------------------------
+// The wavefronts of one alignment run as workgroups of their own, possibly on different XCDs (each XCD has its own L2). Every mailbox word is 64 bits
+// = {value, stamp} and travels as ONE relaxed agent-scope atomic: such an access is single-copy atomic and coherent across the XCDs (sc1 accesses go
+// past the non-coherent caches), so a reader that finds the stamp it expects has the value that was written with it — no fence on either side, nothing
+// to write back or invalidate (an agent-scope release / acquire pair costs an L2 write-back + invalidate: DESIGN "agent-scope fences").
+WM_DEV long long mbox_pack(int val, int stamp) { return (long long)(((unsigned long long)(unsigned)stamp << 32) | (unsigned)val); }
+WM_DEV int mbox_val(long long w) { return (int)(unsigned)(unsigned long long)w; }
+WM_DEV int mbox_stamp(long long w) { return (int)(unsigned)((unsigned long long)w >> 32); }
+WM_DEV long long mbox_ld(const wm_mbox_t *p, int i) { return (long long)__hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }      // per lane
+WM_DEV void mbox_st(wm_mbox_t *p, int i, long long v) { __hip_atomic_store(p + i, (wm_mbox_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }       // per lane, under the exec mask
+// uniform 32-bit control words (progress, stop): every lane reads the same address / lane 0 writes
+WM_DEV int mbox_ld_word(const int *p, int i) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+WM_DEV void mbox_st_word(int *p, int i, int v) { if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(p + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// acc with lane L (a constant) replaced by the uniform value v: v_writelane_b32
+// (this compiler has no __builtin_amdgcn_writelane: the instruction itself; both sources are scalar registers / inline constants)
+template <int L> WM_DEV int wrlane(int acc, int v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	// (one scalar register at most: the lane is an inline constant. readfirstlane: a value the compiler keeps in a vector register — it does so for some
+	// uniform values — must not reach the "s" operand as it is; on a value that already is scalar the builtin folds away)
+	asm("v_writelane_b32 %0, %1, %2" : "+v"(acc) : "s"(__builtin_amdgcn_readfirstlane(v)), "n"(L));
+#endif
+	return acc;
+}
 
 } // namespace simt

@@ -49,6 +49,7 @@ static inline double now_ms() { return std::chrono::duration<double, std::milli>
 #include "ksw_packed_kernel.h"
 #include "ksw_packed_multi_kernel.h"
 #include "ksw_stripe_kernel.h"
+#include "ksw_chain_kernel.h"
 #include "ksw_exts2_kernel.h"
 #include "ksw_plan.h"
 #include "cigar_walk.h"
@@ -175,6 +176,26 @@ __global__ __launch_bounds__(64 * NWV) void ksw_stripe_kernel(wm_ksw_score_t sc,
 	const wm_ksw_djob_t jb = jobs[j];
 	if (jb.flag & KSW_F_APPROX_MAX) wmk::ksw_dp_stripe<BP, NWV, CLIP, HASN, false>(sc, jb, seqs, tb, lds, res + j);
 	else wmk::ksw_dp_stripe<BP, NWV, CLIP, HASN, true>(sc, jb, seqs, tb, lds, res + j);
+}
+
+// chained-workgroup classes (ksw_plan.h: WM_KSW_CHAIN..; ksw_chain_kernel.h): one 64-thread workgroup per WAVEFRONT of an alignment. A workgroup takes a
+// ticket when it starts and the ticket names (job, wavefront) — `cmap[ticket]` = {index into `order`, wavefront, mailbox offset in 128-byte units, wavefronts
+// of the job}, jobs largest first, the wavefronts of a job in consecutive tickets: every lower ticket is running or done, whatever the dispatcher's order.
+template <int BP, bool CLIP, bool HASN>
+__global__ __launch_bounds__(64) void ksw_chain_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
+                                                        const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res,
+                                                        const uint4 *__restrict__ cmap, int *ticket, wm_mbox_t *mail)
+{
+	WM_SETPRIO(WM_STRIPE_PRIO);
+	int tk = 0;
+	if (threadIdx.x == 0) tk = atomicAdd(ticket, 1);
+	tk = __builtin_amdgcn_readfirstlane(tk);
+	const uint4 m = cmap[tk];
+	const int j = order[m.x];
+	const wm_ksw_djob_t jb = jobs[j];
+	wm_mbox_t *mb = mail + (size_t)m.z * 16;
+	if (jb.flag & KSW_F_APPROX_MAX) wmk::ksw_dp_chain<BP, CLIP, HASN, false>(sc, jb, seqs, tb, mb, (int)m.w, (int)m.y, res + j);
+	else wmk::ksw_dp_chain<BP, CLIP, HASN, true>(sc, jb, seqs, tb, mb, (int)m.w, (int)m.y, res + j);
 }
 
 // operands of position jobs (wm_ksw_batch_pos): expand query and target of job blockIdx.x into the batch's sequence slab. Query = two-strand
@@ -369,6 +390,8 @@ struct wm_ksw_dev_batch_s {
 	// device pointers (inside the arena)
 	uint8_t *d_gscratch; uint64_t *d_goff; std::vector<uint64_t> goff;
 	uint8_t *d_b3state; uint64_t *d_b3off; std::vector<uint64_t> b3off;
+	// chained-workgroup classes: ticket -> (job, wavefront, mailbox) per class, the mailboxes (filled with 0xff before the launches), one ticket counter per class
+	std::vector<uint4> cmap[WM_KSW_NCLASS - WM_KSW_CHAIN]; uint4 *d_cmap[WM_KSW_NCLASS - WM_KSW_CHAIN]; wm_mbox_t *d_mail = 0; size_t mail_words = 0; int *d_tickets = 0;
 	wm_ksw_djob_t *d_jobs; int *d_order; uint8_t *d_seqs, *d_tb; wm_ksw_dres_t *d_res; uint32_t *d_cig, *d_off, *d_total, *d_pool; int *d_err;
 	size_t pool_cap, arena_mark, slab_bytes;
 	uint64_t cells, tb_bytes;
@@ -586,6 +609,35 @@ template <int BP, int NWV> static void launch_stripe(int variant, int n, hipStre
 	else hipLaunchKernelGGL((ksw_stripe_kernel<BP, NWV, false, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
 }
 
+// variant = CLIP * 2 + HASN (0, 2, 3); n = wavefronts (= workgroups) of the class
+template <int BP> static void launch_chain(int variant, int n, hipStream_t s, const wm_ksw_score_t &sc, const wm_ksw_djob_t *jobs, const int *order,
+                                           const uint8_t *seqs, uint8_t *tb, wm_ksw_dres_t *res, const uint4 *cmap, int *ticket, wm_mbox_t *mail)
+{
+	dim3 g(n), b(64);
+	if (variant & 1) hipLaunchKernelGGL((ksw_chain_kernel<BP, true, true>), g, b, 0, s, sc, jobs, order, seqs, tb, res, cmap, ticket, mail);
+	else if (variant & 2) hipLaunchKernelGGL((ksw_chain_kernel<BP, true, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res, cmap, ticket, mail);
+	else hipLaunchKernelGGL((ksw_chain_kernel<BP, false, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res, cmap, ticket, mail);
+}
+// WM_KSW_CHAIN (wm_ksw_route_chain's mode): bit 0 = the stripe classes and the old wide-hull kernels' jobs run on the chained-workgroup kernels, bit 1 = long exact
+// extensions of the 8-pair register classes too (from WM_KSW_CHAIN_ROWS rows on); 0 = none (the round-5 routing, A/B). WM_KSW_CHAIN_BP=4: 512-lane stripes.
+static std::atomic<int> g_chain_mode(-1), g_chain_rows(2048), g_chain_geom(0);
+static int chain_mode()
+{
+	if (g_chain_mode.load(std::memory_order_relaxed) < 0) {
+		g_chain_rows = getenv("WM_KSW_CHAIN_ROWS") ? std::max(1, atoi(getenv("WM_KSW_CHAIN_ROWS"))) : 2048;
+		g_chain_geom = getenv("WM_KSW_CHAIN_BP") && atoi(getenv("WM_KSW_CHAIN_BP")) == 4 ? 1 : 0;
+		g_chain_mode = getenv("WM_KSW_CHAIN") ? atoi(getenv("WM_KSW_CHAIN")) & 7 : 1;
+	}
+	return g_chain_mode.load(std::memory_order_relaxed);
+}
+extern "C" void wm_ksw_set_chain_routing(int mode, int min_rows_exact, int bp)
+{
+	chain_mode();
+	if (mode >= 0) g_chain_mode = mode & 7;
+	if (min_rows_exact > 0) g_chain_rows = min_rows_exact;
+	if (bp == 2 || bp == 4) g_chain_geom = bp == 4 ? 1 : 0;
+}
+
 // Plans one batch: kernel class, traceback pitch and arena offsets per job; uploads the job table and the operands. Operands are either
 // bytes (`jobs` + `seqs`: only the part of `seqs` the jobs refer to is uploaded) or positions in resident data (`pos`: expanded in HBM).
 static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs, const wm_ksw_job_t *jobs, const uint8_t *seqs, size_t seqs_bytes,
@@ -671,6 +723,7 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 		int n_col;
 		d.klass = wm_ksw_classify(qlen, tlen, w, has_n, flag, &n_col);
 		if (stripe_min_rows(0)) d.klass = wm_ksw_route(d.klass, n_col, qlen, tlen, w, has_n, stripe_min_rows(4), stripe_min_rows(8), g_stripe_wide16.load(std::memory_order_relaxed));
+		d.klass = wm_ksw_route_chain(d.klass, qlen, tlen, w, has_n, flag, chain_mode(), g_chain_rows.load(std::memory_order_relaxed), g_chain_geom.load(std::memory_order_relaxed));
 		d.n_col = n_col;
 		cells[i] = wm_ksw_cells(qlen, tlen, w, &bands[i]);
 	});
@@ -739,6 +792,29 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 		b->d_b3off = (uint64_t*)arena_take(c, b->b3off.size() * 8 + 64);
 		if (!b->d_b3state || !b->d_b3off) b->d_tb = 0;
 	}
+	{   // chained-workgroup classes: the ticket tables and the mailboxes
+		size_t mw = 0;
+		bool any = false;
+		for (int kc = 0; kc < WM_KSW_NCLASS - WM_KSW_CHAIN; ++kc) {
+			const int sw = 128 * wm_ksw_chain_bp[kc >> 2];
+			const std::vector<int> &o = b->order[WM_KSW_CHAIN + kc];
+			std::vector<uint4> &cm = b->cmap[kc];
+			b->d_cmap[kc] = 0;
+			for (size_t jo = 0; jo < o.size(); ++jo) {
+				const wm_ksw_djob_t &d = b->jobs[o[jo]];
+				const int nwv = wm_chain_nwv(d.n_col, d.tlen, sw);
+				for (int wv = 0; wv < nwv; ++wv) cm.push_back(make_uint4((unsigned)jo, (unsigned)wv, (unsigned)(mw / 16), (unsigned)nwv));
+				mw += ((size_t)wm_chain_box::words(nwv) + 15) & ~(size_t)15;
+			}
+			if (!cm.empty()) { any = true; b->d_cmap[kc] = (uint4*)arena_take(c, cm.size() * sizeof(uint4)); if (!b->d_cmap[kc]) b->d_tb = 0; }
+		}
+		if (any) {
+			b->mail_words = mw;
+			b->d_mail = (wm_mbox_t*)arena_take(c, mw * 8 + 256);
+			b->d_tickets = (int*)arena_take(c, 64 * sizeof(int));
+			if (!b->d_mail || !b->d_tickets) b->d_tb = 0;
+		}
+	}
 	if (!b->d_jobs || !b->d_order || !b->d_res || !b->d_off || !b->d_total || !b->d_err || !b->d_seqs || (any_zd && !b->d_zd) || (pos && !d_src) || !b->d_cig || !b->d_pool || !b->d_tb) {
 		c->arena_used = b->arena_mark;
 		delete b;
@@ -763,6 +839,8 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 	} else if (slab_bytes) HIPCHK(hipMemcpyAsync(b->d_seqs, seqs + slab_lo, slab_bytes, hipMemcpyHostToDevice, c->stream));
 	if (!b->goff.empty()) HIPCHK(hipMemcpyAsync(b->d_goff, b->goff.data(), b->goff.size() * 8, hipMemcpyHostToDevice, c->stream));
 	if (!b->b3off.empty()) HIPCHK(hipMemcpyAsync(b->d_b3off, b->b3off.data(), b->b3off.size() * 8, hipMemcpyHostToDevice, c->stream));
+	for (int kc = 0; kc < WM_KSW_NCLASS - WM_KSW_CHAIN; ++kc)
+		if (!b->cmap[kc].empty()) HIPCHK(hipMemcpyAsync(b->d_cmap[kc], b->cmap[kc].data(), b->cmap[kc].size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(ctx_sync(c));             // (the host tables above are read by the copies until here)
 	*out = b;
 	return WM_OK;
@@ -819,6 +897,10 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	if (n == 0) return WM_OK;
 	// degenerate jobs get the result of ksw_reset_extz (src/ksw2.h:153-158)
 	HIPCHK(hipMemsetAsync(b->d_err, 0, 4, c->stream));
+	if (b->d_mail) {            // mailboxes of the chained-workgroup classes: stamps -1, progress -1, STOP "none"; ticket counters 0
+		HIPCHK(hipMemsetAsync(b->d_mail, 0xff, b->mail_words * 8, c->stream));
+		HIPCHK(hipMemsetAsync(b->d_tickets, 0, 64 * sizeof(int), c->stream));
+	}
 	if (!b->degenerate.empty()) {
 		wm_ksw_dres_t z;
 		memset(&z, 0, sizeof(z));
@@ -884,7 +966,7 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	// launch order: the classes with the longest single jobs first
 	int lorder[WM_KSW_NCLASS], nl = 0;
 	lorder[nl++] = WM_KSW_GENERIC; lorder[nl++] = WM_KSW_BLOCK3; lorder[nl++] = WM_KSW_BLOCK2; lorder[nl++] = WM_KSW_BLOCK;
-	for (int k = WM_KSW_NCLASS - 1; k >= WM_KSW_STRIPE; --k) lorder[nl++] = k;
+	for (int k = WM_KSW_NCLASS - 1; k >= WM_KSW_STRIPE; --k) lorder[nl++] = k;          // (the chained-workgroup classes, then the stripe classes)
 	for (int k = WM_KSW_BLOCK - 1; k >= 0; --k) lorder[nl++] = k;
 	for (int li = 0; li < nl; ++li) {
 		const int k = lorder[li];
@@ -913,6 +995,12 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 				HIPCHK(hipFuncSetAttribute((const void*)ksw_block_kernel<WM_KSW_BLK2_K, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 				hipLaunchKernelGGL((ksw_block_kernel<WM_KSW_BLK2_K, 0>), dim3(nk), dim3(64 * WM_KSW_BLK_NWV), lds, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, (int)WM_KSW_BLK3_SEQ_LDS, (int*)b->d_b3state, b->d_b3off);
 			}
+			continue;
+		}
+		if (k >= WM_KSW_CHAIN) {
+			const int kc = k - WM_KSW_CHAIN, var = kc & 3, nw = (int)b->cmap[kc].size();
+			if (wm_ksw_chain_bp[kc >> 2] == 2) launch_chain<2>(var, nw, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, b->d_cmap[kc], b->d_tickets + kc, b->d_mail);
+			else launch_chain<4>(var, nw, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, b->d_cmap[kc], b->d_tickets + kc, b->d_mail);
 			continue;
 		}
 		if (k >= WM_KSW_STRIPE) {
@@ -1013,7 +1101,7 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 				}
 			}
 		}
-	if (b->h_err == 2) return set_err(WM_EINTERNAL, "a stripe-pipelined alignment kernel gave up waiting for a neighbouring wavefront (watchdog, ksw_stripe_kernel.h); WM_KSW_STRIPE=0 routes around it");
+	if (b->h_err == 2) return set_err(WM_EINTERNAL, "a stripe-pipelined / chained-workgroup alignment kernel gave up waiting for a neighbouring wavefront (watchdog, ksw_stripe_kernel.h, ksw_chain_kernel.h); WM_KSW_CHAIN=0 / WM_KSW_STRIPE=0 route around them");
 	if (b->h_err) return set_err(WM_EINTERNAL, "cigar slot overflow in backtrack");
 	return WM_OK;
 }

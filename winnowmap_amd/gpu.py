@@ -177,6 +177,13 @@ def set_ksw_routing(on=-1, rows4=-1, rows8=-1):
     lib().wm_ksw_set_routing(on, rows4, rows8)
 
 
+def set_ksw_chain_routing(mode=-1, min_rows_exact=-1, bp=-1):
+    """wm_ksw_set_chain_routing: which alignments run on the chained-workgroup kernels (results never depend on it)"""
+    lib().wm_ksw_set_chain_routing.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib().wm_ksw_set_chain_routing.restype = None
+    lib().wm_ksw_set_chain_routing(mode, min_rows_exact, bp)
+
+
 def build_defines():
     """the kernel-variant defines the loaded library was compiled with (wm_build_defines)"""
     lib().wm_build_defines.restype = C.c_char_p
