@@ -72,6 +72,9 @@ CONFIGS = {
     # BASELINE.json configs[1] / configs[2]: reads per step = the reference's 1-Gbase mini-batch (-K 1G)
     2: {"preset": "map-ont", "profile": "ont", "read_len": 15000, "reads_per_step": 65536, "sv_frac": 0.01, "seed": 4, "label": "ONT-profile"},
     3: {"preset": "map-pb", "profile": "hifi", "read_len": 20000, "reads_per_step": 50000, "sv_frac": 0.0, "seed": 5, "label": "HiFi-profile"},
+    # BASELINE.json configs[3] on ONE GPU (one rank's share of "1M x 15 kb vs 3 Gb, sharded across 8"): the same reads against a 3-Gbase reference — the index
+    # (~1.2 x 10^8 minimizers, a 2^28-slot table) no longer sits in L2, which is what changes for the seed stage (src/index.c:88-105)
+    4: {"preset": "map-ont", "profile": "ont", "read_len": 15000, "reads_per_step": 65536, "sv_frac": 0.01, "seed": 4, "label": "ONT-profile", "ref_mb": 3000.0},
 }
 
 
@@ -158,7 +161,7 @@ def ksw_class_name(k):
     spelled as rocprofv3 prints the instantiation ksw_dpp_kernel<BP, CLIP, HASN, EXACT> (jobs with an N run on the CLIP instantiation)"""
     if k >= 52:                                                    # chained-workgroup classes: WM_KSW_CHAIN + geometry * 4 + CLIP * 2 + HASN
         g, v = (k - 52) >> 2, (k - 52) & 3
-        return "ksw_chain_kernel<%s, %s, %s>" % ((2, 4)[g], str(bool(v & 2) or bool(v & 1)).lower(), str(bool(v & 1)).lower())
+        return "ksw_chain_kernel<%s, %s, %s, *>" % ((2, 4)[g], str(bool(v & 2) or bool(v & 1)).lower(), str(bool(v & 1)).lower())      # (two kernels per class: <.., EXACT>)
     if k >= 28:                                                    # stripe classes: WM_KSW_STRIPE + geometry * 4 + CLIP * 2 + HASN
         g, v = (k - 28) >> 2, (k - 28) & 3
         return "ksw_stripe_kernel<%s, %s, %s>" % (("2, 4", "2, 8", "4, 8", "8, 8", "1, 16", "2, 16")[g], str(bool(v & 2) or bool(v & 1)).lower(), str(bool(v & 1)).lower())
@@ -287,7 +290,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=int(os.environ.get("WM_BENCH_CONFIG", 2)), choices=sorted(CONFIGS))
     ap.add_argument("--reads-per-step", type=int, default=int(os.environ.get("WM_BENCH_READS", 0)))
-    ap.add_argument("--ref-mb", type=float, default=float(os.environ.get("WM_BENCH_REF_MB", 250)))
+    ap.add_argument("--ref-mb", type=float, default=float(os.environ.get("WM_BENCH_REF_MB", 0)))
     ap.add_argument("--read-len", type=int, default=0)
     ap.add_argument("--threads", type=int, default=int(os.environ.get("WM_BENCH_THREADS", 0)))
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("WM_BENCH_CPU_SAMPLE", -1)),
@@ -296,6 +299,7 @@ def main():
     cfg = CONFIGS[args.config]
     args.reads_per_step = args.reads_per_step or cfg["reads_per_step"]
     args.read_len = args.read_len or cfg["read_len"]
+    args.ref_mb = args.ref_mb or cfg.get("ref_mb", 250.0)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher of N ranks (one per GPU) — never run 1 rank and call it N

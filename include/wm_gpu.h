@@ -53,6 +53,8 @@ const char *wm_build_defines(void);
 int wm_device_count(void);
 /* time of the last batch call's kernels on the context's stream, measured with HIP events (ms) */
 float wm_last_kernel_ms(const wm_ctx_t *ctx);
+/* the HIP device a context lives on (what wm_ctx_create was given); -1 for NULL */
+int wm_ctx_device(const wm_ctx_t *ctx);
 
 /* ---- ksw2 extension alignment ------------------------------------------------------------------- */
 /* Scoring of one batch; mirrors the arguments of ksw_extd2_sse: match/mismatch/N scores are mat[0],

@@ -3,7 +3,7 @@
 // the mailbox words are 64-bit atomics, exactly the device protocol. The host scheduler supplies the interleavings; `start_skew` > 0 additionally starts
 // the wavefronts in ticket order with a delay, so that consumers really are not there yet when their producers run into back-pressure.
 // WM_CHAIN_EVENT counts the rare paths, WM_CHAIN_SPIN is a watchdog on the polling loops (a protocol deadlock aborts with the place).
-//   emu_chain_extd2(..., force): 400 + bp_index * 10 + (CLIP * 2 + HASN); bp_index 0, 1, 2 = 1, 2, 4 register pairs per wavefront (128 / 256 / 512-lane stripes)
+//   emu_chain_extd2(..., force): 400 + bp_index * 10 + (CLIP * 2 + HASN); bp_index 1, 2 = 2, 4 register pairs per wavefront (256 / 512-lane stripes)
 #include <atomic>
 static std::atomic<long> g_ev[16];
 #define WM_CHAIN_EVENT(k) (++g_ev[k])
@@ -31,16 +31,18 @@ template <int BP> static int run_chain(int variant, const wm_ksw_score_t &sc, co
 		if (g_start_skew_us > 0 && w > 0) std::this_thread::sleep_for(std::chrono::microseconds(g_start_skew_us));
 		th.emplace_back([&, w]() {
 			simt::wave_slot() = 0; simt::exec_mask() = ~0ull;
+			std::vector<int> tbsv(wm_chain_box::GROUP * 32 * BP, 0x5a5a5a5a);       // the wavefront's LDS: traceback rows of the group being staged
+			int *tbs = tbsv.data();
 			if (exact) {
-				if (clip && hasn) wmk::ksw_dp_chain<BP, true, true, true>(sc, jb, seqs, tb, mb.data(), nwv, w, res);
-				else if (clip) wmk::ksw_dp_chain<BP, true, false, true>(sc, jb, seqs, tb, mb.data(), nwv, w, res);
-				else if (hasn) wmk::ksw_dp_chain<BP, false, true, true>(sc, jb, seqs, tb, mb.data(), nwv, w, res);
-				else wmk::ksw_dp_chain<BP, false, false, true>(sc, jb, seqs, tb, mb.data(), nwv, w, res);
+				if (clip && hasn) wmk::ksw_dp_chain<BP, true, true, true>(sc, jb, seqs, tb, mb.data(), nwv, w, tbs, res);
+				else if (clip) wmk::ksw_dp_chain<BP, true, false, true>(sc, jb, seqs, tb, mb.data(), nwv, w, tbs, res);
+				else if (hasn) wmk::ksw_dp_chain<BP, false, true, true>(sc, jb, seqs, tb, mb.data(), nwv, w, tbs, res);
+				else wmk::ksw_dp_chain<BP, false, false, true>(sc, jb, seqs, tb, mb.data(), nwv, w, tbs, res);
 			} else {
-				if (clip && hasn) wmk::ksw_dp_chain<BP, true, true, false>(sc, jb, seqs, tb, mb.data(), nwv, w, res);
-				else if (clip) wmk::ksw_dp_chain<BP, true, false, false>(sc, jb, seqs, tb, mb.data(), nwv, w, res);
-				else if (hasn) wmk::ksw_dp_chain<BP, false, true, false>(sc, jb, seqs, tb, mb.data(), nwv, w, res);
-				else wmk::ksw_dp_chain<BP, false, false, false>(sc, jb, seqs, tb, mb.data(), nwv, w, res);
+				if (clip && hasn) wmk::ksw_dp_chain<BP, true, true, false>(sc, jb, seqs, tb, mb.data(), nwv, w, tbs, res);
+				else if (clip) wmk::ksw_dp_chain<BP, true, false, false>(sc, jb, seqs, tb, mb.data(), nwv, w, tbs, res);
+				else if (hasn) wmk::ksw_dp_chain<BP, false, true, false>(sc, jb, seqs, tb, mb.data(), nwv, w, tbs, res);
+				else wmk::ksw_dp_chain<BP, false, false, false>(sc, jb, seqs, tb, mb.data(), nwv, w, tbs, res);
 			}
 		});
 	}
@@ -78,7 +80,7 @@ int emu_chain_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *tar
 	memset(&res, 0x77, sizeof(res));
 	const int variant = klass & 7;
 	switch (bpi) {
-	case 0: run_chain<1>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
+	case 0: return -1;                              // (one pair per wavefront: not a geometry of this kernel any more)
 	case 1: run_chain<2>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
 	default: run_chain<4>(variant, sc, jb, seqs.data(), tb.data(), &res); break;
 	}

@@ -235,12 +235,19 @@ struct lds_msg_raw { int s; int o[8]; };
 inline void lds_ld_msg_issue(const int *p, lds_msg_raw &m) { m.s = lds_ld_msg(p, m.o); }
 inline int lds_msg_take(const lds_msg_raw &m, int (&o)[8]) { for (int i = 0; i < 8; ++i) o[i] = m.o[i]; return m.s; }
 inline void spin_pause() { sched_yield(); }
+inline void long_pause() { sched_yield(); }
+inline void poll_pause(int) { sched_yield(); }
 // cross-workgroup mailbox words (csrc/simt.h): 64-bit {value, stamp}, one atomic each
+inline void lds_ld4(const int *p, const V<int> &idx, V<int> (&o)[4]) { for (int k = 0; k < 4; ++k) for (int i = 0; i < WAVE; ++i) if (on(i)) { WM_EMU_ASSERT((idx.v[i] & 3) == 0); o[k].v[i] = p[idx.v[i] + k]; } }
+inline V<long long> mbox_pack(const V<int> &val, const V<int> &stamp) { V<long long> r; for (int i = 0; i < WAVE; ++i) r.v[i] = (long long)(((unsigned long long)(unsigned)stamp.v[i] << 32) | (unsigned)val.v[i]); return r; }
 inline V<long long> mbox_pack(const V<int> &val, int stamp) { V<long long> r; for (int i = 0; i < WAVE; ++i) r.v[i] = (long long)(((unsigned long long)(unsigned)stamp << 32) | (unsigned)val.v[i]); return r; }
 inline V<int> mbox_val(const V<long long> &w) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = (int)(unsigned)(unsigned long long)w.v[i]; return r; }
 inline V<int> mbox_stamp(const V<long long> &w) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = (int)(unsigned)((unsigned long long)w.v[i] >> 32); return r; }
 inline V<long long> mbox_ld(const wm_mbox_t *p, const V<int> &idx) { V<long long> r(0); for (int i = 0; i < WAVE; ++i) if (on(i)) r.v[i] = (long long)__atomic_load_n(p + idx.v[i], __ATOMIC_SEQ_CST); return r; }
 inline void mbox_st(wm_mbox_t *p, const V<int> &idx, const V<long long> &v) { for (int i = 0; i < WAVE; ++i) if (on(i)) __atomic_store_n(p + idx.v[i], (wm_mbox_t)v.v[i], __ATOMIC_SEQ_CST); }
+inline V<long long> &mbox_prefetch_reg() { static thread_local V<long long> r(0); return r; }
+inline void mbox_prefetch(const wm_mbox_t *p, const V<int> &idx) { WM_EMU_ASSERT(exec_mask() == ~0ull); mbox_prefetch_reg() = mbox_ld(p, idx); }      // (the emulator takes the snapshot where the load is issued)
+inline V<long long> mbox_prefetched() { return mbox_prefetch_reg(); }
 inline int mbox_ld_word(const int *p, int i) { return __atomic_load_n(p + i, __ATOMIC_SEQ_CST); }
 inline void mbox_st_word(int *p, int i, int v) { if (exec_mask()) __atomic_store_n(p + i, v, __ATOMIC_SEQ_CST); }
 template <int L> V<int> wrlane(const V<int> &acc, int v) { static_assert(L >= 0 && L < WAVE, "lane"); V<int> r = acc; r.v[L] = v; return r; }

@@ -1,5 +1,6 @@
 """GPU: the full product path (sketch → seed → chain → align kernels behind the C-ABI, host MCAS glue) must
 reproduce the reference's hits and CIGARs bit-for-bit on the golden cases; plus PAF/SAM text sanity."""
+import ctypes as C
 import tempfile
 import numpy as np
 import pytest
@@ -214,6 +215,8 @@ def test_index_handed_on_device_to_device_and_the_file_loop_over_two_mappers(ctx
     idx.upload(ctx)
     n_dev = int(gpu.lib().wm_device_count())
     ctx2 = gpu.Context(1 if n_dev > 1 else 0, 2 << 30)          # the second GPU of the node when there is one (hipMemcpyPeer across devices), else a second context of this one
+    gpu.lib().wm_ctx_device.argtypes = [C.c_void_p]
+    assert gpu.lib().wm_ctx_device(ctx2._h) == (1 if n_dev > 1 else 0)          # (on a multi-GPU box this test must really cross devices — hipMemcpyPeer over xGMI)
     idx.upload_peer(ctx2, ctx)
     with pytest.raises(gpu.WmError):                            # source == destination used to free the arrays it then copied from
         idx.upload_peer(ctx, ctx)

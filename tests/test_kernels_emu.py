@@ -600,7 +600,7 @@ def _chain_run(E, cases, forces):
         for force in forces:
             n, ez, cig, klass = emu_ksw(E, c, force)
             if n < 0:
-                assert n == -1, (n, force, len(c["q"]), len(c["t"]), c["w"], hex(c["flag"]))      # -1: needs CLIP / HASN and the variant lacks it; anything else is a failure
+                assert n == -1, (n, force, len(c["q"]), len(c["t"]), c["w"], hex(c["flag"]))      # -1: needs CLIP / HASN and the variant lacks it (or no such geometry); anything else is a failure
                 continue
             if o is None:
                 o = W.o_ksw_extd2(c["q"], c["t"], mat=W.simple_mat(c["a"], c["b"], 1), q=c["q_"], e=c["e"], q2=c["q2"], e2=c["e2"],

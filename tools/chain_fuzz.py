@@ -11,7 +11,7 @@ if __name__ == "__main__":
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
     max_len = int(sys.argv[3]) if len(sys.argv) > 3 else 700
-    geos = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0, 1]
+    geos = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [1, 2]
     E = T._load_chain()
     if len(sys.argv) > 5:
         E.emu_chain_start_skew(int(sys.argv[5]))

@@ -125,8 +125,15 @@ def config5(args):
     del ref
     log("reference %.0f Mb, %d contigs of %d Mb (%.0f s)" % (total / 1e6, len(seqs), args.contig_mb, time.time() - t0))
     ref_paf = os.path.join(tmp, "ref.paf")
-    t_ref, err = run_ref(["-t", "16", "-cx", "asm20", fa, rq], ref_paf)
-    log("reference binary: %.0f s" % t_ref)
+    t_ref, t_ref_map, err = 0.0, None, ""
+    if not args.skip_ref:
+        t_ref, err = run_ref(["-t", "16", "-cx", "asm20", fa, rq], ref_paf)
+        import re
+        m_idx = re.search(r"\[M::main::([0-9.]+)\*[0-9.]+\] loaded/built the index", err)
+        m_end = re.search(r"Real time: ([0-9.]+) sec", err)
+        if m_idx and m_end:
+            t_ref_map = float(m_end.group(1)) - float(m_idx.group(1))          # the reference's mapping phase alone (src/main.c:401, :441)
+        log("reference binary: %.0f s, of which mapping %s s" % (t_ref, "%.1f" % t_ref_map if t_ref_map is not None else "?"))
     ctx = gpu.Context(0, int(args.arena_gb) << 30)
     t0 = time.time()
     idx, ist = gpu.Index.build_on_device(ctx, fa, None, k=19, w=50, n_threads=16)
@@ -139,15 +146,19 @@ def config5(args):
     ours, hits, _, _ = m.map([b"ctg%d" % i for i in range(len(seqs))], seqs)
     t_map = time.time() - t0
     log("mapped %d contigs, %d hits (%.1f s)" % (len(seqs), len(hits), t_map))
-    with open(ref_paf, "rb") as f:
-        d = parity.diff_texts(f.read(), ours, sam=False)
+    if args.skip_ref:
+        d = {"reads": 0, "hits": len(hits), "mismatches": 0, "examples": []}
+    else:
+        with open(ref_paf, "rb") as f:
+            d = parity.diff_texts(f.read(), ours, sam=False)
     ks = m.kernel_stats()
+    hs = m.host_stats()
     n_mini = int(idx.n_minimizers)
     m.close(); idx.close(); ctx.close()
     wide = {k: v for k, v in ks.items() if v[2] > 0}
     return {"record": "BASELINE config 5 contig size, one MI355X", "reference_mb": total / 1e6, "contigs": len(seqs), "contig_mb": args.contig_mb, "preset": "asm20 (k 19, w 50: src/options.c:112-115 leaves w at its default)",
             "index": {"where": "device", "minimizers": n_mini, "seconds": round(t_idx, 1)}, "map_seconds": round(t_map, 1), "gbps": sum(len(s) for s in seqs) / t_map / 1e9,
-            "reference_binary_seconds": round(t_ref, 1),
+            "reference_binary_seconds": round(t_ref, 1), "reference_mapping_seconds": None if t_ref_map is None else round(t_ref_map, 1), "host": hs,
             "ksw_classes_used": {str(k): {"ms": round(v[0], 1), "cells": v[1], "launches": v[2]} for k, v in wide.items()},
             "parity": {"reads_with_hits": d["reads"], "hits": d["hits"], "mismatches": d["mismatches"], "examples": d.get("examples", [])[:3],
                        "compared": "PAF incl. cg:Z vs winnowmap_ref -t 16 -cx asm20 on the same files"}}
@@ -163,6 +174,7 @@ def main():
     ap.add_argument("--ref-mb", type=float, default=600.0)
     ap.add_argument("--arena-gb", type=float, default=40.0)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--skip-ref", action="store_true", help="config5: no reference run, no parity (profiling runs)")
     args = ap.parse_args()
     if not os.path.exists(REF_BIN):
         sys.exit("oracle/_ref/winnowmap_ref is not built (python -m winnowmap_amd.build in the container that has /root/reference)")

@@ -10,7 +10,7 @@
 // has room, and a row costs what ONE wavefront issues for its BP pairs — the left neighbour is simply further ahead in the pipeline.
 //
 // The protocol (cell arithmetic, epochs, bookkeeping hand-over, tie rule: exactly ksw_dp_stripe; what differs is only how wavefronts talk):
-//   * MAILBOX. Per job a block of 64-bit words in HBM (wm_chain_box): a STOP word, one progress word per wavefront, one ring of R = 32 row slots
+//   * MAILBOX. Per job a block of 64-bit words in HBM (wm_chain_box): a STOP word, one progress word per wavefront, one ring of R = 128 row slots
 //     x 16 words per wavefront (messages to its right neighbour). Every word is {value, row stamp} written and read as ONE relaxed agent-scope
 //     atomic (simt.h: mbox_*): coherent across the XCDs' L2s without a fence, and self-validating — a reader that finds stamp r in a word holds the
 //     value published for row r. The host fills the block with 0xff before the launch (stamp -1, progress -1, STOP "none").
@@ -39,10 +39,13 @@
 #ifndef WM_CHAIN_SPIN
 #define WM_CHAIN_SPIN(where, r, a, wv, extra) ((void)0)
 #endif
+#ifndef WM_CHAIN_BACKOFF
+#define WM_CHAIN_BACKOFF 2                // long pauses (~3.4 us each) of a consumer whose prefetched group was not there (measured neutral between 0 and 8: misses are rare)
+#endif
 
 // mailbox geometry of one job, in 64-bit words (host and device)
 struct wm_chain_box {
-	static constexpr int R = 32, SLOT = 16, GROUP = 4;               // ring slots per wavefront, words per slot, rows fetched by one load
+	static constexpr int R = 128, SLOT = 16, GROUP = 4;              // ring slots per wavefront, words per slot, rows fetched by one load
 	static constexpr int I_STOP = 0, I_PROG = 16;                    // 32-bit views of the head: STOP word, progress words
 #ifdef __HIPCC__
 	__host__ __device__
@@ -71,10 +74,12 @@ enum { CM_X = 0, CM_V = 1, CM_X2 = 2, CM_H = 3, CM_PM = 4, CM_PRI = 5, CM_HST0 =
 
 template <int BP, bool CLIP, bool HASN, bool EXACT>
 WM_DEV void ksw_dp_chain(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const uint8_t *__restrict__ seqs,
-                         uint8_t *__restrict__ tb_arena, wm_mbox_t *mb, const int nwv, const int wv, wm_ksw_dres_t *__restrict__ res)
+                         uint8_t *__restrict__ tb_arena, wm_mbox_t *mb, const int nwv, const int wv, int *tbs /* LDS: wm_chain_box::GROUP * 32 * BP ints */,
+                         wm_ksw_dres_t *__restrict__ res)
 {
 	typedef wm_chain_box L;
-	constexpr int SW = 128 * BP, B = 2 * BP, NW = (B + 3) / 4, R = L::R;
+	static_assert(BP == 2 || BP == 4, "BP");
+	constexpr int SW = 128 * BP, B = 2 * BP, NW = (B + 3) / 4, R = L::R, NDW = BP / 2;       // NDW: traceback dwords per thread and row (4 chunks each)
 	constexpr int BIG = 0x7fffffff;
 	const int qlen = jb.qlen, tlen = jb.tlen, flag = jb.flag, zdrop = jb.zdrop;
 	const int w = jb.w < 0 ? (tlen > qlen ? tlen : qlen) : jb.w;
@@ -120,20 +125,20 @@ WM_DEV void ksw_dp_chain(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 	auto stop_by = [&](int row) { return (unsigned)mbox_ld_word(ctl, L::I_STOP) <= (unsigned)row; };      // a z-drop in a row <= `row` (or the watchdog) ended the alignment
 
 	// ---- the inbox: the left neighbour's slots of four rows per load, the next group in flight ----
-	V<long long> wcur = 0, wnxt = 0;
-	int cur_g = -4, nxt_g = -4;                                       // row groups (multiples of 4) held by wcur / wnxt
+	V<long long> wcur = 0;
+	int cur_g = -4, nxt_g = -4;                                       // row groups (multiples of 4) held by wcur / on their way (simt.h: mbox_prefetch)
 	int my_prog = -1;                                                // rows of the left ring up to here may be overwritten (published in I_PROG + wv)
 	auto ld_group = [&](int g) { return mbox_ld(ring_in + (g & (R - 1)) * L::SLOT, ln); };
 	auto publish_prog = [&](int p) { if (p > my_prog) { my_prog = p; mbox_st_word(ctl, L::I_PROG + wv, p); } };
 	// Where the waits go matters more than what they wait for (ksw_packed_kernel.h: loads_land): gfx9 has ONE counter for vector loads and stores, and a wait the
-	// compiler places at the JOIN behind a rare branch runs on every row and drains that row's traceback stores. So every load below is waited for explicitly
-	// INSIDE the branch that issued it (loads_land), except the prefetch, whose first use is inside the next group switch.
+	// compiler places at the JOIN behind a rare branch runs on every row. Every load below is waited for explicitly INSIDE the branch that issued it; the
+	// prefetch of the next group is invisible to the compiler altogether and is collected at the next group switch, a group of rows after it was issued.
 	auto need_group = [&](int g) {
 		if (cur_g != g) {
 			WM_KEEP_BRANCH();
-			if (nxt_g == g) { loads_land(); wcur = wnxt; } else { wcur = ld_group(g); loads_land(); }
+			if (nxt_g == g) wcur = mbox_prefetched(); else { wcur = ld_group(g); loads_land(); }
 			cur_g = g;
-			wnxt = ld_group(g + L::GROUP); nxt_g = g + L::GROUP;          // in flight across the next rows
+			mbox_prefetch(ring_in + ((g + L::GROUP) & (R - 1)) * L::SLOT, ln); nxt_g = g + L::GROUP;
 			publish_prog(g - 1);                                         // groups below g are never read again
 		}
 	};
@@ -144,15 +149,20 @@ WM_DEV void ksw_dp_chain(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 		const vbool mine = ln >= j16 && ln < hi;
 		if (any(mine && mbox_stamp(wcur) != row)) {                       // not there yet: poll (the reload is waited for inside the loop)
 			WM_KEEP_BRANCH();
+			// A consumer that polls eagerly stays right behind its producer: the group it prefetches is never there yet, and EVERY group then costs a
+			// polling round trip (measured: ~1 poll per group, profiles/r06_chain_timing_v2.txt). So a miss makes this wavefront fall back on purpose,
+			// by about three groups of rows, once: from then on its prefetches find their rows as long as it is not faster than its producer.
+			for (int k = 0; k < WM_CHAIN_BACKOFF; ++k) long_pause();
 			spins = 0;
 			do {
 				if (stop_by(row)) return false;
 				WM_CHAIN_SPIN(where, row, a_, wv, 0);
 				if (++spins > WM_STRIPE_SPIN_BUDGET) { give_up(); return false; }
-				spin_pause();
+				poll_pause(spins);                                           // (hundreds of wavefronts wait for their stripe at any time: uncached loads of a few hot lines, so not too often)
 				wcur = ld_group(row & ~(L::GROUP - 1));
 				loads_land();
 			} while (any(mine && mbox_stamp(wcur) != row));
+			if (nxt_g == cur_g + L::GROUP) mbox_prefetch(ring_in + (nxt_g & (R - 1)) * L::SLOT, ln);      // (the prefetch was taken before the pause: again, now that the producer is ahead)
 		}
 		const V<int> lo = mbox_val(wcur);
 #pragma unroll
@@ -162,6 +172,48 @@ WM_DEV void ksw_dp_chain(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 			for (int k = 0; k < 8; ++k) ez[k] = readlane(lo, j16 + 8 + k);
 		}
 		return true;
+	};
+
+	// ---- a GROUP of rows at a time to memory: traceback and outgoing messages ----
+	// Every vector-memory wait of the row loop (there is one counter for loads and stores) sits at a group switch, where everything outstanding was
+	// issued four rows ago: the traceback bytes of a row go to LDS (one dword per thread = its four chunks' cells) and the rows of a group are written
+	// from there with dword stores when the next group begins; the messages to the right neighbour are collected in one register (lanes 16j + k = word k
+	// of row g + j) and leave with ONE 64-lane store. First measurement of the per-row form (profiles/r06_chain_timing_v1.txt): 2.1 us per row of which
+	// 0.3 + 0.4 + 0.13 us were such waits — a wait for the prefetched group also drained the row's traceback stores (~1.2 us to HBM and back).
+	int stg_g = -4, stg_mask = 0, stg_a = 0;                         // the group being staged (rows stg_g ..), its rows with traceback in LDS, the stripe they belong to
+	int out_mask = 0;                                                // ... its rows with a message in outv
+	V<int> outv = 0;
+	auto flush_group = [&]() {
+		if (stg_mask) {
+			WM_KEEP_BRANCH();
+			lds_sync();
+			const V<int> l0 = (ln << 2) & 63, c = (ln >> 4) & 3;          // dword ln of a 256-lane block = target lanes 4 ln ..: chunk c, threads l0 .. l0 + 3
+			const V<int> psel = ((c + 4) << 8) | c;                       // v_perm_b32: {byte c of the first operand's partner, byte c of the other}
+#pragma unroll
+			for (int j = 0; j < L::GROUP; ++j) {
+				if (!(stg_mask >> j & 1)) continue;
+				const int rr = stg_g + j;
+				ksw_geo_t gg;
+				ksw_geo<CLIP>(rr, qlen, tlen, w, gg);                    // (a staged row exists: its band is not empty)
+				int *trow = (int*)(tbp + (size_t)rr * jb.n_col);         // column of lane t = t - st; st, n_col, the stripe start: multiples of 16 -> dword aligned
+#pragma unroll
+				for (int d = 0; d < NDW; ++d) {
+					V<int> q4[4];
+					lds_ld4(tbs, (j * NDW + d) * 64 + l0, q4);
+					const V<int> lo = perm(q4[1], q4[0], psel), hi = perm(q4[3], q4[2], psel);
+					const V<int> word = perm(hi, lo, 0x05040100);
+					const V<int> t0 = (ln << 2) + (stg_a + 256 * d);
+					WM_IF(t0 >= gg.st && t0 <= gg.en) gst(trow, (t0 - gg.st) >> 2, word); WM_END
+				}
+			}
+			stg_mask = 0;
+		}
+		if (out_mask) {
+			WM_KEEP_BRANCH();
+			const V<int> jr = ln >> 4;
+			WM_IF(((V<int>(out_mask) >> jr) & 1) != 0) mbox_st(ring_out + (stg_g & (R - 1)) * L::SLOT, ln, mbox_pack(outv, jr + stg_g)); WM_END
+			out_mask = 0;
+		}
 	};
 
 	V<int> U[BP], Vv[BP], X[BP], Y[BP], X2[BP], Y2[BP];
@@ -255,7 +307,7 @@ WM_DEV void ksw_dp_chain(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 			if (r >= n_rows) { all_done = true; break; }
 			if (!ksw_geo<CLIP>(r, qlen, tlen, w, g)) { end_row = r; all_done = true; break; }
 			const int st = g.st, en = g.en;
-			if (st >= a + SW) { s += nwv; WM_CHAIN_EVENT(0); leave = true; break; }          // the hull has left this stripe for good
+			if (st >= a + SW) { flush_group(); stg_g = -4; s += nwv; WM_CHAIN_EVENT(0); leave = true; break; }          // the hull has left this stripe for good (its staged rows go out; the next stripe starts a group of its own)
 			int r_end = n_rows;                                            // first row of the next epoch
 			{
 				const int X_ = st + 16;                                    // st0 reaches X_: r - qlen + 1 >= X_, or (r - w + 1) >> 1 >= X_
@@ -310,7 +362,27 @@ WM_DEV void ksw_dp_chain(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 				WM_EMU_ASSERT(st0 / 16 * 16 == st && (en0 + 16) / 16 * 16 - 1 == en);
 				const int cend = st0 + (en0 - st0) / 16 * 16 + 15;
 				const int sched = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
-				if (left_now) need_group(r & ~(L::GROUP - 1));               // (the group's load is in flight while the cells run)
+				if ((r & ~(L::GROUP - 1)) != stg_g) {                        // a new group of rows begins
+					WM_KEEP_BRANCH();
+					if (left_now) need_group(r & ~(L::GROUP - 1));           // (first: its wait then only meets what was issued a group ago)
+					WM_ST_LAP(WM_ST_SCAN);
+					flush_group();
+					WM_ST_LAP(WM_ST_WAIT_RIGHT);                             // (diagnostic builds: this slot = writing the finished group out)
+					stg_g = r & ~(L::GROUP - 1); stg_a = a;
+					if (pub && right_seen < stg_g + L::GROUP - 1 - R) {      // (the slots of this group still hold rows - R until the right neighbour has consumed them)
+						spins = 0;
+						bool halt = false;
+						for (;;) {
+							right_seen = mbox_ld_word(ctl, L::I_PROG + right_wv);
+							if (right_seen >= stg_g + L::GROUP - 1 - R) break;
+							if (stop_by(r)) { halt = true; stopped = true; break; }
+							WM_CHAIN_SPIN(2, r, a, wv, right_seen);
+							if (++spins > WM_STRIPE_SPIN_BUDGET) { give_up(); halt = true; break; }
+							poll_pause(spins);
+						}
+						if (halt) { all_done = true; break; }
+					}
+				} else if (left_now) need_group(r & ~(L::GROUP - 1));
 				WM_ST_LAP(WM_ST_SCAN);                                       // (diagnostic builds: the group switch = the wait for the prefetched group)
 
 				// ---- advance the query codes to row r: every lane takes the code of lane t - 1; the stripe's first lane takes query[r - a] ----
@@ -339,7 +411,6 @@ WM_DEV void ksw_dp_chain(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 				if (have_left) { px = m_x; pv = m_v; px2 = m_x2; }
 				const bool is_last = have_cells && en0 < a + SW;                // the band's last lane is here: this wavefront closes the row
 				V<int> hmax = KSW_NEG_INF;
-				uint8_t *trow = tbp + (size_t)r * jb.n_col;                    // column of lane t = t - st
 				// first-column / first-row boundary of lane r (:152-155): y, y2, u of that lane are reset before the cells
 				if (en >= r && r >= a && r < a + SW) {
 					WM_KEEP_BRANCH();
@@ -362,7 +433,7 @@ WM_DEV void ksw_dp_chain(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 				if constexpr (EXACT) { if (is_last) { WM_KEEP_BRANCH(); hprev = en0 - 1 < a ? m_h : h_of(en0 - 1); } }
 				const bool inject = first_here && !moved && st > a;
 
-				V<int> rX[BP], rV[BP], rX2[BP];
+				V<int> rX[BP], rV[BP], rX2[BP], tbp_[BP];
 #pragma unroll
 				for (int i = 0; i < BP; ++i) { rX[i] = ror1(X[i]); rV[i] = ror1(Vv[i]); rX2[i] = ror1(X2[i]); }
 				static_for_desc<BP>([&](auto IC) {
@@ -398,10 +469,9 @@ WM_DEV void ksw_dp_chain(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 					const V<int> ou = U[i];
 					V<int> nu, nv, nx, ny, nx2, ny2, p;
 					ksw_pcell(cc, sv, x1, v1, x21, Y[i], ou, Y2[i], nu, nv, nx, ny, nx2, ny2, p);
+					tbp_[i] = p;                                             // (bits 0-7 of each half: the traceback bytes of lanes c0 + thread, c0 + 64 + thread)
 					if (full_bits >> i & 1) {
 						U[i] = nu; Vv[i] = nv; X[i] = nx; Y[i] = ny; X2[i] = nx2; Y2[i] = ny2;
-						gst(trow, ln + (c0 - st), cast<uint8_t>(p));
-						gst(trow, ln + (c0 + 64 - st), cast<uint8_t>(lshr(p, 16)));
 					} else {
 						WM_KEEP_BRANCH();
 						if constexpr (CLIP) {
@@ -409,8 +479,6 @@ WM_DEV void ksw_dp_chain(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 							U[i] = bfi(m, nu, U[i]); Vv[i] = bfi(m, nv, Vv[i]); X[i] = bfi(m, nx, X[i]); Y[i] = bfi(m, ny, Y[i]);
 							X2[i] = bfi(m, nx2, X2[i]); Y2[i] = bfi(m, ny2, Y2[i]);
 						} else { U[i] = nu; Vv[i] = nv; X[i] = nx; Y[i] = ny; X2[i] = nx2; Y2[i] = ny2; }
-						WM_IF((vm[i] & 0xffff) != 0) gst(trow, ln + (c0 - st), cast<uint8_t>(p)); WM_END
-						WM_IF(lshr(vm[i], 16) != 0) gst(trow, ln + (c0 + 64 - st), cast<uint8_t>(lshr(p, 16))); WM_END
 					}
 					if constexpr (EXACT) {
 						// H += v (:320-345). Lanes outside the band keep their H; lane en0 takes H of its left neighbour + u
@@ -435,6 +503,12 @@ WM_DEV void ksw_dp_chain(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 						}
 					}
 				});
+				if (have_cells) {    // the row's traceback: one dword per thread and four chunks, staged in LDS until the group is written (lanes outside the hull are masked there)
+#pragma unroll
+					for (int d = 0; d < NDW; ++d)
+						lds_st(tbs, ln + ((r & (L::GROUP - 1)) * NDW + d) * 64, perm(tbp_[2 * d + 1], tbp_[2 * d], 0x06040200));
+					stg_mask |= 1 << (r & (L::GROUP - 1));
+				}
 				if constexpr (EXACT) { if (is_last && en0 == tlen - 1) { WM_KEEP_BRANCH(); h_en0 = h_of(en0); } }
 				moved = false;
 				WM_ST_LAP(WM_ST_CELLS);
@@ -546,36 +620,47 @@ WM_DEV void ksw_dp_chain(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 					if (in_tl0 >= 0) { trk = true; H0 = in_th0; last_H0_t = in_tl0; }
 				}
 
-				// ---- publish this row for the right neighbour ----
+				// ---- this row's message for the right neighbour joins the group's register ----
 				WM_ST_LAP(WM_ST_BOOK);
 				if (pub) {
-					if (right_seen < r - R) {                                  // (slot r % R still holds row r - R until the right neighbour has consumed it)
+					if (right_seen < stg_g + L::GROUP - 1 - R) {               // (only when this stripe began to publish inside the group: the check at the group switch did not run)
+						WM_KEEP_BRANCH();
 						spins = 0;
 						bool halt = false;
 						for (;;) {
 							right_seen = mbox_ld_word(ctl, L::I_PROG + right_wv);
-							if (right_seen >= r - R) break;
+							if (right_seen >= stg_g + L::GROUP - 1 - R) break;
 							if (stop_by(r)) { halt = true; stopped = true; break; }
 							WM_CHAIN_SPIN(2, r, a, wv, right_seen);
 							if (++spins > WM_STRIPE_SPIN_BUDGET) { give_up(); halt = true; break; }
-							spin_pause();
+							poll_pause(spins);
 						}
 						if (halt) { all_done = true; break; }
 					}
 					WM_ST_LAP(WM_ST_WAIT_RIGHT);
 					const bool with_ez = EXACT && en == a + SW - 1;
-					V<int> val = 0;
-					val = wrlane<CM_X>(val, lshr(readlane(X[BP - 1], 63), 16)); val = wrlane<CM_V>(val, lshr(readlane(Vv[BP - 1], 63), 16));
-					val = wrlane<CM_X2>(val, lshr(readlane(X2[BP - 1], 63), 16));
-					if constexpr (EXACT) {
-						val = wrlane<CM_H>(val, readlane(H[EXACT ? B - 1 : 0], 63)); val = wrlane<CM_PM>(val, pm); val = wrlane<CM_PRI>(val, ppri); val = wrlane<CM_HST0>(val, hst0);
-						if (with_ez) {
-							WM_KEEP_BRANCH();
-							val = wrlane<CM_EZ + 0>(val, ez_max); val = wrlane<CM_EZ + 1>(val, ez_max_t); val = wrlane<CM_EZ + 2>(val, ez_max_q); val = wrlane<CM_EZ + 3>(val, ez_mqe);
-							val = wrlane<CM_EZ + 4>(val, ez_mqe_t); val = wrlane<CM_EZ + 5>(val, ez_mte); val = wrlane<CM_EZ + 6>(val, ez_mte_q); val = wrlane<CM_EZ + 7>(val, ez_score);
-						}
-					} else { val = wrlane<CM_TH0>(val, out_th0); val = wrlane<CM_TL0>(val, out_tl0); }
-					WM_IF(ln < (with_ez ? 16 : 8)) mbox_st(ring_out + (r & (R - 1)) * L::SLOT, ln, mbox_pack(val, r)); WM_END
+					const int o_x = lshr(readlane(X[BP - 1], 63), 16), o_v = lshr(readlane(Vv[BP - 1], 63), 16), o_x2 = lshr(readlane(X2[BP - 1], 63), 16);
+					const int o_h = EXACT ? readlane(H[EXACT ? B - 1 : 0], 63) : 0;
+					auto put_row = [&](auto JC) {                              // lanes 16 j + k of outv = word k of row stg_g + j
+						constexpr int j16 = decltype(JC)::value * L::SLOT;
+						outv = wrlane<j16 + CM_X>(outv, o_x); outv = wrlane<j16 + CM_V>(outv, o_v); outv = wrlane<j16 + CM_X2>(outv, o_x2);
+						if constexpr (EXACT) {
+							outv = wrlane<j16 + CM_H>(outv, o_h); outv = wrlane<j16 + CM_PM>(outv, pm); outv = wrlane<j16 + CM_PRI>(outv, ppri); outv = wrlane<j16 + CM_HST0>(outv, hst0);
+							if (with_ez) {
+								WM_KEEP_BRANCH();
+								outv = wrlane<j16 + CM_EZ + 0>(outv, ez_max); outv = wrlane<j16 + CM_EZ + 1>(outv, ez_max_t); outv = wrlane<j16 + CM_EZ + 2>(outv, ez_max_q);
+								outv = wrlane<j16 + CM_EZ + 3>(outv, ez_mqe); outv = wrlane<j16 + CM_EZ + 4>(outv, ez_mqe_t); outv = wrlane<j16 + CM_EZ + 5>(outv, ez_mte);
+								outv = wrlane<j16 + CM_EZ + 6>(outv, ez_mte_q); outv = wrlane<j16 + CM_EZ + 7>(outv, ez_score);
+							}
+						} else { outv = wrlane<j16 + CM_TH0>(outv, out_th0); outv = wrlane<j16 + CM_TL0>(outv, out_tl0); }
+					};
+					switch (r & (L::GROUP - 1)) {
+					case 0: put_row(std::integral_constant<int, 0>{}); break;
+					case 1: put_row(std::integral_constant<int, 1>{}); break;
+					case 2: put_row(std::integral_constant<int, 2>{}); break;
+					default: put_row(std::integral_constant<int, 3>{}); break;
+					}
+					out_mask |= 1 << (r & (L::GROUP - 1));
 				}
 				row_done = r; was_last = is_last;
 				WM_ST_LAP(WM_ST_PUBLISH);
@@ -584,6 +669,7 @@ WM_DEV void ksw_dp_chain(const wm_ksw_score_t sc, const wm_ksw_djob_t jb, const 
 	}
 	WM_ST_FLUSH();
 
+	if (!gave_up) flush_group();            // (every way out of the row loop: the staged traceback rows are part of the result up to the stop row)
 	// ---- the alignment is over for this wavefront ----
 	// A wavefront that leaves normally reads no message any more and must not hold its left neighbour back. One that leaves because somebody ELSE ended
 	// the alignment keeps its progress word: the producers to its left then run into back-pressure within R rows and find the STOP word in that loop.

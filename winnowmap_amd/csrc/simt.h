@@ -265,17 +265,47 @@ WM_DEV int lds_msg_take(const lds_msg_raw &m, int (&o)[8])
 	return __builtin_amdgcn_readfirstlane(m.s);
 }
 WM_DEV void spin_pause() { __builtin_amdgcn_s_sleep(1); }
+WM_DEV void long_pause() { __builtin_amdgcn_s_sleep(127); }      // ~8 000 cycles
+// the pause between two polls of a word in memory: short at first, then ~0.5 us, then ~1.7 us (n = polls so far)
+WM_DEV void poll_pause(int n) { if (n < 4) __builtin_amdgcn_s_sleep(2); else if (n < 32) __builtin_amdgcn_s_sleep(20); else __builtin_amdgcn_s_sleep(64); }
 
 // ---- cross-WORKGROUP hand-over through global memory (ksw_chain_kernel.h) --------------------------------------------------------
 // The wavefronts of one alignment run as workgroups of their own, possibly on different XCDs (each XCD has its own L2). Every mailbox word is 64 bits
 // = {value, stamp} and travels as ONE relaxed agent-scope atomic: such an access is single-copy atomic and coherent across the XCDs (sc1 accesses go
 // past the non-coherent caches), so a reader that finds the stamp it expects has the value that was written with it — no fence on either side, nothing
 // to write back or invalidate (an agent-scope release / acquire pair costs an L2 write-back + invalidate: DESIGN "agent-scope fences").
+// four consecutive LDS ints (16-byte aligned index) in one ds_read_b128
+WM_DEV void lds_ld4(const int *p, int i, int (&o)[4])
+{
+	typedef int wm_i4 __attribute__((ext_vector_type(4)));
+	typedef __attribute__((address_space(3))) wm_i4 wm_lds_i4;
+	const wm_i4 a = *(const wm_lds_i4*)((const wm_lds_int*)p + i);
+	o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+}
 WM_DEV long long mbox_pack(int val, int stamp) { return (long long)(((unsigned long long)(unsigned)stamp << 32) | (unsigned)val); }
 WM_DEV int mbox_val(long long w) { return (int)(unsigned)(unsigned long long)w; }
 WM_DEV int mbox_stamp(long long w) { return (int)(unsigned)((unsigned long long)w >> 32); }
 WM_DEV long long mbox_ld(const wm_mbox_t *p, int i) { return (long long)__hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }      // per lane
 WM_DEV void mbox_st(wm_mbox_t *p, int i, long long v) { __hip_atomic_store(p + i, (wm_mbox_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }       // per lane, under the exec mask
+// A load that stays in flight across loop iterations must not live in a variable the compiler sees: its register allocator copies such a value at the joins of
+// the loop's branches, and every copy of a pending load is a wait (measured: one memory round trip per row, profiles/r06_chain_timing_v2.txt). The prefetch
+// therefore lands in two ACCUMULATION registers the compiler never touches (this library uses no MFMA and spills nothing there), issued and collected by hand:
+// mbox_prefetch starts the per-lane 64-bit load, mbox_prefetched waits for every outstanding vector-memory operation of the wave and returns the word.
+WM_DEV void mbox_prefetch(const wm_mbox_t *p, int i)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	const wm_mbox_t *q = p + i;
+	asm volatile("global_load_dwordx2 a[0:1], %0, off sc1" : : "v"(q) : "a0", "a1", "memory");
+#endif
+}
+WM_DEV long long mbox_prefetched()
+{
+	unsigned lo = 0, hi = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("s_waitcnt vmcnt(0)\n\tv_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1" : "=v"(lo), "=v"(hi) : : "memory");
+#endif
+	return (long long)(((unsigned long long)hi << 32) | lo);
+}
 // uniform 32-bit control words (progress, stop): every lane reads the same address / lane 0 writes
 WM_DEV int mbox_ld_word(const int *p, int i) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 WM_DEV void mbox_st_word(int *p, int i, int v) { if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(p + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

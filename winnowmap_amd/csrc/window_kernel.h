@@ -432,7 +432,8 @@ WM_DEV void win_plan_wave(const wm_win_job_t jb, int j, uint64_t a_off, int n, c
 	if (n <= 0) return;
 	const float avg = win_avg_qspan(a_, n);
 	int klass = n > 256 ? (n > 1024 ? 1 : 2) : 3;
-	if (n > 1024) {            // DENSE if a sample of anchors has more than ~900 predecessors within max_dist_x (satellite arrays): 8 waves, 4096-anchor window
+	if (n > 1024) {            // DENSE if a sample of anchors has more than ~900 predecessors within max_dist_x (satellite arrays), or (round 6) if a quarter of the sample has
+		                       // more than two tiles of them: the workgroup kernel scores the whole window in one step, the one-wavefront kernel four tiles at a time
 		V<int> worst = 0;
 		WM_IF(ln >= 1 && ln <= 32)
 			const V<long long> k = cast<long long>(ln) * (long long)n / 33LL;
@@ -447,7 +448,7 @@ WM_DEV void win_plan_wave(const wm_win_job_t jb, int j, uint64_t a_off, int n, c
 				WM_END
 			worst = cast<int>(k - lo);
 		WM_END
-		if (readlane(wave_scan_max(worst), 63) > 900) klass = 0;
+		if (readlane(wave_scan_max(worst), 63) > 900 || popc64(ballot(worst > 128)) >= 8) klass = 0;
 	}
 	WM_IF(ln == 0)
 		wm_chain_job_t o;

@@ -77,9 +77,14 @@ static inline double now_ms() { return std::chrono::duration<double, std::milli>
 #else
 #define WM_SETPRIO(n) ((void)0)
 #endif
+// WM_OCC_HINT (build define, A/B): ask the register allocator for one more wavefront per SIMD where a kernel sits just above a step of the register file
+// (512 / 4 = 128 registers: ksw_dpp_kernel<8, true, *, true> 130-132, ksw_chain_kernel<2, *, *, true> 122-138; tools/kernel_regs.py) at the price of 3-6 spilled values
+#ifndef WM_OCC_HINT
+#define WM_OCC_HINT 0
+#endif
 // register classes: one wave per alignment, two DP cells per lane (ksw_dp_packed, ksw_packed_kernel.h)
 template <int BP, bool CLIP, bool HASN, bool EXACT>
-__global__ __launch_bounds__(64) void ksw_dpp_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs,
+__global__ __launch_bounds__(64, (WM_OCC_HINT && BP == 8 && CLIP && EXACT) ? 4 : 1) void ksw_dpp_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs,
                                                       const int *__restrict__ order, const uint8_t *__restrict__ seqs,
                                                       uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res)
 {
@@ -181,12 +186,13 @@ __global__ __launch_bounds__(64 * NWV) void ksw_stripe_kernel(wm_ksw_score_t sc,
 // chained-workgroup classes (ksw_plan.h: WM_KSW_CHAIN..; ksw_chain_kernel.h): one 64-thread workgroup per WAVEFRONT of an alignment. A workgroup takes a
 // ticket when it starts and the ticket names (job, wavefront) — `cmap[ticket]` = {index into `order`, wavefront, mailbox offset in 128-byte units, wavefronts
 // of the job}, jobs largest first, the wavefronts of a job in consecutive tickets: every lower ticket is running or done, whatever the dispatcher's order.
-template <int BP, bool CLIP, bool HASN>
-__global__ __launch_bounds__(64) void ksw_chain_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
+template <int BP, bool CLIP, bool HASN, bool EXACT>
+__global__ __launch_bounds__(64, (WM_OCC_HINT && BP == 2 && EXACT) ? 4 : 1) void ksw_chain_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order,
                                                         const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res,
                                                         const uint4 *__restrict__ cmap, int *ticket, wm_mbox_t *mail)
 {
 	WM_SETPRIO(WM_STRIPE_PRIO);
+	__shared__ int tbs[wm_chain_box::GROUP * 32 * BP];            // traceback rows of the group being staged
 	int tk = 0;
 	if (threadIdx.x == 0) tk = atomicAdd(ticket, 1);
 	tk = __builtin_amdgcn_readfirstlane(tk);
@@ -194,8 +200,18 @@ __global__ __launch_bounds__(64) void ksw_chain_kernel(wm_ksw_score_t sc, const 
 	const int j = order[m.x];
 	const wm_ksw_djob_t jb = jobs[j];
 	wm_mbox_t *mb = mail + (size_t)m.z * 16;
-	if (jb.flag & KSW_F_APPROX_MAX) wmk::ksw_dp_chain<BP, CLIP, HASN, false>(sc, jb, seqs, tb, mb, (int)m.w, (int)m.y, res + j);
-	else wmk::ksw_dp_chain<BP, CLIP, HASN, true>(sc, jb, seqs, tb, mb, (int)m.w, (int)m.y, res + j);
+	wmk::ksw_dp_chain<BP, CLIP, HASN, EXACT>(sc, jb, seqs, tb, mb, (int)m.w, (int)m.y, tbs, res + j);      // (the launcher's ticket table holds jobs of one kind: 82..94 registers without the exact maximum, 122..138 with it)
+}
+
+// jobs the reference returns from before it does anything (an empty operand, a mismatch that can never be seen: src/ksw2_extd2_sse.c:68,92) get the
+// result of ksw_reset_extz (src/ksw2.h:153-158): one launch over the job table instead of one copy per such job
+__global__ __launch_bounds__(256) void ksw_reset_kernel(int n, const wm_ksw_djob_t *__restrict__ jobs, wm_ksw_dres_t *__restrict__ res)
+{
+	const int j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= n || jobs[j].klass >= 0) return;
+	wm_ksw_dres_t z;
+	z.max = 0; z.zdropped = 0; z.max_q = z.max_t = z.mqe_t = z.mte_q = -1; z.score = z.mqe = z.mte = KSW_NEG_INF; z.reach_end = 0; z.n_cigar = 0; z.bt_i = z.bt_j = -1;
+	res[j] = z;
 }
 
 // operands of position jobs (wm_ksw_batch_pos): expand query and target of job blockIdx.x into the batch's sequence slab. Query = two-strand
@@ -391,7 +407,8 @@ struct wm_ksw_dev_batch_s {
 	uint8_t *d_gscratch; uint64_t *d_goff; std::vector<uint64_t> goff;
 	uint8_t *d_b3state; uint64_t *d_b3off; std::vector<uint64_t> b3off;
 	// chained-workgroup classes: ticket -> (job, wavefront, mailbox) per class, the mailboxes (filled with 0xff before the launches), one ticket counter per class
-	std::vector<uint4> cmap[WM_KSW_NCLASS - WM_KSW_CHAIN]; uint4 *d_cmap[WM_KSW_NCLASS - WM_KSW_CHAIN]; wm_mbox_t *d_mail = 0; size_t mail_words = 0; int *d_tickets = 0;
+	// ([kind]: 0 = approximate maximum, 1 = exact maximum + z-drop: two kernels per class)
+	std::vector<uint4> cmap[WM_KSW_NCLASS - WM_KSW_CHAIN][2]; uint4 *d_cmap[WM_KSW_NCLASS - WM_KSW_CHAIN][2]; wm_mbox_t *d_mail = 0; size_t mail_words = 0; int *d_tickets = 0;
 	wm_ksw_djob_t *d_jobs; int *d_order; uint8_t *d_seqs, *d_tb; wm_ksw_dres_t *d_res; uint32_t *d_cig, *d_off, *d_total, *d_pool; int *d_err;
 	size_t pool_cap, arena_mark, slab_bytes;
 	uint64_t cells, tb_bytes;
@@ -548,6 +565,7 @@ extern "C" void wm_ctx_destroy(wm_ctx_t *c)
 }
 
 extern "C" float wm_last_kernel_ms(const wm_ctx_t *c) { return c ? c->last_ms : 0.f; }
+extern "C" int wm_ctx_device(const wm_ctx_t *c) { return c ? c->device : -1; }
 
 static inline double now_ms();
 static void *arena_take(wm_ctx_t *c, size_t bytes)
@@ -610,13 +628,13 @@ template <int BP, int NWV> static void launch_stripe(int variant, int n, hipStre
 }
 
 // variant = CLIP * 2 + HASN (0, 2, 3); n = wavefronts (= workgroups) of the class
-template <int BP> static void launch_chain(int variant, int n, hipStream_t s, const wm_ksw_score_t &sc, const wm_ksw_djob_t *jobs, const int *order,
-                                           const uint8_t *seqs, uint8_t *tb, wm_ksw_dres_t *res, const uint4 *cmap, int *ticket, wm_mbox_t *mail)
+template <int BP, bool EXACT> static void launch_chain(int variant, int n, hipStream_t s, const wm_ksw_score_t &sc, const wm_ksw_djob_t *jobs, const int *order,
+                                                       const uint8_t *seqs, uint8_t *tb, wm_ksw_dres_t *res, const uint4 *cmap, int *ticket, wm_mbox_t *mail)
 {
 	dim3 g(n), b(64);
-	if (variant & 1) hipLaunchKernelGGL((ksw_chain_kernel<BP, true, true>), g, b, 0, s, sc, jobs, order, seqs, tb, res, cmap, ticket, mail);
-	else if (variant & 2) hipLaunchKernelGGL((ksw_chain_kernel<BP, true, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res, cmap, ticket, mail);
-	else hipLaunchKernelGGL((ksw_chain_kernel<BP, false, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res, cmap, ticket, mail);
+	if (variant & 1) hipLaunchKernelGGL((ksw_chain_kernel<BP, true, true, EXACT>), g, b, 0, s, sc, jobs, order, seqs, tb, res, cmap, ticket, mail);
+	else if (variant & 2) hipLaunchKernelGGL((ksw_chain_kernel<BP, true, false, EXACT>), g, b, 0, s, sc, jobs, order, seqs, tb, res, cmap, ticket, mail);
+	else hipLaunchKernelGGL((ksw_chain_kernel<BP, false, false, EXACT>), g, b, 0, s, sc, jobs, order, seqs, tb, res, cmap, ticket, mail);
 }
 // WM_KSW_CHAIN (wm_ksw_route_chain's mode): bit 0 = the stripe classes and the old wide-hull kernels' jobs run on the chained-workgroup kernels, bit 1 = long exact
 // extensions of the 8-pair register classes too (from WM_KSW_CHAIN_ROWS rows on); 0 = none (the round-5 routing, A/B). WM_KSW_CHAIN_BP=4: 512-lane stripes.
@@ -762,20 +780,45 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 			o.swap(tmp);
 		}
 	}
-	// device buffers
+	// chained-workgroup classes: ticket -> (job, wavefront, mailbox) per class and kind; the mailboxes' sizes
+	size_t chain_mw = 0;
+	bool chain_any = false;
+	for (int kc = 0; kc < WM_KSW_NCLASS - WM_KSW_CHAIN; ++kc) {
+		const int sw = 128 * wm_ksw_chain_bp[kc >> 2];
+		const std::vector<int> &o = b->order[WM_KSW_CHAIN + kc];
+		b->d_cmap[kc][0] = b->d_cmap[kc][1] = 0;
+		for (size_t jo = 0; jo < o.size(); ++jo) {
+			const wm_ksw_djob_t &d = b->jobs[o[jo]];
+			const int nwv = wm_chain_nwv(d.n_col, d.tlen, sw);
+			std::vector<uint4> &cm = b->cmap[kc][(d.flag & KSW_F_APPROX_MAX) ? 0 : 1];
+			for (int wv = 0; wv < nwv; ++wv) cm.push_back(make_uint4((unsigned)jo, (unsigned)wv, (unsigned)(chain_mw / 16), (unsigned)nwv));
+			chain_mw += ((size_t)wm_chain_box::words(nwv) + 15) & ~(size_t)15;
+			chain_any = true;
+		}
+	}
+	// device buffers. The host-made tables — jobs | launch order | operand sources | ticket tables — are ONE block and travel in ONE copy (round 6: a
+	// batched call made ~20 small copies, each a blit kernel of ~0.2 ms on the call's stream: profiles/r05_last_bench.txt, __amd_rocclr_copyBuffer)
 	const size_t nj = n_jobs > 0 ? n_jobs : 1;
-	b->d_jobs = (wm_ksw_djob_t*)arena_take(c, nj * sizeof(wm_ksw_djob_t));
-	b->d_order = (int*)arena_take(c, nj * sizeof(int));
-	b->d_res = (wm_ksw_dres_t*)arena_take(c, nj * sizeof(wm_ksw_dres_t));
-	b->d_off = (uint32_t*)arena_take(c, nj * 4 + 64);
-	b->d_total = (uint32_t*)arena_take(c, 64);
-	b->d_err = (int*)arena_take(c, 64);
+	auto al256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	const size_t o_ord = al256(nj * sizeof(wm_ksw_djob_t)), o_src = o_ord + al256(nj * sizeof(int));
+	size_t o_cm[WM_KSW_NCLASS - WM_KSW_CHAIN][2], tab_bytes = o_src + (pos ? al256(nj * sizeof(wm_ksw_dsrc_t)) : 0);
+	for (int kc = 0; kc < WM_KSW_NCLASS - WM_KSW_CHAIN; ++kc)
+		for (int e = 0; e < 2; ++e) { o_cm[kc][e] = tab_bytes; tab_bytes += al256(b->cmap[kc][e].size() * sizeof(uint4)); }
+	uint8_t *d_tab = (uint8_t*)arena_take(c, tab_bytes);
+	b->d_jobs = (wm_ksw_djob_t*)d_tab;
+	b->d_order = d_tab ? (int*)(d_tab + o_ord) : 0;
+	for (int kc = 0; kc < WM_KSW_NCLASS - WM_KSW_CHAIN && d_tab; ++kc)
+		for (int e = 0; e < 2; ++e) if (!b->cmap[kc][e].empty()) b->d_cmap[kc][e] = (uint4*)(d_tab + o_cm[kc][e]);
+	b->d_res = (wm_ksw_dres_t*)arena_take(c, al256(nj * sizeof(wm_ksw_dres_t)) + nj * 4 + 64);      // results | CIGAR offsets: one copy back (wm_ksw_dev_fetch)
+	b->d_off = b->d_res ? (uint32_t*)((uint8_t*)b->d_res + al256(nj * sizeof(wm_ksw_dres_t))) : 0;
+	b->d_err = (int*)arena_take(c, 64);                          // [0] error flag, [1] total CIGAR ops: one 8-byte copy back
+	b->d_total = b->d_err ? (uint32_t*)(b->d_err + 1) : 0;
 	bool any_zd = false;
 	for (int i = 0; i < n_jobs && !any_zd; ++i) any_zd = (b->jobs[i].flag & WM_KSW_F_ZDWALK) != 0;
 	b->d_zd = any_zd ? (wm_zd_t*)arena_take(c, nj * sizeof(wm_zd_t)) : 0;
 	b->d_seqs = (uint8_t*)arena_take(c, slab_bytes + 64);
 	b->slab_bytes = slab_bytes;
-	wm_ksw_dsrc_t *d_src = pos ? (wm_ksw_dsrc_t*)arena_take(c, nj * sizeof(wm_ksw_dsrc_t)) : 0;
+	wm_ksw_dsrc_t *d_src = pos && d_tab ? (wm_ksw_dsrc_t*)(d_tab + o_src) : 0;
 	b->d_cig = (uint32_t*)arena_take(c, (cig_off + 16) * 4);
 	b->pool_cap = cig_off + 16;
 	b->d_pool = (uint32_t*)arena_take(c, b->pool_cap * 4);
@@ -792,28 +835,11 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 		b->d_b3off = (uint64_t*)arena_take(c, b->b3off.size() * 8 + 64);
 		if (!b->d_b3state || !b->d_b3off) b->d_tb = 0;
 	}
-	{   // chained-workgroup classes: the ticket tables and the mailboxes
-		size_t mw = 0;
-		bool any = false;
-		for (int kc = 0; kc < WM_KSW_NCLASS - WM_KSW_CHAIN; ++kc) {
-			const int sw = 128 * wm_ksw_chain_bp[kc >> 2];
-			const std::vector<int> &o = b->order[WM_KSW_CHAIN + kc];
-			std::vector<uint4> &cm = b->cmap[kc];
-			b->d_cmap[kc] = 0;
-			for (size_t jo = 0; jo < o.size(); ++jo) {
-				const wm_ksw_djob_t &d = b->jobs[o[jo]];
-				const int nwv = wm_chain_nwv(d.n_col, d.tlen, sw);
-				for (int wv = 0; wv < nwv; ++wv) cm.push_back(make_uint4((unsigned)jo, (unsigned)wv, (unsigned)(mw / 16), (unsigned)nwv));
-				mw += ((size_t)wm_chain_box::words(nwv) + 15) & ~(size_t)15;
-			}
-			if (!cm.empty()) { any = true; b->d_cmap[kc] = (uint4*)arena_take(c, cm.size() * sizeof(uint4)); if (!b->d_cmap[kc]) b->d_tb = 0; }
-		}
-		if (any) {
-			b->mail_words = mw;
-			b->d_mail = (wm_mbox_t*)arena_take(c, mw * 8 + 256);
-			b->d_tickets = (int*)arena_take(c, 64 * sizeof(int));
-			if (!b->d_mail || !b->d_tickets) b->d_tb = 0;
-		}
+	if (chain_any) {   // chained-workgroup classes: the mailboxes (filled with 0xff before the launches) and the ticket counters
+		b->mail_words = chain_mw;
+		b->d_mail = (wm_mbox_t*)arena_take(c, chain_mw * 8 + 256);
+		b->d_tickets = (int*)arena_take(c, 64 * sizeof(int));
+		if (!b->d_mail || !b->d_tickets) b->d_tb = 0;
 	}
 	if (!b->d_jobs || !b->d_order || !b->d_res || !b->d_off || !b->d_total || !b->d_err || !b->d_seqs || (any_zd && !b->d_zd) || (pos && !d_src) || !b->d_cig || !b->d_pool || !b->d_tb) {
 		c->arena_used = b->arena_mark;
@@ -825,22 +851,19 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 	for (int k = 0; k < WM_KSW_NCLASS; ++k) b->ord.insert(b->ord.end(), b->order[k].begin(), b->order[k].end());
 	// the job table and the launch order travel through the context's pinned slab: an asynchronous copy out of pageable memory makes the runtime pin
 	// the pages for the duration of the copy (or bounce them through its own staging buffer, waiting in between) — driver calls per batched call
-	UBuf<wm_ksw_djob_t> pj(n_jobs, c);
-	UBuf<int> po(b->ord.size(), c);
-	if (n_jobs) memcpy(pj.data(), b->jobs.data(), (size_t)n_jobs * sizeof(wm_ksw_djob_t));
-	if (!b->ord.empty()) memcpy(po.data(), b->ord.data(), b->ord.size() * sizeof(int));
-	HIPCHK(hipMemcpyAsync(b->d_jobs, pj.data(), n_jobs * sizeof(wm_ksw_djob_t), hipMemcpyHostToDevice, c->stream));
-	if (!b->ord.empty()) HIPCHK(hipMemcpyAsync(b->d_order, po.data(), b->ord.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+	UBuf<uint8_t> ptab(tab_bytes, c);
+	if (n_jobs) memcpy(ptab.data(), b->jobs.data(), (size_t)n_jobs * sizeof(wm_ksw_djob_t));
+	if (!b->ord.empty()) memcpy(ptab.data() + o_ord, b->ord.data(), b->ord.size() * sizeof(int));
+	if (pos && n_jobs > 0) memcpy(ptab.data() + o_src, dsrc.data(), (size_t)n_jobs * sizeof(wm_ksw_dsrc_t));
+	for (int kc = 0; kc < WM_KSW_NCLASS - WM_KSW_CHAIN; ++kc)
+		for (int e = 0; e < 2; ++e)
+			if (!b->cmap[kc][e].empty()) memcpy(ptab.data() + o_cm[kc][e], b->cmap[kc][e].data(), b->cmap[kc][e].size() * sizeof(uint4));
+	HIPCHK(hipMemcpyAsync(d_tab, ptab.data(), tab_bytes, hipMemcpyHostToDevice, c->stream));
 	if (pos) {
-		if (n_jobs > 0) {
-			HIPCHK(hipMemcpyAsync(d_src, dsrc.data(), (size_t)n_jobs * sizeof(wm_ksw_dsrc_t), hipMemcpyHostToDevice, c->stream));
-			hipLaunchKernelGGL(ksw_expand_kernel, dim3(n_jobs), dim3(64), 0, c->stream, b->d_jobs, d_src, c->d_reads, c->d_reads_nm, c->d_S, b->d_seqs);
-		}
+		if (n_jobs > 0) hipLaunchKernelGGL(ksw_expand_kernel, dim3(n_jobs), dim3(64), 0, c->stream, b->d_jobs, d_src, c->d_reads, c->d_reads_nm, c->d_S, b->d_seqs);
 	} else if (slab_bytes) HIPCHK(hipMemcpyAsync(b->d_seqs, seqs + slab_lo, slab_bytes, hipMemcpyHostToDevice, c->stream));
 	if (!b->goff.empty()) HIPCHK(hipMemcpyAsync(b->d_goff, b->goff.data(), b->goff.size() * 8, hipMemcpyHostToDevice, c->stream));
 	if (!b->b3off.empty()) HIPCHK(hipMemcpyAsync(b->d_b3off, b->b3off.data(), b->b3off.size() * 8, hipMemcpyHostToDevice, c->stream));
-	for (int kc = 0; kc < WM_KSW_NCLASS - WM_KSW_CHAIN; ++kc)
-		if (!b->cmap[kc].empty()) HIPCHK(hipMemcpyAsync(b->d_cmap[kc], b->cmap[kc].data(), b->cmap[kc].size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(ctx_sync(c));             // (the host tables above are read by the copies until here)
 	*out = b;
 	return WM_OK;
@@ -901,12 +924,7 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 		HIPCHK(hipMemsetAsync(b->d_mail, 0xff, b->mail_words * 8, c->stream));
 		HIPCHK(hipMemsetAsync(b->d_tickets, 0, 64 * sizeof(int), c->stream));
 	}
-	if (!b->degenerate.empty()) {
-		wm_ksw_dres_t z;
-		memset(&z, 0, sizeof(z));
-		z.max_q = z.max_t = z.mqe_t = z.mte_q = -1; z.score = z.mqe = z.mte = KSW_NEG_INF; z.bt_i = z.bt_j = -1;
-		for (int j : b->degenerate) HIPCHK(hipMemcpyAsync(b->d_res + j, &z, sizeof(z), hipMemcpyHostToDevice, c->stream));
-	}
+	if (!b->degenerate.empty()) hipLaunchKernelGGL(ksw_reset_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, b->d_jobs, b->d_res);
 	HIPCHK(hipEventRecord(c->ev[0], c->stream));
 	int off = 0;
 	static const bool trace_k = getenv("WM_TRACE_KSW") != 0;          // per-class timing (serialises the launches)
@@ -998,9 +1016,18 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 			continue;
 		}
 		if (k >= WM_KSW_CHAIN) {
-			const int kc = k - WM_KSW_CHAIN, var = kc & 3, nw = (int)b->cmap[kc].size();
-			if (wm_ksw_chain_bp[kc >> 2] == 2) launch_chain<2>(var, nw, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, b->d_cmap[kc], b->d_tickets + kc, b->d_mail);
-			else launch_chain<4>(var, nw, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, b->d_cmap[kc], b->d_tickets + kc, b->d_mail);
+			const int kc = k - WM_KSW_CHAIN, var = kc & 3;
+			for (int e = 1; e >= 0; --e) {            // (the exact-maximum jobs first: the longer rows)
+				const int nw = (int)b->cmap[kc][e].size();
+				if (!nw) continue;
+				if (wm_ksw_chain_bp[kc >> 2] == 2) {
+					if (e) launch_chain<2, true>(var, nw, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, b->d_cmap[kc][e], b->d_tickets + 2 * kc + e, b->d_mail);
+					else launch_chain<2, false>(var, nw, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, b->d_cmap[kc][e], b->d_tickets + 2 * kc + e, b->d_mail);
+				} else {
+					if (e) launch_chain<4, true>(var, nw, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, b->d_cmap[kc][e], b->d_tickets + 2 * kc + e, b->d_mail);
+					else launch_chain<4, false>(var, nw, ks, b->sc, b->d_jobs, b->d_order + off, b->d_seqs, b->d_tb, b->d_res, b->d_cmap[kc][e], b->d_tickets + 2 * kc + e, b->d_mail);
+				}
+			}
 			continue;
 		}
 		if (k >= WM_KSW_STRIPE) {
@@ -1079,8 +1106,8 @@ extern "C" int wm_ksw_dev_run(wm_ctx_t *c, wm_ksw_dev_batch_t *b)
 	HIPCHK(hipGetLastError());
 	int *h_small = c->pin_small ? c->pin_small : &b->h_err;            // [0] error flag, [1] total ops
 	uint32_t *h_total = c->pin_small ? (uint32_t*)(c->pin_small + 1) : &b->total_ops;
-	HIPCHK(hipMemcpyAsync(h_small, b->d_err, 4, hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipMemcpyAsync(h_total, b->d_total, 4, hipMemcpyDeviceToHost, c->stream));
+	if (c->pin_small) HIPCHK(hipMemcpyAsync(h_small, b->d_err, 8, hipMemcpyDeviceToHost, c->stream));      // (flag and total are neighbours on both sides)
+	else { HIPCHK(hipMemcpyAsync(h_small, b->d_err, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipMemcpyAsync(h_total, b->d_total, 4, hipMemcpyDeviceToHost, c->stream)); }
 	HIPCHK(ctx_sync(c));
 	b->h_err = *h_small; b->total_ops = *h_total;
 	for (const std::string &f : b->dumped) unlink(f.c_str());
@@ -1112,12 +1139,13 @@ try {
 	const int n = b->n_jobs;
 	if (cigar_used) *cigar_used = b->total_ops;
 	if (n == 0) return WM_OK;
-	UBuf<wm_ksw_dres_t> res(n, c);
-	UBuf<uint32_t> off(n, c);
+	const size_t off_at = (size_t)((uint8_t*)b->d_off - (uint8_t*)b->d_res);
+	UBuf<uint8_t> ro(off_at + (size_t)n * 4, c);
+	const wm_ksw_dres_t *res = (const wm_ksw_dres_t*)ro.data();
+	const uint32_t *off = (const uint32_t*)(ro.data() + off_at);
 	if (b->total_ops > cigar_cap) return set_err(WM_ENOMEM, "cigar_pool too small: need %u ops", b->total_ops);
-	HIPCHK(hipMemcpyAsync(res.data(), b->d_res, n * sizeof(wm_ksw_dres_t), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipMemcpyAsync(off.data(), b->d_off, n * 4, hipMemcpyDeviceToHost, c->stream));
-	if (b->total_ops) HIPCHK(hipMemcpyAsync(cigar_pool, b->d_pool, (size_t)b->total_ops * 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(ro.data(), b->d_res, off_at + (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+	if (b->total_ops) HIPCHK(hipMemcpyAsync(cigar_pool, b->d_pool, (size_t)b->total_ops * 4, hipMemcpyDeviceToHost, c->stream));      // (the mapper hands a pinned buffer: GpuOps)
 	HIPCHK(ctx_sync(c));
 	WM_SITE("ksw.results");
 	wm::parallel_for(c->host_threads, (size_t)n, [&](size_t i) {
@@ -2598,6 +2626,20 @@ __global__ __launch_bounds__(64 * NWV) void win_chain_kernel_block(const wm_chai
 	wmk::chain_block(jb, anchors, NWV, W, sx, sy, sf, sp, st, pub, gf, gp, gt);
 }
 
+// the dense fill with the whole predecessor window of an anchor per step (seedchain_kernel.h: chain_block_wide): 16 wavefronts x KT tiles
+template <int KT>
+__global__ __launch_bounds__(1024) void win_chain_kernel_wide(const wm_chain_job_t *jobs, const int *list, const int *count, const wm128_t *anchors, int *fpvt, int W)
+{
+	WM_SETPRIO(2);
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	if ((int)blockIdx.x >= *count) return;
+	const wm_chain_job_t jb = jobs[list[blockIdx.x]];
+	uint64_t *sx = (uint64_t*)smem, *sy = sx + W;
+	int *sf = (int*)(sy + W), *sp = sf + W, *st = sp + W, *pub = st + W;
+	int *gf = fpvt + jb.a_off * 4, *gp = gf + jb.n, *gt = gp + 2 * (size_t)jb.n;
+	wmk::chain_block_wide<KT>(jb, anchors, 16, W, sx, sy, sf, sp, st, pub, gf, gp, gt);
+}
+
 // src/chain.c:89-165 per job; f, p staged in LDS when the job fits (lo, lds_cap], global slab otherwise (lds_cap = 0)
 __global__ __launch_bounds__(64) void win_extract_kernel(const wm_win_job_t *__restrict__ jobs, wm_win_res_t *res, wm128_t *anchors, int *fpvt, uint64_t *zu, wm128_t *bbuf, wm128_t *wbuf,
                                                           int lo, int lds_cap, uint64_t *u_pool, wm128_t *v_pool, uint64_t *pool_ctr)
@@ -2760,8 +2802,15 @@ static int window_launch(wm_ctx_t *c, int n, const wm_window_job_t *jobs, const 
 	{   // the fill, per class list: 0 dense (8 waves, W 4096) | 1 large sparse (1 wave, W 1024) | 2 n <= 1024 | 3 n <= 256
 		HIPCHK(hipFuncSetAttribute((const void*)win_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		constexpr int NWV = 8;
-		HIPCHK(hipFuncSetAttribute((const void*)win_chain_kernel_block<NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		hipLaunchKernelGGL(win_chain_kernel_block<NWV>, dim3(n), dim3(64 * NWV), (size_t)4096 * 28 + NWV * 69 * 4 + 64, c->stream, d_cj, d_lists, d_counts, d_a, d_fpvt, 4096);
+		// WM_CHAIN_WIDE=0: the round-5 dense fill (8 wavefronts, 512 predecessors per step); default: 16 wavefronts x 5 tiles = a whole max_iter window per step
+		static const bool wide = !(getenv("WM_CHAIN_WIDE") && atoi(getenv("WM_CHAIN_WIDE")) == 0);
+		if (wide) {
+			HIPCHK(hipFuncSetAttribute((const void*)win_chain_kernel_wide<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+			hipLaunchKernelGGL(win_chain_kernel_wide<5>, dim3(n), dim3(1024), (size_t)4096 * 28 + 80 * 69 * 4 + 64, c->stream, d_cj, d_lists, d_counts, d_a, d_fpvt, 4096);
+		} else {
+			HIPCHK(hipFuncSetAttribute((const void*)win_chain_kernel_block<NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+			hipLaunchKernelGGL(win_chain_kernel_block<NWV>, dim3(n), dim3(64 * NWV), (size_t)4096 * 28 + NWV * 69 * 4 + 64, c->stream, d_cj, d_lists, d_counts, d_a, d_fpvt, 4096);
+		}
 		hipLaunchKernelGGL(win_chain_kernel, dim3(n), dim3(64), (size_t)1024 * 28, c->stream, d_cj, d_lists + n, d_counts + 1, d_a, d_fpvt, 1024);
 		hipLaunchKernelGGL(win_chain_kernel, dim3(n), dim3(64), (size_t)1024 * 28, c->stream, d_cj, d_lists + 2 * (size_t)n, d_counts + 2, d_a, d_fpvt, 1024);
 		// (class 3, at most 256 anchors: served by win_small_kernel)
