@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""VGPR / SGPR / spill / LDS / scratch and static instruction counts per kernel, from the device assembly of wm_gpu.hip
+"""VGPR / SGPR / spill / LDS / scratch and static instruction counts per kernel, from the device assembly of the library's units (wm_ksw.hip, wm_index.hip, wm_window.hip)
 (hipcc -S --cuda-device-only with the library's flags, winnowmap_amd/build.py HIP_FLAGS).
   python tools/kernel_regs.py [out.txt]
   python tools/kernel_regs.py --compare [out.txt]     the same table without / with -mllvm -disable-promote-alloca-to-vector"""
@@ -17,17 +17,20 @@ PROMOTE = ["-mllvm", "-disable-promote-alloca-to-vector"]
 
 
 def device_asm(flags):
-    asm = os.path.join(tempfile.mkdtemp(), "wm.s")
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-w", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", asm,
-                           os.path.join(ROOT, "winnowmap_amd", "csrc", "wm_gpu.hip")])
-    return open(asm).read()
+    """the device assembly of the library's kernel-bearing units (winnowmap_amd/build.py UNITS), one after the other"""
+    tmp, txt = tempfile.mkdtemp(), ""
+    for u in ("wm_ksw", "wm_index", "wm_window"):
+        asm = os.path.join(tmp, u + ".s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-w", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", asm,
+                               os.path.join(ROOT, "winnowmap_amd", "csrc", u + ".hip")])
+        txt += open(asm).read() + "\n"
+    return txt
 
 
 def parse(txt):
     """{mangled name: dict(vgpr, sgpr, spill, lds, scratch, valu, salu, mov64)}"""
-    meta = txt[txt.index("amdhsa.kernels:"):]
     out = {}
-    for blk in re.split(r"\n  - \.agpr_count", meta)[1:]:
+    for blk in [b for meta in txt.split("amdhsa.kernels:")[1:] for b in re.split(r"\n  - \.agpr_count", meta.split("amdhsa.target:")[0])[1:]]:      # (one metadata section per unit)
         g = lambda k: (re.search(r"\.%s:\s+(\S+)" % k, blk) or [None, "0"])[1]
         out[g("name")] = dict(vgpr=int(g("vgpr_count")), sgpr=int(g("sgpr_count")), spill=int(g("vgpr_spill_count")),
                               lds=int(g("group_segment_fixed_size")), scratch=int(g("private_segment_fixed_size")), valu=0, salu=0, mov64=0)

@@ -53,8 +53,12 @@ def _newer(target, sources):
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-mllvm", "-disable-promote-alloca-to-vector"]
 
 
+UNITS = ("wm_rt", "wm_ksw", "wm_index", "wm_window", "wm_mapper")      # the translation units of libwmgpu.so (csrc/wm_rt.h says what each holds)
+
+
 def build_gpu(force=False, verbose=False, out=None):
-    """libwmgpu.so (or `out`: a variant library for A/B runs, selected with WM_LIBWMGPU=<path>; built here so that no GPU minute is spent compiling)"""
+    """libwmgpu.so (or `out`: a variant library for A/B runs, selected with WM_LIBWMGPU=<path>; built here so that no GPU minute is spent compiling).
+    The five units are compiled side by side (objects under csrc/.obj/<library name>/, git-ignored) and linked into the one shared object."""
     global LIB
     if out is not None:
         saved, LIB = LIB, out
@@ -62,7 +66,7 @@ def build_gpu(force=False, verbose=False, out=None):
             return build_gpu(force, verbose)
         finally:
             LIB = saved
-    srcs = [os.path.join(d, f) for d, _, fs in os.walk(CSRC) for f in fs] + [os.path.join(ROOT, "include", "wm_gpu.h")]
+    srcs = [os.path.join(d, f) for d, _, fs in os.walk(CSRC) for f in fs if ".obj" not in d] + [os.path.join(ROOT, "include", "wm_gpu.h")]
     # WM_KERNEL_DEFINES="WM_KSW_ROR=0 ...": kernel variants under evaluation (A/B on a GPU box); the default build defines nothing. The defines a
     # library was built with are part of its staleness check (sidecar stamp) and are compiled into it (wm_build_defines(), recorded by bench.py)
     defines = " ".join(os.environ.get("WM_KERNEL_DEFINES", "").split())
@@ -72,10 +76,20 @@ def build_gpu(force=False, verbose=False, out=None):
         if not force and not _newer(LIB, srcs) and have == defines:
             return LIB
         defs = ["-D" + d for d in defines.split()] + ['-DWM_BUILD_DEFINES="%s"' % defines]
-        cmd = lambda out_: [HIPCC] + HIP_FLAGS + defs + ["-shared", "-fPIC", "-o", out_, os.path.join(CSRC, "wm_gpu.hip"), "-lz", "-lpthread"]  # noqa: E731
+        objdir = os.path.join(CSRC, ".obj", os.path.basename(LIB))
+        os.makedirs(objdir, exist_ok=True)
+        cmds = [[HIPCC] + HIP_FLAGS + defs + ["-fPIC", "-c", os.path.join(CSRC, u + ".hip"), "-o", os.path.join(objdir, u + ".o")] for u in UNITS]
         if verbose:
-            print(" ".join(cmd(LIB)), file=sys.stderr)
-        _run_to(LIB, cmd)
+            for c in cmds:
+                print(" ".join(c), file=sys.stderr)
+        procs = [subprocess.Popen(c) for c in cmds]
+        rcs = [p.wait() for p in procs]
+        if any(rcs):
+            raise subprocess.CalledProcessError(next(r for r in rcs if r), cmds[next(i for i, r in enumerate(rcs) if r)])
+        link = lambda out_: [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_] + [os.path.join(objdir, u + ".o") for u in UNITS] + ["-lz", "-lpthread"]  # noqa: E731
+        if verbose:
+            print(" ".join(link(LIB)), file=sys.stderr)
+        _run_to(LIB, link)
         with open(stamp, "w") as f:
             f.write(defines)
     return LIB

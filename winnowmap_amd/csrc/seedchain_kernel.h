@@ -626,7 +626,7 @@ WM_DEV void chain_block_wide(const wm_chain_job_t jb, const wm128_t *anchor_pool
 					}
 				}
 			}
-			block_sync_lds();                                                                   // pub area may be overwritten by the next step
+			if (hi0 - 64LL * NT >= st && !stop) block_sync_lds();                               // another step follows: it overwrites the pub area (after the last step the barrier below does)
 		}
 		if (wv == 0) {
 			WM_IF(ln == 0)
