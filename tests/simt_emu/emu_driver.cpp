@@ -359,6 +359,7 @@ int emu_chain_fill(int64_t n, const uint64_t *ax, const uint64_t *ay, int max_di
 				else if (KT == 1) wmk::chain_block_wide<1>(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
 				else if (KT == 2) wmk::chain_block_wide<2>(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
 				else if (KT == 3) wmk::chain_block_wide<3>(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
+				else if (KT == 10) wmk::chain_block_wide<10>(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
 				else wmk::chain_block_wide<5>(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
 			});
 		for (auto &t : th) t.join();

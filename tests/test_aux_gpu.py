@@ -183,6 +183,29 @@ def test_chain_large_sparse_and_dense_anchor_sets(env):
             assert np.array_equal(u[int(uoff[i]):int(uoff[i]) + nu[i]], ou) and np.array_equal(g["x"], obx) and np.array_equal(g["y"], oby), (i, prm)
 
 
+def test_chain_dense_fill_with_far_predecessors_matches_oracle(env):
+    """Satellite-array anchor sets whose predecessor window (max_iter = 5000, src/chain.c:51-55) is wider than the 4096-anchor LDS window of the dense
+    fill: predecessors, their f / p and the marks t[] then live in the global slab (seedchain_kernel.h: chain_block_wide, one step = the whole window)."""
+    ctx, idx, ref, bloom, L = env
+    PAR = np.dtype([("p", np.int32, 8), ("gs", np.float32), ("is_cdna", np.int32)])
+    for n_mini, copies in ((250, 64), (1000, 64), (20000, 8)):
+        rng = np.random.default_rng(7)
+        qpos = np.cumsum(rng.integers(5, 40, n_mini)).astype(np.int64) + 100
+        k = rng.integers(-copies, copies + 1, (n_mini, copies)).astype(np.int64)
+        x = (1_000_000 + qpos[:, None] + k * 171 + rng.integers(-2, 3, (n_mini, copies))).ravel().astype(np.uint64)
+        y = np.uint64(15 << 32) | np.repeat(qpos, copies).astype(np.uint64)
+        o = np.argsort(x, kind="stable")
+        x, y = x[o], y[o]
+        ou, obx, oby = W.o_chain_dp(x, y, max_dist_x=16000, min_dist_x=1000, max_dist_y=16000, bw=2000, max_skip=25, max_iter=5000)
+        a = np.zeros(len(x), M128); a["x"], a["y"] = x, y
+        par = np.zeros(1, PAR); par["p"][0] = (16000, 1000, 16000, 2000, 25, 5000, 3, 40); par["gs"][0] = 1.0
+        aoff = np.zeros(1, np.uint64); na = np.array([len(a)], np.int32)
+        u = np.zeros(len(a) + 1, np.uint64); uoff = np.zeros(1, np.uint64); nu = np.zeros(1, np.int32); nv = np.zeros(1, np.int32)
+        assert L.wm_chain_batch(ctx._h, 1, a.ctypes.data, aoff, na, par.ctypes.data, u, uoff, nu, nv) == 0, L.wm_last_error()
+        assert nu[0] == len(ou) and np.array_equal(u[:nu[0]], ou), (n_mini, copies, int(nu[0]), len(ou))
+        assert np.array_equal(a["x"][:nv[0]], obx) and np.array_equal(a["y"][:nv[0]], oby), (n_mini, copies)
+
+
 def test_index_build_on_device_equals_host_build(tmp_path):
     """the reference index with mm_sketch of the whole reference on the device (sketch_coop, one wavefront per contig) must be
     bit-identical to the host build — packed bases, key table, position runs, bloom bits — for ragged contigs, N runs, satellite

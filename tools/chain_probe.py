@@ -33,7 +33,7 @@ cap = 80_000_000
 aout = np.zeros(cap, M128); aoff = np.zeros(n, np.uint64); na = np.zeros(n, np.int32); rl = np.zeros(n, np.int32)
 assert L.wm_seed_batch(ctx._h, n, out.ctypes.data, moff, nm, lens, 5000, 0, aout.ctypes.data, cap, aoff, na, rl) == 0, L.wm_last_error()
 print("anchor counts: median %d p90 %d max %d total %d (seed kernel %.1f ms)" % (np.median(na), np.percentile(na, 90), na.max(), na.sum(), L.wm_last_aux_ms(ctx._h)))
-PAR = np.dtype([("p", np.int32, 8), ("gs", np.float32)])
+PAR = np.dtype([("p", np.int32, 8), ("gs", np.float32), ("is_cdna", np.int32)])      # wm_chain_par_t (include/wm_gpu.h)
 for sel_name, sel in (("all", np.arange(n)), ("largest", np.argsort(-na)[:1]), ("n<=256", np.nonzero(na <= 256)[0]), ("1024<n<=4096", np.nonzero((na > 1024) & (na <= 4096))[0]), ("n>4096", np.nonzero(na > 4096)[0])):
     if len(sel) == 0: continue
     parts = [aout[int(aoff[i]):int(aoff[i]) + na[i]] for i in sel]

@@ -8,7 +8,7 @@ from winnowmap_amd import gpu
 import wmtest as W
 
 M128 = np.dtype([("x", np.uint64), ("y", np.uint64)])
-PAR = np.dtype([("p", np.int32, 8), ("gs", np.float32)])
+PAR = np.dtype([("p", np.int32, 8), ("gs", np.float32), ("is_cdna", np.int32)])      # wm_chain_par_t (include/wm_gpu.h)
 buf = open(sys.argv[1], "rb").read()
 rep = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 jobs = []

@@ -138,6 +138,18 @@ __global__ __launch_bounds__(64 * NWV) void chain_kernel_block(const wm_chain_jo
 	int *gf = fpvt + jb.a_off * 4, *gp = gf + jb.n, *gt = gp + 2 * (size_t)jb.n;
 	wmk::chain_block(jb, anchors, NWV, W, sx, sy, sf, sp, st, pub, gf, gp, gt);
 }
+// ... with the whole predecessor window of an anchor per step (chain_block_wide, round 6): blockDim / 64 wavefronts x KT tiles
+template <int KT>
+__global__ __launch_bounds__(1024) void chain_kernel_wide(const wm_chain_job_t *jobs, const int *order, const wm128_t *anchors, int *fpvt, int W)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int j = order[blockIdx.x];
+	const wm_chain_job_t jb = jobs[j];
+	uint64_t *sx = (uint64_t*)smem, *sy = sx + W;
+	int *sf = (int*)(sy + W), *sp = sf + W, *st = sp + W, *pub = st + W;
+	int *gf = fpvt + jb.a_off * 4, *gp = gf + jb.n, *gt = gp + 2 * (size_t)jb.n;
+	wmk::chain_block_wide<KT>(jb, anchors, (int)(blockDim.x >> 6), W, sx, sy, sf, sp, st, pub, gf, gp, gt);
+}
 
 extern "C" float wm_last_aux_ms(const wm_ctx_t *c) { return c ? c->aux_ms : 0.f; }
 
@@ -1026,7 +1038,17 @@ try {
 			int e = b;
 			while (e < n && klass_of(order[e]) == k) ++e;
 			if (e > b) {
-				if (k == 0) hipLaunchKernelGGL(chain_kernel_block<NWV>, dim3(e - b), dim3(64 * NWV), (size_t)4096 * 28 + NWV * 69 * 4 + 64, c->stream, d_jobs, d_order + b, d_a, d_fpvt, 4096);
+				// WM_CHAIN_WIDE=0: the round-5 dense fill; WM_CHAIN_WIDE_GEOM=<wavefronts>x<tiles per wavefront> (16x5 | 8x10 | 16x3 | 8x5 | 4x10; tools/chain_fill_probe.py)
+				static const bool wide = !(getenv("WM_CHAIN_WIDE") && atoi(getenv("WM_CHAIN_WIDE")) == 0);
+				int gw = 16, gk = 5;
+				if (const char *g = getenv("WM_CHAIN_WIDE_GEOM")) sscanf(g, "%dx%d", &gw, &gk);
+				if ((gk != 10 && gk != 3 && gk != 5) || gw < 1 || gw > 16 || gw * gk > 128) { gw = 16; gk = 5; }      // (the instantiated tile counts; chain_block_wide: NT <= 128)
+				if (k == 0 && wide) {
+					const size_t lds = (size_t)4096 * 28 + (size_t)gw * gk * 69 * 4 + 64;
+					if (gk == 10) { HIPCHK(hipFuncSetAttribute((const void*)chain_kernel_wide<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); hipLaunchKernelGGL(chain_kernel_wide<10>, dim3(e - b), dim3(64 * gw), lds, c->stream, d_jobs, d_order + b, d_a, d_fpvt, 4096); }
+					else if (gk == 3) { HIPCHK(hipFuncSetAttribute((const void*)chain_kernel_wide<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); hipLaunchKernelGGL(chain_kernel_wide<3>, dim3(e - b), dim3(64 * gw), lds, c->stream, d_jobs, d_order + b, d_a, d_fpvt, 4096); }
+					else { HIPCHK(hipFuncSetAttribute((const void*)chain_kernel_wide<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); hipLaunchKernelGGL(chain_kernel_wide<5>, dim3(e - b), dim3(64 * gw), lds, c->stream, d_jobs, d_order + b, d_a, d_fpvt, 4096); }
+				} else if (k == 0) hipLaunchKernelGGL(chain_kernel_block<NWV>, dim3(e - b), dim3(64 * NWV), (size_t)4096 * 28 + NWV * 69 * 4 + 64, c->stream, d_jobs, d_order + b, d_a, d_fpvt, 4096);
 				else hipLaunchKernelGGL(chain_kernel, dim3(e - b), dim3(64), (size_t)(k == 3 ? 256 : 1024) * 28, c->stream, d_jobs, d_order + b, d_a, d_fpvt, k == 3 ? 256 : 1024);
 			}
 			b = e;
