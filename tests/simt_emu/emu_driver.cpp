@@ -341,6 +341,8 @@ int emu_chain_fill(int64_t n, const uint64_t *ax, const uint64_t *ay, int max_di
 	int W = 4096;
 	if (max_skip >> 16) { W = max_skip >> 16; jb.max_skip &= 0xffff; }
 	if (jb.max_skip & 0x8000) { jb.is_cdna = 1; jb.max_skip &= 0x7fff; }        // test hook: bit 15 of max_skip = splice mode (src/chain.c:69-74)
+	const int kt_first_hook = (jb.max_skip >> 8) & 15;                          // test hook: bits 8..11 of max_skip = tiles per wavefront in the FIRST step of chain_block_wide (0: as many as in the others)
+	jb.max_skip &= 0xff;
 	std::vector<int> gt(n + 1), sf(W), sp(W), stt(W);
 	std::vector<uint64_t> sx(W), sy(W);
 	simt::exec_mask() = ~0ull;
@@ -356,11 +358,11 @@ int emu_chain_fill(int64_t n, const uint64_t *ax, const uint64_t *ay, int max_di
 			th.emplace_back([&, w]() {
 				simt::wave_slot() = w; simt::exec_mask() = ~0ull;
 				if (KT == 0) wmk::chain_block(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
-				else if (KT == 1) wmk::chain_block_wide<1>(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
-				else if (KT == 2) wmk::chain_block_wide<2>(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
-				else if (KT == 3) wmk::chain_block_wide<3>(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
-				else if (KT == 10) wmk::chain_block_wide<10>(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
-				else wmk::chain_block_wide<5>(jb, a.data(), NWV, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
+				else if (KT == 1) wmk::chain_block_wide<1>(jb, a.data(), NWV, kt_first_hook ? kt_first_hook : 1, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
+				else if (KT == 2) wmk::chain_block_wide<2>(jb, a.data(), NWV, kt_first_hook ? kt_first_hook : 2, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
+				else if (KT == 3) wmk::chain_block_wide<3>(jb, a.data(), NWV, kt_first_hook ? kt_first_hook : 3, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
+				else if (KT == 10) wmk::chain_block_wide<10>(jb, a.data(), NWV, kt_first_hook ? kt_first_hook : 10, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
+				else wmk::chain_block_wide<5>(jb, a.data(), NWV, kt_first_hook ? kt_first_hook : 5, W, sx.data(), sy.data(), sf.data(), sp.data(), stt.data(), pub.data(), f, p, gt.data());
 			});
 		for (auto &t : th) t.join();
 		simt::block_barrier() = 0;

@@ -216,6 +216,7 @@ inline int wave_append(int *counter) { return __atomic_fetch_add(counter, 1, __A
 
 inline V<int> mbcnt(uint64_t mask) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = __builtin_popcountll(mask & ((i ? ((uint64_t)1 << i) : (uint64_t)1) - 1)); return r; }
 
+inline V<int> vclz(const V<int> &v) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = v.v[i] ? __builtin_clz((unsigned)v.v[i]) : 32; return r; }
 inline V<int> vpopc64(const V<uint64_t> &m) { V<int> r; for (int i = 0; i < WAVE; ++i) r.v[i] = __builtin_popcountll(m.v[i]); return r; }
 inline V<uint64_t> lanemask_lt() { V<uint64_t> r; for (int i = 0; i < WAVE; ++i) r.v[i] = ((uint64_t)1 << i) - 1; return r; }
 

@@ -121,21 +121,22 @@ def test_sketch_seed_chain_kernels(env, device_sort, monkeypatch):
         anchors.append(g.copy())
     # chain: stage-1 and stage-2 parameter sets
     PAR = np.dtype([("p", np.int32, 8), ("gs", np.float32), ("is_cdna", np.int32)])
-    for prm in ((5000, 1000, 5000, 500), (16000, 1000, 16000, 2000)):
-        nz = [a for a in anchors if len(a) > 0]
+    for prm in ((5000, 1000, 5000, 500, 1.0, 0), (16000, 1000, 16000, 2000, 1.0, 0), (5000, 1000, 5000, 500, 0.8, 0), (5000, 1000, 200000, 500, 1.0, 1), (5000, 1000, 5000, 500, 1.3, 1)):
+        nz = [a for a in anchors if len(a) > 0]       # (gap scale other than the default, and the splice gap cost: src/chain.c:69-77)
         na2 = np.array([len(a) for a in nz], np.int32)
         aoff2 = np.concatenate([[0], np.cumsum(na2)[:-1]]).astype(np.uint64)
         alla = np.concatenate(nz)
         par = np.zeros(len(nz), PAR)
         par["p"] = [prm[0], prm[1], prm[2], prm[3], 25, 5000, 3, 40]
-        par["gs"] = 1.0
+        par["gs"] = prm[4]
+        par["is_cdna"] = prm[5]
         u = np.zeros(len(alla) + 1, np.uint64)
         uoff = np.zeros(len(nz), np.uint64)
         nu = np.zeros(len(nz), np.int32)
         nv = np.zeros(len(nz), np.int32)
         assert L.wm_chain_batch(ctx._h, len(nz), alla.ctypes.data, aoff2, na2, par.ctypes.data, u, uoff, nu, nv) == 0, L.wm_last_error()
         for i, a in enumerate(nz):
-            ou, obx, oby = W.o_chain_dp(a["x"], a["y"], max_dist_x=prm[0], min_dist_x=prm[1], max_dist_y=prm[2], bw=prm[3])
+            ou, obx, oby = W.o_chain_dp(a["x"], a["y"], max_dist_x=prm[0], min_dist_x=prm[1], max_dist_y=prm[2], bw=prm[3], gap_scale=prm[4], is_cdna=prm[5])
             g = alla[int(aoff2[i]):int(aoff2[i]) + nv[i]]
             assert np.array_equal(u[int(uoff[i]):int(uoff[i]) + nu[i]], ou) and np.array_equal(g["x"], obx) and np.array_equal(g["y"], oby), (i, prm)
 

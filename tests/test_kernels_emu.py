@@ -334,14 +334,16 @@ def test_chain_fill_over_the_whole_predecessor_window_matches_oracle(emu):
         avg = H.h_avg_qspan(n, sy)
         prm = dict(max_dist_x=16000, min_dist_x=1000, max_dist_y=16000, bw=2000)
         ou, obx, oby = W.o_chain_dp(sx, sy, max_skip=max_skip, max_iter=max_iter, **prm)
-        for win, nwv, kt in ((0, 8, 0), (128, 2, 2), (256, 4, 1), (0, 4, 3), (0, 16, 5), (512, 16, 5)):
+        # (LDS window, wavefronts, tiles per wavefront and step, tiles per wavefront in an anchor's FIRST step: 0 = as in the others, the production setting is 1)
+        for win, nwv, kt, ktf in ((0, 8, 0, 0), (128, 2, 2, 0), (256, 4, 1, 0), (0, 4, 3, 0), (0, 16, 5, 0), (512, 16, 5, 0),
+                                  (128, 2, 2, 1), (0, 4, 3, 1), (0, 16, 5, 1), (512, 16, 5, 1), (256, 8, 5, 2), (0, 2, 10, 3)):
             fa = np.zeros(n, np.int32); pa = np.zeros(n, np.int32); va = np.zeros(n, np.int32)
-            emu.emu_chain_fill(n, sx, sy, prm["max_dist_x"], prm["min_dist_x"], prm["max_dist_y"], prm["bw"], max_skip | (win << 16), max_iter | (nwv << 24) | (kt << 20), avg, 1.0, fa, pa, va)
+            emu.emu_chain_fill(n, sx, sy, prm["max_dist_x"], prm["min_dist_x"], prm["max_dist_y"], prm["bw"], max_skip | (ktf << 8) | (win << 16), max_iter | (nwv << 24) | (kt << 20), avg, 1.0, fa, pa, va)
             u = np.zeros(n, np.uint64); bx = np.zeros(n, np.uint64); by = np.zeros(n, np.uint64); nu = C.c_int()
             nv = H.h_chain_extract(n, sx, sy, fa, pa, va, 3, 40, C.byref(nu), u, bx, by)
-            assert np.array_equal(u[:nu.value], ou) and np.array_equal(bx[:nv], obx) and np.array_equal(by[:nv], oby), (seed, n, win, nwv, kt)
+            assert np.array_equal(u[:nu.value], ou) and np.array_equal(bx[:nv], obx) and np.array_equal(by[:nv], oby), (seed, n, win, nwv, kt, ktf)
             n_run += 1
-    assert n_run == 30
+    assert n_run == 60
 
 
 def test_packed_multiwave_ksw_kernel_matches_oracle(emu_v):

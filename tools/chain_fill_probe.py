@@ -26,6 +26,7 @@ def one():
     ctx = gpu.Context(0, 8 << 30)
     L = gpu.lib()
     L.wm_chain_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, W.u64p, W.i32p, C.c_void_p, W.u64p, W.u64p, W.i32p, W.i32p]
+    L.wm_last_aux_ms.restype = C.c_float; L.wm_last_aux_ms.argtypes = [C.c_void_p]
     for name, n_mini, copies in (("dense 5000-window", 4000, 64), ("medium 600-window", 20000, 8)):
         x, y = anchors(7, n_mini, copies)
         a = np.zeros(len(x), M128); a["x"], a["y"] = x, y
@@ -44,6 +45,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "one":
         one()
     else:
-        for env in ({"WM_CHAIN_WIDE": "0"}, {"WM_CHAIN_WIDE_GEOM": "16x5"}, {"WM_CHAIN_WIDE_GEOM": "8x10"}, {"WM_CHAIN_WIDE_GEOM": "16x3"}, {"WM_CHAIN_WIDE_GEOM": "8x5"}, {"WM_CHAIN_WIDE_GEOM": "4x10"}):
+        for env in ({"WM_CHAIN_WIDE": "0"}, {"WM_CHAIN_WIDE_GEOM": "16x5"}, {"WM_CHAIN_WIDE_GEOM": "16x5", "WM_CHAIN_WIDE_FIRST": "2"}, {"WM_CHAIN_WIDE_GEOM": "16x5", "WM_CHAIN_WIDE_FIRST": "5"},
+                    {"WM_CHAIN_WIDE_GEOM": "8x10"}, {"WM_CHAIN_WIDE_GEOM": "16x3"}, {"WM_CHAIN_WIDE_GEOM": "8x5"}, {"WM_CHAIN_WIDE_GEOM": "4x10"}):
             print("==", env, flush=True)
             subprocess.run([sys.executable, os.path.abspath(__file__), "one"], env=dict(os.environ, **env))

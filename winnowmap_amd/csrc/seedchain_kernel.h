@@ -117,17 +117,8 @@ WM_DEV void seed_wave(const wm_index_view_t ix, const wm_seed_job_t jb, const wm
 	WM_END
 }
 
-// 31 - clz for v > 0 (ilog2_32, src/chain.c:15-20)
-WM_DEV V<int> ilog2_pos(V<int> v)
-{
-	V<int> r = 0;
-	r = sel(v >= (1 << 16), r + 16, r); v = sel(v >= (1 << 16), v >> 16, v);
-	r = sel(v >= (1 << 8), r + 8, r);   v = sel(v >= (1 << 8), v >> 8, v);
-	r = sel(v >= (1 << 4), r + 4, r);   v = sel(v >= (1 << 4), v >> 4, v);
-	r = sel(v >= (1 << 2), r + 2, r);   v = sel(v >= (1 << 2), v >> 2, v);
-	r = sel(v >= 2, r + 1, r);
-	return r;
-}
+// floor(log2(v)) for v > 0, 0 for v == 0 (ilog2_32, src/chain.c:15-20, and the dd > 0 guard at its call sites): one v_ffbh_u32
+WM_DEV V<int> ilog2_pos(V<int> v) { return V<int>(31) - vclz(v | 1); }
 
 // LDS holds a circular window of the W most recent anchors (W a power of two >= 128): their x, y and f, p, t — 28 B per
 // anchor — so every dependent access of the sequential part is an LDS round trip. When the anchor set is larger than the
@@ -202,25 +193,30 @@ WM_DEV void chain_tile_resolve(const vbool valid, const V<int> sc, const V<int> 
 	if (brk < 64) cs.stop = true; else cs.n_skip = readlane(nk, 63);
 }
 
-// score of predecessor j for anchor (ri, qi, span): src/chain.c:57-78
-WM_DEV void chain_score(const wm_chain_job_t &jb, uint64_t ri, int qi, int span, const V<uint64_t> xj, const V<uint64_t> yj, const V<int> fj, V<int> &sc, vbool &ok)
+// score of predecessor j for anchor (ri, qi, span): src/chain.c:57-78. Every predecessor that is scored lies in [st, i), and st has been advanced
+// past everything with x[j] + max_dist_x < x[i] (src/chain.c:50) before any relaxation of it, so 0 <= x[i] - x[j] <= max_dist_x < 2^31 there (x is
+// sorted): the LOW words of x decide, and the score is 32-bit arithmetic throughout (the reference's int64 dr and its clamp at :64 never bind).
+// xj, yj: low words of a[j].x (reference position) and a[j].y (query position).
+WM_DEV void chain_score(const wm_chain_job_t &jb, uint32_t ri, int qi, int span, const V<uint32_t> xj, const V<uint32_t> yj, const V<int> fj, V<int> &sc, vbool &ok)
 {
-	const V<long long> dr = cast<long long>(V<uint64_t>(ri) - xj);
-	const V<int> dq = V<int>(qi) - cast<int>(cast<uint32_t>(yj));
-	ok = !(dr == 0LL || dq <= 0) && !(dq > jb.max_dist_y || dq > jb.max_dist_x);                 // :60-61
-	const V<long long> dql = cast<long long>(dq);
-	const V<int> dd = cast<int>(sel(dr > dql, dr - dql, dql - dr));
+	const V<int> dr = cast<int>(V<uint32_t>(ri) - xj);
+	const V<int> dq = V<int>(qi) - cast<int>(yj);
+	ok = !(dr == 0 || dq <= 0) && !(dq > jb.max_dist_y || dq > jb.max_dist_x);                    // :60-61
+	const V<int> dd = sel(dr > dq, dr - dq, dq - dr);
 	ok = ok && !(dd > jb.bw);                                                                      // :63
-	const V<int> drc = cast<int>(sel(dr > (long long)0x7fffffff, V<long long>(0x7fffffff), dr));
-	const V<int> md = vmin(dq, drc);
-	V<int> s0 = vmin(md, V<int>(span));                                                            // :65-66
-	const V<int> lg = sel(dd > 0, ilog2_pos(dd), 0);
+	V<int> s0 = vmin(vmin(dq, dr), V<int>(span));                                                  // :65-66
+	const V<int> lg = ilog2_pos(dd);
 	const V<double> lin = cast<double>(dd) * .01 * (double)jb.avg_qspan;
 	V<int> gc = cast<int>(lin) + (lg >> 1);                                                        // :76
-	if (jb.is_cdna) gc = sel(dr > dql, vmin(cast<int>(lin), lg), gc);                              // :69-74: an intron (reference gap) costs min(linear, log)
-	s0 = s0 - cast<int>(cast<double>(gc) * (double)jb.gap_scale + .499);                           // :77
+	if (jb.is_cdna) gc = sel(dr > dq, vmin(cast<int>(lin), lg), gc);                               // :69-74: an intron (reference gap) costs min(linear, log)
+	if (jb.gap_scale != 1.0f) { WM_KEEP_BRANCH(); gc = cast<int>(cast<double>(gc) * (double)jb.gap_scale + .499); }      // :77 (with the default scale (int)((double)gc + .499) == gc: gc >= 0)
+	s0 = s0 - gc;
 	sc = s0 + fj;
 }
+
+// the low words of x / y of anchor j: in the LDS window (index already wrapped) or in the job's anchor array
+WM_DEV V<uint32_t> chain_lo_lds(const uint64_t *s, const V<int> k) { return gld((const uint32_t*)s, k * 2); }
+WM_DEV V<uint32_t> chain_lo_far(const uint64_t *a, const V<long long> j, int which) { return gld((const uint32_t*)a, j * 4LL + (long long)(2 * which)); }
 
 // U tiles (64 predecessors each) are scored together so that their memory latencies overlap; the automaton is then
 // resolved tile by tile. Marks of a later tile never target an earlier one (p[j] < j), and marks written for tiles
@@ -239,19 +235,20 @@ WM_DEV void chain_group(const wm_chain_job_t &jb, long long hi0, long long st, l
 		const V<long long> j = V<long long>(hi0 - 64 * u) - cast<long long>(ln);                  // lane 0 = first visited
 		jj[u] = j;
 		const vbool in = j >= st, res = j >= lo;
+		const V<int> jw = cast<int>(j) & (int)wm;
 		V<int> pj = -1, fj = 0;
-		V<uint64_t> xj = (uint64_t)0, yj = (uint64_t)0;
+		V<uint32_t> xj = 0u, yj = 0u;
 		sc[u] = 0; tj[u] = 0;
 		valid[u] = in && !in;                                                                      // false
 		if (hi0 - 64 * u - 63 >= lo) {                                                             // whole tile resident (the common case)
-			WM_IF(in) xj = gld(sx, j & wm); yj = gld(sy, j & wm); fj = gld(sf, j & wm); pj = gld(sp, j & wm); WM_END
+			WM_IF(in) xj = chain_lo_lds(sx, jw); yj = chain_lo_lds(sy, jw); fj = gld(sf, jw); pj = gld(sp, jw); WM_END
 		} else {
-			WM_IF(in && res) xj = gld(sx, j & wm); yj = gld(sy, j & wm); fj = gld(sf, j & wm); pj = gld(sp, j & wm); WM_END
-			WM_IF(in && !res) xj = gld(a, j * 2LL); yj = gld(a, j * 2LL + 1LL); fj = cld(gf, j); pj = cld(gp, j); WM_END
+			WM_IF(in && res) xj = chain_lo_lds(sx, jw); yj = chain_lo_lds(sy, jw); fj = gld(sf, jw); pj = gld(sp, jw); WM_END
+			WM_IF(in && !res) xj = chain_lo_far(a, j, 0); yj = chain_lo_far(a, j, 1); fj = cld(gf, j); pj = cld(gp, j); WM_END
 		}
 		WM_IF(in)
 			vbool ok = in;
-			chain_score(jb, ri, qi, span, xj, yj, fj, sc[u], ok);
+			chain_score(jb, (uint32_t)ri, qi, span, xj, yj, fj, sc[u], ok);
 			valid[u] = ok;
 		WM_END
 		// marks (src/chain.c:86): a scored predecessor marks ITS predecessor, if that one can still be visited
@@ -374,31 +371,19 @@ WM_DEV void chain_block(const wm_chain_job_t jb, const wm128_t *anchor_pool, int
 			const V<long long> j = V<long long>(hi) - cast<long long>(ln);
 			const vbool in = j >= st, res = j >= lo;
 			V<int> sc = 0, pj = -1, fj = 0, tj = 0;
-			V<uint64_t> xj = (uint64_t)0, yj = (uint64_t)0;
+			V<uint32_t> xj = 0u, yj = 0u;
+			const V<int> jw = cast<int>(j) & (int)wm;
 			vbool valid = in && !in;
 			const bool all_res = hi - 63 >= lo;                                                     // whole tile resident (the common case)
 			if (all_res) {
-				WM_IF(in) xj = gld(sx, j & wm); yj = gld(sy, j & wm); fj = gld(sf, j & wm); pj = gld(sp, j & wm); WM_END
+				WM_IF(in) xj = chain_lo_lds(sx, jw); yj = chain_lo_lds(sy, jw); fj = gld(sf, jw); pj = gld(sp, jw); WM_END
 			} else {
-				WM_IF(in && res) xj = gld(sx, j & wm); yj = gld(sy, j & wm); fj = gld(sf, j & wm); pj = gld(sp, j & wm); WM_END
-				WM_IF(in && !res) xj = gld(a, j * 2LL); yj = gld(a, j * 2LL + 1LL); fj = cld(gf, j); pj = cld(gp, j); WM_END
+				WM_IF(in && res) xj = chain_lo_lds(sx, jw); yj = chain_lo_lds(sy, jw); fj = gld(sf, jw); pj = gld(sp, jw); WM_END
+				WM_IF(in && !res) xj = chain_lo_far(a, j, 0); yj = chain_lo_far(a, j, 1); fj = cld(gf, j); pj = cld(gp, j); WM_END
 			}
 			WM_IF(in)
-				const V<long long> dr = cast<long long>(V<uint64_t>(ri) - xj);
-				const V<int> dq = V<int>(qi) - cast<int>(cast<uint32_t>(yj));
-				vbool ok = !(dr == 0LL || dq <= 0) && !(dq > jb.max_dist_y || dq > jb.max_dist_x);
-				const V<long long> dql = cast<long long>(dq);
-				const V<int> dd = cast<int>(sel(dr > dql, dr - dql, dql - dr));
-				ok = ok && !(dd > jb.bw);
-				const V<int> drc = cast<int>(sel(dr > (long long)0x7fffffff, V<long long>(0x7fffffff), dr));
-				const V<int> md = vmin(dq, drc);
-				V<int> s0 = vmin(md, V<int>(span));
-				const V<int> lg = sel(dd > 0, ilog2_pos(dd), 0);
-				const V<double> lin = cast<double>(dd) * .01 * (double)jb.avg_qspan;
-				V<int> gc = cast<int>(lin) + (lg >> 1);
-				if (jb.is_cdna) gc = sel(dr > dql, vmin(cast<int>(lin), lg), gc);
-				s0 = s0 - cast<int>(cast<double>(gc) * (double)jb.gap_scale + .499);
-				sc = s0 + fj;
+				vbool ok = in;
+				chain_score(jb, (uint32_t)ri, qi, span, xj, yj, fj, sc, ok);
 				valid = ok;
 			WM_END
 			const V<long long> pjl = cast<long long>(pj);
@@ -480,10 +465,14 @@ WM_DEV void chain_block(const wm_chain_job_t jb, const wm128_t *anchor_pool, int
 // wavefronts), one barrier, every wavefront reads its marks and turns the per-tile maxima (lanes = tiles) into the running maximum before its tiles with
 // one wave scan, publishes the improvement / marked ballots, one barrier, and the automaton runs over the tiles that have events (found with one
 // ballot over the published masks). NWV * KT tiles per step: 16 x 5 = 5 120 predecessors — a whole max_iter window — for the same three barriers.
+// kt_first: tiles per wavefront in the FIRST step of an anchor (a step scores all of its tiles before the automaton runs, so a scan that ends early
+// pays for tiles it never needed). On synthetic arrays whose scans break within a few hundred predecessors a narrow first step wins (8.4 vs 12.1 us per
+// anchor, profiles/r06_chain_fill_probe.txt), but the 5-Mb contigs of BASELINE config 5 scan their whole window: 28.8 s with kt_first = 1 against 20.0 s
+// with kt_first = KT (profiles/r06_closure.jsonl) — so the callers pass KT unless WM_CHAIN_WIDE_FIRST says otherwise.
 // pub: NT * 69 ints (tile maxima | I lo,hi,M lo,hi per tile | 64 scores per tile, written only by tiles that have an improvement), NT = NWV * KT <= 128.
 // ------------------------------------------------------------------------------------------------------
 template <int KT>
-WM_DEV void chain_block_wide(const wm_chain_job_t jb, const wm128_t *anchor_pool, int NWV, int W, uint64_t *sx, uint64_t *sy, int *sf, int *sp, int *st_,
+WM_DEV void chain_block_wide(const wm_chain_job_t jb, const wm128_t *anchor_pool, int NWV, int kt_first, int W, uint64_t *sx, uint64_t *sy, int *sf, int *sp, int *st_,
                              int *pub, int *gf, int *gp, int *gt)
 {
 	const V<int> ln = lane();
@@ -519,10 +508,11 @@ WM_DEV void chain_block_wide(const wm_chain_job_t jb, const wm128_t *anchor_pool
 		st = chain_advance_st(st, i, ri, (uint64_t)jb.max_dist_x, -1, lo, wm, sx, a);
 		if (i - st > jb.max_iter) st = chain_advance_st(st, i, ri, (uint64_t)jb.min_dist_x, jb.max_iter, lo, wm, sx, a);
 		bool stop = false;
-		for (long long hi0 = (long long)i - 1; hi0 >= st && !stop; hi0 -= 64LL * NT) {
+		int NTs = NWV * kt_first;                                                               // tiles of the first step (see the header), NT from the second on
+		for (long long hi0 = (long long)i - 1; hi0 >= st && !stop; hi0 -= 64LL * NTs, NTs = NT) {
 			// tiles of this step that hold predecessors at all: 0 .. nt - 1
 			const long long span_j = hi0 - st + 1;
-			const int nt = span_j >= 64LL * NT ? NT : (int)((span_j + 63) >> 6);
+			const int nt = span_j >= 64LL * NTs ? NTs : (int)((span_j + 63) >> 6);
 			V<int> sc[KT], pmx[KT];
 			vbool valid[KT];
 			bool any_far = false;
@@ -534,24 +524,29 @@ WM_DEV void chain_block_wide(const wm_chain_job_t jb, const wm128_t *anchor_pool
 				valid[k] = ln < 0;                                                              // false
 				if (u >= nt) continue;
 				const long long hi = hi0 - 64LL * u;
-				const V<long long> j = V<long long>(hi) - cast<long long>(ln);
-				const vbool in = j >= st, res = j >= lo;
+				const V<int> j = V<int>((int)hi) - ln;                                          // (anchor indices are ints: n < 2^31)
+				const vbool in = j >= (int)st;
+				const V<int> jw = j & (int)wm;
 				V<int> pj = -1, fj = 0;
-				V<uint64_t> xj = (uint64_t)0, yj = (uint64_t)0;
+				V<uint32_t> xj = 0u, yj = 0u;
 				if (hi - 63 >= lo) {                                                            // whole tile resident (the common case)
-					WM_IF(in) xj = gld(sx, j & wm); yj = gld(sy, j & wm); fj = gld(sf, j & wm); pj = gld(sp, j & wm); WM_END
+					WM_IF(in) xj = chain_lo_lds(sx, jw); yj = chain_lo_lds(sy, jw); fj = gld(sf, jw); pj = gld(sp, jw); WM_END
 				} else {
-					WM_IF(in && res) xj = gld(sx, j & wm); yj = gld(sy, j & wm); fj = gld(sf, j & wm); pj = gld(sp, j & wm); WM_END
-					WM_IF(in && !res) xj = gld(a, j * 2LL); yj = gld(a, j * 2LL + 1LL); fj = cld(gf, j); pj = cld(gp, j); WM_END
+					const vbool res = cast<long long>(j) >= lo;
+					const V<long long> jl = cast<long long>(j);
+					WM_IF(in && res) xj = chain_lo_lds(sx, jw); yj = chain_lo_lds(sy, jw); fj = gld(sf, jw); pj = gld(sp, jw); WM_END
+					WM_IF(in && !res) xj = chain_lo_far(a, jl, 0); yj = chain_lo_far(a, jl, 1); fj = cld(gf, jl); pj = cld(gp, jl); WM_END
 				}
 				WM_IF(in)
 					vbool ok = in;
-					chain_score(jb, ri, qi, span, xj, yj, fj, sc[k], ok);
+					chain_score(jb, (uint32_t)ri, qi, span, xj, yj, fj, sc[k], ok);
 					valid[k] = ok;
 				WM_END
-				const V<long long> pjl = cast<long long>(pj);
-				WM_IF(valid[k] && pj >= 0 && pjl >= lo) gst(st_, pjl & wm, V<int>(i)); WM_END
-				if (st < lo) {
+				if (st >= lo) {                                                                 // every predecessor that can be marked is resident (p[j] < st is never visited: its mark would never be read)
+					WM_IF(valid[k] && pj >= (int)st) gst(st_, pj & (int)wm, V<int>(i)); WM_END
+				} else {
+					const V<long long> pjl = cast<long long>(pj);
+					WM_IF(valid[k] && pj >= 0 && pjl >= lo) gst(st_, pj & (int)wm, V<int>(i)); WM_END
 					const vbool far_mark = valid[k] && pj >= 0 && pjl < lo && pjl >= st;
 					WM_IF(far_mark) cst(gt, pjl, V<int>(i)); WM_END
 					any_far = any_far || any(far_mark);
@@ -574,13 +569,13 @@ WM_DEV void chain_block_wide(const wm_chain_job_t jb, const wm128_t *anchor_pool
 				const int u = k * NWV + wv;
 				if (u >= nt) continue;
 				const long long hi = hi0 - 64LL * u;
-				const V<long long> j = V<long long>(hi) - cast<long long>(ln);
+				const V<int> j = V<int>((int)hi) - ln;
 				V<int> tj = 0;
-				if (hi - 63 >= lo) { WM_IF(valid[k]) tj = gld(st_, j & wm); WM_END }
+				if (hi - 63 >= lo) { WM_IF(valid[k]) tj = gld(st_, j & (int)wm); WM_END }
 				else {
-					const vbool res = j >= lo;
-					WM_IF(valid[k] && res) tj = gld(st_, j & wm); WM_END
-					WM_IF(valid[k] && !res) tj = cld(gt, j); WM_END
+					const vbool res = cast<long long>(j) >= lo;
+					WM_IF(valid[k] && res) tj = gld(st_, j & (int)wm); WM_END
+					WM_IF(valid[k] && !res) tj = cld(gt, cast<long long>(j)); WM_END
 				}
 				int run_before = max_f;
 				if (u > 0) { const int tb = u - 1 < 64 ? readlane(s0, u - 1) : readlane(s1, u - 1 - 64); run_before = tb > run_before ? tb : run_before; }
@@ -626,7 +621,7 @@ WM_DEV void chain_block_wide(const wm_chain_job_t jb, const wm128_t *anchor_pool
 					}
 				}
 			}
-			if (hi0 - 64LL * NT >= st && !stop) block_sync_lds();                               // another step follows: it overwrites the pub area (after the last step the barrier below does)
+			if (hi0 - 64LL * NTs >= st && !stop) block_sync_lds();                               // another step follows: it overwrites the pub area (after the last step the barrier below does)
 		}
 		if (wv == 0) {
 			WM_IF(ln == 0)

@@ -196,6 +196,7 @@ WM_DEV int wave_append(int *counter)
 // number of set bits of `mask` below this lane (v_mbcnt)
 WM_DEV int mbcnt(uint64_t mask) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u)); }
 
+WM_DEV int vclz(int v) { return __builtin_clz((unsigned)v); }                                   // per lane, v != 0
 WM_DEV int vpopc64(uint64_t m) { return __builtin_popcountll(m); }                     // per lane
 WM_DEV uint64_t lanemask_lt() { return ((uint64_t)1 << (threadIdx.x & 63u)) - 1; }      // bits of the lanes below this one
 

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64 * NWV) void chain_kernel_block(const wm_chain_jo
 }
 // ... with the whole predecessor window of an anchor per step (chain_block_wide, round 6): blockDim / 64 wavefronts x KT tiles
 template <int KT>
-__global__ __launch_bounds__(1024) void chain_kernel_wide(const wm_chain_job_t *jobs, const int *order, const wm128_t *anchors, int *fpvt, int W)
+__global__ __launch_bounds__(1024) void chain_kernel_wide(const wm_chain_job_t *jobs, const int *order, const wm128_t *anchors, int *fpvt, int W, int kt_first)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int j = order[blockIdx.x];
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(1024) void chain_kernel_wide(const wm_chain_job_t *
 	uint64_t *sx = (uint64_t*)smem, *sy = sx + W;
 	int *sf = (int*)(sy + W), *sp = sf + W, *st = sp + W, *pub = st + W;
 	int *gf = fpvt + jb.a_off * 4, *gp = gf + jb.n, *gt = gp + 2 * (size_t)jb.n;
-	wmk::chain_block_wide<KT>(jb, anchors, (int)(blockDim.x >> 6), W, sx, sy, sf, sp, st, pub, gf, gp, gt);
+	wmk::chain_block_wide<KT>(jb, anchors, (int)(blockDim.x >> 6), kt_first, W, sx, sy, sf, sp, st, pub, gf, gp, gt);
 }
 
 extern "C" float wm_last_aux_ms(const wm_ctx_t *c) { return c ? c->aux_ms : 0.f; }
@@ -1043,11 +1043,12 @@ try {
 				int gw = 16, gk = 5;
 				if (const char *g = getenv("WM_CHAIN_WIDE_GEOM")) sscanf(g, "%dx%d", &gw, &gk);
 				if ((gk != 10 && gk != 3 && gk != 5) || gw < 1 || gw > 16 || gw * gk > 128) { gw = 16; gk = 5; }      // (the instantiated tile counts; chain_block_wide: NT <= 128)
+				const int kt_first = getenv("WM_CHAIN_WIDE_FIRST") ? std::min(gk, std::max(1, atoi(getenv("WM_CHAIN_WIDE_FIRST")))) : gk;      // tiles per wavefront in an anchor's first step (seedchain_kernel.h)
 				if (k == 0 && wide) {
 					const size_t lds = (size_t)4096 * 28 + (size_t)gw * gk * 69 * 4 + 64;
-					if (gk == 10) { HIPCHK(hipFuncSetAttribute((const void*)chain_kernel_wide<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); hipLaunchKernelGGL(chain_kernel_wide<10>, dim3(e - b), dim3(64 * gw), lds, c->stream, d_jobs, d_order + b, d_a, d_fpvt, 4096); }
-					else if (gk == 3) { HIPCHK(hipFuncSetAttribute((const void*)chain_kernel_wide<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); hipLaunchKernelGGL(chain_kernel_wide<3>, dim3(e - b), dim3(64 * gw), lds, c->stream, d_jobs, d_order + b, d_a, d_fpvt, 4096); }
-					else { HIPCHK(hipFuncSetAttribute((const void*)chain_kernel_wide<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); hipLaunchKernelGGL(chain_kernel_wide<5>, dim3(e - b), dim3(64 * gw), lds, c->stream, d_jobs, d_order + b, d_a, d_fpvt, 4096); }
+					if (gk == 10) { HIPCHK(hipFuncSetAttribute((const void*)chain_kernel_wide<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); hipLaunchKernelGGL(chain_kernel_wide<10>, dim3(e - b), dim3(64 * gw), lds, c->stream, d_jobs, d_order + b, d_a, d_fpvt, 4096, kt_first); }
+					else if (gk == 3) { HIPCHK(hipFuncSetAttribute((const void*)chain_kernel_wide<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); hipLaunchKernelGGL(chain_kernel_wide<3>, dim3(e - b), dim3(64 * gw), lds, c->stream, d_jobs, d_order + b, d_a, d_fpvt, 4096, kt_first); }
+					else { HIPCHK(hipFuncSetAttribute((const void*)chain_kernel_wide<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); hipLaunchKernelGGL(chain_kernel_wide<5>, dim3(e - b), dim3(64 * gw), lds, c->stream, d_jobs, d_order + b, d_a, d_fpvt, 4096, kt_first); }
 				} else if (k == 0) hipLaunchKernelGGL(chain_kernel_block<NWV>, dim3(e - b), dim3(64 * NWV), (size_t)4096 * 28 + NWV * 69 * 4 + 64, c->stream, d_jobs, d_order + b, d_a, d_fpvt, 4096);
 				else hipLaunchKernelGGL(chain_kernel, dim3(e - b), dim3(64), (size_t)(k == 3 ? 256 : 1024) * 28, c->stream, d_jobs, d_order + b, d_a, d_fpvt, k == 3 ? 256 : 1024);
 			}

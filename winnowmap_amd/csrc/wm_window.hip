@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64 * NWV) void win_chain_kernel_block(const wm_chai
 
 // the dense fill with the whole predecessor window of an anchor per step (seedchain_kernel.h: chain_block_wide): 16 wavefronts x KT tiles
 template <int KT>
-__global__ __launch_bounds__(1024) void win_chain_kernel_wide(const wm_chain_job_t *jobs, const int *list, const int *count, const wm128_t *anchors, int *fpvt, int W)
+__global__ __launch_bounds__(1024) void win_chain_kernel_wide(const wm_chain_job_t *jobs, const int *list, const int *count, const wm128_t *anchors, int *fpvt, int W, int kt_first)
 {
 	WM_SETPRIO(2);
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(1024) void win_chain_kernel_wide(const wm_chain_job
 	uint64_t *sx = (uint64_t*)smem, *sy = sx + W;
 	int *sf = (int*)(sy + W), *sp = sf + W, *st = sp + W, *pub = st + W;
 	int *gf = fpvt + jb.a_off * 4, *gp = gf + jb.n, *gt = gp + 2 * (size_t)jb.n;
-	wmk::chain_block_wide<KT>(jb, anchors, 16, W, sx, sy, sf, sp, st, pub, gf, gp, gt);
+	wmk::chain_block_wide<KT>(jb, anchors, 16, kt_first, W, sx, sy, sf, sp, st, pub, gf, gp, gt);
 }
 
 // src/chain.c:89-165 per job; f, p staged in LDS when the job fits (lo, lds_cap], global slab otherwise (lds_cap = 0)
@@ -342,7 +342,8 @@ int window_launch(wm_ctx_t *c, int n, const wm_window_job_t *jobs, const uint8_t
 		static const bool wide = !(getenv("WM_CHAIN_WIDE") && atoi(getenv("WM_CHAIN_WIDE")) == 0);
 		if (wide) {
 			HIPCHK(hipFuncSetAttribute((const void*)win_chain_kernel_wide<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-			hipLaunchKernelGGL(win_chain_kernel_wide<5>, dim3(n), dim3(1024), (size_t)4096 * 28 + 80 * 69 * 4 + 64, c->stream, d_cj, d_lists, d_counts, d_a, d_fpvt, 4096);
+			static const int kt_first = getenv("WM_CHAIN_WIDE_FIRST") ? std::min(5, std::max(1, atoi(getenv("WM_CHAIN_WIDE_FIRST")))) : 5;      // tiles per wavefront in an anchor's first step (seedchain_kernel.h)
+			hipLaunchKernelGGL(win_chain_kernel_wide<5>, dim3(n), dim3(1024), (size_t)4096 * 28 + 80 * 69 * 4 + 64, c->stream, d_cj, d_lists, d_counts, d_a, d_fpvt, 4096, kt_first);
 		} else {
 			HIPCHK(hipFuncSetAttribute((const void*)win_chain_kernel_block<NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 			hipLaunchKernelGGL(win_chain_kernel_block<NWV>, dim3(n), dim3(64 * NWV), (size_t)4096 * 28 + NWV * 69 * 4 + 64, c->stream, d_cj, d_lists, d_counts, d_a, d_fpvt, 4096);
