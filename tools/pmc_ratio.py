@@ -27,6 +27,9 @@ def key(kernel_name):        # "void ksw_dp_kernel<16, true, false>(...)" -> "ks
     if not m:
         return None
     k = m.group(1)
+    cm = re.match(r"ksw_chain_kernel<(\d+), (\w+), (\w+), (\w+)>", k)      # the EXACT variants of one chained-workgroup class share a class id (bench.py: "*")
+    if cm:
+        return "ksw_chain_kernel<%s, %s, %s, *>" % cm.groups()[:3]
     pm = re.match(r"ksw_pmulti_kernel<(\d+), (\d+)", k)      # the <CLIP, HASN> variants of one geometry are one class in bench.py
     return "ksw_pmulti_kernel<%s, %s>" % pm.groups() if pm else k              # (spelled like bench.py's class names, spaces included; stripe kernels keep their <BP, NWV, CLIP, HASN>)
 
