@@ -509,10 +509,11 @@ WM_DEV void chain_block_wide(const wm_chain_job_t jb, const wm128_t *anchor_pool
 		if (i - st > jb.max_iter) st = chain_advance_st(st, i, ri, (uint64_t)jb.min_dist_x, jb.max_iter, lo, wm, sx, a);
 		bool stop = false;
 		int NTs = NWV * kt_first;                                                               // tiles of the first step (see the header), NT from the second on
-		for (long long hi0 = (long long)i - 1; hi0 >= st && !stop; hi0 -= 64LL * NTs, NTs = NT) {
+		const int sti = (int)st, loi = (int)lo;                                                 // (anchor indices are ints, n < 2^31: the tile bounds are 32-bit scalar arithmetic)
+		for (int hi0 = i - 1; hi0 >= sti && !stop; hi0 -= 64 * NTs, NTs = NT) {
 			// tiles of this step that hold predecessors at all: 0 .. nt - 1
-			const long long span_j = hi0 - st + 1;
-			const int nt = span_j >= 64LL * NTs ? NTs : (int)((span_j + 63) >> 6);
+			const int span_j = hi0 - sti + 1;
+			const int nt = span_j >= 64 * NTs ? NTs : (span_j + 63) >> 6;
 			V<int> sc[KT], pmx[KT];
 			vbool valid[KT];
 			bool any_far = false;
@@ -523,32 +524,39 @@ WM_DEV void chain_block_wide(const wm_chain_job_t jb, const wm128_t *anchor_pool
 				sc[k] = 0; pmx[k] = NEG;
 				valid[k] = ln < 0;                                                              // false
 				if (u >= nt) continue;
-				const long long hi = hi0 - 64LL * u;
-				const V<int> j = V<int>((int)hi) - ln;                                          // (anchor indices are ints: n < 2^31)
-				const vbool in = j >= (int)st;
+				const int hi = hi0 - 64 * u;
+				const V<int> j = V<int>(hi) - ln;
 				const V<int> jw = j & (int)wm;
 				V<int> pj = -1, fj = 0;
 				V<uint32_t> xj = 0u, yj = 0u;
-				if (hi - 63 >= lo) {                                                            // whole tile resident (the common case)
-					WM_IF(in) xj = chain_lo_lds(sx, jw); yj = chain_lo_lds(sy, jw); fj = gld(sf, jw); pj = gld(sp, jw); WM_END
-				} else {
-					const vbool res = cast<long long>(j) >= lo;
-					const V<long long> jl = cast<long long>(j);
-					WM_IF(in && res) xj = chain_lo_lds(sx, jw); yj = chain_lo_lds(sy, jw); fj = gld(sf, jw); pj = gld(sp, jw); WM_END
-					WM_IF(in && !res) xj = chain_lo_far(a, jl, 0); yj = chain_lo_far(a, jl, 1); fj = cld(gf, jl); pj = cld(gp, jl); WM_END
-				}
-				WM_IF(in)
-					vbool ok = in;
+				if (hi - 63 >= sti && hi - 63 >= loi) {                                         // every lane holds a resident predecessor (all but the last tile of a scan inside the window): no lane masks
+					WM_KEEP_BRANCH();
+					xj = chain_lo_lds(sx, jw); yj = chain_lo_lds(sy, jw); fj = gld(sf, jw); pj = gld(sp, jw);
+					vbool ok = ln >= 0;
 					chain_score(jb, (uint32_t)ri, qi, span, xj, yj, fj, sc[k], ok);
 					valid[k] = ok;
-				WM_END
-				if (st >= lo) {                                                                 // every predecessor that can be marked is resident (p[j] < st is never visited: its mark would never be read)
-					WM_IF(valid[k] && pj >= (int)st) gst(st_, pj & (int)wm, V<int>(i)); WM_END
 				} else {
-					const V<long long> pjl = cast<long long>(pj);
-					WM_IF(valid[k] && pj >= 0 && pjl >= lo) gst(st_, pj & (int)wm, V<int>(i)); WM_END
-					const vbool far_mark = valid[k] && pj >= 0 && pjl < lo && pjl >= st;
-					WM_IF(far_mark) cst(gt, pjl, V<int>(i)); WM_END
+					const vbool in = j >= sti;
+					if (hi - 63 >= loi) {                                                       // whole tile resident
+						WM_IF(in) xj = chain_lo_lds(sx, jw); yj = chain_lo_lds(sy, jw); fj = gld(sf, jw); pj = gld(sp, jw); WM_END
+					} else {
+						const vbool res = j >= loi;
+						const V<long long> jl = cast<long long>(j);
+						WM_IF(in && res) xj = chain_lo_lds(sx, jw); yj = chain_lo_lds(sy, jw); fj = gld(sf, jw); pj = gld(sp, jw); WM_END
+						WM_IF(in && !res) xj = chain_lo_far(a, jl, 0); yj = chain_lo_far(a, jl, 1); fj = cld(gf, jl); pj = cld(gp, jl); WM_END
+					}
+					WM_IF(in)
+						vbool ok = in;
+						chain_score(jb, (uint32_t)ri, qi, span, xj, yj, fj, sc[k], ok);
+						valid[k] = ok;
+					WM_END
+				}
+				if (sti >= loi) {                                                                 // every predecessor that can be marked is resident (p[j] < st is never visited: its mark would never be read)
+					WM_IF(valid[k] && pj >= sti) gst(st_, pj & (int)wm, V<int>(i)); WM_END
+				} else {
+					WM_IF(valid[k] && pj >= 0 && pj >= loi) gst(st_, pj & (int)wm, V<int>(i)); WM_END
+					const vbool far_mark = valid[k] && pj >= 0 && pj < loi && pj >= sti;
+					WM_IF(far_mark) cst(gt, cast<long long>(pj), V<int>(i)); WM_END
 					any_far = any_far || any(far_mark);
 				}
 				pmx[k] = wave_scan_max(sel(valid[k], sc[k], NEG));                              // inclusive prefix maximum inside the tile (lane 0 = first visited)
@@ -568,12 +576,13 @@ WM_DEV void chain_block_wide(const wm_chain_job_t jb, const wm128_t *anchor_pool
 			for (int k = 0; k < KT; ++k) {
 				const int u = k * NWV + wv;
 				if (u >= nt) continue;
-				const long long hi = hi0 - 64LL * u;
-				const V<int> j = V<int>((int)hi) - ln;
+				const int hi = hi0 - 64 * u;
+				const V<int> j = V<int>(hi) - ln;
 				V<int> tj = 0;
-				if (hi - 63 >= lo) { WM_IF(valid[k]) tj = gld(st_, j & (int)wm); WM_END }
+				if (hi - 63 >= sti && hi - 63 >= loi) tj = gld(st_, j & (int)wm);              // (no mask: only valid lanes' marks are looked at)
+				else if (hi - 63 >= loi) { WM_IF(valid[k]) tj = gld(st_, j & (int)wm); WM_END }
 				else {
-					const vbool res = cast<long long>(j) >= lo;
+					const vbool res = j >= loi;
 					WM_IF(valid[k] && res) tj = gld(st_, j & (int)wm); WM_END
 					WM_IF(valid[k] && !res) tj = cld(gt, cast<long long>(j)); WM_END
 				}
@@ -600,7 +609,7 @@ WM_DEV void chain_block_wide(const wm_chain_job_t jb, const wm128_t *anchor_pool
 					while (evt && !stop) {
 						const int u = __builtin_ctzll(evt) + 64 * half;
 						evt &= evt - 1;
-						const long long hw = hi0 - 64LL * u;
+						const int hw = hi0 - 64 * u;
 						const uint64_t Iw = (uint64_t)(uint32_t)gld(pub_mask, (long long)u * 4) | (uint64_t)(uint32_t)gld(pub_mask, (long long)u * 4 + 1) << 32;
 						const uint64_t Mw = (uint64_t)(uint32_t)gld(pub_mask, (long long)u * 4 + 2) | (uint64_t)(uint32_t)gld(pub_mask, (long long)u * 4 + 3) << 32;
 						int brk = 64;
@@ -621,7 +630,7 @@ WM_DEV void chain_block_wide(const wm_chain_job_t jb, const wm128_t *anchor_pool
 					}
 				}
 			}
-			if (hi0 - 64LL * NTs >= st && !stop) block_sync_lds();                               // another step follows: it overwrites the pub area (after the last step the barrier below does)
+			if (hi0 - 64 * NTs >= sti && !stop) block_sync_lds();                               // another step follows: it overwrites the pub area (after the last step the barrier below does)
 		}
 		if (wv == 0) {
 			WM_IF(ln == 0)
