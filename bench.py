@@ -171,6 +171,8 @@ def ksw_class_name(k):
         return "ksw_pmulti_kernel<4, 4>"
     bp = (4, 8, 16)[k >> 3]
     exact, clip, hasn = bool(k & 4), bool(k & 2) or bool(k & 1), bool(k & 1)
+    if (k & 7) == 0 and bp <= 8 and os.environ.get("WM_KSW_DUAL", "0") not in ("", "0"):      # the gap-fill classes with two alignments per wavefront (ksw_dual_kernel.h, round 6; off by default)
+        return "ksw_dual_kernel<%d>" % (2 * bp)
     return "ksw_dpp_kernel<%d, %s, %s, %s>" % (bp, str(clip).lower(), str(hasn).lower(), str(exact).lower())
 
 

@@ -164,6 +164,12 @@ void wm_ksw_set_routing(int on, int rows4, int rows8);
  * one-wavefront classes with at least min_rows_exact rows, 4 = every job (tests); 0 = none (the round-5 routing). bp = 2 | 4 register pairs per wavefront
  * (256- / 512-lane stripes). < 0 / 0 = leave. Environment defaults: WM_KSW_CHAIN (1), WM_KSW_CHAIN_ROWS (2048), WM_KSW_CHAIN_BP (2). Results never depend on it. */
 void wm_ksw_set_chain_routing(int mode, int min_rows_exact, int bp);
+/* Two alignments per wavefront (round 6; csrc/ksw_dual_kernel.h) for the gap fills — band never clips (w >= qlen, tlen), no ambiguous base, KSW_EZ_APPROX_MAX: the classes
+ * that hold 60 % of all DP cells. Workgroup g runs jobs 2g and 2g + 1 of the class's size-sorted list in the low / high 16-bit halves of the same registers
+ * (ksw_extd2_sse's row loop src/ksw2_extd2_sse.c:123-313 once for both). on = 0 (the default: measured slower in the mapper): one alignment per
+ * wavefront (ksw_dp_packed) for those classes too. Environment default: WM_KSW_DUAL (0). Results never depend on it. wm_ksw_dual_enabled(): the current setting. */
+void wm_ksw_set_dual(int on);
+int wm_ksw_dual_enabled(void);
 
 /* Scalar drop-in with the reference's exact signature minus the kalloc handle (src/ksw2.h:60-61):
  * one alignment through the same kernels; cigar is malloc'd into *cigar_out (caller frees). */

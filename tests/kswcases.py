@@ -161,3 +161,37 @@ def stripe_edge_cases(seed, n, max_len):
                         zdrop=int(rng.choice([400, 200, 25, 50, -1, 100])), end_bonus=int(rng.choice([-1, 10, 0])),
                         flag=int(rng.choice([0x08, 0x08, 0x00, 0x40, 0xC2, 0x42, 0x80, 0x0A, 0x88]))))
     return out
+
+
+def dual_pairs(seed, n, ncs=(4, 8, 16)):
+    """(nc, scoring, [job] or [job, job]) for the two-alignments-per-wavefront kernel (ksw_dual_kernel.h): gap fills — band never clips, no N, approximate
+    maximum — of every size up to the window of nc 64-lane chunks: unrelated operands, related ones with indels, truncated queries, tiny targets, pairs of very
+    different lengths (one alignment finishes long before the other), single jobs (the odd one of a launch), mixed KSW_EZ_RIGHT / REV_CIGAR / EXTZ_ONLY flags"""
+    from winnowmap_amd import synth
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        nc = int(ncs[int(rng.integers(0, len(ncs)))])
+        lim = 64 * nc - 16
+        sc = dict(a=int(rng.integers(1, 4)), b=int(rng.integers(2, 7)), q_=int(rng.integers(2, 8)), e=int(rng.integers(1, 4)), q2=int(rng.integers(8, 30)), e2=1)
+        jobs = []
+        for x in range(1 if rng.random() < 0.15 else 2):
+            style = int(rng.integers(0, 4))
+            tlen = int(rng.integers(1, lim)) if style else int(rng.integers(1, 40))
+            t = rng.integers(0, 4, tlen).astype(np.uint8)
+            if style == 1:
+                q = rng.integers(0, 4, int(rng.integers(1, lim))).astype(np.uint8)
+            else:
+                q = synth.mutate_codes(t, rng, 0.05, 0.04, 0.04)
+                if len(q) == 0:
+                    q = t[:1].copy()
+                if rng.random() < 0.3:
+                    q = q[:max(1, int(rng.integers(1, len(q) + 1)))]
+            q = np.ascontiguousarray(q[:2000], np.uint8)
+            if min(len(q), tlen) > lim - 1:
+                continue
+            flag = 0x08 | (0x02 if rng.random() < 0.5 else 0) | (0x80 if rng.random() < 0.3 else 0) | (0x40 if rng.random() < 0.1 else 0)
+            jobs.append(dict(q=q, t=t, w=-1 if rng.random() < 0.5 else max(len(q), tlen) + int(rng.integers(0, 50)), flag=flag, zdrop=-1, end_bonus=0, **sc))
+        if jobs:
+            out.append((nc, sc, jobs))
+    return out

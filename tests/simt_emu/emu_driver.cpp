@@ -5,6 +5,7 @@
 #include "ksw_kernel.h"              // winnowmap_amd/csrc
 #include "ksw_packed_kernel.h"
 #include "ksw_packed_multi_kernel.h"
+#include "ksw_dual_kernel.h"
 #include "ksw_exts2_kernel.h"
 #include "ksw_plan.h"
 #include "sketch_kernel.h"
@@ -174,6 +175,53 @@ int emu_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 	ez_out[0] = res.max; ez_out[1] = res.zdropped; ez_out[2] = res.max_q; ez_out[3] = res.max_t; ez_out[4] = res.mqe;
 	ez_out[5] = res.mqe_t; ez_out[6] = res.mte; ez_out[7] = res.mte_q; ez_out[8] = res.score; ez_out[9] = res.reach_end;
 	return n;
+}
+// two alignments on ONE emulated wavefront (ksw_dual_kernel.h): nc = chunks of 64 lanes per alignment (4 | 8 | 16); has_b = 0: the second alignment is absent.
+// -1: a job does not qualify (band clips, an N, exact maximum wanted, hull wider than the window)
+int emu_ksw_dual(int nc, int has_b, const int32_t *qlen, const int32_t *tlen, const uint8_t *const *query, const uint8_t *const *target, const int32_t *w, const int32_t *flag,
+                 const int8_t *mat, int q, int e, int q2, int e2, int32_t *ez_out /* 2 x 10 */, uint32_t *cigar_out /* 2 x cigar_cap */, int cigar_cap, int32_t *n_cigar)
+{
+	wm_ksw_score_t sc;
+	sc.match = mat[0]; sc.mismatch = mat[1]; sc.sc_ambi = mat[24];
+	if (q2 + e2 < q + e) { int t = q; q = q2; q2 = t; t = e; e = e2; e2 = t; }
+	sc.q = q; sc.e = e; sc.q2 = q2; sc.e2 = e2;
+	const int n = has_b ? 2 : 1;
+	wm_ksw_djob_t jb[2];
+	memset(jb, 0, sizeof(jb));
+	std::vector<uint8_t> seqs;
+	size_t tb_bytes = 0;
+	for (int x = 0; x < n; ++x) {
+		int n_col;
+		const int has_n = wm_ksw_has_n(query[x], qlen[x]) | wm_ksw_has_n(target[x], tlen[x]);
+		const int klass = wm_ksw_classify(qlen[x], tlen[x], w[x], has_n, flag[x], &n_col);
+		if (klass < 0 || klass >= WM_KSW_BLOCK || (klass & 7) != 0 || n_col > 64 * nc - 16) return -1;      // (unclipped, no N, approximate maximum only)
+		jb[x].q_off = (uint32_t)seqs.size(); seqs.insert(seqs.end(), query[x], query[x] + qlen[x]);
+		jb[x].t_off = (uint32_t)seqs.size(); seqs.insert(seqs.end(), target[x], target[x] + tlen[x]);
+		jb[x].qlen = qlen[x]; jb[x].tlen = tlen[x]; jb[x].w = w[x]; jb[x].zdrop = -1; jb[x].end_bonus = 0; jb[x].flag = flag[x]; jb[x].n_col = n_col; jb[x].klass = klass;
+		jb[x].tb_off = tb_bytes; tb_bytes += (size_t)(qlen[x] + tlen[x] - 1) * n_col + 64;
+	}
+	if (!has_b) jb[1] = jb[0];
+	std::vector<uint8_t> tb(tb_bytes + 64, 0xEE);
+	wm_ksw_dres_t res[2];
+	memset(res, 0, sizeof(res));
+	simt::exec_mask() = ~0ull;
+	if (nc == 4) wmk::ksw_dp_dual<4>(sc, jb[0], jb[1], has_b != 0, seqs.data(), tb.data(), &res[0], &res[1]);
+	else if (nc == 8) wmk::ksw_dp_dual<8>(sc, jb[0], jb[1], has_b != 0, seqs.data(), tb.data(), &res[0], &res[1]);
+	else wmk::ksw_dp_dual<16>(sc, jb[0], jb[1], has_b != 0, seqs.data(), tb.data(), &res[0], &res[1]);
+	for (int x = 0; x < n; ++x) {
+		int nn = 0;
+		uint32_t *cg = cigar_out + (size_t)x * cigar_cap;
+		if (res[x].bt_i >= 0) {
+			nn = wmk::ksw_backtrack_thread(jb[x], tb.data(), res[x].bt_i, res[x].bt_j, cg, cigar_cap);
+			if (nn < 0) return -3;
+			if (!(flag[x] & KSW_F_REV_CIGAR)) std::reverse(cg, cg + nn);
+		}
+		n_cigar[x] = nn;
+		int32_t *ez = ez_out + 10 * x;
+		ez[0] = res[x].max; ez[1] = res[x].zdropped; ez[2] = res[x].max_q; ez[3] = res[x].max_t; ez[4] = res[x].mqe;
+		ez[5] = res[x].mqe_t; ez[6] = res[x].mte; ez[7] = res[x].mte_q; ez[8] = res[x].score; ez[9] = res[x].reach_end;
+	}
+	return 0;
 }
 void emu_set_coop_backtrack(int on) { g_coop_backtrack = on; }       // 1: ksw_backtrack_wave instead of ksw_backtrack_thread
 

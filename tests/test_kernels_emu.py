@@ -403,6 +403,42 @@ def test_packed_multiwave_ksw_kernel_matches_oracle(emu_v):
     assert n_run[20] > 30 and n_run[21] > 60 and n_run[22] >= 4 and n_run[23] >= 4 and n_run[24] >= 5 and n_run[25] >= 8, n_run
 
 
+def emu_ksw_dual(E, nc, sc, jobs):
+    """two alignments (or one) on ONE emulated wavefront (ksw_dual_kernel.h): rc, [(ez, cigar)]"""
+    E.emu_ksw_dual.argtypes = [C.c_int, C.c_int, W.i32p, W.i32p, C.c_void_p, C.c_void_p, W.i32p, W.i32p, W.i8p] + [C.c_int] * 4 + [W.i32p, W.u32p, C.c_int, W.i32p]
+    n = len(jobs)
+    ql = np.array([len(j["q"]) for j in jobs] + [0] * (2 - n), np.int32)
+    tl = np.array([len(j["t"]) for j in jobs] + [0] * (2 - n), np.int32)
+    qs = (C.c_void_p * 2)(*[j["q"].ctypes.data for j in jobs] + [None] * (2 - n))
+    ts = (C.c_void_p * 2)(*[j["t"].ctypes.data for j in jobs] + [None] * (2 - n))
+    w = np.array([j["w"] for j in jobs] + [0] * (2 - n), np.int32)
+    fl = np.array([j["flag"] for j in jobs] + [0] * (2 - n), np.int32)
+    cap = int(max(ql + tl)) + 4
+    ez = np.zeros(20, np.int32); cig = np.zeros(2 * cap, np.uint32); ncg = np.zeros(2, np.int32)
+    rc = E.emu_ksw_dual(nc, int(n == 2), ql, tl, qs, ts, w, fl, W.simple_mat(sc["a"], sc["b"], 1), sc["q_"], sc["e"], sc["q2"], sc["e2"], ez, cig, cap, ncg)
+    return rc, [(ez[10 * x:10 * x + 10].copy(), cig[x * cap:x * cap + ncg[x]].copy()) for x in range(n)]
+
+
+def test_two_alignments_per_wavefront_kernel_matches_oracle(emu):
+    """ksw_dp_dual (ksw_dual_kernel.h): two gap fills in the low / high halves of one wavefront's registers, every window size (4 / 8 / 16 chunks of 64 lanes;
+    the product launches 8 and 16), against the oracle's ksw_extd2 one alignment at a time — ez fields and CIGAR (the traceback layout is shared with
+    ksw_backtrack_thread). tools/dual_fuzz.py runs the same generator for as long as one likes."""
+    n_al = n_single = n_mixed = 0
+    for nc, sc, jobs in kswcases.dual_pairs(11, 260):
+        rc, out = emu_ksw_dual(emu, nc, sc, jobs)
+        if rc == -1:
+            continue
+        assert rc == 0, rc
+        n_single += len(jobs) == 1
+        n_mixed += len(jobs) == 2 and ((jobs[0]["flag"] ^ jobs[1]["flag"]) & 0x02) != 0
+        for j, (ez, cig) in zip(jobs, out):
+            o = W.o_ksw_extd2(j["q"], j["t"], mat=W.simple_mat(sc["a"], sc["b"], 1), q=sc["q_"], e=sc["e"], q2=sc["q2"], e2=sc["e2"], w=j["w"], zdrop=-1, end_bonus=0, flag=j["flag"])
+            assert [int(v) for v in ez] == [o[k] for k in W.EZ_FIELDS], (nc, len(j["q"]), len(j["t"]), hex(j["flag"]), j["w"], [(len(a["q"]), len(a["t"])) for a in jobs])
+            assert np.array_equal(cig, o["cigar"]), (nc, len(j["q"]), len(j["t"]), hex(j["flag"]), j["w"], [(len(a["q"]), len(a["t"])) for a in jobs])
+            n_al += 1
+    assert n_al >= 400 and n_single >= 20 and n_mixed >= 60, (n_al, n_single, n_mixed)
+
+
 def test_exts2_splice_kernel_emulated_matches_oracle(emu):
     """ksw_dp_exts2 + ksw_exts2_backtrack_thread (ksw_exts2_kernel.h) against the oracle's ksw_exts2_sse restatement, which
     tests/test_oracle_vs_ref.py pins to the reference's own function: every splice flag, both gap alignments, exact / approximate maximum,

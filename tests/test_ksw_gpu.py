@@ -413,3 +413,25 @@ def test_chain_kernels_a_launch_larger_than_the_chip(ctx):
         c = cases[i]
         o = W.o_ksw_extd2(c["q"], c["t"], mat=W.simple_mat(2, 4, 1), q=4, e=2, q2=24, e2=1, w=c["w"], zdrop=c["zdrop"], end_bonus=-1, flag=c["flag"])
         assert all(int(res[i][k]) == o[k] for k in W.EZ_FIELDS), (i, res[i], o)
+
+
+def test_two_alignments_per_wavefront_equal_one_per_wavefront_and_the_oracle(ctx):
+    """ksw_dual_kernel (round 6; off by default, wm_ksw_set_dual / WM_KSW_DUAL=1): two gap fills per wavefront. Batches of gap fills of every size (so that the
+    size-sorted class lists pair neighbours, an odd list leaves one job alone, short jobs finish long before their partners) against the oracle, and the same
+    batch with one alignment per wavefront must give identical results."""
+    was = gpu.ksw_dual_enabled()
+    try:
+        for seed in (3, 4, 5):
+            sc, cases = None, []
+            for nc, s, jobs in kswcases.dual_pairs(seed, 400, ncs=(8, 16)):
+                sc = sc or s
+                cases += [dict(j, **sc) for j in jobs]           # one scoring set per batch
+            cases = cases[:701]                                   # (odd: the last job of a class list is alone in its wavefront)
+            gpu.set_ksw_dual(1)
+            bad = _run_group(ctx, cases)
+            assert not bad, bad[:3]
+            gpu.set_ksw_dual(0)
+            bad = _run_group(ctx, cases)
+            assert not bad, bad[:3]
+    finally:
+        gpu.set_ksw_dual(was)

@@ -5,6 +5,7 @@
 #include "ksw_kernel.h"
 #include "ksw_packed_kernel.h"
 #include "ksw_packed_multi_kernel.h"
+#include "ksw_dual_kernel.h"
 #include "ksw_stripe_kernel.h"
 #include "ksw_chain_kernel.h"
 #include "ksw_exts2_kernel.h"
@@ -286,6 +287,31 @@ struct wm_ksw_dev_batch_s {
 	int h_err;
 };
 
+// two alignments per wavefront (ksw_dp_dual, ksw_dual_kernel.h): workgroup g takes jobs order[2g] and order[2g + 1] of a class's size-sorted list (the last one alone
+// when the list is odd). Only the <CLIP, HASN, EXACT> = <false, false, false> classes — the gap fills, 60 % of all DP cells — run here.
+template <int NC>
+__global__ __launch_bounds__(64, (WM_OCC_HINT && NC == 8) ? 4 : 1) void ksw_dual_kernel(wm_ksw_score_t sc, const wm_ksw_djob_t *__restrict__ jobs, const int *__restrict__ order, int n,
+                                                      const uint8_t *__restrict__ seqs, uint8_t *__restrict__ tb, wm_ksw_dres_t *__restrict__ res)
+{
+	const int g = blockIdx.x, jA = order[2 * g];
+	const bool hasB = 2 * g + 1 < n;
+	const int jB = hasB ? order[2 * g + 1] : jA;
+	wmk::ksw_dp_dual<NC>(sc, jobs[jA], jobs[jB], hasB, seqs, tb, res + jA, res + jB);
+}
+// WM_KSW_DUAL=1 switches it on (wm_ksw_set_dual overrides). OFF by default: bit-exact (emulator fuzz, GPU suite) but SLOWER in the mapper — 0.286-0.291 against 0.317-0.319 Gbp/s
+// at 32 768 reads per step in one call, the 4-pair gap fills 253 against 328 GCUPS, the 8-pair ones 86 against 176 (profiles/r06_dual.txt): the hull arithmetic,
+// query fetch, boundary lane and traceback row of a row are still computed PER ALIGNMENT (scalar code that does not vectorise over two different hulls), so a wavefront
+// retires the same instructions for its two alignments as two wavefronts did for one each — on one dependent chain instead of two, with 128 / 245 registers (4 / 2
+// wavefronts per SIMD) instead of 54 / 76. Sharing a row loop only pays for alignments with the SAME (qlen, tlen), which a size-sorted list rarely offers.
+static std::atomic<int> g_dual(-1);
+static int ksw_dual_on()
+{
+	if (g_dual.load(std::memory_order_relaxed) < 0) g_dual = getenv("WM_KSW_DUAL") && atoi(getenv("WM_KSW_DUAL")) != 0;
+	return g_dual.load(std::memory_order_relaxed);
+}
+extern "C" void wm_ksw_set_dual(int on) { g_dual = on ? 1 : 0; }
+extern "C" int wm_ksw_dual_enabled(void) { return ksw_dual_on(); }
+
 // variant = EXACT*4 + CLIP*2 + HASN; jobs with an N run on the CLIP instantiation (a superset: exact emulation of stale lanes)
 template <int BP> static void launch_dpp(int variant, int n, hipStream_t s, const wm_ksw_score_t &sc, const wm_ksw_djob_t *jobs, const int *order,
                                          const uint8_t *seqs, uint8_t *tb, wm_ksw_dres_t *res)
@@ -299,6 +325,7 @@ template <int BP> static void launch_dpp(int variant, int n, hipStream_t s, cons
 	} else {
 		if (hasn) hipLaunchKernelGGL((ksw_dpp_kernel<BP, true, true, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
 		else if (clip) hipLaunchKernelGGL((ksw_dpp_kernel<BP, true, false, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
+		else if (BP <= 8 && ksw_dual_on()) hipLaunchKernelGGL((ksw_dual_kernel<(BP <= 8 ? 2 * BP : 16)>), dim3((n + 1) / 2), b, 0, s, sc, jobs, order, n, seqs, tb, res);
 		else hipLaunchKernelGGL((ksw_dpp_kernel<BP, false, false, false>), g, b, 0, s, sc, jobs, order, seqs, tb, res);
 	}
 }

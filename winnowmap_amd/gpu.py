@@ -184,6 +184,18 @@ def set_ksw_chain_routing(mode=-1, min_rows_exact=-1, bp=-1):
     lib().wm_ksw_set_chain_routing(mode, min_rows_exact, bp)
 
 
+def set_ksw_dual(on):
+    """wm_ksw_set_dual: two alignments per wavefront for the gap-fill classes (results never depend on it)"""
+    lib().wm_ksw_set_dual.argtypes = [C.c_int]
+    lib().wm_ksw_set_dual.restype = None
+    lib().wm_ksw_set_dual(int(on))
+
+
+def ksw_dual_enabled():
+    lib().wm_ksw_dual_enabled.restype = C.c_int
+    return bool(lib().wm_ksw_dual_enabled())
+
+
 def build_defines():
     """the kernel-variant defines the loaded library was compiled with (wm_build_defines)"""
     lib().wm_build_defines.restype = C.c_char_p
