@@ -114,7 +114,7 @@ def build_emu(defines=()):
     srcs = [os.path.join(emu, f) for f in ("emu_driver.cpp", "simt.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     with _Lock(out):
         if _newer(out, srcs):
-            _run_to(out, lambda o: ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas"] +
+            _run_to(out, lambda o: ["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas"] +
                     ["-D" + d for d in defines] + ["-I" + emu, "-I" + CSRC, "-o", o, os.path.join(emu, "emu_driver.cpp")])
     return out
 
@@ -130,7 +130,7 @@ def build_emu_stripe(defines=()):
            [os.path.join(CSRC, f) for f in ("ksw_stripe_kernel.h", "ksw_packed_kernel.h", "ksw_kernel.h", "ksw_plan.h")]
     with _Lock(out):
         if _newer(out, srcs):
-            _run_to(out, lambda o: ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wno-unknown-pragmas"] +
+            _run_to(out, lambda o: ["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wno-unknown-pragmas"] +
                     ["-D" + d for d in defines] + ["-I" + emu, "-I" + CSRC, "-o", o, os.path.join(emu, "emu_stripe.cpp")])
     return out
 
@@ -145,7 +145,7 @@ def build_emu_chain(defines=()):
            [os.path.join(CSRC, f) for f in ("ksw_chain_kernel.h", "ksw_stripe_kernel.h", "ksw_packed_kernel.h", "ksw_kernel.h", "ksw_plan.h")]
     with _Lock(out):
         if _newer(out, srcs):
-            _run_to(out, lambda o: ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wno-unknown-pragmas"] +
+            _run_to(out, lambda o: ["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wno-unknown-pragmas"] +
                     ["-D" + d for d in defines] + ["-I" + emu, "-I" + CSRC, "-o", o, os.path.join(emu, "emu_chain.cpp")])
     return out
 
