@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6, GPU call cc: the query code of a row from a rotating register (WM_KSW_QROT=1, this build) against the code cache + window test + v_readlane (variant library):
-# the ksw GPU suite, then A/B at 32 768 reads per step
+# the ksw GPU suite, then A/B at 32 768 reads per step. Result: no gain (profiles/r06_sched.txt) — the change (commit history: not merged) is NOT in the tree; the script is kept as the record of the call
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/r06cc; mkdir -p $O
 timeout 1500 python -m pytest tests/test_ksw_gpu.py -x -q -m gpu 2>&1 | tail -3
