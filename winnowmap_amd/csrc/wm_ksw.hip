@@ -474,6 +474,11 @@ static int ksw_prepare_impl(wm_ctx_t *c, const wm_ksw_score_t *sc_in, int n_jobs
 		d.q_off = pos ? q_off : (uint32_t)(q_off - slab_lo); d.t_off = pos ? t_off : (uint32_t)(t_off - slab_lo);
 		int n_col;
 		d.klass = wm_ksw_classify(qlen, tlen, w, has_n, flag, &n_col);
+		// exact extensions of the 8-pair window whose band does not clip are a few dozen long jobs per batched call (0.35 % of the cells): as a class of their own they are
+		// ~140 near-empty launches per step, each as long as its longest job. The CLIP instantiation is a superset (it serves the jobs with an N the same way), so they join
+		// the clipped exact 8-pair class (WM_KSW_MERGE_P8X=0: a class of their own, A/B)
+		static const bool merge_p8x = !(getenv("WM_KSW_MERGE_P8X") && atoi(getenv("WM_KSW_MERGE_P8X")) == 0);
+		if (merge_p8x && (d.klass & ~7) == WM_KSW_P8 && (d.klass & 4) && !(d.klass & 2)) d.klass |= 2;
 		if (stripe_min_rows(0)) d.klass = wm_ksw_route(d.klass, n_col, qlen, tlen, w, has_n, stripe_min_rows(4), stripe_min_rows(8), g_stripe_wide16.load(std::memory_order_relaxed));
 		d.klass = wm_ksw_route_chain(d.klass, qlen, tlen, w, has_n, flag, chain_mode(), g_chain_rows.load(std::memory_order_relaxed), g_chain_geom.load(std::memory_order_relaxed));
 		d.n_col = n_col;
